@@ -1,0 +1,255 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference)
+on deterministic synthetic weights/inputs.  Runs only in the build container (the
+reference never travels to the GPU box); the outputs are small data fixtures.
+
+    python oracle/make_golden.py [--full]
+
+Fixtures (all float32 unless noted; `torch_version` recorded in each file):
+  ops_golden.npz     every OPS[name] at C=32, 24x24, N=2, stride 1 and 2: y, dx, param grads,
+                     updated running stats
+  tiny_net.npz       Network(C=16, L=16, R=1), 2x3x128x128: train-mode outputs, both losses,
+                     ~24 named grads, some running stats; eval-mode outputs
+  criteria.npz       Criterion_par / Criterion_pose on fixed logits incl. OHEM edge cases
+  full_net.npz       (--full) Network(C=64), 1x3x384x384 train-mode: stage-1 par_map/pose_map
+                     + summary statistics of all 8 outputs + losses
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from types import SimpleNamespace as NS
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(1, REPO)
+
+import torch  # noqa: E402
+
+torch.Tensor.cuda = lambda self, *a, **k: self  # core/criterion.py:192,197 call .cuda() unconditionally
+torch.nn.Module.cuda = lambda self, *a, **k: self
+
+from models import operations as ref_ops  # noqa: E402
+from models.model_augment import Network as RefNetwork  # noqa: E402
+from core.criterion import Criterion_par, Criterion_pose  # noqa: E402
+
+from npp_amd.synth import synth_state_dict, synth_batch, _rng  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def cfg(C, L=16, R=1):
+    return NS(DATASET=NS(NUM_CLASSES=20, NUM_JOINTS=16), TRAIN=NS(LAYERS=L, INIT_CHANNELS=C),
+              MODEL=NS(DECONV_WITH_BIAS=False, HEAD='PSP', REFINE_LAYERS=R))
+
+
+def load_synth(module, seed=0, prefix=""):
+    sd = module.state_dict()
+    tmpl = {prefix + k: v for k, v in sd.items()}
+    syn = synth_state_dict(tmpl, seed)
+    module.load_state_dict({k: torch.from_numpy(syn[prefix + k]) for k in sd})
+
+
+def f32(t):
+    return t.detach().to(torch.float32).numpy().copy()
+
+
+def gen_ops():
+    out = {"torch_version": np.array(torch.__version__)}
+    C, H, N = 32, 24, 2
+    for name in ref_ops.OPS:
+        for stride in (1, 2):
+            tag = f"{name}/s{stride}"
+            m = ref_ops.OPS[name](C, stride, True)
+            load_synth(m, 0, prefix=f"{name}.s{stride}.")
+            m.train()
+            x = torch.from_numpy(_rng(f"x.{tag}").standard_normal((N, C, H, H)).astype(np.float32))
+            x.requires_grad_(True)
+            y = m(x)
+            gy = torch.from_numpy(_rng(f"gy.{tag}").standard_normal(tuple(y.shape)).astype(np.float32))
+            y.backward(gy)
+            out[f"{tag}/y"] = f32(y)
+            out[f"{tag}/dx"] = f32(x.grad)
+            for k, p in m.named_parameters():
+                if p.grad is not None:
+                    out[f"{tag}/grad/{k}"] = f32(p.grad)
+            for k, b in m.named_buffers():
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    out[f"{tag}/buf/{k}"] = f32(b)
+            # eval-mode forward with the (updated) running statistics
+            m.eval()
+            with torch.no_grad():
+                out[f"{tag}/y_eval"] = f32(m(x))
+    np.savez_compressed(os.path.join(OUT, "ops_golden.npz"), **out)
+    print("ops_golden.npz", len(out), "arrays")
+
+
+def run_net(C, size, n, seed=0):
+    torch.manual_seed(0)
+    net = RefNetwork(cfg(C))
+    load_synth(net, seed)
+    images, lpar, lpose, meta = synth_batch(n, size, seed=seed)
+    images = torch.from_numpy(images)
+    lpar = [torch.from_numpy(a) for a in lpar]
+    lpose = [torch.from_numpy(a[:, :-1]) for a in lpose]
+    crit_pose = Criterion_pose(out_len=2, use_target_weight=False)
+    crit_par = Criterion_par(out_len=2)
+    net.train()
+    pose_list, par_list = net(images)
+    l_par = crit_par(par_list, lpar)
+    l_pose = crit_pose(pose_list, lpose, target_weight=torch.from_numpy(meta["pose_weight"]))
+    loss = (l_par.unsqueeze(0) + l_pose.unsqueeze(0)).mean()
+    net.zero_grad()
+    loss.backward()
+    return net, pose_list, par_list, l_par, l_pose, loss, crit_pose, crit_par, images
+
+
+def gen_tiny():
+    C, size, n = 16, 128, 2
+    net, pose_list, par_list, l_par, l_pose, loss, cpose, cpar, images = run_net(C, size, n)
+    out = {"torch_version": np.array(torch.__version__), "C": np.array(C), "size": np.array(size), "n": np.array(n)}
+    for i in range(2):
+        out[f"train/pose_map{i}"] = f32(pose_list[i][0])
+        out[f"train/pose_aux{i}"] = f32(pose_list[i][1])
+        out[f"train/par_map{i}"] = f32(par_list[i][0])
+        out[f"train/edge{i}"] = f32(par_list[i][1])
+    out["train/loss_par"] = f32(l_par)
+    out["train/loss_pose"] = f32(l_pose)
+    out["train/loss"] = f32(loss)
+    out["train/grad_lamda_pose"] = f32(cpose.lamda.grad)
+    out["train/grad_lamda_par"] = f32(cpar.lamda.grad)
+    names = [k for k, p in net.named_parameters() if p.grad is not None]
+    want = ["stem0.0.weight", "stem5.1.weight", "cells1.0.preprocess0.net.1.weight", "cells1.0._ops.0.net.1.weight",
+            "cells1.0._ops.1.conv1.weight", "cells1.0._ops.1.conv2.bias", "cells1.0._ops.4.bn.weight",
+            "cells1.4._ops.4.net.1.weight", "cells1.4._ops.4.net.2.weight", "cells2.5.preprocess0.conv2.weight",
+            "cells2.5.preprocess0.bn.bias", "cells2.15._ops.7.net.2.bias", "_ops1.2.1.1.weight", "_ops2.1.net.2.weight",
+            "_ops2.1.net.2.bias", "up_ops1.2.1.1.bias", "upsamples1.0._ops.3.0.net.1.weight",
+            "upsamples2.2._ops.4.net.3.weight", "pose_layer.1.weight", "pose_layer.1.bias", "edge_layer.2.weight",
+            "pose_net.0.preprocess1.net.1.weight", "par_net.2._ops.1.conv1.weight", "pose_head.1.4.weight",
+            "edge_head.0.1.weight", "edge_head.1.4.bias", "par_head.0.2.bias", "pose_auxnet.1.1.weight"]
+    for k in want:
+        assert k in names, k
+        out[f"train/grad/{k}"] = f32(dict(net.named_parameters())[k].grad)
+    # L2 norm of every produced gradient (cheap whole-model pin) + the list of never-produced ones
+    out["train/grad_norm_keys"] = np.array(names)
+    out["train/grad_norms"] = np.array([float(dict(net.named_parameters())[k].grad.double().norm()) for k in names],
+                                       dtype=np.float64)
+    out["train/no_grad_keys"] = np.array([k for k, p in net.named_parameters() if p.grad is None])
+    sd = net.state_dict()
+    out["sd_keys"] = np.array(list(sd.keys()))
+    out["sd_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+    for k in ["stem0.1.running_mean", "stem0.1.running_var", "cells1.3._ops.4.bn.running_var",
+              "pose_net.2._ops.7.net.2.running_mean", "edge_head.1.2.running_var", "cells1.5.preprocess0.bn.running_mean"]:
+        out[f"train/buf/{k}"] = f32(sd[k])
+    # eval mode, fresh synthetic running stats (reload: training above mutated them)
+    load_synth(net, 0)
+    net.eval()
+    with torch.no_grad():
+        pose_list, par_list = net(images)
+    for i in range(2):
+        out[f"eval/pose_map{i}"] = f32(pose_list[i][0])
+        out[f"eval/pose_aux{i}"] = f32(pose_list[i][1])
+        out[f"eval/par_map{i}"] = f32(par_list[i][0])
+        out[f"eval/edge{i}"] = f32(par_list[i][1])
+    np.savez_compressed(os.path.join(OUT, "tiny_net.npz"), **out)
+    print("tiny_net.npz", len(out), "arrays; loss", float(loss))
+
+
+def gen_criteria():
+    out = {"torch_version": np.array(torch.__version__)}
+    cases = {
+        # name: (n, label size, logits size, min_kept, thres, logit scale)
+        "small_nvalid_lt_minkept": (2, 64, 16, 131072, 0.9, 3.0),   # n_valid < min_kept -> index n-1
+        "kth_dominates": (2, 96, 24, 4000, 0.2, 6.0),               # k-th smallest prob > thresh
+        "thresh_dominates": (1, 96, 24, 100, 0.9, 1.0),             # all probs small: thresh 0.9 wins
+        "confident": (1, 64, 16, 50, 0.7, 30.0),                    # most p_gt ~ 1 > thresh
+    }
+    for name, (n, S, s, min_kept, thres, scale) in cases.items():
+        r = _rng("crit." + name)
+        par = torch.from_numpy((r.standard_normal((n, 20, s, s)) * scale).astype(np.float32)).requires_grad_(True)
+        edge = torch.from_numpy((r.standard_normal((n, 2, s, s)) * scale).astype(np.float32)).requires_grad_(True)
+        par2 = torch.from_numpy((r.standard_normal((n, 20, s, s)) * scale).astype(np.float32)).requires_grad_(True)
+        edge2 = torch.from_numpy((r.standard_normal((n, 2, s, s)) * scale).astype(np.float32)).requires_grad_(True)
+        _, lpar, _, _ = synth_batch(n, S, seed=__import__("zlib").crc32(name.encode()) % 1000)
+        if name == "confident":  # make logits agree with labels on the coarse grid
+            lab = torch.from_numpy(lpar[0])[:, ::S // s, ::S // s].clone()
+            lab[lab == 255] = 0
+            with torch.no_grad():
+                par.scatter_(1, lab.unsqueeze(1), 40.0)
+        lpar_t = [torch.from_numpy(a) for a in lpar]
+        crit = Criterion_par(out_len=2, thres=thres, min_kept=min_kept)
+        with torch.no_grad():
+            crit.lamda.copy_(torch.tensor([2.3, 1.7]))
+        loss = crit([[par, edge], [par2, edge2]], lpar_t)
+        loss.backward()
+        out[f"par/{name}/cfg"] = np.array([n, S, s, min_kept, thres, scale], dtype=np.float64)
+        for k, v in (("par", par), ("edge", edge), ("par2", par2), ("edge2", edge2)):
+            out[f"par/{name}/in/{k}"] = f32(v)
+            out[f"par/{name}/grad/{k}"] = f32(v.grad)
+        out[f"par/{name}/label_par"] = lpar[0].astype(np.uint8)
+        out[f"par/{name}/label_edge"] = lpar[1].astype(np.uint8)
+        out[f"par/{name}/loss"] = f32(loss)
+        out[f"par/{name}/grad_lamda"] = f32(crit.lamda.grad)
+    # pose
+    n, hm = 2, 32
+    r = _rng("crit.pose")
+    _, _, lpose, _ = synth_batch(n, hm * 4, seed=3)
+    preds = [torch.from_numpy((r.standard_normal((n, 16, hm, hm)) * 0.3).astype(np.float32)).requires_grad_(True)
+             for _ in range(4)]
+    crit = Criterion_pose(out_len=2)
+    with torch.no_grad():
+        crit.lamda.copy_(torch.tensor([-2.5, -1.0]))
+    tgt = [torch.from_numpy(a[:, :-1]) for a in lpose]
+    loss = crit([[preds[0], preds[1]], [preds[2], preds[3]]], tgt)
+    loss.backward()
+    for i, p in enumerate(preds):
+        out[f"pose/in/{i}"] = f32(p)
+        out[f"pose/grad/{i}"] = f32(p.grad)
+    out["pose/target0"] = lpose[0][:, :-1]
+    out["pose/target1"] = lpose[1][:, :-1]
+    out["pose/loss"] = f32(loss)
+    out["pose/grad_lamda"] = f32(crit.lamda.grad)
+    np.savez_compressed(os.path.join(OUT, "criteria.npz"), **out)
+    print("criteria.npz", len(out), "arrays")
+
+
+def gen_full():
+    C, size, n = 64, 384, 1
+    net, pose_list, par_list, l_par, l_pose, loss, cpose, cpar, images = run_net(C, size, n)
+    out = {"torch_version": np.array(torch.__version__)}
+    out["train/pose_map1"] = f32(pose_list[1][0])
+    out["train/par_map1"] = f32(par_list[1][0])
+    stats = {}
+    for i in range(2):
+        for nm, t in (("pose_map", pose_list[i][0]), ("pose_aux", pose_list[i][1]),
+                      ("par_map", par_list[i][0]), ("edge", par_list[i][1])):
+            t = t.detach().double()
+            stats[f"{nm}{i}"] = [float(t.mean()), float(t.abs().max()), float(t.norm())]
+    out["train/stat_keys"] = np.array(list(stats.keys()))
+    out["train/stats"] = np.array(list(stats.values()), dtype=np.float64)
+    out["train/loss_par"] = f32(l_par)
+    out["train/loss_pose"] = f32(l_pose)
+    out["train/loss"] = f32(loss)
+    names = [k for k, p in net.named_parameters() if p.grad is not None]
+    out["train/grad_norm_keys"] = np.array(names)
+    out["train/grad_norms"] = np.array([float(dict(net.named_parameters())[k].grad.double().norm()) for k in names])
+    out["train/no_grad_keys"] = np.array([k for k, p in net.named_parameters() if p.grad is None])
+    sd = net.state_dict()
+    out["sd_keys"] = np.array(list(sd.keys()))
+    out["sd_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+    np.savez_compressed(os.path.join(OUT, "full_net.npz"), **out)
+    print("full_net.npz; loss", float(loss))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    todo = a.only.split(",") if a.only else ["ops", "criteria", "tiny"] + (["full"] if a.full else [])
+    for t in todo:
+        {"ops": gen_ops, "criteria": gen_criteria, "tiny": gen_tiny, "full": gen_full}[t]()
