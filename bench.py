@@ -1,0 +1,192 @@
+"""bench.py -- img/s of the NPPNet (model_augment, fixed genotype, C=64, L=16, R=1) training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--batch 16] [--size 384] [--dtype bf16|f32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One step = model(images) -> Criterion_par + Criterion_pose -> mean -> zero_grad -> backward (+ bucketed RCCL
+gradient all-reduce, SyncBN statistics exchange when N > 1) -> Adam.step  (core/function.py:87-107), on a
+synthetic LIP-shaped batch that is already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FWD_GFLOP_PER_IMG = {384: 243.37, 512: 432.65}   # BASELINE.md §2 (conv FLOPs, 2*MAC)
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # MI355X_MICROARCH.md chip table (dense)
+
+
+def cfg_ns(C=64):
+    from types import SimpleNamespace as NS
+    return NS(DATASET=NS(NUM_CLASSES=20, NUM_JOINTS=16), TRAIN=NS(LAYERS=16, INIT_CHANNELS=C),
+              MODEL=NS(DECONV_WITH_BIAS=False, HEAD='PSP', REFINE_LAYERS=1))
+
+
+def cpu_baseline(size, budget_s=25.0):
+    """The CPU oracle (a port of the reference path, oracle/nppnet_oracle.py) timed on this host's cores:
+    N=1 train-mode fwd + both losses + bwd, fp32.  Baseline only -- not the thing shipped or measured."""
+    import torch
+    from oracle import nppnet_oracle as O
+    from npp_amd.model_augment import Network
+    from npp_amd.synth import synth_batch
+    torch.manual_seed(0)
+    net = Network(cfg_ns())
+    tensors = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k, v in tensors.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    del net
+    images, lpar, lpose, _ = synth_batch(1, size, seed=0)
+    images = torch.from_numpy(images)
+    lpar = [torch.from_numpy(a) for a in lpar]
+    lpose = [torch.from_numpy(a[:, :-1].copy()) for a in lpose]
+    lam_pose = torch.full((2,), -2.5, requires_grad=True)
+    lam_par = torch.full((2,), 2.3, requires_grad=True)
+    times = []
+    t_start = time.time()
+    it = 0
+    while True:
+        t0 = time.time()
+        for v in tensors.values():
+            v.grad = None
+        loss, _, _, _ = O.train_step_loss(tensors, images, lpar, lpose, lam_pose, lam_par)
+        loss.backward()
+        dt = time.time() - t0
+        if it >= 1:
+            times.append(dt)
+        it += 1
+        if (time.time() - t_start > budget_s and len(times) >= 2) or len(times) >= 6:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"N=1 {size}x{size} fp32 train-mode fwd+losses+bwd, median of {len(times)} iterations after 1 warm-up "
+                      f"(torch-CPU oracle, {os.cpu_count()} logical CPUs)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("NPP_BENCH_BATCH", "16")), help="images per GPU")
+    ap.add_argument("--size", type=int, default=384)
+    ap.add_argument("--dtype", default=os.environ.get("NPP_BENCH_DTYPE", "bf16"), choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--local-bn", action="store_true", help="ablation: do not synchronise BN statistics across ranks")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from npp_amd import _lib
+    from npp_amd.model_augment import Network, set_compute_dtype
+    from npp_amd.criterion import Criterion_par, Criterion_pose
+    from npp_amd.synth import synth_batch
+    from npp_amd.ddp import GradReducer, unused_parameter_names
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    set_compute_dtype(dtype)
+    torch.manual_seed(0)
+    net = Network(cfg_ns())
+    sync_bn = world > 1 and not args.local_bn
+    if sync_bn:
+        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)   # augment_lip_sync.py:191
+    net = net.to(dev).train()
+    crit_pose = Criterion_pose(out_len=2).to(dev)
+    crit_par = Criterion_par(out_len=2).to(dev)
+    reducer = GradReducer(net, skip=unused_parameter_names(net)) if world > 1 else None
+    params = list(net.parameters()) + list(crit_pose.parameters()) + list(crit_par.parameters())
+    opt = torch.optim.Adam(params, lr=1e-4)
+
+    images, lpar, lpose, _ = synth_batch(args.batch, args.size, seed=0, rank=rank)
+    images = torch.from_numpy(images).to(dev)
+    lpar = [torch.from_numpy(a).to(dev) for a in lpar]
+    lpose = [torch.from_numpy(a[:, :-1].copy()).to(dev) for a in lpose]
+
+    def step():
+        pose_list, par_list = net(images)
+        loss = (crit_par(par_list, lpar).unsqueeze(0) + crit_pose(pose_list, lpose).unsqueeze(0)).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    prof = not args.no_prof
+    L = _lib.lib()
+    if prof:
+        L.npp_prof_begin(_lib.FAM["conv_igemm"], _lib.NPP_BF16 if dtype == torch.bfloat16 else _lib.NPP_F32)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    import ctypes as C
+    roof = None
+    if prof:
+        ms, fl, by, nl = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        L.npp_prof_end(C.byref(ms), C.byref(fl), C.byref(by), C.byref(nl))
+        if nl.value > 0 and ms.value > 0:
+            ach = fl.value / (ms.value * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[args.dtype]
+            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (conv fwd + dgrad implicit GEMM)",
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None, "launches_per_step": nl.value // max(args.steps, 1),
+                    "avg_launch_us": round(ms.value * 1e3 / nl.value, 2),
+                    "algorithmic_gflop_per_launch": round(fl.value / nl.value / 1e9, 4)}
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    imgs = args.batch * world * args.steps
+    value = imgs / elapsed
+    out = {
+        "metric": "img/s fwd+bwd, model_augment @ %dx%d; 1/2/4/8 MI355X scaling" % (args.size, args.size),
+        "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "model_augment.Network fixed genotype C=64 L=16 R=1, %dx%d, batch %d/GPU, "
+                               "fwd + Criterion_par + Criterion_pose + bwd + Adam step" % (args.size, args.size, args.batch),
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                   "sync_bn": bool(sync_bn), "loss": float(loss)},
+        "model_tflops": round(value * 3 * FWD_GFLOP_PER_IMG.get(args.size, 243.37 * (args.size / 384.0) ** 2) / 1e3, 2),
+    }
+    if roof is not None:
+        out["roofline"] = roof
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.size)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,182 @@
+/* npp_hip.h -- C ABI of libnpp_hip.so: the MI355X (gfx950) kernels behind NPPNet's
+ * multi-branch conv forward/backward hot path.
+ *
+ * The reference (GuHuangAI/NPP) has no FFI of its own: every "kernel" is an ATen op reached
+ * through torch.nn.  Each entry point below therefore names the ATen call
+ * site(s) in the reference that it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - plain C, no C++ types; every function returns 0 on success or a negative NPP_E_* code,
+ *    message via npp_last_error() (thread local).
+ *  - activations are NHWC with an explicit pixel stride `ld` (elements): element (n,h,w,c) is
+ *    ptr[((n*H + h)*W + w)*ld + c].  ld > C addresses a channel slice of a wider buffer
+ *    (zero-copy torch.cat(dim=1), model_augment.py:62).  ld and C must keep 16-byte alignment
+ *    of every pixel row for the vector paths (C % 8 == 0 for bf16, C % 4 == 0 for f32);
+ *    other C fall back to scalar paths.
+ *  - dtype: NPP_F32 (exact-f32 MFMA, the parity mode) or NPP_BF16 (bf16 storage, f32 accumulate).
+ *  - the caller owns all memory (PyTorch caching allocator); nothing is allocated or freed here
+ *    and no pointer is kept past return.  Kernels are enqueued on `stream` (a hipStream_t)
+ *    asynchronously; no host synchronisation inside (graph-capture safe).
+ *  - statistics/accumulator outputs (`double*`, wgrad `float*`) are ADDED into: zero them first.
+ */
+#ifndef NPP_HIP_H
+#define NPP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { NPP_F32 = 0, NPP_BF16 = 1 };
+enum {
+  NPP_OK = 0, NPP_E_SHAPE = -1, NPP_E_DTYPE = -2, NPP_E_ALIGN = -3, NPP_E_HIP = -4,
+  NPP_E_UNSUPPORTED = -5, NPP_E_NULL = -6
+};
+
+typedef struct NppTensor {
+  void* ptr;
+  int64_t n, h, w, c; /* logical NHWC extent */
+  int64_t ld;         /* pixel stride in elements (>= c) */
+  int32_t dtype;      /* NPP_F32 | NPP_BF16 */
+  int32_t _pad;
+} NppTensor;
+
+typedef struct NppConvGeom {
+  int32_t kh, kw;       /* kernel extent */
+  int32_t sh, sw;       /* stride */
+  int32_t ph, pw;       /* padding (may be negative: FactorizedReduce's x[:, :, 1:, 1:] view is pad = -1) */
+  int32_t dh, dw;       /* dilation */
+  int32_t uph, upw;     /* 1 = ordinary conv; s>1 = the input is read as if zero-upsampled by s along h / w
+                           (dgrad of a stride-s conv expressed as a stride-1 conv) */
+  int32_t relu_in;      /* apply max(x,0) to the input while loading (pre-activation ops) */
+} NppConvGeom;
+
+const char* npp_version(void);
+const char* npp_last_error(void);
+
+/* ---- profiling hook (bench.py roofline leg): HIP events around every launch of one kernel family,
+ *      recorded on the launch stream; read back after the caller synchronised. ------------------- */
+enum { NPP_FAM_NONE = 0, NPP_FAM_CONV_IGEMM = 1, NPP_FAM_CONV_WGRAD = 2, NPP_FAM_DWCONV = 3,
+       NPP_FAM_BN = 4, NPP_FAM_ELTWISE = 5, NPP_FAM_POOL = 6, NPP_FAM_BILINEAR = 7, NPP_FAM_LOSS = 8 };
+int npp_prof_begin(int family, int dtype_filter /* -1 = any */);
+int npp_prof_end(double* ms_total, double* flops_total, double* bytes_total, int64_t* launches);
+
+/* ---- dense convolution as implicit GEMM on MFMA -------------------------------------------------
+ * replaces nn.Conv2d (groups=1) forward/backward: operations.py:77 (ReLUConvBN), :149-150
+ * (FactorizedReduce), :182-183 (FacConv), :215 (DilConvS pointwise), :240 (Pooled_Conv);
+ * model_augment.py:244-272 (stems), :332-351, :371-397 (heads), :594, :644 (interaction 1x1). */
+int64_t npp_packed_weight_elems(int cout, int cin, int kh, int kw, int for_dgrad);
+/* w_oihw: f32 [cout][cin][kh][kw] (the state-dict layout).  for_dgrad=0: rows = cout,
+ * k = tap*cin_pad + ci.  for_dgrad=1: rows = cin, k = tap'*cout_pad + co with the taps flipped. */
+int npp_pack_weight(const float* w_oihw, int cout, int cin, int kh, int kw, int for_dgrad,
+                    int dtype, void* out, void* stream);
+/* y = conv(relu?(x)) + bias; optional per-channel sum / sum-of-squares of y added into
+ * stats[0..C) / stats[C..2C) (the BatchNorm batch statistics, operations.py:78);
+ * optional mask: y *= (mask > 0) (ReLU backward when this call is a dgrad). */
+int npp_conv_fwd(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask,
+                 NppTensor* y, double* stats, const NppConvGeom* g, void* stream);
+/* dw_packed[co][tap*cin_pad + ci] += sum_p dy[p][co] * relu?(x)[src(p,tap)][ci]   (f32 atomics);
+ * dw_packed has npp_packed_weight_elems(cout,cin,kh,kw,0) floats, zeroed by the caller. */
+int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw_packed, const NppConvGeom* g,
+                   void* stream);
+/* packed f32 gradient -> the state-dict layout [cout][cin][kh][kw] */
+int npp_unpack_wgrad(const float* dw_packed, int cout, int cin, int kh, int kw, float* dw_oihw, void* stream);
+
+/* ---- depthwise (dilated) convolution: nn.Conv2d(groups=C), operations.py:213-214 -------------- */
+int npp_dwconv_fwd(const NppTensor* x, const float* w /*[C][kh*kw]*/, NppTensor* y,
+                   const NppConvGeom* g, void* stream);
+int npp_dwconv_bwd_data(const NppTensor* dy, const float* w, const NppTensor* x_mask /*opt: relu mask*/,
+                        NppTensor* dx, const NppConvGeom* g, void* stream);
+int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, float* dw /*[C][kh*kw], added*/,
+                          const NppConvGeom* g, void* stream);
+
+/* ---- batch norm (train + eval): nn.BatchNorm2d everywhere, SURVEY §8 a20 ---------------------- */
+int npp_channel_stats(const NppTensor* x, double* stats /*[2C] added*/, void* stream);
+/* from (sum, sumsq, count): mean/invstd, scale = gamma*invstd, shift = beta - mean*scale, and the
+ * running-stat update (momentum, unbiased var).  gamma/beta/running_* may be NULL. */
+int npp_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked /* += 1 */,
+                    float momentum, float eps,
+                    float* scale_shift /*[2C]*/, float* mean_invstd /*[2C]*/, int c, void* stream);
+/* eval mode: scale/shift from the running statistics */
+int npp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale_shift, int c, void* stream);
+/* out = (a*sa + ta) + (b*sb + tb | b | nothing), optional ReLU.  ss_* = [scale[C], shift[C]] or NULL
+ * (identity).  Fuses BN-apply of both branches with the cell's h1 + h2 (model_augment.py:58). */
+int npp_affine_add(NppTensor* out, const NppTensor* a, const float* ss_a, const NppTensor* b,
+                   const float* ss_b, int relu, void* stream);
+/* sums[0..C) += sum dy', sums[C..2C) += sum dy' * xhat, dy' = dout * (out>0 if relu_out given) */
+int npp_bn_bwd_reduce(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,
+                      const float* mean_invstd, double* sums, void* stream);
+/* dy_raw = gamma*invstd*(dy' - sums0/count - xhat*sums1/count); dgamma = sums1, dbeta = sums0 */
+int npp_bn_bwd_apply(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,
+                     const float* mean_invstd, const float* gamma, const double* sums, double count,
+                     NppTensor* dy_raw, float* dgamma, float* dbeta, void* stream);
+/* eval-mode / plain affine backward: dy = dout * scale * (out>0) */
+int npp_scale_mask(const NppTensor* dout, const float* scale /*[C] or NULL*/, const NppTensor* relu_out,
+                   NppTensor* dx, void* stream);
+
+/* ---- pooling: nn.MaxPool2d / nn.AvgPool2d(count_include_pad=False) 3x3 pad 1 (operations.py:55-57),
+ *      nn.AvgPool2d(2) (operations.py:124,237), nn.MaxPool2d(2,2) (model_search_interact.py:43) ---- */
+int npp_pool3x3_fwd(const NppTensor* x, NppTensor* y, uint8_t* argmax /*max only, [N,OH,OW,C]*/,
+                    int is_avg, int stride, double* stats, void* stream);
+int npp_pool3x3_bwd(const NppTensor* dy, const uint8_t* argmax, NppTensor* dx, int is_avg, int stride,
+                    void* stream);
+int npp_pool2x2_fwd(const NppTensor* x, NppTensor* y, int is_avg, double* stats, void* stream);
+int npp_pool2x2_bwd(const NppTensor* dy, const NppTensor* x /*max only*/, NppTensor* dx, int is_avg,
+                    void* stream);
+
+/* ---- squeeze-excite: operations.py:118-123 ------------------------------------------------------ */
+int npp_global_avgpool(const NppTensor* x, float* pooled /*[N][C]*/, void* stream);
+int npp_se_gate_fwd(const float* pooled, const float* w1, const float* b1, const float* w2,
+                    const float* b2, float* hidden /*[N][C/2] post-ReLU*/, float* gate /*[N][C]*/,
+                    int n, int c, void* stream);
+int npp_se_gate_bwd(const float* pooled, const float* hidden, const float* gate, const float* dgate,
+                    const float* w1, const float* w2, float* dw1, float* db1, float* dw2, float* db2,
+                    float* dpooled, int n, int c, void* stream);
+int npp_scale_channels(const NppTensor* x, const float* gate /*[N][C]*/, NppTensor* y, void* stream);
+int npp_se_bwd_reduce(const NppTensor* dout, const NppTensor* x, float* dgate /*[N][C], added*/, void* stream);
+/* dx = dout*gate + dpooled/(H*W) */
+int npp_se_bwd_apply(const NppTensor* dout, const float* gate, const float* dpooled, NppTensor* dx, void* stream);
+
+/* ---- bilinear resample, align_corners=True: F.interpolate, model_augment.py:109-116, 539-543;
+ *      nn.UpsamplingBilinear2d, operations.py:242 ----------------------------------------------- */
+int npp_bilinear_fwd(const NppTensor* x, NppTensor* y, void* stream);
+int npp_bilinear_bwd(const NppTensor* dy, NppTensor* dx, void* stream);
+
+/* ---- layout / elementwise plumbing -------------------------------------------------------------- */
+int npp_copy(const NppTensor* x, NppTensor* y, void* stream);                /* cast + channel-slice copy (cat) */
+int npp_nchw_to_nhwc(const float* src, int n, int c, int h, int w, NppTensor* dst, void* stream); /* pads channels with 0 */
+int npp_nhwc_to_nchw(const NppTensor* src, float* dst, void* stream);
+int npp_channel_sum(const NppTensor* x, double* out /*[C], added*/, void* stream);      /* conv bias grad */
+
+/* ---- loss heads ----------------------------------------------------------------------------------
+ * heat-map MSE, core/criterion.py:98-128: sse += sum (pred - target)^2 ; target is f32 NCHW. */
+int npp_mse_fwd(const NppTensor* pred, const float* target_nchw, double* sse, void* stream);
+/* grad = 2*(pred - target) * (*gscale) */
+int npp_mse_bwd(const NppTensor* pred, const float* target_nchw, const float* gscale, NppTensor* grad, void* stream);
+/* per-pixel softmax cross-entropy on logits bilinearly upsampled (align_corners) to the label size,
+ * core/criterion.py:54-72,181-197.  logits: f32 NHWC [N,h,w,C]; labels: int64 [N,H,W].
+ * Writes p_gt (prob of the GT class; -1 where label == ignore) and wnll = -w[gt]*log p_gt (0 if ignored);
+ * counts valid pixels into n_valid[0] and per-class label histogram is not needed. */
+int npp_ce_pixel_fwd(const NppTensor* logits, const int64_t* labels, int H, int W, const float* class_w,
+                     int ignore, float* p_gt, float* wnll, void* stream);
+/* exact k-th smallest (k clamped to n_valid-1) of the non-negative entries of vals[0..n): the OHEM
+ * threshold core/criterion.py:66-68; ws: >= 8 KiB scratch (zeroed by the callee). result[0] = value,
+ * result[1] = n_valid (as float). */
+int npp_kth_smallest(const float* vals, int64_t n, int64_t k, uint32_t* ws, float* result, void* stream);
+/* OHEM reduction: out[0] += sum wnll over kept, out[1] += kept count, kept = p_gt >= 0 && p_gt < thr,
+ * thr = max(kth[0], thresh) (use_ohem) or +inf; out[2] += sum class_w[label] over kept (weighted-mean CE). */
+int npp_ce_reduce(const float* p_gt, const float* wnll, const int64_t* labels, const float* class_w,
+                  int ignore, int64_t n, const float* kth, float thresh, int use_ohem, double* out, void* stream);
+/* backward through softmax + the bilinear transpose into dlogits (f32 NHWC [N,h,w,C], ADDED into):
+ * for kept pixels dlogit_up[c] = (*gscale) * w[gt] * (softmax_c - [c==gt]); gscale already holds 1/denominator. */
+int npp_ce_pixel_bwd(const NppTensor* logits, const int64_t* labels, int H, int W, const float* class_w,
+                     int ignore, const float* p_gt, const float* kth, float thresh, int use_ohem,
+                     const float* gscale, NppTensor* dlogits, void* stream);
+/* edge class weights from label counts, core/criterion.py:161-166: w = [pos/(pos+neg), neg/(pos+neg)] */
+int npp_edge_weights(const int64_t* labels, int64_t n, double* counts /*[2] zeroed by caller*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPP_HIP_H */

@@ -1,0 +1,32 @@
+"""npp_amd -- MI355X (gfx950) native hot path for NPPNet (GuHuangAI/NPP).
+
+    from npp_amd.model_augment import Network          # == models.model_augment.Network
+    from npp_amd.operations import OPS                 # == models.operations.OPS
+    from npp_amd.criterion import Criterion_pose, Criterion_par   # == core.criterion
+
+`install_as_reference_modules()` registers these under the reference's own module names (`models`,
+`models.operations`, `models.genotypes`, `models.model_augment`, `core.criterion`) so that
+`augment_lip_sync.py` imports them unchanged.
+"""
+import sys
+import types
+
+__version__ = "0.1.0"
+
+
+def install_as_reference_modules():
+    from . import criterion, genotypes, model_augment, operations
+    models = types.ModuleType("models")
+    models.__path__ = []
+    models.operations, models.genotypes, models.model_augment = operations, genotypes, model_augment
+    sys.modules["models"] = models
+    sys.modules["models.operations"] = operations
+    sys.modules["models.genotypes"] = genotypes
+    sys.modules["models.model_augment"] = model_augment
+    core = sys.modules.get("core")
+    if core is None:
+        core = types.ModuleType("core")
+        core.__path__ = []
+        sys.modules["core"] = core
+    core.criterion = criterion
+    sys.modules["core.criterion"] = criterion

@@ -1,0 +1,184 @@
+"""ctypes binding of libnpp_hip.so (include/npp_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails this module
+raises.  Build with `python -c "import __graft_entry__ as g; g.build()"` or
+`npp_amd/csrc/build.sh`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnpp_hip.so")
+
+NPP_F32, NPP_BF16 = 0, 1
+FAM = {"none": 0, "conv_igemm": 1, "conv_wgrad": 2, "dwconv": 3, "bn": 4, "eltwise": 5, "pool": 6,
+       "bilinear": 7, "loss": 8}
+
+
+class NppTensor(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("n", C.c_int64), ("h", C.c_int64), ("w", C.c_int64), ("c", C.c_int64),
+                ("ld", C.c_int64), ("dtype", C.c_int32), ("_pad", C.c_int32)]
+
+
+class NppConvGeom(C.Structure):
+    _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32), ("ph", C.c_int32),
+                ("pw", C.c_int32), ("dh", C.c_int32), ("dw", C.c_int32), ("uph", C.c_int32), ("upw", C.c_int32), ("relu_in", C.c_int32)]
+
+
+_lib = None
+
+_P = C.c_void_p
+_T = C.POINTER(NppTensor)
+_G = C.POINTER(NppConvGeom)
+_SIGS = {
+    "npp_prof_begin": [C.c_int, C.c_int],
+    "npp_prof_end": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
+    "npp_pack_weight": [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
+    "npp_conv_fwd": [_T, _P, _P, _T, _T, _P, _G, _P],
+    "npp_conv_wgrad": [_T, _T, _P, _G, _P],
+    "npp_unpack_wgrad": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
+    "npp_dwconv_fwd": [_T, _P, _T, _G, _P],
+    "npp_dwconv_bwd_data": [_T, _P, _T, _T, _G, _P],
+    "npp_dwconv_bwd_weight": [_T, _T, _P, _G, _P],
+    "npp_channel_stats": [_T, _P, _P],
+    "npp_channel_sum": [_T, _P, _P],
+    "npp_bn_finalize": [_P, C.c_double, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int, _P],
+    "npp_bn_eval_coeffs": [_P, _P, _P, _P, C.c_float, _P, C.c_int, _P],
+    "npp_affine_add": [_T, _T, _P, _T, _P, C.c_int, _P],
+    "npp_bn_bwd_reduce": [_T, _T, _T, _P, _P, _P],
+    "npp_bn_bwd_apply": [_T, _T, _T, _P, _P, _P, C.c_double, _T, _P, _P, _P],
+    "npp_scale_mask": [_T, _P, _T, _T, _P],
+    "npp_pool3x3_fwd": [_T, _T, _P, C.c_int, C.c_int, _P, _P],
+    "npp_pool3x3_bwd": [_T, _P, _T, C.c_int, C.c_int, _P],
+    "npp_pool2x2_fwd": [_T, _T, C.c_int, _P, _P],
+    "npp_pool2x2_bwd": [_T, _T, _T, C.c_int, _P],
+    "npp_global_avgpool": [_T, _P, _P],
+    "npp_se_gate_fwd": [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P],
+    "npp_se_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P],
+    "npp_scale_channels": [_T, _P, _T, _P],
+    "npp_se_bwd_reduce": [_T, _T, _P, _P],
+    "npp_se_bwd_apply": [_T, _P, _P, _T, _P],
+    "npp_bilinear_fwd": [_T, _T, _P],
+    "npp_bilinear_bwd": [_T, _T, _P],
+    "npp_copy": [_T, _T, _P],
+    "npp_nchw_to_nhwc": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _T, _P],
+    "npp_nhwc_to_nchw": [_T, _P, _P],
+    "npp_mse_fwd": [_T, _P, _P, _P],
+    "npp_mse_bwd": [_T, _P, _P, _T, _P],
+    "npp_ce_pixel_fwd": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P],
+    "npp_kth_smallest": [_P, C.c_int64, C.c_int64, _P, _P, _P],
+    "npp_ce_reduce": [_P, _P, _P, _P, C.c_int, C.c_int64, _P, C.c_float, C.c_int, _P, _P],
+    "npp_ce_pixel_bwd": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _T, _P],
+    "npp_edge_weights": [_P, C.c_int64, _P, _P],
+}
+EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_packed_weight_elems"])
+
+
+def lib():
+    """Load (once) and return the C library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU/eager fallback; "
+                f"run npp_amd/csrc/build.sh (or __graft_entry__.build()).")
+        L = C.CDLL(LIB_PATH)
+        L.npp_version.restype = C.c_char_p
+        L.npp_last_error.restype = C.c_char_p
+        L.npp_packed_weight_elems.restype = C.c_int64
+        L.npp_packed_weight_elems.argtypes = [C.c_int] * 5
+        for name, sig in _SIGS.items():
+            f = getattr(L, name)
+            f.restype = C.c_int
+            f.argtypes = sig
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise RuntimeError(f"libnpp_hip {what} failed ({rc}): {lib().npp_last_error().decode()}")
+
+
+def npp_dtype(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return NPP_F32
+    if t == torch.bfloat16:
+        return NPP_BF16
+    raise TypeError(f"libnpp_hip supports float32 / bfloat16 activations, got {t}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def new_nhwc(n: int, c: int, h: int, w: int, dtype, device, zero: bool = False, ld: int = 0) -> torch.Tensor:
+    """Logical [n,c,h,w] tensor stored NHWC (optionally with a wider pixel stride ld)."""
+    ld = ld or c
+    buf = (torch.zeros if zero else torch.empty)((n, h, w, ld), dtype=dtype, device=device)
+    t = buf.permute(0, 3, 1, 2)
+    return t[:, :c] if ld != c else t
+
+
+def nhwc_ld(t: torch.Tensor):
+    """Pixel stride (elements) if `t` is a logical-NCHW tensor with NHWC memory (channel stride 1, dense pixels,
+    possibly a channel slice of a wider buffer); None otherwise."""
+    if t.dim() != 4:
+        return None
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    if c > 1 and sc != 1:
+        return None
+    if w > 1:
+        ld = sw
+    elif h > 1:
+        ld = sh
+    elif n > 1:
+        ld = sn
+    else:
+        ld = c
+    if ld < c:
+        return None
+    if h > 1 and w > 1 and sh != w * ld:
+        return None
+    if n > 1 and (h > 1 or w > 1) and sn != h * w * ld:
+        return None
+    return ld
+
+
+def is_nhwc(t: torch.Tensor) -> bool:
+    return nhwc_ld(t) is not None
+
+
+def desc(t: torch.Tensor) -> NppTensor:
+    """NppTensor view of a logical-NCHW tensor whose memory is NHWC (channel stride 1)."""
+    ld = nhwc_ld(t)
+    if ld is None:
+        raise ValueError(f"tensor is not NHWC-strided: shape {tuple(t.shape)} strides {t.stride()}")
+    n, c, h, w = t.shape
+    return NppTensor(t.data_ptr(), n, h, w, c, ld, npp_dtype(t.dtype), 0)
+
+
+def to_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """Return t if it already is NHWC-strided, else a channels-last copy (made by our own copy kernel when
+    possible)."""
+    if is_nhwc(t):
+        return t
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def geom(kh, kw, sh, sw, ph, pw, dh, dw, up=1, relu_in=0) -> NppConvGeom:
+    uph, upw = (up, up) if isinstance(up, int) else up
+    return NppConvGeom(kh, kw, sh, sw, ph, pw, dh, dw, uph, upw, int(relu_in))
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def tref(t):
+    return None if t is None else C.byref(desc(t))

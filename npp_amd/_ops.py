@@ -1,0 +1,695 @@
+"""torch.autograd.Function wrappers around the C-ABI kernels (include/npp_hip.h).
+
+Every tensor that crosses this layer is logical NCHW with NHWC memory (channel stride 1), possibly a
+channel slice of a wider buffer.  PyTorch is used for allocation, the autograd tape and streams only:
+every byte of activation / gradient arithmetic is done by libnpp_hip.  No fallbacks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+
+from . import _lib as L
+from ._lib import check, desc, geom, lib, new_nhwc, ptr, stream_ptr, to_nhwc, tref
+
+BN_MOMENTUM = 0.1
+
+
+def _byref(t):
+    return C.byref(desc(t))
+
+
+# --------------------------------------------------------------------------------------------------
+# packed-weight cache: f32 OIHW parameter -> MFMA operand image, rebuilt when the parameter changes
+# --------------------------------------------------------------------------------------------------
+_pack_cache = weakref.WeakKeyDictionary()   # parameter object -> {(for_dgrad, dtype): (version, data_ptr, packed)}
+
+
+def packed_weight(w: torch.Tensor, for_dgrad: bool, dtype: torch.dtype) -> torch.Tensor:
+    key = (bool(for_dgrad), dtype)
+    ver = (w._version, w.data_ptr())
+    per = _pack_cache.get(w)
+    if per is None:
+        per = {}
+        _pack_cache[w] = per
+    hit = per.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    co, ci, kh, kw = w.shape
+    n = lib().npp_packed_weight_elems(co, ci, kh, kw, int(for_dgrad))
+    out = torch.empty(n, dtype=dtype, device=w.device)
+    wf = w.detach()
+    if wf.dtype != torch.float32 or not wf.is_contiguous():
+        wf = wf.float().contiguous()
+    check(lib().npp_pack_weight(wf.data_ptr(), co, ci, kh, kw, int(for_dgrad), L.npp_dtype(dtype), out.data_ptr(),
+                                stream_ptr()), "npp_pack_weight")
+    per[key] = (ver, out)
+    return out
+
+
+def clear_caches():
+    _pack_cache.clear()
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _conv_out(h, k, s, p, d):
+    return (h + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+# --------------------------------------------------------------------------------------------------
+# dense conv (MFMA implicit GEMM)
+# --------------------------------------------------------------------------------------------------
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil, relu_in, want_stats, out_hw):
+        x = to_nhwc(x)
+        n, ci, h, w = x.shape
+        co, _, kh, kw = weight.shape
+        if out_hw is None:
+            oh, ow = _conv_out(h, kh, stride[0], pad[0], dil[0]), _conv_out(w, kw, stride[1], pad[1], dil[1])
+        else:
+            oh, ow = out_hw
+        y = new_nhwc(n, co, oh, ow, x.dtype, x.device)
+        stats = torch.zeros(2 * co, dtype=torch.float64, device=x.device) if want_stats else None
+        g = geom(kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 1, relu_in)
+        wp = packed_weight(weight, False, x.dtype)
+        bf = None
+        if bias is not None:
+            bf = bias.detach()
+            if bf.dtype != torch.float32:
+                bf = bf.float()
+        check(lib().npp_conv_fwd(_byref(x), wp.data_ptr(), ptr(bf), None, _byref(y), ptr(stats), C.byref(g),
+                                 stream_ptr()), "npp_conv_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, dil, relu_in, bias is not None)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, weight = ctx.saved_tensors
+        stride, pad, dil, relu_in, has_bias = ctx.cfg
+        dy = to_nhwc(dy)
+        if dy.dtype != x.dtype:
+            dy = cast(dy, x.dtype)
+        n, ci, h, w = x.shape
+        co, _, kh, kw = weight.shape
+        dx = dw = db = None
+        s = stream_ptr()
+        if ctx.needs_input_grad[0]:
+            dx = new_nhwc(n, ci, h, w, x.dtype, x.device)
+            g = geom(kh, kw, 1, 1, dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1], dil[0], dil[1],
+                     (stride[0], stride[1]), 0)
+            wp = packed_weight(weight, True, x.dtype)
+            check(lib().npp_conv_fwd(_byref(dy), wp.data_ptr(), None, _byref(x) if relu_in else None, _byref(dx), None,
+                                     C.byref(g), s), "npp_conv_fwd(dgrad)")
+        if ctx.needs_input_grad[1]:
+            nel = lib().npp_packed_weight_elems(co, ci, kh, kw, 0)
+            dwp = torch.zeros(nel, dtype=torch.float32, device=x.device)
+            g = geom(kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 1, relu_in)
+            check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            check(lib().npp_unpack_wgrad(dwp.data_ptr(), co, ci, kh, kw, dw.data_ptr(), s), "npp_unpack_wgrad")
+            if dw.dtype != weight.dtype:
+                dw = dw.to(weight.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            acc = torch.zeros(co, dtype=torch.float64, device=x.device)
+            check(lib().npp_channel_sum(_byref(dy), acc.data_ptr(), s), "npp_channel_sum")
+            db = acc.float()
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1, relu_in=False, want_stats=False):
+    """y = conv(relu?(x)) + bias, plus (optionally) the f64 [sum | sumsq] statistics of y."""
+    return _Conv2d.apply(x, weight, bias, _pair(stride), _pair(pad), _pair(dil), bool(relu_in), bool(want_stats), None)
+
+
+def conv2d_crop(x, weight, stride=2, relu_in=False, want_stats=False):
+    """1x1 strided conv of the view x[:, :, 1:, 1:] (FactorizedReduce.conv2, operations.py:155) without
+    materialising the view: the crop is a padding of -1 in the gather."""
+    h, w = x.shape[2] - 1, x.shape[3] - 1
+    out_hw = ((h - 1) // stride + 1, (w - 1) // stride + 1)
+    return _Conv2d.apply(x, weight, None, _pair(stride), (-1, -1), (1, 1), bool(relu_in), bool(want_stats), out_hw)
+
+
+# --------------------------------------------------------------------------------------------------
+# depthwise conv
+# --------------------------------------------------------------------------------------------------
+class _DwConv2d(Function):
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad, dil, relu_in):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        _, _, kh, kw = weight.shape
+        oh, ow = _conv_out(h, kh, stride, pad, dil), _conv_out(w, kw, stride, pad, dil)
+        y = new_nhwc(n, c, oh, ow, x.dtype, x.device)
+        g = geom(kh, kw, stride, stride, pad, pad, dil, dil, 1, relu_in)
+        wf = weight.detach()
+        if wf.dtype != torch.float32 or not wf.is_contiguous():
+            wf = wf.float().contiguous()
+        check(lib().npp_dwconv_fwd(_byref(x), wf.data_ptr(), _byref(y), C.byref(g), stream_ptr()), "npp_dwconv_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, dil, relu_in)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, dil, relu_in = ctx.cfg
+        dy = to_nhwc(dy)
+        if dy.dtype != x.dtype:
+            dy = cast(dy, x.dtype)
+        _, _, kh, kw = weight.shape
+        g = geom(kh, kw, stride, stride, pad, pad, dil, dil, 1, relu_in)
+        s = stream_ptr()
+        wf = weight.detach()
+        if wf.dtype != torch.float32 or not wf.is_contiguous():
+            wf = wf.float().contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = new_nhwc(*x.shape, x.dtype, x.device)
+            check(lib().npp_dwconv_bwd_data(_byref(dy), wf.data_ptr(), _byref(x) if relu_in else None, _byref(dx),
+                                            C.byref(g), s), "npp_dwconv_bwd_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+            check(lib().npp_dwconv_bwd_weight(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_dwconv_bwd_weight")
+            if dw.dtype != weight.dtype:
+                dw = dw.to(weight.dtype)
+        return dx, dw, None, None, None, None
+
+
+def dwconv2d(x, weight, stride=1, pad=0, dil=1, relu_in=False):
+    return _DwConv2d.apply(x, weight, int(stride), int(pad), int(dil), bool(relu_in))
+
+
+# --------------------------------------------------------------------------------------------------
+# batch-norm apply fused with the branch add:  out = relu?( A(a) + B(b) )
+# --------------------------------------------------------------------------------------------------
+class BnSide:
+    """One operand of the fused add.  kind 'bn': `x` is a raw (pre-BN) tensor with f64 stats (train) or a
+    BatchNorm holder in eval mode; kind 'plain': `x` is used as is."""
+
+    __slots__ = ("x", "bn", "stats", "count")
+
+    def __init__(self, x, bn=None, stats=None):
+        self.x = x
+        self.bn = bn
+        self.stats = stats
+        self.count = None
+
+
+def _sync_group(bn):
+    """SyncBatchNorm (augment_lip_sync.py:191) -> the process group to reduce statistics over."""
+    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+        grp = bn.process_group
+        ws = dist.get_world_size(grp) if grp is not None else dist.get_world_size()
+        if ws > 1:
+            return grp if grp is not None else dist.group.WORLD, ws
+    return None, 1
+
+
+def _bn_coeffs(side: BnSide, training: bool, device):
+    """scale/shift (+ mean/invstd) for one BN side; updates running stats in train mode."""
+    bn = side.bn
+    c = side.x.shape[1]
+    ss = torch.empty(2 * c, dtype=torch.float32, device=device)
+    gamma = bn.weight.detach() if bn.weight is not None else None
+    beta = bn.bias.detach() if bn.bias is not None else None
+    s = stream_ptr()
+    use_batch = training or bn.running_mean is None
+    if use_batch:
+        stats = side.stats
+        if stats is None:
+            stats = channel_stats(side.x)
+        count = float(side.x.shape[0] * side.x.shape[2] * side.x.shape[3])
+        grp, ws = _sync_group(bn)
+        if grp is not None:
+            dist.all_reduce(stats, group=grp)
+            count *= ws
+        side.count = count
+        mi = torch.empty(2 * c, dtype=torch.float32, device=device)
+        track = bn.track_running_stats and bn.running_mean is not None and training
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
+        check(lib().npp_bn_finalize(stats.data_ptr(), count, ptr(gamma), ptr(beta),
+                                    ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                                    ptr(nbt), float(mom), float(bn.eps), ss.data_ptr(), mi.data_ptr(), c, s),
+              "npp_bn_finalize")
+        return ss, mi, True
+    check(lib().npp_bn_eval_coeffs(ptr(gamma), ptr(beta), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                   float(bn.eps), ss.data_ptr(), c, s), "npp_bn_eval_coeffs")
+    mi = None
+    if torch.is_grad_enabled():   # mean / invstd for the (rare) backward in eval mode
+        mi = torch.cat([bn.running_mean.detach().float(), torch.rsqrt(bn.running_var.detach().float() + bn.eps)])
+    return ss, mi, False
+
+
+class _BnAdd(Function):
+    """out = relu?( [BN_a](a) + [BN_b](b) ).  Tensor args: a, gamma_a, beta_a, b, gamma_b, beta_b."""
+
+    @staticmethod
+    def forward(ctx, a, ga, ba, b, gb, bb, sa: BnSide, sb: Optional[BnSide], relu: bool, training: bool):
+        dev = a.device
+        ssa = mia = ssb = mib = None
+        batch_a = batch_b = False
+        if sa.bn is not None:
+            ssa, mia, batch_a = _bn_coeffs(sa, training, dev)
+        if sb is not None and sb.bn is not None:
+            ssb, mib, batch_b = _bn_coeffs(sb, training, dev)
+        y = new_nhwc(*a.shape, a.dtype, dev)
+        check(lib().npp_affine_add(_byref(y), _byref(a), ptr(ssa), tref(b), ptr(ssb), int(relu), stream_ptr()),
+              "npp_affine_add")
+        ctx.relu = relu
+        ctx.sides = (sa.bn, sb.bn if sb is not None else None, batch_a, batch_b, sa.count, sb.count if sb else None,
+                     b is not None)
+        ctx.save_for_backward(a, b, y if relu else None, mia, mib, ssa, ssb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b, yrelu, mia, mib, ssa, ssb = ctx.saved_tensors
+        bna, bnb, batch_a, batch_b, cnt_a, cnt_b, has_b = ctx.sides
+        dout = to_nhwc(dout)
+        if dout.dtype != a.dtype:
+            dout = cast(dout, a.dtype)
+        s = stream_ptr()
+
+        def side(x, bn, mi, ss, batch, count, need_x, need_g, need_b):
+            dx = dg = db = None
+            if bn is None:
+                if need_x:
+                    if yrelu is None:
+                        dx = dout
+                    else:
+                        dx = new_nhwc(*x.shape, x.dtype, x.device)
+                        check(lib().npp_scale_mask(_byref(dout), None, _byref(yrelu), _byref(dx), s), "npp_scale_mask")
+                return dx, None, None
+            c = x.shape[1]
+            sums = torch.zeros(2 * c, dtype=torch.float64, device=x.device)
+            check(lib().npp_bn_bwd_reduce(_byref(dout), _byref(x), tref(yrelu), mi.data_ptr(), sums.data_ptr(), s),
+                  "npp_bn_bwd_reduce")
+            gamma = bn.weight.detach() if bn.weight is not None else None
+            if batch:
+                grp, ws = _sync_group(bn)
+                dgt = dbt = None
+                if grp is not None:
+                    # SyncBatchNorm: weight/bias grads are the LOCAL sums (DDP averages them afterwards);
+                    # the input gradient uses the all-reduced sums over the global count.
+                    local = sums.clone()
+                    dist.all_reduce(sums, group=grp)
+                    dg, db = local[c:].float(), local[:c].float()
+                else:
+                    dgt = torch.empty(c, dtype=torch.float32, device=x.device)
+                    dbt = torch.empty(c, dtype=torch.float32, device=x.device)
+                    dg, db = dgt, dbt
+                dx = new_nhwc(*x.shape, x.dtype, x.device)
+                check(lib().npp_bn_bwd_apply(_byref(dout), _byref(x), tref(yrelu), mi.data_ptr(), ptr(gamma),
+                                             sums.data_ptr(), float(count), _byref(dx), ptr(dgt), ptr(dbt), s),
+                      "npp_bn_bwd_apply")
+            else:
+                if need_x:
+                    dx = new_nhwc(*x.shape, x.dtype, x.device)
+                    check(lib().npp_scale_mask(_byref(dout), ss.data_ptr(), tref(yrelu), _byref(dx), s), "npp_scale_mask")
+                dg, db = sums[c:].float(), sums[:c].float()
+            return (dx if need_x else None), (dg if need_g else None), (db if need_b else None)
+
+        ni = ctx.needs_input_grad
+        da, dga, dba = side(a, bna, mia, ssa, batch_a, cnt_a, ni[0], ni[1], ni[2])
+        dbx = dgb = dbb = None
+        if has_b:
+            dbx, dgb, dbb = side(b, bnb, mib, ssb, batch_b, cnt_b, ni[3], ni[4], ni[5])
+        return da, dga, dba, dbx, dgb, dbb, None, None, None, None
+
+
+def bn_add(sa: BnSide, sb: Optional[BnSide] = None, relu: bool = False, training: bool = True):
+    """Fused BN-apply (+ second operand, BN'd or plain) (+ ReLU)."""
+    a = to_nhwc(sa.x)
+    sa.x = a
+    ga = sa.bn.weight if sa.bn is not None else None
+    ba = sa.bn.bias if sa.bn is not None else None
+    b = gb = bb = None
+    if sb is not None:
+        b = to_nhwc(sb.x)
+        sb.x = b
+        if b.dtype != a.dtype:
+            b = cast(b, a.dtype)
+            sb.x = b
+        if sb.bn is not None:
+            gb, bb = sb.bn.weight, sb.bn.bias
+    return _BnAdd.apply(a, ga, ba, b, gb, bb, sa, sb, bool(relu), bool(training))
+
+
+def add(a, b):
+    return bn_add(BnSide(a), BnSide(b))
+
+
+def channel_stats(x: torch.Tensor) -> torch.Tensor:
+    x = to_nhwc(x)
+    st = torch.zeros(2 * x.shape[1], dtype=torch.float64, device=x.device)
+    check(lib().npp_channel_stats(_byref(x.detach()), st.data_ptr(), stream_ptr()), "npp_channel_stats")
+    return st
+
+
+# --------------------------------------------------------------------------------------------------
+# pooling
+# --------------------------------------------------------------------------------------------------
+class _Pool3x3(Function):
+    @staticmethod
+    def forward(ctx, x, is_avg, stride, want_stats):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+        y = new_nhwc(n, c, oh, ow, x.dtype, x.device)
+        amax = None if is_avg else torch.empty((n, oh, ow, c), dtype=torch.uint8, device=x.device)
+        stats = torch.zeros(2 * c, dtype=torch.float64, device=x.device) if want_stats else None
+        check(lib().npp_pool3x3_fwd(_byref(x), _byref(y), ptr(amax), int(is_avg), stride, ptr(stats), stream_ptr()),
+              "npp_pool3x3_fwd")
+        ctx.save_for_backward(amax)
+        ctx.cfg = (is_avg, stride, tuple(x.shape), x.dtype)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _):
+        (amax,) = ctx.saved_tensors
+        is_avg, stride, xshape, dtype = ctx.cfg
+        dy = to_nhwc(dy)
+        if dy.dtype != dtype:
+            dy = cast(dy, dtype)
+        dx = new_nhwc(*xshape, dtype, dy.device)
+        check(lib().npp_pool3x3_bwd(_byref(dy), ptr(amax), _byref(dx), int(is_avg), stride, stream_ptr()), "npp_pool3x3_bwd")
+        return dx, None, None, None
+
+
+def pool3x3(x, is_avg=False, stride=1, want_stats=False):
+    return _Pool3x3.apply(x, bool(is_avg), int(stride), bool(want_stats))
+
+
+class _Pool2x2(Function):
+    @staticmethod
+    def forward(ctx, x, is_avg, want_stats):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = new_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
+        stats = torch.zeros(2 * c, dtype=torch.float64, device=x.device) if want_stats else None
+        check(lib().npp_pool2x2_fwd(_byref(x), _byref(y), int(is_avg), ptr(stats), stream_ptr()), "npp_pool2x2_fwd")
+        ctx.save_for_backward(None if is_avg else x)
+        ctx.cfg = (is_avg, tuple(x.shape), x.dtype)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _):
+        (x,) = ctx.saved_tensors
+        is_avg, xshape, dtype = ctx.cfg
+        dy = to_nhwc(dy)
+        if dy.dtype != dtype:
+            dy = cast(dy, dtype)
+        odd = xshape[2] % 2 or xshape[3] % 2
+        if odd:
+            raise NotImplementedError("pool2x2 backward with odd extents")
+        dx = new_nhwc(*xshape, dtype, dy.device)
+        check(lib().npp_pool2x2_bwd(_byref(dy), tref(x), _byref(dx), int(is_avg), stream_ptr()), "npp_pool2x2_bwd")
+        return dx, None, None
+
+
+def pool2x2(x, is_avg=True, want_stats=False):
+    return _Pool2x2.apply(x, bool(is_avg), bool(want_stats))
+
+
+# --------------------------------------------------------------------------------------------------
+# squeeze-excite gate:  y = x * sigmoid(W2 relu(W1 gap(x) + b1) + b2)
+# --------------------------------------------------------------------------------------------------
+class _SEScale(Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        dev = x.device
+        s = stream_ptr()
+        pooled = torch.zeros((n, c), dtype=torch.float32, device=dev)
+        check(lib().npp_global_avgpool(_byref(x), pooled.data_ptr(), s), "npp_global_avgpool")
+        hidden = torch.empty((n, c // 2), dtype=torch.float32, device=dev)
+        gate = torch.empty((n, c), dtype=torch.float32, device=dev)
+        w1f, b1f, w2f, b2f = (t.detach().float().contiguous() for t in (w1, b1, w2, b2))
+        check(lib().npp_se_gate_fwd(pooled.data_ptr(), w1f.data_ptr(), b1f.data_ptr(), w2f.data_ptr(), b2f.data_ptr(),
+                                    hidden.data_ptr(), gate.data_ptr(), n, c, s), "npp_se_gate_fwd")
+        y = new_nhwc(n, c, h, w, x.dtype, dev)
+        check(lib().npp_scale_channels(_byref(x), gate.data_ptr(), _byref(y), s), "npp_scale_channels")
+        ctx.save_for_backward(x, w1, w2, pooled, hidden, gate)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, pooled, hidden, gate = ctx.saved_tensors
+        dy = to_nhwc(dy)
+        if dy.dtype != x.dtype:
+            dy = cast(dy, x.dtype)
+        n, c, h, w = x.shape
+        dev = x.device
+        s = stream_ptr()
+        dgate = torch.zeros((n, c), dtype=torch.float32, device=dev)
+        check(lib().npp_se_bwd_reduce(_byref(dy), _byref(x), dgate.data_ptr(), s), "npp_se_bwd_reduce")
+        dw1 = torch.zeros(w1.shape, dtype=torch.float32, device=dev)
+        db1 = torch.zeros(c // 2, dtype=torch.float32, device=dev)
+        dw2 = torch.zeros(w2.shape, dtype=torch.float32, device=dev)
+        db2 = torch.zeros(c, dtype=torch.float32, device=dev)
+        dpooled = torch.empty((n, c), dtype=torch.float32, device=dev)
+        w1f, w2f = w1.detach().float().contiguous(), w2.detach().float().contiguous()
+        check(lib().npp_se_gate_bwd(pooled.data_ptr(), hidden.data_ptr(), gate.data_ptr(), dgate.data_ptr(),
+                                    w1f.data_ptr(), w2f.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
+                                    db2.data_ptr(), dpooled.data_ptr(), n, c, s), "npp_se_gate_bwd")
+        dx = new_nhwc(n, c, h, w, x.dtype, dev)
+        check(lib().npp_se_bwd_apply(_byref(dy), gate.data_ptr(), dpooled.data_ptr(), _byref(dx), s), "npp_se_bwd_apply")
+        return dx, dw1, db1, dw2, db2
+
+
+def se_scale(x, w1, b1, w2, b2):
+    return _SEScale.apply(x, w1, b1, w2, b2)
+
+
+# --------------------------------------------------------------------------------------------------
+# bilinear (align_corners=True)
+# --------------------------------------------------------------------------------------------------
+class _Bilinear(Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = new_nhwc(n, c, oh, ow, x.dtype, x.device)
+        check(lib().npp_bilinear_fwd(_byref(x), _byref(y), stream_ptr()), "npp_bilinear_fwd")
+        ctx.cfg = (tuple(x.shape), x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xshape, dtype = ctx.cfg
+        dy = to_nhwc(dy)
+        if dy.dtype != dtype:
+            dy = cast(dy, dtype)
+        dx = new_nhwc(*xshape, dtype, dy.device)
+        check(lib().npp_bilinear_bwd(_byref(dy), _byref(dx), stream_ptr()), "npp_bilinear_bwd")
+        return dx, None, None
+
+
+def bilinear(x, oh: int, ow: int):
+    if x.shape[2] == oh and x.shape[3] == ow:
+        return x   # align_corners identity resample (Interpolate(1.0), model_augment.py:638-645) is exact
+    return _Bilinear.apply(x, int(oh), int(ow))
+
+
+def interpolate_scale(x, scale: float):
+    """F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=True): out = floor(in * scale)."""
+    import math
+    oh, ow = int(math.floor(x.shape[2] * scale)), int(math.floor(x.shape[3] * scale))
+    return bilinear(x, oh, ow)
+
+
+# --------------------------------------------------------------------------------------------------
+# layout plumbing
+# --------------------------------------------------------------------------------------------------
+class _Cast(Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        x = to_nhwc(x)
+        y = new_nhwc(*x.shape, dtype, x.device)
+        check(lib().npp_copy(_byref(x), _byref(y), stream_ptr()), "npp_copy")
+        ctx.dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _Cast.apply(dy, ctx.dtype), None
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    return _Cast.apply(x, dtype)
+
+
+class _Concat(Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [to_nhwc(x) for x in xs]
+        n, _, h, w = xs[0].shape
+        ctot = sum(x.shape[1] for x in xs)
+        y = new_nhwc(n, ctot, h, w, xs[0].dtype, xs[0].device)
+        s = stream_ptr()
+        off = 0
+        for x in xs:
+            c = x.shape[1]
+            check(lib().npp_copy(_byref(x), _byref(y[:, off:off + c]), s), "npp_copy")
+            off += c
+        ctx.splits = [x.shape[1] for x in xs]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = to_nhwc(dy)
+        outs = []
+        off = 0
+        for c in ctx.splits:
+            outs.append(dy[:, off:off + c])   # channel-slice views: consumers take ld, no copy
+            off += c
+        return tuple(outs)
+
+
+def concat(xs: Sequence[torch.Tensor]):
+    return _Concat.apply(*xs)
+
+
+class _ImageToNhwc(Function):
+    @staticmethod
+    def forward(ctx, x, dtype, cpad):
+        xf = x.detach()
+        if xf.dtype != torch.float32 or not xf.is_contiguous():
+            xf = xf.float().contiguous()
+        n, c, h, w = xf.shape
+        y = new_nhwc(n, cpad, h, w, dtype, x.device)
+        check(lib().npp_nchw_to_nhwc(xf.data_ptr(), n, c, h, w, _byref(y), stream_ptr()), "npp_nchw_to_nhwc")
+        return y[:, :c]
+
+    @staticmethod
+    def backward(ctx, dy):
+        return None, None, None   # the network input needs no gradient (core/function.py:87)
+
+
+def image_to_nhwc(x, dtype, cpad=8):
+    """NCHW f32 image batch -> NHWC `dtype`, channels zero-padded to `cpad` in memory (logical C kept)."""
+    return _ImageToNhwc.apply(x, dtype, cpad)
+
+
+def nhwc_to_nchw_f32(x):
+    x = to_nhwc(x)
+    out = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+    check(lib().npp_nhwc_to_nchw(_byref(x.detach()), out.data_ptr(), stream_ptr()), "npp_nhwc_to_nchw")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# loss heads
+# --------------------------------------------------------------------------------------------------
+class _MseSse(Function):
+    """sum((pred - target)^2) as an f32 scalar; target is f32 NCHW-contiguous."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred = to_nhwc(pred)
+        tgt = target.detach()
+        if tgt.dtype != torch.float32 or not tgt.is_contiguous():
+            tgt = tgt.float().contiguous()
+        sse = torch.zeros(1, dtype=torch.float64, device=pred.device)
+        check(lib().npp_mse_fwd(_byref(pred), tgt.data_ptr(), sse.data_ptr(), stream_ptr()), "npp_mse_fwd")
+        ctx.save_for_backward(pred, tgt)
+        return sse.float().reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, tgt = ctx.saved_tensors
+        gs = g.detach().float().reshape(1).contiguous()
+        grad = new_nhwc(*pred.shape, pred.dtype, pred.device)
+        check(lib().npp_mse_bwd(_byref(pred), tgt.data_ptr(), gs.data_ptr(), _byref(grad), stream_ptr()), "npp_mse_bwd")
+        return grad, None
+
+
+def mse_sse(pred, target):
+    return _MseSse.apply(pred, target)
+
+
+class _UpsampledCE(Function):
+    """Cross-entropy of logits bilinearly upsampled (align_corners) to the label size.
+    ohem=(thresh, min_kept): OhemCrossEntropy (core/criterion.py:54-72), mean over kept pixels;
+    ohem=None: F.cross_entropy(weight, ignore_index) weighted mean (core/criterion.py:194-197)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, class_w, ignore, ohem):
+        logits = to_nhwc(logits)
+        n, c, h, w = logits.shape
+        H, W = labels.shape[1], labels.shape[2]
+        dev = logits.device
+        lab = labels.detach()
+        if lab.dtype != torch.int64 or not lab.is_contiguous():
+            lab = lab.long().contiguous()
+        cw = class_w.detach().float().contiguous()
+        npx = n * H * W
+        p_gt = torch.empty(npx, dtype=torch.float32, device=dev)
+        wnll = torch.empty(npx, dtype=torch.float32, device=dev)
+        s = stream_ptr()
+        check(lib().npp_ce_pixel_fwd(_byref(logits), lab.data_ptr(), H, W, cw.data_ptr(), ignore, p_gt.data_ptr(),
+                                     wnll.data_ptr(), s), "npp_ce_pixel_fwd")
+        kth = None
+        thresh = 0.0
+        if ohem is not None:
+            thresh, min_kept = ohem
+            ws = torch.empty(260, dtype=torch.int32, device=dev)
+            kth = torch.empty(2, dtype=torch.float32, device=dev)
+            check(lib().npp_kth_smallest(p_gt.data_ptr(), npx, max(1, int(min_kept)), ws.data_ptr(), kth.data_ptr(), s),
+                  "npp_kth_smallest")
+        acc = torch.zeros(3, dtype=torch.float64, device=dev)
+        check(lib().npp_ce_reduce(p_gt.data_ptr(), wnll.data_ptr(), lab.data_ptr(), cw.data_ptr(), ignore, npx, ptr(kth),
+                                  float(thresh), int(ohem is not None), acc.data_ptr(), s), "npp_ce_reduce")
+        denom = acc[1] if ohem is not None else acc[2]
+        loss = (acc[0] / denom).float()
+        ctx.save_for_backward(logits, lab, cw, p_gt, kth, denom)
+        ctx.cfg = (ignore, thresh, ohem is not None, H, W)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, lab, cw, p_gt, kth, denom = ctx.saved_tensors
+        ignore, thresh, use_ohem, H, W = ctx.cfg
+        gs = (g.detach().double() / denom).float().reshape(1).contiguous()
+        n, c, h, w = logits.shape
+        dl = new_nhwc(n, c, h, w, torch.float32, logits.device, zero=True)
+        check(lib().npp_ce_pixel_bwd(_byref(logits), lab.data_ptr(), H, W, cw.data_ptr(), ignore, p_gt.data_ptr(), ptr(kth),
+                                     float(thresh), int(use_ohem), gs.data_ptr(), _byref(dl), stream_ptr()), "npp_ce_pixel_bwd")
+        if logits.dtype != torch.float32:
+            dl = cast(dl, logits.dtype)
+        return dl, None, None, None, None
+
+
+def upsampled_ce(logits, labels, class_w, ignore=255, ohem=None):
+    return _UpsampledCE.apply(logits, labels, class_w, int(ignore), ohem)
+
+
+def edge_class_weights(labels: torch.Tensor) -> torch.Tensor:
+    """[pos/(pos+neg), neg/(pos+neg)] from the edge label map (core/criterion.py:161-166), on device."""
+    lab = labels.detach()
+    if lab.dtype != torch.int64 or not lab.is_contiguous():
+        lab = lab.long().contiguous()
+    cnt = torch.zeros(2, dtype=torch.float64, device=lab.device)
+    check(lib().npp_edge_weights(lab.data_ptr(), lab.numel(), cnt.data_ptr(), stream_ptr()), "npp_edge_weights")
+    tot = cnt.sum()
+    return torch.stack([cnt[1] / tot, cnt[0] / tot]).float()

@@ -1,0 +1,119 @@
+"""Loss heads on the HIP kernels -- drop-in for the reference's `core/criterion.py`.
+
+Same classes / constructor arguments / `lamda` parameters: `Criterion_pose(out_len, use_target_weight)`
+(core/criterion.py:74-145), `OhemCrossEntropy` (:43-72), `Criterion_par(out_len, ignore_index, thres,
+min_kept)` (:148-217).  The per-pixel work (bilinear x4 upsample of the logits to the label size, softmax,
+weighted NLL, OHEM selection, and all of their backward) runs in `csrc/loss.hip`; the upsampled
+[N,C,384,384] logits are never materialised and OHEM's global sort is an exact radix select.  Only the
+scalar tail (`* exp(-lamda) + lamda`, the final mean) is torch arithmetic on 0-d tensors.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _ops as K
+
+# LIP class weights, core/criterion.py:17-21
+lip = [0.7602572, 0.94236198, 0.85644457, 1.04346266, 1.10627293, 0.80980162,
+       0.95168713, 0.8403769, 1.05798412, 0.85746254, 1.01274366, 1.05854692,
+       1.03430773, 0.84867818, 0.88027721, 0.87580925, 0.98747462, 0.9876475,
+       1.00016535, 1.00108882]
+weights_lip = torch.tensor(lip, dtype=torch.float32)
+pascal = [0.82877791, 0.95688253, 0.94921949, 1.00538108, 1.0201687, 1.01665831, 1.05470914]
+weights_pascal = torch.tensor(pascal, dtype=torch.float32)
+
+
+class OhemCrossEntropy(nn.Module):
+    """core/criterion.py:43-72.  `score` may be at the label resolution or lower (it is then upsampled
+    bilinearly with align_corners=True inside the kernel, as Criterion_par does before calling the
+    reference's OhemCrossEntropy)."""
+
+    def __init__(self, ignore_index=255, thres=0.7, min_kept=100000, weight=weights_lip):
+        super().__init__()
+        self.thresh = thres
+        self.min_kept = max(1, min_kept)
+        self.ignore_index = ignore_index
+        self.register_buffer("class_weight", weight.clone().float(), persistent=False)
+
+    def forward(self, score, target, **kwargs):
+        cw = self.class_weight
+        if cw.device != score.device:
+            cw = cw.to(score.device)
+            self.class_weight = cw
+        return K.upsampled_ce(score, target, cw, self.ignore_index, ohem=(self.thresh, self.min_kept))
+
+
+class Criterion_pose(nn.Module):
+    """core/criterion.py:74-145."""
+
+    def __init__(self, out_len=1, use_target_weight=False):
+        super().__init__()
+        self.use_target_weight = use_target_weight
+        self.lamda = nn.Parameter(-2.5 * torch.ones(out_len))
+
+    def joint_loss(self, output, target, target_weight=None):
+        """sum_j MSE(pred_j, gt_j) over main (+ aux) maps / num_joints, criterion.py:82-128.
+        Every per-joint MSE is a mean over N*H*W elements, so the sum over joints is SSE / (N*H*W)."""
+        if self.use_target_weight:
+            raise NotImplementedError("use_target_weight=True is not used by either launcher "
+                                      "(augment_lip_sync.py:187, search_lip_sync.py) and is not implemented")
+        outs = output if isinstance(output, list) else [output]
+        tgts = target if isinstance(target, list) else [target]
+        if not isinstance(output, list):
+            tgts = tgts[:1]
+        J = outs[0].size(1)
+        loss = 0.
+        for o, t in zip(outs, tgts):
+            if tuple(o.shape[2:]) != tuple(t.shape[2:]):
+                raise NotImplementedError("heat-map / target size mismatch (criterion.py:95 resamples; unused)")
+            loss = loss + K.mse_sse(o, t) / float(o.size(0) * o.size(2) * o.size(3))
+        return loss / J
+
+    def forward(self, output, target, target_weight=None):
+        loss = 0.
+        if isinstance(output, list):
+            for i in range(len(output)):
+                loss = loss + self.joint_loss(output[i], target, target_weight) * torch.exp(-self.lamda[i]) + self.lamda[i]
+        else:
+            loss = loss + self.joint_loss(output, target, target_weight) * torch.exp(-self.lamda) + self.lamda
+        return loss
+
+
+class Criterion_par(nn.Module):
+    """core/criterion.py:148-217."""
+
+    def __init__(self, out_len=1, ignore_index=255, thres=0.9, min_kept=131072):
+        super().__init__()
+        self.ignore_index = ignore_index
+        self.criterion = OhemCrossEntropy(ignore_index=ignore_index, thres=thres, min_kept=min_kept, weight=weights_lip)
+        self.lamda = nn.Parameter(2.3 * torch.ones(out_len))
+
+    def parsing_loss(self, preds, target, edge_w=None):
+        """criterion.py:158-202: OHEM CE on the parsing logits + class-balanced CE on the edge logits, both on
+        logits upsampled to the label size."""
+        if edge_w is None:
+            edge_w = K.edge_class_weights(target[1])
+        loss = 0.
+        if isinstance(preds, list):
+            par = preds[0]
+            if isinstance(par, list):
+                loss = loss + self.criterion(par[0], target[0]) + self.criterion(par[1], target[0]) * 0.4
+            else:
+                loss = loss + self.criterion(par, target[0])
+            edges = preds[1] if isinstance(preds[1], list) else [preds[1]]
+            for e in edges:
+                loss = loss + K.upsampled_ce(e, target[1], edge_w, self.ignore_index, ohem=None)
+        else:
+            loss = loss + self.criterion(preds, target[0])
+        return loss
+
+    def forward(self, preds, target):
+        loss = 0.
+        if isinstance(preds, list):
+            edge_w = K.edge_class_weights(target[1])
+            for i in range(len(preds)):
+                loss = loss + self.parsing_loss(preds[i], target, edge_w) * torch.exp(-self.lamda[i]) + self.lamda[i]
+        else:
+            loss = loss + self.criterion(preds, target) * torch.exp(-self.lamda) + self.lamda
+        return loss

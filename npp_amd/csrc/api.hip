@@ -1,0 +1,86 @@
+// libnpp_hip: error reporting, version, and the per-family launch profiler used by bench.py.
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void npp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int npp_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    npp_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return NPP_E_HIP;
+  }
+  return NPP_OK;
+}
+
+extern "C" const char* npp_version(void) { return "npp_hip 0.1 (gfx950)"; }
+extern "C" const char* npp_last_error(void) { return g_err; }
+
+// ---- profiler ------------------------------------------------------------------------------------
+namespace {
+struct ProfState {
+  std::mutex mu;
+  int family = NPP_FAM_NONE;
+  int dtype = -1;
+  std::vector<hipEvent_t> ev;  // pairs
+  int used = 0;                // events used
+  double flops = 0, bytes = 0;
+} g_prof;
+}  // namespace
+
+ProfScope::ProfScope(int family, int dtype, hipStream_t s, double flops, double bytes) : slot(-1), stream(s) {
+  if (g_prof.family != family) return;
+  if (g_prof.dtype >= 0 && g_prof.dtype != dtype) return;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  if (g_prof.used + 2 > (int)g_prof.ev.size()) {
+    if (g_prof.ev.size() >= 400000) return;
+    for (int i = 0; i < 2; ++i) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      g_prof.ev.push_back(e);
+    }
+  }
+  slot = g_prof.used;
+  g_prof.used += 2;
+  g_prof.flops += flops;
+  g_prof.bytes += bytes;
+  hipEventRecord(g_prof.ev[slot], s);
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) hipEventRecord(g_prof.ev[slot + 1], stream);
+}
+
+extern "C" int npp_prof_begin(int family, int dtype_filter) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.family = family;
+  g_prof.dtype = dtype_filter;
+  g_prof.used = 0;
+  g_prof.flops = g_prof.bytes = 0;
+  return NPP_OK;
+}
+
+extern "C" int npp_prof_end(double* ms_total, double* flops_total, double* bytes_total, int64_t* launches) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  double ms = 0;
+  for (int i = 0; i + 1 < g_prof.used; i += 2) {
+    float t = 0;
+    if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) continue;
+    if (hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]) == hipSuccess) ms += t;
+  }
+  if (ms_total) *ms_total = ms;
+  if (flops_total) *flops_total = g_prof.flops;
+  if (bytes_total) *bytes_total = g_prof.bytes;
+  if (launches) *launches = g_prof.used / 2;
+  g_prof.family = NPP_FAM_NONE;
+  g_prof.used = 0;
+  return NPP_OK;
+}

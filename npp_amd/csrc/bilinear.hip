@@ -1,0 +1,136 @@
+// Bilinear resampling with align_corners=True (any size ratio, up or down), NHWC channel vectors.
+// Forward = 4-tap gather.  Backward is ALSO a gather (no atomics, deterministic): every input pixel
+// walks the output pixels whose source coordinate falls within one pixel of it and re-derives the
+// forward weights with the same float arithmetic.
+//
+// Replaces F.interpolate(..., mode='bilinear', align_corners=True) at model_augment.py:109-116,539-543
+// and nn.UpsamplingBilinear2d at operations.py:242-244 (ATen upsample_bilinear2d fwd/bwd).
+#include "vecio.h"
+
+namespace {
+
+NPP_DEV void src_index(float scale, int o, int in_size, int& i0, int& i1p, float& l0, float& l1) {
+  const float s = scale * (float)o;           // area_pixel_compute_source_index, align_corners=True
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1p = (i0 < in_size - 1) ? 1 : 0;
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
+                                                           int N, int H, int W, int OH, int OW, int cv, float sh, float sw) {
+  const long total = (long)N * OH * OW * cv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / cv;
+    const int c0 = (int)(i - p * cv) * V;
+    const int ow = (int)(p % OW);
+    const long t2 = p / OW;
+    const int oh = (int)(t2 % OH), n = (int)(t2 / OH);
+    int h0, hp, w0, wp;
+    float lh0, lh1, lw0, lw1;
+    src_index(sh, oh, H, h0, hp, lh0, lh1);
+    src_index(sw, ow, W, w0, wp, lw0, lw1);
+    const T* b = x + ((long)(n * H + h0) * W + w0) * ldx + c0;
+    float v00[V], v01[V], v10[V], v11[V], o[V];
+    ldv<T, V>(b, v00);
+    ldv<T, V>(b + (long)wp * ldx, v01);
+    ldv<T, V>(b + (long)hp * W * ldx, v10);
+    ldv<T, V>(b + ((long)hp * W + wp) * ldx, v11);
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+      o[j] = lh0 * (lw0 * v00[j] + lw1 * v01[j]) + lh1 * (lw0 * v10[j] + lw1 * v11[j]);
+    stv<T, V>(y + p * ldy + c0, o);
+  }
+}
+
+NPP_DEV void contrib_range(float scale, int i, int out_size, int& lo, int& hi) {
+  if (scale <= 0.f) { lo = 0; hi = out_size - 1; return; }
+  const float inv = 1.f / scale;
+  lo = (int)floorf(((float)i - 1.f) * inv) - 1;
+  hi = (int)ceilf(((float)i + 1.f) * inv) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out_size - 1) hi = out_size - 1;
+}
+
+NPP_DEV float contrib_weight(float scale, int o, int i, int in_size) {
+  int i0, ip;
+  float l0, l1;
+  src_index(scale, o, in_size, i0, ip, l0, l1);
+  float w = 0.f;
+  if (i0 == i) w += l0;
+  if (i0 + ip == i) w += (ip ? l1 : l1);   // ip == 0: the second tap aliases the first (weight l1 on i0)
+  return w;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ dy, long ldy, T* __restrict__ dx, long ldx,
+                                                           int N, int H, int W, int OH, int OW, int cv, float sh, float sw) {
+  const long total = (long)N * H * W * cv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / cv;
+    const int c0 = (int)(i - p * cv) * V;
+    const int iw = (int)(p % W);
+    const long t2 = p / W;
+    const int ih = (int)(t2 % H), n = (int)(t2 / H);
+    int hlo, hhi, wlo, whi;
+    contrib_range(sh, ih, OH, hlo, hhi);
+    contrib_range(sw, iw, OW, wlo, whi);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    for (int oh = hlo; oh <= hhi; ++oh) {
+      const float wh = contrib_weight(sh, oh, ih, H);
+      if (wh == 0.f) continue;
+      for (int ow = wlo; ow <= whi; ++ow) {
+        const float ww = contrib_weight(sw, ow, iw, W);
+        if (ww == 0.f) continue;
+        float d[V];
+        ldv<T, V>(dy + ((long)(n * OH + oh) * OW + ow) * ldy + c0, d);
+        const float w = wh * ww;
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += w * d[j];
+      }
+    }
+    stv<T, V>(dx + p * ldx + c0, acc);
+  }
+}
+
+}  // namespace
+
+static inline float ac_scale(long in_size, long out_size) {
+  return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+}
+
+extern "C" int npp_bilinear_fwd(const NppTensor* x, NppTensor* y, void* stream) {
+  NPP_REQUIRE(x && y && x->ptr && y->ptr, NPP_E_NULL, "npp_bilinear_fwd: null pointer");
+  NPP_REQUIRE(dtype_ok(x) && x->dtype == y->dtype, NPP_E_DTYPE, "npp_bilinear_fwd: dtype mismatch");
+  NPP_REQUIRE(x->n == y->n && x->c == y->c && y->h > 0 && y->w > 0, NPP_E_SHAPE, "npp_bilinear_fwd: shape mismatch");
+  const bool vk = vec_ok(x) && vec_ok(y);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(NPP_FAM_BILINEAR, x->dtype, s, 0, (double)(npix(x) + npix(y)) * x->c * esize(x->dtype));
+  NPP_DISPATCH_TV(x->dtype, vk, {
+    const int cv = (int)(x->c / V);
+    hipLaunchKernelGGL((bilinear_fwd_kernel<T, V>), dim3(grid_for(npix(y) * cv)), dim3(256), 0, s, (const T*)x->ptr,
+                       (long)x->ld, (T*)y->ptr, (long)y->ld, (int)x->n, (int)x->h, (int)x->w, (int)y->h, (int)y->w, cv,
+                       ac_scale(x->h, y->h), ac_scale(x->w, y->w));
+  });
+  return npp_check_launch("bilinear_fwd");
+}
+
+extern "C" int npp_bilinear_bwd(const NppTensor* dy, NppTensor* dx, void* stream) {
+  NPP_REQUIRE(dy && dx && dy->ptr && dx->ptr, NPP_E_NULL, "npp_bilinear_bwd: null pointer");
+  NPP_REQUIRE(dtype_ok(dy) && dx->dtype == dy->dtype, NPP_E_DTYPE, "npp_bilinear_bwd: dtype mismatch");
+  NPP_REQUIRE(dx->n == dy->n && dx->c == dy->c, NPP_E_SHAPE, "npp_bilinear_bwd: shape mismatch");
+  const bool vk = vec_ok(dy) && vec_ok(dx);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(NPP_FAM_BILINEAR, dy->dtype, s, 0, (double)(npix(dx) + npix(dy)) * dx->c * esize(dx->dtype));
+  NPP_DISPATCH_TV(dy->dtype, vk, {
+    const int cv = (int)(dx->c / V);
+    hipLaunchKernelGGL((bilinear_bwd_kernel<T, V>), dim3(grid_for(npix(dx) * cv)), dim3(256), 0, s, (const T*)dy->ptr,
+                       (long)dy->ld, (T*)dx->ptr, (long)dx->ld, (int)dx->n, (int)dx->h, (int)dx->w, (int)dy->h, (int)dy->w,
+                       cv, ac_scale(dx->h, dy->h), ac_scale(dx->w, dy->w));
+  });
+  return npp_check_launch("bilinear_bwd");
+}

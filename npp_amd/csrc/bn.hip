@@ -1,0 +1,362 @@
+// BatchNorm (training statistics, apply, backward) and the fused per-pixel affine/add/ReLU kernel.
+// All HBM-bound: 16-byte channel vectors per lane over NHWC, per-channel reductions kept in f64
+// registers -> LDS -> one f64 atomic per (block, channel).
+//
+// Replaces nn.BatchNorm2d forward/backward (operations.py:61,78,153,216,241; model_augment.py:246-395)
+// and the `h1 + h2` / `s1 + z1` adds (model_augment.py:58,100,443-444).
+#include "vecio.h"
+
+namespace {
+
+struct ColMap {  // column-persistent thread mapping: thread -> (channel vector, pixel row lane)
+  int cv, cols_blk, rows;
+};
+static inline ColMap col_map(long c, int v) {
+  ColMap m;
+  m.cv = (int)(c / v);
+  m.cols_blk = m.cv < 256 ? m.cv : 256;
+  m.rows = 256 / m.cols_blk;
+  return m;
+}
+static inline dim3 col_grid(const ColMap& m, long npix) {
+  long bx = (npix + m.rows - 1) / m.rows;
+  // enough blocks to fill the chip, few enough that the f64 atomics stay negligible
+  const long cap = 1024;
+  if (bx > cap) bx = cap;
+  if (bx < 1) bx = 1;
+  return dim3((unsigned)bx, (unsigned)((m.cv + m.cols_blk - 1) / m.cols_blk));
+}
+
+template <int NQ, int V>
+NPP_DEV void block_col_reduce(double (&acc)[NQ][V], float* red /*[256][NQ*V] doubles as 2 floats*/, int t, int col,
+                              int row, int rows, int cols_blk, bool active, double* const* outs, int colg, int C) {
+  double* dred = reinterpret_cast<double*>(red);
+  if (active) {
+#pragma unroll
+    for (int qn = 0; qn < NQ; ++qn)
+#pragma unroll
+      for (int j = 0; j < V; ++j) dred[(long)t * NQ * V + qn * V + j] = acc[qn][j];
+  }
+  __syncthreads();
+  if (active && row == 0) {
+#pragma unroll
+    for (int qn = 0; qn < NQ; ++qn)
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        double s = 0.0;
+        for (int rr = 0; rr < rows; ++rr) s += dred[(long)(rr * cols_blk + col) * NQ * V + qn * V + j];
+        const int ch = colg * V + j;
+        if (ch < C) atomicAdd(outs[qn] + ch, s);
+      }
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, long ld, long npix, int C, ColMap m,
+                                                            double* stats, int want_sq) {
+  __shared__ __attribute__((aligned(16))) float red[256 * 2 * V * 2];
+  const int t = threadIdx.x;
+  const bool active = t < m.rows * m.cols_blk;
+  const int col = t % m.cols_blk, row = t / m.cols_blk;
+  const int colg = blockIdx.y * m.cols_blk + col;
+  double acc[2][V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { acc[0][j] = 0.0; acc[1][j] = 0.0; }
+  const bool work = active && colg < m.cv;
+  if (work) {
+    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += (long)gridDim.x * m.rows) {
+      float v[V];
+      ldv<T, V>(x + p * ld + (long)colg * V, v);
+#pragma unroll
+      for (int j = 0; j < V; ++j) { acc[0][j] += v[j]; acc[1][j] += (double)v[j] * v[j]; }
+    }
+  }
+  double* outs[2] = {stats, stats + C};
+  if (want_sq) block_col_reduce<2, V>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
+  else {
+    double a1[1][V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) a1[0][j] = acc[0][j];
+    block_col_reduce<1, V>(a1, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, long* nbt, float momentum, float eps,
+                                   float* ss, float* mi, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  const double mean = stats[c] / count;
+  double var = stats[C + c] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float scale = (float)(g * invstd);
+  ss[c] = scale;
+  ss[C + c] = (float)(b - mean * g * invstd);
+  if (mi) { mi[c] = (float)mean; mi[C + c] = (float)invstd; }
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* ss, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rv[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  ss[c] = g * invstd;
+  ss[C + c] = b - rm[c] * g * invstd;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void affine_add_kernel(T* __restrict__ out, long ldo, const T* __restrict__ a, long lda,
+                                                         const float* __restrict__ ssa, const T* __restrict__ b, long ldb,
+                                                         const float* __restrict__ ssb, int relu, long npix, int C, int cv) {
+  const long total = npix * cv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / cv;
+    const int c0 = (int)(i - p * cv) * V;
+    float va[V], o[V];
+    ldv<T, V>(a + p * lda + c0, va);
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = ssa ? va[j] * ssa[c0 + j] + ssa[C + c0 + j] : va[j];
+    if (b) {
+      float vb[V];
+      ldv<T, V>(b + p * ldb + c0, vb);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] += ssb ? vb[j] * ssb[c0 + j] + ssb[C + c0 + j] : vb[j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = fmaxf(o[j], 0.f);
+    }
+    stv<T, V>(out + p * ldo + c0, o);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
+                                                            long ldy, const T* __restrict__ ro, long ldr,
+                                                            const float* __restrict__ mi, long npix, int C, ColMap m,
+                                                            double* sums) {
+  __shared__ __attribute__((aligned(16))) float red[256 * 2 * V * 2];
+  const int t = threadIdx.x;
+  const bool active = t < m.rows * m.cols_blk;
+  const int col = t % m.cols_blk, row = t / m.cols_blk;
+  const int colg = blockIdx.y * m.cols_blk + col;
+  const bool work = active && colg < m.cv;
+  double acc[2][V];
+  float mean[V], invstd[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    acc[0][j] = 0.0; acc[1][j] = 0.0;
+    const int ch = colg * V + j;
+    mean[j] = (work && ch < C) ? mi[ch] : 0.f;
+    invstd[j] = (work && ch < C) ? mi[C + ch] : 0.f;
+  }
+  if (work) {
+    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += (long)gridDim.x * m.rows) {
+      float d[V], v[V];
+      ldv<T, V>(dout + p * ldd + (long)colg * V, d);
+      ldv<T, V>(y + p * ldy + (long)colg * V, v);
+      if (ro) {
+        float o[V];
+        ldv<T, V>(ro + p * ldr + (long)colg * V, o);
+#pragma unroll
+        for (int j = 0; j < V; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        acc[0][j] += d[j];
+        acc[1][j] += (double)d[j] * ((v[j] - mean[j]) * invstd[j]);
+      }
+    }
+  }
+  double* outs[2] = {sums, sums + C};
+  block_col_reduce<2, V>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
+                                                           long ldy, const T* __restrict__ ro, long ldr,
+                                                           const float* __restrict__ mi, const float* __restrict__ gamma,
+                                                           const double* __restrict__ sums, double inv_count,
+                                                           T* __restrict__ dy, long ldo, float* dgamma, float* dbeta,
+                                                           long npix, int C, int cv) {
+  const long total = npix * cv;
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      if (dgamma) dgamma[c] = (float)sums[C + c];
+      if (dbeta) dbeta[c] = (float)sums[c];
+    }
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / cv;
+    const int c0 = (int)(i - p * cv) * V;
+    float d[V], v[V], o[V];
+    ldv<T, V>(dout + p * ldd + c0, d);
+    ldv<T, V>(y + p * ldy + c0, v);
+    if (ro) {
+      float r[V];
+      ldv<T, V>(ro + p * ldr + c0, r);
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] = r[j] > 0.f ? d[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int ch = c0 + j;
+      const float mean = mi[ch], invstd = mi[C + ch];
+      const float g = gamma ? gamma[ch] : 1.f;
+      const float m0 = (float)(sums[ch] * inv_count), m1 = (float)(sums[C + ch] * inv_count);
+      const float xh = (v[j] - mean) * invstd;
+      o[j] = g * invstd * (d[j] - m0 - xh * m1);
+    }
+    stv<T, V>(dy + p * ldo + c0, o);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void scale_mask_kernel(const T* __restrict__ dout, long ldd, const float* __restrict__ scale,
+                                                         const T* __restrict__ ro, long ldr, T* __restrict__ dx, long ldo,
+                                                         long npix, int cv) {
+  const long total = npix * cv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / cv;
+    const int c0 = (int)(i - p * cv) * V;
+    float d[V];
+    ldv<T, V>(dout + p * ldd + c0, d);
+    if (scale) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] *= scale[c0 + j];
+    }
+    if (ro) {
+      float r[V];
+      ldv<T, V>(ro + p * ldr + c0, r);
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] = r[j] > 0.f ? d[j] : 0.f;
+    }
+    stv<T, V>(dx + p * ldo + c0, d);
+  }
+}
+
+}  // namespace
+
+extern "C" int npp_channel_stats(const NppTensor* x, double* stats, void* stream) {
+  NPP_REQUIRE(x && x->ptr && stats, NPP_E_NULL, "npp_channel_stats: null pointer");
+  NPP_REQUIRE(dtype_ok(x), NPP_E_DTYPE, "npp_channel_stats: bad dtype");
+  const bool vk = vec_ok(x);
+  ProfScope prof(NPP_FAM_BN, x->dtype, (hipStream_t)stream, 0, (double)npix(x) * x->c * esize(x->dtype));
+  NPP_DISPATCH_TV(x->dtype, vk, {
+    ColMap m = col_map(x->c, V);
+    hipLaunchKernelGGL((channel_stats_kernel<T, V>), col_grid(m, npix(x)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x->ptr, (long)x->ld, (long)npix(x), (int)x->c, m, stats, 1);
+  });
+  return npp_check_launch("channel_stats");
+}
+
+extern "C" int npp_channel_sum(const NppTensor* x, double* out, void* stream) {
+  NPP_REQUIRE(x && x->ptr && out, NPP_E_NULL, "npp_channel_sum: null pointer");
+  NPP_REQUIRE(dtype_ok(x), NPP_E_DTYPE, "npp_channel_sum: bad dtype");
+  const bool vk = vec_ok(x);
+  NPP_DISPATCH_TV(x->dtype, vk, {
+    ColMap m = col_map(x->c, V);
+    hipLaunchKernelGGL((channel_stats_kernel<T, V>), col_grid(m, npix(x)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x->ptr, (long)x->ld, (long)npix(x), (int)x->c, m, out, 0);
+  });
+  return npp_check_launch("channel_sum");
+}
+
+extern "C" int npp_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                               float eps, float* scale_shift, float* mean_invstd, int c, void* stream) {
+  NPP_REQUIRE(stats && scale_shift && c > 0 && count > 0, NPP_E_NULL, "npp_bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, count, gamma,
+                     beta, running_mean, running_var, (long*)num_batches_tracked, momentum, eps, scale_shift, mean_invstd, c);
+  return npp_check_launch("bn_finalize");
+}
+
+extern "C" int npp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale_shift, int c, void* stream) {
+  NPP_REQUIRE(running_mean && running_var && scale_shift && c > 0, NPP_E_NULL, "npp_bn_eval_coeffs: bad arguments");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, scale_shift, c);
+  return npp_check_launch("bn_eval_coeffs");
+}
+
+extern "C" int npp_affine_add(NppTensor* out, const NppTensor* a, const float* ss_a, const NppTensor* b,
+                              const float* ss_b, int relu, void* stream) {
+  NPP_REQUIRE(out && a && out->ptr && a->ptr, NPP_E_NULL, "npp_affine_add: null pointer");
+  NPP_REQUIRE(same_shape(out, a) && (!b || same_shape(out, b)), NPP_E_SHAPE, "npp_affine_add: shape mismatch");
+  NPP_REQUIRE(dtype_ok(out) && out->dtype == a->dtype && (!b || b->dtype == a->dtype), NPP_E_DTYPE,
+              "npp_affine_add: dtype mismatch");
+  const bool vk = vec_ok(out) && vec_ok(a) && (!b || vec_ok(b));
+  const int nt = b ? 3 : 2;
+  ProfScope prof(NPP_FAM_ELTWISE, out->dtype, (hipStream_t)stream, 0, (double)npix(out) * out->c * esize(out->dtype) * nt);
+  NPP_DISPATCH_TV(out->dtype, vk, {
+    const int cv = (int)(out->c / V);
+    hipLaunchKernelGGL((affine_add_kernel<T, V>), dim3(grid_for(npix(out) * cv)), dim3(256), 0, (hipStream_t)stream,
+                       (T*)out->ptr, (long)out->ld, (const T*)a->ptr, (long)a->ld, ss_a, b ? (const T*)b->ptr : nullptr,
+                       b ? (long)b->ld : 0L, ss_b, relu, (long)npix(out), (int)out->c, cv);
+  });
+  return npp_check_launch("affine_add");
+}
+
+extern "C" int npp_bn_bwd_reduce(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,
+                                 const float* mean_invstd, double* sums, void* stream) {
+  NPP_REQUIRE(dout && y_raw && mean_invstd && sums, NPP_E_NULL, "npp_bn_bwd_reduce: null pointer");
+  NPP_REQUIRE(same_shape(dout, y_raw) && (!relu_out || same_shape(dout, relu_out)), NPP_E_SHAPE,
+              "npp_bn_bwd_reduce: shape mismatch");
+  NPP_REQUIRE(dtype_ok(dout) && dout->dtype == y_raw->dtype && (!relu_out || relu_out->dtype == dout->dtype), NPP_E_DTYPE,
+              "npp_bn_bwd_reduce: dtype mismatch");
+  const bool vk = vec_ok(dout) && vec_ok(y_raw) && (!relu_out || vec_ok(relu_out));
+  ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 2);
+  NPP_DISPATCH_TV(dout->dtype, vk, {
+    ColMap m = col_map(dout->c, V);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, V>), col_grid(m, npix(dout)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
+                       relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, mean_invstd,
+                       (long)npix(dout), (int)dout->c, m, sums);
+  });
+  return npp_check_launch("bn_bwd_reduce");
+}
+
+extern "C" int npp_bn_bwd_apply(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,
+                                const float* mean_invstd, const float* gamma, const double* sums, double count,
+                                NppTensor* dy_raw, float* dgamma, float* dbeta, void* stream) {
+  NPP_REQUIRE(dout && y_raw && mean_invstd && sums && dy_raw, NPP_E_NULL, "npp_bn_bwd_apply: null pointer");
+  NPP_REQUIRE(same_shape(dout, y_raw) && same_shape(dout, dy_raw) && (!relu_out || same_shape(dout, relu_out)), NPP_E_SHAPE,
+              "npp_bn_bwd_apply: shape mismatch");
+  NPP_REQUIRE(dtype_ok(dout) && dout->dtype == y_raw->dtype && dout->dtype == dy_raw->dtype, NPP_E_DTYPE,
+              "npp_bn_bwd_apply: dtype mismatch");
+  const bool vk = vec_ok(dout) && vec_ok(y_raw) && vec_ok(dy_raw) && (!relu_out || vec_ok(relu_out));
+  ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 3);
+  NPP_DISPATCH_TV(dout->dtype, vk, {
+    const int cv = (int)(dout->c / V);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(grid_for(npix(dout) * cv)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
+                       relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, mean_invstd, gamma,
+                       sums, 1.0 / count, (T*)dy_raw->ptr, (long)dy_raw->ld, dgamma, dbeta, (long)npix(dout), (int)dout->c, cv);
+  });
+  return npp_check_launch("bn_bwd_apply");
+}
+
+extern "C" int npp_scale_mask(const NppTensor* dout, const float* scale, const NppTensor* relu_out, NppTensor* dx,
+                              void* stream) {
+  NPP_REQUIRE(dout && dx && dout->ptr && dx->ptr, NPP_E_NULL, "npp_scale_mask: null pointer");
+  NPP_REQUIRE(same_shape(dout, dx) && (!relu_out || same_shape(dout, relu_out)), NPP_E_SHAPE, "npp_scale_mask: shape mismatch");
+  NPP_REQUIRE(dtype_ok(dout) && dout->dtype == dx->dtype && (!relu_out || relu_out->dtype == dout->dtype), NPP_E_DTYPE,
+              "npp_scale_mask: dtype mismatch");
+  const bool vk = vec_ok(dout) && vec_ok(dx) && (!relu_out || vec_ok(relu_out));
+  NPP_DISPATCH_TV(dout->dtype, vk, {
+    const int cv = (int)(dout->c / V);
+    hipLaunchKernelGGL((scale_mask_kernel<T, V>), dim3(grid_for(npix(dout) * cv)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)dout->ptr, (long)dout->ld, scale, relu_out ? (const T*)relu_out->ptr : nullptr,
+                       relu_out ? (long)relu_out->ld : 0L, (T*)dx->ptr, (long)dx->ld, (long)npix(dout), cv);
+  });
+  return npp_check_launch("scale_mask");
+}

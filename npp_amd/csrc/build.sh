@@ -1,0 +1,21 @@
+#!/bin/bash
+# Build libnpp_hip.so for gfx950 (cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+OUT=../libnpp_hip.so
+SRCS="api.hip conv_igemm.hip conv_wgrad.hip dwconv.hip bn.hip pool.hip bilinear.hip misc.hip loss.hip"
+OBJS=""
+mkdir -p build
+pids=()
+for s in $SRCS; do
+  [ -f "$s" ] || continue
+  o=build/${s%.hip}.o
+  OBJS="$OBJS $o"
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/npp_hip.h -nt "$o" ]; then
+    hipcc --offload-arch=gfx950 -O3 -fPIC -munsafe-fp-atomics -std=c++17 -Wno-unused-result -c "$s" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
+echo "built $OUT"

@@ -1,0 +1,106 @@
+// Shared device/host helpers for libnpp_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/npp_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define NPP_DEV __device__ __forceinline__
+
+// ---- bf16 <-> f32 (round-to-nearest-even via the hardware convert) ---------------------------
+NPP_DEV float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+NPP_DEV bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32, NaN-preserving (MI355X_MICROARCH.md, correctness table)
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+template <typename T> struct Elt;
+template <> struct Elt<float> {
+  static constexpr int VEC = 4;  // elements per 16 bytes
+  static NPP_DEV float ld(const float* p) { return *p; }
+  static NPP_DEV void st(float* p, float v) { *p = v; }
+  static NPP_DEV float round(float v) { return v; }
+};
+template <> struct Elt<bf16_t> {
+  static constexpr int VEC = 8;
+  static NPP_DEV float ld(const bf16_t* p) { return bf2f(*p); }
+  static NPP_DEV void st(bf16_t* p, float v) { *p = f2bf(v); }
+  static NPP_DEV float round(float v) { return bf2f(f2bf(v)); }
+};
+
+// 16-byte vector of T unpacked to floats and back
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  static NPP_DEV void load(const float* p, float* o) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
+  static NPP_DEV void store(float* p, const float* o) {
+    f32x4 v = {o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(p) = v;
+  }
+};
+template <> struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  static NPP_DEV void load(const bf16_t* p, float* o) {
+    u32x4 v = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(v[i] << 16);
+      o[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+    }
+  }
+  static NPP_DEV void store(bf16_t* p, const float* o) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (unsigned)f2bf(o[2 * i]) | ((unsigned)f2bf(o[2 * i + 1]) << 16);
+    *reinterpret_cast<u32x4*>(p) = v;
+  }
+};
+
+NPP_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+NPP_DEV double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+void npp_set_error(const char* fmt, ...);
+int npp_check_launch(const char* what);
+
+struct ProfScope {  // HIP events around one launch when the family is being profiled
+  ProfScope(int family, int dtype, hipStream_t s, double flops, double bytes);
+  ~ProfScope();
+  int slot;
+  hipStream_t stream;
+};
+
+static inline bool vec_ok(const NppTensor* t) {
+  const int v = t->dtype == NPP_BF16 ? 8 : 4;
+  return (t->c % v == 0) && (t->ld % v == 0) && ((reinterpret_cast<uintptr_t>(t->ptr) & 15) == 0);
+}
+static inline int64_t npix(const NppTensor* t) { return t->n * t->h * t->w; }
+static inline int esize(int dtype) { return dtype == NPP_BF16 ? 2 : 4; }
+
+#define NPP_REQUIRE(cond, code, ...)        \
+  do {                                      \
+    if (!(cond)) {                          \
+      npp_set_error(__VA_ARGS__);           \
+      return code;                          \
+    }                                       \
+  } while (0)

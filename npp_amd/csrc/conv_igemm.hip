@@ -1,0 +1,384 @@
+// Dense convolution forward / data-gradient as an implicit GEMM on the gfx950 matrix cores.
+//
+//   out[m][n] = sum_k A[m][k] * Wp[n][k]        m = output pixel (n,oh,ow), n = output channel,
+//                                               k = tap*Cp + c  (tap = kh*KW + kw)
+//
+// A is never materialised: every 16-byte piece of an A tile row is gathered straight from the NHWC
+// input (one tap, VEC consecutive channels), ReLU'd in registers (pre-activation ops,
+// operations.py:76) and written to LDS.  Both MFMA operands are then read from LDS as one
+// 16-byte fragment per lane ([row][k] images, pitch 144 B: conflict-free ds_read_b128), so the f32
+// build (v_mfma_f32_32x32x2_f32 x4 per fragment, exact f32 = the parity mode) and the bf16 build
+// (v_mfma_f32_32x32x16_bf16) share everything but the MFMA call.
+//
+// Tile: 128 pixels x BN channels (BN = 128/64/32 by Cout) x 128 bytes of K per stage, 4 waves,
+// double-buffered LDS with the next stage's global loads in flight during the MFMAs.
+// Epilogue: accumulators -> LDS -> 16-byte rows: + bias, * ReLU-mask (when this launch is a dgrad),
+// round to the storage type, per-channel sum / sum-of-squares of what was stored (BatchNorm batch
+// statistics, added to global memory with f64 atomics), coalesced store into a channel slice (ld).
+//
+// Replaces nn.Conv2d fwd/bwd-data at operations.py:77,149-150,182-183,215,240 and
+// model_augment.py:244-272,332-351,371-397,594,644.
+#include "common.h"
+
+namespace {
+
+struct IgemmParams {
+  const void* x; const void* w; const float* bias; const void* mask; void* y; double* stats;
+  int N, H, W, Cin; long ldx;
+  int OH, OW, Cout; long ldy; long ldm;
+  int Cp, Kpad;
+  int KH, KW, sh, sw, ph, pw, dh, dw, uph, upw, relu_in;
+  int M, mtiles, ntiles;
+  int vec_io;
+};
+
+constexpr int BM = 128;
+constexpr int BKB = 128;          // bytes of K per stage
+constexpr int PITCH = BKB + 16;   // LDS row pitch (bytes)
+
+template <typename T> NPP_DEV u32x4 relu16(u32x4 v);
+template <> NPP_DEV u32x4 relu16<float>(u32x4 v) {
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = __float_as_uint(fmaxf(__uint_as_float(v[i]), 0.f));
+  return o;
+}
+template <> NPP_DEV u32x4 relu16<bf16_t>(u32x4 v) {
+  // a negative bf16 is a negative int16: one v_pk_max_i16 per dword
+  s16x8 s = __builtin_bit_cast(s16x8, v);
+  s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  s = __builtin_elementwise_max(s, z);
+  return __builtin_bit_cast(u32x4, s);
+}
+
+template <typename T> NPP_DEV void mma_frag(f32x16& acc, u32x4 a, u32x4 b);
+template <> NPP_DEV void mma_frag<bf16_t>(f32x16& acc, u32x4 a, u32x4 b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> NPP_DEV void mma_frag<float>(f32x16& acc, u32x4 a, u32x4 b) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int BK = BKB / (int)sizeof(T);
+  constexpr int WN = (BN == 128) ? 64 : 32;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int WAVES_M = 4 / WAVES_N;
+  constexpr int WM = BM / WAVES_M;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int BROWS = BN / 32;                 // B rows per thread
+  constexpr int STAGE = (BM + BN) * PITCH;       // bytes per LDS stage
+  constexpr int CP = BN + 4;                     // epilogue C-tile pitch (floats)
+  constexpr int SMEM = (2 * STAGE > BM * CP * 4 ? 2 * STAGE : BM * CP * 4) + 256 * 8 * 2 * 4 * 0;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+  const int t = threadIdx.x;
+  // XCD-aware remap (cdna_hip_programming.md T1, bijective form): blocks that share an XCD get a
+  // contiguous range of logical tiles, N-tile fastest, so the tiles re-reading one A panel hit one L2.
+  const int nwg = gridDim.x;
+  int lid;
+  {
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int ntile = lid % p.ntiles, mtile = lid / p.ntiles;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+
+  const int piece = t & 7, row0 = t >> 3;
+  // per-row gather bases (4 A rows per thread)
+  int ih0[4], iw0[4], pixb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + row0 + 32 * i;
+    if (m < p.M) {
+      const int ow = m % p.OW;
+      const int t2 = m / p.OW;
+      const int oh = t2 % p.OH;
+      const int n = t2 / p.OH;
+      ih0[i] = oh * p.sh - p.ph;
+      iw0[i] = ow * p.sw - p.pw;
+      pixb[i] = n * p.H * p.W;
+    } else {
+      ih0[i] = -(1 << 28);
+      iw0[i] = 0;
+      pixb[i] = 0;
+    }
+  }
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  const int taps = p.KH * p.KW;
+  // this thread's K position: element kk = chunk*BK + piece*VEC -> (tap, c)
+  int kk = piece * VEC;
+  int tap = kk / p.Cp;
+  int c = kk - tap * p.Cp;
+
+  u32x4 ra[4], rb[BROWS];
+  const int nchunks = p.Kpad / BK;
+
+  auto load_stage = [&](int chunk) {
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const bool tap_ok = tap < taps;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int ih = ih0[i] + kh * p.dh, iw = iw0[i] + kw * p.dw;
+      bool ok = tap_ok && ih >= 0 && iw >= 0;
+      if (p.uph > 1) { ok = ok && (ih % p.uph == 0); ih /= p.uph; }
+      if (p.upw > 1) { ok = ok && (iw % p.upw == 0); iw /= p.upw; }
+      ok = ok && ih < p.H && iw < p.W;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) {
+        const long off = (long)(pixb[i] + ih * p.W + iw) * p.ldx + c;
+        v = *reinterpret_cast<const u32x4*>(xg + off);
+        if (p.relu_in) v = relu16<T>(v);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+      const long off = (long)(n0 + row0 + 32 * i) * p.Kpad + (long)chunk * BK + piece * VEC;
+      rb[i] = *reinterpret_cast<const u32x4*>(wg + off);
+    }
+    // advance (tap, c) to the next chunk
+    c += BK;
+    while (c >= p.Cp) { c -= p.Cp; ++tap; }
+  };
+  auto store_stage = [&](int buf) {
+    unsigned char* sA = smem + buf * STAGE;
+    unsigned char* sB = sA + BM * PITCH;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sA + (row0 + 32 * i) * PITCH + piece * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) *reinterpret_cast<u32x4*>(sB + (row0 + 32 * i) * PITCH + piece * 16) = rb[i];
+  };
+
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int r = lane & 31, h = lane >> 5;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int cur = ch & 1;
+    if (ch + 1 < nchunks) load_stage(ch + 1);
+    const unsigned char* sA = smem + cur * STAGE + (wm * WM + r) * PITCH + h * 16;
+    const unsigned char* sB = smem + cur * STAGE + BM * PITCH + (wn * WN + r) * PITCH + h * 16;
+#pragma unroll
+    for (int s = 0; s < BKB / 32; ++s) {
+      u32x4 fa[MI], fb[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fa[mi] = *reinterpret_cast<const u32x4*>(sA + mi * 32 * PITCH + s * 32);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(sB + ni * 32 * PITCH + s * 32);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mma_frag<T>(acc[mi][ni], fa[mi], fb[ni]);
+    }
+    if (ch + 1 < nchunks) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS C tile (f32) ------------------------------------------------
+  float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int col = wn * WN + ni * 32 + r;
+        sC[row * CP + col] = acc[mi][ni][e];
+      }
+  __syncthreads();
+
+  constexpr int PCOLS = BN / VEC;          // 16-byte pieces per output row
+  constexpr int RSTEP = 256 / PCOLS;       // rows covered per pass
+  const int pc = t % PCOLS, pr = t / PCOLS;
+  const int nbase = n0 + pc * VEC;
+  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+  const T* __restrict__ mg = reinterpret_cast<const T*>(p.mask);
+  float bsum[VEC], bsq[VEC], bias[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    bsum[j] = 0.f; bsq[j] = 0.f;
+    bias[j] = (p.bias && nbase + j < p.Cout) ? p.bias[nbase + j] : 0.f;
+  }
+  const bool full_vec = p.vec_io && (nbase + VEC <= p.Cout);
+  for (int row = pr; row < BM; row += RSTEP) {
+    const int m = m0 + row;
+    if (m >= p.M) break;
+    if (nbase >= p.Cout) break;
+    float v[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = sC[row * CP + pc * VEC + j] + bias[j];
+    if (full_vec) {
+      if (mg) {
+        float mk[VEC];
+        Vec16<T>::load(mg + (long)m * p.ldm + nbase, mk);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = mk[j] > 0.f ? v[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        v[j] = Elt<T>::round(v[j]);
+        bsum[j] += v[j];
+        bsq[j] += v[j] * v[j];
+      }
+      Vec16<T>::store(yg + (long)m * p.ldy + nbase, v);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (nbase + j < p.Cout) {
+          if (mg && !(Elt<T>::ld(mg + (long)m * p.ldm + nbase + j) > 0.f)) v[j] = 0.f;
+          v[j] = Elt<T>::round(v[j]);
+          bsum[j] += v[j];
+          bsq[j] += v[j] * v[j];
+          Elt<T>::st(yg + (long)m * p.ldy + nbase + j, v[j]);
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();  // C tile consumed; reuse LDS for the cross-thread reduction
+    float* red = reinterpret_cast<float*>(smem);  // [256][VEC][2]
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      red[(t * VEC + j) * 2 + 0] = bsum[j];
+      red[(t * VEC + j) * 2 + 1] = bsq[j];
+    }
+    __syncthreads();
+    if (t < BN) {
+      const int col = t, cpc = col / VEC, j = col % VEC;
+      float s = 0.f, q = 0.f;
+      for (int rr = 0; rr < RSTEP; ++rr) {
+        const int tt = rr * PCOLS + cpc;
+        s += red[(tt * VEC + j) * 2 + 0];
+        q += red[(tt * VEC + j) * 2 + 1];
+      }
+      if (n0 + col < p.Cout) {
+        atomicAdd(p.stats + n0 + col, (double)s);
+        atomicAdd(p.stats + p.Cout + n0 + col, (double)q);
+      }
+    }
+  }
+}
+
+// ---- weight packing: f32 OIHW -> [rows_pad][Kpad] (k contiguous), zero padded -------------------
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin,
+                                   int kh, int kw, int for_dgrad, int cp, int kpad, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int row = (int)(i / kpad), k = (int)(i % kpad);
+  const int taps = kh * kw;
+  const int tap = k / cp, c = k % cp;
+  float v = 0.f;
+  if (tap < taps) {
+    if (!for_dgrad) {
+      if (row < cout && c < cin) v = w[((long)row * cin + c) * taps + tap];
+    } else {
+      // rows = cin, reduction over (flipped tap, cout)
+      if (row < cin && c < cout) v = w[((long)c * cin + row) * taps + (taps - 1 - tap)];
+    }
+  }
+  Elt<T>::st(out + i, v);
+}
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+extern "C" int64_t npp_packed_weight_elems(int cout, int cin, int kh, int kw, int for_dgrad) {
+  const int rows = for_dgrad ? cin : cout, red = for_dgrad ? cout : cin;
+  const int cp = round_up(red, 8);
+  const int kpad = round_up(kh * kw * cp, 64);
+  return (int64_t)round_up(rows, 32) * kpad;
+}
+
+extern "C" int npp_pack_weight(const float* w, int cout, int cin, int kh, int kw, int for_dgrad, int dtype,
+                               void* out, void* stream) {
+  NPP_REQUIRE(w && out, NPP_E_NULL, "npp_pack_weight: null pointer");
+  const int rows = for_dgrad ? cin : cout, red = for_dgrad ? cout : cin;
+  const int cp = round_up(red, 8);
+  const int kpad = round_up(kh * kw * cp, 64);
+  const long total = (long)round_up(rows, 32) * kpad;
+  const int blocks = (int)((total + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == NPP_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, (bf16_t*)out, cout, cin, kh, kw,
+                       for_dgrad, cp, kpad, total);
+  else if (dtype == NPP_F32)
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, w, (float*)out, cout, cin, kh, kw,
+                       for_dgrad, cp, kpad, total);
+  else
+    NPP_REQUIRE(false, NPP_E_DTYPE, "npp_pack_weight: bad dtype %d", dtype);
+  return npp_check_launch("pack_weight");
+}
+
+extern "C" int npp_conv_fwd(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask,
+                            NppTensor* y, double* stats, const NppConvGeom* g, void* stream) {
+  NPP_REQUIRE(x && w_packed && y && g && x->ptr && y->ptr, NPP_E_NULL, "npp_conv_fwd: null pointer");
+  NPP_REQUIRE(x->dtype == y->dtype && (!mask || mask->dtype == y->dtype), NPP_E_DTYPE,
+              "npp_conv_fwd: x/y/mask dtypes must match (%d,%d)", x->dtype, y->dtype);
+  NPP_REQUIRE(x->dtype == NPP_F32 || x->dtype == NPP_BF16, NPP_E_DTYPE, "npp_conv_fwd: bad dtype");
+  const int vec = x->dtype == NPP_BF16 ? 8 : 4;
+  const int cp = round_up((int)x->c, 8);
+  NPP_REQUIRE(x->ld >= cp && x->ld % vec == 0 && ((uintptr_t)x->ptr & 15) == 0, NPP_E_ALIGN,
+              "npp_conv_fwd: input needs ld >= round_up(C,8) (C=%ld ld=%ld) and 16-byte aligned rows", (long)x->c,
+              (long)x->ld);
+  NPP_REQUIRE(g->uph >= 1 && g->upw >= 1 && g->sh >= 1 && g->sw >= 1 && g->dh >= 1 && g->dw >= 1, NPP_E_SHAPE, "npp_conv_fwd: bad geometry");
+  // output extent: the last output's last tap must stay inside the (padded) input
+  if (g->uph == 1 && g->upw == 1) {
+    const long lh = (y->h - 1) * g->sh - g->ph + (long)g->dh * (g->kh - 1);
+    const long lw = (y->w - 1) * g->sw - g->pw + (long)g->dw * (g->kw - 1);
+    NPP_REQUIRE(y->h >= 1 && y->w >= 1 && lh <= x->h - 1 + (g->ph > 0 ? g->ph : 0) && lw <= x->w - 1 + (g->pw > 0 ? g->pw : 0),
+                NPP_E_SHAPE, "npp_conv_fwd: output %ldx%ld does not fit input %ldx%ld with this geometry", (long)y->h,
+                (long)y->w, (long)x->h, (long)x->w);
+  }
+  NPP_REQUIRE(x->n == y->n && y->ld >= y->c, NPP_E_SHAPE, "npp_conv_fwd: batch/ld mismatch");
+  if (mask) NPP_REQUIRE(mask->n == y->n && mask->h == y->h && mask->w == y->w && mask->c == y->c, NPP_E_SHAPE,
+                        "npp_conv_fwd: mask shape mismatch");
+  IgemmParams p;
+  p.x = x->ptr; p.w = w_packed; p.bias = bias; p.mask = mask ? mask->ptr : nullptr; p.y = y->ptr; p.stats = stats;
+  p.N = (int)x->n; p.H = (int)x->h; p.W = (int)x->w; p.Cin = (int)x->c; p.ldx = x->ld;
+  p.OH = (int)y->h; p.OW = (int)y->w; p.Cout = (int)y->c; p.ldy = y->ld; p.ldm = mask ? mask->ld : 0;
+  p.Cp = cp; p.Kpad = round_up(g->kh * g->kw * cp, 64);
+  p.KH = g->kh; p.KW = g->kw; p.sh = g->sh; p.sw = g->sw; p.ph = g->ph; p.pw = g->pw; p.dh = g->dh; p.dw = g->dw;
+  p.uph = g->uph; p.upw = g->upw; p.relu_in = g->relu_in;
+  const long M = (long)y->n * y->h * y->w;
+  NPP_REQUIRE(M > 0 && M < (1L << 30) && (long)x->n * x->h * x->w < (1L << 30), NPP_E_SHAPE, "npp_conv_fwd: too many pixels");
+  p.M = (int)M;
+  p.vec_io = (y->ld % vec == 0) && (((uintptr_t)y->ptr & 15) == 0) &&
+             (!mask || ((mask->ld % vec == 0) && (((uintptr_t)mask->ptr & 15) == 0)));
+  const int npad = round_up(p.Cout, 32);
+  const int bn = (npad % 128 == 0) ? 128 : (npad % 64 == 0 ? 64 : 32);
+  p.mtiles = (p.M + BM - 1) / BM;
+  p.ntiles = npad / bn;
+  const int grid = p.mtiles * p.ntiles;
+  hipStream_t s = (hipStream_t)stream;
+  const double flops = 2.0 * (double)M * p.Cout * (double)(g->kh * g->kw) * p.Cin;
+  const double bytes = ((double)x->n * x->h * x->w * x->c + (double)M * y->c + (double)p.Cout * g->kh * g->kw * p.Cin) * esize(x->dtype);
+  ProfScope prof(NPP_FAM_CONV_IGEMM, x->dtype, s, flops, bytes);
+#define LAUNCH(T, BN_) hipLaunchKernelGGL((conv_igemm_kernel<T, BN_>), dim3(grid), dim3(256), 0, s, p)
+  if (x->dtype == NPP_BF16) {
+    if (bn == 128) LAUNCH(bf16_t, 128); else if (bn == 64) LAUNCH(bf16_t, 64); else LAUNCH(bf16_t, 32);
+  } else {
+    if (bn == 128) LAUNCH(float, 128); else if (bn == 64) LAUNCH(float, 64); else LAUNCH(float, 32);
+  }
+#undef LAUNCH
+  return npp_check_launch("conv_igemm");
+}

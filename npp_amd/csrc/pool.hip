@@ -1,0 +1,479 @@
+// Pooling and squeeze-excite kernels (HBM-bound NHWC stencils, 16-byte channel vectors per lane).
+//
+// pool3x3 : nn.MaxPool2d(3,s,1) / nn.AvgPool2d(3,s,1,count_include_pad=False)   operations.py:55-57
+// pool2x2 : nn.AvgPool2d(2) (operations.py:124,237), nn.MaxPool2d(2,2) (model_search_interact.py:43)
+// SE      : AdaptiveAvgPool2d(1) -> 1x1 conv -> ReLU -> 1x1 conv -> sigmoid -> x*w   operations.py:118-123
+// The forward kernels can add the per-channel sum / sum-of-squares of their output (the statistics of
+// the BatchNorm that follows, operations.py:61,129) so no extra pass over the tensor is needed.
+#include "vecio.h"
+
+namespace {
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pool3x3_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
+                                                          unsigned char* __restrict__ amax, int N, int H, int W, int OH,
+                                                          int OW, int C, int cv, int is_avg, int stride) {
+  const long total = (long)N * OH * OW * cv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / cv;
+    const int c0 = (int)(i - p * cv) * V;
+    const int ow = (int)(p % OW);
+    const long t2 = p / OW;
+    const int oh = (int)(t2 % OH), n = (int)(t2 / OH);
+    float acc[V];
+    int arg[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { acc[j] = is_avg ? 0.f : -INFINITY; arg[j] = 0; }
+    int cnt = 0;
+    bool first = true;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh * stride - 1 + kh;
+      if (ih < 0 || ih >= H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow * stride - 1 + kw;
+        if (iw < 0 || iw >= W) continue;
+        float v[V];
+        ldv<T, V>(x + ((long)(n * H + ih) * W + iw) * ldx + c0, v);
+        if (is_avg) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += v[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            // ATen max_pool2d: take the first maximum in scan order (val > max) or NaN
+            if (first || v[j] > acc[j] || v[j] != v[j]) { acc[j] = v[j]; arg[j] = kh * 3 + kw; }
+          }
+        }
+        first = false;
+        ++cnt;
+      }
+    }
+    if (is_avg) {
+      const float inv = 1.f / (float)cnt;
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] = acc[j] / (float)cnt;
+      (void)inv;
+    }
+    stv<T, V>(y + p * ldy + c0, acc);
+    if (amax) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) amax[p * C + c0 + j] = (unsigned char)arg[j];
+    }
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pool3x3_bwd_kernel(const T* __restrict__ dy, long ldy,
+                                                          const unsigned char* __restrict__ amax, T* __restrict__ dx,
+                                                          long ldx, int N, int H, int W, int OH, int OW, int C, int cv,
+                                                          int is_avg, int stride) {
+  // gather form: every input pixel sums the windows that contain it (no atomics)
+  const long total = (long)N * H * W * cv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / cv;
+    const int c0 = (int)(i - p * cv) * V;
+    const int iw = (int)(p % W);
+    const long t2 = p / W;
+    const int ih = (int)(t2 % H), n = (int)(t2 / H);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int th = ih + 1 - kh;
+      if (th < 0 || th % stride) continue;
+      const int oh = th / stride;
+      if (oh >= OH) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tw = iw + 1 - kw;
+        if (tw < 0 || tw % stride) continue;
+        const int ow = tw / stride;
+        if (ow >= OW) continue;
+        const long op = (long)(n * OH + oh) * OW + ow;
+        float d[V];
+        ldv<T, V>(dy + op * ldy + c0, d);
+        if (is_avg) {
+          // divisor = number of in-bounds taps of that window (count_include_pad=False)
+          const int h0 = oh * stride - 1, w0 = ow * stride - 1;
+          const int nh = (h0 + 3 < H ? h0 + 3 : H) - (h0 > 0 ? h0 : 0);
+          const int nw = (w0 + 3 < W ? w0 + 3 : W) - (w0 > 0 ? w0 : 0);
+          const float inv = 1.f / (float)(nh * nw);
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += d[j] * inv;
+        } else {
+          const int tap = kh * 3 + kw;
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += (amax[op * C + c0 + j] == tap) ? d[j] : 0.f;
+        }
+      }
+    }
+    stv<T, V>(dx + p * ldx + c0, acc);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pool2x2_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
+                                                          int N, int H, int W, int OH, int OW, int cv, int is_avg) {
+  const long total = (long)N * OH * OW * cv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / cv;
+    const int c0 = (int)(i - p * cv) * V;
+    const int ow = (int)(p % OW);
+    const long t2 = p / OW;
+    const int oh = (int)(t2 % OH), n = (int)(t2 / OH);
+    float v[4][V];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      ldv<T, V>(x + ((long)(n * H + 2 * oh + (k >> 1)) * W + 2 * ow + (k & 1)) * ldx + c0, v[k]);
+    float o[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      if (is_avg) o[j] = (v[0][j] + v[1][j] + v[2][j] + v[3][j]) * 0.25f;
+      else {
+        float m = v[0][j];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (v[k][j] > m || v[k][j] != v[k][j]) m = v[k][j];
+        o[j] = m;
+      }
+    }
+    stv<T, V>(y + p * ldy + c0, o);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pool2x2_bwd_kernel(const T* __restrict__ dy, long ldy, const T* __restrict__ x,
+                                                          long ldx, T* __restrict__ dx, long ldo, int N, int H, int W,
+                                                          int OH, int OW, int cv, int is_avg) {
+  // one thread per OUTPUT pixel writes its 2x2 input window (windows are disjoint); rows/cols of x
+  // beyond 2*OH / 2*OW (odd extents) are zeroed by the caller.
+  const long total = (long)N * OH * OW * cv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / cv;
+    const int c0 = (int)(i - p * cv) * V;
+    const int ow = (int)(p % OW);
+    const long t2 = p / OW;
+    const int oh = (int)(t2 % OH), n = (int)(t2 / OH);
+    float d[V];
+    ldv<T, V>(dy + p * ldy + c0, d);
+    if (is_avg) {
+      float o[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = d[j] * 0.25f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        stv<T, V>(dx + ((long)(n * H + 2 * oh + (k >> 1)) * W + 2 * ow + (k & 1)) * ldo + c0, o);
+    } else {
+      float v[4][V];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        ldv<T, V>(x + ((long)(n * H + 2 * oh + (k >> 1)) * W + 2 * ow + (k & 1)) * ldx + c0, v[k]);
+      int arg[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float m = v[0][j];
+        arg[j] = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (v[k][j] > m || v[k][j] != v[k][j]) { m = v[k][j]; arg[j] = k; }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float o[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = arg[j] == k ? d[j] : 0.f;
+        stv<T, V>(dx + ((long)(n * H + 2 * oh + (k >> 1)) * W + 2 * ow + (k & 1)) * ldo + c0, o);
+      }
+    }
+  }
+}
+
+// ---- squeeze-excite --------------------------------------------------------------------------------
+// per-(image, channel) reduction over H*W:  mode 0: sum x / HW (global average pool)
+//                                            mode 1: sum dout * x   (gradient of the gate)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void se_reduce_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb,
+                                                        float* __restrict__ out, int HW, int C, int cv, int cols_blk,
+                                                        int rows, int mode, int slabs) {
+  __shared__ float red[256 * 8];
+  const int t = threadIdx.x;
+  const bool active = t < rows * cols_blk;
+  const int col = t % cols_blk, row = t / cols_blk;
+  const int n = blockIdx.z;
+  const int colg = blockIdx.y * cols_blk + col;
+  const bool work = active && colg < cv;
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  if (work) {
+    // slab = blockIdx.x: contiguous pixel range (keeps each partial sum short: f32 is enough)
+    const int per = (HW + slabs - 1) / slabs;
+    const int p0 = blockIdx.x * per, p1 = (p0 + per < HW) ? p0 + per : HW;
+    for (int p = p0 + row; p < p1; p += rows) {
+      float va[V];
+      ldv<T, V>(a + ((long)n * HW + p) * lda + (long)colg * V, va);
+      if (mode == 1) {
+        float vb[V];
+        ldv<T, V>(b + ((long)n * HW + p) * ldb + (long)colg * V, vb);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += va[j] * vb[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += va[j];
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[t * V + j] = acc[j];
+  }
+  __syncthreads();
+  if (work && row == 0) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float s = 0.f;
+      for (int rr = 0; rr < rows; ++rr) s += red[(rr * cols_blk + col) * V + j];
+      if (mode == 0) s *= 1.f / (float)HW;
+      atomicAdd(out + (long)n * C + colg * V + j, s);
+    }
+  }
+}
+
+// gate MLP: one block per image.  hidden = relu(W1 pooled + b1) [C/2], gate = sigmoid(W2 hidden + b2) [C]
+__global__ void se_gate_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ b1,
+                                   const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ hidden,
+                                   float* __restrict__ gate, int C) {
+  extern __shared__ float sm[];  // pooled[C] + hidden[C/2]
+  const int n = blockIdx.x, Ch = C / 2;
+  float* sp = sm;
+  float* sh = sm + C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) sp[c] = pooled[(long)n * C + c];
+  __syncthreads();
+  for (int o = threadIdx.x; o < Ch; o += blockDim.x) {
+    float s = b1[o];
+    for (int c = 0; c < C; ++c) s += w1[(long)o * C + c] * sp[c];
+    s = fmaxf(s, 0.f);
+    sh[o] = s;
+    hidden[(long)n * Ch + o] = s;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C; o += blockDim.x) {
+    float s = b2[o];
+    for (int c = 0; c < Ch; ++c) s += w2[(long)o * Ch + c] * sh[c];
+    gate[(long)n * C + o] = 1.f / (1.f + expf(-s));
+  }
+}
+
+// backward of the gate MLP; grid = N blocks; parameter grads via float atomics (tiny)
+__global__ void se_gate_bwd_kernel(const float* __restrict__ pooled, const float* __restrict__ hidden,
+                                   const float* __restrict__ gate, const float* __restrict__ dgate,
+                                   const float* __restrict__ w1, const float* __restrict__ w2, float* dw1, float* db1,
+                                   float* dw2, float* db2, float* __restrict__ dpooled, int C) {
+  extern __shared__ float sm[];  // dz2[C] + dz1[C/2] + pooled[C] + hidden[C/2]
+  const int n = blockIdx.x, Ch = C / 2;
+  float* dz2 = sm;
+  float* dz1 = sm + C;
+  float* sp = dz1 + Ch;
+  float* sh = sp + C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float g = gate[(long)n * C + c];
+    dz2[c] = dgate[(long)n * C + c] * g * (1.f - g);
+    sp[c] = pooled[(long)n * C + c];
+  }
+  for (int c = threadIdx.x; c < Ch; c += blockDim.x) sh[c] = hidden[(long)n * Ch + c];
+  __syncthreads();
+  for (int o = threadIdx.x; o < C; o += blockDim.x) {
+    atomicAdd(db2 + o, dz2[o]);
+    for (int c = 0; c < Ch; ++c) atomicAdd(dw2 + (long)o * Ch + c, dz2[o] * sh[c]);
+  }
+  for (int c = threadIdx.x; c < Ch; c += blockDim.x) {
+    float s = 0.f;
+    for (int o = 0; o < C; ++o) s += w2[(long)o * Ch + c] * dz2[o];
+    dz1[c] = sh[c] > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < Ch; o += blockDim.x) {
+    atomicAdd(db1 + o, dz1[o]);
+    for (int c = 0; c < C; ++c) atomicAdd(dw1 + (long)o * C + c, dz1[o] * sp[c]);
+  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int o = 0; o < Ch; ++o) s += w1[(long)o * C + c] * dz1[o];
+    dpooled[(long)n * C + c] = s;
+  }
+}
+
+// y = x * gate[n][c]            (mode 0)
+// y = x * gate[n][c] + add[n][c] / HW   (mode 1: SE backward, x = dout)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void scale_channels_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gate,
+                                                             const float* __restrict__ add, float inv_hw, T* __restrict__ y,
+                                                             long ldy, long npix, int HW, int C, int cv) {
+  const long total = npix * cv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / cv;
+    const int c0 = (int)(i - p * cv) * V;
+    const long n = p / HW;
+    float v[V];
+    ldv<T, V>(x + p * ldx + c0, v);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      v[j] *= gate[n * C + c0 + j];
+      if (add) v[j] += add[n * C + c0 + j] * inv_hw;
+    }
+    stv<T, V>(y + p * ldy + c0, v);
+  }
+}
+
+}  // namespace
+
+extern "C" int npp_pool3x3_fwd(const NppTensor* x, NppTensor* y, uint8_t* argmax, int is_avg, int stride, double* stats,
+                               void* stream) {
+  NPP_REQUIRE(x && y && x->ptr && y->ptr, NPP_E_NULL, "npp_pool3x3_fwd: null pointer");
+  NPP_REQUIRE(dtype_ok(x) && x->dtype == y->dtype, NPP_E_DTYPE, "npp_pool3x3_fwd: dtype mismatch");
+  NPP_REQUIRE(stride >= 1 && y->h == (x->h - 1) / stride + 1 && y->w == (x->w - 1) / stride + 1 && x->n == y->n && x->c == y->c,
+              NPP_E_SHAPE, "npp_pool3x3_fwd: shape mismatch");
+  const bool vk = vec_ok(x) && vec_ok(y);
+  hipStream_t s = (hipStream_t)stream;
+  {
+    ProfScope prof(NPP_FAM_POOL, x->dtype, s, 0, (double)(npix(x) + npix(y)) * x->c * esize(x->dtype));
+    NPP_DISPATCH_TV(x->dtype, vk, {
+      const int cv = (int)(x->c / V);
+      hipLaunchKernelGGL((pool3x3_fwd_kernel<T, V>), dim3(grid_for(npix(y) * cv)), dim3(256), 0, s, (const T*)x->ptr,
+                         (long)x->ld, (T*)y->ptr, (long)y->ld, is_avg ? nullptr : argmax, (int)x->n, (int)x->h, (int)x->w,
+                         (int)y->h, (int)y->w, (int)x->c, cv, is_avg, stride);
+    });
+  }
+  int rc = npp_check_launch("pool3x3_fwd");
+  if (rc == NPP_OK && stats) rc = npp_channel_stats(y, stats, stream);
+  return rc;
+}
+
+extern "C" int npp_pool3x3_bwd(const NppTensor* dy, const uint8_t* argmax, NppTensor* dx, int is_avg, int stride,
+                               void* stream) {
+  NPP_REQUIRE(dy && dx && dy->ptr && dx->ptr && (is_avg || argmax), NPP_E_NULL, "npp_pool3x3_bwd: null pointer");
+  NPP_REQUIRE(dtype_ok(dy) && dx->dtype == dy->dtype, NPP_E_DTYPE, "npp_pool3x3_bwd: dtype mismatch");
+  NPP_REQUIRE(stride >= 1 && dy->h == (dx->h - 1) / stride + 1 && dy->w == (dx->w - 1) / stride + 1 && dx->n == dy->n &&
+                  dx->c == dy->c, NPP_E_SHAPE, "npp_pool3x3_bwd: shape mismatch");
+  const bool vk = vec_ok(dy) && vec_ok(dx);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(NPP_FAM_POOL, dy->dtype, s, 0, (double)(npix(dx) + npix(dy)) * dx->c * esize(dx->dtype));
+  NPP_DISPATCH_TV(dy->dtype, vk, {
+    const int cv = (int)(dx->c / V);
+    hipLaunchKernelGGL((pool3x3_bwd_kernel<T, V>), dim3(grid_for(npix(dx) * cv)), dim3(256), 0, s, (const T*)dy->ptr,
+                       (long)dy->ld, argmax, (T*)dx->ptr, (long)dx->ld, (int)dx->n, (int)dx->h, (int)dx->w, (int)dy->h,
+                       (int)dy->w, (int)dx->c, cv, is_avg, stride);
+  });
+  return npp_check_launch("pool3x3_bwd");
+}
+
+extern "C" int npp_pool2x2_fwd(const NppTensor* x, NppTensor* y, int is_avg, double* stats, void* stream) {
+  NPP_REQUIRE(x && y && x->ptr && y->ptr, NPP_E_NULL, "npp_pool2x2_fwd: null pointer");
+  NPP_REQUIRE(dtype_ok(x) && x->dtype == y->dtype, NPP_E_DTYPE, "npp_pool2x2_fwd: dtype mismatch");
+  NPP_REQUIRE(y->h == x->h / 2 && y->w == x->w / 2 && x->n == y->n && x->c == y->c, NPP_E_SHAPE, "npp_pool2x2_fwd: shape mismatch");
+  const bool vk = vec_ok(x) && vec_ok(y);
+  hipStream_t s = (hipStream_t)stream;
+  NPP_DISPATCH_TV(x->dtype, vk, {
+    const int cv = (int)(x->c / V);
+    hipLaunchKernelGGL((pool2x2_fwd_kernel<T, V>), dim3(grid_for(npix(y) * cv)), dim3(256), 0, s, (const T*)x->ptr,
+                       (long)x->ld, (T*)y->ptr, (long)y->ld, (int)x->n, (int)x->h, (int)x->w, (int)y->h, (int)y->w, cv, is_avg);
+  });
+  int rc = npp_check_launch("pool2x2_fwd");
+  if (rc == NPP_OK && stats) rc = npp_channel_stats(y, stats, stream);
+  return rc;
+}
+
+extern "C" int npp_pool2x2_bwd(const NppTensor* dy, const NppTensor* x, NppTensor* dx, int is_avg, void* stream) {
+  NPP_REQUIRE(dy && dx && dy->ptr && dx->ptr && (is_avg || (x && x->ptr)), NPP_E_NULL, "npp_pool2x2_bwd: null pointer");
+  NPP_REQUIRE(dtype_ok(dy) && dx->dtype == dy->dtype, NPP_E_DTYPE, "npp_pool2x2_bwd: dtype mismatch");
+  NPP_REQUIRE(dy->h == dx->h / 2 && dy->w == dx->w / 2 && dx->n == dy->n && dx->c == dy->c, NPP_E_SHAPE,
+              "npp_pool2x2_bwd: shape mismatch");
+  NPP_REQUIRE(dx->h % 2 == 0 && dx->w % 2 == 0, NPP_E_UNSUPPORTED, "npp_pool2x2_bwd: odd extents need a zeroed dx (not handled)");
+  const bool vk = vec_ok(dy) && vec_ok(dx) && (is_avg || vec_ok(x));
+  hipStream_t s = (hipStream_t)stream;
+  NPP_DISPATCH_TV(dy->dtype, vk, {
+    const int cv = (int)(dx->c / V);
+    hipLaunchKernelGGL((pool2x2_bwd_kernel<T, V>), dim3(grid_for(npix(dy) * cv)), dim3(256), 0, s, (const T*)dy->ptr,
+                       (long)dy->ld, is_avg ? nullptr : (const T*)x->ptr, is_avg ? 0L : (long)x->ld, (T*)dx->ptr,
+                       (long)dx->ld, (int)dx->n, (int)dx->h, (int)dx->w, (int)dy->h, (int)dy->w, cv, is_avg);
+  });
+  return npp_check_launch("pool2x2_bwd");
+}
+
+static int se_reduce_launch(const NppTensor* a, const NppTensor* b, float* out, int mode, void* stream) {
+  const bool vk = vec_ok(a) && (!b || vec_ok(b));
+  const int HW = (int)(a->h * a->w);
+  hipStream_t s = (hipStream_t)stream;
+  NPP_DISPATCH_TV(a->dtype, vk, {
+    const int cv = (int)(a->c / V);
+    const int cols_blk = cv < 256 ? cv : 256;
+    const int rows = 256 / cols_blk;
+    int slabs = (HW + rows * 8 - 1) / (rows * 8);
+    if (slabs > 64) slabs = 64;
+    if (slabs < 1) slabs = 1;
+    dim3 grid(slabs, (cv + cols_blk - 1) / cols_blk, (unsigned)a->n);
+    hipLaunchKernelGGL((se_reduce_kernel<T, V>), grid, dim3(256), 0, s, (const T*)a->ptr, (long)a->ld,
+                       b ? (const T*)b->ptr : nullptr, b ? (long)b->ld : 0L, out, HW, (int)a->c, cv, cols_blk, rows, mode, slabs);
+  });
+  return npp_check_launch("se_reduce");
+}
+
+extern "C" int npp_global_avgpool(const NppTensor* x, float* pooled, void* stream) {
+  NPP_REQUIRE(x && x->ptr && pooled, NPP_E_NULL, "npp_global_avgpool: null pointer");
+  NPP_REQUIRE(dtype_ok(x), NPP_E_DTYPE, "npp_global_avgpool: bad dtype");
+  return se_reduce_launch(x, nullptr, pooled, 0, stream);
+}
+
+extern "C" int npp_se_bwd_reduce(const NppTensor* dout, const NppTensor* x, float* dgate, void* stream) {
+  NPP_REQUIRE(dout && x && dout->ptr && x->ptr && dgate, NPP_E_NULL, "npp_se_bwd_reduce: null pointer");
+  NPP_REQUIRE(dtype_ok(x) && x->dtype == dout->dtype, NPP_E_DTYPE, "npp_se_bwd_reduce: dtype mismatch");
+  NPP_REQUIRE(same_shape(dout, x), NPP_E_SHAPE, "npp_se_bwd_reduce: shape mismatch");
+  return se_reduce_launch(dout, x, dgate, 1, stream);
+}
+
+extern "C" int npp_se_gate_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+                               float* hidden, float* gate, int n, int c, void* stream) {
+  NPP_REQUIRE(pooled && w1 && b1 && w2 && b2 && hidden && gate, NPP_E_NULL, "npp_se_gate_fwd: null pointer");
+  NPP_REQUIRE(c >= 2 && c % 2 == 0 && c <= 8192, NPP_E_SHAPE, "npp_se_gate_fwd: bad channel count %d", c);
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(n), dim3(256), (c + c / 2) * sizeof(float), (hipStream_t)stream, pooled, w1, b1,
+                     w2, b2, hidden, gate, c);
+  return npp_check_launch("se_gate_fwd");
+}
+
+extern "C" int npp_se_gate_bwd(const float* pooled, const float* hidden, const float* gate, const float* dgate,
+                               const float* w1, const float* w2, float* dw1, float* db1, float* dw2, float* db2,
+                               float* dpooled, int n, int c, void* stream) {
+  NPP_REQUIRE(pooled && hidden && gate && dgate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpooled, NPP_E_NULL,
+              "npp_se_gate_bwd: null pointer");
+  NPP_REQUIRE(c >= 2 && c % 2 == 0 && c <= 8192, NPP_E_SHAPE, "npp_se_gate_bwd: bad channel count %d", c);
+  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(n), dim3(256), 3 * c * sizeof(float), (hipStream_t)stream, pooled, hidden, gate,
+                     dgate, w1, w2, dw1, db1, dw2, db2, dpooled, c);
+  return npp_check_launch("se_gate_bwd");
+}
+
+extern "C" int npp_scale_channels(const NppTensor* x, const float* gate, NppTensor* y, void* stream) {
+  NPP_REQUIRE(x && y && gate && x->ptr && y->ptr, NPP_E_NULL, "npp_scale_channels: null pointer");
+  NPP_REQUIRE(dtype_ok(x) && x->dtype == y->dtype, NPP_E_DTYPE, "npp_scale_channels: dtype mismatch");
+  NPP_REQUIRE(same_shape(x, y), NPP_E_SHAPE, "npp_scale_channels: shape mismatch");
+  const bool vk = vec_ok(x) && vec_ok(y);
+  ProfScope prof(NPP_FAM_ELTWISE, x->dtype, (hipStream_t)stream, 0, (double)npix(x) * x->c * esize(x->dtype) * 2);
+  NPP_DISPATCH_TV(x->dtype, vk, {
+    const int cv = (int)(x->c / V);
+    hipLaunchKernelGGL((scale_channels_kernel<T, V>), dim3(grid_for(npix(x) * cv)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x->ptr, (long)x->ld, gate, (const float*)nullptr, 0.f, (T*)y->ptr, (long)y->ld,
+                       (long)npix(x), (int)(x->h * x->w), (int)x->c, cv);
+  });
+  return npp_check_launch("scale_channels");
+}
+
+extern "C" int npp_se_bwd_apply(const NppTensor* dout, const float* gate, const float* dpooled, NppTensor* dx, void* stream) {
+  NPP_REQUIRE(dout && dx && gate && dpooled && dout->ptr && dx->ptr, NPP_E_NULL, "npp_se_bwd_apply: null pointer");
+  NPP_REQUIRE(dtype_ok(dout) && dout->dtype == dx->dtype, NPP_E_DTYPE, "npp_se_bwd_apply: dtype mismatch");
+  NPP_REQUIRE(same_shape(dout, dx), NPP_E_SHAPE, "npp_se_bwd_apply: shape mismatch");
+  const bool vk = vec_ok(dout) && vec_ok(dx);
+  NPP_DISPATCH_TV(dout->dtype, vk, {
+    const int cv = (int)(dout->c / V);
+    const int HW = (int)(dout->h * dout->w);
+    hipLaunchKernelGGL((scale_channels_kernel<T, V>), dim3(grid_for(npix(dout) * cv)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)dout->ptr, (long)dout->ld, gate, dpooled, 1.f / (float)HW, (T*)dx->ptr, (long)dx->ld,
+                       (long)npix(dout), HW, (int)dout->c, cv);
+  });
+  return npp_check_launch("se_bwd_apply");
+}

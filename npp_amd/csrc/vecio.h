@@ -1,0 +1,35 @@
+// Vector / scalar element access shared by the memory-bound kernels, and the (dtype, vector-ok)
+// dispatch macro.  V = elements per access: Elt<T>::VEC (16 bytes) on the vector path, 1 otherwise.
+#pragma once
+#include "common.h"
+
+template <typename T, int V> NPP_DEV void ldv(const T* p, float* o) {
+  if constexpr (V == 1) o[0] = Elt<T>::ld(p); else Vec16<T>::load(p, o);
+}
+template <typename T, int V> NPP_DEV void stv(T* p, const float* o) {
+  if constexpr (V == 1) Elt<T>::st(p, o[0]); else Vec16<T>::store(p, o);
+}
+
+// expands BODY with typedef T and constexpr int V in scope
+#define NPP_DISPATCH_TV(dtype, vecok, ...)                                         \
+  do {                                                                             \
+    if ((dtype) == NPP_BF16) {                                                     \
+      typedef bf16_t T;                                                            \
+      if (vecok) { constexpr int V = 8; __VA_ARGS__; } else { constexpr int V = 1; __VA_ARGS__; } \
+    } else {                                                                       \
+      typedef float T;                                                             \
+      if (vecok) { constexpr int V = 4; __VA_ARGS__; } else { constexpr int V = 1; __VA_ARGS__; } \
+    }                                                                              \
+  } while (0)
+
+static inline int grid_for(long items, int per_block = 256, int cap = 4096) {
+  long b = (items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+static inline bool same_shape(const NppTensor* a, const NppTensor* b) {
+  return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c;
+}
+static inline bool dtype_ok(const NppTensor* a) { return a->dtype == NPP_F32 || a->dtype == NPP_BF16; }

@@ -1,0 +1,423 @@
+"""Fixed-genotype NPPNet on the HIP kernels -- drop-in for the reference's `models/model_augment.py`.
+
+Same constructor (`Network(cfg, steps=4, multiplier=4, stem_multiplier=4)`, reading
+`cfg.DATASET.NUM_CLASSES/NUM_JOINTS`, `cfg.TRAIN.LAYERS/INIT_CHANNELS`,
+`cfg.MODEL.DECONV_WITH_BIAS/HEAD/REFINE_LAYERS`, model_augment.py:236-242), same module tree and
+therefore the same `state_dict()` keys and `named_parameters()` prefixes (`cells1.`, `cells2`, `stem`,
+augment_lip_sync.py:193-202), same `forward(x) -> (pose_list, par_list)` nesting, `_init_params()` and
+`load_pretrain_backbone(path)`.
+
+What differs is everything underneath: activations live in NHWC (logical NCHW, channels-last strides)
+in the compute dtype (f32 = parity mode, bf16 = throughput mode, `set_compute_dtype`), every cell step
+is two fused conv launches plus ONE BN-apply+add launch, and no ATen convolution / batch-norm is used.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _ops as K
+from . import genotypes as gt
+from ._ops import BnSide
+from .operations import OPS, FactorizedReduce, ReLUConvBN, fused_sum, _use_batch_stats  # noqa: F401
+from .operations import *  # noqa: F401,F403  (reference does `from models.operations import *`)
+
+BN_MOMENTUM = 0.1
+
+_compute_dtype = torch.float32
+
+
+def set_compute_dtype(dtype):
+    """torch.float32 (exact-f32 MFMA, parity mode) or torch.bfloat16 (bf16 storage, f32 accumulate)."""
+    global _compute_dtype
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    _compute_dtype = dtype
+
+
+def get_compute_dtype():
+    return _compute_dtype
+
+
+class Interpolate(nn.Module):
+    """model_augment.py:109-116: bilinear, align_corners=True, by scale factor."""
+
+    def __init__(self, scale_factor, mode='bilinear'):
+        super().__init__()
+        self.s = scale_factor
+        self.mode = mode
+
+    def forward(self, x):
+        return K.interpolate_scale(x, self.s)
+
+
+# ---- sequential containers that keep the reference's child indices but run fused ------------------
+class _Stem(nn.Sequential):
+    """Conv3x3 - BN [- ReLU]  (model_augment.py:244-272)."""
+
+    def forward(self, x):
+        conv, bn = self[0], self[1]
+        y, st = K.conv2d(x, conv.weight, None, conv.stride, conv.padding, 1, relu_in=False,
+                         want_stats=_use_batch_stats(bn))
+        return K.bn_add(BnSide(y, bn, st), None, relu=len(self) > 2, training=bn.training)
+
+
+class _Layer(nn.Sequential):
+    """ReLU - Conv1x1(bias) - BN  (model_augment.py:332-351)."""
+
+    def forward(self, x):
+        conv, bn = self[1], self[2]
+        y, st = K.conv2d(x, conv.weight, conv.bias, 1, conv.padding, 1, relu_in=True, want_stats=_use_batch_stats(bn))
+        return K.bn_add(BnSide(y, bn, st), None, relu=False, training=bn.training)
+
+
+class _Head(nn.Sequential):
+    """ReLU - Conv(k, bias?) - BN - ReLU - Conv1x1(bias)  (model_augment.py:365-398)."""
+
+    def forward(self, x):
+        c1, bn, c2 = self[1], self[2], self[4]
+        y, st = K.conv2d(x, c1.weight, c1.bias, 1, c1.padding, 1, relu_in=True, want_stats=_use_batch_stats(bn))
+        y = K.bn_add(BnSide(y, bn, st), None, relu=True, training=bn.training)
+        out, _ = K.conv2d(y, c2.weight, c2.bias, 1, 0, 1, relu_in=False)
+        return out
+
+
+class _ResampleConv(nn.Sequential):
+    """Interpolate(scale) - Conv1x1(bias): the `extra_conv` of the cross-task edges (model_augment.py:590-595)."""
+
+    def forward(self, x):
+        y = self[0](x)
+        out, _ = K.conv2d(y, self[1].weight, self[1].bias, 1, 0, 1, relu_in=False)
+        return out
+
+
+# ---- cells -------------------------------------------------------------------------------------------
+class _DagCell(nn.Module):
+    """Shared body of Cell / Upsample / PoseCell1 / ParCell1: `steps` nodes, each the sum of two ops
+    applied to earlier states (model_augment.py:48-62, 92-106, 153-172, 210-229)."""
+
+    def _build(self, C, edges, concat, stride_of, wrap_of):
+        names, indices = zip(*edges)
+        assert len(names) == len(indices)
+        self._steps = len(names) // 2
+        self._concat = concat
+        self.multiplier = len(concat)
+        self._ops = nn.ModuleList()
+        for name, index in zip(names, indices):
+            op = OPS[name](C, stride_of(index), True)
+            scale = wrap_of(index)
+            if scale is not None:
+                op = nn.Sequential(op, Interpolate(scale_factor=scale))
+            self._ops += [op]
+        self._indices = indices
+
+    def _run(self, states):
+        for i in range(self._steps):
+            i1, i2 = self._indices[2 * i], self._indices[2 * i + 1]
+            states.append(fused_sum(self._ops[2 * i], states[i1], self._ops[2 * i + 1], states[i2]))
+        return states
+
+
+class Cell(_DagCell):
+    """Encoder cell, model_augment.py:16-62."""
+
+    def __init__(self, genotype, C_prev_prev, C_prev, C, reduction, reduction_prev):
+        super().__init__()
+        if reduction_prev:
+            self.preprocess0 = FactorizedReduce(C_prev_prev, C)
+        else:
+            self.preprocess0 = ReLUConvBN(C_prev_prev, C, 1, 1, 0, affine=True)
+        self.preprocess1 = ReLUConvBN(C_prev, C, 1, 1, 0, affine=True)
+        edges, concat = (genotype.reduce, genotype.reduce_concat) if reduction else \
+            (genotype.normal, genotype.normal_concat)
+        self._build(C, edges, concat, lambda idx: 2 if reduction and idx < 2 else 1, lambda idx: None)
+
+    def forward(self, s0, s1):
+        st = self._run([self.preprocess0(s0), self.preprocess1(s1)])
+        return K.concat([st[i] for i in self._concat])
+
+
+class Upsample(_DagCell):
+    """Decoder cell, model_augment.py:64-106: ops fed from input 0 are followed by a x2 bilinear."""
+
+    def __init__(self, upsample, upsample_concat, C_prev_prev, C_prev):
+        super().__init__()
+        self.preprocess0 = ReLUConvBN(C_prev_prev, C_prev // 4, 1, 1, 0, affine=True)
+        self.preprocess1 = ReLUConvBN(C_prev, C_prev // 4, 1, 1, 0, affine=True)
+        self._build(C_prev // 4, upsample, upsample_concat, lambda idx: 1, lambda idx: 2 if idx == 0 else None)
+
+    def forward(self, s0, s1):
+        st = self._run([self.preprocess0(s0), self.preprocess1(s1)])
+        return K.concat([st[i] for i in self._concat])
+
+
+class _FuseCell(_DagCell):
+    def __init__(self, edges, concat, C_prev_prev, C_prev, C_cur, order):
+        super().__init__()
+        self.order = order
+        if order == 0:
+            self.preprocess0 = ReLUConvBN(C_prev_prev, C_cur, 1, 1, 0, affine=True)
+            self.preprocess1 = ReLUConvBN(C_prev, C_cur, 1, 1, 0, affine=True)
+            self.preprocess2 = ReLUConvBN(C_cur, C_cur, 1, 1, 0, affine=True)
+        else:
+            self.preprocess0 = ReLUConvBN(3 * C_cur, C_cur, 1, 1, 0, affine=True)
+            self.preprocess1 = ReLUConvBN(4 * C_cur, C_cur, 1, 1, 0, affine=True)
+            self.preprocess2 = ReLUConvBN(4 * C_cur, C_cur, 1, 1, 0, affine=True)
+        wrap = (lambda idx: {0: 4, 1: 2}.get(idx)) if order == 0 else (lambda idx: None)
+        self._build(C_cur, edges, concat, lambda idx: 1, wrap)
+
+    def forward(self, s0, s1, s2):
+        st = self._run([self.preprocess0(s0), self.preprocess1(s1), self.preprocess2(s2)])
+        if self.order == 0:
+            # F.interpolate(scale_factor=4/2) with the default (nearest) mode, model_augment.py:167-169
+            raise NotImplementedError("order == 0 fuse cells are never built by Network (model_augment.py:357-363)")
+        fea1 = K.concat(st[0:3])
+        fea2 = K.concat([st[i] for i in self._concat])
+        return fea1, fea2
+
+
+class PoseCell1(_FuseCell):
+    """model_augment.py:119-172"""
+
+    def __init__(self, pose, pose_concat, C_prev_prev, C_prev, C_cur, order):
+        super().__init__(pose, pose_concat, C_prev_prev, C_prev, C_cur, order)
+
+
+class ParCell1(_FuseCell):
+    """model_augment.py:176-229"""
+
+    def __init__(self, par, par_concat, C_prev_prev, C_prev, C_cur, order):
+        super().__init__(par, par_concat, C_prev_prev, C_prev, C_cur, order)
+
+
+# ---- network -----------------------------------------------------------------------------------------
+class Network(nn.Module):
+    """model_augment.py:231-709."""
+
+    def __init__(self, cfg, steps=4, multiplier=4, stem_multiplier=4):
+        super().__init__()
+        self._num_classes = cfg.DATASET.NUM_CLASSES
+        self._num_joints = cfg.DATASET.NUM_JOINTS
+        self._layers = cfg.TRAIN.LAYERS
+        self.C = cfg.TRAIN.INIT_CHANNELS
+        self.deconv_with_bias = cfg.MODEL.DECONV_WITH_BIAS
+        self._head = cfg.MODEL.HEAD
+        self.refine_layers = cfg.MODEL.REFINE_LAYERS
+        C = self.C
+
+        def stem(cin, cout, stride, relu):
+            mods = [nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False),
+                    nn.BatchNorm2d(cout, momentum=BN_MOMENTUM)]
+            if relu:
+                mods.append(nn.ReLU(inplace=True))
+            return _Stem(*mods)
+
+        self.stem0, self.stem1, self.stem2 = stem(3, C, 2, True), stem(C, 2 * C, 2, True), stem(2 * C, 2 * C, 1, False)
+        self.stem3, self.stem4, self.stem5 = stem(3, C, 2, True), stem(C, 2 * C, 2, True), stem(2 * C, 2 * C, 1, False)
+
+        L = self._layers
+        self._taps = [L // 4 - 1, 2 * L // 4 - 1, 3 * L // 4 - 1, 4 * L // 4 - 1]
+        reductions = [L // 4, 2 * L // 4, 3 * L // 4]
+        C_pp, C_p, C_curr = 2 * C, 2 * C, int(C / 2)
+        self.cells1, self.cells2 = nn.ModuleList(), nn.ModuleList()
+        self.num_inchannels = []
+        red_prev = False
+        for i in range(L):
+            if i in self._taps:
+                self.num_inchannels.append(int(C_curr * multiplier))
+            red = i in reductions
+            if red:
+                C_curr *= 2
+            self.cells1 += [Cell(gt.ENCODER, C_pp, C_p, C_curr, red, red_prev)]
+            self.cells2 += [Cell(gt.ENCODER, C_pp, C_p, C_curr, red, red_prev)]
+            red_prev = red
+            C_pp, C_p = C_p, multiplier * C_curr
+        self.num_inchannels = self.num_inchannels[::-1]
+        widths = self.num_inchannels[::-1]
+
+        # encoder-stage cross-task edges (model_augment.py:301-309, _compile :576-599)
+        self._indices1, ops = self._compile(gt.INTER.task1, widths)
+        self._ops1 = nn.ModuleList(ops)
+        self._indices2, ops = self._compile(gt.INTER.task2, widths)
+        self._ops2 = nn.ModuleList(ops)
+        # decoder-stage cross-task edges (model_augment.py:311-320, _compile3 :626-649)
+        resolution = [1, 1 / 2, 1 / 4, 1 / 8, 1 / 4, 1 / 2, 1]
+        channels = [int(2 * C / r) for r in resolution]
+        self.up_indices1, ops = self._compile3(gt.INTER.task3, resolution, channels)
+        self.up_ops1 = nn.ModuleList(ops)
+        self.up_indices2, ops = self._compile3(gt.INTER.task4, resolution, channels)
+        self.up_ops2 = nn.ModuleList(ops)
+
+        self.upsamples1, self.upsamples2 = nn.ModuleList(), nn.ModuleList()
+        nin = self.num_inchannels
+        for j in range(len(nin) - 1):
+            self.upsamples1 += [Upsample(gt.DECODER.upsample1, gt.DECODER.upsample_concat1, nin[j], nin[j + 1])]
+        for j in range(len(nin) - 1):
+            self.upsamples2 += [Upsample(gt.DECODER.upsample2, gt.DECODER.upsample_concat2, nin[j], nin[j + 1])]
+
+        Cf = nin[3]
+
+        def layer(cout):
+            return _Layer(nn.ReLU(), nn.Conv2d(8 * Cf, cout, kernel_size=1, padding=0, dilation=1),
+                          nn.BatchNorm2d(cout, momentum=BN_MOMENTUM))
+
+        self.pose_layer = layer(4 * Cf)
+        self.pose_auxlayer = layer(3 * Cf)
+        self.par_layer = layer(4 * Cf)
+        self.edge_layer = layer(3 * Cf)
+
+        self.pose_net, self.par_net = nn.ModuleList(), nn.ModuleList()
+        for _ in range(3):
+            self.pose_net.append(PoseCell1(gt.FUSION.pose, gt.FUSION.pose_concat, Cf, Cf, Cf, 1))
+            self.par_net.append(ParCell1(gt.FUSION.par, gt.FUSION.par_concat, Cf, Cf, Cf, 1))
+
+        def head(cin, mid, k, cout, bias1=True):
+            return _Head(nn.ReLU(), nn.Conv2d(cin, mid, kernel_size=k, padding=k // 2, dilation=1, bias=bias1),
+                         nn.BatchNorm2d(mid, momentum=BN_MOMENTUM), nn.ReLU(inplace=True),
+                         nn.Conv2d(mid, cout, kernel_size=1, padding=0, dilation=1, bias=True))
+
+        self.pose_head, self.pose_auxnet = nn.ModuleList(), nn.ModuleList()
+        self.par_head, self.edge_head = nn.ModuleList(), nn.ModuleList()
+        for _ in range(self.refine_layers + 1):
+            self.pose_head.append(head(4 * Cf, 256, 1, self._num_joints))
+            self.pose_auxnet.append(head(3 * Cf, 128, 3, self._num_joints))
+            self.par_head.append(head(4 * Cf, 256, 1, self._num_classes))
+            self.edge_head.append(head(3 * Cf, 6, 3, 2, bias1=False))
+        self._init_params()
+
+    # -- construction helpers ---------------------------------------------------------------------------
+    @staticmethod
+    def _edge(name, c_src, c_dst, scale, needs_extra):
+        op = OPS[name](c_src, 1, True)
+        if needs_extra:
+            op = nn.Sequential(op, _ResampleConv(Interpolate(scale), nn.Conv2d(c_src, c_dst, 1)))
+        return op
+
+    def _compile(self, geno, C_list):
+        indices, ops = [], []
+        for cont, stage in enumerate(geno):
+            names, idx = zip(*stage)
+            indices.append(idx)
+            for n, ind in zip(names, idx):
+                ops.append(self._edge(n, C_list[ind], C_list[cont], 1 / 2 ** (cont - ind), ind != cont))
+        return indices, ops
+
+    def _compile3(self, geno, resolutions, C_list):
+        indices, ops = [], []
+        for cont, stage in enumerate(geno):
+            names, idx = zip(*stage)
+            indices.append(idx)
+            for n, ind in zip(names, idx):
+                ops.append(self._edge(n, C_list[ind], C_list[4 + cont], resolutions[4 + cont] / resolutions[ind],
+                                      ind != 4 + cont))
+        return indices, ops
+
+    # -- forward ----------------------------------------------------------------------------------------
+    @staticmethod
+    def _cross(ops, base, indices, feats):
+        """sum_j ops[base + j](feats[indices[j]])"""
+        z = None
+        for j, ind in enumerate(indices):
+            y = ops[base + j](feats[ind])
+            z = y if z is None else K.add(z, y)
+        return z
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("npp_amd.Network runs on the MI355X HIP kernels only: move the input to cuda "
+                               "(there is no CPU fallback)")
+        dt = _compute_dtype
+        x = K.image_to_nhwc(x, dt)
+        s1 = self.stem2(s0 := self.stem1(self.stem0(x)))
+        s3 = self.stem5(s2 := self.stem4(self.stem3(x)))
+        f1, f2 = [], []
+        k1 = k2 = stage = 0
+        for i, (cell1, cell2) in enumerate(zip(self.cells1, self.cells2)):
+            s0, s1 = s1, cell1(s0, s1)
+            s2, s3 = s3, cell2(s2, s3)
+            if i in self._taps:
+                f1.append(s1)
+                f2.append(s3)
+                ind1, ind2 = self._indices1[stage], self._indices2[stage]
+                z1 = self._cross(self._ops1, k1, ind1, f2)
+                z2 = self._cross(self._ops2, k2, ind2, f1)
+                k1 += len(ind1)
+                k2 += len(ind2)
+                stage += 1
+                s1 = K.add(s1, z1)
+                s3 = K.add(s3, z2)
+                f1[-1], f2[-1] = s1, s3
+        # decoder: three structurally identical stages (model_augment.py:448-533)
+        k1 = k2 = 0
+        for d in range(3):
+            o1 = self.upsamples1[d](f1[3] if d == 0 else f1[-1], f1[2 - d])
+            o2 = self.upsamples2[d](f2[3] if d == 0 else f2[-1], f2[2 - d])
+            f1.append(o1)
+            f2.append(o2)
+            ind1, ind2 = self.up_indices1[d], self.up_indices2[d]
+            z1 = self._cross(self.up_ops1, k1, ind1, f2)
+            z2 = self._cross(self.up_ops2, k2, ind2, f1)
+            k1 += len(ind1)
+            k2 += len(ind2)
+            f1[-1], f2[-1] = K.add(o1, z1), K.add(o2, z2)
+        H, W = f1[0].shape[2], f1[0].shape[3]
+        x1 = K.concat([f1[0], f1[6], K.bilinear(f1[5], H, W), K.bilinear(f1[4], H, W)])
+        x2 = K.concat([f2[0], f2[6], K.bilinear(f2[5], H, W), K.bilinear(f2[4], H, W)])
+        in1, in2 = self.pose_auxlayer(x1), self.edge_layer(x2)
+        in3, in4 = self.pose_layer(x1), self.par_layer(x2)
+        pose_list, par_list = [], []
+
+        def heads(i):
+            edge = self.edge_head[i](in2)
+            pose_aux = self.pose_auxnet[i](in1)
+            pose_map = self.pose_head[i](in3)
+            par_map = self.par_head[i](in4)
+            pose_list.append([pose_map, pose_aux])
+            par_list.append([par_map, edge])
+
+        heads(0)
+        for i in range(1, self.refine_layers + 1):
+            for j in range(3):
+                m = 2 * (i - 1) + j
+                n1, tmp = self.pose_net[m](in1, in3, in4)
+                in2, n4 = self.par_net[m](in2, in3, in4)
+                in1, in3, in4 = n1, tmp, n4
+            heads(i)
+        return pose_list, par_list
+
+    # -- parameter handling -------------------------------------------------------------------------------
+    def _init_params(self):
+        """model_augment.py:651-671: xavier-normal conv weights, zero biases, BN gamma=1 beta=0."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_normal_(m.weight.data)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+                if m.affine:
+                    m.weight.data.fill_(1)
+                    m.bias.data.zero_()
+
+    def load_pretrain_backbone(self, path=''):
+        """Tolerant key-wise loader, model_augment.py:673-709: strips a leading `module.`, keeps our tensor
+        where shapes disagree, ignores unknown keys, leaves missing ones untouched."""
+        if not os.path.isfile(path):
+            return
+        loaded = torch.load(path, map_location='cpu')
+        own = self.state_dict()
+        merged = {}
+        for k, v in loaded.items():
+            kk = k[7:] if k.startswith('module') else k
+            if kk in own:
+                if tuple(v.shape) != tuple(own[kk].shape):
+                    print('Skip loading parameter {}, required shape{}, loaded shape{}.'.format(
+                        kk, tuple(own[kk].shape), tuple(v.shape)))
+                    v = own[kk]
+                merged[kk] = v
+        for k, v in own.items():
+            merged.setdefault(k, v)
+        msg = self.load_state_dict(merged, strict=False)
+        print("=> loading information:", msg)
+        print('successful load pretrained backbone from {}'.format(path))

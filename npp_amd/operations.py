@@ -1,0 +1,289 @@
+"""NAS cell primitives on the HIP kernels -- drop-in for the reference's `models/operations.py`.
+
+Same public surface: `OPS[name](C, stride, affine) -> nn.Module`, same class names, constructor
+arguments, attribute names and therefore the same `state_dict()` keys (`net.1.weight`,
+`net.2.running_mean`, `conv1.bias`, ...).  The child `nn.Conv2d` / `nn.BatchNorm2d` modules are kept
+as *parameter holders* (so `nn.SyncBatchNorm.convert_sync_batchnorm`, `.cuda()`, DDP and checkpoints
+work unchanged, augment_lip_sync.py:191-208) but their own `forward` is never used: every module's
+forward calls the fused HIP ops in `_ops.py`:
+
+    ReLU is folded into the conv's load, the BatchNorm batch statistics into the conv's epilogue,
+    and BN-apply is deferred (`pending()`) so the consuming cell can fuse it with the branch add.
+
+Reference lines are cited per class.  Inputs must be CUDA tensors; there is no CPU path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _ops as K
+from ._ops import BnSide
+
+BN_MOMENTUM = 0.1   # operations.py:27
+
+
+def _use_batch_stats(bn) -> bool:
+    return bn.training or bn.running_mean is None
+
+
+class _BnOp(nn.Module):
+    """An op that ends in BatchNorm: `pending(x)` returns the raw tensor + statistics, `forward`
+    materialises the normalised output."""
+
+    def pending(self, x) -> BnSide:
+        raise NotImplementedError
+
+    def forward(self, x):
+        side = self.pending(x)
+        return K.bn_add(side, None, relu=False, training=side.bn.training)
+
+
+def pending_of(op, x) -> BnSide:
+    """Deferred-BN view of any op (plain ops / containers just run)."""
+    if isinstance(op, _BnOp):
+        return op.pending(x)
+    return BnSide(op(x))
+
+
+def fused_sum(op1, h1, op2, h2):
+    """`op1(h1) + op2(h2)` (model_augment.py:54-59) with both BN-applies folded into the add."""
+    a, b = pending_of(op1, h1), pending_of(op2, h2)
+    if a.bn is None and b.bn is not None:
+        a, b = b, a
+    training = a.bn.training if a.bn is not None else False
+    return K.bn_add(a, b, relu=False, training=training)
+
+
+class Zero(nn.Module):
+    """operations.py:31-41"""
+
+    def __init__(self, stride):
+        super().__init__()
+        self.stride = stride
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        if self.stride != 1:
+            h, w = (h + self.stride - 1) // self.stride, (w + self.stride - 1) // self.stride
+        return K.new_nhwc(n, c, h, w, x.dtype, x.device, zero=True)
+
+
+class PoolBN(_BnOp):
+    """AvgPool or MaxPool - BN, operations.py:44-66."""
+
+    def __init__(self, pool_type, C, kernel_size, stride, padding, affine=True):
+        super().__init__()
+        pt = pool_type.lower()
+        if pt == 'max':
+            self.pool = nn.MaxPool2d(kernel_size, stride, padding)
+        elif pt == 'avg':
+            self.pool = nn.AvgPool2d(kernel_size, stride, padding, count_include_pad=False)
+        else:
+            raise ValueError()
+        if kernel_size != 3 or padding != 1:
+            raise NotImplementedError("PoolBN: only the 3x3 / pad 1 form used by OPS is implemented")
+        self._avg = pt == 'avg'
+        self._stride = stride
+        self.bn = nn.BatchNorm2d(C, affine=affine, momentum=BN_MOMENTUM)
+
+    def pending(self, x):
+        y, st = K.pool3x3(x, self._avg, self._stride, want_stats=_use_batch_stats(self.bn))
+        return BnSide(y, self.bn, st)
+
+
+class ReLUConvBN(_BnOp):
+    """ReLU - Conv - BN, operations.py:69-82."""
+
+    def __init__(self, C_in, C_out, kernel_size, stride, padding, affine=True):
+        super().__init__()
+        self.net = nn.Sequential(
+            nn.ReLU(),
+            nn.Conv2d(C_in, C_out, kernel_size, stride, padding, bias=False),
+            nn.BatchNorm2d(C_out, affine=affine, momentum=BN_MOMENTUM))
+
+    def pending(self, x):
+        conv, bn = self.net[1], self.net[2]
+        y, st = K.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, relu_in=True,
+                         want_stats=_use_batch_stats(bn))
+        return BnSide(y, bn, st)
+
+
+class DilConv(_BnOp):
+    """ReLU - dense dilated conv - BN, operations.py:85-101 (unused by the fixed genotype)."""
+
+    def __init__(self, C_in, C_out, kernel_size, stride, padding, dilation, affine=True):
+        super().__init__()
+        self.net = nn.Sequential(
+            nn.ReLU(),
+            nn.Conv2d(C_in, C_out, kernel_size, stride, padding, dilation=dilation, bias=False),
+            nn.BatchNorm2d(C_out, affine=affine, momentum=BN_MOMENTUM))
+
+    pending = ReLUConvBN.pending
+
+
+class StdConv(ReLUConvBN):
+    """operations.py:159-172 (same computation as ReLUConvBN)."""
+
+
+class SE_Block(nn.Module):
+    """Squeeze-excite gate, operations.py:105-129.  `bn`/`pool2` exist (state-dict keys, never-used
+    parameters when stride == 1) exactly as in the reference."""
+
+    def __init__(self, C_in, stride, affine=True):
+        super().__init__()
+        self.pool = nn.AdaptiveAvgPool2d(1)
+        self.conv1 = nn.Conv2d(C_in, C_in // 2, 1, 1, 0)
+        self.conv2 = nn.Conv2d(C_in // 2, C_in, 1, 1, 0)
+        self.relu = nn.ReLU()
+        self.stride = stride
+        self.pool2 = nn.AvgPool2d(2)
+        self.bn = nn.BatchNorm2d(C_in, momentum=BN_MOMENTUM)
+
+    def _gate(self, x):
+        return K.se_scale(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+
+    def pending(self, x):
+        out = self._gate(x)
+        if self.stride == 1:
+            return BnSide(out)
+        y, st = K.pool2x2(out, True, want_stats=_use_batch_stats(self.bn))
+        return BnSide(y, self.bn, st)
+
+    def forward(self, x):
+        side = self.pending(x)
+        if side.bn is None:
+            return side.x
+        return K.bn_add(side, None, relu=False, training=self.bn.training)
+
+
+class Identity(nn.Module):
+    """operations.py:133-138"""
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, x):
+        return x
+
+
+class FactorizedReduce(_BnOp):
+    """Stride-2 channel-split pointwise reduce, operations.py:142-157.  The `x[:, :, 1:, 1:]` view of the
+    second conv is a padding of -1 in the kernel's geometry: no sliced copy is made."""
+
+    def __init__(self, C_in, C_out, affine=True):
+        super().__init__()
+        self.relu = nn.ReLU()
+        self.conv1 = nn.Conv2d(C_in, C_out // 2, 1, stride=2, padding=0, bias=False)
+        self.conv2 = nn.Conv2d(C_in, C_out // 2, 1, stride=2, padding=0, bias=False)
+        self.bn = nn.BatchNorm2d(C_out, affine=affine, momentum=BN_MOMENTUM)
+
+    def pending(self, x):
+        want = _use_batch_stats(self.bn)
+        y1, s1 = K.conv2d(x, self.conv1.weight, None, 2, 0, 1, relu_in=True, want_stats=want)
+        y2, s2 = K.conv2d_crop(x, self.conv2.weight, 2, relu_in=True, want_stats=want)
+        if y1.shape[2:] != y2.shape[2:]:
+            raise RuntimeError("FactorizedReduce needs even spatial extents (torch.cat would fail too)")
+        y = K.concat([y1, y2])
+        st = None
+        if want:
+            c = y1.shape[1]
+            st = torch.cat([s1[:c], s2[:c], s1[c:], s2[c:]])
+        return BnSide(y, self.bn, st)
+
+
+class FacConv(_BnOp):
+    """ReLU - Conv(Kx1) - Conv(1xK) - BN, operations.py:174-188."""
+
+    def __init__(self, C_in, C_out, kernel_length, stride, padding, affine=True):
+        super().__init__()
+        self.net = nn.Sequential(
+            nn.ReLU(),
+            nn.Conv2d(C_in, C_in, (kernel_length, 1), (stride, 1), (padding, 0), bias=False),
+            nn.Conv2d(C_in, C_out, (1, kernel_length), (1, stride), (0, padding), bias=False),
+            nn.BatchNorm2d(C_out, affine=affine, momentum=BN_MOMENTUM))
+
+    def pending(self, x):
+        c1, c2, bn = self.net[1], self.net[2], self.net[3]
+        y, _ = K.conv2d(x, c1.weight, None, c1.stride, c1.padding, 1, relu_in=True)
+        y, st = K.conv2d(y, c2.weight, None, c2.stride, c2.padding, 1, relu_in=False, want_stats=_use_batch_stats(bn))
+        return BnSide(y, bn, st)
+
+
+class DilConvS(_BnOp):
+    """ReLU - depthwise (dilated) - pointwise - BN, operations.py:202-220."""
+
+    def __init__(self, C_in, C_out, kernel_size, stride, padding, dilation, affine=True):
+        super().__init__()
+        self.net = nn.Sequential(
+            nn.ReLU(),
+            nn.Conv2d(C_in, C_in, kernel_size, stride, padding, dilation=dilation, groups=C_in, bias=False),
+            nn.Conv2d(C_in, C_out, 1, stride=1, padding=0, bias=False),
+            nn.BatchNorm2d(C_out, affine=affine, momentum=BN_MOMENTUM))
+
+    def pending(self, x):
+        dw, pw, bn = self.net[1], self.net[2], self.net[3]
+        y = K.dwconv2d(x, dw.weight, dw.stride[0], dw.padding[0], dw.dilation[0], relu_in=True)
+        y, st = K.conv2d(y, pw.weight, None, 1, 0, 1, relu_in=False, want_stats=_use_batch_stats(bn))
+        return BnSide(y, bn, st)
+
+
+class Sep_Conv(_BnOp):
+    """Two stacked DilConvS (dilation 1), operations.py:190-200."""
+
+    def __init__(self, C_in, C_out, kernel_size, stride, padding, affine=True):
+        super().__init__()
+        self.net = nn.Sequential(
+            DilConvS(C_in, C_in, kernel_size, stride, padding, dilation=1, affine=affine),
+            DilConvS(C_in, C_out, kernel_size, 1, padding, dilation=1, affine=affine))
+
+    def pending(self, x):
+        return self.net[1].pending(self.net[0](x))
+
+
+class Pooled_Conv(nn.Module):
+    """AvgPool2 - [ReLU - Conv3x3(bias) - BN] x n - bilinear x2 (x2), operations.py:222-251."""
+
+    def __init__(self, C_in, C_out, kernel_size, stride, padding, conv_nums, affine=True):
+        super().__init__()
+        layers = [nn.AvgPool2d(2, 2)]
+        for _ in range(conv_nums):
+            layers.append(nn.ReLU())
+            layers.append(nn.Conv2d(C_in, C_out, kernel_size, stride, padding))
+            layers.append(nn.BatchNorm2d(C_out, affine=affine, momentum=BN_MOMENTUM))
+        layers.append(nn.UpsamplingBilinear2d(scale_factor=2))
+        if conv_nums == 2 and stride == 2:
+            layers.append(nn.UpsamplingBilinear2d(scale_factor=2))
+        self.net = nn.Sequential(*layers)
+        self._n = conv_nums
+        self._ups = 2 if (conv_nums == 2 and stride == 2) else 1
+
+    def forward(self, x):
+        y, _ = K.pool2x2(x, True)
+        for i in range(self._n):
+            conv, bn = self.net[2 + 3 * i], self.net[3 + 3 * i]
+            y, st = K.conv2d(y, conv.weight, conv.bias, conv.stride, conv.padding, 1, relu_in=True,
+                             want_stats=_use_batch_stats(bn))
+            y = K.bn_add(BnSide(y, bn, st), None, relu=False, training=bn.training)
+        for _ in range(self._ups):
+            y = K.bilinear(y, y.shape[2] * 2, y.shape[3] * 2)
+        return y
+
+
+OPS = {   # operations.py:9-25
+    'none': lambda C, stride, affine: Zero(stride),
+    'avg_pool_3x3': lambda C, stride, affine: PoolBN('avg', C, 3, stride, 1, affine=affine),
+    'max_pool_3x3': lambda C, stride, affine: PoolBN('max', C, 3, stride, 1, affine=affine),
+    'skip_connect': lambda C, stride, affine: Identity() if stride == 1 else FactorizedReduce(C, C, affine=affine),
+    'std_conv_3x3': lambda C, stride, affine: ReLUConvBN(C, C, 3, stride, 1, affine=affine),
+    'std_conv_1x1': lambda C, stride, affine: ReLUConvBN(C, C, 1, stride, 0, affine=affine),
+    'dil_conv_3x3_2': lambda C, stride, affine: DilConvS(C, C, 3, stride, 2, 2, affine=affine),
+    'dil_conv_3x3_4': lambda C, stride, affine: DilConvS(C, C, 3, stride, 4, 4, affine=affine),
+    'dil_conv_5x5_4': lambda C, stride, affine: DilConvS(C, C, 5, stride, 4, 2, affine=affine),
+    'se_connect': lambda C, stride, affine: SE_Block(C, stride, affine=affine),
+    'conv_7x1_1x7': lambda C, stride, affine: FacConv(C, C, 7, stride, 3, affine=affine),
+    'sep_conv_3x3': lambda C, stride, affine: Sep_Conv(C, C, 3, stride, 1, affine=affine),
+    'sep_conv_5x5': lambda C, stride, affine: Sep_Conv(C, C, 5, stride, 2, affine=affine),
+    'poled_conv_x1': lambda C, stride, affine: Pooled_Conv(C, C, 3, stride, 1, 1, affine=affine),
+    'poled_conv_x2': lambda C, stride, affine: Pooled_Conv(C, C, 3, stride, 1, 2, affine=affine),
+}

@@ -1,0 +1,224 @@
+"""Kernel-level GPU parity through the C ABI (via npp_amd._ops) against a plain PyTorch f32 CPU reference of
+the same op, on shapes the per-OPS goldens do not reach: every MFMA tile variant (BN = 32/64/128), ragged
+M / odd channel counts (3, 6, 16, 20, 2), channel-slice views (ld > C), stride 2, dilation, bias, and
+resampling ratios used by the network."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed):
+    return torch.from_numpy(np.random.default_rng(seed).standard_normal(shape).astype(np.float32))
+
+
+def _to_dev(x_cpu, dtype, slice_pad=0):
+    """NHWC device copy; with slice_pad > 0 the tensor is a channel slice of a wider buffer (ld = C + pad)."""
+    from npp_amd import _ops as K
+    n, c, h, w = x_cpu.shape
+    dev = _dev()
+    if slice_pad:
+        buf = torch.full((n, h, w, c + slice_pad), float("nan"), device=dev).permute(0, 3, 1, 2)
+        buf = K.cast(buf, dtype) if dtype != torch.float32 else buf
+        view = buf[:, :c]
+        tmp = K.cast(x_cpu.to(dev).contiguous(memory_format=torch.channels_last), dtype)
+        from npp_amd._lib import lib, check, stream_ptr
+        import ctypes as C
+        check(lib().npp_copy(C.byref(K.desc(tmp)), C.byref(K.desc(view)), stream_ptr()))
+        return view
+    return K.cast(x_cpu.to(dev).contiguous(memory_format=torch.channels_last), dtype)
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, dil, H, W, N, relu, bias, slice_pad
+    (32, 32, 3, 1, 1, 1, 13, 17, 2, True, False, 0),       # BN=32 tile, ragged M
+    (64, 64, 3, 1, 1, 1, 24, 24, 2, True, False, 8),       # BN=64, input is a channel slice
+    (128, 128, 3, 1, 1, 1, 24, 24, 1, True, False, 0),     # BN=128
+    (128, 256, 1, 1, 0, 1, 12, 12, 3, True, True, 0),      # 1x1 + bias, 2 N-tiles
+    (512, 128, 1, 1, 0, 1, 12, 12, 2, True, False, 0),     # long K
+    (64, 128, 3, 2, 1, 1, 20, 20, 2, False, False, 0),     # stem-like stride 2
+    (3, 16, 3, 2, 1, 1, 32, 32, 2, False, False, 0),       # image stem: Cin = 3 (padded to 8 in memory)
+    (384, 6, 3, 1, 1, 1, 12, 12, 2, True, False, 0),       # edge head: Cout = 6
+    (256, 20, 1, 1, 0, 1, 12, 12, 2, False, True, 0),      # parsing head: Cout = 20 + bias
+    (128, 16, 1, 1, 0, 1, 12, 12, 2, False, True, 0),      # pose head
+    (32, 32, 3, 1, 2, 2, 16, 16, 2, True, False, 0),       # dense dilated (DilConv)
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case, dtype, tol):
+    from npp_amd import _ops as K
+    cin, cout, k, stride, pad, dil, H, W, N, relu, bias, sp = case
+    x_cpu = _rand((N, cin, H, W), 1)
+    w_cpu = _rand((cout, cin, k, k), 2) * (1.0 / np.sqrt(cin * k * k))
+    b_cpu = _rand((cout,), 3) if bias else None
+    if dtype == torch.bfloat16:   # compare against the same bf16-rounded operands
+        x_cpu = x_cpu.bfloat16().float()
+    xr = x_cpu.clone().requires_grad_(True)
+    wr = w_cpu.clone().requires_grad_(True)
+    wq = wr.bfloat16().float() if dtype == torch.bfloat16 else wr
+    br = b_cpu.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(F.relu(xr) if relu else xr, wq, br, stride, pad, dil)
+    gy_cpu = _rand(tuple(yr.shape), 4)
+    if dtype == torch.bfloat16:
+        gy_cpu = gy_cpu.bfloat16().float()
+    yr.backward(gy_cpu)
+
+    dev = _dev()
+    if cin == 3:
+        x = K.image_to_nhwc(x_cpu.to(dev), dtype).detach().requires_grad_(True)
+    else:
+        x = _to_dev(x_cpu, dtype, sp).detach().requires_grad_(True)
+    w = w_cpu.to(dev).requires_grad_(True)
+    b = b_cpu.to(dev).requires_grad_(True) if bias else None
+    y, st = K.conv2d(x, w, b, stride, pad, dil, relu_in=relu, want_stats=True)
+    y.backward(_to_dev(gy_cpu, dtype))
+    torch.cuda.synchronize()
+    yf = y.detach().float().cpu()
+    assert rel_err(yf.numpy(), yr.detach().numpy()) < tol
+    # epilogue statistics = statistics of what was stored
+    s_ref = torch.cat([yf.double().sum((0, 2, 3)), (yf.double() ** 2).sum((0, 2, 3))])
+    assert rel_err(st.cpu().numpy(), s_ref.numpy()) < 1e-5
+    if cin != 3:
+        assert rel_err(x.grad.float().cpu().numpy(), xr.grad.numpy()) < tol
+    assert rel_err(w.grad.cpu().numpy(), wr.grad.numpy()) < tol * 2
+    if bias:
+        assert rel_err(b.grad.cpu().numpy(), br.grad.numpy()) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C,k,stride,dil,H", [(32, 3, 1, 2, 24), (128, 3, 2, 4, 24), (64, 5, 1, 2, 16), (1024, 3, 1, 2, 6),
+                                                 (256, 3, 2, 2, 12)])
+def test_dwconv_fwd_bwd(C, k, stride, dil, H, dtype, tol):
+    from npp_amd import _ops as K
+    pad = dil * (k - 1) // 2
+    N = 2
+    x_cpu = _rand((N, C, H, H), 5)
+    w_cpu = _rand((C, 1, k, k), 6) * 0.3
+    if dtype == torch.bfloat16:
+        x_cpu = x_cpu.bfloat16().float()
+    xr, wr = x_cpu.clone().requires_grad_(True), w_cpu.clone().requires_grad_(True)
+    yr = F.conv2d(F.relu(xr), wr, None, stride, pad, dil, groups=C)
+    gy = _rand(tuple(yr.shape), 7)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    yr.backward(gy)
+    x = _to_dev(x_cpu, dtype).detach().requires_grad_(True)
+    w = w_cpu.to(_dev()).requires_grad_(True)
+    y = K.dwconv2d(x, w, stride, pad, dil, relu_in=True)
+    y.backward(_to_dev(gy, dtype))
+    torch.cuda.synchronize()
+    assert rel_err(y.detach().float().cpu().numpy(), yr.detach().numpy()) < tol
+    assert rel_err(x.grad.float().cpu().numpy(), xr.grad.numpy()) < tol
+    assert rel_err(w.grad.cpu().numpy(), wr.grad.numpy()) < tol * 2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C,hin,hout", [(32, 12, 24), (256, 12, 96), (64, 24, 12), (128, 24, 6), (16, 13, 29), (512, 6, 48)])
+def test_bilinear_fwd_bwd(C, hin, hout, dtype, tol):
+    from npp_amd import _ops as K
+    x_cpu = _rand((2, C, hin, hin), 8)
+    if dtype == torch.bfloat16:
+        x_cpu = x_cpu.bfloat16().float()
+    xr = x_cpu.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=(hout, hout), mode='bilinear', align_corners=True)
+    gy = _rand(tuple(yr.shape), 9)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    yr.backward(gy)
+    x = _to_dev(x_cpu, dtype).detach().requires_grad_(True)
+    y = K.bilinear(x, hout, hout)
+    y.backward(_to_dev(gy, dtype))
+    torch.cuda.synchronize()
+    assert rel_err(y.detach().float().cpu().numpy(), yr.detach().numpy()) < tol
+    assert rel_err(x.grad.float().cpu().numpy(), xr.grad.numpy()) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C,H,N,relu,two", [(32, 24, 2, False, True), (128, 12, 4, True, False), (6, 12, 2, True, False),
+                                              (384, 6, 2, False, True), (1024, 3, 2, False, False)])
+def test_batchnorm_fused_add(C, H, N, relu, two, dtype, tol):
+    """out = relu?(BN(a) [+ BN(b)]) in train mode vs nn.BatchNorm2d, incl. running stats and all grads."""
+    from npp_amd import _ops as K
+    dev = _dev()
+    a_cpu, b_cpu = _rand((N, C, H, H), 10) * 2 + 0.5, _rand((N, C, H, H), 11)
+    if dtype == torch.bfloat16:
+        a_cpu, b_cpu = a_cpu.bfloat16().float(), b_cpu.bfloat16().float()
+    bns = [torch.nn.BatchNorm2d(C, momentum=0.1) for _ in range(2)]
+    for i, bn in enumerate(bns):
+        with torch.no_grad():
+            bn.weight.copy_(_rand((C,), 12 + i) * 0.2 + 1)
+            bn.bias.copy_(_rand((C,), 14 + i) * 0.1)
+    import copy
+    ref = copy.deepcopy(bns)
+    ar, br = a_cpu.clone().requires_grad_(True), b_cpu.clone().requires_grad_(True)
+    yr = ref[0](ar) + (ref[1](br) if two else 0)
+    if relu:
+        yr = F.relu(yr)
+    gy = _rand(tuple(yr.shape), 16)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    yr.backward(gy)
+    for bn in bns:
+        bn.to(dev)
+    a = _to_dev(a_cpu, dtype).detach().requires_grad_(True)
+    b = _to_dev(b_cpu, dtype).detach().requires_grad_(True)
+    y = K.bn_add(K.BnSide(a, bns[0]), K.BnSide(b, bns[1]) if two else None, relu=relu, training=True)
+    y.backward(_to_dev(gy, dtype))
+    torch.cuda.synchronize()
+    assert rel_err(y.detach().float().cpu().numpy(), yr.detach().numpy()) < tol
+    assert rel_err(a.grad.float().cpu().numpy(), ar.grad.numpy()) < tol * 5
+    assert rel_err(bns[0].weight.grad.cpu().numpy(), ref[0].weight.grad.numpy()) < tol * 5
+    assert rel_err(bns[0].bias.grad.cpu().numpy(), ref[0].bias.grad.numpy()) < tol * 5
+    assert rel_err(bns[0].running_mean.cpu().numpy(), ref[0].running_mean.numpy()) < tol
+    assert rel_err(bns[0].running_var.cpu().numpy(), ref[0].running_var.numpy()) < tol
+    assert int(bns[0].num_batches_tracked) == 1
+    if two:
+        assert rel_err(b.grad.float().cpu().numpy(), br.grad.numpy()) < tol * 5
+        assert rel_err(bns[1].weight.grad.cpu().numpy(), ref[1].weight.grad.numpy()) < tol * 5
+
+
+def test_concat_and_slice_views_roundtrip():
+    from npp_amd import _ops as K
+    xs = [_rand((2, c, 8, 8), 20 + i) for i, c in enumerate((8, 16, 8, 32))]
+    dx = [_to_dev(x, torch.float32).requires_grad_(True) for x in xs]
+    y = K.concat(dx)
+    ref = torch.cat(xs, dim=1)
+    assert rel_err(y.detach().cpu().numpy(), ref.numpy()) == 0.0
+    gy = _rand(tuple(ref.shape), 30)
+    y.backward(_to_dev(gy, torch.float32))
+    off = 0
+    for t, x in zip(dx, xs):
+        c = x.shape[1]
+        assert rel_err(t.grad.cpu().numpy(), gy[:, off:off + c].numpy()) == 0.0
+        off += c
+
+
+def test_kth_smallest_is_exact():
+    """OHEM threshold (criterion.py:66-68): radix select must return the identical float, ties included."""
+    import ctypes as C
+    from npp_amd._lib import lib, check, stream_ptr
+    dev = _dev()
+    rng = np.random.default_rng(0)
+    vals = rng.random(200001).astype(np.float32)
+    vals[::7] = -1.0                      # ignored pixels
+    vals[5::11] = vals[5]                 # many exact ties
+    v = torch.from_numpy(vals).to(dev)
+    valid = np.sort(vals[vals >= 0])
+    for k in (0, 1, 1000, 131072, len(valid) - 1, 10 ** 7):
+        ws = torch.empty(260, dtype=torch.int32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        check(lib().npp_kth_smallest(v.data_ptr(), v.numel(), k, ws.data_ptr(), out.data_ptr(), stream_ptr()))
+        torch.cuda.synchronize()
+        assert float(out[0]) == float(valid[min(k, len(valid) - 1)]), k
+        assert int(out[1]) == len(valid)
