@@ -47,9 +47,27 @@ def cpu_baseline(size, budget_s=25.0):
     lpose = [torch.from_numpy(a[:, :-1].copy()) for a in lpose]
     lam_pose = torch.full((2,), -2.5, requires_grad=True)
     lam_par = torch.full((2,), 2.3, requires_grad=True)
+    def one():
+        for v in tensors.values():
+            v.grad = None
+        loss, _, _, _ = O.train_step_loss(tensors, images, lpar, lpose, lam_pose, lam_par)
+        loss.backward()
+
+    # pick the thread count that is fastest on this host (oneDNN over-subscribes badly on 100+ core boxes)
+    ncpu = os.cpu_count() or 8
+    best_t, best_dt = None, None
+    one()
+    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        t0 = time.time()
+        one()
+        dt = time.time() - t0
+        if best_dt is None or dt < best_dt:
+            best_t, best_dt = nt, dt
+    torch.set_num_threads(best_t)
     times = []
     t_start = time.time()
-    it = 0
+    it = 1
     while True:
         t0 = time.time()
         for v in tensors.values():

@@ -27,6 +27,10 @@ extern "C" {
 #endif
 
 enum { NPP_F32 = 0, NPP_BF16 = 1 };
+/* Per-channel f64 accumulators (BN statistics, BN-backward sums, bias gradients) are kept in NPP_STAT_REPLICAS
+ * copies: workgroup b adds into copy b % R, so at most (#workgroups / R) float atomics serialise on one address
+ * (same-address atomics cost ~100 ns each on gfx950).  Layout [R][len]; consumers take the replica count. */
+#define NPP_STAT_REPLICAS 16
 enum {
   NPP_OK = 0, NPP_E_SHAPE = -1, NPP_E_DTYPE = -2, NPP_E_ALIGN = -3, NPP_E_HIP = -4,
   NPP_E_UNSUPPORTED = -5, NPP_E_NULL = -6
@@ -70,7 +74,7 @@ int64_t npp_packed_weight_elems(int cout, int cin, int kh, int kw, int for_dgrad
 int npp_pack_weight(const float* w_oihw, int cout, int cin, int kh, int kw, int for_dgrad,
                     int dtype, void* out, void* stream);
 /* y = conv(relu?(x)) + bias; optional per-channel sum / sum-of-squares of y added into
- * stats[0..C) / stats[C..2C) (the BatchNorm batch statistics, operations.py:78);
+ * stats[r][0..C) / stats[r][C..2C), r < NPP_STAT_REPLICAS (the BatchNorm batch statistics, operations.py:78);
  * optional mask: y *= (mask > 0) (ReLU backward when this call is a dgrad). */
 int npp_conv_fwd(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask,
                  NppTensor* y, double* stats, const NppConvGeom* g, void* stream);
@@ -90,10 +94,10 @@ int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, float* dw /*[
                           const NppConvGeom* g, void* stream);
 
 /* ---- batch norm (train + eval): nn.BatchNorm2d everywhere, SURVEY §8 a20 ---------------------- */
-int npp_channel_stats(const NppTensor* x, double* stats /*[2C] added*/, void* stream);
+int npp_channel_stats(const NppTensor* x, double* stats /*[R][2C] added*/, void* stream);
 /* from (sum, sumsq, count): mean/invstd, scale = gamma*invstd, shift = beta - mean*scale, and the
- * running-stat update (momentum, unbiased var).  gamma/beta/running_* may be NULL. */
-int npp_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+ * running-stat update (momentum, unbiased var).  gamma/beta/running_* may be NULL.  stats = [nrep][2C]. */
+int npp_bn_finalize(const double* stats, int nrep, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked /* += 1 */,
                     float momentum, float eps,
                     float* scale_shift /*[2C]*/, float* mean_invstd /*[2C]*/, int c, void* stream);
@@ -104,13 +108,15 @@ int npp_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
  * (identity).  Fuses BN-apply of both branches with the cell's h1 + h2 (model_augment.py:58). */
 int npp_affine_add(NppTensor* out, const NppTensor* a, const float* ss_a, const NppTensor* b,
                    const float* ss_b, int relu, void* stream);
-/* sums[0..C) += sum dy', sums[C..2C) += sum dy' * xhat, dy' = dout * (out>0 if relu_out given) */
+/* sums[r][0..C) += sum dy', sums[r][C..2C) += sum dy' * xhat, dy' = dout * (out>0 if relu_out given) */
 int npp_bn_bwd_reduce(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,
-                      const float* mean_invstd, double* sums, void* stream);
-/* dy_raw = gamma*invstd*(dy' - sums0/count - xhat*sums1/count); dgamma = sums1, dbeta = sums0 */
+                      const float* mean_invstd, double* sums /*[R][2C]*/, void* stream);
+/* per-channel coefficients of dy_raw = A*dy' + B*y_raw + C  (= gamma*invstd*(dy' - s0/n - xhat*s1/n)),
+ * coeffs = [A[C] | B[C] | C[C]]; dgamma = s1, dbeta = s0 (optional).  sums = [nrep][2C]. */
+int npp_bn_bwd_coeffs(const double* sums, int nrep, double count, const float* mean_invstd, const float* gamma,
+                      float* coeffs, float* dgamma, float* dbeta, int c, void* stream);
 int npp_bn_bwd_apply(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,
-                     const float* mean_invstd, const float* gamma, const double* sums, double count,
-                     NppTensor* dy_raw, float* dgamma, float* dbeta, void* stream);
+                     const float* coeffs, NppTensor* dy_raw, void* stream);
 /* eval-mode / plain affine backward: dy = dout * scale * (out>0) */
 int npp_scale_mask(const NppTensor* dout, const float* scale /*[C] or NULL*/, const NppTensor* relu_out,
                    NppTensor* dx, void* stream);
@@ -147,7 +153,7 @@ int npp_bilinear_bwd(const NppTensor* dy, NppTensor* dx, void* stream);
 int npp_copy(const NppTensor* x, NppTensor* y, void* stream);                /* cast + channel-slice copy (cat) */
 int npp_nchw_to_nhwc(const float* src, int n, int c, int h, int w, NppTensor* dst, void* stream); /* pads channels with 0 */
 int npp_nhwc_to_nchw(const NppTensor* src, float* dst, void* stream);
-int npp_channel_sum(const NppTensor* x, double* out /*[C], added*/, void* stream);      /* conv bias grad */
+int npp_channel_sum(const NppTensor* x, double* out /*[R][C], added*/, void* stream);      /* conv bias grad */
 
 /* ---- loss heads ----------------------------------------------------------------------------------
  * heat-map MSE, core/criterion.py:98-128: sse += sum (pred - target)^2 ; target is f32 NCHW. */

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnpp_hip.so")
 
 NPP_F32, NPP_BF16 = 0, 1
+STAT_REPLICAS = 16   # NPP_STAT_REPLICAS in include/npp_hip.h
 FAM = {"none": 0, "conv_igemm": 1, "conv_wgrad": 2, "dwconv": 3, "bn": 4, "eltwise": 5, "pool": 6,
        "bilinear": 7, "loss": 8}
 
@@ -46,11 +47,12 @@ _SIGS = {
     "npp_dwconv_bwd_weight": [_T, _T, _P, _G, _P],
     "npp_channel_stats": [_T, _P, _P],
     "npp_channel_sum": [_T, _P, _P],
-    "npp_bn_finalize": [_P, C.c_double, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int, _P],
+    "npp_bn_finalize": [_P, C.c_int, C.c_double, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int, _P],
     "npp_bn_eval_coeffs": [_P, _P, _P, _P, C.c_float, _P, C.c_int, _P],
     "npp_affine_add": [_T, _T, _P, _T, _P, C.c_int, _P],
     "npp_bn_bwd_reduce": [_T, _T, _T, _P, _P, _P],
-    "npp_bn_bwd_apply": [_T, _T, _T, _P, _P, _P, C.c_double, _T, _P, _P, _P],
+    "npp_bn_bwd_coeffs": [_P, C.c_int, C.c_double, _P, _P, _P, _P, _P, C.c_int, _P],
+    "npp_bn_bwd_apply": [_T, _T, _T, _P, _T, _P],
     "npp_scale_mask": [_T, _P, _T, _T, _P],
     "npp_pool3x3_fwd": [_T, _T, _P, C.c_int, C.c_int, _P, _P],
     "npp_pool3x3_bwd": [_T, _P, _T, C.c_int, C.c_int, _P],
@@ -118,7 +120,9 @@ def stream_ptr() -> int:
 
 def new_nhwc(n: int, c: int, h: int, w: int, dtype, device, zero: bool = False, ld: int = 0) -> torch.Tensor:
     """Logical [n,c,h,w] tensor stored NHWC (optionally with a wider pixel stride ld)."""
-    ld = ld or c
+    if not ld:
+        ld = c if c % 8 == 0 else (c + 7) // 8 * 8    # odd channel counts (3, 6, 20, 2): 16-byte rows, zero pad
+        zero = zero or ld != c
     buf = (torch.zeros if zero else torch.empty)((n, h, w, ld), dtype=dtype, device=device)
     t = buf.permute(0, 3, 1, 2)
     return t[:, :c] if ld != c else t

@@ -20,23 +20,58 @@ from ._lib import check, desc, geom, lib, new_nhwc, ptr, stream_ptr, to_nhwc, tr
 BN_MOMENTUM = 0.1
 
 
+R = L.STAT_REPLICAS
+
+
 def _byref(t):
     return C.byref(desc(t))
+
+
+class _ZeroPool:
+    """Pre-zeroed scratch carved from large chunks: one memset per chunk instead of one fill launch per
+    statistics / gradient accumulator (~3000 tiny fills per training step otherwise)."""
+
+    def __init__(self, dtype, chunk_elems):
+        self.dtype, self.chunk = dtype, chunk_elems
+        self.buf, self.off = None, 0
+
+    def get(self, n: int, device) -> torch.Tensor:
+        n_al = (n + 63) // 64 * 64
+        if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
+            self.buf = torch.zeros(max(self.chunk, n_al), dtype=self.dtype, device=device)
+            self.off = 0
+        t = self.buf[self.off:self.off + n]
+        self.off += n_al
+        return t
+
+
+_zpool64 = _ZeroPool(torch.float64, 1 << 21)
+_zpool32 = _ZeroPool(torch.float32, 1 << 24)
+
+
+def zeros_f64(n, device):
+    return _zpool64.get(n, device)
+
+
+def zeros_f32(n, device):
+    return _zpool32.get(n, device)
 
 
 # --------------------------------------------------------------------------------------------------
 # packed-weight cache: f32 OIHW parameter -> MFMA operand image, rebuilt when the parameter changes
 # --------------------------------------------------------------------------------------------------
-_pack_cache = weakref.WeakKeyDictionary()   # parameter object -> {(for_dgrad, dtype): (version, data_ptr, packed)}
+_pack_cache = {}   # id(parameter) -> (weakref, {(for_dgrad, dtype): ((version, data_ptr), packed)})
 
 
 def packed_weight(w: torch.Tensor, for_dgrad: bool, dtype: torch.dtype) -> torch.Tensor:
     key = (bool(for_dgrad), dtype)
     ver = (w._version, w.data_ptr())
-    per = _pack_cache.get(w)
-    if per is None:
-        per = {}
-        _pack_cache[w] = per
+    wid = id(w)
+    ent = _pack_cache.get(wid)
+    if ent is None or ent[0]() is not w:
+        ent = (weakref.ref(w, lambda _r, _k=wid: _pack_cache.pop(_k, None)), {})
+        _pack_cache[wid] = ent
+    per = ent[1]
     hit = per.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
@@ -56,6 +91,20 @@ def clear_caches():
     _pack_cache.clear()
 
 
+def _gemm_ready(x: torch.Tensor) -> torch.Tensor:
+    """The MFMA gathers read whole 16-byte channel groups: a tensor whose channel count is not a multiple of 8
+    must sit in rows padded (with zeros) to the next multiple.  Tensors made by this package already do."""
+    c = x.shape[1]
+    if c % 8 == 0:
+        return x
+    ld = L.nhwc_ld(x)
+    if ld is not None and ld >= (c + 7) // 8 * 8 and ld % 8 == 0:
+        return x
+    y = new_nhwc(*x.shape, x.dtype, x.device)
+    check(lib().npp_copy(_byref(x), _byref(y), stream_ptr()), "npp_copy")
+    return y
+
+
 def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
@@ -70,7 +119,7 @@ def _conv_out(h, k, s, p, d):
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, relu_in, want_stats, out_hw):
-        x = to_nhwc(x)
+        x = _gemm_ready(to_nhwc(x))
         n, ci, h, w = x.shape
         co, _, kh, kw = weight.shape
         if out_hw is None:
@@ -78,7 +127,7 @@ class _Conv2d(Function):
         else:
             oh, ow = out_hw
         y = new_nhwc(n, co, oh, ow, x.dtype, x.device)
-        stats = torch.zeros(2 * co, dtype=torch.float64, device=x.device) if want_stats else None
+        stats = zeros_f64(R * 2 * co, x.device) if want_stats else None
         g = geom(kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 1, relu_in)
         wp = packed_weight(weight, False, x.dtype)
         bf = None
@@ -101,6 +150,7 @@ class _Conv2d(Function):
         dy = to_nhwc(dy)
         if dy.dtype != x.dtype:
             dy = cast(dy, x.dtype)
+        dy = _gemm_ready(dy)
         n, ci, h, w = x.shape
         co, _, kh, kw = weight.shape
         dx = dw = db = None
@@ -114,7 +164,7 @@ class _Conv2d(Function):
                                      C.byref(g), s), "npp_conv_fwd(dgrad)")
         if ctx.needs_input_grad[1]:
             nel = lib().npp_packed_weight_elems(co, ci, kh, kw, 0)
-            dwp = torch.zeros(nel, dtype=torch.float32, device=x.device)
+            dwp = zeros_f32(nel, x.device)
             g = geom(kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 1, relu_in)
             check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
             dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
@@ -122,9 +172,9 @@ class _Conv2d(Function):
             if dw.dtype != weight.dtype:
                 dw = dw.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
-            acc = torch.zeros(co, dtype=torch.float64, device=x.device)
+            acc = zeros_f64(R * co, x.device)
             check(lib().npp_channel_sum(_byref(dy), acc.data_ptr(), s), "npp_channel_sum")
-            db = acc.float()
+            db = acc.view(R, co).sum(0).float()
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -180,7 +230,7 @@ class _DwConv2d(Function):
             check(lib().npp_dwconv_bwd_data(_byref(dy), wf.data_ptr(), _byref(x) if relu_in else None, _byref(dx),
                                             C.byref(g), s), "npp_dwconv_bwd_data")
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+            dw = zeros_f32(weight.numel(), x.device).view(weight.shape)
             check(lib().npp_dwconv_bwd_weight(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_dwconv_bwd_weight")
             if dw.dtype != weight.dtype:
                 dw = dw.to(weight.dtype)
@@ -230,9 +280,12 @@ def _bn_coeffs(side: BnSide, training: bool, device):
         stats = side.stats
         if stats is None:
             stats = channel_stats(side.x)
+        nrep = stats.numel() // (2 * c)
         count = float(side.x.shape[0] * side.x.shape[2] * side.x.shape[3])
         grp, ws = _sync_group(bn)
         if grp is not None:
+            stats = stats.view(nrep, 2 * c).sum(0)
+            nrep = 1
             dist.all_reduce(stats, group=grp)
             count *= ws
         side.count = count
@@ -240,7 +293,7 @@ def _bn_coeffs(side: BnSide, training: bool, device):
         track = bn.track_running_stats and bn.running_mean is not None and training
         mom = bn.momentum if bn.momentum is not None else 0.1
         nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
-        check(lib().npp_bn_finalize(stats.data_ptr(), count, ptr(gamma), ptr(beta),
+        check(lib().npp_bn_finalize(stats.data_ptr(), nrep, count, ptr(gamma), ptr(beta),
                                     ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                                     ptr(nbt), float(mom), float(bn.eps), ss.data_ptr(), mi.data_ptr(), c, s),
               "npp_bn_finalize")
@@ -294,32 +347,39 @@ class _BnAdd(Function):
                         check(lib().npp_scale_mask(_byref(dout), None, _byref(yrelu), _byref(dx), s), "npp_scale_mask")
                 return dx, None, None
             c = x.shape[1]
-            sums = torch.zeros(2 * c, dtype=torch.float64, device=x.device)
+            sums = zeros_f64(R * 2 * c, x.device)
             check(lib().npp_bn_bwd_reduce(_byref(dout), _byref(x), tref(yrelu), mi.data_ptr(), sums.data_ptr(), s),
                   "npp_bn_bwd_reduce")
             gamma = bn.weight.detach() if bn.weight is not None else None
             if batch:
                 grp, ws = _sync_group(bn)
+                nrep = R
                 dgt = dbt = None
                 if grp is not None:
                     # SyncBatchNorm: weight/bias grads are the LOCAL sums (DDP averages them afterwards);
                     # the input gradient uses the all-reduced sums over the global count.
-                    local = sums.clone()
-                    dist.all_reduce(sums, group=grp)
+                    local = sums.view(R, 2 * c).sum(0)
                     dg, db = local[c:].float(), local[:c].float()
+                    sums = local.clone()
+                    nrep = 1
+                    dist.all_reduce(sums, group=grp)
                 else:
                     dgt = torch.empty(c, dtype=torch.float32, device=x.device)
                     dbt = torch.empty(c, dtype=torch.float32, device=x.device)
                     dg, db = dgt, dbt
-                dx = new_nhwc(*x.shape, x.dtype, x.device)
-                check(lib().npp_bn_bwd_apply(_byref(dout), _byref(x), tref(yrelu), mi.data_ptr(), ptr(gamma),
-                                             sums.data_ptr(), float(count), _byref(dx), ptr(dgt), ptr(dbt), s),
-                      "npp_bn_bwd_apply")
+                co = torch.empty(3 * c, dtype=torch.float32, device=x.device)
+                check(lib().npp_bn_bwd_coeffs(sums.data_ptr(), nrep, float(count), mi.data_ptr(), ptr(gamma), co.data_ptr(),
+                                              ptr(dgt), ptr(dbt), c, s), "npp_bn_bwd_coeffs")
+                if need_x:
+                    dx = new_nhwc(*x.shape, x.dtype, x.device)
+                    check(lib().npp_bn_bwd_apply(_byref(dout), _byref(x), tref(yrelu), co.data_ptr(), _byref(dx), s),
+                          "npp_bn_bwd_apply")
             else:
                 if need_x:
                     dx = new_nhwc(*x.shape, x.dtype, x.device)
                     check(lib().npp_scale_mask(_byref(dout), ss.data_ptr(), tref(yrelu), _byref(dx), s), "npp_scale_mask")
-                dg, db = sums[c:].float(), sums[:c].float()
+                tot = sums.view(R, 2 * c).sum(0)
+                dg, db = tot[c:].float(), tot[:c].float()
             return (dx if need_x else None), (dg if need_g else None), (db if need_b else None)
 
         ni = ctx.needs_input_grad
@@ -354,7 +414,7 @@ def add(a, b):
 
 def channel_stats(x: torch.Tensor) -> torch.Tensor:
     x = to_nhwc(x)
-    st = torch.zeros(2 * x.shape[1], dtype=torch.float64, device=x.device)
+    st = zeros_f64(R * 2 * x.shape[1], x.device)
     check(lib().npp_channel_stats(_byref(x.detach()), st.data_ptr(), stream_ptr()), "npp_channel_stats")
     return st
 
@@ -370,7 +430,7 @@ class _Pool3x3(Function):
         oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
         y = new_nhwc(n, c, oh, ow, x.dtype, x.device)
         amax = None if is_avg else torch.empty((n, oh, ow, c), dtype=torch.uint8, device=x.device)
-        stats = torch.zeros(2 * c, dtype=torch.float64, device=x.device) if want_stats else None
+        stats = zeros_f64(R * 2 * c, x.device) if want_stats else None
         check(lib().npp_pool3x3_fwd(_byref(x), _byref(y), ptr(amax), int(is_avg), stride, ptr(stats), stream_ptr()),
               "npp_pool3x3_fwd")
         ctx.save_for_backward(amax)
@@ -401,7 +461,7 @@ class _Pool2x2(Function):
         x = to_nhwc(x)
         n, c, h, w = x.shape
         y = new_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
-        stats = torch.zeros(2 * c, dtype=torch.float64, device=x.device) if want_stats else None
+        stats = zeros_f64(R * 2 * c, x.device) if want_stats else None
         check(lib().npp_pool2x2_fwd(_byref(x), _byref(y), int(is_avg), ptr(stats), stream_ptr()), "npp_pool2x2_fwd")
         ctx.save_for_backward(None if is_avg else x)
         ctx.cfg = (is_avg, tuple(x.shape), x.dtype)
@@ -438,7 +498,7 @@ class _SEScale(Function):
         n, c, h, w = x.shape
         dev = x.device
         s = stream_ptr()
-        pooled = torch.zeros((n, c), dtype=torch.float32, device=dev)
+        pooled = zeros_f32(n * c, dev).view(n, c)
         check(lib().npp_global_avgpool(_byref(x), pooled.data_ptr(), s), "npp_global_avgpool")
         hidden = torch.empty((n, c // 2), dtype=torch.float32, device=dev)
         gate = torch.empty((n, c), dtype=torch.float32, device=dev)
@@ -459,12 +519,12 @@ class _SEScale(Function):
         n, c, h, w = x.shape
         dev = x.device
         s = stream_ptr()
-        dgate = torch.zeros((n, c), dtype=torch.float32, device=dev)
+        dgate = zeros_f32(n * c, dev).view(n, c)
         check(lib().npp_se_bwd_reduce(_byref(dy), _byref(x), dgate.data_ptr(), s), "npp_se_bwd_reduce")
-        dw1 = torch.zeros(w1.shape, dtype=torch.float32, device=dev)
-        db1 = torch.zeros(c // 2, dtype=torch.float32, device=dev)
-        dw2 = torch.zeros(w2.shape, dtype=torch.float32, device=dev)
-        db2 = torch.zeros(c, dtype=torch.float32, device=dev)
+        dw1 = zeros_f32(w1.numel(), dev).view(w1.shape)
+        db1 = zeros_f32(c // 2, dev)
+        dw2 = zeros_f32(w2.numel(), dev).view(w2.shape)
+        db2 = zeros_f32(c, dev)
         dpooled = torch.empty((n, c), dtype=torch.float32, device=dev)
         w1f, w2f = w1.detach().float().contiguous(), w2.detach().float().contiguous()
         check(lib().npp_se_gate_bwd(pooled.data_ptr(), hidden.data_ptr(), gate.data_ptr(), dgate.data_ptr(),

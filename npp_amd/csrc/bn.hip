@@ -21,7 +21,7 @@ static inline ColMap col_map(long c, int v) {
 static inline dim3 col_grid(const ColMap& m, long npix) {
   long bx = (npix + m.rows - 1) / m.rows;
   // enough blocks to fill the chip, few enough that the f64 atomics stay negligible
-  const long cap = 1024;
+  const long cap = 512;
   if (bx > cap) bx = cap;
   if (bx < 1) bx = 1;
   return dim3((unsigned)bx, (unsigned)((m.cv + m.cols_blk - 1) / m.cols_blk));
@@ -46,7 +46,7 @@ NPP_DEV void block_col_reduce(double (&acc)[NQ][V], float* red /*[256][NQ*V] dou
         double s = 0.0;
         for (int rr = 0; rr < rows; ++rr) s += dred[(long)(rr * cols_blk + col) * NQ * V + qn * V + j];
         const int ch = colg * V + j;
-        if (ch < C) atomicAdd(outs[qn] + ch, s);
+        if (ch < C) atomicAdd(outs[qn] + ch, s);   // outs already point at this block's replica
       }
   }
 }
@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
       for (int j = 0; j < V; ++j) { acc[0][j] += v[j]; acc[1][j] += (double)v[j] * v[j]; }
     }
   }
-  double* outs[2] = {stats, stats + C};
+  double* rep = stats + (long)(blockIdx.x % NPP_STAT_REPLICAS) * (want_sq ? 2 : 1) * C;
+  double* outs[2] = {rep, rep + C};
   if (want_sq) block_col_reduce<2, V>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
   else {
     double a1[1][V];
@@ -81,14 +82,16 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
   }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* gamma, const float* beta,
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int nrep, double count, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, long* nbt, float momentum, float eps,
                                    float* ss, float* mi, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && nbt) nbt[0] += 1;
   if (c >= C) return;
-  const double mean = stats[c] / count;
-  double var = stats[C + c] / count - mean * mean;
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = 0; r < nrep; ++r) { s0 += stats[(long)r * 2 * C + c]; s1 += stats[(long)r * 2 * C + C + c]; }
+  const double mean = s0 / count;
+  double var = s1 / count - mean * mean;
   if (var < 0.0) var = 0.0;
   const double invstd = 1.0 / sqrt(var + (double)eps);
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -177,24 +180,35 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       }
     }
   }
-  double* outs[2] = {sums, sums + C};
+  double* rep = sums + (long)(blockIdx.x % NPP_STAT_REPLICAS) * 2 * C;
+  double* outs[2] = {rep, rep + C};
   block_col_reduce<2, V>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
+}
+
+__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums, int nrep, double inv_count, const float* __restrict__ mi,
+                                     const float* __restrict__ gamma, float* __restrict__ co, float* dgamma, float* dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = 0; r < nrep; ++r) { s0 += sums[(long)r * 2 * C + c]; s1 += sums[(long)r * 2 * C + C + c]; }
+  const float mean = mi[c], invstd = mi[C + c];
+  const float g = gamma ? gamma[c] : 1.f;
+  const float m0 = (float)(s0 * inv_count), m1 = (float)(s1 * inv_count);
+  const float k1 = g * invstd;
+  // dy = k1*(d - m0 - (v - mean)*invstd*m1)
+  co[c] = k1;
+  co[C + c] = -k1 * invstd * m1;
+  co[2 * C + c] = k1 * (mean * invstd * m1 - m0);
+  if (dgamma) dgamma[c] = (float)s1;
+  if (dbeta) dbeta[c] = (float)s0;
 }
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
                                                            long ldy, const T* __restrict__ ro, long ldr,
-                                                           const float* __restrict__ mi, const float* __restrict__ gamma,
-                                                           const double* __restrict__ sums, double inv_count,
-                                                           T* __restrict__ dy, long ldo, float* dgamma, float* dbeta,
+                                                           const float* __restrict__ co, T* __restrict__ dy, long ldo,
                                                            long npix, int C, int cv) {
   const long total = npix * cv;
-  if (blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < C; c += 256) {
-      if (dgamma) dgamma[c] = (float)sums[C + c];
-      if (dbeta) dbeta[c] = (float)sums[c];
-    }
-  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long p = i / cv;
     const int c0 = (int)(i - p * cv) * V;
@@ -208,14 +222,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       for (int j = 0; j < V; ++j) d[j] = r[j] > 0.f ? d[j] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const int ch = c0 + j;
-      const float mean = mi[ch], invstd = mi[C + ch];
-      const float g = gamma ? gamma[ch] : 1.f;
-      const float m0 = (float)(sums[ch] * inv_count), m1 = (float)(sums[C + ch] * inv_count);
-      const float xh = (v[j] - mean) * invstd;
-      o[j] = g * invstd * (d[j] - m0 - xh * m1);
-    }
+    for (int j = 0; j < V; ++j) o[j] = fmaf(co[c0 + j], d[j], fmaf(co[C + c0 + j], v[j], co[2 * C + c0 + j]));
     stv<T, V>(dy + p * ldo + c0, o);
   }
 }
@@ -271,11 +278,11 @@ extern "C" int npp_channel_sum(const NppTensor* x, double* out, void* stream) {
   return npp_check_launch("channel_sum");
 }
 
-extern "C" int npp_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+extern "C" int npp_bn_finalize(const double* stats, int nrep, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                                float eps, float* scale_shift, float* mean_invstd, int c, void* stream) {
   NPP_REQUIRE(stats && scale_shift && c > 0 && count > 0, NPP_E_NULL, "npp_bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, count, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, nrep, count, gamma,
                      beta, running_mean, running_var, (long*)num_batches_tracked, momentum, eps, scale_shift, mean_invstd, c);
   return npp_check_launch("bn_finalize");
 }
@@ -325,10 +332,17 @@ extern "C" int npp_bn_bwd_reduce(const NppTensor* dout, const NppTensor* y_raw, 
   return npp_check_launch("bn_bwd_reduce");
 }
 
+extern "C" int npp_bn_bwd_coeffs(const double* sums, int nrep, double count, const float* mean_invstd, const float* gamma,
+                                 float* coeffs, float* dgamma, float* dbeta, int c, void* stream) {
+  NPP_REQUIRE(sums && mean_invstd && coeffs && c > 0 && count > 0 && nrep >= 1, NPP_E_NULL, "npp_bn_bwd_coeffs: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, nrep, 1.0 / count,
+                     mean_invstd, gamma, coeffs, dgamma, dbeta, c);
+  return npp_check_launch("bn_bwd_coeffs");
+}
+
 extern "C" int npp_bn_bwd_apply(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,
-                                const float* mean_invstd, const float* gamma, const double* sums, double count,
-                                NppTensor* dy_raw, float* dgamma, float* dbeta, void* stream) {
-  NPP_REQUIRE(dout && y_raw && mean_invstd && sums && dy_raw, NPP_E_NULL, "npp_bn_bwd_apply: null pointer");
+                                const float* coeffs, NppTensor* dy_raw, void* stream) {
+  NPP_REQUIRE(dout && y_raw && coeffs && dy_raw, NPP_E_NULL, "npp_bn_bwd_apply: null pointer");
   NPP_REQUIRE(same_shape(dout, y_raw) && same_shape(dout, dy_raw) && (!relu_out || same_shape(dout, relu_out)), NPP_E_SHAPE,
               "npp_bn_bwd_apply: shape mismatch");
   NPP_REQUIRE(dtype_ok(dout) && dout->dtype == y_raw->dtype && dout->dtype == dy_raw->dtype, NPP_E_DTYPE,
@@ -339,8 +353,8 @@ extern "C" int npp_bn_bwd_apply(const NppTensor* dout, const NppTensor* y_raw, c
     const int cv = (int)(dout->c / V);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(grid_for(npix(dout) * cv)), dim3(256), 0, (hipStream_t)stream,
                        (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
-                       relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, mean_invstd, gamma,
-                       sums, 1.0 / count, (T*)dy_raw->ptr, (long)dy_raw->ld, dgamma, dbeta, (long)npix(dout), (int)dout->c, cv);
+                       relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, coeffs,
+                       (T*)dy_raw->ptr, (long)dy_raw->ld, (long)npix(dout), (int)dout->c, cv);
   });
   return npp_check_launch("bn_bwd_apply");
 }

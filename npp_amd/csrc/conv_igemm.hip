@@ -270,8 +270,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
         q += red[(tt * VEC + j) * 2 + 1];
       }
       if (n0 + col < p.Cout) {
-        atomicAdd(p.stats + n0 + col, (double)s);
-        atomicAdd(p.stats + p.Cout + n0 + col, (double)q);
+        double* st = p.stats + (long)(mtile % NPP_STAT_REPLICAS) * 2 * p.Cout;
+        atomicAdd(st + n0 + col, (double)s);
+        atomicAdd(st + p.Cout + n0 + col, (double)q);
       }
     }
   }

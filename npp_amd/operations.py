@@ -188,7 +188,8 @@ class FactorizedReduce(_BnOp):
         st = None
         if want:
             c = y1.shape[1]
-            st = torch.cat([s1[:c], s2[:c], s1[c:], s2[c:]])
+            a, b = s1.view(-1, 2 * c), s2.view(-1, 2 * c)      # [replica][sum | sumsq] per half
+            st = torch.cat([a[:, :c], b[:, :c], a[:, c:], b[:, c:]], dim=1).reshape(-1)
         return BnSide(y, self.bn, st)
 
 

@@ -39,3 +39,11 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def rel_l2(a, b):
+    """||a-b|| / ||b||: the bf16 (storage precision) checks use the norm, because rounding moves arg-max
+    ties of max-pool and individual elements by O(1) while the tensor as a whole stays close."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
