@@ -19,18 +19,9 @@
 // Replaces nn.Conv2d fwd/bwd-data at operations.py:77,149-150,182-183,215,240 and
 // model_augment.py:244-272,332-351,371-397,594,644.
 #include "common.h"
+#include "conv_params.h"
 
 namespace {
-
-struct IgemmParams {
-  const void* x; const void* w; const float* bias; const void* mask; void* y; double* stats;
-  int N, H, W, Cin; long ldx;
-  int OH, OW, Cout; long ldy; long ldm;
-  int Cp, Kpad;
-  int KH, KW, sh, sw, ph, pw, dh, dw, uph, upw, relu_in;
-  int M, mtiles, ntiles;
-  int vec_io;
-};
 
 constexpr int BM = 128;
 constexpr int BKB = 128;          // bytes of K per stage
@@ -132,8 +123,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
       u32x4 v = {0u, 0u, 0u, 0u};
       if (ok) {
         const long off = (long)(pixb[i] + ih * p.W + iw) * p.ldx + c;
-        v = *reinterpret_cast<const u32x4*>(xg + off);
-        if (p.relu_in) v = relu16<T>(v);
+        v = *reinterpret_cast<const u32x4*>(xg + off);   // ReLU at store_stage (no wait on the load here)
       }
       ra[i] = v;
     }
@@ -150,7 +140,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     unsigned char* sA = smem + buf * STAGE;
     unsigned char* sB = sA + BM * PITCH;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sA + (row0 + 32 * i) * PITCH + piece * 16) = ra[i];
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<u32x4*>(sA + (row0 + 32 * i) * PITCH + piece * 16) = p.relu_in ? relu16<T>(ra[i]) : ra[i];
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) *reinterpret_cast<u32x4*>(sB + (row0 + 32 * i) * PITCH + piece * 16) = rb[i];
   };
@@ -374,6 +365,7 @@ extern "C" int npp_conv_fwd(const NppTensor* x, const void* w_packed, const floa
   const double flops = 2.0 * (double)M * p.Cout * (double)(g->kh * g->kw) * p.Cin;
   const double bytes = ((double)x->n * x->h * x->w * x->c + (double)M * y->c + (double)p.Cout * g->kh * g->kw * p.Cin) * esize(x->dtype);
   ProfScope prof(NPP_FAM_CONV_IGEMM, x->dtype, s, flops, bytes);
+  if (conv_s1_launch(p, x->dtype, s)) return npp_check_launch("conv_s1");
 #define LAUNCH(T, BN_) hipLaunchKernelGGL((conv_igemm_kernel<T, BN_>), dim3(grid), dim3(256), 0, s, p)
   if (x->dtype == NPP_BF16) {
     if (bn == 128) LAUNCH(bf16_t, 128); else if (bn == 64) LAUNCH(bf16_t, 64); else LAUNCH(bf16_t, 32);

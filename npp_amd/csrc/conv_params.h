@@ -1,0 +1,13 @@
+// Parameter block shared by the dense-conv kernels (generic implicit GEMM and the stride-1 fast path).
+#pragma once
+struct IgemmParams {
+  const void* x; const void* w; const float* bias; const void* mask; void* y; double* stats;
+  int N, H, W, Cin; long ldx;
+  int OH, OW, Cout; long ldy; long ldm;
+  int Cp, Kpad;
+  int KH, KW, sh, sw, ph, pw, dh, dw, uph, upw, relu_in;
+  int M, mtiles, ntiles;
+  int vec_io;
+};
+// stride-1 "same" convolution fast path (conv_s1.hip); returns false when the shape is not eligible
+bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream);

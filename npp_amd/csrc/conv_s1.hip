@@ -1,0 +1,394 @@
+// Stride-1 "same" convolution (1x1, 3x3, ... dil 1) forward / data-gradient: the fast path that carries
+// ~90 % of NPPNet's FLOPs (128->128 3x3 @96^2, the 1024->512/384 heads, the 512->128 fuse-cell inputs, ...).
+//
+// Compared with the generic gather kernel (conv_igemm.hip) the input tile is staged ONCE per 64-channel chunk
+// and reused by every tap:
+//   * pixels are addressed on a ZERO-GAPPED axis: q = (n*(H+P) + y)*(W+P) + x, i.e. P zero pixels after every
+//     image row and P zero rows after every image.  An output tile is BM consecutive q; its input footprint for
+//     a KxK kernel is the contiguous range [q0 - halo, q0 + BM + halo), halo = P*(W+P) + P, and tap (kh,kw) of
+//     output row m is simply footprint row m + halo + (kh-P)*(W+P) + (kw-P): the gaps supply the zero padding,
+//     so the hot loop has no bounds test, no mask and no per-tap gather (1-3 % of the MFMA rows are gap rows).
+//   * the footprint is copied HBM -> registers -> (ReLU, once) -> LDS as 128-byte rows at a 144-byte pitch
+//     (conflict-free ds_read_b128 fragments, k-step as an immediate offset).
+//   * weights for (chunk, tap) are a [128 x 64] tile of the packed matrix, double buffered; the A footprint is
+//     double buffered per chunk; one barrier per stage (16 MFMAs of 32x32x16 per wave).
+// Block = BM x 128 outputs, BM/64 x 2 waves of 64 x 64, one block per CU (up to 147 KiB of the 160 KiB LDS).
+// Epilogue as in conv_igemm.hip (bias, ReLU-backward mask, rounding, BN statistics, 16-byte stores).
+#include "common.h"
+#include "conv_params.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int KCB = 128;       // bytes of K (channels) per LDS row = per chunk
+constexpr int BN = 128;
+constexpr int PITCH = KCB + 16;   // LDS row pitch (bytes)
+constexpr int BTILE = BN * PITCH;
+
+template <typename T> NPP_DEV u32x4 relu16s(u32x4 v);
+template <> NPP_DEV u32x4 relu16s<float>(u32x4 v) {
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = __float_as_uint(fmaxf(__uint_as_float(v[i]), 0.f));
+  return o;
+}
+template <> NPP_DEV u32x4 relu16s<bf16_t>(u32x4 v) {
+  s16x8 s = __builtin_bit_cast(s16x8, v);
+  s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  s = __builtin_elementwise_max(s, z);
+  return __builtin_bit_cast(u32x4, s);
+}
+
+template <typename T> NPP_DEV void mma_frag_s(f32x16& acc, u32x4 a, u32x4 b);
+template <> NPP_DEV void mma_frag_s<bf16_t>(f32x16& acc, u32x4 a, u32x4 b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> NPP_DEV void mma_frag_s<float>(f32x16& acc, u32x4 a, u32x4 b) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
+}
+
+struct S1Extra {
+  int P, halo, AR, apt, nchunks, taps;
+  int Wp, Hp;  // gapped row length / rows per image
+  long Mp;     // gapped pixel count
+  int abufs;   // 2: A footprint double buffered (1x1: a new footprint every stage); 1: single buffer (KxK: one per K*K stages)
+  long NHW;
+  int dbg;   // timing experiments only (NPP_S1_DBG): 1 = skip the main loop, 2 = skip the epilogue stores, 4 = no stats
+};
+
+template <typename T, int BM>
+__global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra e) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int KC = KCB / (int)sizeof(T);       // channels per chunk: 64 bf16 / 32 f32
+  constexpr int NT = BM * 2;
+  constexpr int WAVES_M = BM / 64;
+  constexpr int BPT = (BN * 8) / NT;             // B pieces per thread per stage
+  constexpr int APT_MAX = (BM == 128) ? 12 : 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int asz = e.AR * PITCH;
+  unsigned char* const sA0 = smem;
+  unsigned char* const sB0 = smem + e.abufs * asz;
+
+  const int t = threadIdx.x;
+  const int nwg = gridDim.x;
+  int lid;
+  {
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int ntile = lid % p.ntiles, mtile = lid / p.ntiles;
+  const long q0 = (long)mtile * BM;          // first gapped pixel of this tile
+  const int n0 = ntile * BN;
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+  const int img = e.Hp * e.Wp;
+
+  // ---- staging roles ------------------------------------------------------------------------------
+  const T* asrc[APT_MAX];
+  int adst[APT_MAX];
+  {
+    // this thread stages footprint rows j = (t>>3) + i*(NT/8); decode the first one (shifted by one image so the
+    // dividend is non-negative), then walk the gapped axis incrementally: no division per row.
+    const int pc8 = t & 7;
+    const int j0 = t >> 3;
+    const int qq = (int)(q0 - e.halo) + j0 + img;
+    int n = qq / img - 1;
+    const int rem = qq - (n + 1) * img;
+    int y = rem / e.Wp, x = rem - y * e.Wp;
+#pragma unroll
+    for (int i = 0; i < APT_MAX; ++i) {
+      const int j = j0 + i * (NT / 8);
+      const bool in_fp = (i < e.apt) && (j < e.AR);
+      const T* src = nullptr;
+      if (in_fp && n >= 0 && n < p.N && y < p.H && x < p.W)
+        src = xg + ((long)(n * p.H + y) * p.W + x) * p.ldx + pc8 * VEC;
+      asrc[i] = src;
+      adst[i] = in_fp ? j * PITCH + pc8 * 16 : -1;
+      x += NT / 8;
+      while (x >= e.Wp) { x -= e.Wp; ++y; }
+      while (y >= e.Hp) { y -= e.Hp; ++n; }
+    }
+  }
+  const T* bsrc[BPT];
+  int bdst[BPT];
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) {
+    const int el = t + i * NT;
+    const int n = el >> 3, pc8 = el & 7;
+    bsrc[i] = wg + (long)(n0 + n) * p.Kpad + pc8 * VEC;
+    bdst[i] = n * PITCH + pc8 * 16;
+  }
+  u32x4 ra[APT_MAX], rb[BPT];
+
+  auto load_A = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < APT_MAX; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (asrc[i]) v = *reinterpret_cast<const u32x4*>(asrc[i] + (long)chunk * KC);
+      ra[i] = v;   // ReLU is applied at store_A: touching the value here would wait for the load
+    }
+  };
+  auto store_A = [&](int buf) {
+    unsigned char* d = sA0 + buf * asz;
+#pragma unroll
+    for (int i = 0; i < APT_MAX; ++i)
+      if (adst[i] >= 0) *reinterpret_cast<u32x4*>(d + adst[i]) = p.relu_in ? relu16s<T>(ra[i]) : ra[i];
+  };
+  auto load_B = [&](int chunk, int tap) {
+    const long koff = (long)tap * p.Cp + (long)chunk * KC;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) rb[i] = *reinterpret_cast<const u32x4*>(bsrc[i] + koff);
+  };
+  auto store_B = [&](int buf) {
+    unsigned char* d = sB0 + buf * BTILE;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) *reinterpret_cast<u32x4*>(d + bdst[i]) = rb[i];
+  };
+
+  // ---- compute roles ------------------------------------------------------------------------------
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int boff = (wn * 64 + r) * PITCH + h * 16;      // + ni*32*PITCH + ks*32 as immediates
+  const int aoff = (wm * 64 + r) * PITCH + h * 16;      // + tap offset + mi*32*PITCH + ks*32
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int el = 0; el < 16; ++el) acc[mi][ni][el] = 0.f;
+
+  const int nstages = (e.dbg & 1) ? 0 : e.nchunks * e.taps;
+  // stage counters: (chunk, tap) of stages s, s+1, s+2
+  int c0 = 0, t0 = 0, c1 = 0, t1 = 1, c2, t2;
+  if (t1 == e.taps) { t1 = 0; c1 = 1; }
+  c2 = c1; t2 = t1 + 1;
+  if (t2 == e.taps) { t2 = 0; ++c2; }
+
+  load_A(0);
+  load_B(0, 0);
+  store_A(0);
+  store_B(0);
+  if (nstages > 1) load_B(c1, t1);                    // in flight during stage 0
+  if (e.abufs == 2 && nstages > 1) load_A(1);
+  __syncthreads();
+
+  for (int s = 0; s < nstages; ++s) {
+    const bool has1 = s + 1 < nstages, has2 = s + 2 < nstages;
+    // registers hold stage s+1 (issued one full stage ago): put it in the other LDS buffer (last read in stage
+    // s-1, fenced by the barrier that ended it), then refill the registers with stage s+2.
+    if (has1) {
+      store_B((s + 1) & 1);
+      if (e.abufs == 2) store_A((s + 1) & 1);
+    }
+    if (has2) {
+      load_B(c2, t2);
+      if (e.abufs == 2) load_A(c2);
+    }
+    const bool fetch_fp = (e.abufs == 1) && (t0 == 0) && (c0 + 1 < e.nchunks);   // KxK: next chunk's footprint
+    if (fetch_fp) load_A(c0 + 1);
+
+    const int kh = t0 / p.KW, kw = t0 - kh * p.KW;
+    const int off = e.halo + (kh - e.P) * e.Wp + (kw - e.P);
+    const unsigned char* a = sA0 + ((c0 & 1) & (e.abufs - 1)) * asz + off * PITCH + aoff;
+    const unsigned char* b = sB0 + (s & 1) * BTILE + boff;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) fa[mi] = *reinterpret_cast<const u32x4*>(a + mi * 32 * PITCH + ks * 32);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(b + ni * 32 * PITCH + ks * 32);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) mma_frag_s<T>(acc[mi][ni], fa[mi], fb[ni]);
+    }
+    if (e.abufs == 1 && has1 && t1 == 0) {
+      __syncthreads();          // every wave is done with this chunk's footprint
+      store_A(0);
+    }
+    __syncthreads();
+    c0 = c1; t0 = t1; c1 = c2; t1 = t2;
+    if (++t2 == e.taps) { t2 = 0; ++c2; }
+  }
+
+  // ---- epilogue: two rounds of 128 rows through an LDS C tile ------------------------------------
+  constexpr int CP = BN + 4;
+  float* sC = reinterpret_cast<float*>(smem);
+  constexpr int PCOLS = BN / VEC;
+  constexpr int RSTEP = NT / PCOLS;
+  const int pc = t % PCOLS, pr = t / PCOLS;
+  const int nbase = n0 + pc * VEC;
+  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+  const T* __restrict__ mg = reinterpret_cast<const T*>(p.mask);
+  float bsum[VEC], bsq[VEC], bias[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    bsum[j] = 0.f; bsq[j] = 0.f;
+    bias[j] = (p.bias && nbase + j < p.Cout) ? p.bias[nbase + j] : 0.f;
+  }
+  const bool full_vec = p.vec_io && (nbase + VEC <= p.Cout);
+  constexpr int ROUNDS = BM / 128;
+  for (int rd = 0; rd < ((e.dbg & 2) ? 0 : ROUNDS); ++rd) {
+    if (rd > 0) __syncthreads();
+    if ((wm >> 1) == rd) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int el = 0; el < 16; ++el) {
+            const int row = (wm & 1) * 64 + mi * 32 + (el & 3) + 8 * (el >> 2) + 4 * h;
+            const int col = wn * 64 + ni * 32 + r;
+            sC[row * CP + col] = acc[mi][ni][el];
+          }
+    }
+    __syncthreads();
+    int dn = 0, dy = 0, dx = 0;
+    if (e.P) {
+      const int qs = (int)q0 + rd * 128 + pr;
+      dn = qs / img;
+      const int rem = qs - dn * img;
+      dy = rem / e.Wp;
+      dx = rem - dy * e.Wp;
+    }
+    for (int row = pr; row < 128; row += RSTEP) {
+      const long q = q0 + rd * 128 + row;
+      if (q >= e.Mp) break;
+      if (nbase >= p.Cout) break;
+      long m = q;
+      if (e.P) {      // gapped -> real pixel index; gap rows produce nothing
+        const bool real = dy < p.H && dx < p.W;
+        m = (long)(dn * p.H + dy) * p.W + dx;
+        dx += RSTEP;
+        while (dx >= e.Wp) { dx -= e.Wp; ++dy; }
+        while (dy >= e.Hp) { dy -= e.Hp; ++dn; }
+        if (!real) continue;
+      }
+      float v[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = sC[row * CP + pc * VEC + j] + bias[j];
+      if (full_vec) {
+        if (mg) {
+          float mk[VEC];
+          Vec16<T>::load(mg + m * p.ldm + nbase, mk);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] = mk[j] > 0.f ? v[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          v[j] = Elt<T>::round(v[j]);
+          bsum[j] += v[j];
+          bsq[j] += v[j] * v[j];
+        }
+        Vec16<T>::store(yg + m * p.ldy + nbase, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          if (nbase + j < p.Cout) {
+            if (mg && !(Elt<T>::ld(mg + m * p.ldm + nbase + j) > 0.f)) v[j] = 0.f;
+            v[j] = Elt<T>::round(v[j]);
+            bsum[j] += v[j];
+            bsq[j] += v[j] * v[j];
+            Elt<T>::st(yg + m * p.ldy + nbase + j, v[j]);
+          }
+        }
+      }
+    }
+  }
+  if (p.stats && !(e.dbg & 4)) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [NT][VEC][2]
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      red[(t * VEC + j) * 2 + 0] = bsum[j];
+      red[(t * VEC + j) * 2 + 1] = bsq[j];
+    }
+    __syncthreads();
+    if (t < BN) {
+      const int col = t, cpc = col / VEC, j = col % VEC;
+      float s = 0.f, q = 0.f;
+      for (int rr = 0; rr < RSTEP; ++rr) {
+        const int tt = rr * PCOLS + cpc;
+        s += red[(tt * VEC + j) * 2 + 0];
+        q += red[(tt * VEC + j) * 2 + 1];
+      }
+      if (n0 + col < p.Cout) {
+        double* st = p.stats + (long)(mtile % NPP_STAT_REPLICAS) * 2 * p.Cout;
+        atomicAdd(st + n0 + col, (double)s);
+        atomicAdd(st + p.Cout + n0 + col, (double)q);
+      }
+    }
+  }
+}
+
+template <typename K>
+bool raise_lds(K kernel, size_t bytes) {
+  static thread_local const void* done[8];
+  static thread_local size_t done_sz[8];
+  const void* fp = reinterpret_cast<const void*>(kernel);
+  for (int i = 0; i < 8; ++i)
+    if (done[i] == fp && done_sz[i] >= bytes) return true;
+  if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)) != hipSuccess) return false;
+  for (int i = 0; i < 8; ++i)
+    if (!done[i] || done[i] == fp) { done[i] = fp; done_sz[i] = 160 * 1024; break; }
+  return true;
+}
+
+}  // namespace
+
+bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
+  static const bool disabled = getenv("NPP_DISABLE_S1") != nullptr;
+  if (disabled) return false;
+  const int kc = dtype == NPP_BF16 ? 64 : 32;
+  if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.uph != 1 || p.upw != 1) return false;
+  if (p.KH != p.KW || (p.KH & 1) == 0 || p.KH > 5) return false;
+  const int P = (p.KH - 1) / 2;
+  if (p.ph != P || p.pw != P) return false;
+  if (p.OH != p.H || p.OW != p.W) return false;
+  if (p.Cin % kc != 0 || p.Cp != p.Cin) return false;
+  if (((p.Cout + 31) / 32 * 32) % BN != 0) return false;
+  const int Wp = p.W + P, Hp = p.H + P;
+  const int halo = P * Wp + P;
+  const long NHW = (long)p.N * p.H * p.W;
+  const long Mp = (long)p.N * Hp * Wp;
+  // tile height: 256 rows (8 waves) when the problem has enough tiles and the footprint fits, else 128
+  int bm = 256;
+  const int abufs = (p.KH * p.KW == 1) ? 2 : 1;
+  auto lds_for = [&](int bm_) { return (size_t)abufs * (bm_ + 2 * halo) * PITCH + 2 * BTILE; };
+  auto epi_for = [&](int bm_) { return (size_t)128 * (BN + 4) * 4; };
+  const size_t cap = 160 * 1024;
+  static const int force_bm = getenv("NPP_S1_BM") ? atoi(getenv("NPP_S1_BM")) : 0;
+  if (Mp < 256L * 200 || lds_for(256) > cap || force_bm == 128) bm = 128;
+  if (lds_for(bm) > cap) return false;
+  S1Extra e;
+  static const int dbg = getenv("NPP_S1_DBG") ? atoi(getenv("NPP_S1_DBG")) : 0;
+  e.dbg = dbg;
+  e.abufs = abufs;
+  e.Wp = Wp; e.Hp = Hp; e.Mp = Mp;
+  e.P = P; e.halo = halo; e.AR = bm + 2 * halo; e.nchunks = p.Cin / kc; e.taps = p.KH * p.KW; e.NHW = NHW;
+  const int nt = bm * 2;
+  e.apt = (e.AR * 8 + nt - 1) / nt;
+  if (e.apt > (bm == 128 ? 12 : 8)) return false;
+  size_t lds = lds_for(bm);
+  if (lds < epi_for(bm)) lds = epi_for(bm);
+  if (lds < (size_t)nt * 8 * 2 * 4) lds = (size_t)nt * 8 * 2 * 4;
+  IgemmParams q = p;
+  q.mtiles = (int)((Mp + bm - 1) / bm);
+  q.ntiles = ((p.Cout + 31) / 32 * 32) / BN;
+  const int grid = q.mtiles * q.ntiles;
+#define LAUNCH(T, BM_)                                                                       \
+  do {                                                                                       \
+    if (!raise_lds(conv_s1_kernel<T, BM_>, lds)) return false;                               \
+    hipLaunchKernelGGL((conv_s1_kernel<T, BM_>), dim3(grid), dim3(BM_ * 2), lds, stream, q, e); \
+  } while (0)
+  if (dtype == NPP_BF16) { if (bm == 256) LAUNCH(bf16_t, 256); else LAUNCH(bf16_t, 128); }
+  else { if (bm == 256) LAUNCH(float, 256); else LAUNCH(float, 128); }
+#undef LAUNCH
+  return true;
+}

@@ -125,8 +125,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
       const int ih = boh[j] * p.sh + dih, iw = bow[j] * p.sw + diw;
       if (col_ok && bn_[j] < p.N && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
         const long off = ((long)bn_[j] * p.H * p.W + (long)ih * p.W + iw) * p.ldx + cch;
-        v = *reinterpret_cast<const u32x4*>(xg + off);
-        if (p.relu_in) v = relu16w<T>(v);
+        v = *reinterpret_cast<const u32x4*>(xg + off);   // ReLU at store_stage
       }
       rb[j] = v;
       // advance this row slot to the next chunk (pixels are contiguous: +KP)
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
       *reinterpret_cast<u32x4*>(sA + (arow0 + j * ROWS_A) * PA + apiece * 16) = ra[j];
 #pragma unroll
     for (int j = 0; j < PASS_B; ++j)
-      *reinterpret_cast<u32x4*>(sX + (brow0 + j * ROWS_B) * PX + bpiece * 16) = rb[j];
+      *reinterpret_cast<u32x4*>(sX + (brow0 + j * ROWS_B) * PX + bpiece * 16) = p.relu_in ? relu16w<T>(rb[j]) : rb[j];
   };
 
   f32x16 acc[MI];
