@@ -49,6 +49,12 @@ _zpool64 = _ZeroPool(torch.float64, 1 << 21)
 _zpool32 = _ZeroPool(torch.float32, 1 << 24)
 
 
+def reset_pools():
+    """Drop the current scratch chunks (call after CUDA-graph capture: captured chunks belong to the graph)."""
+    _zpool64.buf = None
+    _zpool32.buf = None
+
+
 def zeros_f64(n, device):
     return _zpool64.get(n, device)
 
@@ -139,12 +145,15 @@ class _Conv2d(Function):
                                  stream_ptr()), "npp_conv_fwd")
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, relu_in, bias is not None)
+        ctx.set_materialize_grads(False)     # no zero tensor for the (non-differentiable) statistics output
         if stats is not None:
             ctx.mark_non_differentiable(stats)
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _dstats):
+        if dy is None:
+            return (None,) * 9
         x, weight = ctx.saved_tensors
         stride, pad, dil, relu_in, has_bias = ctx.cfg
         dy = to_nhwc(dy)
@@ -435,12 +444,15 @@ class _Pool3x3(Function):
               "npp_pool3x3_fwd")
         ctx.save_for_backward(amax)
         ctx.cfg = (is_avg, stride, tuple(x.shape), x.dtype)
+        ctx.set_materialize_grads(False)
         if stats is not None:
             ctx.mark_non_differentiable(stats)
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _):
+        if dy is None:
+            return None, None, None, None
         (amax,) = ctx.saved_tensors
         is_avg, stride, xshape, dtype = ctx.cfg
         dy = to_nhwc(dy)
@@ -465,12 +477,15 @@ class _Pool2x2(Function):
         check(lib().npp_pool2x2_fwd(_byref(x), _byref(y), int(is_avg), ptr(stats), stream_ptr()), "npp_pool2x2_fwd")
         ctx.save_for_backward(None if is_avg else x)
         ctx.cfg = (is_avg, tuple(x.shape), x.dtype)
+        ctx.set_materialize_grads(False)
         if stats is not None:
             ctx.mark_non_differentiable(stats)
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _):
+        if dy is None:
+            return None, None, None
         (x,) = ctx.saved_tensors
         is_avg, xshape, dtype = ctx.cfg
         dy = to_nhwc(dy)

@@ -22,9 +22,11 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
                                                            int N, int H, int W, int OH, int OW, int cv, float sh, float sw) {
   const long total = (long)N * OH * OW * cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long p = i / cv;
-    const int c0 = (int)(i - p * cv) * V;
+  const FastDiv fd((unsigned)cv);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+    unsigned p, pr_;
+    fast_divmod(i, fd, p, pr_);
+    const int c0 = (int)pr_ * V;
     const int ow = (int)(p % OW);
     const long t2 = p / OW;
     const int oh = (int)(t2 % OH), n = (int)(t2 / OH);
@@ -68,9 +70,11 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ dy, long ldy, T* __restrict__ dx, long ldx,
                                                            int N, int H, int W, int OH, int OW, int cv, float sh, float sw) {
   const long total = (long)N * H * W * cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long p = i / cv;
-    const int c0 = (int)(i - p * cv) * V;
+  const FastDiv fd((unsigned)cv);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+    unsigned p, pr_;
+    fast_divmod(i, fd, p, pr_);
+    const int c0 = (int)pr_ * V;
     const int iw = (int)(p % W);
     const long t2 = p / W;
     const int ih = (int)(t2 % H), n = (int)(t2 / H);

@@ -27,6 +27,13 @@ static inline dim3 col_grid(const ColMap& m, long npix) {
   return dim3((unsigned)bx, (unsigned)((m.cv + m.cols_blk - 1) / m.cols_blk));
 }
 
+static inline dim3 col_grid_ew(const ColMap& m, long npix) {
+  long bx = (npix + 2L * m.rows - 1) / (2L * m.rows);
+  if (bx > 2048) bx = 2048;
+  if (bx < 1) bx = 1;
+  return dim3((unsigned)bx, (unsigned)((m.cv + m.cols_blk - 1) / m.cols_blk));
+}
+
 template <int NQ, int V>
 NPP_DEV void block_col_reduce(double (&acc)[NQ][V], float* red /*[256][NQ*V] doubles as 2 floats*/, int t, int col,
                               int row, int rows, int cols_blk, bool active, double* const* outs, int colg, int C) {
@@ -82,14 +89,24 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
   }
 }
 
+// One 16-lane group per channel: lane r reads replica r (r < nrep), a 4-step shuffle tree sums them.
+NPP_DEV void replica_sum(const double* __restrict__ buf, int nrep, int C, int c, int sub, double& s0, double& s1) {
+  s0 = 0.0; s1 = 0.0;
+  for (int r = sub; r < nrep; r += 16) { s0 += buf[(long)r * 2 * C + c]; s1 += buf[(long)r * 2 * C + C + c]; }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 16); s1 += __shfl_xor(s1, o, 16); }
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int nrep, double count, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, long* nbt, float momentum, float eps,
                                    float* ss, float* mi, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) nbt[0] += 1;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int r = 0; r < nrep; ++r) { s0 += stats[(long)r * 2 * C + c]; s1 += stats[(long)r * 2 * C + C + c]; }
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gid >> 4, sub = gid & 15;
+  if (gid == 0 && nbt) nbt[0] += 1;
+  const bool live = c < C;
+  double s0, s1;
+  replica_sum(stats, nrep, C, live ? c : 0, sub, s0, s1);
+  if (!live || sub != 0) return;
   const double mean = s0 / count;
   double var = s1 / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -116,29 +133,53 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
   ss[C + c] = b - rm[c] * g * invstd;
 }
 
+// Column-persistent elementwise mapping: a thread owns ONE 16-byte channel group (its per-channel coefficients
+// live in registers for the whole kernel) and walks pixels, two per iteration to keep more loads in flight.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void affine_add_kernel(T* __restrict__ out, long ldo, const T* __restrict__ a, long lda,
                                                          const float* __restrict__ ssa, const T* __restrict__ b, long ldb,
-                                                         const float* __restrict__ ssb, int relu, long npix, int C, int cv) {
-  const long total = npix * cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long p = i / cv;
-    const int c0 = (int)(i - p * cv) * V;
-    float va[V], o[V];
+                                                         const float* __restrict__ ssb, int relu, long npix, int C, ColMap m) {
+  const int t = threadIdx.x;
+  if (t >= m.rows * m.cols_blk) return;
+  const int col = t % m.cols_blk, row = t / m.cols_blk;
+  const int colg = blockIdx.y * m.cols_blk + col;
+  if (colg >= m.cv) return;
+  const int c0 = colg * V;
+  float sa[V], ta[V], sb[V], tb[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    sa[j] = ssa ? ssa[c0 + j] : 1.f;
+    ta[j] = ssa ? ssa[C + c0 + j] : 0.f;
+    sb[j] = ssb ? ssb[c0 + j] : 1.f;
+    tb[j] = ssb ? ssb[C + c0 + j] : 0.f;
+  }
+  const long step = (long)gridDim.x * m.rows;
+  for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += 2 * step) {
+    const long p2 = p + step;
+    const bool two = p2 < npix;
+    float va[V], vb[V], wa[V], wb[V], o[V], o2[V];
     ldv<T, V>(a + p * lda + c0, va);
-#pragma unroll
-    for (int j = 0; j < V; ++j) o[j] = ssa ? va[j] * ssa[c0 + j] + ssa[C + c0 + j] : va[j];
-    if (b) {
-      float vb[V];
-      ldv<T, V>(b + p * ldb + c0, vb);
-#pragma unroll
-      for (int j = 0; j < V; ++j) o[j] += ssb ? vb[j] * ssb[c0 + j] + ssb[C + c0 + j] : vb[j];
+    if (b) ldv<T, V>(b + p * ldb + c0, vb);
+    if (two) {
+      ldv<T, V>(a + p2 * lda + c0, wa);
+      if (b) ldv<T, V>(b + p2 * ldb + c0, wb);
     }
-    if (relu) {
 #pragma unroll
-      for (int j = 0; j < V; ++j) o[j] = fmaxf(o[j], 0.f);
+    for (int j = 0; j < V; ++j) {
+      o[j] = fmaf(va[j], sa[j], ta[j]);
+      if (b) o[j] += fmaf(vb[j], sb[j], tb[j]);
+      if (relu) o[j] = fmaxf(o[j], 0.f);
     }
     stv<T, V>(out + p * ldo + c0, o);
+    if (two) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        o2[j] = fmaf(wa[j], sa[j], ta[j]);
+        if (b) o2[j] += fmaf(wb[j], sb[j], tb[j]);
+        if (relu) o2[j] = fmaxf(o2[j], 0.f);
+      }
+      stv<T, V>(out + p2 * ldo + c0, o2);
+    }
   }
 }
 
@@ -163,20 +204,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     invstd[j] = (work && ch < C) ? mi[C + ch] : 0.f;
   }
   if (work) {
-    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += (long)gridDim.x * m.rows) {
-      float d[V], v[V];
-      ldv<T, V>(dout + p * ldd + (long)colg * V, d);
-      ldv<T, V>(y + p * ldy + (long)colg * V, v);
+    const long step = (long)gridDim.x * m.rows;
+    const long cofs = (long)colg * V;
+    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += 2 * step) {
+      const long p2 = p + step;
+      const bool two = p2 < npix;
+      float d[V], v[V], d2[V], v2[V];
+      ldv<T, V>(dout + p * ldd + cofs, d);
+      ldv<T, V>(y + p * ldy + cofs, v);
+      if (two) {
+        ldv<T, V>(dout + p2 * ldd + cofs, d2);
+        ldv<T, V>(y + p2 * ldy + cofs, v2);
+      }
       if (ro) {
         float o[V];
-        ldv<T, V>(ro + p * ldr + (long)colg * V, o);
+        ldv<T, V>(ro + p * ldr + cofs, o);
 #pragma unroll
         for (int j = 0; j < V; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+        if (two) {
+          ldv<T, V>(ro + p2 * ldr + cofs, o);
+#pragma unroll
+          for (int j = 0; j < V; ++j) d2[j] = o[j] > 0.f ? d2[j] : 0.f;
+        }
       }
+      // pairs are summed in f32 (two terms), the running sums stay f64
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        acc[0][j] += d[j];
-        acc[1][j] += (double)d[j] * ((v[j] - mean[j]) * invstd[j]);
+        float a0 = d[j], a1 = d[j] * ((v[j] - mean[j]) * invstd[j]);
+        if (two) { a0 += d2[j]; a1 += d2[j] * ((v2[j] - mean[j]) * invstd[j]); }
+        acc[0][j] += a0;
+        acc[1][j] += a1;
       }
     }
   }
@@ -187,10 +244,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 
 __global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums, int nrep, double inv_count, const float* __restrict__ mi,
                                      const float* __restrict__ gamma, float* __restrict__ co, float* dgamma, float* dbeta, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int r = 0; r < nrep; ++r) { s0 += sums[(long)r * 2 * C + c]; s1 += sums[(long)r * 2 * C + C + c]; }
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gid >> 4, sub = gid & 15;
+  const bool live = c < C;
+  double s0, s1;
+  replica_sum(sums, nrep, C, live ? c : 0, sub, s0, s1);
+  if (!live || sub != 0) return;
   const float mean = mi[c], invstd = mi[C + c];
   const float g = gamma ? gamma[c] : 1.f;
   const float m0 = (float)(s0 * inv_count), m1 = (float)(s1 * inv_count);
@@ -207,23 +266,45 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
                                                            long ldy, const T* __restrict__ ro, long ldr,
                                                            const float* __restrict__ co, T* __restrict__ dy, long ldo,
-                                                           long npix, int C, int cv) {
-  const long total = npix * cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long p = i / cv;
-    const int c0 = (int)(i - p * cv) * V;
-    float d[V], v[V], o[V];
+                                                           long npix, int C, ColMap m) {
+  const int t = threadIdx.x;
+  if (t >= m.rows * m.cols_blk) return;
+  const int col = t % m.cols_blk, row = t / m.cols_blk;
+  const int colg = blockIdx.y * m.cols_blk + col;
+  if (colg >= m.cv) return;
+  const int c0 = colg * V;
+  float ca[V], cb[V], cc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { ca[j] = co[c0 + j]; cb[j] = co[C + c0 + j]; cc[j] = co[2 * C + c0 + j]; }
+  const long step = (long)gridDim.x * m.rows;
+  for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += 2 * step) {
+    const long p2 = p + step;
+    const bool two = p2 < npix;
+    float d[V], v[V], d2[V], v2[V], r[V], o[V];
     ldv<T, V>(dout + p * ldd + c0, d);
     ldv<T, V>(y + p * ldy + c0, v);
+    if (two) {
+      ldv<T, V>(dout + p2 * ldd + c0, d2);
+      ldv<T, V>(y + p2 * ldy + c0, v2);
+    }
     if (ro) {
-      float r[V];
       ldv<T, V>(ro + p * ldr + c0, r);
 #pragma unroll
       for (int j = 0; j < V; ++j) d[j] = r[j] > 0.f ? d[j] : 0.f;
+      if (two) {
+        ldv<T, V>(ro + p2 * ldr + c0, r);
+#pragma unroll
+        for (int j = 0; j < V; ++j) d2[j] = r[j] > 0.f ? d2[j] : 0.f;
+      }
     }
 #pragma unroll
-    for (int j = 0; j < V; ++j) o[j] = fmaf(co[c0 + j], d[j], fmaf(co[C + c0 + j], v[j], co[2 * C + c0 + j]));
+    for (int j = 0; j < V; ++j) o[j] = fmaf(ca[j], d[j], fmaf(cb[j], v[j], cc[j]));
     stv<T, V>(dy + p * ldo + c0, o);
+    if (two) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = fmaf(ca[j], d2[j], fmaf(cb[j], v2[j], cc[j]));
+      stv<T, V>(dy + p2 * ldo + c0, o);
+    }
   }
 }
 
@@ -232,9 +313,11 @@ __global__ __launch_bounds__(256) void scale_mask_kernel(const T* __restrict__ d
                                                          const T* __restrict__ ro, long ldr, T* __restrict__ dx, long ldo,
                                                          long npix, int cv) {
   const long total = npix * cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long p = i / cv;
-    const int c0 = (int)(i - p * cv) * V;
+  const FastDiv fd((unsigned)cv);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+    unsigned p, pr_;
+    fast_divmod(i, fd, p, pr_);
+    const int c0 = (int)pr_ * V;
     float d[V];
     ldv<T, V>(dout + p * ldd + c0, d);
     if (scale) {
@@ -282,7 +365,7 @@ extern "C" int npp_bn_finalize(const double* stats, int nrep, double count, cons
                                float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                                float eps, float* scale_shift, float* mean_invstd, int c, void* stream) {
   NPP_REQUIRE(stats && scale_shift && c > 0 && count > 0, NPP_E_NULL, "npp_bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, nrep, count, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, nrep, count, gamma,
                      beta, running_mean, running_var, (long*)num_batches_tracked, momentum, eps, scale_shift, mean_invstd, c);
   return npp_check_launch("bn_finalize");
 }
@@ -305,10 +388,10 @@ extern "C" int npp_affine_add(NppTensor* out, const NppTensor* a, const float* s
   const int nt = b ? 3 : 2;
   ProfScope prof(NPP_FAM_ELTWISE, out->dtype, (hipStream_t)stream, 0, (double)npix(out) * out->c * esize(out->dtype) * nt);
   NPP_DISPATCH_TV(out->dtype, vk, {
-    const int cv = (int)(out->c / V);
-    hipLaunchKernelGGL((affine_add_kernel<T, V>), dim3(grid_for(npix(out) * cv)), dim3(256), 0, (hipStream_t)stream,
+    ColMap m = col_map(out->c, V);
+    hipLaunchKernelGGL((affine_add_kernel<T, V>), col_grid_ew(m, npix(out)), dim3(256), 0, (hipStream_t)stream,
                        (T*)out->ptr, (long)out->ld, (const T*)a->ptr, (long)a->ld, ss_a, b ? (const T*)b->ptr : nullptr,
-                       b ? (long)b->ld : 0L, ss_b, relu, (long)npix(out), (int)out->c, cv);
+                       b ? (long)b->ld : 0L, ss_b, relu, (long)npix(out), (int)out->c, m);
   });
   return npp_check_launch("affine_add");
 }
@@ -335,7 +418,7 @@ extern "C" int npp_bn_bwd_reduce(const NppTensor* dout, const NppTensor* y_raw, 
 extern "C" int npp_bn_bwd_coeffs(const double* sums, int nrep, double count, const float* mean_invstd, const float* gamma,
                                  float* coeffs, float* dgamma, float* dbeta, int c, void* stream) {
   NPP_REQUIRE(sums && mean_invstd && coeffs && c > 0 && count > 0 && nrep >= 1, NPP_E_NULL, "npp_bn_bwd_coeffs: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, nrep, 1.0 / count,
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((c * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, nrep, 1.0 / count,
                      mean_invstd, gamma, coeffs, dgamma, dbeta, c);
   return npp_check_launch("bn_bwd_coeffs");
 }
@@ -350,11 +433,11 @@ extern "C" int npp_bn_bwd_apply(const NppTensor* dout, const NppTensor* y_raw, c
   const bool vk = vec_ok(dout) && vec_ok(y_raw) && vec_ok(dy_raw) && (!relu_out || vec_ok(relu_out));
   ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 3);
   NPP_DISPATCH_TV(dout->dtype, vk, {
-    const int cv = (int)(dout->c / V);
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(grid_for(npix(dout) * cv)), dim3(256), 0, (hipStream_t)stream,
+    ColMap m = col_map(dout->c, V);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), col_grid_ew(m, npix(dout)), dim3(256), 0, (hipStream_t)stream,
                        (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
                        relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, coeffs,
-                       (T*)dy_raw->ptr, (long)dy_raw->ld, (long)npix(dout), (int)dout->c, cv);
+                       (T*)dy_raw->ptr, (long)dy_raw->ld, (long)npix(dout), (int)dout->c, m);
   });
   return npp_check_launch("bn_bwd_apply");
 }

@@ -63,7 +63,6 @@ __global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra 
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int KC = KCB / (int)sizeof(T);       // channels per chunk: 64 bf16 / 32 f32
   constexpr int NT = BM * 2;
-  constexpr int WAVES_M = BM / 64;
   constexpr int BPT = (BN * 8) / NT;             // B pieces per thread per stage
   constexpr int APT_MAX = (BM == 128) ? 12 : 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -72,56 +71,59 @@ __global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra 
   unsigned char* const sB0 = smem + e.abufs * asz;
 
   const int t = threadIdx.x;
-  const int nwg = gridDim.x;
-  int lid;
-  {
-    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
-  const int ntile = lid % p.ntiles, mtile = lid / p.ntiles;
-  const long q0 = (long)mtile * BM;          // first gapped pixel of this tile
-  const int n0 = ntile * BN;
   const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
   const int img = e.Hp * e.Wp;
+  const int total_tiles = p.mtiles * p.ntiles;
 
-  // ---- staging roles ------------------------------------------------------------------------------
+  // ---- staging roles (recomputed per tile) -------------------------------------------------------------
   const T* asrc[APT_MAX];
   int adst[APT_MAX];
-  {
-    // this thread stages footprint rows j = (t>>3) + i*(NT/8); decode the first one (shifted by one image so the
-    // dividend is non-negative), then walk the gapped axis incrementally: no division per row.
-    const int pc8 = t & 7;
-    const int j0 = t >> 3;
-    const int qq = (int)(q0 - e.halo) + j0 + img;
-    int n = qq / img - 1;
-    const int rem = qq - (n + 1) * img;
-    int y = rem / e.Wp, x = rem - y * e.Wp;
-#pragma unroll
-    for (int i = 0; i < APT_MAX; ++i) {
-      const int j = j0 + i * (NT / 8);
-      const bool in_fp = (i < e.apt) && (j < e.AR);
-      const T* src = nullptr;
-      if (in_fp && n >= 0 && n < p.N && y < p.H && x < p.W)
-        src = xg + ((long)(n * p.H + y) * p.W + x) * p.ldx + pc8 * VEC;
-      asrc[i] = src;
-      adst[i] = in_fp ? j * PITCH + pc8 * 16 : -1;
-      x += NT / 8;
-      while (x >= e.Wp) { x -= e.Wp; ++y; }
-      while (y >= e.Hp) { y -= e.Hp; ++n; }
-    }
-  }
   const T* bsrc[BPT];
   int bdst[BPT];
 #pragma unroll
   for (int i = 0; i < BPT; ++i) {
     const int el = t + i * NT;
-    const int n = el >> 3, pc8 = el & 7;
-    bsrc[i] = wg + (long)(n0 + n) * p.Kpad + pc8 * VEC;
-    bdst[i] = n * PITCH + pc8 * 16;
+    bdst[i] = (el >> 3) * PITCH + (el & 7) * 16;
   }
+#pragma unroll
+  for (int i = 0; i < APT_MAX; ++i) {
+    const int j = (t >> 3) + i * (NT / 8);
+    adst[i] = ((i < e.apt) && (j < e.AR)) ? j * PITCH + (t & 7) * 16 : -1;
+  }
+  // XCD-aware tile order (cdna_hip_programming.md T1): the tiles of one XCD's blocks are contiguous, N-tile
+  // fastest, so the blocks that re-read one input footprint share an L2.
+  auto tile_coords = [&](int tile, long& q0, int& n0) {
+    const int xcd = tile & 7, qd = total_tiles >> 3, rm = total_tiles & 7;
+    const int lid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (tile >> 3);
+    q0 = (long)(lid / p.ntiles) * BM;
+    n0 = (lid % p.ntiles) * BN;
+  };
+  auto setup_roles = [&](long q0, int n0) {
+    // this thread stages footprint rows j = (t>>3) + i*(NT/8); decode the first one (shifted by one image so the
+    // dividend is non-negative), then walk the gapped axis incrementally: no division per row.
+    const int pc8 = t & 7;
+    const int qq = (int)(q0 - e.halo) + (t >> 3) + img;
+    int n = qq / img - 1;
+    const int rem = qq - (n + 1) * img;
+    int y = rem / e.Wp, x = rem - y * e.Wp;
+#pragma unroll
+    for (int i = 0; i < APT_MAX; ++i) {
+      const T* src = nullptr;
+      if (adst[i] >= 0 && n >= 0 && n < p.N && y < p.H && x < p.W)
+        src = xg + ((long)(n * p.H + y) * p.W + x) * p.ldx + pc8 * VEC;
+      asrc[i] = src;
+      x += NT / 8;
+      while (x >= e.Wp) { x -= e.Wp; ++y; }
+      while (y >= e.Hp) { y -= e.Hp; ++n; }
+    }
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+      const int el = t + i * NT;
+      bsrc[i] = wg + (long)(n0 + (el >> 3)) * p.Kpad + (el & 7) * VEC;
+    }
+  };
   u32x4 ra[APT_MAX], rb[BPT];
-
   auto load_A = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < APT_MAX; ++i) {
@@ -153,177 +155,198 @@ __global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra 
   const int r = lane & 31, h = lane >> 5;
   const int boff = (wn * 64 + r) * PITCH + h * 16;      // + ni*32*PITCH + ks*32 as immediates
   const int aoff = (wm * 64 + r) * PITCH + h * 16;      // + tap offset + mi*32*PITCH + ks*32
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int el = 0; el < 16; ++el) acc[mi][ni][el] = 0.f;
-
-  const int nstages = (e.dbg & 1) ? 0 : e.nchunks * e.taps;
-  // stage counters: (chunk, tap) of stages s, s+1, s+2
-  int c0 = 0, t0 = 0, c1 = 0, t1 = 1, c2, t2;
-  if (t1 == e.taps) { t1 = 0; c1 = 1; }
-  c2 = c1; t2 = t1 + 1;
-  if (t2 == e.taps) { t2 = 0; ++c2; }
-
-  load_A(0);
-  load_B(0, 0);
-  store_A(0);
-  store_B(0);
-  if (nstages > 1) load_B(c1, t1);                    // in flight during stage 0
-  if (e.abufs == 2 && nstages > 1) load_A(1);
-  __syncthreads();
-
-  for (int s = 0; s < nstages; ++s) {
-    const bool has1 = s + 1 < nstages, has2 = s + 2 < nstages;
-    // registers hold stage s+1 (issued one full stage ago): put it in the other LDS buffer (last read in stage
-    // s-1, fenced by the barrier that ended it), then refill the registers with stage s+2.
-    if (has1) {
-      store_B((s + 1) & 1);
-      if (e.abufs == 2) store_A((s + 1) & 1);
-    }
-    if (has2) {
-      load_B(c2, t2);
-      if (e.abufs == 2) load_A(c2);
-    }
-    const bool fetch_fp = (e.abufs == 1) && (t0 == 0) && (c0 + 1 < e.nchunks);   // KxK: next chunk's footprint
-    if (fetch_fp) load_A(c0 + 1);
-
-    const int kh = t0 / p.KW, kw = t0 - kh * p.KW;
-    const int off = e.halo + (kh - e.P) * e.Wp + (kw - e.P);
-    const unsigned char* a = sA0 + ((c0 & 1) & (e.abufs - 1)) * asz + off * PITCH + aoff;
-    const unsigned char* b = sB0 + (s & 1) * BTILE + boff;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 fa[2], fb[2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) fa[mi] = *reinterpret_cast<const u32x4*>(a + mi * 32 * PITCH + ks * 32);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(b + ni * 32 * PITCH + ks * 32);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) mma_frag_s<T>(acc[mi][ni], fa[mi], fb[ni]);
-    }
-    if (e.abufs == 1 && has1 && t1 == 0) {
-      __syncthreads();          // every wave is done with this chunk's footprint
-      store_A(0);
-    }
-    __syncthreads();
-    c0 = c1; t0 = t1; c1 = c2; t1 = t2;
-    if (++t2 == e.taps) { t2 = 0; ++c2; }
-  }
-
-  // ---- epilogue: two rounds of 128 rows through an LDS C tile ------------------------------------
   constexpr int CP = BN + 4;
   float* sC = reinterpret_cast<float*>(smem);
   constexpr int PCOLS = BN / VEC;
   constexpr int RSTEP = NT / PCOLS;
   const int pc = t % PCOLS, pr = t / PCOLS;
-  const int nbase = n0 + pc * VEC;
   T* __restrict__ yg = reinterpret_cast<T*>(p.y);
   const T* __restrict__ mg = reinterpret_cast<const T*>(p.mask);
-  float bsum[VEC], bsq[VEC], bias[VEC];
+  const int nstages = (e.dbg & 1) ? 0 : e.nchunks * e.taps;
+
+  // ---- persistent loop over tiles: the first stage of tile i+1 is fetched before the epilogue of tile i ----
+  int tile = blockIdx.x;
+  long q0; int n0;
+  tile_coords(tile, q0, n0);
+  setup_roles(q0, n0);
+  load_A(0);
+  load_B(0, 0);
+  while (true) {
+    f32x16 acc[2][2];
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    bsum[j] = 0.f; bsq[j] = 0.f;
-    bias[j] = (p.bias && nbase + j < p.Cout) ? p.bias[nbase + j] : 0.f;
-  }
-  const bool full_vec = p.vec_io && (nbase + VEC <= p.Cout);
-  constexpr int ROUNDS = BM / 128;
-  for (int rd = 0; rd < ((e.dbg & 2) ? 0 : ROUNDS); ++rd) {
-    if (rd > 0) __syncthreads();
-    if ((wm >> 1) == rd) {
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int el = 0; el < 16; ++el) {
-            const int row = (wm & 1) * 64 + mi * 32 + (el & 3) + 8 * (el >> 2) + 4 * h;
-            const int col = wn * 64 + ni * 32 + r;
-            sC[row * CP + col] = acc[mi][ni][el];
-          }
-    }
+        for (int el = 0; el < 16; ++el) acc[mi][ni][el] = 0.f;
+    // stage counters: (chunk, tap) of stages s, s+1, s+2
+    int c0 = 0, t0 = 0, c1 = 0, t1 = 1, c2, t2;
+    if (t1 == e.taps) { t1 = 0; c1 = 1; }
+    c2 = c1; t2 = t1 + 1;
+    if (t2 == e.taps) { t2 = 0; ++c2; }
+
+    store_A(0);
+    store_B(0);
+    if (nstages > 1) load_B(c1, t1);                    // in flight during stage 0
+    if (e.abufs == 2 && nstages > 1) load_A(1);
     __syncthreads();
-    int dn = 0, dy = 0, dx = 0;
-    if (e.P) {
-      const int qs = (int)q0 + rd * 128 + pr;
-      dn = qs / img;
-      const int rem = qs - dn * img;
-      dy = rem / e.Wp;
-      dx = rem - dy * e.Wp;
-    }
-    for (int row = pr; row < 128; row += RSTEP) {
-      const long q = q0 + rd * 128 + row;
-      if (q >= e.Mp) break;
-      if (nbase >= p.Cout) break;
-      long m = q;
-      if (e.P) {      // gapped -> real pixel index; gap rows produce nothing
-        const bool real = dy < p.H && dx < p.W;
-        m = (long)(dn * p.H + dy) * p.W + dx;
-        dx += RSTEP;
-        while (dx >= e.Wp) { dx -= e.Wp; ++dy; }
-        while (dy >= e.Hp) { dy -= e.Hp; ++dn; }
-        if (!real) continue;
+
+    for (int s = 0; s < nstages; ++s) {
+      const bool has1 = s + 1 < nstages, has2 = s + 2 < nstages;
+      // registers hold stage s+1 (issued one full stage ago): put it in the other LDS buffer (last read in
+      // stage s-1, fenced by the barrier that ended it), then refill the registers with stage s+2.
+      if (has1) {
+        store_B((s + 1) & 1);
+        if (e.abufs == 2) store_A((s + 1) & 1);
       }
-      float v[VEC];
+      if (has2) {
+        load_B(c2, t2);
+        if (e.abufs == 2) load_A(c2);
+      }
+      const bool fetch_fp = (e.abufs == 1) && (t0 == 0) && (c0 + 1 < e.nchunks);   // KxK: next chunk's footprint
+      if (fetch_fp) load_A(c0 + 1);
+
+      const int kh = t0 / p.KW, kw = t0 - kh * p.KW;
+      const int off = e.halo + (kh - e.P) * e.Wp + (kw - e.P);
+      const unsigned char* a = sA0 + ((c0 & 1) & (e.abufs - 1)) * asz + off * PITCH + aoff;
+      const unsigned char* b = sB0 + (s & 1) * BTILE + boff;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) v[j] = sC[row * CP + pc * VEC + j] + bias[j];
-      if (full_vec) {
-        if (mg) {
-          float mk[VEC];
-          Vec16<T>::load(mg + m * p.ldm + nbase, mk);
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4 fa[2], fb[2];
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) v[j] = mk[j] > 0.f ? v[j] : 0.f;
+        for (int mi = 0; mi < 2; ++mi) fa[mi] = *reinterpret_cast<const u32x4*>(a + mi * 32 * PITCH + ks * 32);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(b + ni * 32 * PITCH + ks * 32);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) mma_frag_s<T>(acc[mi][ni], fa[mi], fb[ni]);
+      }
+      if (e.abufs == 1 && has1 && t1 == 0) {
+        __syncthreads();          // every wave is done with this chunk's footprint
+        store_A(0);
+      }
+      __syncthreads();
+      c0 = c1; t0 = t1; c1 = c2; t1 = t2;
+      if (++t2 == e.taps) { t2 = 0; ++c2; }
+    }
+
+    // ---- prefetch the next tile's first stage (lands during the epilogue) ----------------------------------
+    const long q0c = q0;
+    const int n0c = n0;
+    const int next = tile + gridDim.x;
+    const bool more = next < total_tiles;
+    if (more) {
+      tile_coords(next, q0, n0);
+      setup_roles(q0, n0);
+      load_A(0);
+      load_B(0, 0);
+    }
+
+    // ---- epilogue: rounds of 128 rows through an LDS C tile -------------------------------------------------
+    const int nbase = n0c + pc * VEC;
+    float bsum[VEC], bsq[VEC], bias[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      bsum[j] = 0.f; bsq[j] = 0.f;
+      bias[j] = (p.bias && nbase + j < p.Cout) ? p.bias[nbase + j] : 0.f;
+    }
+    const bool full_vec = p.vec_io && (nbase + VEC <= p.Cout);
+    constexpr int ROUNDS = BM / 128;
+    for (int rd = 0; rd < ((e.dbg & 2) ? 0 : ROUNDS); ++rd) {
+      if (rd > 0) __syncthreads();
+      if ((wm >> 1) == rd) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int el = 0; el < 16; ++el) {
+              const int row = (wm & 1) * 64 + mi * 32 + (el & 3) + 8 * (el >> 2) + 4 * h;
+              const int col = wn * 64 + ni * 32 + r;
+              sC[row * CP + col] = acc[mi][ni][el];
+            }
+      }
+      __syncthreads();
+      int dn = 0, dy = 0, dx = 0;
+      if (e.P) {
+        const int qs = (int)q0c + rd * 128 + pr;
+        dn = qs / img;
+        const int rem = qs - dn * img;
+        dy = rem / e.Wp;
+        dx = rem - dy * e.Wp;
+      }
+      for (int row = pr; row < 128; row += RSTEP) {
+        const long q = q0c + rd * 128 + row;
+        if (q >= e.Mp) break;
+        if (nbase >= p.Cout) break;
+        long m = q;
+        if (e.P) {      // gapped -> real pixel index; gap rows produce nothing
+          const bool real = dy < p.H && dx < p.W;
+          m = (long)(dn * p.H + dy) * p.W + dx;
+          dx += RSTEP;
+          while (dx >= e.Wp) { dx -= e.Wp; ++dy; }
+          while (dy >= e.Hp) { dy -= e.Hp; ++dn; }
+          if (!real) continue;
         }
+        float v[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          v[j] = Elt<T>::round(v[j]);
-          bsum[j] += v[j];
-          bsq[j] += v[j] * v[j];
-        }
-        Vec16<T>::store(yg + m * p.ldy + nbase, v);
-      } else {
+        for (int j = 0; j < VEC; ++j) v[j] = sC[row * CP + pc * VEC + j] + bias[j];
+        if (full_vec) {
+          if (mg) {
+            float mk[VEC];
+            Vec16<T>::load(mg + m * p.ldm + nbase, mk);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          if (nbase + j < p.Cout) {
-            if (mg && !(Elt<T>::ld(mg + m * p.ldm + nbase + j) > 0.f)) v[j] = 0.f;
+            for (int j = 0; j < VEC; ++j) v[j] = mk[j] > 0.f ? v[j] : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
             v[j] = Elt<T>::round(v[j]);
             bsum[j] += v[j];
             bsq[j] += v[j] * v[j];
-            Elt<T>::st(yg + m * p.ldy + nbase + j, v[j]);
+          }
+          Vec16<T>::store(yg + m * p.ldy + nbase, v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            if (nbase + j < p.Cout) {
+              if (mg && !(Elt<T>::ld(mg + m * p.ldm + nbase + j) > 0.f)) v[j] = 0.f;
+              v[j] = Elt<T>::round(v[j]);
+              bsum[j] += v[j];
+              bsq[j] += v[j] * v[j];
+              Elt<T>::st(yg + m * p.ldy + nbase + j, v[j]);
+            }
           }
         }
       }
     }
-  }
-  if (p.stats && !(e.dbg & 4)) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [NT][VEC][2]
+    if (p.stats && !(e.dbg & 4)) {
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);  // [NT][VEC][2]
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      red[(t * VEC + j) * 2 + 0] = bsum[j];
-      red[(t * VEC + j) * 2 + 1] = bsq[j];
-    }
-    __syncthreads();
-    if (t < BN) {
-      const int col = t, cpc = col / VEC, j = col % VEC;
-      float s = 0.f, q = 0.f;
-      for (int rr = 0; rr < RSTEP; ++rr) {
-        const int tt = rr * PCOLS + cpc;
-        s += red[(tt * VEC + j) * 2 + 0];
-        q += red[(tt * VEC + j) * 2 + 1];
+      for (int j = 0; j < VEC; ++j) {
+        red[(t * VEC + j) * 2 + 0] = bsum[j];
+        red[(t * VEC + j) * 2 + 1] = bsq[j];
       }
-      if (n0 + col < p.Cout) {
-        double* st = p.stats + (long)(mtile % NPP_STAT_REPLICAS) * 2 * p.Cout;
-        atomicAdd(st + n0 + col, (double)s);
-        atomicAdd(st + p.Cout + n0 + col, (double)q);
+      __syncthreads();
+      if (t < BN) {
+        const int col = t, cpc = col / VEC, j = col % VEC;
+        float sm = 0.f, sq = 0.f;
+        for (int rr = 0; rr < RSTEP; ++rr) {
+          const int tt = rr * PCOLS + cpc;
+          sm += red[(tt * VEC + j) * 2 + 0];
+          sq += red[(tt * VEC + j) * 2 + 1];
+        }
+        if (n0c + col < p.Cout) {
+          double* st = p.stats + (long)((q0c / BM) % NPP_STAT_REPLICAS) * 2 * p.Cout;
+          atomicAdd(st + n0c + col, (double)sm);
+          atomicAdd(st + p.Cout + n0c + col, (double)sq);
+        }
       }
     }
+    if (!more) break;
+    tile = next;
+    __syncthreads();   // the epilogue's LDS reads are done before the next tile's staging overwrites it
   }
 }
 
@@ -381,7 +404,18 @@ bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   IgemmParams q = p;
   q.mtiles = (int)((Mp + bm - 1) / bm);
   q.ntiles = ((p.Cout + 31) / 32 * 32) / BN;
-  const int grid = q.mtiles * q.ntiles;
+  int ncu = 256;
+  {
+    static int cached = 0;
+    if (!cached) {
+      int dev = 0; hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount;
+      if (cached <= 0) cached = 256;
+    }
+    ncu = cached;
+  }
+  const int tiles = q.mtiles * q.ntiles;
+  const int grid = tiles < ncu ? tiles : ncu;   // persistent: one block per CU walks tiles b, b+grid, ...
 #define LAUNCH(T, BM_)                                                                       \
   do {                                                                                       \
     if (!raise_lds(conv_s1_kernel<T, BM_>, lds)) return false;                               \

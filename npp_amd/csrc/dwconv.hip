@@ -30,9 +30,11 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
   const int taps = p.KH * p.KW;
   stage_weights(w, swt, p.C, taps);
   const long total = (long)p.N * p.OH * p.OW * p.cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long pix = i / p.cv;
-    const int c0 = (int)(i - pix * p.cv) * V;
+  const FastDiv fd((unsigned)p.cv);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+    unsigned pix, pr_;
+    fast_divmod(i, fd, pix, pr_);
+    const int c0 = (int)pr_ * V;
     const int ow = (int)(pix % p.OW);
     const long t2 = pix / p.OW;
     const int oh = (int)(t2 % p.OH), n = (int)(t2 / p.OH);
@@ -67,9 +69,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T* __restric
   const int taps = p.KH * p.KW;
   stage_weights(w, swt, p.C, taps);
   const long total = (long)p.N * p.H * p.W * p.cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long pix = i / p.cv;
-    const int c0 = (int)(i - pix * p.cv) * V;
+  const FastDiv fd((unsigned)p.cv);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+    unsigned pix, pr_;
+    fast_divmod(i, fd, pix, pr_);
+    const int c0 = (int)pr_ * V;
     const int iw = (int)(pix % p.W);
     const long t2 = pix / p.W;
     const int ih = (int)(t2 % p.H), n = (int)(t2 / p.H);

@@ -7,9 +7,11 @@ template <typename TI, typename TO, int V>
 __global__ __launch_bounds__(256) void copy_kernel(const TI* __restrict__ x, long ldx, TO* __restrict__ y, long ldy,
                                                    long npix, int cv) {
   const long total = npix * cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long p = i / cv;
-    const int c0 = (int)(i - p * cv) * V;
+  const FastDiv fd((unsigned)cv);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+    unsigned p, pr_;
+    fast_divmod(i, fd, p, pr_);
+    const int c0 = (int)pr_ * V;
     const TI* src = x + p * ldx + c0;
     TO* dst = y + p * ldy + c0;
     if constexpr (V == 1) {

@@ -14,9 +14,11 @@ __global__ __launch_bounds__(256) void pool3x3_fwd_kernel(const T* __restrict__ 
                                                           unsigned char* __restrict__ amax, int N, int H, int W, int OH,
                                                           int OW, int C, int cv, int is_avg, int stride) {
   const long total = (long)N * OH * OW * cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long p = i / cv;
-    const int c0 = (int)(i - p * cv) * V;
+  const FastDiv fd((unsigned)cv);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+    unsigned p, pr_;
+    fast_divmod(i, fd, p, pr_);
+    const int c0 = (int)pr_ * V;
     const int ow = (int)(p % OW);
     const long t2 = p / OW;
     const int oh = (int)(t2 % OH), n = (int)(t2 / OH);
@@ -69,9 +71,11 @@ __global__ __launch_bounds__(256) void pool3x3_bwd_kernel(const T* __restrict__ 
                                                           int is_avg, int stride) {
   // gather form: every input pixel sums the windows that contain it (no atomics)
   const long total = (long)N * H * W * cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long p = i / cv;
-    const int c0 = (int)(i - p * cv) * V;
+  const FastDiv fd((unsigned)cv);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+    unsigned p, pr_;
+    fast_divmod(i, fd, p, pr_);
+    const int c0 = (int)pr_ * V;
     const int iw = (int)(p % W);
     const long t2 = p / W;
     const int ih = (int)(t2 % H), n = (int)(t2 / H);
@@ -114,9 +118,11 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void pool2x2_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
                                                           int N, int H, int W, int OH, int OW, int cv, int is_avg) {
   const long total = (long)N * OH * OW * cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long p = i / cv;
-    const int c0 = (int)(i - p * cv) * V;
+  const FastDiv fd((unsigned)cv);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+    unsigned p, pr_;
+    fast_divmod(i, fd, p, pr_);
+    const int c0 = (int)pr_ * V;
     const int ow = (int)(p % OW);
     const long t2 = p / OW;
     const int oh = (int)(t2 % OH), n = (int)(t2 / OH);
@@ -146,9 +152,11 @@ __global__ __launch_bounds__(256) void pool2x2_bwd_kernel(const T* __restrict__ 
   // one thread per OUTPUT pixel writes its 2x2 input window (windows are disjoint); rows/cols of x
   // beyond 2*OH / 2*OW (odd extents) are zeroed by the caller.
   const long total = (long)N * OH * OW * cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long p = i / cv;
-    const int c0 = (int)(i - p * cv) * V;
+  const FastDiv fd((unsigned)cv);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+    unsigned p, pr_;
+    fast_divmod(i, fd, p, pr_);
+    const int c0 = (int)pr_ * V;
     const int ow = (int)(p % OW);
     const long t2 = p / OW;
     const int oh = (int)(t2 % OH), n = (int)(t2 / OH);
@@ -307,9 +315,11 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const T* __restrict
                                                              const float* __restrict__ add, float inv_hw, T* __restrict__ y,
                                                              long ldy, long npix, int HW, int C, int cv) {
   const long total = npix * cv;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long p = i / cv;
-    const int c0 = (int)(i - p * cv) * V;
+  const FastDiv fd((unsigned)cv);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+    unsigned p, pr_;
+    fast_divmod(i, fd, p, pr_);
+    const int c0 = (int)pr_ * V;
     const long n = p / HW;
     float v[V];
     ldv<T, V>(x + p * ldx + c0, v);

@@ -22,6 +22,19 @@ template <typename T, int V> NPP_DEV void stv(T* p, const float* o) {
     }                                                                              \
   } while (0)
 
+// exact division of a 32-bit index by a runtime constant without the 64-bit (or even 32-bit) divide sequence
+struct FastDiv {
+  unsigned d, m;
+  __host__ __device__ FastDiv() : d(1), m(0) {}
+  __host__ __device__ explicit FastDiv(unsigned d_) : d(d_), m(d_ > 1 ? (unsigned)((1ull << 32) / d_) : 0) {}
+};
+NPP_DEV void fast_divmod(unsigned i, const FastDiv& f, unsigned& q, unsigned& r) {
+  if (f.d == 1) { q = i; r = 0; return; }
+  q = __umulhi(i, f.m);           // floor estimate, at most 1 too small for i < 2^31
+  r = i - q * f.d;
+  if (r >= f.d) { ++q; r -= f.d; }
+}
+
 static inline int grid_for(long items, int per_block = 256, int cap = 4096) {
   long b = (items + per_block - 1) / per_block;
   if (b < 1) b = 1;
