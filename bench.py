@@ -188,7 +188,7 @@ def main():
     import ctypes as C
     dt_code = _lib.NPP_BF16 if dtype == torch.bfloat16 else _lib.NPP_F32
     if prof and graph is None:
-        L.npp_prof_begin(_lib.FAM["conv_igemm"], dt_code)
+        L.npp_prof_begin(_lib.FAM["conv_s1"], dt_code)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -200,7 +200,7 @@ def main():
         # a replayed graph cannot carry the event pairs: time the same kernels (same shapes, same data) with HIP
         # events on the launch stream in two eager steps right after the timed region
         prof_steps = 2
-        L.npp_prof_begin(_lib.FAM["conv_igemm"], dt_code)
+        L.npp_prof_begin(_lib.FAM["conv_s1"], dt_code)
         for _ in range(prof_steps):
             eager_step()
         barrier()
@@ -210,7 +210,7 @@ def main():
         if nl.value > 0 and ms.value > 0:
             ach = fl.value / (ms.value * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.dtype]
-            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (conv fwd + dgrad implicit GEMM)",
+            roof = {"bound": "mfma", "kernel": "conv_s1_kernel (stride-1 conv fwd + dgrad on MFMA, both tile heights)",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": None, "launches_per_step": nl.value // max(prof_steps, 1),
                     "avg_launch_us": round(ms.value * 1e3 / nl.value, 2),

@@ -60,7 +60,8 @@ const char* npp_last_error(void);
 /* ---- profiling hook (bench.py roofline leg): HIP events around every launch of one kernel family,
  *      recorded on the launch stream; read back after the caller synchronised. ------------------- */
 enum { NPP_FAM_NONE = 0, NPP_FAM_CONV_IGEMM = 1, NPP_FAM_CONV_WGRAD = 2, NPP_FAM_DWCONV = 3,
-       NPP_FAM_BN = 4, NPP_FAM_ELTWISE = 5, NPP_FAM_POOL = 6, NPP_FAM_BILINEAR = 7, NPP_FAM_LOSS = 8 };
+       NPP_FAM_BN = 4, NPP_FAM_ELTWISE = 5, NPP_FAM_POOL = 6, NPP_FAM_BILINEAR = 7, NPP_FAM_LOSS = 8,
+       NPP_FAM_CONV_S1 = 9 /* the stride-1 fast path only (conv_s1_kernel) */ };
 int npp_prof_begin(int family, int dtype_filter /* -1 = any */);
 int npp_prof_end(double* ms_total, double* flops_total, double* bytes_total, int64_t* launches);
 
@@ -73,6 +74,14 @@ int64_t npp_packed_weight_elems(int cout, int cin, int kh, int kw, int for_dgrad
  * k = tap*cin_pad + ci.  for_dgrad=1: rows = cin, k = tap'*cout_pad + co with the taps flipped. */
 int npp_pack_weight(const float* w_oihw, int cout, int cin, int kh, int kw, int for_dgrad,
                     int dtype, void* out, void* stream);
+/* every conv weight of a model in one launch (device-resident job table, built once by the host):
+ * job i covers blocks [first_block_i, first_block_{i+1}) of 256 packed elements each. */
+typedef struct NppPackJob {
+  const float* w; void* out;
+  int32_t cout, cin, kh, kw, for_dgrad, dtype;
+  int64_t first_block;
+} NppPackJob;
+int npp_pack_weights_batched(const NppPackJob* jobs_dev, int njobs, int64_t total_blocks, void* stream);
 /* y = conv(relu?(x)) + bias; optional per-channel sum / sum-of-squares of y added into
  * stats[r][0..C) / stats[r][C..2C), r < NPP_STAT_REPLICAS (the BatchNorm batch statistics, operations.py:78);
  * optional mask: y *= (mask > 0) (ReLU backward when this call is a dgrad). */
@@ -138,7 +147,7 @@ int npp_se_gate_fwd(const float* pooled, const float* w1, const float* b1, const
                     int n, int c, void* stream);
 int npp_se_gate_bwd(const float* pooled, const float* hidden, const float* gate, const float* dgate,
                     const float* w1, const float* w2, float* dw1, float* db1, float* dw2, float* db2,
-                    float* dpooled, int n, int c, void* stream);
+                    float* dpooled, float* scratch /*[n][c + c/2]*/, int n, int c, void* stream);
 int npp_scale_channels(const NppTensor* x, const float* gate /*[N][C]*/, NppTensor* y, void* stream);
 int npp_se_bwd_reduce(const NppTensor* dout, const NppTensor* x, float* dgate /*[N][C], added*/, void* stream);
 /* dx = dout*gate + dpooled/(H*W) */

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libnpp_hip.so")
 NPP_F32, NPP_BF16 = 0, 1
 STAT_REPLICAS = 16   # NPP_STAT_REPLICAS in include/npp_hip.h
 FAM = {"none": 0, "conv_igemm": 1, "conv_wgrad": 2, "dwconv": 3, "bn": 4, "eltwise": 5, "pool": 6,
-       "bilinear": 7, "loss": 8}
+       "bilinear": 7, "loss": 8, "conv_s1": 9}
 
 
 class NppTensor(C.Structure):
@@ -30,6 +30,11 @@ class NppConvGeom(C.Structure):
                 ("pw", C.c_int32), ("dh", C.c_int32), ("dw", C.c_int32), ("uph", C.c_int32), ("upw", C.c_int32), ("relu_in", C.c_int32)]
 
 
+class NppPackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("kh", C.c_int32),
+                ("kw", C.c_int32), ("for_dgrad", C.c_int32), ("dtype", C.c_int32), ("first_block", C.c_int64)]
+
+
 _lib = None
 
 _P = C.c_void_p
@@ -39,6 +44,7 @@ _SIGS = {
     "npp_prof_begin": [C.c_int, C.c_int],
     "npp_prof_end": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "npp_pack_weight": [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
+    "npp_pack_weights_batched": [_P, C.c_int, C.c_int64, _P],
     "npp_conv_fwd": [_T, _P, _P, _T, _T, _P, _G, _P],
     "npp_conv_wgrad": [_T, _T, _P, _G, _P],
     "npp_unpack_wgrad": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
@@ -60,7 +66,7 @@ _SIGS = {
     "npp_pool2x2_bwd": [_T, _T, _T, C.c_int, _P],
     "npp_global_avgpool": [_T, _P, _P],
     "npp_se_gate_fwd": [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P],
-    "npp_se_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P],
+    "npp_se_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P],
     "npp_scale_channels": [_T, _P, _T, _P],
     "npp_se_bwd_reduce": [_T, _T, _P, _P],
     "npp_se_bwd_apply": [_T, _P, _P, _T, _P],

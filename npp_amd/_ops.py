@@ -97,6 +97,67 @@ def clear_caches():
     _pack_cache.clear()
 
 
+class WeightPacker:
+    """Packs every dense-conv weight of a model (forward and data-gradient operand images) with ONE kernel
+    launch whenever any of them changed (i.e. once per optimizer step) instead of ~820 tiny launches."""
+
+    def __init__(self, weights):
+        self.weights = list(weights)
+        self.sig = None
+        self.table = None
+        self.outs = None
+        self.key = None
+
+    def _build(self, dtype, device):
+        import numpy as np
+        jobs = (L.NppPackJob * (2 * len(self.weights)))()
+        outs = []
+        blk = 0
+        i = 0
+        for w in self.weights:
+            co, ci, kh, kw = w.shape
+            for dg in (0, 1):
+                n = lib().npp_packed_weight_elems(co, ci, kh, kw, dg)
+                out = torch.empty(n, dtype=dtype, device=device)
+                outs.append(out)
+                jobs[i] = L.NppPackJob(w.data_ptr(), out.data_ptr(), co, ci, kh, kw, dg, L.npp_dtype(dtype), blk)
+                blk += (n + 255) // 256
+                i += 1
+        raw = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()
+        self.table = torch.from_numpy(raw).to(device)
+        self.outs = outs
+        self.nblocks = blk
+        self.key = (dtype, device, tuple(w.data_ptr() for w in self.weights))
+
+    def pack_if_stale(self, dtype, device):
+        ws = self.weights
+        if not ws:
+            return
+        sig = tuple(w._version for w in ws)
+        key = (dtype, device, tuple(w.data_ptr() for w in ws))
+        if self.key != key:
+            if any(w.dtype != torch.float32 or not w.is_contiguous() or w.device != device for w in ws):
+                return        # unusual storage: leave it to the per-call path
+            self._build(dtype, device)
+            self.sig = None
+        if sig == self.sig:
+            return
+        check(lib().npp_pack_weights_batched(self.table.data_ptr(), 2 * len(ws), self.nblocks, stream_ptr()),
+              "npp_pack_weights_batched")
+        self.sig = sig
+        k = 0
+        for w in ws:
+            wid = id(w)
+            ent = _pack_cache.get(wid)
+            if ent is None or ent[0]() is not w:
+                ent = (weakref.ref(w, lambda _r, _k=wid: _pack_cache.pop(_k, None)), {})
+                _pack_cache[wid] = ent
+            ver = (w._version, w.data_ptr())
+            ent[1][(False, dtype)] = (ver, self.outs[k])
+            ent[1][(True, dtype)] = (ver, self.outs[k + 1])
+            k += 2
+
+
 def _gemm_ready(x: torch.Tensor) -> torch.Tensor:
     """The MFMA gathers read whole 16-byte channel groups: a tensor whose channel count is not a multiple of 8
     must sit in rows padded (with zeros) to the next multiple.  Tensors made by this package already do."""
@@ -173,11 +234,16 @@ class _Conv2d(Function):
                                      C.byref(g), s), "npp_conv_fwd(dgrad)")
         if ctx.needs_input_grad[1]:
             nel = lib().npp_packed_weight_elems(co, ci, kh, kw, 0)
-            dwp = zeros_f32(nel, x.device)
             g = geom(kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 1, relu_in)
-            check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-            check(lib().npp_unpack_wgrad(dwp.data_ptr(), co, ci, kh, kw, dw.data_ptr(), s), "npp_unpack_wgrad")
+            if kh == 1 and kw == 1 and ci % 64 == 0 and co % 32 == 0:
+                # packed [co][ci] == OIHW: accumulate straight into the gradient tensor
+                dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+                check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
+            else:
+                dwp = zeros_f32(nel, x.device)
+                check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
+                dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                check(lib().npp_unpack_wgrad(dwp.data_ptr(), co, ci, kh, kw, dw.data_ptr(), s), "npp_unpack_wgrad")
             if dw.dtype != weight.dtype:
                 dw = dw.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
@@ -239,7 +305,7 @@ class _DwConv2d(Function):
             check(lib().npp_dwconv_bwd_data(_byref(dy), wf.data_ptr(), _byref(x) if relu_in else None, _byref(dx),
                                             C.byref(g), s), "npp_dwconv_bwd_data")
         if ctx.needs_input_grad[1]:
-            dw = zeros_f32(weight.numel(), x.device).view(weight.shape)
+            dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
             check(lib().npp_dwconv_bwd_weight(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_dwconv_bwd_weight")
             if dw.dtype != weight.dtype:
                 dw = dw.to(weight.dtype)
@@ -536,15 +602,16 @@ class _SEScale(Function):
         s = stream_ptr()
         dgate = zeros_f32(n * c, dev).view(n, c)
         check(lib().npp_se_bwd_reduce(_byref(dy), _byref(x), dgate.data_ptr(), s), "npp_se_bwd_reduce")
-        dw1 = zeros_f32(w1.numel(), dev).view(w1.shape)
-        db1 = zeros_f32(c // 2, dev)
-        dw2 = zeros_f32(w2.numel(), dev).view(w2.shape)
-        db2 = zeros_f32(c, dev)
+        dw1 = torch.empty(w1.shape, dtype=torch.float32, device=dev)
+        db1 = torch.empty(c // 2, dtype=torch.float32, device=dev)
+        dw2 = torch.empty(w2.shape, dtype=torch.float32, device=dev)
+        db2 = torch.empty(c, dtype=torch.float32, device=dev)
         dpooled = torch.empty((n, c), dtype=torch.float32, device=dev)
+        scratch = torch.empty((n, c + c // 2), dtype=torch.float32, device=dev)
         w1f, w2f = w1.detach().float().contiguous(), w2.detach().float().contiguous()
         check(lib().npp_se_gate_bwd(pooled.data_ptr(), hidden.data_ptr(), gate.data_ptr(), dgate.data_ptr(),
                                     w1f.data_ptr(), w2f.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
-                                    db2.data_ptr(), dpooled.data_ptr(), n, c, s), "npp_se_gate_bwd")
+                                    db2.data_ptr(), dpooled.data_ptr(), scratch.data_ptr(), n, c, s), "npp_se_gate_bwd")
         dx = new_nhwc(n, c, h, w, x.dtype, dev)
         check(lib().npp_se_bwd_apply(_byref(dy), gate.data_ptr(), dpooled.data_ptr(), _byref(dx), s), "npp_se_bwd_apply")
         return dx, dw1, db1, dw2, db2

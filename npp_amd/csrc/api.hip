@@ -37,7 +37,8 @@ struct ProfState {
 } g_prof;
 }  // namespace
 
-ProfScope::ProfScope(int family, int dtype, hipStream_t s, double flops, double bytes) : slot(-1), stream(s) {
+ProfScope::ProfScope(int family, int dtype, hipStream_t s, double flops, double bytes)
+    : slot(-1), stream(s), flops_(flops), bytes_(bytes) {
   if (g_prof.family != family) return;
   if (g_prof.dtype >= 0 && g_prof.dtype != dtype) return;
   std::lock_guard<std::mutex> lk(g_prof.mu);
@@ -56,7 +57,18 @@ ProfScope::ProfScope(int family, int dtype, hipStream_t s, double flops, double 
   hipEventRecord(g_prof.ev[slot], s);
 }
 ProfScope::~ProfScope() {
-  if (slot >= 0) hipEventRecord(g_prof.ev[slot + 1], stream);
+  if (slot >= 0) (void)hipEventRecord(g_prof.ev[slot + 1], stream);
+}
+
+void ProfScope::cancel() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  if (g_prof.used == slot + 2) {
+    g_prof.used -= 2;
+    g_prof.flops -= flops_;
+    g_prof.bytes -= bytes_;
+  }
+  slot = -1;
 }
 
 extern "C" int npp_prof_begin(int family, int dtype_filter) {

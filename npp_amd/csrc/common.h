@@ -86,8 +86,10 @@ int npp_check_launch(const char* what);
 struct ProfScope {  // HIP events around one launch when the family is being profiled
   ProfScope(int family, int dtype, hipStream_t s, double flops, double bytes);
   ~ProfScope();
+  void cancel();   // the launch this scope was opened for did not happen
   int slot;
   hipStream_t stream;
+  double flops_, bytes_;
 };
 
 static inline bool vec_ok(const NppTensor* t) {

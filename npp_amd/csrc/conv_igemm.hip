@@ -292,7 +292,43 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+// all conv weights of a model in ONE launch: block -> job by binary search over the jobs' first block
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const NppPackJob* __restrict__ jobs, int njobs) {
+  const long b = blockIdx.x;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const NppPackJob j = jobs[lo];
+  const int rows = j.for_dgrad ? j.cin : j.cout, red = j.for_dgrad ? j.cout : j.cin;
+  const int cp = (red + 7) / 8 * 8;
+  const int taps = j.kh * j.kw;
+  const int kpad = (taps * cp + 63) / 64 * 64;
+  const unsigned total = (unsigned)((rows + 31) / 32 * 32) * (unsigned)kpad;   // < 2^31 for any real conv
+  const unsigned i = (unsigned)(b - j.first_block) * 256u + threadIdx.x;
+  if (i >= total) return;
+  const unsigned row = i / (unsigned)kpad, k = i - row * (unsigned)kpad;
+  const int tap = (int)(k / (unsigned)cp), c = (int)(k - (unsigned)tap * (unsigned)cp);
+  float v = 0.f;
+  if (tap < taps) {
+    if (!j.for_dgrad) {
+      if ((int)row < j.cout && c < j.cin) v = j.w[((long)row * j.cin + c) * taps + tap];
+    } else {
+      if ((int)row < j.cin && c < j.cout) v = j.w[((long)c * j.cin + row) * taps + (taps - 1 - tap)];
+    }
+  }
+  if (j.dtype == NPP_BF16) reinterpret_cast<bf16_t*>(j.out)[i] = f2bf(v);
+  else reinterpret_cast<float*>(j.out)[i] = v;
+}
+
 }  // namespace
+
+extern "C" int npp_pack_weights_batched(const NppPackJob* jobs_dev, int njobs, int64_t total_blocks, void* stream) {
+  NPP_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0 && total_blocks < (1L << 31), NPP_E_NULL, "npp_pack_weights_batched: bad arguments");
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+  return npp_check_launch("pack_weights_batched");
+}
 
 extern "C" int64_t npp_packed_weight_elems(int cout, int cin, int kh, int kw, int for_dgrad) {
   const int rows = for_dgrad ? cin : cout, red = for_dgrad ? cout : cin;
@@ -364,8 +400,12 @@ extern "C" int npp_conv_fwd(const NppTensor* x, const void* w_packed, const floa
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * (double)M * p.Cout * (double)(g->kh * g->kw) * p.Cin;
   const double bytes = ((double)x->n * x->h * x->w * x->c + (double)M * y->c + (double)p.Cout * g->kh * g->kw * p.Cin) * esize(x->dtype);
+  {
+    ProfScope prof1(NPP_FAM_CONV_S1, x->dtype, s, flops, bytes);
+    if (conv_s1_launch(p, x->dtype, s)) return npp_check_launch("conv_s1");
+    prof1.cancel();    // not taken: the generic kernel below is a different family
+  }
   ProfScope prof(NPP_FAM_CONV_IGEMM, x->dtype, s, flops, bytes);
-  if (conv_s1_launch(p, x->dtype, s)) return npp_check_launch("conv_s1");
 #define LAUNCH(T, BN_) hipLaunchKernelGGL((conv_igemm_kernel<T, BN_>), dim3(grid), dim3(256), 0, s, p)
   if (x->dtype == NPP_BF16) {
     if (bn == 128) LAUNCH(bf16_t, 128); else if (bn == 64) LAUNCH(bf16_t, 64); else LAUNCH(bf16_t, 32);

@@ -19,6 +19,7 @@
 //
 // Replaces the weight-gradient half of nn.Conv2d backward for every call site listed in conv_igemm.hip.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -259,7 +260,8 @@ extern "C" int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw
   p.rowtiles = rows_pad / tm;
   const int coltiles = (p.Kpad + 127) / 128;
   const int tiles = p.rowtiles * coltiles;
-  int splits = 1024 / tiles;
+  static const int target_blocks = getenv("NPP_WGRAD_BLOCKS") ? atoi(getenv("NPP_WGRAD_BLOCKS")) : 512;
+  int splits = target_blocks / tiles;
   if (splits < 1) splits = 1;
   if (splits > p.nchunks) splits = p.nchunks;
   p.chunks_per_split = (p.nchunks + splits - 1) / splits;

@@ -269,42 +269,63 @@ __global__ void se_gate_fwd_kernel(const float* __restrict__ pooled, const float
   }
 }
 
-// backward of the gate MLP; grid = N blocks; parameter grads via float atomics (tiny)
-__global__ void se_gate_bwd_kernel(const float* __restrict__ pooled, const float* __restrict__ hidden,
-                                   const float* __restrict__ gate, const float* __restrict__ dgate,
-                                   const float* __restrict__ w1, const float* __restrict__ w2, float* dw1, float* db1,
-                                   float* dw2, float* db2, float* __restrict__ dpooled, int C) {
-  extern __shared__ float sm[];  // dz2[C] + dz1[C/2] + pooled[C] + hidden[C/2]
+// backward of the gate MLP, phase A (grid = N blocks): per-image pre-activation gradients dz2 [C], dz1 [C/2]
+// (written to scratch) and dpooled; phase B: parameter gradients as plain sums over the batch (no atomics).
+__global__ void se_gate_bwd_a_kernel(const float* __restrict__ hidden, const float* __restrict__ gate,
+                                     const float* __restrict__ dgate, const float* __restrict__ w1,
+                                     const float* __restrict__ w2, float* __restrict__ dz /*[N][C + C/2]*/,
+                                     float* __restrict__ dpooled, int C) {
+  extern __shared__ float sm[];  // dz2[C] + dz1[C/2]
   const int n = blockIdx.x, Ch = C / 2;
   float* dz2 = sm;
   float* dz1 = sm + C;
-  float* sp = dz1 + Ch;
-  float* sh = sp + C;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float g = gate[(long)n * C + c];
     dz2[c] = dgate[(long)n * C + c] * g * (1.f - g);
-    sp[c] = pooled[(long)n * C + c];
   }
-  for (int c = threadIdx.x; c < Ch; c += blockDim.x) sh[c] = hidden[(long)n * Ch + c];
   __syncthreads();
-  for (int o = threadIdx.x; o < C; o += blockDim.x) {
-    atomicAdd(db2 + o, dz2[o]);
-    for (int c = 0; c < Ch; ++c) atomicAdd(dw2 + (long)o * Ch + c, dz2[o] * sh[c]);
-  }
   for (int c = threadIdx.x; c < Ch; c += blockDim.x) {
     float s = 0.f;
     for (int o = 0; o < C; ++o) s += w2[(long)o * Ch + c] * dz2[o];
-    dz1[c] = sh[c] > 0.f ? s : 0.f;
+    dz1[c] = hidden[(long)n * Ch + c] > 0.f ? s : 0.f;
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < Ch; o += blockDim.x) {
-    atomicAdd(db1 + o, dz1[o]);
-    for (int c = 0; c < C; ++c) atomicAdd(dw1 + (long)o * C + c, dz1[o] * sp[c]);
-  }
+  float* dzn = dz + (long)n * (C + Ch);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    dzn[c] = dz2[c];
     float s = 0.f;
     for (int o = 0; o < Ch; ++o) s += w1[(long)o * C + c] * dz1[o];
     dpooled[(long)n * C + c] = s;
+  }
+  for (int c = threadIdx.x; c < Ch; c += blockDim.x) dzn[C + c] = dz1[c];
+}
+
+__global__ void se_gate_bwd_b_kernel(const float* __restrict__ pooled, const float* __restrict__ hidden,
+                                     const float* __restrict__ dz, float* __restrict__ dw1, float* __restrict__ db1,
+                                     float* __restrict__ dw2, float* __restrict__ db2, int N, int C) {
+  const int Ch = C / 2, ld = C + Ch;
+  const int nw = C * Ch;                       // elements of each weight matrix
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nw) {                                // dw2[o][c] = sum_n dz2[n][o] * hidden[n][c]
+    const int o = i / Ch, c = i - o * Ch;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dz[(long)n * ld + o] * hidden[(long)n * Ch + c];
+    dw2[i] = s;
+  } else if (i < 2 * nw) {                     // dw1[c][k] = sum_n dz1[n][c] * pooled[n][k]
+    const int e = i - nw, c = e / C, k = e - c * C;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dz[(long)n * ld + C + c] * pooled[(long)n * C + k];
+    dw1[e] = s;
+  } else if (i < 2 * nw + C) {                 // db2
+    const int o = i - 2 * nw;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dz[(long)n * ld + o];
+    db2[o] = s;
+  } else if (i < 2 * nw + C + Ch) {            // db1
+    const int c = i - 2 * nw - C;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dz[(long)n * ld + C + c];
+    db1[c] = s;
   }
 }
 
@@ -449,12 +470,16 @@ extern "C" int npp_se_gate_fwd(const float* pooled, const float* w1, const float
 
 extern "C" int npp_se_gate_bwd(const float* pooled, const float* hidden, const float* gate, const float* dgate,
                                const float* w1, const float* w2, float* dw1, float* db1, float* dw2, float* db2,
-                               float* dpooled, int n, int c, void* stream) {
-  NPP_REQUIRE(pooled && hidden && gate && dgate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpooled, NPP_E_NULL,
+                               float* dpooled, float* scratch, int n, int c, void* stream) {
+  NPP_REQUIRE(pooled && hidden && gate && dgate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpooled && scratch, NPP_E_NULL,
               "npp_se_gate_bwd: null pointer");
   NPP_REQUIRE(c >= 2 && c % 2 == 0 && c <= 8192, NPP_E_SHAPE, "npp_se_gate_bwd: bad channel count %d", c);
-  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(n), dim3(256), 3 * c * sizeof(float), (hipStream_t)stream, pooled, hidden, gate,
-                     dgate, w1, w2, dw1, db1, dw2, db2, dpooled, c);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(se_gate_bwd_a_kernel, dim3(n), dim3(256), (c + c / 2) * sizeof(float), s, hidden, gate, dgate, w1, w2,
+                     scratch, dpooled, c);
+  const int total = c * (c / 2) * 2 + c + c / 2;
+  hipLaunchKernelGGL(se_gate_bwd_b_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pooled, hidden, scratch, dw1, db1, dw2,
+                     db2, n, c);
   return npp_check_launch("se_gate_bwd");
 }
 

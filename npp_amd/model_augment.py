@@ -285,6 +285,7 @@ class Network(nn.Module):
             self.pose_auxnet.append(head(3 * Cf, 128, 3, self._num_joints))
             self.par_head.append(head(4 * Cf, 256, 1, self._num_classes))
             self.edge_head.append(head(3 * Cf, 6, 3, 2, bias1=False))
+        self._packer = None
         self._init_params()
 
     # -- construction helpers ---------------------------------------------------------------------------
@@ -329,6 +330,15 @@ class Network(nn.Module):
             raise RuntimeError("npp_amd.Network runs on the MI355X HIP kernels only: move the input to cuda "
                                "(there is no CPU fallback)")
         dt = _compute_dtype
+        if self._packer is None:
+            from .operations import SE_Block
+            skip = set()
+            for m in self.modules():
+                if isinstance(m, SE_Block):
+                    skip.update((id(m.conv1.weight), id(m.conv2.weight)))
+            self._packer = K.WeightPacker(m.weight for m in self.modules()
+                                          if isinstance(m, nn.Conv2d) and m.groups == 1 and id(m.weight) not in skip)
+        self._packer.pack_if_stale(dt, x.device)
         x = K.image_to_nhwc(x, dt)
         s1 = self.stem2(s0 := self.stem1(self.stem0(x)))
         s3 = self.stem5(s2 := self.stem4(self.stem3(x)))
