@@ -117,9 +117,12 @@ int npp_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
  * (identity).  Fuses BN-apply of both branches with the cell's h1 + h2 (model_augment.py:58). */
 int npp_affine_add(NppTensor* out, const NppTensor* a, const float* ss_a, const NppTensor* b,
                    const float* ss_b, int relu, void* stream);
-/* sums[r][0..C) += sum dy', sums[r][C..2C) += sum dy' * xhat, dy' = dout * (out>0 if relu_out given) */
+/* partials[b][0..C) = sum dy', partials[b][C..2C) = sum dy' * xhat over block b's pixels, dy' = dout * (out>0 if
+ * relu_out given): one private slab per block (written, not added: no atomics, no zero-init).
+ * nblocks = npp_reduce_blocks(N*H*W, C, dtype) (or fewer); bn_bwd_coeffs sums the slabs (nrep = nblocks). */
+int npp_reduce_blocks(int64_t npix, int64_t c, int dtype);
 int npp_bn_bwd_reduce(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,
-                      const float* mean_invstd, double* sums /*[R][2C]*/, void* stream);
+                      const float* mean_invstd, double* partials /*[nblocks][2C]*/, int nblocks, void* stream);
 /* per-channel coefficients of dy_raw = A*dy' + B*y_raw + C  (= gamma*invstd*(dy' - s0/n - xhat*s1/n)),
  * coeffs = [A[C] | B[C] | C[C]]; dgamma = s1, dbeta = s0 (optional).  sums = [nrep][2C]. */
 int npp_bn_bwd_coeffs(const double* sums, int nrep, double count, const float* mean_invstd, const float* gamma,

@@ -56,7 +56,8 @@ _SIGS = {
     "npp_bn_finalize": [_P, C.c_int, C.c_double, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int, _P],
     "npp_bn_eval_coeffs": [_P, _P, _P, _P, C.c_float, _P, C.c_int, _P],
     "npp_affine_add": [_T, _T, _P, _T, _P, C.c_int, _P],
-    "npp_bn_bwd_reduce": [_T, _T, _T, _P, _P, _P],
+    "npp_bn_bwd_reduce": [_T, _T, _T, _P, _P, C.c_int, _P],
+
     "npp_bn_bwd_coeffs": [_P, C.c_int, C.c_double, _P, _P, _P, _P, _P, C.c_int, _P],
     "npp_bn_bwd_apply": [_T, _T, _T, _P, _T, _P],
     "npp_scale_mask": [_T, _P, _T, _T, _P],
@@ -83,7 +84,7 @@ _SIGS = {
     "npp_ce_pixel_bwd": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _T, _P],
     "npp_edge_weights": [_P, C.c_int64, _P, _P],
 }
-EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_packed_weight_elems"])
+EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_packed_weight_elems", "npp_reduce_blocks"])
 
 
 def lib():
@@ -99,6 +100,8 @@ def lib():
         L.npp_last_error.restype = C.c_char_p
         L.npp_packed_weight_elems.restype = C.c_int64
         L.npp_packed_weight_elems.argtypes = [C.c_int] * 5
+        L.npp_reduce_blocks.restype = C.c_int
+        L.npp_reduce_blocks.argtypes = [C.c_int64, C.c_int64, C.c_int]
         for name, sig in _SIGS.items():
             f = getattr(L, name)
             f.restype = C.c_int

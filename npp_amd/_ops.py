@@ -422,18 +422,19 @@ class _BnAdd(Function):
                         check(lib().npp_scale_mask(_byref(dout), None, _byref(yrelu), _byref(dx), s), "npp_scale_mask")
                 return dx, None, None
             c = x.shape[1]
-            sums = zeros_f64(R * 2 * c, x.device)
-            check(lib().npp_bn_bwd_reduce(_byref(dout), _byref(x), tref(yrelu), mi.data_ptr(), sums.data_ptr(), s),
+            nb = lib().npp_reduce_blocks(x.shape[0] * x.shape[2] * x.shape[3], c, L.npp_dtype(x.dtype))
+            sums = torch.empty(nb * 2 * c, dtype=torch.float64, device=x.device)   # one slab per block, written
+            check(lib().npp_bn_bwd_reduce(_byref(dout), _byref(x), tref(yrelu), mi.data_ptr(), sums.data_ptr(), nb, s),
                   "npp_bn_bwd_reduce")
             gamma = bn.weight.detach() if bn.weight is not None else None
             if batch:
                 grp, ws = _sync_group(bn)
-                nrep = R
+                nrep = nb
                 dgt = dbt = None
                 if grp is not None:
                     # SyncBatchNorm: weight/bias grads are the LOCAL sums (DDP averages them afterwards);
                     # the input gradient uses the all-reduced sums over the global count.
-                    local = sums.view(R, 2 * c).sum(0)
+                    local = sums.view(nb, 2 * c).sum(0)
                     dg, db = local[c:].float(), local[:c].float()
                     sums = local.clone()
                     nrep = 1
@@ -453,7 +454,7 @@ class _BnAdd(Function):
                 if need_x:
                     dx = new_nhwc(*x.shape, x.dtype, x.device)
                     check(lib().npp_scale_mask(_byref(dout), ss.data_ptr(), tref(yrelu), _byref(dx), s), "npp_scale_mask")
-                tot = sums.view(R, 2 * c).sum(0)
+                tot = sums.view(nb, 2 * c).sum(0)
                 dg, db = tot[c:].float(), tot[:c].float()
             return (dx if need_x else None), (dg if need_g else None), (db if need_b else None)
 

@@ -34,7 +34,7 @@ static inline dim3 col_grid_ew(const ColMap& m, long npix) {
   return dim3((unsigned)bx, (unsigned)((m.cv + m.cols_blk - 1) / m.cols_blk));
 }
 
-template <int NQ, int V>
+template <int NQ, int V, bool STORE = false>
 NPP_DEV void block_col_reduce(double (&acc)[NQ][V], float* red /*[256][NQ*V] doubles as 2 floats*/, int t, int col,
                               int row, int rows, int cols_blk, bool active, double* const* outs, int colg, int C) {
   double* dred = reinterpret_cast<double*>(red);
@@ -53,7 +53,10 @@ NPP_DEV void block_col_reduce(double (&acc)[NQ][V], float* red /*[256][NQ*V] dou
         double s = 0.0;
         for (int rr = 0; rr < rows; ++rr) s += dred[(long)(rr * cols_blk + col) * NQ * V + qn * V + j];
         const int ch = colg * V + j;
-        if (ch < C) atomicAdd(outs[qn] + ch, s);   // outs already point at this block's replica
+        if (ch < C) {
+          if (STORE) outs[qn][ch] = s;             // private partial slab: no atomics, no zero-init
+          else atomicAdd(outs[qn] + ch, s);        // outs already point at this block's replica
+        }
       }
   }
 }
@@ -95,6 +98,13 @@ NPP_DEV void replica_sum(const double* __restrict__ buf, int nrep, int C, int c,
   for (int r = sub; r < nrep; r += 16) { s0 += buf[(long)r * 2 * C + c]; s1 += buf[(long)r * 2 * C + C + c]; }
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 16); s1 += __shfl_xor(s1, o, 16); }
+}
+// One whole wave per channel (up to ~1000 partial slabs)
+NPP_DEV void slab_sum(const double* __restrict__ buf, int nrep, int C, int c, int lane, double& s0, double& s1) {
+  s0 = 0.0; s1 = 0.0;
+  for (int r = lane; r < nrep; r += 64) { s0 += buf[(long)r * 2 * C + c]; s1 += buf[(long)r * 2 * C + C + c]; }
+  s0 = wave_sum_d(s0);
+  s1 = wave_sum_d(s1);
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int nrep, double count, const float* gamma, const float* beta,
@@ -237,18 +247,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       }
     }
   }
-  double* rep = sums + (long)(blockIdx.x % NPP_STAT_REPLICAS) * 2 * C;
+  double* rep = sums + (long)blockIdx.x * 2 * C;      // one partial slab per blockIdx.x
   double* outs[2] = {rep, rep + C};
-  block_col_reduce<2, V>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
+  block_col_reduce<2, V, true>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
 }
 
 __global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums, int nrep, double inv_count, const float* __restrict__ mi,
                                      const float* __restrict__ gamma, float* __restrict__ co, float* dgamma, float* dbeta, int C) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = gid >> 4, sub = gid & 15;
+  const int c = gid >> 6, sub = gid & 63;
   const bool live = c < C;
   double s0, s1;
-  replica_sum(sums, nrep, C, live ? c : 0, sub, s0, s1);
+  slab_sum(sums, nrep, C, live ? c : 0, sub, s0, s1);
   if (!live || sub != 0) return;
   const float mean = mi[c], invstd = mi[C + c];
   const float g = gamma ? gamma[c] : 1.f;
@@ -396,21 +406,33 @@ extern "C" int npp_affine_add(NppTensor* out, const NppTensor* a, const float* s
   return npp_check_launch("affine_add");
 }
 
+static inline int reduce_blocks(long npix, long c, int dtype) {
+  const int v = dtype == NPP_BF16 ? 8 : 4;
+  ColMap m = col_map(c, (c % v == 0) ? v : 1);
+  long bx = (npix + 2L * m.rows - 1) / (2L * m.rows);
+  if (bx > 1024) bx = 1024;
+  if (bx < 1) bx = 1;
+  return (int)bx;
+}
+extern "C" int npp_reduce_blocks(int64_t npix, int64_t c, int dtype) { return reduce_blocks(npix, c, dtype); }
+
 extern "C" int npp_bn_bwd_reduce(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,
-                                 const float* mean_invstd, double* sums, void* stream) {
-  NPP_REQUIRE(dout && y_raw && mean_invstd && sums, NPP_E_NULL, "npp_bn_bwd_reduce: null pointer");
+                                 const float* mean_invstd, double* partials, int nblocks, void* stream) {
+  NPP_REQUIRE(dout && y_raw && mean_invstd && partials, NPP_E_NULL, "npp_bn_bwd_reduce: null pointer");
   NPP_REQUIRE(same_shape(dout, y_raw) && (!relu_out || same_shape(dout, relu_out)), NPP_E_SHAPE,
               "npp_bn_bwd_reduce: shape mismatch");
   NPP_REQUIRE(dtype_ok(dout) && dout->dtype == y_raw->dtype && (!relu_out || relu_out->dtype == dout->dtype), NPP_E_DTYPE,
               "npp_bn_bwd_reduce: dtype mismatch");
+  NPP_REQUIRE(nblocks >= 1 && nblocks <= 65535, NPP_E_SHAPE, "npp_bn_bwd_reduce: bad partial-slab count %d", nblocks);
   const bool vk = vec_ok(dout) && vec_ok(y_raw) && (!relu_out || vec_ok(relu_out));
   ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 2);
   NPP_DISPATCH_TV(dout->dtype, vk, {
     ColMap m = col_map(dout->c, V);
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, V>), col_grid(m, npix(dout)), dim3(256), 0, (hipStream_t)stream,
+    dim3 grid((unsigned)nblocks, (unsigned)((m.cv + m.cols_blk - 1) / m.cols_blk));
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, V>), grid, dim3(256), 0, (hipStream_t)stream,
                        (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
                        relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, mean_invstd,
-                       (long)npix(dout), (int)dout->c, m, sums);
+                       (long)npix(dout), (int)dout->c, m, partials);
   });
   return npp_check_launch("bn_bwd_reduce");
 }
@@ -418,7 +440,7 @@ extern "C" int npp_bn_bwd_reduce(const NppTensor* dout, const NppTensor* y_raw, 
 extern "C" int npp_bn_bwd_coeffs(const double* sums, int nrep, double count, const float* mean_invstd, const float* gamma,
                                  float* coeffs, float* dgamma, float* dbeta, int c, void* stream) {
   NPP_REQUIRE(sums && mean_invstd && coeffs && c > 0 && count > 0 && nrep >= 1, NPP_E_NULL, "npp_bn_bwd_coeffs: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((c * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, nrep, 1.0 / count,
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((c * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, nrep, 1.0 / count,
                      mean_invstd, gamma, coeffs, dgamma, dbeta, c);
   return npp_check_launch("bn_bwd_coeffs");
 }

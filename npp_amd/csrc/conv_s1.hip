@@ -20,10 +20,8 @@
 
 namespace {
 
-constexpr int KCB = 128;       // bytes of K (channels) per LDS row = per chunk
-constexpr int BN = 128;
-constexpr int PITCH = KCB + 16;   // LDS row pitch (bytes)
-constexpr int BTILE = BN * PITCH;
+// KCB = bytes of K (channels) per LDS row = per chunk (128 or 64); LDS row pitch = KCB + 16; BN = output channels
+// per tile (128 / 64 / 32: two, one, one wave columns of 64 / 64 / 32 channels).
 
 template <typename T> NPP_DEV u32x4 relu16s(u32x4 v);
 template <> NPP_DEV u32x4 relu16s<float>(u32x4 v) {
@@ -58,13 +56,20 @@ struct S1Extra {
   int dbg;   // timing experiments only (NPP_S1_DBG): 1 = skip the main loop, 2 = skip the epilogue stores, 4 = no stats
 };
 
-template <typename T, int BM>
-__global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra e) {
+template <typename T, int BM, int BN, int KCB>
+__global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_kernel(IgemmParams p, S1Extra e) {
   constexpr int VEC = 16 / (int)sizeof(T);
-  constexpr int KC = KCB / (int)sizeof(T);       // channels per chunk: 64 bf16 / 32 f32
-  constexpr int NT = BM * 2;
-  constexpr int BPT = (BN * 8) / NT;             // B pieces per thread per stage
-  constexpr int APT_MAX = (BM == 128) ? 12 : 8;
+  constexpr int KC = KCB / (int)sizeof(T);       // channels per chunk
+  constexpr int PITCH = KCB + 16;
+  constexpr int BTILE = BN * PITCH;
+  constexpr int PPR = KCB / 16;                  // 16-byte pieces per LDS row
+  constexpr int KS = KCB / 32;                   // MFMA k-steps (fragment pairs) per stage
+  constexpr int WAVES_N = BN >= 128 ? 2 : 1;
+  constexpr int WN = BN / WAVES_N;               // 64, 64, 32
+  constexpr int NI = WN / 32;
+  constexpr int NT = (BM / 64) * WAVES_N * 64;
+  constexpr int BPT = (BN * PPR + NT - 1) / NT;  // B pieces per thread per stage
+  constexpr int APT_MAX = (BM == 256 && BN == 128) ? 8 : 12;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int asz = e.AR * PITCH;
   unsigned char* const sA0 = smem;
@@ -84,12 +89,12 @@ __global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra 
 #pragma unroll
   for (int i = 0; i < BPT; ++i) {
     const int el = t + i * NT;
-    bdst[i] = (el >> 3) * PITCH + (el & 7) * 16;
+    bdst[i] = (el < BN * PPR) ? (el / PPR) * PITCH + (el % PPR) * 16 : -1;
   }
 #pragma unroll
   for (int i = 0; i < APT_MAX; ++i) {
-    const int j = (t >> 3) + i * (NT / 8);
-    adst[i] = ((i < e.apt) && (j < e.AR)) ? j * PITCH + (t & 7) * 16 : -1;
+    const int j = (t / PPR) + i * (NT / PPR);
+    adst[i] = ((i < e.apt) && (j < e.AR)) ? j * PITCH + (t % PPR) * 16 : -1;
   }
   // XCD-aware tile order (cdna_hip_programming.md T1): the tiles of one XCD's blocks are contiguous, N-tile
   // fastest, so the blocks that re-read one input footprint share an L2.
@@ -102,8 +107,8 @@ __global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra 
   auto setup_roles = [&](long q0, int n0) {
     // this thread stages footprint rows j = (t>>3) + i*(NT/8); decode the first one (shifted by one image so the
     // dividend is non-negative), then walk the gapped axis incrementally: no division per row.
-    const int pc8 = t & 7;
-    const int qq = (int)(q0 - e.halo) + (t >> 3) + img;
+    const int pc8 = t % PPR;
+    const int qq = (int)(q0 - e.halo) + (t / PPR) + img;
     int n = qq / img - 1;
     const int rem = qq - (n + 1) * img;
     int y = rem / e.Wp, x = rem - y * e.Wp;
@@ -113,14 +118,14 @@ __global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra 
       if (adst[i] >= 0 && n >= 0 && n < p.N && y < p.H && x < p.W)
         src = xg + ((long)(n * p.H + y) * p.W + x) * p.ldx + pc8 * VEC;
       asrc[i] = src;
-      x += NT / 8;
+      x += NT / PPR;
       while (x >= e.Wp) { x -= e.Wp; ++y; }
       while (y >= e.Hp) { y -= e.Hp; ++n; }
     }
 #pragma unroll
     for (int i = 0; i < BPT; ++i) {
       const int el = t + i * NT;
-      bsrc[i] = wg + (long)(n0 + (el >> 3)) * p.Kpad + (el & 7) * VEC;
+      bsrc[i] = wg + (long)(n0 + (el / PPR) % BN) * p.Kpad + (el % PPR) * VEC;
     }
   };
   u32x4 ra[APT_MAX], rb[BPT];
@@ -141,19 +146,21 @@ __global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra 
   auto load_B = [&](int chunk, int tap) {
     const long koff = (long)tap * p.Cp + (long)chunk * KC;
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) rb[i] = *reinterpret_cast<const u32x4*>(bsrc[i] + koff);
+    for (int i = 0; i < BPT; ++i)
+      if (bdst[i] >= 0) rb[i] = *reinterpret_cast<const u32x4*>(bsrc[i] + koff);
   };
   auto store_B = [&](int buf) {
     unsigned char* d = sB0 + buf * BTILE;
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) *reinterpret_cast<u32x4*>(d + bdst[i]) = rb[i];
+    for (int i = 0; i < BPT; ++i)
+      if (bdst[i] >= 0) *reinterpret_cast<u32x4*>(d + bdst[i]) = rb[i];
   };
 
   // ---- compute roles ------------------------------------------------------------------------------
   const int wave = t >> 6, lane = t & 63;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int r = lane & 31, h = lane >> 5;
-  const int boff = (wn * 64 + r) * PITCH + h * 16;      // + ni*32*PITCH + ks*32 as immediates
+  const int boff = (wn * WN + r) * PITCH + h * 16;      // + ni*32*PITCH + ks*32 as immediates
   const int aoff = (wm * 64 + r) * PITCH + h * 16;      // + tap offset + mi*32*PITCH + ks*32
   constexpr int CP = BN + 4;
   float* sC = reinterpret_cast<float*>(smem);
@@ -172,11 +179,11 @@ __global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra 
   load_A(0);
   load_B(0, 0);
   while (true) {
-    f32x16 acc[2][2];
+    f32x16 acc[2][NI];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int el = 0; el < 16; ++el) acc[mi][ni][el] = 0.f;
     // stage counters: (chunk, tap) of stages s, s+1, s+2
@@ -211,16 +218,16 @@ __global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra 
       const unsigned char* a = sA0 + ((c0 & 1) & (e.abufs - 1)) * asz + off * PITCH + aoff;
       const unsigned char* b = sB0 + (s & 1) * BTILE + boff;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        u32x4 fa[2], fb[2];
+      for (int ks = 0; ks < KS; ++ks) {
+        u32x4 fa[2], fb[NI];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) fa[mi] = *reinterpret_cast<const u32x4*>(a + mi * 32 * PITCH + ks * 32);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(b + ni * 32 * PITCH + ks * 32);
+        for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(b + ni * 32 * PITCH + ks * 32);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) mma_frag_s<T>(acc[mi][ni], fa[mi], fb[ni]);
+          for (int ni = 0; ni < NI; ++ni) mma_frag_s<T>(acc[mi][ni], fa[mi], fb[ni]);
       }
       if (e.abufs == 1 && has1 && t1 == 0) {
         __syncthreads();          // every wave is done with this chunk's footprint
@@ -259,11 +266,11 @@ __global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra 
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int el = 0; el < 16; ++el) {
               const int row = (wm & 1) * 64 + mi * 32 + (el & 3) + 8 * (el >> 2) + 4 * h;
-              const int col = wn * 64 + ni * 32 + r;
+              const int col = wn * WN + ni * 32 + r;
               sC[row * CP + col] = acc[mi][ni][el];
             }
       }
@@ -352,13 +359,13 @@ __global__ __launch_bounds__(BM * 2) void conv_s1_kernel(IgemmParams p, S1Extra 
 
 template <typename K>
 bool raise_lds(K kernel, size_t bytes) {
-  static thread_local const void* done[8];
-  static thread_local size_t done_sz[8];
+  static thread_local const void* done[32];
+  static thread_local size_t done_sz[32];
   const void* fp = reinterpret_cast<const void*>(kernel);
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 32; ++i)
     if (done[i] == fp && done_sz[i] >= bytes) return true;
   if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)) != hipSuccess) return false;
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 32; ++i)
     if (!done[i] || done[i] == fp) { done[i] = fp; done_sz[i] = 160 * 1024; break; }
   return true;
 }
@@ -368,26 +375,37 @@ bool raise_lds(K kernel, size_t bytes) {
 bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   static const bool disabled = getenv("NPP_DISABLE_S1") != nullptr;
   if (disabled) return false;
-  const int kc = dtype == NPP_BF16 ? 64 : 32;
+  const int es = dtype == NPP_BF16 ? 2 : 4;
   if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.uph != 1 || p.upw != 1) return false;
   if (p.KH != p.KW || (p.KH & 1) == 0 || p.KH > 5) return false;
   const int P = (p.KH - 1) / 2;
   if (p.ph != P || p.pw != P) return false;
   if (p.OH != p.H || p.OW != p.W) return false;
-  if (p.Cin % kc != 0 || p.Cp != p.Cin) return false;
-  if (((p.Cout + 31) / 32 * 32) % BN != 0) return false;
+  if (p.Cp != p.Cin) return false;
+  int kcb;
+  if (p.Cin % (128 / es) == 0) kcb = 128; else if (p.Cin % (64 / es) == 0) kcb = 64; else return false;
+  const int kc = kcb / es;
+  const int npad = (p.Cout + 31) / 32 * 32;
+  const int bn = (npad % 128 == 0) ? 128 : (npad % 64 == 0 ? 64 : 32);
+  // Narrow outputs (Cout 32 / 64: the encoder cells) are latency-bound, not MFMA-bound: many small blocks of the
+  // generic kernel (3 per CU) beat one big block per CU here (measured 21 vs 28 us on 32->32 3x3 @96^2), so the fast
+  // path is taken for 128-wide output tiles only unless NPP_S1_NARROW=1.
+  static const bool narrow = getenv("NPP_S1_NARROW") != nullptr;
+  if (bn != 128 && !narrow) return false;
+  const int pitch = kcb + 16;
   const int Wp = p.W + P, Hp = p.H + P;
   const int halo = P * Wp + P;
   const long NHW = (long)p.N * p.H * p.W;
   const long Mp = (long)p.N * Hp * Wp;
-  // tile height: 256 rows (8 waves) when the problem has enough tiles and the footprint fits, else 128
-  int bm = 256;
   const int abufs = (p.KH * p.KW == 1) ? 2 : 1;
-  auto lds_for = [&](int bm_) { return (size_t)abufs * (bm_ + 2 * halo) * PITCH + 2 * BTILE; };
-  auto epi_for = [&](int bm_) { return (size_t)128 * (BN + 4) * 4; };
+  auto lds_for = [&](int bm_) { return (size_t)abufs * (bm_ + 2 * halo) * pitch + (size_t)2 * bn * pitch; };
   const size_t cap = 160 * 1024;
   static const int force_bm = getenv("NPP_S1_BM") ? atoi(getenv("NPP_S1_BM")) : 0;
-  if (Mp < 256L * 200 || lds_for(256) > cap || force_bm == 128) bm = 128;
+  // tile height: the 8-wave shape (256 rows x 128 ch, or 512 rows x 64/32 ch) when the problem has enough tiles and
+  // the footprint fits, else the 4-wave shape
+  const int bm_big = bn == 128 ? 256 : 512, bm_small = bm_big / 2;
+  int bm = bm_big;
+  if (Mp < (long)bm_big * 200 || lds_for(bm_big) > cap || force_bm == 128) bm = bm_small;
   if (lds_for(bm) > cap) return false;
   S1Extra e;
   static const int dbg = getenv("NPP_S1_DBG") ? atoi(getenv("NPP_S1_DBG")) : 0;
@@ -395,15 +413,17 @@ bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   e.abufs = abufs;
   e.Wp = Wp; e.Hp = Hp; e.Mp = Mp;
   e.P = P; e.halo = halo; e.AR = bm + 2 * halo; e.nchunks = p.Cin / kc; e.taps = p.KH * p.KW; e.NHW = NHW;
-  const int nt = bm * 2;
-  e.apt = (e.AR * 8 + nt - 1) / nt;
-  if (e.apt > (bm == 128 ? 12 : 8)) return false;
+  const int nt = (bm / 64) * (bn >= 128 ? 2 : 1) * 64;
+  const int ppr = kcb / 16;
+  e.apt = (e.AR * ppr + nt - 1) / nt;
+  if (e.apt > ((bm == 256 && bn == 128) ? 8 : 12)) return false;
   size_t lds = lds_for(bm);
-  if (lds < epi_for(bm)) lds = epi_for(bm);
-  if (lds < (size_t)nt * 8 * 2 * 4) lds = (size_t)nt * 8 * 2 * 4;
+  const size_t epi = (size_t)128 * (bn + 4) * 4, red = (size_t)nt * 8 * 2 * 4;
+  if (lds < epi) lds = epi;
+  if (lds < red) lds = red;
   IgemmParams q = p;
   q.mtiles = (int)((Mp + bm - 1) / bm);
-  q.ntiles = ((p.Cout + 31) / 32 * 32) / BN;
+  q.ntiles = npad / bn;
   int ncu = 256;
   {
     static int cached = 0;
@@ -416,13 +436,26 @@ bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   }
   const int tiles = q.mtiles * q.ntiles;
   const int grid = tiles < ncu ? tiles : ncu;   // persistent: one block per CU walks tiles b, b+grid, ...
-#define LAUNCH(T, BM_)                                                                       \
-  do {                                                                                       \
-    if (!raise_lds(conv_s1_kernel<T, BM_>, lds)) return false;                               \
-    hipLaunchKernelGGL((conv_s1_kernel<T, BM_>), dim3(grid), dim3(BM_ * 2), lds, stream, q, e); \
+#define LAUNCH(T, BM_, BN_, KCB_)                                                                   \
+  do {                                                                                              \
+    if (!raise_lds(conv_s1_kernel<T, BM_, BN_, KCB_>, lds)) return false;                           \
+    hipLaunchKernelGGL((conv_s1_kernel<T, BM_, BN_, KCB_>), dim3(grid), dim3(nt), lds, stream, q, e); \
   } while (0)
-  if (dtype == NPP_BF16) { if (bm == 256) LAUNCH(bf16_t, 256); else LAUNCH(bf16_t, 128); }
-  else { if (bm == 256) LAUNCH(float, 256); else LAUNCH(float, 128); }
+#define PICK(T)                                                                                     \
+  do {                                                                                              \
+    if (bn == 128) {                                                                                \
+      if (kcb == 128) { if (bm == 256) LAUNCH(T, 256, 128, 128); else LAUNCH(T, 128, 128, 128); }    \
+      else            { if (bm == 256) LAUNCH(T, 256, 128, 64);  else LAUNCH(T, 128, 128, 64); }     \
+    } else if (bn == 64) {                                                                          \
+      if (kcb == 128) { if (bm == 512) LAUNCH(T, 512, 64, 128); else LAUNCH(T, 256, 64, 128); }      \
+      else            { if (bm == 512) LAUNCH(T, 512, 64, 64);  else LAUNCH(T, 256, 64, 64); }       \
+    } else {                                                                                        \
+      if (kcb == 128) { if (bm == 512) LAUNCH(T, 512, 32, 128); else LAUNCH(T, 256, 32, 128); }      \
+      else            { if (bm == 512) LAUNCH(T, 512, 32, 64);  else LAUNCH(T, 256, 32, 64); }       \
+    }                                                                                               \
+  } while (0)
+  if (dtype == NPP_BF16) PICK(bf16_t); else PICK(float);
+#undef PICK
 #undef LAUNCH
   return true;
 }
