@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--local-bn", action="store_true", help="ablation: do not synchronise BN statistics across ranks")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="exercise the multi-GPU path (process group, SyncBN exchange, bucketed all-reduce) on ONE rank")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("NPP_BENCH_GRAPH", "-1")),
                     help="1: capture the whole step (fwd+loss+bwd+Adam) in one hipGraph and replay it; 0: eager; "
                          "-1 (default): graph on 1 GPU, eager on N > 1")
@@ -112,8 +114,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from npp_amd import _lib
@@ -126,15 +130,18 @@ def main():
     set_compute_dtype(dtype)
     torch.manual_seed(0)
     net = Network(cfg_ns())
-    sync_bn = world > 1 and not args.local_bn
+    sync_bn = use_dist and not args.local_bn
+    if args.force_dist:
+        from npp_amd import _ops as _K
+        _K._SYNC_EVEN_ALONE = True
     if sync_bn:
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)   # augment_lip_sync.py:191
     net = net.to(dev).train()
     crit_pose = Criterion_pose(out_len=2).to(dev)
     crit_par = Criterion_par(out_len=2).to(dev)
-    reducer = GradReducer(net, skip=unused_parameter_names(net)) if world > 1 else None
+    reducer = GradReducer(net, skip=unused_parameter_names(net), always_reduce=args.force_dist) if use_dist else None
     params = list(net.parameters()) + list(crit_pose.parameters()) + list(crit_par.parameters())
-    use_graph = args.graph == 1 or (args.graph == -1 and world == 1)
+    use_graph = args.graph != 0      # default: graph for every N (RCCL collectives are captured too; falls back to eager)
     opt = torch.optim.Adam(params, lr=1e-4, capturable=use_graph)
 
     images, lpar, lpose, _ = synth_batch(args.batch, args.size, seed=0, rank=rank)
@@ -153,32 +160,40 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     graph = None
+    eager_step = step
     if use_graph:
-        # hipGraph capture of the static step: ~8000 launches become one replay
+        # hipGraph capture of the static step: ~7000 launches (and, for N > 1, the SyncBN and gradient
+        # collectives) become one replay.  Any capture failure falls back to eager on every rank.
         from npp_amd import _ops as K
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        K.reset_pools()
-        opt.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = step()
-        K.reset_pools()
-        eager_step = step
-
-        def step():      # noqa: F811
-            graph.replay()
-            return static_loss
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            K.reset_pools()
+            opt.zero_grad(set_to_none=True)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_loss = step()
+            K.reset_pools()
+            graph = g
+        except Exception as exc:      # noqa: BLE001
+            sys.stderr.write(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager\n")
+            graph = None
+            K.reset_pools()
+            torch.cuda.synchronize()
+        if graph is not None:
+            def step():      # noqa: F811
+                graph.replay()
+                return static_loss
 
     for _ in range(args.warmup):
         step()
@@ -215,7 +230,7 @@ def main():
                     "traffic": None, "launches_per_step": nl.value // max(prof_steps, 1),
                     "avg_launch_us": round(ms.value * 1e3 / nl.value, 2),
                     "algorithmic_gflop_per_launch": round(fl.value / nl.value / 1e9, 4)}
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -236,10 +251,18 @@ def main():
         out["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints a version banner through C stdio (flushed at exit, i.e. AFTER python's own prints): flush it now so
+    # the JSON record is the last line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001
+        pass
     if rank == 0:
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
 
 

@@ -99,8 +99,10 @@ int npp_dwconv_fwd(const NppTensor* x, const float* w /*[C][kh*kw]*/, NppTensor*
                    const NppConvGeom* g, void* stream);
 int npp_dwconv_bwd_data(const NppTensor* dy, const float* w, const NppTensor* x_mask /*opt: relu mask*/,
                         NppTensor* dx, const NppConvGeom* g, void* stream);
-int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, float* dw /*[C][kh*kw], added*/,
-                          const NppConvGeom* g, void* stream);
+/* dw [C][kh*kw] is WRITTEN; ws = scratch of npp_dwconv_bwd_weight_ws(dy, g) floats (per-block partial slabs) */
+int64_t npp_dwconv_bwd_weight_ws(const NppTensor* dy, const NppConvGeom* g);
+int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, float* dw, float* ws, const NppConvGeom* g,
+                          void* stream);
 
 /* ---- batch norm (train + eval): nn.BatchNorm2d everywhere, SURVEY §8 a20 ---------------------- */
 int npp_channel_stats(const NppTensor* x, double* stats /*[R][2C] added*/, void* stream);
@@ -191,6 +193,11 @@ int npp_ce_reduce(const float* p_gt, const float* wnll, const int64_t* labels, c
 int npp_ce_pixel_bwd(const NppTensor* logits, const int64_t* labels, int H, int W, const float* class_w,
                      int ignore, const float* p_gt, const float* kth, float thresh, int use_ohem,
                      const float* gscale, NppTensor* dlogits, void* stream);
+/* same gradient, left at the label resolution: dup = f32 [N*H*W][C] (written; zero rows for dropped pixels).  Follow
+ * with npp_bilinear_bwd(dup as [N,H,W,C] -> dlogits) for the transpose of the upsampling: no atomics at all. */
+int npp_ce_pixel_grad_up(const NppTensor* logits, const int64_t* labels, int H, int W, const float* class_w,
+                         int ignore, const float* p_gt, const float* kth, float thresh, int use_ohem,
+                         const float* gscale, float* dup, void* stream);
 /* edge class weights from label counts, core/criterion.py:161-166: w = [pos/(pos+neg), neg/(pos+neg)] */
 int npp_edge_weights(const int64_t* labels, int64_t n, double* counts /*[2] zeroed by caller*/, void* stream);
 

@@ -50,7 +50,7 @@ _SIGS = {
     "npp_unpack_wgrad": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
     "npp_dwconv_fwd": [_T, _P, _T, _G, _P],
     "npp_dwconv_bwd_data": [_T, _P, _T, _T, _G, _P],
-    "npp_dwconv_bwd_weight": [_T, _T, _P, _G, _P],
+    "npp_dwconv_bwd_weight": [_T, _T, _P, _P, _G, _P],
     "npp_channel_stats": [_T, _P, _P],
     "npp_channel_sum": [_T, _P, _P],
     "npp_bn_finalize": [_P, C.c_int, C.c_double, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int, _P],
@@ -82,9 +82,11 @@ _SIGS = {
     "npp_kth_smallest": [_P, C.c_int64, C.c_int64, _P, _P, _P],
     "npp_ce_reduce": [_P, _P, _P, _P, C.c_int, C.c_int64, _P, C.c_float, C.c_int, _P, _P],
     "npp_ce_pixel_bwd": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _T, _P],
+    "npp_ce_pixel_grad_up": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P],
     "npp_edge_weights": [_P, C.c_int64, _P, _P],
 }
-EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_packed_weight_elems", "npp_reduce_blocks"])
+EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_packed_weight_elems", "npp_reduce_blocks",
+                                 "npp_dwconv_bwd_weight_ws"])
 
 
 def lib():
@@ -100,6 +102,8 @@ def lib():
         L.npp_last_error.restype = C.c_char_p
         L.npp_packed_weight_elems.restype = C.c_int64
         L.npp_packed_weight_elems.argtypes = [C.c_int] * 5
+        L.npp_dwconv_bwd_weight_ws.restype = C.c_int64
+        L.npp_dwconv_bwd_weight_ws.argtypes = [_T, _G]
         L.npp_reduce_blocks.restype = C.c_int
         L.npp_reduce_blocks.argtypes = [C.c_int64, C.c_int64, C.c_int]
         for name, sig in _SIGS.items():

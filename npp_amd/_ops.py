@@ -305,8 +305,11 @@ class _DwConv2d(Function):
             check(lib().npp_dwconv_bwd_data(_byref(dy), wf.data_ptr(), _byref(x) if relu_in else None, _byref(dx),
                                             C.byref(g), s), "npp_dwconv_bwd_data")
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
-            check(lib().npp_dwconv_bwd_weight(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_dwconv_bwd_weight")
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            nws = lib().npp_dwconv_bwd_weight_ws(_byref(dy), C.byref(g))
+            ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+            check(lib().npp_dwconv_bwd_weight(_byref(x), _byref(dy), dw.data_ptr(), ws.data_ptr(), C.byref(g), s),
+                  "npp_dwconv_bwd_weight")
             if dw.dtype != weight.dtype:
                 dw = dw.to(weight.dtype)
         return dx, dw, None, None, None, None
@@ -323,13 +326,17 @@ class BnSide:
     """One operand of the fused add.  kind 'bn': `x` is a raw (pre-BN) tensor with f64 stats (train) or a
     BatchNorm holder in eval mode; kind 'plain': `x` is used as is."""
 
-    __slots__ = ("x", "bn", "stats", "count")
+    __slots__ = ("x", "bn", "stats", "count", "synced_ws")
 
     def __init__(self, x, bn=None, stats=None):
         self.x = x
         self.bn = bn
         self.stats = stats
         self.count = None
+        self.synced_ws = 0
+
+
+_SYNC_EVEN_ALONE = False   # test hook: run the SyncBN collectives on a 1-rank group (bench.py --force-dist)
 
 
 def _sync_group(bn):
@@ -337,9 +344,40 @@ def _sync_group(bn):
     if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
         grp = bn.process_group
         ws = dist.get_world_size(grp) if grp is not None else dist.get_world_size()
-        if ws > 1:
+        if ws > 1 or _SYNC_EVEN_ALONE:
             return grp if grp is not None else dist.group.WORLD, ws
     return None, 1
+
+
+def _presync_stats(sides, training: bool):
+    """SyncBN forward exchange for the (up to two) BN sides of one fused add with ONE all-reduce of the
+    concatenated [sum | sumsq] vectors (864 -> ~600 small collectives per step on this network)."""
+    todo = []
+    for sd in sides:
+        if sd is None or sd.bn is None or not (training or sd.bn.running_mean is None):
+            continue
+        grp, ws = _sync_group(sd.bn)
+        if grp is None:
+            continue
+        if sd.stats is None:
+            sd.stats = channel_stats(sd.x)
+        c = sd.x.shape[1]
+        nrep = sd.stats.numel() // (2 * c)
+        todo.append((sd, sd.stats.view(nrep, 2 * c).sum(0), grp, ws))
+    if not todo:
+        return
+    grp = todo[0][2]
+    if len(todo) == 2 and todo[1][2] is grp:
+        buf = torch.cat([todo[0][1], todo[1][1]])
+        dist.all_reduce(buf, group=grp)
+        n0 = todo[0][1].numel()
+        todo[0][0].stats, todo[1][0].stats = buf[:n0], buf[n0:]
+    else:
+        for sd, v, g, _ in todo:
+            dist.all_reduce(v, group=g)
+            sd.stats = v
+    for sd, _, _, ws in todo:
+        sd.synced_ws = ws
 
 
 def _bn_coeffs(side: BnSide, training: bool, device):
@@ -357,12 +395,15 @@ def _bn_coeffs(side: BnSide, training: bool, device):
             stats = channel_stats(side.x)
         nrep = stats.numel() // (2 * c)
         count = float(side.x.shape[0] * side.x.shape[2] * side.x.shape[3])
-        grp, ws = _sync_group(bn)
-        if grp is not None:
-            stats = stats.view(nrep, 2 * c).sum(0)
-            nrep = 1
-            dist.all_reduce(stats, group=grp)
-            count *= ws
+        if side.synced_ws:            # already all-reduced by _presync_stats
+            count *= side.synced_ws
+        else:
+            grp, ws = _sync_group(bn)
+            if grp is not None:
+                stats = stats.view(nrep, 2 * c).sum(0)
+                nrep = 1
+                dist.all_reduce(stats, group=grp)
+                count *= ws
         side.count = count
         mi = torch.empty(2 * c, dtype=torch.float32, device=device)
         track = bn.track_running_stats and bn.running_mean is not None and training
@@ -389,6 +430,7 @@ class _BnAdd(Function):
         dev = a.device
         ssa = mia = ssb = mib = None
         batch_a = batch_b = False
+        _presync_stats((sa, sb), training)
         if sa.bn is not None:
             ssa, mia, batch_a = _bn_coeffs(sa, training, dev)
         if sb is not None and sb.bn is not None:
@@ -411,34 +453,68 @@ class _BnAdd(Function):
             dout = cast(dout, a.dtype)
         s = stream_ptr()
 
-        def side(x, bn, mi, ss, batch, count, need_x, need_g, need_b):
-            dx = dg = db = None
-            if bn is None:
-                if need_x:
-                    if yrelu is None:
-                        dx = dout
-                    else:
-                        dx = new_nhwc(*x.shape, x.dtype, x.device)
-                        check(lib().npp_scale_mask(_byref(dout), None, _byref(yrelu), _byref(dx), s), "npp_scale_mask")
-                return dx, None, None
+        def plain_side(x, need_x):
+            if not need_x:
+                return None
+            if yrelu is None:
+                return dout
+            dx = new_nhwc(*x.shape, x.dtype, x.device)
+            check(lib().npp_scale_mask(_byref(dout), None, _byref(yrelu), _byref(dx), s), "npp_scale_mask")
+            return dx
+
+        def reduce_side(x, mi):
             c = x.shape[1]
             nb = lib().npp_reduce_blocks(x.shape[0] * x.shape[2] * x.shape[3], c, L.npp_dtype(x.dtype))
             sums = torch.empty(nb * 2 * c, dtype=torch.float64, device=x.device)   # one slab per block, written
             check(lib().npp_bn_bwd_reduce(_byref(dout), _byref(x), tref(yrelu), mi.data_ptr(), sums.data_ptr(), nb, s),
                   "npp_bn_bwd_reduce")
+            return sums, nb
+
+        ni = ctx.needs_input_grad
+        sides = [(a, bna, mia, ssa, batch_a, cnt_a, ni[0], ni[1], ni[2])]
+        if has_b:
+            sides.append((b, bnb, mib, ssb, batch_b, cnt_b, ni[3], ni[4], ni[5]))
+        # phase 1: local reductions of every BN side
+        red = [reduce_side(x, mi) if bn is not None else None for (x, bn, mi, *_r) in sides]
+        # phase 2 (SyncBatchNorm): ONE all-reduce for the side(s) of this node.  Weight/bias grads stay the LOCAL sums
+        # (DDP averages them afterwards, as torch.nn.SyncBatchNorm does); the input gradient uses the global sums.
+        local = [None] * len(sides)
+        sync = []
+        for i, (x, bn, mi, ss, batch, count, *_r) in enumerate(sides):
+            if bn is None or not batch:
+                continue
+            grp, ws = _sync_group(bn)
+            if grp is not None:
+                c = x.shape[1]
+                local[i] = red[i][0].view(red[i][1], 2 * c).sum(0)
+                sync.append((i, grp))
+        if sync:
+            grp = sync[0][1]
+            if len(sync) == 2 and sync[1][1] is grp:
+                buf = torch.cat([local[sync[0][0]], local[sync[1][0]]])
+                dist.all_reduce(buf, group=grp)
+                n0 = local[sync[0][0]].numel()
+                red[sync[0][0]] = (buf[:n0], 1)
+                red[sync[1][0]] = (buf[n0:], 1)
+            else:
+                for i, g in sync:
+                    glob = local[i].clone()
+                    dist.all_reduce(glob, group=g)
+                    red[i] = (glob, 1)
+        # phase 3: coefficients + apply
+        outs = []
+        for i, (x, bn, mi, ss, batch, count, need_x, need_g, need_b) in enumerate(sides):
+            if bn is None:
+                outs.append((plain_side(x, need_x), None, None))
+                continue
+            c = x.shape[1]
+            sums, nrep = red[i]
             gamma = bn.weight.detach() if bn.weight is not None else None
+            dx = dg = db = None
             if batch:
-                grp, ws = _sync_group(bn)
-                nrep = nb
                 dgt = dbt = None
-                if grp is not None:
-                    # SyncBatchNorm: weight/bias grads are the LOCAL sums (DDP averages them afterwards);
-                    # the input gradient uses the all-reduced sums over the global count.
-                    local = sums.view(nb, 2 * c).sum(0)
-                    dg, db = local[c:].float(), local[:c].float()
-                    sums = local.clone()
-                    nrep = 1
-                    dist.all_reduce(sums, group=grp)
+                if local[i] is not None:
+                    dg, db = local[i][c:].float(), local[i][:c].float()
                 else:
                     dgt = torch.empty(c, dtype=torch.float32, device=x.device)
                     dbt = torch.empty(c, dtype=torch.float32, device=x.device)
@@ -454,15 +530,13 @@ class _BnAdd(Function):
                 if need_x:
                     dx = new_nhwc(*x.shape, x.dtype, x.device)
                     check(lib().npp_scale_mask(_byref(dout), ss.data_ptr(), tref(yrelu), _byref(dx), s), "npp_scale_mask")
-                tot = sums.view(nb, 2 * c).sum(0)
+                tot = sums.view(nrep, 2 * c).sum(0)
                 dg, db = tot[c:].float(), tot[:c].float()
-            return (dx if need_x else None), (dg if need_g else None), (db if need_b else None)
-
-        ni = ctx.needs_input_grad
-        da, dga, dba = side(a, bna, mia, ssa, batch_a, cnt_a, ni[0], ni[1], ni[2])
+            outs.append((dx, dg if need_g else None, db if need_b else None))
+        da, dga, dba = outs[0]
         dbx = dgb = dbb = None
         if has_b:
-            dbx, dgb, dbb = side(b, bnb, mib, ssb, batch_b, cnt_b, ni[3], ni[4], ni[5])
+            dbx, dgb, dbb = outs[1]
         return da, dga, dba, dbx, dgb, dbb, None, None, None, None
 
 
@@ -815,9 +889,14 @@ class _UpsampledCE(Function):
         ignore, thresh, use_ohem, H, W = ctx.cfg
         gs = (g.detach().double() / denom).float().reshape(1).contiguous()
         n, c, h, w = logits.shape
-        dl = new_nhwc(n, c, h, w, torch.float32, logits.device, zero=True)
-        check(lib().npp_ce_pixel_bwd(_byref(logits), lab.data_ptr(), H, W, cw.data_ptr(), ignore, p_gt.data_ptr(), ptr(kth),
-                                     float(thresh), int(use_ohem), gs.data_ptr(), _byref(dl), stream_ptr()), "npp_ce_pixel_bwd")
+        s = stream_ptr()
+        # gradient at the label resolution (f32 rows of c), then the atomic-free bilinear transpose down to h x w
+        dup = torch.empty((n, H, W, c), dtype=torch.float32, device=logits.device).permute(0, 3, 1, 2)
+        check(lib().npp_ce_pixel_grad_up(_byref(logits), lab.data_ptr(), H, W, cw.data_ptr(), ignore, p_gt.data_ptr(),
+                                         ptr(kth), float(thresh), int(use_ohem), gs.data_ptr(), dup.data_ptr(), s),
+              "npp_ce_pixel_grad_up")
+        dl = new_nhwc(n, c, h, w, torch.float32, logits.device)
+        check(lib().npp_bilinear_bwd(_byref(dup), _byref(dl), s), "npp_bilinear_bwd")
         if logits.dtype != torch.float32:
             dl = cast(dl, logits.dtype)
         return dl, None, None, None, None

@@ -162,10 +162,17 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < p.C * taps; i += 256) {
-    const float v = sdw[i];
-    if (v != 0.f) atomicAdd(dwg + i, v);
-  }
+  // one private slab per block (same-address global atomics from 512 blocks serialise for ~50 us)
+  float* slab = dwg + (long)blockIdx.x * p.C * taps;
+  for (int i = threadIdx.x; i < p.C * taps; i += 256) slab[i] = sdw[i];
+}
+
+__global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslabs, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < nslabs; ++b) s += slabs[(long)b * n + i];
+  out[i] = s;
 }
 
 int fill_params(DwParams& p, const NppTensor* x, const NppTensor* y, const NppConvGeom* g, const char* who) {
@@ -240,26 +247,45 @@ extern "C" int npp_dwconv_bwd_data(const NppTensor* dy, const float* w, const Np
   return npp_check_launch("dwconv_bwd_data");
 }
 
-extern "C" int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, float* dw, const NppConvGeom* g, void* stream) {
-  NPP_REQUIRE(x && dy && dw && g && x->ptr && dy->ptr, NPP_E_NULL, "npp_dwconv_bwd_weight: null pointer");
+static inline int dw_bwd_blocks(long npixo, int cv) {
+  const int cols_blk = cv < 256 ? cv : 256;
+  const int rows = 256 / cols_blk;
+  long bx = (npixo + (long)rows * 16 - 1) / ((long)rows * 16);
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  return (int)bx;
+}
+
+extern "C" int64_t npp_dwconv_bwd_weight_ws(const NppTensor* dy, const NppConvGeom* g) {
+  if (!dy || !g) return 0;
+  const int v = dy->dtype == NPP_BF16 ? 8 : 4;
+  const int cv = (int)(dy->c % v == 0 ? dy->c / v : dy->c);
+  return (int64_t)dw_bwd_blocks(npix(dy), cv) * dy->c * g->kh * g->kw;
+}
+
+extern "C" int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, float* dw, float* ws, const NppConvGeom* g,
+                                     void* stream) {
+  NPP_REQUIRE(x && dy && dw && ws && g && x->ptr && dy->ptr, NPP_E_NULL, "npp_dwconv_bwd_weight: null pointer");
   DwParams p;
   int rc = fill_params(p, x, dy, g, "npp_dwconv_bwd_weight");
   if (rc) return rc;
   const bool vk = vec_ok(x) && vec_ok(dy);
-  const size_t lds = (size_t)p.C * g->kh * g->kw * sizeof(float);
+  const int taps = g->kh * g->kw;
+  const size_t lds = (size_t)p.C * taps * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  ProfScope prof(NPP_FAM_DWCONV, x->dtype, s, 2.0 * npix(dy) * p.C * g->kh * g->kw, (double)(npix(x) + npix(dy)) * p.C * esize(x->dtype));
+  ProfScope prof(NPP_FAM_DWCONV, x->dtype, s, 2.0 * npix(dy) * p.C * taps, (double)(npix(x) + npix(dy)) * p.C * esize(x->dtype));
+  int nblk = 1;
   NPP_DISPATCH_TV(x->dtype, vk, {
     p.cv = p.C / V;
     const int cols_blk = p.cv < 256 ? p.cv : 256;
     const int rows = 256 / cols_blk;
-    long bx = (npix(dy) + (long)rows * 16 - 1) / ((long)rows * 16);
-    if (bx > 512) bx = 512;
-    if (bx < 1) bx = 1;
+    nblk = dw_bwd_blocks(npix(dy), p.cv);
     rc = allow_lds(dwconv_bwd_weight_kernel<T, V, 9>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, V, 9>), dim3((unsigned)bx), dim3(256), lds, s, (const T*)x->ptr,
-                       (const T*)dy->ptr, dw, p, cols_blk, rows);
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, V, 9>), dim3((unsigned)nblk), dim3(256), lds, s, (const T*)x->ptr,
+                       (const T*)dy->ptr, ws, p, cols_blk, rows);
   });
+  const int n = p.C * taps;
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ws, nblk, n, dw);
   return npp_check_launch("dwconv_bwd_weight");
 }

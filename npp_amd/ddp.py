@@ -53,15 +53,16 @@ class _Bucket:
 
 class GradReducer:
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_mb: float = 32.0,
-                 skip: Optional[Iterable[str]] = None, broadcast_parameters: bool = True):
+                 skip: Optional[Iterable[str]] = None, broadcast_parameters: bool = True, always_reduce: bool = False):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        self.always = always_reduce      # run the collectives even on a 1-rank group (single-GPU exercise of the path)
         skip = set(skip or ())
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and n not in skip]
         self.skipped = sorted(skip)
-        if broadcast_parameters and self.world > 1:
+        if broadcast_parameters and (self.world > 1 or always_reduce):
             # DDP construction broadcasts rank 0's parameters and buffers
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -109,7 +110,7 @@ class GradReducer:
         with ctx, torch.no_grad():
             views = [b.flat[o:o + p.numel()].view_as(p) for o, p in zip(b.offsets, b.params)]
             torch._foreach_copy_(views, [p.grad for p in b.params])
-            if self.world > 1:
+            if self.world > 1 or self.always:
                 b.work = dist.all_reduce(b.flat, group=self.group, async_op=True)
         self._launched += 1
 
@@ -128,7 +129,7 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self._side)
         with torch.no_grad():
             for b in self.buckets:
-                if self.world > 1:
+                if self.world > 1 or self.always:
                     b.flat.mul_(scale)
                     views = [b.flat[o:o + p.numel()].view_as(p) for o, p in zip(b.offsets, b.params)]
                     torch._foreach_copy_([p.grad for p in b.params], views)
