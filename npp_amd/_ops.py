@@ -307,7 +307,7 @@ class _DwConv2d(Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
             nws = lib().npp_dwconv_bwd_weight_ws(_byref(dy), C.byref(g))
-            ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+            ws = zeros_f32(nws, x.device)
             check(lib().npp_dwconv_bwd_weight(_byref(x), _byref(dy), dw.data_ptr(), ws.data_ptr(), C.byref(g), s),
                   "npp_dwconv_bwd_weight")
             if dw.dtype != weight.dtype:

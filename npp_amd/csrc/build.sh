@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libnpp_hip.so
-SRCS="api.hip conv_igemm.hip conv_s1.hip conv_wgrad.hip dwconv.hip bn.hip pool.hip bilinear.hip misc.hip loss.hip"
+SRCS="api.hip conv_igemm.hip conv_s1.hip conv_wgrad.hip conv_wgrad_s1.hip dwconv.hip bn.hip pool.hip bilinear.hip misc.hip loss.hip"
 OBJS=""
 mkdir -p build
 pids=()
@@ -11,7 +11,7 @@ for s in $SRCS; do
   [ -f "$s" ] || continue
   o=build/${s%.hip}.o
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_params.h -nt "$o" ] || [ vecio.h -nt "$o" ] || [ ../../include/npp_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_params.h -nt "$o" ] || [ conv_wgrad_params.h -nt "$o" ] || [ vecio.h -nt "$o" ] || [ ../../include/npp_hip.h -nt "$o" ]; then
     hipcc --offload-arch=gfx950 -O3 -fPIC -munsafe-fp-atomics -std=c++17 -Wno-unused-result -c "$s" -o "$o" &
     pids+=($!)
   fi

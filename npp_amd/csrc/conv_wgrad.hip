@@ -19,21 +19,10 @@
 //
 // Replaces the weight-gradient half of nn.Conv2d backward for every call site listed in conv_igemm.hip.
 #include "common.h"
+#include "conv_wgrad_params.h"
 #include <stdlib.h>
 
 namespace {
-
-struct WgradParams {
-  const void* x; const void* dy; float* dwp;
-  int N, H, W, Cin; long ldx;
-  int OH, OW, Cout; long ldy;
-  int Cp, Kpad, taps;
-  int KH, KW, sh, sw, ph, pw, dh, dw, relu_in;
-  int P;             // N*OH*OW
-  int chunks_per_split, nchunks;
-  int rowtiles;
-  int vec_dy;
-};
 
 template <typename T> NPP_DEV u32x4 relu16w(u32x4 v);
 template <> NPP_DEV u32x4 relu16w<float>(u32x4 v) {
@@ -270,6 +259,7 @@ extern "C" int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw
   const double flops = 2.0 * (double)P * p.Cout * (double)p.taps * p.Cin;
   const double bytes = ((double)x->n * x->h * x->w * x->c + (double)P * dy->c) * esize(x->dtype);
   ProfScope prof(NPP_FAM_CONV_WGRAD, x->dtype, s, flops, bytes);
+  if (conv_wgrad_tap_launch(p, x->dtype, s)) return npp_check_launch("conv_wgrad_tap");
   dim3 grid(tiles, splits);
 #define LAUNCH(T, TM_) hipLaunchKernelGGL((conv_wgrad_kernel<T, TM_>), grid, dim3(256), 0, s, p)
   if (x->dtype == NPP_BF16) {

@@ -1,0 +1,15 @@
+// Parameter block shared by the weight-gradient kernels.
+#pragma once
+struct WgradParams {
+  const void* x; const void* dy; float* dwp;
+  int N, H, W, Cin; long ldx;
+  int OH, OW, Cout; long ldy;
+  int Cp, Kpad, taps;
+  int KH, KW, sh, sw, ph, pw, dh, dw, relu_in;
+  int P;             // N*OH*OW
+  int chunks_per_split, nchunks;
+  int rowtiles;
+  int vec_dy;
+};
+// tap-stationary 3x3 stride-1 kernel (conv_wgrad_s1.hip); false when the shape is not eligible
+bool conv_wgrad_tap_launch(const WgradParams& p, int dtype, hipStream_t stream);

@@ -130,10 +130,18 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
       for (int k = 0; k < TG; ++k)
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[k][j] = 0.f;
-      for (long pix = (long)blockIdx.x * rows + row; pix < npixo; pix += (long)gridDim.x * rows) {
-        const int ow = (int)(pix % p.OW);
-        const long t2 = pix / p.OW;
-        const int oh = (int)(t2 % p.OH), n = (int)(t2 / p.OH);
+      // walk the output pixels of this thread without any division: (n, oh, ow) advance by the block stride
+      const unsigned stride = gridDim.x * rows;
+      unsigned pix0 = blockIdx.x * rows + row;
+      int ow = (int)(pix0 % (unsigned)p.OW);
+      unsigned t2 = pix0 / (unsigned)p.OW;
+      int oh = (int)(t2 % (unsigned)p.OH), n = (int)(t2 / (unsigned)p.OH);
+      const int s_ow = (int)(stride % (unsigned)p.OW);
+      const unsigned s_t2 = stride / (unsigned)p.OW;
+      const int s_oh = (int)(s_t2 % (unsigned)p.OH), s_n = (int)(s_t2 / (unsigned)p.OH);
+      for (long pix = pix0; pix < npixo; pix += stride, ow += s_ow, oh += s_oh, n += s_n) {
+        if (ow >= p.OW) { ow -= p.OW; ++oh; }
+        if (oh >= p.OH) { oh -= p.OH; ++n; }
         float d[V];
         ldv<T, V>(dy + pix * p.ldy + c0, d);
 #pragma unroll
@@ -162,9 +170,12 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
     }
   }
   __syncthreads();
-  // one private slab per block (same-address global atomics from 512 blocks serialise for ~50 us)
-  float* slab = dwg + (long)blockIdx.x * p.C * taps;
-  for (int i = threadIdx.x; i < p.C * taps; i += 256) slab[i] = sdw[i];
+  // 16 replica slabs (block b adds into slab b % 16): same-address float atomics from hundreds of blocks serialise
+  float* slab = dwg + (long)(blockIdx.x % NPP_STAT_REPLICAS) * p.C * taps;
+  for (int i = threadIdx.x; i < p.C * taps; i += 256) {
+    const float v = sdw[i];
+    if (v != 0.f) atomicAdd(slab + i, v);
+  }
 }
 
 __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslabs, int n, float* __restrict__ out) {
@@ -250,8 +261,8 @@ extern "C" int npp_dwconv_bwd_data(const NppTensor* dy, const float* w, const Np
 static inline int dw_bwd_blocks(long npixo, int cv) {
   const int cols_blk = cv < 256 ? cv : 256;
   const int rows = 256 / cols_blk;
-  long bx = (npixo + (long)rows * 16 - 1) / ((long)rows * 16);
-  if (bx > 256) bx = 256;
+  long bx = (npixo + (long)rows * 8 - 1) / ((long)rows * 8);
+  if (bx > 1024) bx = 1024;
   if (bx < 1) bx = 1;
   return (int)bx;
 }
@@ -260,7 +271,7 @@ extern "C" int64_t npp_dwconv_bwd_weight_ws(const NppTensor* dy, const NppConvGe
   if (!dy || !g) return 0;
   const int v = dy->dtype == NPP_BF16 ? 8 : 4;
   const int cv = (int)(dy->c % v == 0 ? dy->c / v : dy->c);
-  return (int64_t)dw_bwd_blocks(npix(dy), cv) * dy->c * g->kh * g->kw;
+  return (int64_t)NPP_STAT_REPLICAS * dy->c * g->kh * g->kw;   // zeroed by the caller
 }
 
 extern "C" int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, float* dw, float* ws, const NppConvGeom* g,
@@ -286,6 +297,6 @@ extern "C" int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, fl
                        (const T*)dy->ptr, ws, p, cols_blk, rows);
   });
   const int n = p.C * taps;
-  hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ws, nblk, n, dw);
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ws, NPP_STAT_REPLICAS, n, dw);
   return npp_check_launch("dwconv_bwd_weight");
 }
