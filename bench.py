@@ -142,7 +142,11 @@ def main():
     reducer = GradReducer(net, skip=unused_parameter_names(net), always_reduce=args.force_dist) if use_dist else None
     params = list(net.parameters()) + list(crit_pose.parameters()) + list(crit_par.parameters())
     use_graph = args.graph != 0      # default: graph for every N (RCCL collectives are captured too; falls back to eager)
-    opt = torch.optim.Adam(params, lr=1e-4, capturable=use_graph)
+    # fused multi-tensor Adam: the capturable foreach path issues ~3000 scalar-math launches per step (13 ms)
+    try:
+        opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=use_graph)
+    except (RuntimeError, ValueError):
+        opt = torch.optim.Adam(params, lr=1e-4, capturable=use_graph)
 
     images, lpar, lpose, _ = synth_batch(args.batch, args.size, seed=0, rank=rank)
     images = torch.from_numpy(images).to(dev)
@@ -225,9 +229,15 @@ def main():
         if nl.value > 0 and ms.value > 0:
             ach = fl.value / (ms.value * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.dtype]
+            traffic = None
+            try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
+                with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as fh:
+                    traffic = round(json.load(fh)["traffic_bytes_per_launch"])
+            except Exception:      # noqa: BLE001
+                traffic = None
             roof = {"bound": "mfma", "kernel": "conv_s1_kernel (stride-1 conv fwd + dgrad on MFMA, both tile heights)",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "launches_per_step": nl.value // max(prof_steps, 1),
+                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC)", "launches_per_step": nl.value // max(prof_steps, 1),
                     "avg_launch_us": round(ms.value * 1e3 / nl.value, 2),
                     "algorithmic_gflop_per_launch": round(fl.value / nl.value / 1e9, 4)}
     if use_dist:
