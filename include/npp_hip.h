@@ -169,6 +169,16 @@ int npp_nchw_to_nhwc(const float* src, int n, int c, int h, int w, NppTensor* ds
 int npp_nhwc_to_nchw(const NppTensor* src, float* dst, void* stream);
 int npp_channel_sum(const NppTensor* x, double* out /*[R][C], added*/, void* stream);      /* conv bias grad */
 
+/* ---- search supernet (model_search_interact.py:22-74): F.interpolate(mode='nearest') fwd/bwd, the PC-DARTS mixed
+ *      sum  out = sum_k w[k]*y_k  (k <= 8; backward also reduces dw[k] = sum dout*y_k into [R][8] f64), and
+ *      channel_shuffle(cat([a,b],1), 2) as an interleaving copy (and its inverse for the backward). ------------------ */
+int npp_nearest(const NppTensor* x, NppTensor* y, float scale_h, float scale_w, int backward, void* stream);
+int npp_weighted_sum_fwd(const NppTensor* const* ys, int k, const float* w, NppTensor* out, void* stream);
+int npp_weighted_sum_bwd(const NppTensor* const* ys, NppTensor* const* dys, int k, const float* w,
+                         const NppTensor* dout, double* dw, void* stream);
+int npp_interleave2(const NppTensor* a, const NppTensor* b, NppTensor* out, int inverse, NppTensor* oa, NppTensor* ob,
+                    void* stream);
+
 /* ---- loss heads ----------------------------------------------------------------------------------
  * heat-map MSE, core/criterion.py:98-128: sse += sum (pred - target)^2 ; target is f32 NCHW. */
 int npp_mse_fwd(const NppTensor* pred, const float* target_nchw, double* sse, void* stream);

@@ -5,8 +5,8 @@
     from npp_amd.criterion import Criterion_pose, Criterion_par   # == core.criterion
 
 `install_as_reference_modules()` registers these under the reference's own module names (`models`,
-`models.operations`, `models.genotypes`, `models.model_augment`, `core.criterion`) so that
-`augment_lip_sync.py` imports them unchanged.
+`models.operations`, `models.genotypes`, `models.model_augment`, `models.model_search_interact`,
+`core.criterion`) so that `augment_lip_sync.py` / `search_lip_sync.py` import them unchanged.
 """
 import sys
 import types
@@ -15,7 +15,7 @@ __version__ = "0.1.0"
 
 
 def install_as_reference_modules():
-    from . import criterion, genotypes, model_augment, operations
+    from . import criterion, genotypes, model_augment, model_search_interact, operations
     models = types.ModuleType("models")
     models.__path__ = []
     models.operations, models.genotypes, models.model_augment = operations, genotypes, model_augment
@@ -23,6 +23,8 @@ def install_as_reference_modules():
     sys.modules["models.operations"] = operations
     sys.modules["models.genotypes"] = genotypes
     sys.modules["models.model_augment"] = model_augment
+    models.model_search_interact = model_search_interact
+    sys.modules["models.model_search_interact"] = model_search_interact
     core = sys.modules.get("core")
     if core is None:
         core = types.ModuleType("core")

@@ -76,6 +76,10 @@ _SIGS = {
     "npp_copy": [_T, _T, _P],
     "npp_nchw_to_nhwc": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _T, _P],
     "npp_nhwc_to_nchw": [_T, _P, _P],
+    "npp_nearest": [_T, _T, C.c_float, C.c_float, C.c_int, _P],
+    "npp_weighted_sum_fwd": [_P, C.c_int, _P, _T, _P],
+    "npp_weighted_sum_bwd": [_P, _P, C.c_int, _P, _T, _P, _P],
+    "npp_interleave2": [_T, _T, _T, C.c_int, _T, _T, _P],
     "npp_mse_fwd": [_T, _P, _P, _P],
     "npp_mse_bwd": [_T, _P, _P, _T, _P],
     "npp_ce_pixel_fwd": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P],

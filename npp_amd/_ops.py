@@ -915,3 +915,110 @@ def edge_class_weights(labels: torch.Tensor) -> torch.Tensor:
     check(lib().npp_edge_weights(lab.data_ptr(), lab.numel(), cnt.data_ptr(), stream_ptr()), "npp_edge_weights")
     tot = cnt.sum()
     return torch.stack([cnt[1] / tot, cnt[0] / tot]).float()
+
+
+# --------------------------------------------------------------------------------------------------
+# search supernet plumbing (model_search_interact.py:22-74)
+# --------------------------------------------------------------------------------------------------
+class _Nearest(Function):
+    """F.interpolate(x, scale_factor=s) with the default mode 'nearest' (src = floor(dst / s))."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        import math
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        oh, ow = int(math.floor(h * scale)), int(math.floor(w * scale))
+        y = new_nhwc(n, c, oh, ow, x.dtype, x.device)
+        inv = 1.0 / float(scale)
+        check(lib().npp_nearest(_byref(x), _byref(y), inv, inv, 0, stream_ptr()), "npp_nearest")
+        ctx.cfg = (tuple(x.shape), x.dtype, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xshape, dtype, inv = ctx.cfg
+        dy = to_nhwc(dy)
+        if dy.dtype != dtype:
+            dy = cast(dy, dtype)
+        dx = new_nhwc(*xshape, dtype, dy.device)
+        check(lib().npp_nearest(_byref(dy), _byref(dx), inv, inv, 1, stream_ptr()), "npp_nearest(bwd)")
+        return dx, None
+
+
+def nearest(x, scale):
+    if float(scale) == 1.0:
+        return x
+    return _Nearest.apply(x, float(scale))
+
+
+class _WeightedSum(Function):
+    """out = sum_k w[k] * y_k with w a 1-D tensor (softmaxed architecture weights); grads to every y_k and to w."""
+
+    @staticmethod
+    def forward(ctx, w, *ys):
+        ys = [to_nhwc(y) for y in ys]
+        k = len(ys)
+        wf = w.detach().float().contiguous()
+        out = new_nhwc(*ys[0].shape, ys[0].dtype, ys[0].device)
+        descs = [desc(y) for y in ys]
+        arr = (C.POINTER(L.NppTensor) * k)(*[C.pointer(d) for d in descs])
+        check(lib().npp_weighted_sum_fwd(arr, k, wf.data_ptr(), _byref(out), stream_ptr()), "npp_weighted_sum_fwd")
+        ctx.save_for_backward(wf, *ys)
+        ctx.wdtype = w.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        wf, *ys = ctx.saved_tensors
+        k = len(ys)
+        dout = to_nhwc(dout)
+        if dout.dtype != ys[0].dtype:
+            dout = cast(dout, ys[0].dtype)
+        need = ctx.needs_input_grad
+        dys = [new_nhwc(*y.shape, y.dtype, y.device) if need[1 + i] else None for i, y in enumerate(ys)]
+        ydesc = [desc(y) for y in ys]
+        ddesc = [desc(d) if d is not None else None for d in dys]
+        ya = (C.POINTER(L.NppTensor) * k)(*[C.pointer(d) for d in ydesc])
+        da = (C.POINTER(L.NppTensor) * k)(*[C.pointer(d) if d is not None else None for d in ddesc])
+        dw = zeros_f64(R * 8, dout.device)
+        check(lib().npp_weighted_sum_bwd(ya, da, k, wf.data_ptr(), _byref(dout), dw.data_ptr(), stream_ptr()),
+              "npp_weighted_sum_bwd")
+        gw = dw.view(R, 8).sum(0)[:k].to(ctx.wdtype) if need[0] else None
+        return (gw, *dys)
+
+
+def weighted_sum(w, ys):
+    return _WeightedSum.apply(w, *ys)
+
+
+class _Interleave2(Function):
+    """channel_shuffle(torch.cat([a, b], 1), groups=2)  (model_search_interact.py:22-36,71-72)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = to_nhwc(a), to_nhwc(b)
+        n, c, h, w = a.shape
+        out = new_nhwc(n, 2 * c, h, w, a.dtype, a.device)
+        check(lib().npp_interleave2(_byref(a), _byref(b), _byref(out), 0, None, None, stream_ptr()), "npp_interleave2")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = to_nhwc(dout)
+        n, c2, h, w = dout.shape
+        da = new_nhwc(n, c2 // 2, h, w, dout.dtype, dout.device)
+        db = new_nhwc(n, c2 // 2, h, w, dout.dtype, dout.device)
+        check(lib().npp_interleave2(None, None, _byref(dout), 1, _byref(da), _byref(db), stream_ptr()), "npp_interleave2(bwd)")
+        return da, db
+
+
+def interleave2(a, b):
+    if b.dtype != a.dtype:
+        b = cast(b, a.dtype)
+    return _Interleave2.apply(a, b)
+
+
+def scale_by(x, w_scalar):
+    """w * x for a 0-d tensor w (the beta edge weights): a one-operand weighted sum."""
+    return _WeightedSum.apply(w_scalar.reshape(1), x)

@@ -104,3 +104,242 @@ extern "C" int npp_nhwc_to_nchw(const NppTensor* src, float* dst, void* stream) 
                        (long)src->ld, dst, (int)src->c, HW, total);
   return npp_check_launch("nhwc_to_nchw");
 }
+
+// ---- search-supernet plumbing (model_search_interact.py:22-74): nearest resample, PC-DARTS mixed sum, channel shuffle ----
+namespace {
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void nearest_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int N,
+                                                      int H, int W, int OH, int OW, int cv, float sh, float sw, int backward) {
+  // forward: y[oh,ow] = x[src(oh), src(ow)], src(o) = min(floor(o * scale), in-1)   (ATen nearest, scale = 1/scale_factor)
+  // backward (x = dy at the OUTPUT size OHxOW... see host): gather form over the inputs that map to each source pixel
+  const FastDiv fd((unsigned)cv);
+  if (!backward) {
+    const unsigned total = (unsigned)N * OH * OW * cv;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+      unsigned p, pr_;
+      fast_divmod(i, fd, p, pr_);
+      const int c0 = (int)pr_ * V;
+      const int ow = (int)(p % (unsigned)OW);
+      const unsigned t2 = p / (unsigned)OW;
+      const int oh = (int)(t2 % (unsigned)OH), n = (int)(t2 / (unsigned)OH);
+      int ih = (int)floorf((float)oh * sh), iw = (int)floorf((float)ow * sw);
+      if (ih > H - 1) ih = H - 1;
+      if (iw > W - 1) iw = W - 1;
+      float v[V];
+      ldv<T, V>(x + ((long)(n * H + ih) * W + iw) * ldx + c0, v);
+      stv<T, V>(y + (long)p * ldy + c0, v);
+    }
+  } else {
+    // here x = dy [N,OH,OW], y = dx [N,H,W]: dx[ih,iw] = sum of dy over outputs whose source is (ih,iw)
+    const unsigned total = (unsigned)N * H * W * cv;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+      unsigned p, pr_;
+      fast_divmod(i, fd, p, pr_);
+      const int c0 = (int)pr_ * V;
+      const int iw = (int)(p % (unsigned)W);
+      const unsigned t2 = p / (unsigned)W;
+      const int ih = (int)(t2 % (unsigned)H), n = (int)(t2 / (unsigned)H);
+      float acc[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] = 0.f;
+      // candidate outputs: o with min(floor(o*s), in-1) == i  ->  o in [ceil(i/s) - 1, floor((i+1)/s) + 1], verified exactly
+      int h_lo = (int)floorf((float)ih / sh) - 1, h_hi = (int)floorf((float)(ih + 1) / sh) + 1;
+      int w_lo = (int)floorf((float)iw / sw) - 1, w_hi = (int)floorf((float)(iw + 1) / sw) + 1;
+      if (h_lo < 0) h_lo = 0;
+      if (w_lo < 0) w_lo = 0;
+      if (h_hi > OH - 1) h_hi = OH - 1;
+      if (w_hi > OW - 1) w_hi = OW - 1;
+      for (int oh = h_lo; oh <= h_hi; ++oh) {
+        int sh_i = (int)floorf((float)oh * sh);
+        if (sh_i > H - 1) sh_i = H - 1;
+        if (sh_i != ih) continue;
+        for (int ow = w_lo; ow <= w_hi; ++ow) {
+          int sw_i = (int)floorf((float)ow * sw);
+          if (sw_i > W - 1) sw_i = W - 1;
+          if (sw_i != iw) continue;
+          float d[V];
+          ldv<T, V>(x + ((long)(n * OH + oh) * OW + ow) * ldx + c0, d);
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += d[j];
+        }
+      }
+      stv<T, V>(y + (long)p * ldy + c0, acc);
+    }
+  }
+}
+
+struct WsPtrs { const void* y[8]; long ld[8]; void* dy[8]; long ldd[8]; };
+
+// out = sum_k w[k] * y_k                (forward)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void weighted_sum_fwd_kernel(WsPtrs ptrs, int K, const float* __restrict__ w, T* __restrict__ out,
+                                                               long ldo, long npix, int cv) {
+  const FastDiv fd((unsigned)cv);
+  const unsigned total = (unsigned)(npix * cv);
+  float wk[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) wk[k] = k < K ? w[k] : 0.f;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    unsigned p, pr_;
+    fast_divmod(i, fd, p, pr_);
+    const int c0 = (int)pr_ * V;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < K) {
+        float v[V];
+        ldv<T, V>(reinterpret_cast<const T*>(ptrs.y[k]) + (long)p * ptrs.ld[k] + c0, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = fmaf(wk[k], v[j], acc[j]);
+      }
+    }
+    stv<T, V>(out + (long)p * ldo + c0, acc);
+  }
+}
+
+// dy_k = w[k] * dout ;  dw[k] += sum dout * y_k        (backward)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void weighted_sum_bwd_kernel(WsPtrs ptrs, int K, const float* __restrict__ w,
+                                                               const T* __restrict__ dout, long ldo, long npix, int cv,
+                                                               double* __restrict__ dw) {
+  __shared__ double red[8][4];
+  const FastDiv fd((unsigned)cv);
+  const unsigned total = (unsigned)(npix * cv);
+  float wk[8];
+  double part[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { wk[k] = k < K ? w[k] : 0.f; part[k] = 0.0; }
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    unsigned p, pr_;
+    fast_divmod(i, fd, p, pr_);
+    const int c0 = (int)pr_ * V;
+    float d[V];
+    ldv<T, V>(dout + (long)p * ldo + c0, d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < K) {
+        float v[V], o[V];
+        ldv<T, V>(reinterpret_cast<const T*>(ptrs.y[k]) + (long)p * ptrs.ld[k] + c0, v);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s = fmaf(d[j], v[j], s); o[j] = wk[k] * d[j]; }
+        part[k] += s;
+        if (ptrs.dy[k]) stv<T, V>(reinterpret_cast<T*>(ptrs.dy[k]) + (long)p * ptrs.ldd[k] + c0, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const double s = wave_sum_d(part[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < K)
+    atomicAdd(dw + (blockIdx.x % NPP_STAT_REPLICAS) * 8 + threadIdx.x,
+              red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// channel_shuffle(cat([a, b], 1), groups=2): out[:, 2i] = a[:, i], out[:, 2i+1] = b[:, i]   (and its inverse)
+template <typename T>
+__global__ __launch_bounds__(256) void interleave2_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb,
+                                                          T* __restrict__ out, long ldo, long npix, int ch, int inverse,
+                                                          T* __restrict__ oa, long ldoa, T* __restrict__ ob, long ldob) {
+  const FastDiv fd((unsigned)ch);
+  const unsigned total = (unsigned)(npix * ch);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    unsigned p, c;
+    fast_divmod(i, fd, p, c);
+    if (!inverse) {
+      out[(long)p * ldo + 2 * c] = a[(long)p * lda + c];
+      out[(long)p * ldo + 2 * c + 1] = b[(long)p * ldb + c];
+    } else {   // `out` holds the gradient of the shuffled tensor; scatter back to the two halves
+      oa[(long)p * ldoa + c] = out[(long)p * ldo + 2 * c];
+      ob[(long)p * ldob + c] = out[(long)p * ldo + 2 * c + 1];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int npp_nearest(const NppTensor* x, NppTensor* y, float scale_h, float scale_w, int backward, void* stream) {
+  // forward: x [N,H,W,C] -> y [N,OH,OW,C] with src = floor(dst * scale) (scale = 1 / scale_factor);
+  // backward: x = dy [N,OH,OW,C], y = dx [N,H,W,C], same scales
+  NPP_REQUIRE(x && y && x->ptr && y->ptr, NPP_E_NULL, "npp_nearest: null pointer");
+  NPP_REQUIRE(dtype_ok(x) && x->dtype == y->dtype && x->n == y->n && x->c == y->c, NPP_E_SHAPE, "npp_nearest: mismatch");
+  const bool vk = vec_ok(x) && vec_ok(y);
+  hipStream_t s = (hipStream_t)stream;
+  const NppTensor* in = backward ? y : x;     // the low-level kernel takes (H,W) = source extent, (OH,OW) = resampled extent
+  const NppTensor* rs = backward ? x : y;
+  NPP_DISPATCH_TV(x->dtype, vk, {
+    const int cv = (int)(x->c / V);
+    const long items = (backward ? npix(y) : npix(y)) * cv;
+    hipLaunchKernelGGL((nearest_kernel<T, V>), dim3(grid_for(items)), dim3(256), 0, s, (const T*)x->ptr, (long)x->ld, (T*)y->ptr,
+                       (long)y->ld, (int)x->n, (int)in->h, (int)in->w, (int)rs->h, (int)rs->w, cv, scale_h, scale_w, backward);
+  });
+  return npp_check_launch("nearest");
+}
+
+extern "C" int npp_weighted_sum_fwd(const NppTensor* const* ys, int k, const float* w, NppTensor* out, void* stream) {
+  NPP_REQUIRE(ys && w && out && out->ptr && k >= 1 && k <= 8, NPP_E_NULL, "npp_weighted_sum_fwd: bad arguments");
+  WsPtrs ptrs;
+  bool vk = vec_ok(out);
+  for (int i = 0; i < 8; ++i) { ptrs.y[i] = nullptr; ptrs.ld[i] = 0; ptrs.dy[i] = nullptr; ptrs.ldd[i] = 0; }
+  for (int i = 0; i < k; ++i) {
+    NPP_REQUIRE(ys[i] && ys[i]->ptr && same_shape(ys[i], out) && ys[i]->dtype == out->dtype, NPP_E_SHAPE,
+                "npp_weighted_sum_fwd: operand %d mismatch", i);
+    ptrs.y[i] = ys[i]->ptr; ptrs.ld[i] = ys[i]->ld;
+    vk = vk && vec_ok(ys[i]);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  NPP_DISPATCH_TV(out->dtype, vk, {
+    const int cv = (int)(out->c / V);
+    hipLaunchKernelGGL((weighted_sum_fwd_kernel<T, V>), dim3(grid_for(npix(out) * cv)), dim3(256), 0, s, ptrs, k, w,
+                       (T*)out->ptr, (long)out->ld, (long)npix(out), cv);
+  });
+  return npp_check_launch("weighted_sum_fwd");
+}
+
+extern "C" int npp_weighted_sum_bwd(const NppTensor* const* ys, NppTensor* const* dys, int k, const float* w,
+                                    const NppTensor* dout, double* dw /*[R][8] zeroed*/, void* stream) {
+  NPP_REQUIRE(ys && dys && w && dout && dout->ptr && dw && k >= 1 && k <= 8, NPP_E_NULL, "npp_weighted_sum_bwd: bad arguments");
+  WsPtrs ptrs;
+  bool vk = vec_ok(dout);
+  for (int i = 0; i < 8; ++i) { ptrs.y[i] = nullptr; ptrs.ld[i] = 0; ptrs.dy[i] = nullptr; ptrs.ldd[i] = 0; }
+  for (int i = 0; i < k; ++i) {
+    NPP_REQUIRE(ys[i] && ys[i]->ptr && same_shape(ys[i], dout) && ys[i]->dtype == dout->dtype, NPP_E_SHAPE,
+                "npp_weighted_sum_bwd: operand %d mismatch", i);
+    ptrs.y[i] = ys[i]->ptr; ptrs.ld[i] = ys[i]->ld;
+    vk = vk && vec_ok(ys[i]);
+    if (dys[i]) { ptrs.dy[i] = dys[i]->ptr; ptrs.ldd[i] = dys[i]->ld; vk = vk && vec_ok(dys[i]); }
+  }
+  hipStream_t s = (hipStream_t)stream;
+  NPP_DISPATCH_TV(dout->dtype, vk, {
+    const int cv = (int)(dout->c / V);
+    hipLaunchKernelGGL((weighted_sum_bwd_kernel<T, V>), dim3(grid_for(npix(dout) * cv, 256, 1024)), dim3(256), 0, s, ptrs, k, w,
+                       (const T*)dout->ptr, (long)dout->ld, (long)npix(dout), cv, dw);
+  });
+  return npp_check_launch("weighted_sum_bwd");
+}
+
+extern "C" int npp_interleave2(const NppTensor* a, const NppTensor* b, NppTensor* out, int inverse, NppTensor* oa, NppTensor* ob,
+                               void* stream) {
+  // forward: out[:, 2i] = a[:, i], out[:, 2i+1] = b[:, i].  inverse: oa[:, i] = out[:, 2i], ob[:, i] = out[:, 2i+1]
+  NPP_REQUIRE(out && out->ptr, NPP_E_NULL, "npp_interleave2: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int ch = (int)(out->c / 2);
+  NPP_REQUIRE(out->c % 2 == 0, NPP_E_SHAPE, "npp_interleave2: odd channel count");
+  if (!inverse) NPP_REQUIRE(a && b && a->c == ch && b->c == ch && a->dtype == out->dtype && b->dtype == out->dtype, NPP_E_SHAPE, "npp_interleave2: operand mismatch");
+  else NPP_REQUIRE(oa && ob && oa->c == ch && ob->c == ch && oa->dtype == out->dtype && ob->dtype == out->dtype, NPP_E_SHAPE, "npp_interleave2: operand mismatch");
+  const long np_ = npix(out);
+#define IL(T)                                                                                                              \
+  hipLaunchKernelGGL(interleave2_kernel<T>, dim3(grid_for(np_ * ch)), dim3(256), 0, s, inverse ? nullptr : (const T*)a->ptr, \
+                     inverse ? 0L : (long)a->ld, inverse ? nullptr : (const T*)b->ptr, inverse ? 0L : (long)b->ld,            \
+                     (T*)out->ptr, (long)out->ld, np_, ch, inverse, inverse ? (T*)oa->ptr : nullptr, inverse ? (long)oa->ld : 0L, \
+                     inverse ? (T*)ob->ptr : nullptr, inverse ? (long)ob->ld : 0L)
+  if (out->dtype == NPP_BF16) IL(bf16_t); else IL(float);
+#undef IL
+  return npp_check_launch("interleave2");
+}

@@ -1,0 +1,406 @@
+"""NPPNet search supernet on the HIP kernels -- drop-in for the reference's `models/model_search_interact.py`
+(BASELINE config 5: every cross-task / fusion edge is a PC-DARTS `MixedOp` with all 7 `PRIMITIVES_INTER`
+candidates live on the first half of the channels).
+
+Same surface: `MixedOp(C, stride, up_scale, extra_conv)`, `channel_shuffle`, `PoseCell` / `ParCell(steps,
+multiplier, C_prev_prev, C_prev, C_cur, order)`, `Network(cfg, steps=4, multiplier=4)` reading
+`cfg.SEARCH.LAYERS / INIT_CHANNELS`, the 12 architecture tensors (`alphas1..4`, `alphas_pose/par`, `betas*`),
+`arch_parameters()`, `loss_entropy()`, `btw()`, `genotype()`, identical state-dict keys.  Reference lines are cited
+per class (model_search_interact.py).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _ops as K
+from . import genotypes as gt
+from ._ops import BnSide
+from .genotypes import PRIMITIVES_INTER, Genotype_fuse, Genotype_inter
+from .model_augment import (Cell, Interpolate, ParCell1, PoseCell1, Upsample, _Head, _Layer, _Stem,  # noqa: F401
+                            get_compute_dtype)
+from .operations import OPS, _use_batch_stats
+
+BN_MOMENTUM = 0.1
+
+
+def channel_shuffle(x, groups):
+    """model_search_interact.py:22-36.  For the groups == 2 case the supernet uses, see `_ops.interleave2`."""
+    n, c, h, w = x.shape
+    if groups == 2:
+        return K.interleave2(x[:, :c // 2], x[:, c // 2:])
+    raise NotImplementedError("channel_shuffle: only groups == 2 is used by the supernet")
+
+
+class _OpThenBN(nn.Sequential):
+    """nn.Sequential(op, nn.BatchNorm2d(C, affine=False)) of MixedOp's pooling candidates (:48-49), run on the HIP
+    kernels whatever the BN child has been converted to."""
+
+    def forward(self, x):
+        y = self[0](x)
+        bn = self[1]
+        return K.bn_add(BnSide(y, bn, None), None, relu=False, training=bn.training)
+
+
+class MixedOp(nn.Module):
+    """PC-DARTS mixed edge, model_search_interact.py:39-74: the 7 candidates act on the first C/2 channels, their
+    softmax-weighted sum is concatenated with the (resampled) untouched half and channel-shuffled."""
+
+    def __init__(self, C, stride, up_scale=None, extra_conv=None):
+        super().__init__()
+        self._ops = nn.ModuleList()
+        self.mp = nn.MaxPool2d(2, 2)
+        for primitive in PRIMITIVES_INTER:
+            op = OPS[primitive](C // 2, stride, False)
+            if 'pool' in primitive:
+                op = _OpThenBN(op, nn.BatchNorm2d(C // 2, affine=False))
+            if up_scale:
+                op = nn.Sequential(op, Interpolate(scale_factor=up_scale))
+            self._ops.append(op)
+        self.up_scale = up_scale
+        self.extra_conv = extra_conv
+
+    def forward(self, x, weights):
+        c = x.shape[1]
+        xtemp, xtemp2 = x[:, :c // 2], x[:, c // 2:]
+        temp1 = K.weighted_sum(weights, [op(xtemp) for op in self._ops])
+        if self.up_scale:
+            xtemp2 = K.nearest(xtemp2, self.up_scale)       # F.interpolate default mode (:63-64)
+        if temp1.shape[2] != xtemp2.shape[2]:
+            xtemp2, _ = K.pool2x2(xtemp2, is_avg=False)      # self.mp (:69)
+        ans = K.interleave2(temp1, xtemp2)
+        if self.extra_conv is not None:
+            ec = self.extra_conv
+            ans, _ = K.conv2d(ans, ec.weight, ec.bias, 1, 0, 1, relu_in=False)
+        return ans
+
+
+class _MixedCell(nn.Module):
+    """PoseCell / ParCell, model_search_interact.py:332-430."""
+
+    def __init__(self, steps, multiplier, C_prev_prev, C_prev, C_cur, order):
+        super().__init__()
+        from .operations import ReLUConvBN
+        if order == 0:
+            self.preprocess0 = ReLUConvBN(C_prev_prev, C_cur, 1, 1, 0, affine=True)
+            self.preprocess1 = ReLUConvBN(C_prev, C_cur, 1, 1, 0, affine=True)
+            self.preprocess2 = ReLUConvBN(C_cur, C_cur, 1, 1, 0, affine=True)
+        else:
+            self.preprocess0 = ReLUConvBN(3 * C_prev, C_cur, 1, 1, 0, affine=True)
+            self.preprocess1 = ReLUConvBN(4 * C_prev, C_cur, 1, 1, 0, affine=True)
+            self.preprocess2 = ReLUConvBN(4 * C_prev, C_cur, 1, 1, 0, affine=True)
+        self._steps = steps
+        self._multiplier = multiplier
+        self.order = order
+        self._ops = nn.ModuleList()
+        for i in range(steps):
+            for j in range(3 + i):
+                up = {0: 4, 1: 2}.get(j) if order == 0 else None
+                self._ops.append(MixedOp(C_cur, 1, up))
+
+    def forward(self, s0, s1, s2, weights, weights2):
+        states = [self.preprocess0(s0), self.preprocess1(s1), self.preprocess2(s2)]
+        offset = 0
+        for _ in range(self._steps):
+            outs = [self._ops[offset + j](h, weights[offset + j]) for j, h in enumerate(states)]
+            states.append(K.weighted_sum(weights2[offset:offset + len(states)], outs))
+            offset += len(outs)
+        if self.order == 0:
+            states[0] = K.nearest(states[0], 4)
+            states[1] = K.nearest(states[1], 2)
+        fea1 = K.concat(states[0:3])
+        fea2 = K.concat(states[-self._multiplier:])
+        return fea1, fea2
+
+
+class PoseCell(_MixedCell):
+    pass
+
+
+class ParCell(_MixedCell):
+    pass
+
+
+class Network(nn.Module):
+    """model_search_interact.py:432-1089."""
+
+    def __init__(self, cfg, steps=4, multiplier=4):
+        super().__init__()
+        self._num_classes = cfg.DATASET.NUM_CLASSES
+        self._num_joints = cfg.DATASET.NUM_JOINTS
+        self._layers = cfg.SEARCH.LAYERS
+        self._steps = steps
+        self._multiplier = multiplier
+        self.C = cfg.SEARCH.INIT_CHANNELS
+        self._head = cfg.MODEL.HEAD
+        self.refine_layers = cfg.MODEL.REFINE_LAYERS
+        C = self.C
+
+        def stem(cin, cout, stride, relu):
+            mods = [nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False),
+                    nn.BatchNorm2d(cout, momentum=BN_MOMENTUM)]
+            if relu:
+                mods.append(nn.ReLU(inplace=True))
+            return _Stem(*mods)
+
+        self.stem0, self.stem1, self.stem2 = stem(3, C, 2, True), stem(C, 2 * C, 2, True), stem(2 * C, 2 * C, 1, False)
+        self.stem3, self.stem4, self.stem5 = stem(3, C, 2, True), stem(C, 2 * C, 2, True), stem(2 * C, 2 * C, 1, False)
+
+        L = self._layers
+        self._taps = [L // 4 - 1, 2 * L // 4 - 1, 3 * L // 4 - 1, 4 * L // 4 - 1]
+        reductions = [L // 4, 2 * L // 4, 3 * L // 4]
+        C_pp, C_p, C_curr = 2 * C, 2 * C, int(C / 2)
+        self.cells1, self.cells2 = nn.ModuleList(), nn.ModuleList()
+        self.num_inchannels = []
+        red_prev = False
+        for i in range(L):
+            if i in self._taps:
+                self.num_inchannels.append(int(C_curr * multiplier))
+            red = i in reductions
+            if red:
+                C_curr *= 2
+            self.cells1 += [Cell(gt.ENCODER, C_pp, C_p, C_curr, red, red_prev)]
+            self.cells2 += [Cell(gt.ENCODER, C_pp, C_p, C_curr, red, red_prev)]
+            red_prev = red
+            C_pp, C_p = C_p, multiplier * C_curr
+        self.num_inchannels = self.num_inchannels[::-1]
+        nin = self.num_inchannels
+
+        # encoder-stage mixed edges (:503-523)
+        self._ops1, self._ops2 = nn.ModuleList(), nn.ModuleList()
+        for i in range(len(nin)):
+            for j in range(1 + i):
+                up = 1 / 2 ** (i - j)
+                ec1 = nn.Conv2d(nin[3 - j], nin[3 - i], 1) if i != j else None
+                ec2 = nn.Conv2d(nin[3 - j], nin[3 - i], 1) if i != j else None
+                self._ops1.append(MixedOp(nin[3 - j], 1, up, ec1))
+                self._ops2.append(MixedOp(nin[3 - j], 1, up, ec2))
+
+        self.upsamples1, self.upsamples2 = nn.ModuleList(), nn.ModuleList()
+        for j in range(len(nin) - 1):
+            self.upsamples1 += [Upsample(gt.DECODER.upsample1, gt.DECODER.upsample_concat1, nin[j], nin[j + 1])]
+        for j in range(len(nin) - 1):
+            self.upsamples2 += [Upsample(gt.DECODER.upsample2, gt.DECODER.upsample_concat2, nin[j], nin[j + 1])]
+
+        # decoder-stage mixed edges (:537-559)
+        self.up_ops1, self.up_ops2 = nn.ModuleList(), nn.ModuleList()
+        resolution = [1, 1 / 2, 1 / 4, 1 / 8, 1 / 4, 1 / 2, 1]
+        channels = [int(2 * C / r) for r in resolution]
+        for i in range(len(resolution) - 4):
+            for j in range(4 + 1 + i):
+                up = resolution[4 + i] / resolution[j]
+                ec1 = nn.Conv2d(channels[j], channels[4 + i], 1) if 4 + i != j else None
+                ec2 = nn.Conv2d(channels[j], channels[4 + i], 1) if 4 + i != j else None
+                self.up_ops1.append(MixedOp(channels[j], 1, up, ec1))
+                self.up_ops2.append(MixedOp(channels[j], 1, up, ec2))
+
+        Cf = nin[3]
+
+        def layer(cout):
+            return _Layer(nn.ReLU(), nn.Conv2d(8 * Cf, cout, kernel_size=1, padding=0, dilation=1), nn.BatchNorm2d(cout))
+
+        self.pose_layer = layer(4 * Cf)
+        self.pose_auxlayer = layer(3 * Cf)
+        self.par_layer = layer(4 * Cf)
+        self.edge_layer = layer(3 * Cf)
+
+        self.pose_net, self.par_net = nn.ModuleList(), nn.ModuleList()
+        for _ in range(3):
+            self.pose_net.append(PoseCell(4, 4, Cf, Cf, Cf, 1))
+            self.par_net.append(ParCell(4, 4, Cf, Cf, Cf, 1))
+
+        def head(cin, mid, k, cout, bias1=True):
+            return _Head(nn.ReLU(), nn.Conv2d(cin, mid, kernel_size=k, padding=k // 2, dilation=1, bias=bias1),
+                         nn.BatchNorm2d(mid, momentum=BN_MOMENTUM), nn.ReLU(inplace=True),
+                         nn.Conv2d(mid, cout, kernel_size=1, padding=0, dilation=1, bias=True))
+
+        self.pose_head, self.pose_auxnet = nn.ModuleList(), nn.ModuleList()
+        self.par_head, self.edge_head = nn.ModuleList(), nn.ModuleList()
+        for _ in range(self.refine_layers + 1):
+            self.pose_head.append(head(4 * Cf, 256, 1, self._num_joints))
+            self.pose_auxnet.append(head(3 * Cf, 128, 3, self._num_joints))
+            self.par_head.append(head(4 * Cf, 256, 1, self._num_classes))
+            self.edge_head.append(head(3 * Cf, 6, 3, 2, bias1=False))
+        self._packer = None
+        self.init_weights()
+        self._initialize_alphas()
+
+    # -- architecture parameters (:772-804) -------------------------------------------------------------------
+    def _initialize_alphas(self):
+        k = sum(1 for i in range(self._steps) for _ in range(3 + i))
+        num_ops = len(PRIMITIVES_INTER)
+        self.alphas1 = nn.Parameter(1e-3 * torch.ones(10, num_ops))
+        self.alphas2 = nn.Parameter(1e-3 * torch.ones(10, num_ops))
+        self.alphas3 = nn.Parameter(1e-3 * torch.ones(18, num_ops))
+        self.alphas4 = nn.Parameter(1e-3 * torch.ones(18, num_ops))
+        self.betas1 = nn.Parameter(1e-3 * torch.ones(10))
+        self.betas2 = nn.Parameter(1e-3 * torch.ones(10))
+        self.betas3 = nn.Parameter(1e-3 * torch.ones(18))
+        self.betas4 = nn.Parameter(1e-3 * torch.ones(18))
+        self.alphas_pose = nn.Parameter(1e-3 * torch.ones(k, num_ops))
+        self.alphas_par = nn.Parameter(1e-3 * torch.ones(k, num_ops))
+        self.betas_pose = nn.Parameter(1e-3 * torch.ones(k))
+        self.betas_par = nn.Parameter(1e-3 * torch.ones(k))
+        self._arch_parameters = [self.alphas1, self.alphas2, self.alphas3, self.alphas4, self.alphas_pose, self.alphas_par,
+                                 self.betas1, self.betas2, self.betas3, self.betas4, self.betas_pose, self.betas_par]
+
+    def arch_parameters(self):
+        return self._arch_parameters
+
+    def btw(self, n_input, steps, betas):
+        """beta -> per-node softmax edge weights (:1054-1065)."""
+        parts, start, n = [], 0, n_input
+        for _ in range(steps):
+            parts.append(F.softmax(betas[start:start + n], dim=-1))
+            start += n
+            n += 1
+        return torch.cat(parts, dim=0)
+
+    def loss_entropy(self):
+        """:881-890 (normalised entropy of the alpha rows)."""
+        length = len(self._arch_parameters)
+        alphas = self._arch_parameters[0:length // 2]
+        en_alphas = 0.
+        for a in alphas:
+            w1 = F.softmax(a, dim=-1)
+            en = -(w1 * torch.log(w1)).sum(-1) / math.log(w1.shape[1])
+            en_alphas = en_alphas + en.mean(dim=0)
+        return 0.25 * 2 * en_alphas / length
+
+    # -- forward (:626-770) -------------------------------------------------------------------------------------
+    def _mix(self, ops, base, feats, alpha_rows, beta_rows):
+        w = F.softmax(alpha_rows, dim=-1)
+        w2 = F.softmax(beta_rows, dim=-1)
+        outs = [ops[base + j](h, w[j]) for j, h in enumerate(feats)]
+        return K.weighted_sum(w2, outs)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("npp_amd supernet runs on the MI355X HIP kernels only (no CPU fallback)")
+        dt = get_compute_dtype()
+        if self._packer is None:
+            from .operations import SE_Block
+            skip = set()
+            for m in self.modules():
+                if isinstance(m, SE_Block):
+                    skip.update((id(m.conv1.weight), id(m.conv2.weight)))
+            self._packer = K.WeightPacker(m.weight for m in self.modules()
+                                          if isinstance(m, nn.Conv2d) and m.groups == 1 and id(m.weight) not in skip)
+        self._packer.pack_if_stale(dt, x.device)
+        x = K.image_to_nhwc(x, dt)
+        s1 = self.stem2(s0 := self.stem1(self.stem0(x)))
+        s3 = self.stem5(s2 := self.stem4(self.stem3(x)))
+        f1, f2 = [], []
+        offset = 0
+        for i, (cell1, cell2) in enumerate(zip(self.cells1, self.cells2)):
+            s0, s1 = s1, cell1(s0, s1)
+            s2, s3 = s3, cell2(s2, s3)
+            if i in self._taps:
+                f1.append(s1)
+                f2.append(s3)
+                n = len(f1)
+                z1 = self._mix(self._ops1, offset, f2, self.alphas1[offset:offset + n], self.betas1[offset:offset + n])
+                z2 = self._mix(self._ops2, offset, f1, self.alphas2[offset:offset + n], self.betas2[offset:offset + n])
+                s1 = K.add(s1, z1)
+                s3 = K.add(s3, z2)
+                f1[-1], f2[-1] = s1, s3
+                offset += n
+        cont = 0
+        for d in range(3):
+            o1 = self.upsamples1[d](f1[3] if d == 0 else f1[-1], f1[2 - d])
+            o2 = self.upsamples2[d](f2[3] if d == 0 else f2[-1], f2[2 - d])
+            f1.append(o1)
+            f2.append(o2)
+            n = len(f1)
+            z1 = self._mix(self.up_ops1, cont, f2, self.alphas3[cont:cont + n], self.betas3[cont:cont + n])
+            z2 = self._mix(self.up_ops2, cont, f1, self.alphas4[cont:cont + n], self.betas4[cont:cont + n])
+            f1[-1], f2[-1] = K.add(o1, z1), K.add(o2, z2)
+            cont += n
+        H, W = f1[0].shape[2], f1[0].shape[3]
+        x1 = K.concat([f1[0], f1[6], K.bilinear(f1[5], H, W), K.bilinear(f1[4], H, W)])
+        x2 = K.concat([f2[0], f2[6], K.bilinear(f2[5], H, W), K.bilinear(f2[4], H, W)])
+        in1, in2 = self.pose_auxlayer(x1), self.edge_layer(x2)
+        in3, in4 = self.pose_layer(x1), self.par_layer(x2)
+        pose_list, par_list = [], []
+
+        def heads(i):
+            edge = self.edge_head[i](in2)
+            pose_aux = self.pose_auxnet[i](in1)
+            pose_map = self.pose_head[i](in3)
+            par_map = self.par_head[i](in4)
+            pose_list.append([pose_map, pose_aux])
+            par_list.append([par_map, edge])
+
+        heads(0)
+        w_pose = F.softmax(self.alphas_pose, dim=-1)
+        w_pose2 = self.btw(3, self._steps, self.betas_pose)
+        w_par = F.softmax(self.alphas_par, dim=-1)
+        w_par2 = self.btw(3, self._steps, self.betas_par)
+        for i in range(1, self.refine_layers + 1):
+            for j in range(3):
+                m = 2 * (i - 1) + j
+                n1, tmp = self.pose_net[m](in1, in3, in4, w_pose, w_pose2)
+                in2, n4 = self.par_net[m](in2, in3, in4, w_par, w_par2)
+                in1, in3, in4 = n1, tmp, n4
+            heads(i)
+        return pose_list, par_list
+
+    # -- genotype extraction (:913-1052; host-side numpy on the architecture tensors) --------------------------------
+    def genotype(self):
+        def parse_inter(w1, w2, n_input, step):
+            gene, start, n = [], 0, n_input
+            for _ in range(step):
+                Wm = w1[start:start + n].copy() * w2[start:start + n].copy()[:, None]
+                prob, picks = 0., []
+                while prob < 0.7 and len(picks) < 4:
+                    m = np.max(Wm)
+                    prob += m
+                    idx = np.where(Wm == m)
+                    Wm[idx] = 0
+                    picks.append((PRIMITIVES_INTER[idx[1][0]], int(idx[0][0])))
+                gene.append(picks)
+                start += n
+                n += 1
+            return gene
+
+        def parse_fuse(w1, w2):
+            gene, start, n = [], 0, 3
+            for i in range(self._steps):
+                Wm = w1[start:start + n].copy() * w2[start:start + n].copy()[:, None]
+                edges = sorted(range(i + 3), key=lambda e: -max(Wm[e]))[:2]
+                for j in edges:
+                    gene.append((PRIMITIVES_INTER[int(np.argmax(Wm[j]))], j))
+                start += n
+                n += 1
+            return gene
+
+        def sm(a):
+            return F.softmax(a, dim=-1).data.cpu().numpy()
+
+        inter = Genotype_inter(
+            task1=parse_inter(sm(self.alphas1), self.btw(1, 4, self.betas1).data.cpu().numpy(), 1, 4),
+            task2=parse_inter(sm(self.alphas2), self.btw(1, 4, self.betas2).data.cpu().numpy(), 1, 4),
+            task3=parse_inter(sm(self.alphas3), self.btw(5, 3, self.betas3).data.cpu().numpy(), 5, 3),
+            task4=parse_inter(sm(self.alphas4), self.btw(5, 3, self.betas4).data.cpu().numpy(), 5, 3))
+        fuse = Genotype_fuse(
+            pose=parse_fuse(sm(self.alphas_pose), self.btw(3, self._steps, self.betas_pose).data.cpu().numpy()),
+            pose_concat=range(3, 7),
+            par=parse_fuse(sm(self.alphas_par), self.btw(3, self._steps, self.betas_par).data.cpu().numpy()),
+            par_concat=range(3, 7))
+        return inter, fuse
+
+    def init_weights(self, pretrained=''):
+        """:1067-1089"""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_normal_(m.weight.data)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+                if m.affine:
+                    m.weight.data.fill_(1)
+                    m.bias.data.zero_()

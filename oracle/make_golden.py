@@ -34,6 +34,7 @@ torch.nn.Module.cuda = lambda self, *a, **k: self
 
 from models import operations as ref_ops  # noqa: E402
 from models.model_augment import Network as RefNetwork  # noqa: E402
+from models.model_search_interact import Network as RefSearchNetwork  # noqa: E402
 from core.criterion import Criterion_par, Criterion_pose  # noqa: E402
 
 from npp_amd.synth import synth_state_dict, synth_batch, _rng  # noqa: E402
@@ -216,6 +217,56 @@ def gen_criteria():
     print("criteria.npz", len(out), "arrays")
 
 
+def gen_search():
+    """Search supernet (config 5), C=16, 2x3x128x128, non-uniform alpha/beta: train-mode outputs, losses, selected grads
+    incl. every architecture tensor."""
+    C, size, n = 16, 128, 2
+    torch.manual_seed(0)
+    c = cfg(C)
+    c.SEARCH = NS(LAYERS=16, INIT_CHANNELS=C)
+    net = RefSearchNetwork(c)
+    load_synth(net, 0)
+    with torch.no_grad():      # synthetic alphas/betas are N(0, 0.1): spread them so the softmaxes are non-uniform
+        for a in net.arch_parameters():
+            a.mul_(8.0)
+    images, lpar, lpose, meta = synth_batch(n, size, seed=0)
+    images = torch.from_numpy(images)
+    lpar = [torch.from_numpy(a) for a in lpar]
+    lpose = [torch.from_numpy(a[:, :-1]) for a in lpose]
+    crit_pose = Criterion_pose(out_len=2, use_target_weight=False)
+    crit_par = Criterion_par(out_len=2)
+    net.train()
+    pose_list, par_list = net(images)
+    l_par = crit_par(par_list, lpar)
+    l_pose = crit_pose(pose_list, lpose)
+    loss = (l_par.unsqueeze(0) + l_pose.unsqueeze(0)).mean()
+    net.zero_grad()
+    loss.backward()
+    out = {"torch_version": np.array(torch.__version__), "C": np.array(C), "size": np.array(size), "n": np.array(n)}
+    for i in range(2):
+        out[f"train/pose_map{i}"] = f32(pose_list[i][0])
+        out[f"train/pose_aux{i}"] = f32(pose_list[i][1])
+        out[f"train/par_map{i}"] = f32(par_list[i][0])
+        out[f"train/edge{i}"] = f32(par_list[i][1])
+    out["train/loss"] = f32(loss)
+    params = dict(net.named_parameters())
+    for k in ["alphas1", "alphas2", "alphas3", "alphas4", "alphas_pose", "alphas_par", "betas1", "betas2", "betas3",
+              "betas4", "betas_pose", "betas_par", "_ops1.3.extra_conv.weight", "_ops1.0._ops.0.0.net.1.weight",
+              "up_ops2.7._ops.4.0.net.2.weight", "pose_net.1._ops.5._ops.6.net.2.weight", "par_net.0._ops.2._ops.2.conv1.bias",
+              "stem0.0.weight", "pose_head.1.4.weight"]:
+        assert params[k].grad is not None, k
+        out[f"train/grad/{k}"] = f32(params[k].grad)
+    names = [k for k, p in net.named_parameters() if p.grad is not None]
+    out["train/grad_norm_keys"] = np.array(names)
+    out["train/grad_norms"] = np.array([float(params[k].grad.double().norm()) for k in names], dtype=np.float64)
+    sd = net.state_dict()
+    out["sd_keys"] = np.array(list(sd.keys()))
+    out["sd_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+    out["entropy"] = f32(net.loss_entropy())
+    np.savez_compressed(os.path.join(OUT, "search_net.npz"), **out)
+    print("search_net.npz", len(out), "arrays; loss", float(loss))
+
+
 def gen_full():
     C, size, n = 64, 384, 1
     net, pose_list, par_list, l_par, l_pose, loss, cpose, cpar, images = run_net(C, size, n)
@@ -250,6 +301,6 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["ops", "criteria", "tiny"] + (["full"] if a.full else [])
+    todo = a.only.split(",") if a.only else ["ops", "criteria", "tiny", "search"] + (["full"] if a.full else [])
     for t in todo:
-        {"ops": gen_ops, "criteria": gen_criteria, "tiny": gen_tiny, "full": gen_full}[t]()
+        {"ops": gen_ops, "criteria": gen_criteria, "tiny": gen_tiny, "full": gen_full, "search": gen_search}[t]()

@@ -421,3 +421,148 @@ def train_step_loss(tensors, images, labels_par, labels_pose, lam_pose, lam_par,
     lq = criterion_pose(pose_list, labels_pose, lam_pose)
     loss = (lp.reshape(1) + lq.reshape(1)).mean()
     return loss, pose_list, par_list, newb
+
+
+# ---- search supernet (models/model_search_interact.py) -------------------------------------------------------------
+PRIMITIVES_INTER = ['std_conv_3x3', 'dil_conv_3x3_4', 'se_connect', 'max_pool_3x3', 'dil_conv_3x3_2', 'std_conv_1x1',
+                    'poled_conv_x1']   # models/genotypes.py:20-28
+
+
+def channel_shuffle2(x):
+    """channel_shuffle(x, 2), model_search_interact.py:22-36."""
+    n, c, h, w = x.shape
+    return x.view(n, 2, c // 2, h, w).transpose(1, 2).contiguous().view(n, c, h, w)
+
+
+def mixed_op(c: Ctx, pre: str, x, weights, up_scale, has_extra):
+    """MixedOp.forward, model_search_interact.py:56-74 (candidates built with affine=False, :46)."""
+    C = x.shape[1]
+    xt, xt2 = x[:, :C // 2], x[:, C // 2:]
+    temp1 = 0.
+    for k, name in enumerate(PRIMITIVES_INTER):
+        p = f'{pre}_ops.{k}.'
+        nest = ('0.' if up_scale else '')                      # Sequential(op, Interpolate) wrapper (:50-51)
+        if 'pool' in name:                                     # Sequential(PoolBN, BatchNorm2d(affine=False)) (:48-49)
+            y = apply_op(c, name, p + nest + '0.', xt, 1)
+            y = bn(c, p + nest + '1.', y, affine=False)
+        else:
+            y = apply_op(c, name, p + nest, xt, 1)
+        if up_scale:
+            y = interp(y, up_scale)
+        temp1 = temp1 + weights[k] * y
+    if up_scale:
+        xt2 = F.interpolate(xt2, scale_factor=up_scale)        # default mode: nearest (:63-64)
+    if temp1.shape[2] != xt2.shape[2]:
+        xt2 = F.max_pool2d(xt2, 2, 2)
+    ans = channel_shuffle2(torch.cat([temp1, xt2], dim=1))
+    if has_extra:
+        ans = F.conv2d(ans, c[pre + 'extra_conv.weight'], c[pre + 'extra_conv.bias'])
+    return ans
+
+
+def mixed_cell(c, pre, s0, s1, s2, weights, weights2, steps=4, multiplier=4):
+    """PoseCell / ParCell with order=1, model_search_interact.py:361-378."""
+    states = [relu_conv_bn(c, pre + 'preprocess0.', s0, 1, 1, 0), relu_conv_bn(c, pre + 'preprocess1.', s1, 1, 1, 0),
+              relu_conv_bn(c, pre + 'preprocess2.', s2, 1, 1, 0)]
+    offset = 0
+    for _ in range(steps):
+        s = 0.
+        for j, h in enumerate(states):
+            s = s + weights2[offset + j] * mixed_op(c, f'{pre}_ops.{offset + j}.', h, weights[offset + j], None, False)
+        offset += len(states)
+        states.append(s)
+    return torch.cat(states[0:3], dim=1), torch.cat(states[-multiplier:], dim=1)
+
+
+def btw(n_input, steps, betas):
+    """model_search_interact.py:1054-1065."""
+    parts, start, n = [], 0, n_input
+    for _ in range(steps):
+        parts.append(F.softmax(betas[start:start + n], dim=-1))
+        start += n
+        n += 1
+    return torch.cat(parts, dim=0)
+
+
+def search_network_forward(tensors, x, layers=16, refine_layers=1, train=True):
+    """search Network.forward, model_search_interact.py:626-770."""
+    c = Ctx(tensors, train)
+    L = layers
+    s0 = _stem(c, 'stem1.', _stem(c, 'stem0.', x, 2, True), 2, True)
+    s1 = _stem(c, 'stem2.', s0, 1, False)
+    s2 = _stem(c, 'stem4.', _stem(c, 'stem3.', x, 2, True), 2, True)
+    s3 = _stem(c, 'stem5.', s2, 1, False)
+    f1, f2 = [], []
+    taps = [L // 4 - 1, 2 * L // 4 - 1, 3 * L // 4 - 1, L - 1]
+    reds = [L // 4, 2 * L // 4, 3 * L // 4]
+    red_prev = False
+    offset = 0
+    stage = 0
+
+    def mix(name, base, feats, alphas, betas, up_of, extra_of):
+        w = F.softmax(alphas, dim=-1)
+        w2 = F.softmax(betas, dim=-1)
+        z = 0.
+        for j, h in enumerate(feats):
+            z = z + w2[j] * mixed_op(c, f'{name}.{base + j}.', h, w[j], up_of(j), extra_of(j))
+        return z
+
+    for i in range(L):
+        red = i in reds
+        s0, s1 = s1, cell(c, f'cells1.{i}.', s0, s1, red, red_prev)
+        s2, s3 = s3, cell(c, f'cells2.{i}.', s2, s3, red, red_prev)
+        red_prev = red
+        if i in taps:
+            f1.append(s1)
+            f2.append(s3)
+            n = len(f1)
+            up_of = lambda j, st=stage: 1 / 2 ** (st - j)          # noqa: E731
+            ex_of = lambda j, st=stage: st != j                    # noqa: E731
+            z1 = mix('_ops1', offset, f2, c['alphas1'][offset:offset + n], c['betas1'][offset:offset + n], up_of, ex_of)
+            z2 = mix('_ops2', offset, f1, c['alphas2'][offset:offset + n], c['betas2'][offset:offset + n], up_of, ex_of)
+            s1 = s1 + z1
+            s3 = s3 + z2
+            f1[-1], f2[-1] = s1, s3
+            offset += n
+            stage += 1
+    res = [1, 1 / 2, 1 / 4, 1 / 8, 1 / 4, 1 / 2, 1]
+    cont = 0
+    for d in range(3):
+        o1 = upsample_cell(c, f'upsamples1.{d}.', f1[3] if d == 0 else f1[-1], f1[2 - d], DEC_UP1)
+        o2 = upsample_cell(c, f'upsamples2.{d}.', f2[3] if d == 0 else f2[-1], f2[2 - d], DEC_UP2)
+        f1.append(o1)
+        f2.append(o2)
+        n = len(f1)
+        up_of = lambda j, dd=d: res[4 + dd] / res[j]               # noqa: E731
+        ex_of = lambda j, dd=d: 4 + dd != j                        # noqa: E731
+        z1 = mix('up_ops1', cont, f2, c['alphas3'][cont:cont + n], c['betas3'][cont:cont + n], up_of, ex_of)
+        z2 = mix('up_ops2', cont, f1, c['alphas4'][cont:cont + n], c['betas4'][cont:cont + n], up_of, ex_of)
+        f1[-1], f2[-1] = o1 + z1, o2 + z2
+        cont += n
+    x1 = torch.cat((f1[0], f1[6], interp(f1[5], 2), interp(f1[4], 4)), dim=1)
+    x2 = torch.cat((f2[0], f2[6], interp(f2[5], 2), interp(f2[4], 4)), dim=1)
+    in1 = _layer(c, 'pose_auxlayer.', x1)
+    in2 = _layer(c, 'edge_layer.', x2)
+    in3 = _layer(c, 'pose_layer.', x1)
+    in4 = _layer(c, 'par_layer.', x2)
+    pose_list, par_list = [], []
+
+    def heads(i):
+        edge = _head2(c, f'edge_head.{i}.', in2, 3)
+        pose_aux = _head2(c, f'pose_auxnet.{i}.', in1, 3)
+        pose_map = _head2(c, f'pose_head.{i}.', in3, 1)
+        par_map = _head2(c, f'par_head.{i}.', in4, 1)
+        pose_list.append([pose_map, pose_aux])
+        par_list.append([par_map, edge])
+
+    heads(0)
+    w_pose, w_pose2 = F.softmax(c['alphas_pose'], dim=-1), btw(3, 4, c['betas_pose'])
+    w_par, w_par2 = F.softmax(c['alphas_par'], dim=-1), btw(3, 4, c['betas_par'])
+    for i in range(1, refine_layers + 1):
+        for j in range(3):
+            m = 2 * (i - 1) + j
+            n1, tmp = mixed_cell(c, f'pose_net.{m}.', in1, in3, in4, w_pose, w_pose2)
+            in2, n4 = mixed_cell(c, f'par_net.{m}.', in2, in3, in4, w_par, w_par2)
+            in1, in3, in4 = n1, tmp, n4
+        heads(i)
+    return pose_list, par_list, c.new_buffers

@@ -240,8 +240,45 @@ def test_full_network_384_matches_reference():
     pose_list, par_list, l_par, l_pose, loss, _, _ = _train_step(net, 1, 384, dev)
     assert rel_err(_f32(pose_list[1][0]), g["train/pose_map1"]) < 1e-3
     assert rel_err(_f32(par_list[1][0]), g["train/par_map1"]) < 1e-3
-    assert abs(float(loss) - float(g["train/loss"])) < 1e-3 * abs(float(g["train/loss"]))
+    assert abs(float(loss.detach()) - float(g["train/loss"])) < 1e-3 * abs(float(g["train/loss"]))
     params = dict(net.named_parameters())
     keys = [str(s) for s in g["train/grad_norm_keys"]]
     norms = np.array([float(params[k].grad.double().norm()) for k in keys])
     assert np.abs(norms - g["train/grad_norms"]).max() / g["train/grad_norms"].max() < 3e-2
+
+
+def test_search_supernet_matches_reference():
+    """BASELINE config 5 path: the MixedOp supernet (all 7 PRIMITIVES_INTER candidates live) on the HIP kernels vs the
+    reference's outputs, loss, and gradients incl. all 12 architecture tensors."""
+    from types import SimpleNamespace as NS
+    from npp_amd.model_search_interact import Network
+    from npp_amd.model_augment import set_compute_dtype
+    from npp_amd.criterion import Criterion_par, Criterion_pose
+    g = load_golden("search_net.npz")
+    dev = _dev()
+    set_compute_dtype(torch.float32)
+    C = int(g["C"])
+    cfg = NS(DATASET=NS(NUM_CLASSES=20, NUM_JOINTS=16), SEARCH=NS(LAYERS=16, INIT_CHANNELS=C),
+             MODEL=NS(DECONV_WITH_BIAS=False, HEAD='PSP', REFINE_LAYERS=1))
+    net = Network(cfg)
+    sd = synth_tensors(template_from_golden(g), 0)
+    for k in ["alphas1", "alphas2", "alphas3", "alphas4", "alphas_pose", "alphas_par", "betas1", "betas2", "betas3",
+              "betas4", "betas_pose", "betas_par"]:
+        sd[k] = sd[k] * 8.0
+    net.load_state_dict(sd)
+    assert list(net.state_dict().keys()) == [str(k) for k in g["sd_keys"]]
+    net = net.to(dev).train()
+    pose_list, par_list, l_par, l_pose, loss, _, _ = _train_step(net, int(g["n"]), int(g["size"]), dev)
+    for i in range(2):
+        assert rel_err(_f32(pose_list[i][0]), g[f"train/pose_map{i}"]) < 1e-3
+        assert rel_err(_f32(par_list[i][0]), g[f"train/par_map{i}"]) < 1e-3
+        assert rel_err(_f32(par_list[i][1]), g[f"train/edge{i}"]) < 1e-3
+        assert rel_err(_f32(pose_list[i][1]), g[f"train/pose_aux{i}"]) < 1e-3
+    assert abs(float(loss.detach()) - float(g["train/loss"])) < 1e-3 * abs(float(g["train/loss"]))
+    params = dict(net.named_parameters())
+    for k in g.files:
+        if k.startswith("train/grad/"):
+            pk = k[len("train/grad/"):]
+            assert params[pk].grad is not None, pk
+            assert rel_err(_f32(params[pk].grad), g[k]) < 4e-2, pk     # OHEM conditioning, see the tiny-net test
+    assert abs(float(net.loss_entropy()) - float(g["entropy"])) < 1e-5

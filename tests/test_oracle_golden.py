@@ -187,3 +187,31 @@ def test_gradient_conditioning():
     assert rel_err(pr32[1][0].detach().numpy(), pr64[1][0].detach().numpy()) < 1e-3
     gap = rel_err(t32["stem0.0.weight"].grad.numpy(), t64["stem0.0.weight"].grad.numpy())
     assert 1e-4 < gap < 4e-2, gap
+
+
+def test_search_supernet_matches_reference():
+    """Config 5 (model_search_interact.Network, all 7 candidates live in 164 MixedOps): oracle vs the reference."""
+    g = load_golden("search_net.npz")
+    t = synth_tensors(template_from_golden(g), 0)
+    arch = ["alphas1", "alphas2", "alphas3", "alphas4", "alphas_pose", "alphas_par", "betas1", "betas2", "betas3",
+            "betas4", "betas_pose", "betas_par"]
+    for k in arch:
+        t[k] = t[k] * 8.0
+    for k, v in t.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    images, lpar, lpose, _ = synth_batch(int(g["n"]), int(g["size"]), seed=0)
+    pose_list, par_list, _ = O.search_network_forward(t, torch.from_numpy(images))
+    lam_pose = torch.full((2,), -2.5)
+    lam_par = torch.full((2,), 2.3)
+    loss = (O.criterion_par(par_list, [torch.from_numpy(a) for a in lpar], lam_par).reshape(1) +
+            O.criterion_pose(pose_list, [torch.from_numpy(a[:, :-1]) for a in lpose], lam_pose).reshape(1)).mean()
+    loss.backward()
+    for i in range(2):
+        assert rel_err(pose_list[i][0].detach().numpy(), g[f"train/pose_map{i}"]) < 1e-4
+        assert rel_err(par_list[i][0].detach().numpy(), g[f"train/par_map{i}"]) < 1e-4
+    assert abs(float(loss) - float(g["train/loss"])) < 1e-4 * abs(float(g["train/loss"]))
+    for k in g.files:
+        if k.startswith("train/grad/"):
+            pk = k[len("train/grad/"):]
+            assert rel_err(t[pk].grad.numpy(), g[k]) < 1e-3, pk
