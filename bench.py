@@ -181,11 +181,16 @@ def main():
                 for _ in range(2):
                     step()
             torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
+            barrier()
+            if use_dist:
+                # the ProcessGroup watchdog thread polls the events of the eager collectives above; let it retire them
+                # before capture starts, and capture in thread-local mode so that its polling (a different thread) can
+                # never be an illegal call inside a global-mode capture
+                time.sleep(1.0)
             K.reset_pools()
             opt.zero_grad(set_to_none=True)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 static_loss = step()
             K.reset_pools()
             graph = g

@@ -129,6 +129,11 @@ int npp_bn_bwd_reduce(const NppTensor* dout, const NppTensor* y_raw, const NppTe
  * coeffs = [A[C] | B[C] | C[C]]; dgamma = s1, dbeta = s0 (optional).  sums = [nrep][2C]. */
 int npp_bn_bwd_coeffs(const double* sums, int nrep, double count, const float* mean_invstd, const float* gamma,
                       float* coeffs, float* dgamma, float* dbeta, int c, void* stream);
+/* SyncBatchNorm backward (torch.nn.SyncBatchNorm semantics, augment_lip_sync.py:191): total[2C] = sum of this rank's
+ * slabs (the caller all-reduces it, then calls npp_bn_bwd_coeffs with nrep = 1 and the global count); dgamma / dbeta are
+ * the LOCAL sums. */
+int npp_bn_bwd_sum(const double* partials, int nblocks, double* total /*[2C]*/, float* dgamma, float* dbeta, int c,
+                   void* stream);
 int npp_bn_bwd_apply(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,
                      const float* coeffs, NppTensor* dy_raw, void* stream);
 /* eval-mode / plain affine backward: dy = dout * scale * (out>0) */

@@ -53,10 +53,62 @@ def reset_pools():
     """Drop the current scratch chunks (call after CUDA-graph capture: captured chunks belong to the graph)."""
     _zpool64.buf = None
     _zpool32.buf = None
+    _sync_pool.drop()
 
 
 def zeros_f64(n, device):
     return _zpool64.get(n, device)
+
+
+class _SyncStatsPool(_ZeroPool):
+    """Statistics of SyncBatchNorm layers live back to back in one chunk, so that every vector produced since the
+    last exchange travels in ONE all-reduce of the range [synced_off, off) -- no gather / concat / slice kernels
+    around the collective (augment_lip_sync.py:191 turns all 490 BNs into SyncBatchNorm)."""
+
+    def __init__(self, chunk_elems):
+        super().__init__(torch.float64, chunk_elems)
+        self.synced_off = 0
+        self.waiting = []      # BnSides whose statistics sit in the un-exchanged range
+        self.group = None
+        self.ws = 1
+
+    def get(self, n, device):
+        n_al = (n + 63) // 64 * 64
+        if self.buf is not None and self.off + n_al > self.buf.numel():
+            self.flush()       # the old chunk is about to be left behind
+        if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
+            self.buf = torch.zeros(max(self.chunk, n_al), dtype=self.dtype, device=device)
+            self.off = self.synced_off = 0
+        return super().get(n, device)
+
+    def holds_unsynced(self, t):
+        if self.buf is None or t is None or t.device != self.buf.device:
+            return False
+        d = t.data_ptr() - self.buf.data_ptr()
+        return self.synced_off * 8 <= d < self.off * 8
+
+    def enlist(self, side, grp, ws):
+        self.waiting.append(side)
+        self.group, self.ws = grp, ws
+
+    def flush(self):
+        if self.waiting:
+            dist.all_reduce(self.buf[self.synced_off:self.off], group=self.group)
+            for sd in self.waiting:
+                sd.synced_ws = self.ws
+            self.waiting = []
+        self.synced_off = self.off
+
+    def drop(self):
+        self.buf, self.off, self.synced_off, self.waiting = None, 0, 0, []
+
+
+_sync_pool = _SyncStatsPool(1 << 21)
+
+
+def stats_buffer(n, device, want_stats):
+    """want_stats: 1 = local statistics, 2 = statistics that will be exchanged across ranks (SyncBatchNorm)."""
+    return _sync_pool.get(n, device) if want_stats == 2 else _zpool64.get(n, device)
 
 
 def zeros_f32(n, device):
@@ -194,7 +246,7 @@ class _Conv2d(Function):
         else:
             oh, ow = out_hw
         y = new_nhwc(n, co, oh, ow, x.dtype, x.device)
-        stats = zeros_f64(R * 2 * co, x.device) if want_stats else None
+        stats = stats_buffer(R * 2 * co, x.device, want_stats) if want_stats else None
         g = geom(kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 1, relu_in)
         wp = packed_weight(weight, False, x.dtype)
         bf = None
@@ -255,7 +307,7 @@ class _Conv2d(Function):
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1, relu_in=False, want_stats=False):
     """y = conv(relu?(x)) + bias, plus (optionally) the f64 [sum | sumsq] statistics of y."""
-    return _Conv2d.apply(x, weight, bias, _pair(stride), _pair(pad), _pair(dil), bool(relu_in), bool(want_stats), None)
+    return _Conv2d.apply(x, weight, bias, _pair(stride), _pair(pad), _pair(dil), bool(relu_in), int(want_stats), None)
 
 
 def conv2d_crop(x, weight, stride=2, relu_in=False, want_stats=False):
@@ -263,7 +315,7 @@ def conv2d_crop(x, weight, stride=2, relu_in=False, want_stats=False):
     materialising the view: the crop is a padding of -1 in the gather."""
     h, w = x.shape[2] - 1, x.shape[3] - 1
     out_hw = ((h - 1) // stride + 1, (w - 1) // stride + 1)
-    return _Conv2d.apply(x, weight, None, _pair(stride), (-1, -1), (1, 1), bool(relu_in), bool(want_stats), out_hw)
+    return _Conv2d.apply(x, weight, None, _pair(stride), (-1, -1), (1, 1), bool(relu_in), int(want_stats), out_hw)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -334,6 +386,10 @@ class BnSide:
         self.stats = stats
         self.count = None
         self.synced_ws = 0
+        if stats is not None and bn is not None and _sync_pool.holds_unsynced(stats):
+            grp, ws = _sync_group(bn)
+            if grp is not None:
+                _sync_pool.enlist(self, grp, ws)
 
 
 _SYNC_EVEN_ALONE = False   # test hook: run the SyncBN collectives on a 1-rank group (bench.py --force-dist)
@@ -349,35 +405,33 @@ def _sync_group(bn):
     return None, 1
 
 
+def stats_level(bn) -> int:
+    """0: running statistics; 1: batch statistics; 2: batch statistics exchanged across ranks."""
+    if not (bn.training or bn.running_mean is None):
+        return 0
+    return 2 if _sync_group(bn)[0] is not None else 1
+
+
 def _presync_stats(sides, training: bool):
-    """SyncBN forward exchange for the (up to two) BN sides of one fused add with ONE all-reduce of the
-    concatenated [sum | sumsq] vectors (864 -> ~600 small collectives per step on this network)."""
-    todo = []
+    """SyncBN forward exchange.  Statistics written by the producing kernels into the sync pool are all-reduced in place,
+    replicas and all, together with every other vector produced since the previous exchange (one collective per
+    fused-add node or fewer, zero glue kernels); anything else (FactorizedReduce's stitched halves, statistics computed
+    on demand) is all-reduced on its own."""
     for sd in sides:
-        if sd is None or sd.bn is None or not (training or sd.bn.running_mean is None):
+        if sd is None or sd.bn is None or sd.synced_ws or not (training or sd.bn.running_mean is None):
             continue
         grp, ws = _sync_group(sd.bn)
         if grp is None:
             continue
         if sd.stats is None:
-            sd.stats = channel_stats(sd.x)
-        c = sd.x.shape[1]
-        nrep = sd.stats.numel() // (2 * c)
-        todo.append((sd, sd.stats.view(nrep, 2 * c).sum(0), grp, ws))
-    if not todo:
-        return
-    grp = todo[0][2]
-    if len(todo) == 2 and todo[1][2] is grp:
-        buf = torch.cat([todo[0][1], todo[1][1]])
-        dist.all_reduce(buf, group=grp)
-        n0 = todo[0][1].numel()
-        todo[0][0].stats, todo[1][0].stats = buf[:n0], buf[n0:]
-    else:
-        for sd, v, g, _ in todo:
-            dist.all_reduce(v, group=g)
-            sd.stats = v
-    for sd, _, _, ws in todo:
-        sd.synced_ws = ws
+            sd.stats = channel_stats(sd.x, 2)
+            if _sync_pool.holds_unsynced(sd.stats):
+                _sync_pool.enlist(sd, grp, ws)
+        if any(w is sd for w in _sync_pool.waiting):
+            _sync_pool.flush()
+        else:
+            dist.all_reduce(sd.stats, group=grp)
+            sd.synced_ws = ws
 
 
 def _bn_coeffs(side: BnSide, training: bool, device):
@@ -395,15 +449,11 @@ def _bn_coeffs(side: BnSide, training: bool, device):
             stats = channel_stats(side.x)
         nrep = stats.numel() // (2 * c)
         count = float(side.x.shape[0] * side.x.shape[2] * side.x.shape[3])
-        if side.synced_ws:            # already all-reduced by _presync_stats
+        if not side.synced_ws:
+            _presync_stats((side,), training)
+            stats = side.stats
+        if side.synced_ws:            # all-reduced: the replicas now hold global partial sums
             count *= side.synced_ws
-        else:
-            grp, ws = _sync_group(bn)
-            if grp is not None:
-                stats = stats.view(nrep, 2 * c).sum(0)
-                nrep = 1
-                dist.all_reduce(stats, group=grp)
-                count *= ws
         side.count = count
         mi = torch.empty(2 * c, dtype=torch.float32, device=device)
         track = bn.track_running_stats and bn.running_mean is not None and training
@@ -476,8 +526,8 @@ class _BnAdd(Function):
             sides.append((b, bnb, mib, ssb, batch_b, cnt_b, ni[3], ni[4], ni[5]))
         # phase 1: local reductions of every BN side
         red = [reduce_side(x, mi) if bn is not None else None for (x, bn, mi, *_r) in sides]
-        # phase 2 (SyncBatchNorm): ONE all-reduce for the side(s) of this node.  Weight/bias grads stay the LOCAL sums
-        # (DDP averages them afterwards, as torch.nn.SyncBatchNorm does); the input gradient uses the global sums.
+        # phase 2 (SyncBatchNorm): collapse each side's slabs to one vector (+ the LOCAL dgamma / dbeta, which DDP
+        # averages afterwards as torch.nn.SyncBatchNorm does), then ONE all-reduce of the side(s) of this node.
         local = [None] * len(sides)
         sync = []
         for i, (x, bn, mi, ss, batch, count, *_r) in enumerate(sides):
@@ -485,22 +535,23 @@ class _BnAdd(Function):
                 continue
             grp, ws = _sync_group(bn)
             if grp is not None:
-                c = x.shape[1]
-                local[i] = red[i][0].view(red[i][1], 2 * c).sum(0)
-                sync.append((i, grp))
+                sync.append((i, grp, x.shape[1]))
         if sync:
-            grp = sync[0][1]
-            if len(sync) == 2 and sync[1][1] is grp:
-                buf = torch.cat([local[sync[0][0]], local[sync[1][0]]])
-                dist.all_reduce(buf, group=grp)
-                n0 = local[sync[0][0]].numel()
-                red[sync[0][0]] = (buf[:n0], 1)
-                red[sync[1][0]] = (buf[n0:], 1)
+            tot = torch.empty(sum(2 * c for _, _, c in sync), dtype=torch.float64, device=dout.device)
+            off = 0
+            for i, grp, c in sync:
+                dgl = torch.empty(2 * c, dtype=torch.float32, device=dout.device)
+                part = tot[off:off + 2 * c]
+                check(lib().npp_bn_bwd_sum(red[i][0].data_ptr(), red[i][1], part.data_ptr(), dgl[:c].data_ptr(),
+                                           dgl[c:].data_ptr(), c, s), "npp_bn_bwd_sum")
+                local[i] = dgl
+                red[i] = (part, 1)
+                off += 2 * c
+            if len(sync) == 2 and sync[0][1] is not sync[1][1]:
+                for i, grp, c in sync:
+                    dist.all_reduce(red[i][0], group=grp)
             else:
-                for i, g in sync:
-                    glob = local[i].clone()
-                    dist.all_reduce(glob, group=g)
-                    red[i] = (glob, 1)
+                dist.all_reduce(tot, group=sync[0][1])
         # phase 3: coefficients + apply
         outs = []
         for i, (x, bn, mi, ss, batch, count, need_x, need_g, need_b) in enumerate(sides):
@@ -514,7 +565,7 @@ class _BnAdd(Function):
             if batch:
                 dgt = dbt = None
                 if local[i] is not None:
-                    dg, db = local[i][c:].float(), local[i][:c].float()
+                    dg, db = local[i][:c], local[i][c:]
                 else:
                     dgt = torch.empty(c, dtype=torch.float32, device=x.device)
                     dbt = torch.empty(c, dtype=torch.float32, device=x.device)
@@ -562,9 +613,9 @@ def add(a, b):
     return bn_add(BnSide(a), BnSide(b))
 
 
-def channel_stats(x: torch.Tensor) -> torch.Tensor:
+def channel_stats(x: torch.Tensor, level: int = 1) -> torch.Tensor:
     x = to_nhwc(x)
-    st = zeros_f64(R * 2 * x.shape[1], x.device)
+    st = stats_buffer(R * 2 * x.shape[1], x.device, level)
     check(lib().npp_channel_stats(_byref(x.detach()), st.data_ptr(), stream_ptr()), "npp_channel_stats")
     return st
 
@@ -580,7 +631,7 @@ class _Pool3x3(Function):
         oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
         y = new_nhwc(n, c, oh, ow, x.dtype, x.device)
         amax = None if is_avg else torch.empty((n, oh, ow, c), dtype=torch.uint8, device=x.device)
-        stats = zeros_f64(R * 2 * c, x.device) if want_stats else None
+        stats = stats_buffer(R * 2 * c, x.device, want_stats) if want_stats else None
         check(lib().npp_pool3x3_fwd(_byref(x), _byref(y), ptr(amax), int(is_avg), stride, ptr(stats), stream_ptr()),
               "npp_pool3x3_fwd")
         ctx.save_for_backward(amax)
@@ -605,7 +656,7 @@ class _Pool3x3(Function):
 
 
 def pool3x3(x, is_avg=False, stride=1, want_stats=False):
-    return _Pool3x3.apply(x, bool(is_avg), int(stride), bool(want_stats))
+    return _Pool3x3.apply(x, bool(is_avg), int(stride), int(want_stats))
 
 
 class _Pool2x2(Function):
@@ -614,7 +665,7 @@ class _Pool2x2(Function):
         x = to_nhwc(x)
         n, c, h, w = x.shape
         y = new_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
-        stats = zeros_f64(R * 2 * c, x.device) if want_stats else None
+        stats = stats_buffer(R * 2 * c, x.device, want_stats) if want_stats else None
         check(lib().npp_pool2x2_fwd(_byref(x), _byref(y), int(is_avg), ptr(stats), stream_ptr()), "npp_pool2x2_fwd")
         ctx.save_for_backward(None if is_avg else x)
         ctx.cfg = (is_avg, tuple(x.shape), x.dtype)
@@ -641,7 +692,7 @@ class _Pool2x2(Function):
 
 
 def pool2x2(x, is_avg=True, want_stats=False):
-    return _Pool2x2.apply(x, bool(is_avg), bool(want_stats))
+    return _Pool2x2.apply(x, bool(is_avg), int(want_stats))
 
 
 # --------------------------------------------------------------------------------------------------

@@ -272,6 +272,22 @@ __global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums, int nrep, 
   if (dbeta) dbeta[c] = (float)s0;
 }
 
+// SyncBatchNorm: collapse this rank's per-block slabs to one [sum_dy | sum_dy_xhat] vector (f64, to be all-reduced)
+// and emit the LOCAL dgamma / dbeta (DDP averages those afterwards, as torch.nn.SyncBatchNorm does).
+__global__ void bn_bwd_sum_kernel(const double* __restrict__ sums, int nrep, double* __restrict__ total, float* dgamma,
+                                  float* dbeta, int C) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gid >> 6, sub = gid & 63;
+  const bool live = c < C;
+  double s0, s1;
+  slab_sum(sums, nrep, C, live ? c : 0, sub, s0, s1);
+  if (!live || sub != 0) return;
+  total[c] = s0;
+  total[C + c] = s1;
+  if (dgamma) dgamma[c] = (float)s1;
+  if (dbeta) dbeta[c] = (float)s0;
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
                                                            long ldy, const T* __restrict__ ro, long ldr,
@@ -443,6 +459,14 @@ extern "C" int npp_bn_bwd_coeffs(const double* sums, int nrep, double count, con
   hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((c * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, nrep, 1.0 / count,
                      mean_invstd, gamma, coeffs, dgamma, dbeta, c);
   return npp_check_launch("bn_bwd_coeffs");
+}
+
+extern "C" int npp_bn_bwd_sum(const double* partials, int nblocks, double* total, float* dgamma, float* dbeta, int c,
+                              void* stream) {
+  NPP_REQUIRE(partials && total && c > 0 && nblocks >= 1, NPP_E_NULL, "npp_bn_bwd_sum: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((c * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, nblocks, total,
+                     dgamma, dbeta, c);
+  return npp_check_launch("bn_bwd_sum");
 }
 
 extern "C" int npp_bn_bwd_apply(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,

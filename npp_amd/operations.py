@@ -23,8 +23,9 @@ from ._ops import BnSide
 BN_MOMENTUM = 0.1   # operations.py:27
 
 
-def _use_batch_stats(bn) -> bool:
-    return bn.training or bn.running_mean is None
+def _use_batch_stats(bn) -> int:
+    """0 / 1 / 2 = running statistics / batch statistics / batch statistics exchanged across ranks (SyncBatchNorm)."""
+    return K.stats_level(bn)
 
 
 class _BnOp(nn.Module):
@@ -180,6 +181,7 @@ class FactorizedReduce(_BnOp):
 
     def pending(self, x):
         want = _use_batch_stats(self.bn)
+        want = min(want, 1)     # the halves are stitched below, outside the SyncBN exchange pool
         y1, s1 = K.conv2d(x, self.conv1.weight, None, 2, 0, 1, relu_in=True, want_stats=want)
         y2, s2 = K.conv2d_crop(x, self.conv2.weight, 2, relu_in=True, want_stats=want)
         if y1.shape[2:] != y2.shape[2:]:
