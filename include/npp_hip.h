@@ -99,8 +99,10 @@ int npp_dwconv_fwd(const NppTensor* x, const float* w /*[C][kh*kw]*/, NppTensor*
                    const NppConvGeom* g, void* stream);
 int npp_dwconv_bwd_data(const NppTensor* dy, const float* w, const NppTensor* x_mask /*opt: relu mask*/,
                         NppTensor* dx, const NppConvGeom* g, void* stream);
-/* dw [C][kh*kw] is WRITTEN; ws = ZEROED scratch of npp_dwconv_bwd_weight_ws(dy, g) floats (replica slabs) */
+/* dw [C][kh*kw] is WRITTEN; ws = scratch of npp_dwconv_bwd_weight_ws(dy, g) floats (per-block slabs), which must be
+ * zero on entry iff npp_dwconv_bwd_weight_ws_zeroed(dy, g) returns 1 (the generic any-geometry kernel) */
 int64_t npp_dwconv_bwd_weight_ws(const NppTensor* dy, const NppConvGeom* g);
+int npp_dwconv_bwd_weight_ws_zeroed(const NppTensor* dy, const NppConvGeom* g);
 int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, float* dw, float* ws, const NppConvGeom* g,
                           void* stream);
 

@@ -91,7 +91,7 @@ _SIGS = {
     "npp_edge_weights": [_P, C.c_int64, _P, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_packed_weight_elems", "npp_reduce_blocks",
-                                 "npp_dwconv_bwd_weight_ws"])
+                                 "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed"])
 
 
 def lib():
@@ -109,6 +109,8 @@ def lib():
         L.npp_packed_weight_elems.argtypes = [C.c_int] * 5
         L.npp_dwconv_bwd_weight_ws.restype = C.c_int64
         L.npp_dwconv_bwd_weight_ws.argtypes = [_T, _G]
+        L.npp_dwconv_bwd_weight_ws_zeroed.restype = C.c_int
+        L.npp_dwconv_bwd_weight_ws_zeroed.argtypes = [_T, _G]
         L.npp_reduce_blocks.restype = C.c_int
         L.npp_reduce_blocks.argtypes = [C.c_int64, C.c_int64, C.c_int]
         for name, sig in _SIGS.items():

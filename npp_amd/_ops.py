@@ -235,6 +235,9 @@ def _conv_out(h, k, s, p, d):
 # --------------------------------------------------------------------------------------------------
 # dense conv (MFMA implicit GEMM)
 # --------------------------------------------------------------------------------------------------
+SHAPE_LOG = None     # tools/shape_prof.py: list of (kind, n, ci, h, w, co, kh, stride, dil) in launch order
+
+
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, relu_in, want_stats, out_hw):
@@ -256,6 +259,8 @@ class _Conv2d(Function):
                 bf = bf.float()
         check(lib().npp_conv_fwd(_byref(x), wp.data_ptr(), ptr(bf), None, _byref(y), ptr(stats), C.byref(g),
                                  stream_ptr()), "npp_conv_fwd")
+        if SHAPE_LOG is not None:
+            SHAPE_LOG.append(("fwd", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, relu_in, bias is not None)
         ctx.set_materialize_grads(False)     # no zero tensor for the (non-differentiable) statistics output
@@ -284,6 +289,8 @@ class _Conv2d(Function):
             wp = packed_weight(weight, True, x.dtype)
             check(lib().npp_conv_fwd(_byref(dy), wp.data_ptr(), None, _byref(x) if relu_in else None, _byref(dx), None,
                                      C.byref(g), s), "npp_conv_fwd(dgrad)")
+            if SHAPE_LOG is not None:
+                SHAPE_LOG.append(("dgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
         if ctx.needs_input_grad[1]:
             nel = lib().npp_packed_weight_elems(co, ci, kh, kw, 0)
             g = geom(kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 1, relu_in)
@@ -296,6 +303,8 @@ class _Conv2d(Function):
                 check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
                 dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
                 check(lib().npp_unpack_wgrad(dwp.data_ptr(), co, ci, kh, kw, dw.data_ptr(), s), "npp_unpack_wgrad")
+            if SHAPE_LOG is not None:
+                SHAPE_LOG.append(("wgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
             if dw.dtype != weight.dtype:
                 dw = dw.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
@@ -359,7 +368,10 @@ class _DwConv2d(Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
             nws = lib().npp_dwconv_bwd_weight_ws(_byref(dy), C.byref(g))
-            ws = zeros_f32(nws, x.device)
+            if lib().npp_dwconv_bwd_weight_ws_zeroed(_byref(dy), C.byref(g)):
+                ws = zeros_f32(nws, x.device)
+            else:
+                ws = torch.empty(nws, dtype=torch.float32, device=x.device)
             check(lib().npp_dwconv_bwd_weight(_byref(x), _byref(dy), dw.data_ptr(), ws.data_ptr(), C.byref(g), s),
                   "npp_dwconv_bwd_weight")
             if dw.dtype != weight.dtype:
@@ -444,14 +456,13 @@ def _bn_coeffs(side: BnSide, training: bool, device):
     s = stream_ptr()
     use_batch = training or bn.running_mean is None
     if use_batch:
+        if not side.synced_ws:
+            _presync_stats((side,), training)     # SyncBatchNorm: all-reduce (computing the statistics if need be)
+        if side.stats is None:
+            side.stats = channel_stats(side.x)
         stats = side.stats
-        if stats is None:
-            stats = channel_stats(side.x)
         nrep = stats.numel() // (2 * c)
         count = float(side.x.shape[0] * side.x.shape[2] * side.x.shape[3])
-        if not side.synced_ws:
-            _presync_stats((side,), training)
-            stats = side.stats
         if side.synced_ws:            # all-reduced: the replicas now hold global partial sums
             count *= side.synced_ws
         side.count = count

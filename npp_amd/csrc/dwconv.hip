@@ -178,12 +178,263 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
   }
 }
 
+// ---- 3x3 "run" kernels ------------------------------------------------------------------------------------------
+// A thread owns one 16-byte channel vector and one RUN of output pixels of a row: ow = phase + delta*i with
+// delta = dil / stride, so that the input column of tap kw at step i is  base + dil*(i + kw): consecutive steps
+// slide a 3-column register window by one column, and each pixel costs 3 new loads (one per kernel row) instead of 9.
+// Forward and (stride-1) data gradient share the kernel: the data gradient is the forward pass over dy with the taps
+// flipped, pad' = dil*(K-1) - pad, and the ReLU mask of x applied at the store.
+struct RunGeom {
+  int IH, IW, OH, OW;      // input / output extents of THIS pass
+  int s, pad_h, pad_w, d;  // stride, padding, dilation of THIS pass
+  int delta;               // dil / stride
+  int nseg, seglen;        // every run is cut into nseg pieces of seglen steps (parallelism for small batches)
+  long ld_in, ld_out, ld_mask;
+  int N, C, cv, relu_in, flip;
+};
+
+// A 16-byte (or scalar) element vector kept in its storage form until it is used, so that the loads of the NEXT step
+// can be in flight while the current step computes.
+template <typename T, int V> struct RawVec;
+template <> struct RawVec<bf16_t, 8> {
+  u32x4 v;
+  NPP_DEV void load(const bf16_t* p) { v = *reinterpret_cast<const u32x4*>(p); }
+  NPP_DEV void unpack(float* o) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(v[i] << 16);
+      o[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+    }
+  }
+};
+template <> struct RawVec<float, 4> {
+  f32x4 v;
+  NPP_DEV void load(const float* p) { v = *reinterpret_cast<const f32x4*>(p); }
+  NPP_DEV void unpack(float* o) const { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+};
+template <typename T> struct RawVec<T, 1> {
+  T v;
+  NPP_DEV void load(const T* p) { v = *p; }
+  NPP_DEV void unpack(float* o) const { o[0] = Elt<T>::ld(&v); }
+};
+
+// Branch-free tap fetch: an out-of-range tap reads a valid address (column 0 of a valid row) and is zeroed when it is
+// unpacked, so the loads of one step are issued back to back.
+template <typename T, int V> struct RunTap {
+  RawVec<T, V> raw;
+  bool ok;
+  NPP_DEV void fetch(const T* __restrict__ row, bool row_ok, int col, const RunGeom& g, int c0) {
+    ok = row_ok && col >= 0 && col < g.IW;
+    raw.load(row + (long)(ok ? col : 0) * g.ld_in + c0);
+  }
+  NPP_DEV void get(float* o, int relu) const {
+    raw.unpack(o);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float v = relu ? fmaxf(o[j], 0.f) : o[j];
+      o[j] = ok ? v : 0.f;
+    }
+  }
+};
+
+struct RunIdx {
+  int cg, ph, oh, n, ibeg, npx, base;
+};
+NPP_DEV RunIdx run_decode(unsigned gi, const RunGeom& g) {
+  RunIdx r;
+  unsigned run = gi / (unsigned)g.cv;
+  r.cg = (int)(gi - run * (unsigned)g.cv);
+  unsigned q = run / (unsigned)g.nseg;
+  const int seg = (int)(run - q * (unsigned)g.nseg);
+  run = q;
+  q = run / (unsigned)g.delta;
+  r.ph = (int)(run - q * (unsigned)g.delta);
+  run = q;
+  q = run / (unsigned)g.OH;
+  r.oh = (int)(run - q * (unsigned)g.OH);
+  r.n = (int)q;
+  const int npx_all = r.ph < g.OW ? (g.OW - r.ph + g.delta - 1) / g.delta : 0;
+  r.ibeg = seg * g.seglen;
+  r.npx = min(npx_all, r.ibeg + g.seglen);
+  r.base = r.ph * g.s - g.pad_w;
+  return r;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dw3_run_fwd_kernel(const T* __restrict__ in, const float* __restrict__ w,
+                                                          const T* __restrict__ mask, T* __restrict__ out, RunGeom g) {
+  extern __shared__ float swt[];   // [tap][C], taps already flipped for the data gradient
+  for (int i = threadIdx.x; i < g.C * 9; i += 256) {
+    const int c = i / 9, tap = i - c * 9;
+    swt[(g.flip ? 8 - tap : tap) * g.C + c] = w[i];
+  }
+  __syncthreads();
+  const unsigned total = (unsigned)g.N * g.OH * g.delta * g.nseg * g.cv;
+  for (unsigned gi = blockIdx.x * 256 + threadIdx.x; gi < total; gi += gridDim.x * 256) {
+    const RunIdx r = run_decode(gi, g);
+    const int c0 = r.cg * V;
+    float wr[9][V];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < V; ++j) wr[t][j] = swt[t * g.C + c0 + j];
+    const T* rows[3];
+    bool rok[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = r.oh * g.s - g.pad_h + kh * g.d;
+      rok[kh] = ih >= 0 && ih < g.IH;
+      rows[kh] = in + ((long)r.n * g.IH + (rok[kh] ? ih : 0)) * g.IW * g.ld_in;
+    }
+    float win[3][3][V];
+    RunTap<T, V> nx[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      RunTap<T, V> a, b;
+      a.fetch(rows[kh], rok[kh], r.base + g.d * r.ibeg, g, c0);
+      b.fetch(rows[kh], rok[kh], r.base + g.d * (r.ibeg + 1), g, c0);
+      nx[kh].fetch(rows[kh], rok[kh], r.base + g.d * (r.ibeg + 2), g, c0);
+      a.get(win[kh][0], g.relu_in);
+      b.get(win[kh][1], g.relu_in);
+    }
+    T* orow = out + ((long)r.n * g.OH + r.oh) * g.OW * g.ld_out + c0;
+    const T* mrow = mask ? mask + ((long)r.n * g.OH + r.oh) * g.OW * g.ld_mask + c0 : nullptr;
+    RawVec<T, V> mk;
+    if (mrow && r.ibeg < r.npx) mk.load(mrow + (long)(r.ph + g.delta * r.ibeg) * g.ld_mask);
+    for (int i0 = r.ibeg; i0 < r.npx; i0 += 3) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int i = i0 + u;
+        if (i < r.npx) {
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) nx[kh].get(win[kh][(u + 2) % 3], g.relu_in);
+          float m[V];
+          if (mrow) mk.unpack(m);
+          // the next step's column (and mask) start their trip now; past the end of the run they re-read this one
+          const int inx = i + 1 < r.npx ? i + 1 : i;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) nx[kh].fetch(rows[kh], rok[kh], r.base + g.d * (inx + 2), g, c0);
+          if (mrow) mk.load(mrow + (long)(r.ph + g.delta * inx) * g.ld_mask);
+          float acc[V];
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+              for (int j = 0; j < V; ++j) acc[j] = fmaf(win[kh][(u + kw) % 3][j], wr[kh * 3 + kw][j], acc[j]);
+          if (mrow) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] = m[j] > 0.f ? acc[j] : 0.f;
+          }
+          stv<T, V>(orow + (long)(r.ph + g.delta * i) * g.ld_out, acc);
+        }
+      }
+    }
+  }
+}
+
+// weight gradient over the same runs: acc[kh][kw] += dy * window[kh][kw]; the block folds its threads' sums into an LDS
+// [C][9] image (LDS float atomics) and writes ONE private slab (no global atomics, no zero-init); sum_slabs adds them.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dw3_run_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            float* __restrict__ slabs, RunGeom g) {
+  // LDS: 4 per-wave images [tap*V + j][cv] (plain stores after an in-wave shuffle reduction; same-address LDS float
+  // atomics from the 4..16 lanes that share a channel vector cost 3x the whole main loop)
+  extern __shared__ float sdw[];
+  const int img = g.C * 9;
+  for (int i = threadIdx.x; i < 4 * img; i += 256) sdw[i] = 0.f;
+  __syncthreads();
+  float acc[9][V];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[t][j] = 0.f;
+  const unsigned total = (unsigned)g.N * g.OH * g.delta * g.nseg * g.cv;
+  for (unsigned gi = blockIdx.x * 256 + threadIdx.x; gi < total; gi += gridDim.x * 256) {
+    const RunIdx r = run_decode(gi, g);
+    const int c0 = r.cg * V;
+    const T* rows[3];
+    bool rok[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = r.oh * g.s - g.pad_h + kh * g.d;
+      rok[kh] = ih >= 0 && ih < g.IH;
+      rows[kh] = x + ((long)r.n * g.IH + (rok[kh] ? ih : 0)) * g.IW * g.ld_in;
+    }
+    float win[3][3][V];
+    RunTap<T, V> nx[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      RunTap<T, V> a, b;
+      a.fetch(rows[kh], rok[kh], r.base + g.d * r.ibeg, g, c0);
+      b.fetch(rows[kh], rok[kh], r.base + g.d * (r.ibeg + 1), g, c0);
+      nx[kh].fetch(rows[kh], rok[kh], r.base + g.d * (r.ibeg + 2), g, c0);
+      a.get(win[kh][0], g.relu_in);
+      b.get(win[kh][1], g.relu_in);
+    }
+    const T* drow = dy + ((long)r.n * g.OH + r.oh) * g.OW * g.ld_out + c0;
+    RawVec<T, V> dn;
+    if (r.ibeg < r.npx) dn.load(drow + (long)(r.ph + g.delta * r.ibeg) * g.ld_out);
+    for (int i0 = r.ibeg; i0 < r.npx; i0 += 3) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int i = i0 + u;
+        if (i < r.npx) {
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) nx[kh].get(win[kh][(u + 2) % 3], g.relu_in);
+          float dv[V];
+          dn.unpack(dv);
+          const int inx = i + 1 < r.npx ? i + 1 : i;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) nx[kh].fetch(rows[kh], rok[kh], r.base + g.d * (inx + 2), g, c0);
+          dn.load(drow + (long)(r.ph + g.delta * inx) * g.ld_out);
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+              for (int j = 0; j < V; ++j) acc[kh * 3 + kw][j] = fmaf(dv[j], win[kh][(u + kw) % 3][j], acc[kh * 3 + kw][j]);
+        }
+      }
+    }
+  }
+  // threads of a block keep their channel vector over the grid-stride loop (256 and the grid stride are multiples of
+  // cv, a power of two -- the host checks), so one reduction at the end is enough
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cg = (int)((blockIdx.x * 256 + threadIdx.x) % (unsigned)g.cv);
+  for (int o = g.cv; o < 64; o <<= 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[t][j] += __shfl_xor(acc[t][j], o);
+  }
+  if (lane < g.cv) {
+    float* mine = sdw + wave * img;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < V; ++j) mine[(t * V + j) * g.cv + cg] += acc[t][j];
+  }
+  __syncthreads();
+  float* slab = slabs + (long)blockIdx.x * img;
+  for (int i = threadIdx.x; i < img; i += 256) {
+    const int tj = i / g.cv, c_g = i - tj * g.cv;
+    const int t = tj / V, j = tj - t * V;
+    slab[(c_g * V + j) * 9 + t] = sdw[i] + sdw[img + i] + sdw[2 * img + i] + sdw[3 * img + i];
+  }
+}
+
+// out[i] = sum over slabs: 64 lanes stride over the slabs of one element, then a wave reduction
 __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslabs, int n, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid >> 6, lane = gid & 63;
   float s = 0.f;
-  for (int b = 0; b < nslabs; ++b) s += slabs[(long)b * n + i];
-  out[i] = s;
+  if (i < n)
+    for (int b = lane; b < nslabs; b += 64) s += slabs[(long)b * n + i];
+  s = wave_sum(s);
+  if (i < n && lane == 0) out[i] = s;
 }
 
 int fill_params(DwParams& p, const NppTensor* x, const NppTensor* y, const NppConvGeom* g, const char* who) {
@@ -199,6 +450,31 @@ int fill_params(DwParams& p, const NppTensor* x, const NppTensor* y, const NppCo
   p.relu_in = g->relu_in;
   p.ldx = x->ld; p.ldy = y->ld; p.ldm = 0;
   return NPP_OK;
+}
+
+// the run kernels cover 3x3 taps with dil % stride == 0 (every depthwise conv of the fixed genotype)
+static bool run_plan(const DwParams& p, RunGeom& g, int& nblk, int V) {
+  if (p.KH != 3 || p.KW != 3 || p.dh != p.dw || p.sh != p.sw || p.dh % p.sh != 0 || p.C % V != 0) return false;
+  g.IH = p.H; g.IW = p.W; g.OH = p.OH; g.OW = p.OW;
+  g.s = p.sh; g.pad_h = p.ph; g.pad_w = p.pw; g.d = p.dh; g.delta = p.dh / p.sh;
+  g.ld_in = p.ldx; g.ld_out = p.ldy; g.ld_mask = 0;
+  g.N = p.N; g.C = p.C; g.cv = p.C / V; g.relu_in = p.relu_in; g.flip = 0;
+  const int npx = (g.OW + g.delta - 1) / g.delta;
+  const long base_threads = (long)g.N * g.OH * g.delta * g.cv;
+  int nseg = (int)((256L * 256 * 3 + base_threads - 1) / base_threads);
+  if (getenv("NPP_DW_THREADS")) nseg = (int)((atol(getenv("NPP_DW_THREADS")) + base_threads - 1) / base_threads);
+  const int max_seg = npx / 6 > 1 ? npx / 6 : 1;
+  if (nseg > max_seg) nseg = max_seg;
+  if (nseg < 1) nseg = 1;
+  int seglen = (npx + nseg - 1) / nseg;
+  seglen = (seglen + 2) / 3 * 3;
+  nseg = (npx + seglen - 1) / seglen;
+  g.nseg = nseg; g.seglen = seglen;
+  if (base_threads * nseg >= (1L << 31)) return false;
+  long nb = (base_threads * nseg + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  nblk = (int)(nb < 1 ? 1 : nb);
+  return true;
 }
 
 template <typename K>
@@ -226,6 +502,15 @@ extern "C" int npp_dwconv_fwd(const NppTensor* x, const float* w, NppTensor* y, 
   ProfScope prof(NPP_FAM_DWCONV, x->dtype, s, 2.0 * npix(y) * p.C * g->kh * g->kw, (double)(npix(x) + npix(y)) * p.C * esize(x->dtype));
   NPP_DISPATCH_TV(x->dtype, vk, {
     p.cv = p.C / V;
+    RunGeom rg;
+    int nb = 0;
+    if (!getenv("NPP_DISABLE_DW_RUN") && run_plan(p, rg, nb, V)) {
+      rc = allow_lds(dw3_run_fwd_kernel<T, V>, lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL((dw3_run_fwd_kernel<T, V>), dim3((unsigned)nb), dim3(256), lds, s, (const T*)x->ptr, w,
+                         (const T*)nullptr, (T*)y->ptr, rg);
+      return npp_check_launch("dwconv_fwd(run)");
+    }
     rc = allow_lds(dwconv_fwd_kernel<T, V>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((dwconv_fwd_kernel<T, V>), dim3(grid_for(npix(y) * p.cv, 256, 2048)), dim3(256), lds, s,
@@ -250,6 +535,24 @@ extern "C" int npp_dwconv_bwd_data(const NppTensor* dy, const float* w, const Np
   ProfScope prof(NPP_FAM_DWCONV, dy->dtype, s, 2.0 * npix(dy) * p.C * g->kh * g->kw, (double)(npix(dx) * 2 + npix(dy)) * p.C * esize(dy->dtype));
   NPP_DISPATCH_TV(dy->dtype, vk, {
     p.cv = p.C / V;
+    if (!getenv("NPP_DISABLE_DW_RUN") && p.sh == 1 && p.sw == 1) {
+      // the data gradient of a stride-1 conv is the forward pass over dy with flipped taps and pad' = dil*(K-1) - pad
+      DwParams q = p;
+      q.H = p.OH; q.W = p.OW; q.OH = p.H; q.OW = p.W;
+      q.ph = p.dh * (p.KH - 1) - p.ph; q.pw = p.dw * (p.KW - 1) - p.pw;
+      q.ldx = p.ldy; q.ldy = p.ldx; q.relu_in = 0;
+      RunGeom rg;
+      int nb = 0;
+      if (q.ph >= 0 && q.pw >= 0 && run_plan(q, rg, nb, V)) {
+        rg.flip = 1;
+        rg.ld_mask = p.ldm;
+        rc = allow_lds(dw3_run_fwd_kernel<T, V>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((dw3_run_fwd_kernel<T, V>), dim3((unsigned)nb), dim3(256), lds, s, (const T*)dy->ptr, w,
+                           x_mask ? (const T*)x_mask->ptr : nullptr, (T*)dx->ptr, rg);
+        return npp_check_launch("dwconv_bwd_data(run)");
+      }
+    }
     rc = allow_lds(dwconv_bwd_data_kernel<T, V>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((dwconv_bwd_data_kernel<T, V>), dim3(grid_for(npix(dx) * p.cv, 256, 2048)), dim3(256), lds, s,
@@ -267,11 +570,29 @@ static inline int dw_bwd_blocks(long npixo, int cv) {
   return (int)bx;
 }
 
+static bool wgrad_plan(const NppTensor* dy, const NppConvGeom* g, int& nblk) {
+  DwParams p;
+  memset(&p, 0, sizeof(p));
+  p.N = (int)dy->n; p.OH = (int)dy->h; p.OW = (int)dy->w; p.C = (int)dy->c;
+  p.KH = g->kh; p.KW = g->kw; p.sh = g->sh; p.sw = g->sw; p.ph = g->ph; p.pw = g->pw; p.dh = g->dh; p.dw = g->dw;
+  const int v = dy->dtype == NPP_BF16 ? 8 : 4;
+  RunGeom rg;
+  const long cv = dy->c / v;
+  const bool pow2 = dy->c % v == 0 && cv >= 1 && cv <= 256 && (cv & (cv - 1)) == 0;
+  return !getenv("NPP_DISABLE_DW_RUN") && pow2 && dy->ld % v == 0 && 4L * dy->c * 9 * 4 <= 160 * 1024 - 2048 &&
+         run_plan(p, rg, nblk, v);
+}
+
 extern "C" int64_t npp_dwconv_bwd_weight_ws(const NppTensor* dy, const NppConvGeom* g) {
   if (!dy || !g) return 0;
-  const int v = dy->dtype == NPP_BF16 ? 8 : 4;
-  const int cv = (int)(dy->c % v == 0 ? dy->c / v : dy->c);
-  return (int64_t)NPP_STAT_REPLICAS * dy->c * g->kh * g->kw;   // zeroed by the caller
+  int nblk = 0;
+  if (wgrad_plan(dy, g, nblk)) return (int64_t)nblk * dy->c * 9;           // one written slab per block
+  return (int64_t)NPP_STAT_REPLICAS * dy->c * g->kh * g->kw;                // replica slabs, zeroed by the caller
+}
+
+extern "C" int npp_dwconv_bwd_weight_ws_zeroed(const NppTensor* dy, const NppConvGeom* g) {
+  int nblk = 0;
+  return (dy && g && wgrad_plan(dy, g, nblk)) ? 0 : 1;
 }
 
 extern "C" int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, float* dw, float* ws, const NppConvGeom* g,
@@ -288,6 +609,22 @@ extern "C" int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, fl
   int nblk = 1;
   NPP_DISPATCH_TV(x->dtype, vk, {
     p.cv = p.C / V;
+    RunGeom rg;
+    int nb = 0;
+    int nb_ws = 0;
+    const bool planned = wgrad_plan(dy, g, nb_ws);
+    if (planned && V > 1 && run_plan(p, rg, nb, V) && nb <= nb_ws) {
+      const size_t lds4 = 4 * lds;
+      rc = allow_lds(dw3_run_wgrad_kernel<T, V>, lds4);
+      if (rc) return rc;
+      hipLaunchKernelGGL((dw3_run_wgrad_kernel<T, V>), dim3((unsigned)nb), dim3(256), lds4, s, (const T*)x->ptr,
+                         (const T*)dy->ptr, ws, rg);
+      const int n = p.C * taps;
+      hipLaunchKernelGGL(sum_slabs_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, s, ws, nb, n, dw);
+      return npp_check_launch("dwconv_bwd_weight(run)");
+    }
+    if (planned)   // the caller sized (and did not zero) ws for the run kernel, which cannot take these operands
+      (void)hipMemsetAsync(ws, 0, sizeof(float) * NPP_STAT_REPLICAS * p.C * taps, s);
     const int cols_blk = p.cv < 256 ? p.cv : 256;
     const int rows = 256 / cols_blk;
     nblk = dw_bwd_blocks(npix(dy), p.cv);
@@ -297,6 +634,6 @@ extern "C" int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, fl
                        (const T*)dy->ptr, ws, p, cols_blk, rows);
   });
   const int n = p.C * taps;
-  hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ws, NPP_STAT_REPLICAS, n, dw);
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, s, ws, NPP_STAT_REPLICAS, n, dw);
   return npp_check_launch("dwconv_bwd_weight");
 }
