@@ -224,6 +224,9 @@ def main():
         # a replayed graph cannot carry the event pairs: time the same kernels (same shapes, same data) with HIP
         # events on the launch stream in two eager steps right after the timed region
         prof_steps = 2
+        # single-stream for these steps: with the two branches overlapping, an event pair would also time the other
+        # branch's kernels sharing the chip
+        os.environ["NPP_STREAMS"] = "1"
         L.npp_prof_begin(_lib.FAM["conv_s1"], dt_code)
         for _ in range(prof_steps):
             eager_step()

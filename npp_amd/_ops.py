@@ -7,6 +7,7 @@ every byte of activation / gradient arithmetic is done by libnpp_hip.  No fallba
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -45,19 +46,69 @@ class _ZeroPool:
         return t
 
 
-_zpool64 = _ZeroPool(torch.float64, 1 << 21)
-_zpool32 = _ZeroPool(torch.float32, 1 << 24)
+class _PerStream:
+    """One pool per HIP stream: a chunk is zeroed by a fill on the stream that creates it, so its slices may only be
+    handed to kernels of that stream (the network runs its two branches on two streams)."""
+
+    def __init__(self, make):
+        self.make, self.pools = make, {}
+
+    def cur(self):
+        key = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
+        pool = self.pools.get(key)
+        if pool is None:
+            pool = self.pools[key] = self.make()
+        return pool
+
+    def all(self):
+        return list(self.pools.values())
+
+
+_helper_streams = {}
+_branch_b_streams = set()      # raw handles of the side streams the network runs its second branch on
+_helper_uses = 0
+
+
+def helper_stream():
+    """The helper stream paired with the current stream (NPP_STREAMS=4: the two edges of a cell node overlap), or None.
+    Opt-in and eager-only: on ROCm 7.0 hipStreamEndCapture segfaults when two non-origin streams of a capture wait on
+    each other in both directions (tools/capture_repro.py, variants `bidir` / `nested`), which is exactly what the
+    helper of the side-stream branch does.  Fork/join with the capture's origin stream is fine, hence 2 streams."""
+    if os.environ.get("NPP_STREAMS", "2") != "4" or not torch.cuda.is_available():
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    global _helper_uses
+    lim = os.environ.get("NPP_HELPER_MAX")
+    if lim is not None:
+        _helper_uses += 1
+        if _helper_uses > int(lim):
+            return None
+    # two helpers per device, created together and before any hipGraph capture (streams created while a capture is in
+    # progress crash hipStreamEndCapture on this stack): [0] serves whatever stream the caller runs on, [1] the
+    # parsing-branch stream registered by the network
+    cur = torch.cuda.current_stream()
+    key = (cur.device.type, cur.device.index)
+    pair = _helper_streams.get(key)
+    if pair is None:
+        pair = _helper_streams[key] = (torch.cuda.Stream(device=cur.device), torch.cuda.Stream(device=cur.device))
+    return pair[1] if cur.cuda_stream in _branch_b_streams else pair[0]
+
+
+_zpool64 = _PerStream(lambda: _ZeroPool(torch.float64, 1 << 21))
+_zpool32 = _PerStream(lambda: _ZeroPool(torch.float32, 1 << 24))
 
 
 def reset_pools():
     """Drop the current scratch chunks (call after CUDA-graph capture: captured chunks belong to the graph)."""
-    _zpool64.buf = None
-    _zpool32.buf = None
-    _sync_pool.drop()
+    for pool in _zpool64.all() + _zpool32.all():
+        pool.buf = None
+    for pool in _sync_pool.all():
+        pool.drop()
 
 
 def zeros_f64(n, device):
-    return _zpool64.get(n, device)
+    return _zpool64.cur().get(n, device)
 
 
 class _SyncStatsPool(_ZeroPool):
@@ -103,16 +154,16 @@ class _SyncStatsPool(_ZeroPool):
         self.buf, self.off, self.synced_off, self.waiting = None, 0, 0, []
 
 
-_sync_pool = _SyncStatsPool(1 << 21)
+_sync_pool = _PerStream(lambda: _SyncStatsPool(1 << 21))
 
 
 def stats_buffer(n, device, want_stats):
     """want_stats: 1 = local statistics, 2 = statistics that will be exchanged across ranks (SyncBatchNorm)."""
-    return _sync_pool.get(n, device) if want_stats == 2 else _zpool64.get(n, device)
+    return _sync_pool.cur().get(n, device) if want_stats == 2 else _zpool64.cur().get(n, device)
 
 
 def zeros_f32(n, device):
-    return _zpool32.get(n, device)
+    return _zpool32.cur().get(n, device)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -398,10 +449,10 @@ class BnSide:
         self.stats = stats
         self.count = None
         self.synced_ws = 0
-        if stats is not None and bn is not None and _sync_pool.holds_unsynced(stats):
+        if stats is not None and bn is not None and _sync_pool.cur().holds_unsynced(stats):
             grp, ws = _sync_group(bn)
             if grp is not None:
-                _sync_pool.enlist(self, grp, ws)
+                _sync_pool.cur().enlist(self, grp, ws)
 
 
 _SYNC_EVEN_ALONE = False   # test hook: run the SyncBN collectives on a 1-rank group (bench.py --force-dist)
@@ -437,10 +488,11 @@ def _presync_stats(sides, training: bool):
             continue
         if sd.stats is None:
             sd.stats = channel_stats(sd.x, 2)
-            if _sync_pool.holds_unsynced(sd.stats):
-                _sync_pool.enlist(sd, grp, ws)
-        if any(w is sd for w in _sync_pool.waiting):
-            _sync_pool.flush()
+            if _sync_pool.cur().holds_unsynced(sd.stats):
+                _sync_pool.cur().enlist(sd, grp, ws)
+        owner = next((pl for pl in _sync_pool.all() if any(w is sd for w in pl.waiting)), None)
+        if owner is not None:
+            owner.flush()
         else:
             dist.all_reduce(sd.stats, group=grp)
             sd.synced_ws = ws

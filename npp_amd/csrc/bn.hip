@@ -34,10 +34,49 @@ static inline dim3 col_grid_ew(const ColMap& m, long npix) {
   return dim3((unsigned)bx, (unsigned)((m.cv + m.cols_blk - 1) / m.cols_blk));
 }
 
+// Block reduction of per-thread column sums.  Power-of-two column counts (every C of this network but 384 and 6):
+// lanes of a wave that share a column are folded with xor-shuffles, each wave (or, for >= 64 columns, each pixel row)
+// then stores ONE conflict-free image [q][col] and the images are summed.  The general path (any column count)
+// stages every thread's sums in LDS, thread-major, and lets the first row walk them.
 template <int NQ, int V, bool STORE = false>
 NPP_DEV void block_col_reduce(double (&acc)[NQ][V], float* red /*[256][NQ*V] doubles as 2 floats*/, int t, int col,
                               int row, int rows, int cols_blk, bool active, double* const* outs, int colg, int C) {
   double* dred = reinterpret_cast<double*>(red);
+  constexpr int NQV = NQ * V;
+  if ((cols_blk & (cols_blk - 1)) == 0 && rows * cols_blk == 256) {
+    int groups, gidx;
+    if (cols_blk < 64) {
+      for (int o = cols_blk; o < 64; o <<= 1) {
+#pragma unroll
+        for (int qn = 0; qn < NQ; ++qn)
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[qn][j] += __shfl_xor(acc[qn][j], o);
+      }
+      groups = 4; gidx = t >> 6;
+    } else {
+      groups = rows; gidx = row;
+    }
+    if (cols_blk >= 64 || (t & 63) < cols_blk) {
+#pragma unroll
+      for (int qn = 0; qn < NQ; ++qn)
+#pragma unroll
+        for (int j = 0; j < V; ++j) dred[(gidx * NQV + qn * V + j) * cols_blk + col] = active ? acc[qn][j] : 0.0;
+    }
+    __syncthreads();
+    const int cbase = colg - col;          // first column vector of this block
+    for (int i = t; i < NQV * cols_blk; i += 256) {
+      const int q = i / cols_blk, cc = i - q * cols_blk;
+      double s = 0.0;
+      for (int g2 = 0; g2 < groups; ++g2) s += dred[(g2 * NQV + q) * cols_blk + cc];
+      const int qn = q / V, j = q - qn * V;
+      const int ch = (cbase + cc) * V + j;
+      if (ch < C) {
+        if (STORE) outs[qn][ch] = s;
+        else atomicAdd(outs[qn] + ch, s);
+      }
+    }
+    return;
+  }
   if (active) {
 #pragma unroll
     for (int qn = 0; qn < NQ; ++qn)

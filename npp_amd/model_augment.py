@@ -13,6 +13,7 @@ is two fused conv launches plus ONE BN-apply+add launch, and no ATen convolution
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -193,6 +194,24 @@ class ParCell1(_FuseCell):
 
 
 # ---- network -----------------------------------------------------------------------------------------
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+        K._branch_b_streams.add(st.cuda_stream)
+    return st
+
+
+def _two_streams() -> bool:
+    """NPP_STREAMS=1 keeps the whole network on the caller's stream; 2 (default) = one stream per task branch; 4 = plus
+    a helper stream per branch for the second edge of every cell node (eager only, see _ops.helper_stream)."""
+    return os.environ.get("NPP_STREAMS", "2") != "1"
+
+
 class Network(nn.Module):
     """model_augment.py:231-709."""
 
@@ -340,50 +359,84 @@ class Network(nn.Module):
                                           if isinstance(m, nn.Conv2d) and m.groups == 1 and id(m.weight) not in skip)
         self._packer.pack_if_stale(dt, x.device)
         x = K.image_to_nhwc(x, dt)
+        # The pose branch runs on the caller's stream ("A"), the parsing branch on a side stream ("B"); the branches
+        # meet at the 4 encoder taps, the 3 decoder stages and the refinement cells.  Kernels of one branch that cannot
+        # fill 256 CUs (12x12 / 24x24 maps, tile tails) overlap with the other branch's; a captured hipGraph keeps the
+        # two-branch structure (tools/graph_concurrency.py) and autograd replays each node's backward on the stream of
+        # its forward.
+        two = _two_streams()
+        K._helper_uses = 0
+        if two:
+            sa = torch.cuda.current_stream()
+            sb = _side_stream(x.device)
+
+        def on_b():
+            return torch.cuda.stream(sb) if two else contextlib.nullcontext()
+
+        def meet(*tensors):
+            """Each stream waits for what the other has issued so far; `tensors` cross streams from here on."""
+            if not two:
+                return
+            ea, eb = torch.cuda.Event(), torch.cuda.Event()
+            ea.record(sa)
+            eb.record(sb)
+            sa.wait_event(eb)
+            sb.wait_event(ea)
+            for t in tensors:
+                t.record_stream(sa)
+                t.record_stream(sb)
+
+        meet(x)
         s1 = self.stem2(s0 := self.stem1(self.stem0(x)))
-        s3 = self.stem5(s2 := self.stem4(self.stem3(x)))
+        with on_b():
+            s3 = self.stem5(s2 := self.stem4(self.stem3(x)))
         f1, f2 = [], []
         k1 = k2 = stage = 0
         for i, (cell1, cell2) in enumerate(zip(self.cells1, self.cells2)):
             s0, s1 = s1, cell1(s0, s1)
-            s2, s3 = s3, cell2(s2, s3)
+            with on_b():
+                s2, s3 = s3, cell2(s2, s3)
             if i in self._taps:
                 f1.append(s1)
                 f2.append(s3)
+                meet(*f1, *f2)
                 ind1, ind2 = self._indices1[stage], self._indices2[stage]
-                z1 = self._cross(self._ops1, k1, ind1, f2)
-                z2 = self._cross(self._ops2, k2, ind2, f1)
+                s1 = K.add(s1, self._cross(self._ops1, k1, ind1, f2))
+                with on_b():
+                    s3 = K.add(s3, self._cross(self._ops2, k2, ind2, f1))
                 k1 += len(ind1)
                 k2 += len(ind2)
                 stage += 1
-                s1 = K.add(s1, z1)
-                s3 = K.add(s3, z2)
                 f1[-1], f2[-1] = s1, s3
         # decoder: three structurally identical stages (model_augment.py:448-533)
         k1 = k2 = 0
         for d in range(3):
             o1 = self.upsamples1[d](f1[3] if d == 0 else f1[-1], f1[2 - d])
-            o2 = self.upsamples2[d](f2[3] if d == 0 else f2[-1], f2[2 - d])
+            with on_b():
+                o2 = self.upsamples2[d](f2[3] if d == 0 else f2[-1], f2[2 - d])
             f1.append(o1)
             f2.append(o2)
+            meet(*f1, *f2)
             ind1, ind2 = self.up_indices1[d], self.up_indices2[d]
-            z1 = self._cross(self.up_ops1, k1, ind1, f2)
-            z2 = self._cross(self.up_ops2, k2, ind2, f1)
+            f1[-1] = K.add(o1, self._cross(self.up_ops1, k1, ind1, f2))
+            with on_b():
+                f2[-1] = K.add(o2, self._cross(self.up_ops2, k2, ind2, f1))
             k1 += len(ind1)
             k2 += len(ind2)
-            f1[-1], f2[-1] = K.add(o1, z1), K.add(o2, z2)
         H, W = f1[0].shape[2], f1[0].shape[3]
         x1 = K.concat([f1[0], f1[6], K.bilinear(f1[5], H, W), K.bilinear(f1[4], H, W)])
-        x2 = K.concat([f2[0], f2[6], K.bilinear(f2[5], H, W), K.bilinear(f2[4], H, W)])
-        in1, in2 = self.pose_auxlayer(x1), self.edge_layer(x2)
-        in3, in4 = self.pose_layer(x1), self.par_layer(x2)
+        in1, in3 = self.pose_auxlayer(x1), self.pose_layer(x1)
+        with on_b():
+            x2 = K.concat([f2[0], f2[6], K.bilinear(f2[5], H, W), K.bilinear(f2[4], H, W)])
+            in2, in4 = self.edge_layer(x2), self.par_layer(x2)
         pose_list, par_list = [], []
 
         def heads(i):
-            edge = self.edge_head[i](in2)
             pose_aux = self.pose_auxnet[i](in1)
             pose_map = self.pose_head[i](in3)
-            par_map = self.par_head[i](in4)
+            with on_b():
+                edge = self.edge_head[i](in2)
+                par_map = self.par_head[i](in4)
             pose_list.append([pose_map, pose_aux])
             par_list.append([par_map, edge])
 
@@ -391,10 +444,17 @@ class Network(nn.Module):
         for i in range(1, self.refine_layers + 1):
             for j in range(3):
                 m = 2 * (i - 1) + j
+                meet(in1, in2, in3, in4)
                 n1, tmp = self.pose_net[m](in1, in3, in4)
-                in2, n4 = self.par_net[m](in2, in3, in4)
+                with on_b():
+                    in2, n4 = self.par_net[m](in2, in3, in4)
                 in1, in3, in4 = n1, tmp, n4
             heads(i)
+        if two:      # the caller's stream owns every output from here on
+            sa.wait_stream(sb)
+            for pair in par_list:
+                for t in pair:
+                    t.record_stream(sa)
         return pose_list, par_list
 
     # -- parameter handling -------------------------------------------------------------------------------

@@ -47,9 +47,24 @@ def pending_of(op, x) -> BnSide:
     return BnSide(op(x))
 
 
+def _is_trivial(op) -> bool:
+    return isinstance(op, (Identity, Zero))
+
+
 def fused_sum(op1, h1, op2, h2):
     """`op1(h1) + op2(h2)` (model_augment.py:54-59) with both BN-applies folded into the add."""
-    a, b = pending_of(op1, h1), pending_of(op2, h2)
+    helper = K.helper_stream() if not (_is_trivial(op1) or _is_trivial(op2)) else None
+    if helper is None:
+        a, b = pending_of(op1, h1), pending_of(op2, h2)
+    else:
+        # the two edges of a node are independent: the second one runs on this stream's helper stream and joins before
+        # the fused add (autograd replays the same fork in backward)
+        cur = torch.cuda.current_stream()
+        helper.wait_stream(cur)
+        with torch.cuda.stream(helper):
+            b = pending_of(op2, h2)
+        a = pending_of(op1, h1)
+        cur.wait_stream(helper)
     if a.bn is None and b.bn is not None:
         a, b = b, a
     training = a.bn.training if a.bn is not None else False

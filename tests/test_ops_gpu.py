@@ -282,3 +282,34 @@ def test_search_supernet_matches_reference():
             assert params[pk].grad is not None, pk
             assert rel_err(_f32(params[pk].grad), g[k]) < 4e-2, pk     # OHEM conditioning, see the tiny-net test
     assert abs(float(net.loss_entropy()) - float(g["entropy"])) < 1e-5
+
+
+def test_two_stream_forward_equals_single_stream(monkeypatch):
+    """The task branches run on two HIP streams (model_augment.Network.forward): outputs and gradients must equal the
+    single-stream run up to the summation order of the statistics / squeeze atomics (a missing cross-stream
+    dependency shows up as a gross difference)."""
+    g = load_golden("tiny_net.npz")
+    dev = _dev()
+    images, _, _, _ = synth_batch(int(g["n"]), int(g["size"]), seed=0)
+    x = torch.from_numpy(images).to(dev)
+    res = {}
+    for mode in ("1", "2"):
+        monkeypatch.setenv("NPP_STREAMS", mode)
+        net = _build_net(int(g["C"]), torch.float32, g).eval()
+        with torch.no_grad():
+            p, q = net(x)
+        ev = [_f32(t) for pair in p + q for t in pair]
+        net.train()
+        p, q = net(x)
+        loss = sum((t.float() ** 2).mean() for pair in p + q for t in pair)
+        net.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (ev, [_f32(t) for pair in p + q for t in pair],
+                     {k: _f32(v.grad) for k, v in net.named_parameters() if v.grad is not None})
+    for a, b in zip(res["1"][0], res["2"][0]):
+        assert rel_err(a, b) < 1e-5       # not bit-equal: the SE squeeze (global average) sums with float atomics
+    for a, b in zip(res["1"][1], res["2"][1]):
+        assert rel_err(a, b) < 1e-5
+    for k, a in res["1"][2].items():
+        assert rel_err(res["2"][2][k], a) < 1e-3 or np.abs(a).max() < 1e-6, k
