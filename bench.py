@@ -139,9 +139,11 @@ def main():
     net = net.to(dev).train()
     crit_pose = Criterion_pose(out_len=2).to(dev)
     crit_par = Criterion_par(out_len=2).to(dev)
-    reducer = GradReducer(net, skip=unused_parameter_names(net), always_reduce=args.force_dist) if use_dist else None
-    params = list(net.parameters()) + list(crit_pose.parameters()) + list(crit_par.parameters())
     use_graph = args.graph != 0      # default: graph for every N (RCCL collectives are captured too; falls back to eager)
+    # under capture every collective is issued on the capture's origin stream (GradReducer overlap=False, _ops.hub_all_reduce)
+    reducer = GradReducer(net, skip=unused_parameter_names(net), always_reduce=args.force_dist,
+                          overlap=not use_graph) if use_dist else None
+    params = list(net.parameters()) + list(crit_pose.parameters()) + list(crit_par.parameters())
     # fused multi-tensor Adam: the capturable foreach path issues ~3000 scalar-math launches per step (13 ms)
     try:
         opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=use_graph)

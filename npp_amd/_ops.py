@@ -64,6 +64,29 @@ class _PerStream:
         return list(self.pools.values())
 
 
+_hub_stream = None     # the stream Network.forward was called on while it runs its branches on two streams
+
+
+def hub_all_reduce(t, group):
+    """SyncBatchNorm exchange.  Every collective of the step is issued on ONE stream (the caller's / the hipGraph
+    capture's origin stream): a branch running on the side stream hands over with an event each way.  One stream per
+    communicator is the topology RCCL-in-hipGraph users run; and the only cross-stream edges this adds to a capture
+    involve its origin stream (see helper_stream for what ROCm 7.0 does otherwise)."""
+    hub = _hub_stream
+    cur = torch.cuda.current_stream() if t.is_cuda else None
+    if hub is None or cur is None or cur.cuda_stream == hub.cuda_stream:
+        dist.all_reduce(t, group=group)
+        return
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    hub.wait_event(ev)
+    with torch.cuda.stream(hub):
+        dist.all_reduce(t, group=group)
+        back = torch.cuda.Event()
+        back.record(hub)
+    cur.wait_event(back)
+
+
 _helper_streams = {}
 _branch_b_streams = set()      # raw handles of the side streams the network runs its second branch on
 _helper_uses = 0
@@ -144,7 +167,7 @@ class _SyncStatsPool(_ZeroPool):
 
     def flush(self):
         if self.waiting:
-            dist.all_reduce(self.buf[self.synced_off:self.off], group=self.group)
+            hub_all_reduce(self.buf[self.synced_off:self.off], self.group)
             for sd in self.waiting:
                 sd.synced_ws = self.ws
             self.waiting = []
@@ -494,7 +517,7 @@ def _presync_stats(sides, training: bool):
         if owner is not None:
             owner.flush()
         else:
-            dist.all_reduce(sd.stats, group=grp)
+            hub_all_reduce(sd.stats, grp)
             sd.synced_ws = ws
 
 
@@ -612,9 +635,9 @@ class _BnAdd(Function):
                 off += 2 * c
             if len(sync) == 2 and sync[0][1] is not sync[1][1]:
                 for i, grp, c in sync:
-                    dist.all_reduce(red[i][0], group=grp)
+                    hub_all_reduce(red[i][0], grp)
             else:
-                dist.all_reduce(tot, group=sync[0][1])
+                hub_all_reduce(tot, sync[0][1])
         # phase 3: coefficients + apply
         outs = []
         for i, (x, bn, mi, ss, batch, count, need_x, need_g, need_b) in enumerate(sides):

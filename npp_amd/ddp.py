@@ -36,7 +36,7 @@ def unused_parameter_names(model: torch.nn.Module) -> Set[str]:
 
 
 class _Bucket:
-    __slots__ = ("params", "offsets", "flat", "pending", "work", "numel")
+    __slots__ = ("params", "offsets", "flat", "pending", "work", "numel", "streams")
 
     def __init__(self, params, device, dtype):
         self.params = params
@@ -49,16 +49,23 @@ class _Bucket:
         self.flat = torch.zeros(off, dtype=dtype, device=device)
         self.pending = len(params)
         self.work = None
+        self.streams = {}      # compute streams the gradients of this bucket were accumulated on (the network runs
+                               # its two task branches, and therefore their backward, on two streams)
 
 
 class GradReducer:
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_mb: float = 32.0,
-                 skip: Optional[Iterable[str]] = None, broadcast_parameters: bool = True, always_reduce: bool = False):
+                 skip: Optional[Iterable[str]] = None, broadcast_parameters: bool = True, always_reduce: bool = False,
+                 overlap: bool = True):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.always = always_reduce      # run the collectives even on a 1-rank group (single-GPU exercise of the path)
+        # overlap=False: the bucket all-reduces are issued by finish() on the caller's stream instead of from the
+        # autograd hooks on a side stream.  Meant for hipGraph capture, where every collective of the step then sits on
+        # the capture's origin stream (the unoverlapped 308 MB all-reduce is ~2 ms on an 8-GPU xGMI node).
+        self.overlap = overlap
         skip = set(skip or ())
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and n not in skip]
         self.skipped = sorted(skip)
@@ -94,15 +101,21 @@ class GradReducer:
     def _on_grad(self, p):
         bi, pi = self._where[p]
         b = self.buckets[bi]
+        if self._cuda:
+            st = torch.cuda.current_stream()
+            b.streams[st.cuda_stream] = st
         b.pending -= 1
-        if b.pending == 0:
+        if b.pending == 0 and self.overlap:
             self._launch(b)
 
     def _launch(self, b: _Bucket):
         if self._cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self._side.wait_event(ev)
+            # fence the side stream behind every stream that accumulated one of this bucket's gradients
+            for st in b.streams.values():
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self._side.wait_event(ev)
+            b.streams = {}
             ctx = torch.cuda.stream(self._side)
         else:
             import contextlib
@@ -125,7 +138,15 @@ class GradReducer:
             if b.work is not None:
                 b.work.wait()
                 b.work = None
-        if self._cuda:
+        if not self.overlap:
+            with torch.no_grad():
+                for b in self.buckets:
+                    views = [b.flat[o:o + p.numel()].view_as(p) for o, p in zip(b.offsets, b.params)]
+                    torch._foreach_copy_(views, [p.grad for p in b.params])
+                    if self.world > 1 or self.always:
+                        dist.all_reduce(b.flat, group=self.group)
+                    b.streams = {}
+        elif self._cuda:
             torch.cuda.current_stream().wait_stream(self._side)
         with torch.no_grad():
             for b in self.buckets:

@@ -364,11 +364,18 @@ class Network(nn.Module):
         # fill 256 CUs (12x12 / 24x24 maps, tile tails) overlap with the other branch's; a captured hipGraph keeps the
         # two-branch structure (tools/graph_concurrency.py) and autograd replays each node's backward on the stream of
         # its forward.
-        two = _two_streams()
+        # SyncBatchNorm across ranks: every collective must sit on one stream (the hipGraph capture's origin; RCCL's own
+        # launch ordering adds two-way edges between the user stream and its internal stream, which this ROCm only
+        # survives on the origin), and funnelling the side branch's ~430 exchanges through it serialises the branches
+        # (measured: 103 ms vs 83 ms).  So multi-rank SyncBN runs single-stream.
+        two = _two_streams() and not self._sync_bn_active()
         K._helper_uses = 0
         if two:
             sa = torch.cuda.current_stream()
             sb = _side_stream(x.device)
+            K._hub_stream = sa       # collectives (SyncBatchNorm) of both branches, forward and backward, go here
+        else:
+            K._hub_stream = None
 
         def on_b():
             return torch.cuda.stream(sb) if two else contextlib.nullcontext()
@@ -456,6 +463,14 @@ class Network(nn.Module):
                 for t in pair:
                     t.record_stream(sa)
         return pose_list, par_list
+
+    def _sync_bn_active(self) -> bool:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        if dist.get_world_size() <= 1 and not K._SYNC_EVEN_ALONE:
+            return False
+        return any(isinstance(m, nn.SyncBatchNorm) for m in self.modules())
 
     # -- parameter handling -------------------------------------------------------------------------------
     def _init_params(self):

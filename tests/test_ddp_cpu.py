@@ -22,7 +22,7 @@ class _Toy(torch.nn.Module):
         return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, overlap=True):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -30,7 +30,7 @@ def _worker(rank, world, port, out):
     from npp_amd.ddp import GradReducer
     torch.manual_seed(123 + rank)          # different init per rank: the reducer must broadcast rank 0's
     m = _Toy()
-    red = GradReducer(m, bucket_mb=0.01, skip={"unused.weight", "unused.bias"})
+    red = GradReducer(m, bucket_mb=0.01, skip={"unused.weight", "unused.bias"}, overlap=overlap)
     assert len(red.buckets) >= 3
     torch.manual_seed(7)
     xs = torch.randn(world * 5, 16)
@@ -46,9 +46,13 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_grad_reducer_matches_single_process(tmp_path):
-    world, port = 2, 29500 + os.getpid() % 1000
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+import pytest
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_grad_reducer_matches_single_process(tmp_path, overlap):
+    world, port = 2, 29500 + os.getpid() % 1000 + (0 if overlap else 1000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
     sd = torch.load(f"{tmp_path}/sd.pt")
     m = _Toy()
     m.load_state_dict(sd)
