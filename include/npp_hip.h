@@ -87,6 +87,14 @@ int npp_pack_weights_batched(const NppPackJob* jobs_dev, int njobs, int64_t tota
  * optional mask: y *= (mask > 0) (ReLU backward when this call is a dgrad). */
 int npp_conv_fwd(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask,
                  NppTensor* y, double* stats, const NppConvGeom* g, void* stream);
+/* The same with caller-owned scratch: small feature maps (12x12, 24x24 at batch 16) give too few output tiles for
+ * 256 CUs, so the stride-1 kernel splits the reduction (taps / channel chunks) over more blocks, writes f32 partial
+ * tiles to `ws` and finishes (bias, mask, rounding, statistics) in a second launch.  npp_conv_fwd_ws_bytes returns
+ * the scratch size for a shape (0 = not needed; only n/h/w/c/ld/dtype of x and y are read).  Without enough scratch
+ * the single-launch path runs. */
+int npp_conv_fwd_ws(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* relu_mask,
+                    NppTensor* y, double* stats, const NppConvGeom* g, void* ws, int64_t ws_bytes, void* stream);
+int64_t npp_conv_fwd_ws_bytes(const NppTensor* x, const NppTensor* y, const NppConvGeom* g);
 /* dw_packed[co][tap*cin_pad + ci] += sum_p dy[p][co] * relu?(x)[src(p,tap)][ci]   (f32 atomics);
  * dw_packed has npp_packed_weight_elems(cout,cin,kh,kw,0) floats, zeroed by the caller. */
 int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw_packed, const NppConvGeom* g,

@@ -46,6 +46,7 @@ _SIGS = {
     "npp_pack_weight": [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
     "npp_pack_weights_batched": [_P, C.c_int, C.c_int64, _P],
     "npp_conv_fwd": [_T, _P, _P, _T, _T, _P, _G, _P],
+    "npp_conv_fwd_ws": [_T, _P, _P, _T, _T, _P, _G, _P, C.c_int64, _P],
     "npp_conv_wgrad": [_T, _T, _P, _G, _P],
     "npp_unpack_wgrad": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
     "npp_dwconv_fwd": [_T, _P, _T, _G, _P],
@@ -91,7 +92,7 @@ _SIGS = {
     "npp_edge_weights": [_P, C.c_int64, _P, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_packed_weight_elems", "npp_reduce_blocks",
-                                 "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed"])
+                                 "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes"])
 
 
 def lib():
@@ -109,6 +110,8 @@ def lib():
         L.npp_packed_weight_elems.argtypes = [C.c_int] * 5
         L.npp_dwconv_bwd_weight_ws.restype = C.c_int64
         L.npp_dwconv_bwd_weight_ws.argtypes = [_T, _G]
+        L.npp_conv_fwd_ws_bytes.restype = C.c_int64
+        L.npp_conv_fwd_ws_bytes.argtypes = [_T, _T, _G]
         L.npp_dwconv_bwd_weight_ws_zeroed.restype = C.c_int
         L.npp_dwconv_bwd_weight_ws_zeroed.argtypes = [_T, _G]
         L.npp_reduce_blocks.restype = C.c_int

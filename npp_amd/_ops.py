@@ -309,6 +309,23 @@ def _conv_out(h, k, s, p, d):
 # --------------------------------------------------------------------------------------------------
 # dense conv (MFMA implicit GEMM)
 # --------------------------------------------------------------------------------------------------
+_conv_ws_cache = {}
+
+
+def _conv_launch(x, wp, bf, mask, y, stats, g, s, what):
+    """npp_conv_fwd with the split-K scratch the library asks for on small feature maps (queried once per shape)."""
+    key = (tuple(x.shape), L.nhwc_ld(x), tuple(y.shape), L.nhwc_ld(y), x.dtype, g.kh, g.kw, g.sh, g.sw,
+           g.ph, g.pw, g.dh, g.dw, g.uph, g.upw)
+    nbytes = _conv_ws_cache.get(key)
+    if nbytes is None:
+        nbytes = _conv_ws_cache[key] = int(lib().npp_conv_fwd_ws_bytes(_byref(x), _byref(y), C.byref(g)))
+    if nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        check(lib().npp_conv_fwd_ws(_byref(x), wp, bf, mask, _byref(y), stats, C.byref(g), ws.data_ptr(), nbytes, s), what)
+    else:
+        check(lib().npp_conv_fwd(_byref(x), wp, bf, mask, _byref(y), stats, C.byref(g), s), what)
+
+
 SHAPE_LOG = None     # tools/shape_prof.py: list of (kind, n, ci, h, w, co, kh, stride, dil) in launch order
 
 
@@ -331,8 +348,7 @@ class _Conv2d(Function):
             bf = bias.detach()
             if bf.dtype != torch.float32:
                 bf = bf.float()
-        check(lib().npp_conv_fwd(_byref(x), wp.data_ptr(), ptr(bf), None, _byref(y), ptr(stats), C.byref(g),
-                                 stream_ptr()), "npp_conv_fwd")
+        _conv_launch(x, wp.data_ptr(), ptr(bf), None, y, ptr(stats), g, stream_ptr(), "npp_conv_fwd")
         if SHAPE_LOG is not None:
             SHAPE_LOG.append(("fwd", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
         ctx.save_for_backward(x, weight)
@@ -361,8 +377,7 @@ class _Conv2d(Function):
             g = geom(kh, kw, 1, 1, dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1], dil[0], dil[1],
                      (stride[0], stride[1]), 0)
             wp = packed_weight(weight, True, x.dtype)
-            check(lib().npp_conv_fwd(_byref(dy), wp.data_ptr(), None, _byref(x) if relu_in else None, _byref(dx), None,
-                                     C.byref(g), s), "npp_conv_fwd(dgrad)")
+            _conv_launch(dy, wp.data_ptr(), None, _byref(x) if relu_in else None, dx, None, g, s, "npp_conv_fwd(dgrad)")
             if SHAPE_LOG is not None:
                 SHAPE_LOG.append(("dgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
         if ctx.needs_input_grad[1]:

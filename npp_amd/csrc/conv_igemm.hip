@@ -357,8 +357,32 @@ extern "C" int npp_pack_weight(const float* w, int cout, int cin, int kh, int kw
   return npp_check_launch("pack_weight");
 }
 
+static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask, NppTensor* y,
+                         double* stats, const NppConvGeom* g, void* ws, size_t ws_bytes, void* stream, size_t* ws_query);
+
 extern "C" int npp_conv_fwd(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask,
                             NppTensor* y, double* stats, const NppConvGeom* g, void* stream) {
+  return conv_fwd_impl(x, w_packed, bias, mask, y, stats, g, nullptr, 0, stream, nullptr);
+}
+
+extern "C" int npp_conv_fwd_ws(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask,
+                               NppTensor* y, double* stats, const NppConvGeom* g, void* ws, int64_t ws_bytes, void* stream) {
+  return conv_fwd_impl(x, w_packed, bias, mask, y, stats, g, ws, ws_bytes > 0 ? (size_t)ws_bytes : 0, stream, nullptr);
+}
+
+extern "C" int64_t npp_conv_fwd_ws_bytes(const NppTensor* x, const NppTensor* y, const NppConvGeom* g) {
+  if (!x || !y || !g) return 0;
+  size_t q = 0;
+  NppTensor xx = *x, yy = *y;
+  if (!xx.ptr) xx.ptr = reinterpret_cast<void*>(16);      // shapes only: nothing is dereferenced or launched
+  if (!yy.ptr) yy.ptr = reinterpret_cast<void*>(16);
+  if (conv_fwd_impl(&xx, reinterpret_cast<const void*>(16), nullptr, nullptr, &yy, nullptr, g, nullptr, 0, nullptr, &q) != NPP_OK)
+    return 0;
+  return (int64_t)q;
+}
+
+static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask, NppTensor* y,
+                         double* stats, const NppConvGeom* g, void* ws, size_t ws_bytes, void* stream, size_t* ws_query) {
   NPP_REQUIRE(x && w_packed && y && g && x->ptr && y->ptr, NPP_E_NULL, "npp_conv_fwd: null pointer");
   NPP_REQUIRE(x->dtype == y->dtype && (!mask || mask->dtype == y->dtype), NPP_E_DTYPE,
               "npp_conv_fwd: x/y/mask dtypes must match (%d,%d)", x->dtype, y->dtype);
@@ -397,12 +421,16 @@ extern "C" int npp_conv_fwd(const NppTensor* x, const void* w_packed, const floa
   p.mtiles = (p.M + BM - 1) / BM;
   p.ntiles = npad / bn;
   const int grid = p.mtiles * p.ntiles;
+  if (ws_query) {
+    *ws_query = conv_s1_ws_bytes(p, x->dtype);
+    return NPP_OK;
+  }
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * (double)M * p.Cout * (double)(g->kh * g->kw) * p.Cin;
   const double bytes = ((double)x->n * x->h * x->w * x->c + (double)M * y->c + (double)p.Cout * g->kh * g->kw * p.Cin) * esize(x->dtype);
   {
     ProfScope prof1(NPP_FAM_CONV_S1, x->dtype, s, flops, bytes);
-    if (conv_s1_launch(p, x->dtype, s)) return npp_check_launch("conv_s1");
+    if (conv_s1_launch(p, x->dtype, s, ws, ws_bytes)) return npp_check_launch("conv_s1");
     prof1.cancel();    // not taken: the generic kernel below is a different family
   }
   ProfScope prof(NPP_FAM_CONV_IGEMM, x->dtype, s, flops, bytes);

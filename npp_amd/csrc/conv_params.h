@@ -10,4 +10,6 @@ struct IgemmParams {
   int vec_io;
 };
 // stride-1 "same" convolution fast path (conv_s1.hip); returns false when the shape is not eligible
-bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream);
+bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream, void* ws, size_t ws_bytes);
+// bytes of caller-owned scratch the fast path wants for this shape (split-K partial tiles); 0 = none
+size_t conv_s1_ws_bytes(const IgemmParams& p, int dtype);

@@ -47,17 +47,37 @@ template <> NPP_DEV void mma_frag_s<float>(f32x16& acc, u32x4 a, u32x4 b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. it waits for the global
+// loads of the NEXT stages that were issued precisely so that they could fly across this barrier; their consumers
+// (the LDS stores one stage later) get the compiler's counted vmcnt(N) instead.
+NPP_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct S1Extra {
   int P, halo, AR, apt, nchunks, taps;
   int Wp, Hp;  // gapped row length / rows per image
   long Mp;     // gapped pixel count
   int abufs;   // 2: A footprint double buffered (1x1: a new footprint every stage); 1: single buffer (KxK: one per K*K stages)
   long NHW;
+  int boff;  // DMA path: byte offset of the 4 weight buffers in LDS (past the footprint AND the epilogue's C tile)
   int dbg;   // timing experiments only (NPP_S1_DBG): 1 = skip the main loop, 2 = skip the epilogue stores, 4 = no stats
+  // split-K (small feature maps: too few output tiles for 256 CUs): tile index = (m, n, split); a KxK conv splits its
+  // taps (split s owns taps [s*taps, (s+1)*taps) of every chunk), a 1x1 conv its chunks; partial tiles go to
+  // ws[split][gapped pixel][padded channel] in f32 and conv_s1_finish_kernel does the real epilogue.
+  int splits, split_taps;
+  float* ws;
+  long ws_rows;  // mtiles * BM
+  int ws_cols;   // ntiles * BN
 };
 
-template <typename T, int BM, int BN, int KCB>
-__global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_kernel(IgemmParams p, S1Extra e) {
+// DMAB: the weight tiles of a KxK conv travel HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of 4 buffers,
+// three stages ahead, tracked with counted vmcnt: a register-staged tile issued ONE stage ahead (the other path) makes
+// every stage wait out a full global-load latency (~1 us against ~0.4 us of MFMA work).  Rows are 128 bytes, unpadded
+// (the DMA writes 1 KiB per wave instruction, lane-linear), with the 16-byte pieces XOR-swizzled by (row & 7) on the
+// SOURCE address and on the fragment read (cdna_hip_programming.md rule 21).
+// WM = output rows per wave (64 or 128).  A 64 x 64 wave tile reads one 1-KiB fragment per MFMA (2 A + 2 B per 4), which
+// makes the CU's LDS bandwidth (128 B/clk) as busy as its four MFMA pipes; 128 x 64 reads 6 per 8.
+template <typename T, int BM, int BN, int KCB, bool DMAB = false, int WM = 64>
+__global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_kernel(IgemmParams p, S1Extra e) {
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int KC = KCB / (int)sizeof(T);       // channels per chunk
   constexpr int PITCH = KCB + 16;
@@ -67,19 +87,23 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
   constexpr int WAVES_N = BN >= 128 ? 2 : 1;
   constexpr int WN = BN / WAVES_N;               // 64, 64, 32
   constexpr int NI = WN / 32;
-  constexpr int NT = (BM / 64) * WAVES_N * 64;
+  constexpr int NT = (BM / WM) * WAVES_N * 64;
+  constexpr int MI = WM / 32;
   constexpr int BPT = (BN * PPR + NT - 1) / NT;  // B pieces per thread per stage
-  constexpr int APT_MAX = (BM == 256 && BN == 128) ? 8 : 12;
+  constexpr int APT_MAX = WM == 128 ? 16 : ((BM == 256 && BN == 128) ? 8 : 12);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int asz = e.AR * PITCH;
   unsigned char* const sA0 = smem;
-  unsigned char* const sB0 = smem + e.abufs * asz;
+  unsigned char* const sB0 = smem + (DMAB ? e.boff : e.abufs * asz);
+  constexpr int DTILE = BN * 128;                          // DMA path: unpadded 128-byte rows
+  constexpr int DPW = DMAB ? (DTILE / 1024) / (NT / 64) : 1;   // 1-KiB DMA instructions per wave per stage
+  static_assert(!DMAB || (KCB == 128 && (DTILE / 1024) % (NT / 64) == 0), "DMA path: 128-byte rows, whole instructions per wave");
 
   const int t = threadIdx.x;
   const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
   const int img = e.Hp * e.Wp;
-  const int total_tiles = p.mtiles * p.ntiles;
+  const int total_tiles = p.mtiles * p.ntiles * e.splits;
 
   // ---- staging roles (recomputed per tile) -------------------------------------------------------------
   const T* asrc[APT_MAX];
@@ -98,9 +122,16 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
   }
   // XCD-aware tile order (cdna_hip_programming.md T1): the tiles of one XCD's blocks are contiguous, N-tile
   // fastest, so the blocks that re-read one input footprint share an L2.
+  int split = 0, tap0 = 0, chunk0 = 0;
   auto tile_coords = [&](int tile, long& q0, int& n0) {
     const int xcd = tile & 7, qd = total_tiles >> 3, rm = total_tiles & 7;
-    const int lid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (tile >> 3);
+    int lid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (tile >> 3);
+    if (e.splits > 1) {
+      split = lid % e.splits;
+      lid /= e.splits;
+      tap0 = e.split_taps ? split * e.taps : 0;
+      chunk0 = e.split_taps ? 0 : split * e.nchunks;
+    }
     q0 = (long)(lid / p.ntiles) * BM;
     n0 = (lid % p.ntiles) * BN;
   };
@@ -133,7 +164,7 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
 #pragma unroll
     for (int i = 0; i < APT_MAX; ++i) {
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (asrc[i]) v = *reinterpret_cast<const u32x4*>(asrc[i] + (long)chunk * KC);
+      if (asrc[i]) v = *reinterpret_cast<const u32x4*>(asrc[i] + (long)(chunk0 + chunk) * KC);
       ra[i] = v;   // ReLU is applied at store_A: touching the value here would wait for the load
     }
   };
@@ -144,7 +175,7 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
       if (adst[i] >= 0) *reinterpret_cast<u32x4*>(d + adst[i]) = p.relu_in ? relu16s<T>(ra[i]) : ra[i];
   };
   auto load_B = [&](int chunk, int tap) {
-    const long koff = (long)tap * p.Cp + (long)chunk * KC;
+    const long koff = (long)(tap0 + tap) * p.Cp + (long)(chunk0 + chunk) * KC;
 #pragma unroll
     for (int i = 0; i < BPT; ++i)
       if (bdst[i] >= 0) rb[i] = *reinterpret_cast<const u32x4*>(bsrc[i] + koff);
@@ -156,12 +187,31 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
       if (bdst[i] >= 0) *reinterpret_cast<u32x4*>(d + bdst[i]) = rb[i];
   };
 
+  // DMA path: wave w issues instructions i = 0..DPW-1 of a stage; instruction (w, i) fills rows [8*(w*DPW+i), +8)
+  const int dl = t & 63, dw = t >> 6;
+  const int dsrc_piece = (dl & 7) ^ (dl >> 3);            // source piece of the row this lane's LDS slot belongs to
+  auto dma_B = [&](int chunk, int tap, int buf, int n0_) {
+    if constexpr (DMAB) {
+      const long koff = (long)(tap0 + tap) * p.Cp + (long)(chunk0 + chunk) * KC;
+#pragma unroll
+      for (int i = 0; i < DPW; ++i) {
+        const int pb = dw * DPW + i;
+        const T* src = wg + (long)(n0_ + pb * 8 + (dl >> 3)) * p.Kpad + koff + dsrc_piece * VEC;
+        // wave-uniform LDS byte address (readfirstlane: the compiler only sees a per-thread value)
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(sB0 + buf * DTILE + pb * 1024));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+      }
+    }
+  };
+
   // ---- compute roles ------------------------------------------------------------------------------
   const int wave = t >> 6, lane = t & 63;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int r = lane & 31, h = lane >> 5;
   const int boff = (wn * WN + r) * PITCH + h * 16;      // + ni*32*PITCH + ks*32 as immediates
-  const int aoff = (wm * 64 + r) * PITCH + h * 16;      // + tap offset + mi*32*PITCH + ks*32
+  const int aoff = (wm * WM + r) * PITCH + h * 16;      // + tap offset + mi*32*PITCH + ks*32
   constexpr int CP = BN + 4;
   float* sC = reinterpret_cast<float*>(smem);
   constexpr int PCOLS = BN / VEC;
@@ -177,11 +227,17 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
   tile_coords(tile, q0, n0);
   setup_roles(q0, n0);
   load_A(0);
-  load_B(0, 0);
+  if constexpr (DMAB) {
+    // stages 0..2 of the first tile (stage s = chunk s / taps, tap s % taps)
+    for (int s = 0; s < 3 && s < nstages; ++s) dma_B(s / e.taps, s % e.taps, s, n0);
+  } else {
+    load_B(0, 0);
+  }
+  const int bsw = ((lane >> 5) ^ (lane & 7)) << 4;        // DMA path: per-lane swizzle of the fragment's piece
   while (true) {
-    f32x16 acc[2][NI];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -192,11 +248,52 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
     c2 = c1; t2 = t1 + 1;
     if (t2 == e.taps) { t2 = 0; ++c2; }
 
+    if constexpr (DMAB) {
+      int c3 = c2, t3 = t2 + 1;                         // stage s + 3
+      if (t3 == e.taps) { t3 = 0; ++c3; }
+      store_A(0);
+      for (int s = 0; s < nstages; ++s) {
+        const bool has1 = s + 1 < nstages;
+        // the DMA of stage s was followed by those of s+1 and s+2 (DPW instructions each): at most that many may still
+        // be in flight.  After the barrier every wave's pieces of stage s are in LDS and nobody reads buffer (s-1)&3.
+        if (s + 2 < nstages) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DPW) : "memory");
+        else if (has1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (s + 3 < nstages) dma_B(c3, t3, (s + 3) & 3, n0);
+        const bool fetch_fp = (t0 == 0) && (c0 + 1 < e.nchunks);   // next chunk's footprint (register staged: ReLU)
+        if (fetch_fp) load_A(c0 + 1);
+
+        const int kh = (tap0 + t0) / p.KW, kw = (tap0 + t0) - kh * p.KW;
+        const int off = e.halo + (kh - e.P) * e.Wp + (kw - e.P);
+        const unsigned char* a = sA0 + off * PITCH + aoff;
+        const unsigned char* b = sB0 + (s & 3) * DTILE + (wn * WN + r) * 128;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          u32x4 fa[MI], fb[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) fa[mi] = *reinterpret_cast<const u32x4*>(a + mi * 32 * PITCH + ks * 32);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(b + ni * 32 * 128 + ((ks * 32) ^ bsw));
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) mma_frag_s<T>(acc[mi][ni], fa[mi], fb[ni]);
+        }
+        if (has1 && t1 == 0) {
+          lds_barrier();          // every wave is done with this chunk's footprint
+          store_A(0);             // published by the barrier that opens the next stage
+        }
+        c0 = c1; t0 = t1; c1 = c2; t1 = t2; c2 = c3; t2 = t3;
+        if (++t3 == e.taps) { t3 = 0; ++c3; }
+      }
+      lds_barrier();              // all fragment reads done: the ring and the footprint may be overwritten
+    } else {
     store_A(0);
     store_B(0);
     if (nstages > 1) load_B(c1, t1);                    // in flight during stage 0
     if (e.abufs == 2 && nstages > 1) load_A(1);
-    __syncthreads();
+    lds_barrier();
 
     for (int s = 0; s < nstages; ++s) {
       const bool has1 = s + 1 < nstages, has2 = s + 2 < nstages;
@@ -213,41 +310,47 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
       const bool fetch_fp = (e.abufs == 1) && (t0 == 0) && (c0 + 1 < e.nchunks);   // KxK: next chunk's footprint
       if (fetch_fp) load_A(c0 + 1);
 
-      const int kh = t0 / p.KW, kw = t0 - kh * p.KW;
+      const int kh = (tap0 + t0) / p.KW, kw = (tap0 + t0) - kh * p.KW;
       const int off = e.halo + (kh - e.P) * e.Wp + (kw - e.P);
       const unsigned char* a = sA0 + ((c0 & 1) & (e.abufs - 1)) * asz + off * PITCH + aoff;
       const unsigned char* b = sB0 + (s & 1) * BTILE + boff;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        u32x4 fa[2], fb[NI];
+        u32x4 fa[MI], fb[NI];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) fa[mi] = *reinterpret_cast<const u32x4*>(a + mi * 32 * PITCH + ks * 32);
+        for (int mi = 0; mi < MI; ++mi) fa[mi] = *reinterpret_cast<const u32x4*>(a + mi * 32 * PITCH + ks * 32);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(b + ni * 32 * PITCH + ks * 32);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) mma_frag_s<T>(acc[mi][ni], fa[mi], fb[ni]);
       }
       if (e.abufs == 1 && has1 && t1 == 0) {
-        __syncthreads();          // every wave is done with this chunk's footprint
+        lds_barrier();          // every wave is done with this chunk's footprint
         store_A(0);
       }
-      __syncthreads();
+      lds_barrier();
       c0 = c1; t0 = t1; c1 = c2; t1 = t2;
       if (++t2 == e.taps) { t2 = 0; ++c2; }
+    }
     }
 
     // ---- prefetch the next tile's first stage (lands during the epilogue) ----------------------------------
     const long q0c = q0;
     const int n0c = n0;
+    const int splitc = split;
     const int next = tile + gridDim.x;
     const bool more = next < total_tiles;
     if (more) {
       tile_coords(next, q0, n0);
       setup_roles(q0, n0);
       load_A(0);
-      load_B(0, 0);
+      if constexpr (DMAB) {
+        for (int s = 0; s < 3 && s < nstages; ++s) dma_B(s / e.taps, s % e.taps, s, n0);
+      } else {
+        load_B(0, 0);
+      }
     }
 
     // ---- epilogue: rounds of 128 rows through an LDS C tile -------------------------------------------------
@@ -261,20 +364,29 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
     const bool full_vec = p.vec_io && (nbase + VEC <= p.Cout);
     constexpr int ROUNDS = BM / 128;
     for (int rd = 0; rd < ((e.dbg & 2) ? 0 : ROUNDS); ++rd) {
-      if (rd > 0) __syncthreads();
-      if ((wm >> 1) == rd) {
+      if (rd > 0) lds_barrier();
+      if ((wm * WM) / 128 == rd) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int el = 0; el < 16; ++el) {
-              const int row = (wm & 1) * 64 + mi * 32 + (el & 3) + 8 * (el >> 2) + 4 * h;
+              const int row = (wm * WM) % 128 + mi * 32 + (el & 3) + 8 * (el >> 2) + 4 * h;
               const int col = wn * WN + ni * 32 + r;
               sC[row * CP + col] = acc[mi][ni][el];
             }
       }
-      __syncthreads();
+      lds_barrier();
+      if (e.splits > 1) {
+        float* wsp = e.ws + ((long)splitc * e.ws_rows + q0c + rd * 128) * e.ws_cols + n0c + pc * VEC;
+        for (int row = pr; row < 128; row += RSTEP) {
+#pragma unroll
+          for (int j = 0; j < VEC; j += 4)
+            *reinterpret_cast<f32x4*>(wsp + (long)row * e.ws_cols + j) = *reinterpret_cast<const f32x4*>(&sC[row * CP + pc * VEC + j]);
+        }
+        continue;
+      }
       int dn = 0, dy = 0, dx = 0;
       if (e.P) {
         const int qs = (int)q0c + rd * 128 + pr;
@@ -327,15 +439,15 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
         }
       }
     }
-    if (p.stats && !(e.dbg & 4)) {
-      __syncthreads();
+    if (p.stats && !(e.dbg & 4) && e.splits == 1) {
+      lds_barrier();
       float* red = reinterpret_cast<float*>(smem);  // [NT][VEC][2]
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         red[(t * VEC + j) * 2 + 0] = bsum[j];
         red[(t * VEC + j) * 2 + 1] = bsq[j];
       }
-      __syncthreads();
+      lds_barrier();
       if (t < BN) {
         const int col = t, cpc = col / VEC, j = col % VEC;
         float sm = 0.f, sq = 0.f;
@@ -353,7 +465,95 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
     }
     if (!more) break;
     tile = next;
-    __syncthreads();   // the epilogue's LDS reads are done before the next tile's staging overwrites it
+    lds_barrier();   // the epilogue's LDS reads are done before the next tile's staging overwrites it
+  }
+}
+
+// Epilogue of a split-K launch: y = round(sum_splits ws + bias) (* mask), BN statistics of the rounded values.
+// One thread per (pixel lane, 16-byte channel vector); a block covers PPB consecutive real pixels.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_s1_finish_kernel(IgemmParams p, S1Extra e, int ppb) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  __shared__ float red[256 * VEC * 2];
+  const int t = threadIdx.x;
+  const int pcols = (p.Cout + VEC - 1) / VEC;          // <= 256 (host checks)
+  const int rows = 256 / pcols;
+  const int pc = t % pcols, pr = t / pcols;
+  const bool active = pr < rows;
+  const int nbase = pc * VEC;
+  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+  const T* __restrict__ mg = reinterpret_cast<const T*>(p.mask);
+  float bsum[VEC], bsq[VEC], bias[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    bsum[j] = 0.f; bsq[j] = 0.f;
+    bias[j] = (p.bias && nbase + j < p.Cout) ? p.bias[nbase + j] : 0.f;
+  }
+  const bool full_vec = p.vec_io && (nbase + VEC <= p.Cout);
+  const long m_end = min((long)(blockIdx.x + 1) * ppb, e.NHW);
+  if (active) {
+    for (long m = (long)blockIdx.x * ppb + pr; m < m_end; m += rows) {
+      const int x = (int)(m % p.W);
+      const long tq = m / p.W;
+      const int y = (int)(tq % p.H), n = (int)(tq / p.H);
+      const long q = ((long)n * e.Hp + y) * e.Wp + x;
+      float v[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = bias[j];
+      for (int sp = 0; sp < e.splits; ++sp) {
+        const float* src = e.ws + ((long)sp * e.ws_rows + q) * e.ws_cols + nbase;
+#pragma unroll
+        for (int j = 0; j < VEC; j += 4) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(src + j);
+          v[j] += a[0]; v[j + 1] += a[1]; v[j + 2] += a[2]; v[j + 3] += a[3];
+        }
+      }
+      if (full_vec) {
+        if (mg) {
+          float mk[VEC];
+          Vec16<T>::load(mg + m * p.ldm + nbase, mk);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] = mk[j] > 0.f ? v[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          v[j] = Elt<T>::round(v[j]);
+          bsum[j] += v[j];
+          bsq[j] += v[j] * v[j];
+        }
+        Vec16<T>::store(yg + m * p.ldy + nbase, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          if (nbase + j < p.Cout) {
+            if (mg && !(Elt<T>::ld(mg + m * p.ldm + nbase + j) > 0.f)) v[j] = 0.f;
+            v[j] = Elt<T>::round(v[j]);
+            bsum[j] += v[j];
+            bsq[j] += v[j] * v[j];
+            Elt<T>::st(yg + m * p.ldy + nbase + j, v[j]);
+          }
+        }
+      }
+    }
+  }
+  if (!p.stats) return;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    red[(t * VEC + j) * 2 + 0] = active ? bsum[j] : 0.f;
+    red[(t * VEC + j) * 2 + 1] = active ? bsq[j] : 0.f;
+  }
+  __syncthreads();
+  for (int col = t; col < p.Cout; col += 256) {
+    const int cpc = col / VEC, j = col % VEC;
+    float sm = 0.f, sq = 0.f;
+    for (int rr = 0; rr < rows; ++rr) {
+      const int tt = rr * pcols + cpc;
+      sm += red[(tt * VEC + j) * 2 + 0];
+      sq += red[(tt * VEC + j) * 2 + 1];
+    }
+    double* st = p.stats + (long)(blockIdx.x % NPP_STAT_REPLICAS) * 2 * p.Cout;
+    atomicAdd(st + col, (double)sm);
+    atomicAdd(st + p.Cout + col, (double)sq);
   }
 }
 
@@ -372,7 +572,15 @@ bool raise_lds(K kernel, size_t bytes) {
 
 }  // namespace
 
-bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
+namespace {
+struct S1Plan {
+  int kcb, bn, bm, P, halo, abufs, npad, mtiles, ntiles, splits, split_taps;
+  long Mp, NHW;
+  size_t ws_bytes;
+};
+
+// shape eligibility + tile / split choice, shared by the launcher and the workspace query
+bool s1_plan(const IgemmParams& p, int dtype, S1Plan& pl) {
   static const bool disabled = getenv("NPP_DISABLE_S1") != nullptr;
   if (disabled) return false;
   const int es = dtype == NPP_BF16 ? 2 : 4;
@@ -395,7 +603,6 @@ bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   const int pitch = kcb + 16;
   const int Wp = p.W + P, Hp = p.H + P;
   const int halo = P * Wp + P;
-  const long NHW = (long)p.N * p.H * p.W;
   const long Mp = (long)p.N * Hp * Wp;
   const int abufs = (p.KH * p.KW == 1) ? 2 : 1;
   auto lds_for = [&](int bm_) { return (size_t)abufs * (bm_ + 2 * halo) * pitch + (size_t)2 * bn * pitch; };
@@ -407,20 +614,86 @@ bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   int bm = bm_big;
   if (Mp < (long)bm_big * 200 || lds_for(bm_big) > cap || force_bm == 128) bm = bm_small;
   if (lds_for(bm) > cap) return false;
+  pl.kcb = kcb; pl.bn = bn; pl.bm = bm; pl.P = P; pl.halo = halo; pl.abufs = abufs; pl.npad = npad;
+  pl.Mp = Mp; pl.NHW = (long)p.N * p.H * p.W;
+  pl.mtiles = (int)((Mp + bm - 1) / bm);
+  pl.ntiles = npad / bn;
+  // split-K: few tiles and a deep reduction.  KxK convs split their taps, 1x1 convs their channel chunks; the number
+  // of splits is the smallest divisor that brings the grid to >= 96 blocks.
+  pl.splits = 1; pl.split_taps = 0; pl.ws_bytes = 0;
+  static const bool nosplit = getenv("NPP_S1_NOSPLIT") != nullptr;
+  const int tiles = pl.mtiles * pl.ntiles;
+  const int taps = p.KH * p.KW, nchunks = p.Cin / kc;
+  if (!nosplit && tiles <= 64 && taps * nchunks >= 6 && (p.Cout + (16 / es) - 1) / (16 / es) <= 256) {
+    const int dim = taps > 1 ? taps : nchunks;
+    int best = 1;
+    for (int d = 2; d <= dim && d <= 9; ++d) {
+      if (dim % d) continue;
+      if ((taps > 1 ? nchunks * (taps / d) : nchunks / d) < 2) break;     // keep >= 2 stages per block
+      best = d;
+      if (tiles * d >= 96) break;
+    }
+    if (best > 1) {
+      pl.splits = best;
+      pl.split_taps = taps > 1 ? 1 : 0;
+      pl.ws_bytes = (size_t)best * pl.mtiles * bm * (size_t)pl.ntiles * bn * sizeof(float);
+    }
+  }
+  return true;
+}
+}  // namespace
+
+size_t conv_s1_ws_bytes(const IgemmParams& p, int dtype) {
+  S1Plan pl;
+  return s1_plan(p, dtype, pl) ? pl.ws_bytes : 0;
+}
+
+bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream, void* ws, size_t ws_bytes) {
+  S1Plan pl;
+  if (!s1_plan(p, dtype, pl)) return false;
+  if (pl.splits > 1 && (!ws || ws_bytes < pl.ws_bytes || ((uintptr_t)ws & 15))) { pl.splits = 1; pl.split_taps = 0; }
+  const int es = dtype == NPP_BF16 ? 2 : 4;
+  const int kcb = pl.kcb, bn = pl.bn, bm = pl.bm, P = pl.P, halo = pl.halo, abufs = pl.abufs, npad = pl.npad;
+  const int kc = kcb / es;
+  const int pitch = kcb + 16;
+  const int Wp = p.W + P, Hp = p.H + P;
+  const long Mp = pl.Mp, NHW = pl.NHW;
+  auto lds_for = [&](int bm_) { return (size_t)abufs * (bm_ + 2 * halo) * pitch + (size_t)2 * bn * pitch; };
   S1Extra e;
   static const int dbg = getenv("NPP_S1_DBG") ? atoi(getenv("NPP_S1_DBG")) : 0;
   e.dbg = dbg;
   e.abufs = abufs;
   e.Wp = Wp; e.Hp = Hp; e.Mp = Mp;
   e.P = P; e.halo = halo; e.AR = bm + 2 * halo; e.nchunks = p.Cin / kc; e.taps = p.KH * p.KW; e.NHW = NHW;
-  const int nt = (bm / 64) * (bn >= 128 ? 2 : 1) * 64;
+  e.splits = pl.splits; e.split_taps = pl.split_taps; e.ws = reinterpret_cast<float*>(ws);
+  e.ws_rows = (long)pl.mtiles * bm; e.ws_cols = pl.ntiles * bn;
+  if (e.splits > 1) {
+    if (e.split_taps) e.taps /= e.splits; else e.nchunks /= e.splits;
+  }
+  static const bool wm128_env = getenv("NPP_S1_WM128") != nullptr;
+  const bool wm128 = wm128_env && bm == 256 && bn == 128 && kcb == 128 && abufs == 1;
+  const int nt = wm128 ? 256 : (bm / 64) * (bn >= 128 ? 2 : 1) * 64;
   const int ppr = kcb / 16;
   e.apt = (e.AR * ppr + nt - 1) / nt;
-  if (e.apt > ((bm == 256 && bn == 128) ? 8 : 12)) return false;
+  if (e.apt > (wm128 ? 16 : ((bm == 256 && bn == 128) ? 8 : 12))) return false;
   size_t lds = lds_for(bm);
   const size_t epi = (size_t)128 * (bn + 4) * 4, red = (size_t)nt * 8 * 2 * 4;
   if (lds < epi) lds = epi;
   if (lds < red) lds = red;
+  // weight tiles by LDS-DMA (KxK convs, 128-byte K chunks, 128-wide tiles): ring of 4 buffers past footprint / C tile
+  // (measured on 128->128 3x3 @96^2: 99 us with the DMA ring vs 87 us register-staged -- the stage time is not set by
+  // the weight loads' latency -- so the ring is opt-in: NPP_S1_DMA=1; NPP_S1_WM128=1 adds the 128 x 64 wave tile)
+  static const bool usedma = getenv("NPP_S1_DMA") != nullptr || getenv("NPP_S1_WM128") != nullptr;
+  bool dma = usedma && abufs == 1 && kcb == 128 && bn == 128;
+  e.boff = 0;
+  if (dma) {
+    size_t boff = (size_t)e.AR * pitch;
+    if (boff < epi) boff = epi;
+    if (boff < red) boff = red;
+    boff = (boff + 1023) / 1024 * 1024;
+    const size_t need = boff + (size_t)4 * bn * 128;
+    if (need <= 160 * 1024) { e.boff = (int)boff; lds = need; } else dma = false;
+  }
   IgemmParams q = p;
   q.mtiles = (int)((Mp + bm - 1) / bm);
   q.ntiles = npad / bn;
@@ -434,16 +707,28 @@ bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
     }
     ncu = cached;
   }
-  const int tiles = q.mtiles * q.ntiles;
+  const int tiles = q.mtiles * q.ntiles * e.splits;
   const int grid = tiles < ncu ? tiles : ncu;   // persistent: one block per CU walks tiles b, b+grid, ...
 #define LAUNCH(T, BM_, BN_, KCB_)                                                                   \
   do {                                                                                              \
     if (!raise_lds(conv_s1_kernel<T, BM_, BN_, KCB_>, lds)) return false;                           \
     hipLaunchKernelGGL((conv_s1_kernel<T, BM_, BN_, KCB_>), dim3(grid), dim3(nt), lds, stream, q, e); \
   } while (0)
+#define LAUNCHD(T, BM_)                                                                             \
+  do {                                                                                              \
+    if (!raise_lds(conv_s1_kernel<T, BM_, 128, 128, true>, lds)) return false;                      \
+    hipLaunchKernelGGL((conv_s1_kernel<T, BM_, 128, 128, true>), dim3(grid), dim3(nt), lds, stream, q, e); \
+  } while (0)
+#define LAUNCHW(T)                                                                                  \
+  do {                                                                                              \
+    if (!raise_lds(conv_s1_kernel<T, 256, 128, 128, true, 128>, lds)) return false;                 \
+    hipLaunchKernelGGL((conv_s1_kernel<T, 256, 128, 128, true, 128>), dim3(grid), dim3(256), lds, stream, q, e); \
+  } while (0)
 #define PICK(T)                                                                                     \
   do {                                                                                              \
-    if (bn == 128) {                                                                                \
+    if (dma) {                                                                                      \
+      if (bm == 256 && wm128) LAUNCHW(T); else if (bm == 256) LAUNCHD(T, 256); else LAUNCHD(T, 128);  \
+    } else if (bn == 128) {                                                                         \
       if (kcb == 128) { if (bm == 256) LAUNCH(T, 256, 128, 128); else LAUNCH(T, 128, 128, 128); }    \
       else            { if (bm == 256) LAUNCH(T, 256, 128, 64);  else LAUNCH(T, 128, 128, 64); }     \
     } else if (bn == 64) {                                                                          \
@@ -457,5 +742,13 @@ bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (dtype == NPP_BF16) PICK(bf16_t); else PICK(float);
 #undef PICK
 #undef LAUNCH
+#undef LAUNCHD
+#undef LAUNCHW
+  if (e.splits > 1) {
+    const int ppb = 16;
+    const int fgrid = (int)((NHW + ppb - 1) / ppb);
+    if (dtype == NPP_BF16) hipLaunchKernelGGL((conv_s1_finish_kernel<bf16_t>), dim3(fgrid), dim3(256), 0, stream, q, e, ppb);
+    else hipLaunchKernelGGL((conv_s1_finish_kernel<float>), dim3(fgrid), dim3(256), 0, stream, q, e, ppb);
+  }
   return true;
 }

@@ -9,10 +9,12 @@ from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 FWD_K = ("conv_s1_kernel", "conv_igemm_kernel")
+FIN_K = "conv_s1_finish_kernel"
 WG_K = ("wgrad_tap_kernel", "conv_wgrad_kernel")
 
 
 def run(path, steps=3):
+    os.environ["NPP_STREAMS"] = "1"      # launch order == execution order: the join pairs records with trace rows
     import torch
     import bench
     from npp_amd import _ops as K
@@ -43,15 +45,27 @@ def run(path, steps=3):
 def join(log_path, trace_path):
     d = json.load(open(log_path))
     log = d["log"]
-    rows = []
+    rows, fins = [], []
     with open(trace_path) as f:
         for r in csv.DictReader(f):
             nm = r["Kernel_Name"]
             kind = "f" if any(k in nm for k in FWD_K) else ("w" if any(k in nm for k in WG_K) else None)
+            if FIN_K in nm:               # split-K second launch: its time belongs to the conv launched just before
+                fins.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+                continue
             if kind:
                 rows.append((int(r["Start_Timestamp"]), kind, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                              nm.split("<")[0].split("::")[-1] + "<" + nm.split("<")[1].split(">")[0].replace("unsigned short, ", "") + ">"))
     rows.sort()
+    import bisect
+    starts = [r[0] for r in rows]
+    for ts, dur in fins:
+        i = bisect.bisect_right(starts, ts) - 1
+        while i >= 0 and rows[i][1] != "f":
+            i -= 1
+        if i >= 0:
+            r0 = rows[i]
+            rows[i] = (r0[0], r0[1], r0[2] + dur, r0[3] + "+finish")
     fq = [r for r in rows if r[1] == "f"]
     wq = [r for r in rows if r[1] == "w"]
     lf = [l for l in log if l[0] in ("fwd", "dgrad")]
