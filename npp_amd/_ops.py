@@ -385,7 +385,7 @@ class _Conv2d(Function):
             g = geom(kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 1, relu_in)
             if kh == 1 and kw == 1 and ci % 64 == 0 and co % 32 == 0:
                 # packed [co][ci] == OIHW: accumulate straight into the gradient tensor
-                dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+                dw = zeros_f32(weight.numel(), x.device).view(weight.shape)     # pre-zeroed pool slice: no fill launch
                 check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
             else:
                 dwp = zeros_f32(nel, x.device)

@@ -58,6 +58,7 @@ struct S1Extra {
   long Mp;     // gapped pixel count
   int abufs;   // 2: A footprint double buffered (1x1: a new footprint every stage); 1: single buffer (KxK: one per K*K stages)
   long NHW;
+  int epi_rows;  // rows of the LDS C tile per epilogue round: BM when the LDS allocation holds the whole tile, else 128
   int boff;  // DMA path: byte offset of the 4 weight buffers in LDS (past the footprint AND the epilogue's C tile)
   int dbg;   // timing experiments only (NPP_S1_DBG): 1 = skip the main loop, 2 = skip the epilogue stores, 4 = no stats
   // split-K (small feature maps: too few output tiles for 256 CUs): tile index = (m, n, split); a KxK conv splits its
@@ -222,6 +223,10 @@ __global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
   const int nstages = (e.dbg & 1) ? 0 : e.nchunks * e.taps;
 
   // ---- persistent loop over tiles: the first stage of tile i+1 is fetched before the epilogue of tile i ----
+  // BN statistics accumulate in registers across this block's tiles (same output columns) and are reduced once
+  float bsum[VEC], bsq[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { bsum[j] = 0.f; bsq[j] = 0.f; }
   int tile = blockIdx.x;
   long q0; int n0;
   tile_coords(tile, q0, n0);
@@ -355,32 +360,30 @@ __global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
 
     // ---- epilogue: rounds of 128 rows through an LDS C tile -------------------------------------------------
     const int nbase = n0c + pc * VEC;
-    float bsum[VEC], bsq[VEC], bias[VEC];
+    float bias[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      bsum[j] = 0.f; bsq[j] = 0.f;
-      bias[j] = (p.bias && nbase + j < p.Cout) ? p.bias[nbase + j] : 0.f;
-    }
+    for (int j = 0; j < VEC; ++j) bias[j] = (p.bias && nbase + j < p.Cout) ? p.bias[nbase + j] : 0.f;
     const bool full_vec = p.vec_io && (nbase + VEC <= p.Cout);
-    constexpr int ROUNDS = BM / 128;
-    for (int rd = 0; rd < ((e.dbg & 2) ? 0 : ROUNDS); ++rd) {
+    const int RPR = e.epi_rows;
+    const int rounds = BM / RPR;
+    for (int rd = 0; rd < ((e.dbg & 2) ? 0 : rounds); ++rd) {
       if (rd > 0) lds_barrier();
-      if ((wm * WM) / 128 == rd) {
+      if ((wm * WM) / RPR == rd) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int el = 0; el < 16; ++el) {
-              const int row = (wm * WM) % 128 + mi * 32 + (el & 3) + 8 * (el >> 2) + 4 * h;
+              const int row = (wm * WM) % RPR + mi * 32 + (el & 3) + 8 * (el >> 2) + 4 * h;
               const int col = wn * WN + ni * 32 + r;
               sC[row * CP + col] = acc[mi][ni][el];
             }
       }
       lds_barrier();
       if (e.splits > 1) {
-        float* wsp = e.ws + ((long)splitc * e.ws_rows + q0c + rd * 128) * e.ws_cols + n0c + pc * VEC;
-        for (int row = pr; row < 128; row += RSTEP) {
+        float* wsp = e.ws + ((long)splitc * e.ws_rows + q0c + rd * RPR) * e.ws_cols + n0c + pc * VEC;
+        for (int row = pr; row < RPR; row += RSTEP) {
 #pragma unroll
           for (int j = 0; j < VEC; j += 4)
             *reinterpret_cast<f32x4*>(wsp + (long)row * e.ws_cols + j) = *reinterpret_cast<const f32x4*>(&sC[row * CP + pc * VEC + j]);
@@ -389,14 +392,14 @@ __global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
       }
       int dn = 0, dy = 0, dx = 0;
       if (e.P) {
-        const int qs = (int)q0c + rd * 128 + pr;
+        const int qs = (int)q0c + rd * RPR + pr;
         dn = qs / img;
         const int rem = qs - dn * img;
         dy = rem / e.Wp;
         dx = rem - dy * e.Wp;
       }
-      for (int row = pr; row < 128; row += RSTEP) {
-        const long q = q0c + rd * 128 + row;
+      for (int row = pr; row < RPR; row += RSTEP) {
+        const long q = q0c + rd * RPR + row;
         if (q >= e.Mp) break;
         if (nbase >= p.Cout) break;
         long m = q;
@@ -439,7 +442,7 @@ __global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
         }
       }
     }
-    if (p.stats && !(e.dbg & 4) && e.splits == 1) {
+    if (p.stats && !(e.dbg & 4) && e.splits == 1 && (!more || n0 != n0c)) {
       lds_barrier();
       float* red = reinterpret_cast<float*>(smem);  // [NT][VEC][2]
 #pragma unroll
@@ -457,11 +460,13 @@ __global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
           sq += red[(tt * VEC + j) * 2 + 1];
         }
         if (n0c + col < p.Cout) {
-          double* st = p.stats + (long)((q0c / BM) % NPP_STAT_REPLICAS) * 2 * p.Cout;
+          double* st = p.stats + (long)(blockIdx.x % NPP_STAT_REPLICAS) * 2 * p.Cout;
           atomicAdd(st + n0c + col, (double)sm);
           atomicAdd(st + p.Cout + n0c + col, (double)sq);
         }
       }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { bsum[j] = 0.f; bsq[j] = 0.f; }
     }
     if (!more) break;
     tile = next;
@@ -592,6 +597,8 @@ bool s1_plan(const IgemmParams& p, int dtype, S1Plan& pl) {
   if (p.Cp != p.Cin) return false;
   int kcb;
   if (p.Cin % (128 / es) == 0) kcb = 128; else if (p.Cin % (64 / es) == 0) kcb = 64; else return false;
+  static const int force_kcb = getenv("NPP_S1_KCB") ? atoi(getenv("NPP_S1_KCB")) : 0;
+  if (force_kcb == 64 && p.Cin % (64 / es) == 0) kcb = 64;
   const int kc = kcb / es;
   const int npad = (p.Cout + 31) / 32 * 32;
   const int bn = (npad % 128 == 0) ? 128 : (npad % 64 == 0 ? 64 : 32);
@@ -680,6 +687,11 @@ bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream, void* w
   const size_t epi = (size_t)128 * (bn + 4) * 4, red = (size_t)nt * 8 * 2 * 4;
   if (lds < epi) lds = epi;
   if (lds < red) lds = red;
+  // the whole C tile in LDS (one epilogue round instead of BM/128) when the allocation allows it
+  const size_t epi_full = (size_t)bm * (bn + 4) * 4;
+  e.epi_rows = 128;
+  static const bool noepifull = getenv("NPP_S1_EPI128") != nullptr;
+  if (!noepifull && epi_full <= 160 * 1024) { e.epi_rows = bm; if (lds < epi_full) lds = epi_full; }
   // weight tiles by LDS-DMA (KxK convs, 128-byte K chunks, 128-wide tiles): ring of 4 buffers past footprint / C tile
   // (measured on 128->128 3x3 @96^2: 99 us with the DMA ring vs 87 us register-staged -- the stage time is not set by
   // the weight loads' latency -- so the ring is opt-in: NPP_S1_DMA=1; NPP_S1_WM128=1 adds the 128 x 64 wave tile)
@@ -689,10 +701,11 @@ bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream, void* w
   if (dma) {
     size_t boff = (size_t)e.AR * pitch;
     if (boff < epi) boff = epi;
+    if (e.epi_rows == bm && boff < epi_full) boff = epi_full;
     if (boff < red) boff = red;
     boff = (boff + 1023) / 1024 * 1024;
     const size_t need = boff + (size_t)4 * bn * 128;
-    if (need <= 160 * 1024) { e.boff = (int)boff; lds = need; } else dma = false;
+    if (need <= 160 * 1024) { e.boff = (int)boff; if (lds < need) lds = need; } else dma = false;
   }
   IgemmParams q = p;
   q.mtiles = (int)((Mp + bm - 1) / bm);
@@ -708,7 +721,9 @@ bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream, void* w
     ncu = cached;
   }
   const int tiles = q.mtiles * q.ntiles * e.splits;
-  const int grid = tiles < ncu ? tiles : ncu;   // persistent: one block per CU walks tiles b, b+grid, ...
+  static const int bpc = getenv("NPP_S1_BPC") ? atoi(getenv("NPP_S1_BPC")) : 1;
+  const int slots = ncu * (bpc > 0 ? bpc : 1);
+  const int grid = tiles < slots ? tiles : slots;   // persistent: one block per CU walks tiles b, b+grid, ...
 #define LAUNCH(T, BM_, BN_, KCB_)                                                                   \
   do {                                                                                              \
     if (!raise_lds(conv_s1_kernel<T, BM_, BN_, KCB_>, lds)) return false;                           \
