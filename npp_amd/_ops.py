@@ -92,6 +92,38 @@ _branch_b_streams = set()      # raw handles of the side streams the network run
 _helper_uses = 0
 
 
+_hub_offload = None      # (hub stream, {raw handles of the branch streams}) while Network.forward runs the hub topology
+_hub_counter = 0
+
+
+def helper_stream_for_edge():
+    """Stream for the second edge of a cell node: the hub stream for a share of the nodes of either branch (hub topology),
+    else the eager helper stream (NPP_STREAMS=4), else None."""
+    global _hub_counter
+    off = _hub_offload
+    if off is not None:
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream in off[1]:
+            _hub_counter += 1
+            num, den = _HUB_SHARE
+            if (_hub_counter % den) < num:
+                return off[0]
+        return None
+    return helper_stream()
+
+
+def _parse_share():
+    v = os.environ.get("NPP_HUB_SHARE", "2/3")
+    try:
+        a, b = v.split("/")
+        return max(0, int(a)), max(1, int(b))
+    except ValueError:
+        return 2, 3
+
+
+_HUB_SHARE = _parse_share()
+
+
 def helper_stream():
     """The helper stream paired with the current stream (NPP_STREAMS=4: the two edges of a cell node overlap), or None.
     Opt-in and eager-only: on ROCm 7.0 hipStreamEndCapture segfaults when two non-origin streams of a capture wait on

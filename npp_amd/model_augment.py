@@ -169,8 +169,24 @@ class _FuseCell(_DagCell):
         wrap = (lambda idx: {0: 4, 1: 2}.get(idx)) if order == 0 else (lambda idx: None)
         self._build(C_cur, edges, concat, lambda idx: 1, wrap)
 
-    def forward(self, s0, s1, s2):
-        st = self._run([self.preprocess0(s0), self.preprocess1(s1), self.preprocess2(s2)])
+    def forward(self, s0, s1, s2, foreign=None, hub=None):
+        """`foreign`: index of the input produced by the other task branch; with the hub topology (Network.forward) the
+        op that consumes it runs on the hub stream, so that the two branch streams never wait on each other directly."""
+        pre = [self.preprocess0, self.preprocess1, self.preprocess2]
+        ins = [s0, s1, s2]
+        if hub is not None and foreign is not None:
+            outs = [None, None, None]
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(hub):
+                outs[foreign] = pre[foreign](ins[foreign])
+            for i in range(3):
+                if i != foreign:
+                    outs[i] = pre[i](ins[i])
+            cur.wait_stream(hub)
+            outs[foreign].record_stream(cur)
+        else:
+            outs = [pre[i](ins[i]) for i in range(3)]
+        st = self._run(outs)
         if self.order == 0:
             # F.interpolate(scale_factor=4/2) with the default (nearest) mode, model_augment.py:167-169
             raise NotImplementedError("order == 0 fuse cells are never built by Network (model_augment.py:357-363)")
@@ -197,19 +213,22 @@ class ParCell1(_FuseCell):
 _side_streams = {}
 
 
-def _side_stream(device):
-    key = (device.type, device.index)
+def _side_stream(device, which=0):
+    key = (device.type, device.index, which)
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=device)
-        K._branch_b_streams.add(st.cuda_stream)
+        if which == 0:
+            K._branch_b_streams.add(st.cuda_stream)
     return st
 
 
-def _two_streams() -> bool:
-    """NPP_STREAMS=1 keeps the whole network on the caller's stream; 2 (default) = one stream per task branch; 4 = plus
-    a helper stream per branch for the second edge of every cell node (eager only, see _ops.helper_stream)."""
-    return os.environ.get("NPP_STREAMS", "2") != "1"
+def _stream_mode() -> int:
+    """NPP_STREAMS: 1 = everything on the caller's stream; 2 (default) = one stream per task branch (the pose branch on the
+    caller's); 3 = hub topology: both branches on side streams, the caller's stream runs what touches both and a share of
+    the cells' second edges (NPP_HUB_SHARE, default 2/3) -- capturable, but measured slower than 2 (81-87 vs 77 ms); 4 = 2 plus per-branch helper streams (eager only, see _ops.helper_stream)."""
+    v = os.environ.get("NPP_STREAMS", "2")
+    return {"1": 1, "2": 2, "3": 3, "4": 2}.get(v, 2)
 
 
 class Network(nn.Module):
@@ -368,39 +387,61 @@ class Network(nn.Module):
         # launch ordering adds two-way edges between the user stream and its internal stream, which this ROCm only
         # survives on the origin), and funnelling the side branch's ~430 exchanges through it serialises the branches
         # (measured: 103 ms vs 83 ms).  So multi-rank SyncBN runs single-stream.
-        two = _two_streams() and not self._sync_bn_active()
+        mode = _stream_mode() if not self._sync_bn_active() else 1
+        two = mode >= 2
         K._helper_uses = 0
+        K._hub_offload = None
+        so = sa = sb = None
         if two:
-            sa = torch.cuda.current_stream()
-            sb = _side_stream(x.device)
-            K._hub_stream = sa       # collectives (SyncBatchNorm) of both branches, forward and backward, go here
+            so = torch.cuda.current_stream()
+            sb = _side_stream(x.device, 0)
+            # 2: the pose branch shares the caller's stream.  3 (hub): both branches get their own stream; the caller's
+            # stream (the hipGraph capture's origin) runs everything that touches both branches -- the cross-task
+            # edges, the refinement cells' foreign inputs -- plus a share of the cells' second edges, and is the only
+            # stream either branch ever waits on (a capture on this ROCm dies on two-way waits between non-origin streams)
+            sa = _side_stream(x.device, 1) if mode == 3 else so
+            K._hub_stream = so       # collectives (SyncBatchNorm) of both branches, forward and backward, go here
+            if mode == 3:
+                K._hub_offload = (so, {sa.cuda_stream, sb.cuda_stream})
         else:
             K._hub_stream = None
+        hub = so if mode == 3 else None
+
+        def on_a():
+            return torch.cuda.stream(sa) if mode == 3 else contextlib.nullcontext()
 
         def on_b():
             return torch.cuda.stream(sb) if two else contextlib.nullcontext()
 
         def meet(*tensors):
-            """Each stream waits for what the other has issued so far; `tensors` cross streams from here on."""
+            """Each stream waits for what the others have issued so far; `tensors` cross streams from here on."""
             if not two:
                 return
-            ea, eb = torch.cuda.Event(), torch.cuda.Event()
-            ea.record(sa)
-            eb.record(sb)
-            sa.wait_event(eb)
-            sb.wait_event(ea)
+            if mode == 3:
+                so.wait_stream(sa)
+                so.wait_stream(sb)
+                sa.wait_stream(so)
+                sb.wait_stream(so)
+            else:
+                ea, eb = torch.cuda.Event(), torch.cuda.Event()
+                ea.record(so)
+                eb.record(sb)
+                so.wait_event(eb)
+                sb.wait_event(ea)
             for t in tensors:
-                t.record_stream(sa)
-                t.record_stream(sb)
+                for st in {id(so): so, id(sa): sa, id(sb): sb}.values():
+                    t.record_stream(st)
 
         meet(x)
-        s1 = self.stem2(s0 := self.stem1(self.stem0(x)))
+        with on_a():
+            s1 = self.stem2(s0 := self.stem1(self.stem0(x)))
         with on_b():
             s3 = self.stem5(s2 := self.stem4(self.stem3(x)))
         f1, f2 = [], []
         k1 = k2 = stage = 0
         for i, (cell1, cell2) in enumerate(zip(self.cells1, self.cells2)):
-            s0, s1 = s1, cell1(s0, s1)
+            with on_a():
+                s0, s1 = s1, cell1(s0, s1)
             with on_b():
                 s2, s3 = s3, cell2(s2, s3)
             if i in self._taps:
@@ -408,9 +449,21 @@ class Network(nn.Module):
                 f2.append(s3)
                 meet(*f1, *f2)
                 ind1, ind2 = self._indices1[stage], self._indices2[stage]
-                s1 = K.add(s1, self._cross(self._ops1, k1, ind1, f2))
-                with on_b():
-                    s3 = K.add(s3, self._cross(self._ops2, k2, ind2, f1))
+                if mode == 3:
+                    z1 = self._cross(self._ops1, k1, ind1, f2)      # hub: reads the other branch's features
+                    z2 = self._cross(self._ops2, k2, ind2, f1)
+                    sa.wait_stream(so)
+                    sb.wait_stream(so)
+                    z1.record_stream(sa)
+                    z2.record_stream(sb)
+                    with on_a():
+                        s1 = K.add(s1, z1)
+                    with on_b():
+                        s3 = K.add(s3, z2)
+                else:
+                    s1 = K.add(s1, self._cross(self._ops1, k1, ind1, f2))
+                    with on_b():
+                        s3 = K.add(s3, self._cross(self._ops2, k2, ind2, f1))
                 k1 += len(ind1)
                 k2 += len(ind2)
                 stage += 1
@@ -418,29 +471,44 @@ class Network(nn.Module):
         # decoder: three structurally identical stages (model_augment.py:448-533)
         k1 = k2 = 0
         for d in range(3):
-            o1 = self.upsamples1[d](f1[3] if d == 0 else f1[-1], f1[2 - d])
+            with on_a():
+                o1 = self.upsamples1[d](f1[3] if d == 0 else f1[-1], f1[2 - d])
             with on_b():
                 o2 = self.upsamples2[d](f2[3] if d == 0 else f2[-1], f2[2 - d])
             f1.append(o1)
             f2.append(o2)
             meet(*f1, *f2)
             ind1, ind2 = self.up_indices1[d], self.up_indices2[d]
-            f1[-1] = K.add(o1, self._cross(self.up_ops1, k1, ind1, f2))
-            with on_b():
-                f2[-1] = K.add(o2, self._cross(self.up_ops2, k2, ind2, f1))
+            if mode == 3:
+                z1 = self._cross(self.up_ops1, k1, ind1, f2)
+                z2 = self._cross(self.up_ops2, k2, ind2, f1)
+                sa.wait_stream(so)
+                sb.wait_stream(so)
+                z1.record_stream(sa)
+                z2.record_stream(sb)
+                with on_a():
+                    f1[-1] = K.add(o1, z1)
+                with on_b():
+                    f2[-1] = K.add(o2, z2)
+            else:
+                f1[-1] = K.add(o1, self._cross(self.up_ops1, k1, ind1, f2))
+                with on_b():
+                    f2[-1] = K.add(o2, self._cross(self.up_ops2, k2, ind2, f1))
             k1 += len(ind1)
             k2 += len(ind2)
         H, W = f1[0].shape[2], f1[0].shape[3]
-        x1 = K.concat([f1[0], f1[6], K.bilinear(f1[5], H, W), K.bilinear(f1[4], H, W)])
-        in1, in3 = self.pose_auxlayer(x1), self.pose_layer(x1)
+        with on_a():
+            x1 = K.concat([f1[0], f1[6], K.bilinear(f1[5], H, W), K.bilinear(f1[4], H, W)])
+            in1, in3 = self.pose_auxlayer(x1), self.pose_layer(x1)
         with on_b():
             x2 = K.concat([f2[0], f2[6], K.bilinear(f2[5], H, W), K.bilinear(f2[4], H, W)])
             in2, in4 = self.edge_layer(x2), self.par_layer(x2)
         pose_list, par_list = [], []
 
         def heads(i):
-            pose_aux = self.pose_auxnet[i](in1)
-            pose_map = self.pose_head[i](in3)
+            with on_a():
+                pose_aux = self.pose_auxnet[i](in1)
+                pose_map = self.pose_head[i](in3)
             with on_b():
                 edge = self.edge_head[i](in2)
                 par_map = self.par_head[i](in4)
@@ -452,16 +520,20 @@ class Network(nn.Module):
             for j in range(3):
                 m = 2 * (i - 1) + j
                 meet(in1, in2, in3, in4)
-                n1, tmp = self.pose_net[m](in1, in3, in4)
+                with on_a():
+                    n1, tmp = self.pose_net[m](in1, in3, in4, foreign=2, hub=hub)     # in4 comes from the parsing branch
                 with on_b():
-                    in2, n4 = self.par_net[m](in2, in3, in4)
+                    in2, n4 = self.par_net[m](in2, in3, in4, foreign=1, hub=hub)      # in3 from the pose branch
                 in1, in3, in4 = n1, tmp, n4
             heads(i)
+        K._hub_offload = None
         if two:      # the caller's stream owns every output from here on
-            sa.wait_stream(sb)
-            for pair in par_list:
+            so.wait_stream(sb)
+            if mode == 3:
+                so.wait_stream(sa)
+            for pair in par_list + (pose_list if mode == 3 else []):
                 for t in pair:
-                    t.record_stream(sa)
+                    t.record_stream(so)
         return pose_list, par_list
 
     def _sync_bn_active(self) -> bool:

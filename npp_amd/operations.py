@@ -53,7 +53,7 @@ def _is_trivial(op) -> bool:
 
 def fused_sum(op1, h1, op2, h2):
     """`op1(h1) + op2(h2)` (model_augment.py:54-59) with both BN-applies folded into the add."""
-    helper = K.helper_stream() if not (_is_trivial(op1) or _is_trivial(op2)) else None
+    helper = K.helper_stream_for_edge() if not (_is_trivial(op1) or _is_trivial(op2)) else None
     if helper is None:
         a, b = pending_of(op1, h1), pending_of(op2, h2)
     else:
@@ -65,6 +65,9 @@ def fused_sum(op1, h1, op2, h2):
             b = pending_of(op2, h2)
         a = pending_of(op1, h1)
         cur.wait_stream(helper)
+        b.x.record_stream(cur)
+        if b.stats is not None:
+            b.stats.record_stream(cur)
     if a.bn is None and b.bn is not None:
         a, b = b, a
     training = a.bn.training if a.bn is not None else False

@@ -293,7 +293,7 @@ def test_two_stream_forward_equals_single_stream(monkeypatch):
     images, _, _, _ = synth_batch(int(g["n"]), int(g["size"]), seed=0)
     x = torch.from_numpy(images).to(dev)
     res = {}
-    for mode in ("1", "2"):
+    for mode in ("1", "2", "3"):
         monkeypatch.setenv("NPP_STREAMS", mode)
         net = _build_net(int(g["C"]), torch.float32, g).eval()
         with torch.no_grad():
@@ -307,9 +307,10 @@ def test_two_stream_forward_equals_single_stream(monkeypatch):
         torch.cuda.synchronize()
         res[mode] = (ev, [_f32(t) for pair in p + q for t in pair],
                      {k: _f32(v.grad) for k, v in net.named_parameters() if v.grad is not None})
-    for a, b in zip(res["1"][0], res["2"][0]):
-        assert rel_err(a, b) < 1e-5       # not bit-equal: the SE squeeze (global average) sums with float atomics
-    for a, b in zip(res["1"][1], res["2"][1]):
-        assert rel_err(a, b) < 1e-5
-    for k, a in res["1"][2].items():
-        assert rel_err(res["2"][2][k], a) < 1e-3 or np.abs(a).max() < 1e-6, k
+    for other in ("2", "3"):
+        for a, b in zip(res["1"][0], res[other][0]):
+            assert rel_err(a, b) < 1e-5       # not bit-equal: the SE squeeze (global average) sums with float atomics
+        for a, b in zip(res["1"][1], res[other][1]):
+            assert rel_err(a, b) < 1e-5
+        for k, a in res["1"][2].items():
+            assert rel_err(res[other][2][k], a) < 1e-3 or np.abs(a).max() < 1e-6, (other, k)

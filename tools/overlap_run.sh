@@ -1,0 +1,5 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rm -rf /tmp/ov; rocprofv3 --kernel-trace --output-format csv -d /tmp/ov -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-prof > /tmp/ov.log 2>&1
+f=$(find /tmp/ov -name "*kernel_trace.csv" | head -1)
+python3 tools/overlap_stats.py "$f" 0.5 0.95
