@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("NPP_BENCH_BATCH", "16")), help="images per GPU")
     ap.add_argument("--size", type=int, default=384)
     ap.add_argument("--dtype", default=os.environ.get("NPP_BENCH_DTYPE", "bf16"), choices=["bf16", "f32"])
+    ap.add_argument("--model", default="augment", choices=["augment", "search"],
+                    help="augment: model_augment.Network (the metric's workload); search: the MixedOp supernet of "
+                         "BASELINE config 5 (C=32, weights-only train() pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--local-bn", action="store_true", help="ablation: do not synchronise BN statistics across ranks")
@@ -129,7 +132,14 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     set_compute_dtype(dtype)
     torch.manual_seed(0)
-    net = Network(cfg_ns())
+    if args.model == "search":
+        from types import SimpleNamespace as NS
+        from npp_amd.model_search_interact import Network as SearchNetwork
+        net = SearchNetwork(NS(DATASET=NS(NUM_CLASSES=20, NUM_JOINTS=16), SEARCH=NS(LAYERS=16, INIT_CHANNELS=32),
+                               MODEL=NS(DECONV_WITH_BIAS=False, HEAD='PSP', REFINE_LAYERS=1)))
+        args.no_cpu_baseline = True      # the CPU baseline leg times the augment network only
+    else:
+        net = Network(cfg_ns())
     sync_bn = use_dist and not args.local_bn
     if args.force_dist:
         from npp_amd import _ops as _K
@@ -143,7 +153,8 @@ def main():
     # under capture every collective is issued on the capture's origin stream (GradReducer overlap=False, _ops.hub_all_reduce)
     reducer = GradReducer(net, skip=unused_parameter_names(net), always_reduce=args.force_dist,
                           overlap=not use_graph) if use_dist else None
-    params = list(net.parameters()) + list(crit_pose.parameters()) + list(crit_par.parameters())
+    arch_ids = {id(a) for a in net.arch_parameters()} if args.model == "search" else set()
+    params = [q for q in net.parameters() if id(q) not in arch_ids] + list(crit_pose.parameters()) + list(crit_par.parameters())
     # fused multi-tensor Adam: the capturable foreach path issues ~3000 scalar-math launches per step (13 ms)
     try:
         opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=use_graph)
@@ -261,11 +272,14 @@ def main():
         "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "model_augment.Network fixed genotype C=64 L=16 R=1, %dx%d, batch %d/GPU, "
-                               "fwd + Criterion_par + Criterion_pose + bwd + Adam step" % (args.size, args.size, args.batch),
+        "config": {"workload": ("model_augment.Network fixed genotype C=64 L=16 R=1" if args.model == "augment" else
+                                "model_search_interact.Network supernet C=32 L=16 (weights pass)") +
+                               ", %dx%d, batch %d/GPU, fwd + Criterion_par + Criterion_pose + bwd + Adam step"
+                               % (args.size, args.size, args.batch),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "sync_bn": bool(sync_bn), "hip_graph": graph is not None, "loss": float(loss)},
-        "model_tflops": round(value * 3 * FWD_GFLOP_PER_IMG.get(args.size, 243.37 * (args.size / 384.0) ** 2) / 1e3, 2),
+        "model_tflops": round(value * 3 * (FWD_GFLOP_PER_IMG.get(args.size, 243.37 * (args.size / 384.0) ** 2)
+                                           if args.model == "augment" else 88.70 * (args.size / 384.0) ** 2) / 1e3, 2),
     }
     if roof is not None:
         out["roofline"] = roof

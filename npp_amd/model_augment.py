@@ -491,9 +491,10 @@ class Network(nn.Module):
                 with on_b():
                     f2[-1] = K.add(o2, z2)
             else:
+                g1 = list(f1)        # both cross sums read the features as they are BEFORE this stage's adds
                 f1[-1] = K.add(o1, self._cross(self.up_ops1, k1, ind1, f2))
                 with on_b():
-                    f2[-1] = K.add(o2, self._cross(self.up_ops2, k2, ind2, f1))
+                    f2[-1] = K.add(o2, self._cross(self.up_ops2, k2, ind2, g1))
             k1 += len(ind1)
             k2 += len(ind2)
         H, W = f1[0].shape[2], f1[0].shape[3]

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import math
 
+import contextlib
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -292,46 +294,80 @@ class Network(nn.Module):
                                           if isinstance(m, nn.Conv2d) and m.groups == 1 and id(m.weight) not in skip)
         self._packer.pack_if_stale(dt, x.device)
         x = K.image_to_nhwc(x, dt)
+        # two task branches on two HIP streams, as in model_augment.Network.forward (the pose branch on the caller's)
+        from .model_augment import _side_stream, _stream_mode, Network as _AugNet
+        two = _stream_mode() >= 2 and not _AugNet._sync_bn_active(self)
+        K._hub_offload = None
+        K._hub_stream = None
+        if two:
+            sa = torch.cuda.current_stream()
+            sb = _side_stream(x.device, 0)
+            K._hub_stream = sa
+
+        def on_b():
+            return torch.cuda.stream(sb) if two else contextlib.nullcontext()
+
+        def meet(*tensors):
+            if not two:
+                return
+            ea, eb = torch.cuda.Event(), torch.cuda.Event()
+            ea.record(sa)
+            eb.record(sb)
+            sa.wait_event(eb)
+            sb.wait_event(ea)
+            for t in tensors:
+                t.record_stream(sa)
+                t.record_stream(sb)
+
+        meet(x)
         s1 = self.stem2(s0 := self.stem1(self.stem0(x)))
-        s3 = self.stem5(s2 := self.stem4(self.stem3(x)))
+        with on_b():
+            s3 = self.stem5(s2 := self.stem4(self.stem3(x)))
         f1, f2 = [], []
         offset = 0
         for i, (cell1, cell2) in enumerate(zip(self.cells1, self.cells2)):
             s0, s1 = s1, cell1(s0, s1)
-            s2, s3 = s3, cell2(s2, s3)
+            with on_b():
+                s2, s3 = s3, cell2(s2, s3)
             if i in self._taps:
                 f1.append(s1)
                 f2.append(s3)
                 n = len(f1)
-                z1 = self._mix(self._ops1, offset, f2, self.alphas1[offset:offset + n], self.betas1[offset:offset + n])
-                z2 = self._mix(self._ops2, offset, f1, self.alphas2[offset:offset + n], self.betas2[offset:offset + n])
-                s1 = K.add(s1, z1)
-                s3 = K.add(s3, z2)
+                meet(*f1, *f2)
+                s1 = K.add(s1, self._mix(self._ops1, offset, f2, self.alphas1[offset:offset + n], self.betas1[offset:offset + n]))
+                with on_b():
+                    s3 = K.add(s3, self._mix(self._ops2, offset, f1, self.alphas2[offset:offset + n],
+                                             self.betas2[offset:offset + n]))
                 f1[-1], f2[-1] = s1, s3
                 offset += n
         cont = 0
         for d in range(3):
             o1 = self.upsamples1[d](f1[3] if d == 0 else f1[-1], f1[2 - d])
-            o2 = self.upsamples2[d](f2[3] if d == 0 else f2[-1], f2[2 - d])
+            with on_b():
+                o2 = self.upsamples2[d](f2[3] if d == 0 else f2[-1], f2[2 - d])
             f1.append(o1)
             f2.append(o2)
             n = len(f1)
-            z1 = self._mix(self.up_ops1, cont, f2, self.alphas3[cont:cont + n], self.betas3[cont:cont + n])
-            z2 = self._mix(self.up_ops2, cont, f1, self.alphas4[cont:cont + n], self.betas4[cont:cont + n])
-            f1[-1], f2[-1] = K.add(o1, z1), K.add(o2, z2)
+            meet(*f1, *f2)
+            g1 = list(f1)        # both mixes read the features as they are BEFORE this stage's adds
+            f1[-1] = K.add(o1, self._mix(self.up_ops1, cont, f2, self.alphas3[cont:cont + n], self.betas3[cont:cont + n]))
+            with on_b():
+                f2[-1] = K.add(o2, self._mix(self.up_ops2, cont, g1, self.alphas4[cont:cont + n], self.betas4[cont:cont + n]))
             cont += n
         H, W = f1[0].shape[2], f1[0].shape[3]
         x1 = K.concat([f1[0], f1[6], K.bilinear(f1[5], H, W), K.bilinear(f1[4], H, W)])
-        x2 = K.concat([f2[0], f2[6], K.bilinear(f2[5], H, W), K.bilinear(f2[4], H, W)])
-        in1, in2 = self.pose_auxlayer(x1), self.edge_layer(x2)
-        in3, in4 = self.pose_layer(x1), self.par_layer(x2)
+        in1, in3 = self.pose_auxlayer(x1), self.pose_layer(x1)
+        with on_b():
+            x2 = K.concat([f2[0], f2[6], K.bilinear(f2[5], H, W), K.bilinear(f2[4], H, W)])
+            in2, in4 = self.edge_layer(x2), self.par_layer(x2)
         pose_list, par_list = [], []
 
         def heads(i):
-            edge = self.edge_head[i](in2)
             pose_aux = self.pose_auxnet[i](in1)
             pose_map = self.pose_head[i](in3)
-            par_map = self.par_head[i](in4)
+            with on_b():
+                edge = self.edge_head[i](in2)
+                par_map = self.par_head[i](in4)
             pose_list.append([pose_map, pose_aux])
             par_list.append([par_map, edge])
 
@@ -343,10 +379,17 @@ class Network(nn.Module):
         for i in range(1, self.refine_layers + 1):
             for j in range(3):
                 m = 2 * (i - 1) + j
+                meet(in1, in2, in3, in4, w_par, w_par2)
                 n1, tmp = self.pose_net[m](in1, in3, in4, w_pose, w_pose2)
-                in2, n4 = self.par_net[m](in2, in3, in4, w_par, w_par2)
+                with on_b():
+                    in2, n4 = self.par_net[m](in2, in3, in4, w_par, w_par2)
                 in1, in3, in4 = n1, tmp, n4
             heads(i)
+        if two:
+            sa.wait_stream(sb)
+            for pair in par_list:
+                for t in pair:
+                    t.record_stream(sa)
         return pose_list, par_list
 
     # -- genotype extraction (:913-1052; host-side numpy on the architecture tensors) --------------------------------
