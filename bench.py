@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--model", default="augment", choices=["augment", "search"],
                     help="augment: model_augment.Network (the metric's workload); search: the MixedOp supernet of "
                          "BASELINE config 5 (C=32, weights-only train() pass)")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of npp_amd.optim.FusedAdam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--local-bn", action="store_true", help="ablation: do not synchronise BN statistics across ranks")
@@ -155,11 +156,17 @@ def main():
                           overlap=not use_graph) if use_dist else None
     arch_ids = {id(a) for a in net.arch_parameters()} if args.model == "search" else set()
     params = [q for q in net.parameters() if id(q) not in arch_ids] + list(crit_pose.parameters()) + list(crit_par.parameters())
-    # fused multi-tensor Adam: the capturable foreach path issues ~3000 scalar-math launches per step (13 ms)
-    try:
-        opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=use_graph)
-    except (RuntimeError, ValueError):
-        opt = torch.optim.Adam(params, lr=1e-4, capturable=use_graph)
+    # Adam (augment_lip_sync.py:210-213).  Default: npp_amd.optim.FusedAdam, one launch over a device job table (SURVEY
+    # §8f-2); --torch-adam: torch's fused multi-tensor Adam (~46 launches, 1.8 ms/step); the capturable foreach path
+    # issues ~3000 scalar-math launches per step (13 ms)
+    if args.torch_adam:
+        try:
+            opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=use_graph)
+        except (RuntimeError, ValueError):
+            opt = torch.optim.Adam(params, lr=1e-4, capturable=use_graph)
+    else:
+        from npp_amd.optim import FusedAdam
+        opt = FusedAdam(params, lr=1e-4)
 
     images, lpar, lpose, _ = synth_batch(args.batch, args.size, seed=0, rank=rank)
     images = torch.from_numpy(images).to(dev)

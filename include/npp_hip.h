@@ -226,6 +226,22 @@ int npp_ce_pixel_grad_up(const NppTensor* logits, const int64_t* labels, int H, 
 /* edge class weights from label counts, core/criterion.py:161-166: w = [pos/(pos+neg), neg/(pos+neg)] */
 int npp_edge_weights(const int64_t* labels, int64_t n, double* counts /*[2] zeroed by caller*/, void* stream);
 
+/* ---- optimizer --------------------------------------------------------------------------------
+ * torch.optim.Adam(params, lr, betas, eps, weight_decay) of augment_lip_sync.py:210-213 as ONE launch over a
+ * device-resident table: param / exp_avg / exp_avg_sq are f32 and updated in place, grad is f32.  `chunks` holds
+ * (job index, chunk index) pairs, one per block, chunk = npp_adam_chunk_elems() elements; `step` is a device int64 that
+ * the call increments before use (bias corrections 1 - beta^step).  Same formula as torch's fused / capturable path:
+ * g += wd*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps). */
+typedef struct NppAdamJob {
+  void* param; const void* grad; void* exp_avg; void* exp_avg_sq;
+  int64_t n;
+  float lr, beta1, beta2, eps, weight_decay;
+  int32_t _pad;
+} NppAdamJob;
+int npp_adam_chunk_elems(void);
+int npp_adam_step(const NppAdamJob* jobs /*device*/, const int32_t* chunks /*device [nchunks][2]*/, int nchunks,
+                  int64_t* step /*device*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

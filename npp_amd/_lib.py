@@ -30,6 +30,12 @@ class NppConvGeom(C.Structure):
                 ("pw", C.c_int32), ("dh", C.c_int32), ("dw", C.c_int32), ("uph", C.c_int32), ("upw", C.c_int32), ("relu_in", C.c_int32)]
 
 
+class NppAdamJob(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("_pad", C.c_int32)]
+
+
 class NppPackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("kh", C.c_int32),
                 ("kw", C.c_int32), ("for_dgrad", C.c_int32), ("dtype", C.c_int32), ("first_block", C.c_int64)]
@@ -90,9 +96,10 @@ _SIGS = {
     "npp_ce_pixel_bwd": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _T, _P],
     "npp_ce_pixel_grad_up": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P],
     "npp_edge_weights": [_P, C.c_int64, _P, _P],
+    "npp_adam_step": [_P, _P, C.c_int, _P, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_packed_weight_elems", "npp_reduce_blocks",
-                                 "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes"])
+                                 "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems"])
 
 
 def lib():
@@ -110,6 +117,8 @@ def lib():
         L.npp_packed_weight_elems.argtypes = [C.c_int] * 5
         L.npp_dwconv_bwd_weight_ws.restype = C.c_int64
         L.npp_dwconv_bwd_weight_ws.argtypes = [_T, _G]
+        L.npp_adam_chunk_elems.restype = C.c_int
+        L.npp_adam_chunk_elems.argtypes = []
         L.npp_conv_fwd_ws_bytes.restype = C.c_int64
         L.npp_conv_fwd_ws_bytes.argtypes = [_T, _T, _G]
         L.npp_dwconv_bwd_weight_ws_zeroed.restype = C.c_int

@@ -285,17 +285,30 @@ __global__ void se_gate_bwd_a_kernel(const float* __restrict__ hidden, const flo
   }
   __syncthreads();
   for (int c = threadIdx.x; c < Ch; c += blockDim.x) {
-    float s = 0.f;
-    for (int o = 0; o < C; ++o) s += w2[(long)o * Ch + c] * dz2[o];
+    // 8 independent partial sums: the loads of one chunk are in flight together (a single dependent chain of C L2
+    // round trips made this 20 us kernel)
+    float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int o = 0;
+    for (; o + 8 <= C; o += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ps[u] = fmaf(w2[(long)(o + u) * Ch + c], dz2[o + u], ps[u]);
+    }
+    for (; o < C; ++o) ps[0] = fmaf(w2[(long)o * Ch + c], dz2[o], ps[0]);
+    const float s = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
     dz1[c] = hidden[(long)n * Ch + c] > 0.f ? s : 0.f;
   }
   __syncthreads();
   float* dzn = dz + (long)n * (C + Ch);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     dzn[c] = dz2[c];
-    float s = 0.f;
-    for (int o = 0; o < Ch; ++o) s += w1[(long)o * C + c] * dz1[o];
-    dpooled[(long)n * C + c] = s;
+    float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int o = 0;
+    for (; o + 8 <= Ch; o += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ps[u] = fmaf(w1[(long)(o + u) * C + c], dz1[o + u], ps[u]);
+    }
+    for (; o < Ch; ++o) ps[0] = fmaf(w1[(long)o * C + c], dz1[o], ps[0]);
+    dpooled[(long)n * C + c] = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
   }
   for (int c = threadIdx.x; c < Ch; c += blockDim.x) dzn[C + c] = dz1[c];
 }

@@ -1,0 +1,124 @@
+"""Multi-tensor Adam on one HIP launch -- drop-in for `torch.optim.Adam(params, lr, betas, eps, weight_decay)` as the
+reference builds it (augment_lip_sync.py:210-213: parameter groups with their own lr / weight decay, no amsgrad).
+
+SURVEY §8f-2.  Parameters and gradients stay the tensors autograd and `state_dict()` know; what is new is a device-resident
+job table (`NppAdamJob` per tensor + one (job, chunk) pair per block) so that the whole model -- 1756 tensors, 77 M
+elements for NPPNet -- is ONE kernel at HBM speed instead of ~46 multi-tensor launches.  Per step the host only gathers the
+gradient pointers (autograd hands out fresh gradient tensors in eager mode); the table is re-uploaded when one of them, or a
+hyper-parameter, changed -- from pinned memory allocated beforehand, so the upload can sit inside a hipGraph capture.
+There is no CPU path: parameters must live on the GPU (the product path fails loudly without the HIP library).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ._lib import check, lib, stream_ptr
+
+_JOB = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("n", "<i8"),
+                 ("lr", "<f4"), ("beta1", "<f4"), ("beta2", "<f4"), ("eps", "<f4"), ("weight_decay", "<f4"), ("_pad", "<i4")])
+assert _JOB.itemsize == 64        # sizeof(NppAdamJob), include/npp_hip.h
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("FusedAdam: invalid hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._chunk = int(lib().npp_adam_chunk_elems())
+        self._plist = None        # parameters that took part in the last table
+        self._jobs = None         # numpy structured array (host image of the table)
+        self._hyper = None
+        self._pin = None          # (pinned jobs, pinned chunks)
+        self._dev = None          # (device jobs, device chunks)
+        self._step = None         # device int64
+
+    def _state_for(self, p):
+        st = self.state[p]
+        if "exp_avg" not in st:
+            st["step"] = torch.zeros((), dtype=torch.float32)      # placeholder for state_dict compatibility
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    def _rebuild(self, plist, hyper, dev):
+        n = len(plist)
+        jobs = np.zeros(n, dtype=_JOB)
+        sizes = np.empty(n, dtype=np.int64)
+        for i, p in enumerate(plist):
+            if p.dtype != torch.float32 or not p.is_contiguous() or not p.is_cuda:
+                raise RuntimeError("FusedAdam: parameters must be contiguous float32 GPU tensors (no CPU path)")
+            st = self._state_for(p)
+            jobs["param"][i] = p.data_ptr()
+            jobs["exp_avg"][i] = st["exp_avg"].data_ptr()
+            jobs["exp_avg_sq"][i] = st["exp_avg_sq"].data_ptr()
+            sizes[i] = p.numel()
+        jobs["n"] = sizes
+        h = np.asarray(hyper, dtype=np.float32)
+        jobs["lr"], jobs["beta1"], jobs["beta2"], jobs["eps"], jobs["weight_decay"] = h[:, 0], h[:, 1], h[:, 2], h[:, 3], h[:, 4]
+        nch = (sizes + self._chunk - 1) // self._chunk
+        chunks = np.empty((int(nch.sum()), 2), dtype=np.int32)
+        chunks[:, 0] = np.repeat(np.arange(n, dtype=np.int32), nch)
+        starts = np.cumsum(nch) - nch
+        chunks[:, 1] = np.arange(int(nch.sum()), dtype=np.int64) - np.repeat(starts, nch)
+        self._jobs, self._plist, self._hyper = jobs, plist, hyper
+        # two pinned images of the job table, used alternately: the host never waits for the upload of the previous step
+        pjs = [torch.empty(n * _JOB.itemsize, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        pc = torch.from_numpy(chunks.reshape(-1).copy()).pin_memory()
+        self._pin = (pjs, pc)
+        self._pin_ev = [None, None]
+        self._pin_i = 0
+        self._dev = (torch.empty(pjs[0].numel(), dtype=torch.uint8, device=dev), torch.empty(pc.numel(), dtype=torch.int32, device=dev))
+        self._dev[1].copy_(pc, non_blocking=True)
+        self._nchunks = int(chunks.shape[0])
+        if self._step is None:
+            self._step = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._grad_ptrs = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        plist, hyper = [], []
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            h = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]))
+            for p in group["params"]:
+                if p.grad is not None:
+                    plist.append(p)
+                    hyper.append(h)
+        if not plist:
+            return loss
+        same = self._plist is not None and len(plist) == len(self._plist) and all(a is b for a, b in zip(plist, self._plist))
+        if not same or hyper != self._hyper:
+            if self._plist is not None and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FusedAdam: the parameter set / hyper-parameters changed inside a hipGraph capture "
+                                   "(run one eager step with the same set first: pinned tables are allocated there)")
+            self._rebuild(plist, hyper, plist[0].device)
+        for p in plist:
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                p.grad = g.float().contiguous()
+        gp = np.fromiter((p.grad.data_ptr() for p in plist), dtype=np.uint64, count=len(plist))
+        if self._grad_ptrs is None or not np.array_equal(gp, self._grad_ptrs):
+            capturing = torch.cuda.is_current_stream_capturing()
+            i = self._pin_i
+            self._pin_i ^= 1
+            if self._pin_ev[i] is not None and not capturing:
+                self._pin_ev[i].synchronize()         # the upload issued two steps ago has read this pinned image
+            self._jobs["grad"] = gp
+            self._pin[0][i].numpy()[:] = self._jobs.view(np.uint8)
+            self._dev[0].copy_(self._pin[0][i], non_blocking=True)
+            if not capturing:
+                self._pin_ev[i] = torch.cuda.Event()
+                self._pin_ev[i].record()
+            self._grad_ptrs = gp
+        check(lib().npp_adam_step(self._dev[0].data_ptr(), self._dev[1].data_ptr(), self._nchunks, self._step.data_ptr(),
+                                  stream_ptr()), "npp_adam_step")
+        torch.autograd.graph.increment_version(plist)   # in-place update behind autograd's back: derived caches must see it
+        return loss
+
+    def device_step_count(self) -> int:
+        return int(self._step.item()) if self._step is not None else 0

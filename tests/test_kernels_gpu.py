@@ -222,3 +222,28 @@ def test_kth_smallest_is_exact():
         torch.cuda.synchronize()
         assert float(out[0]) == float(valid[min(k, len(valid) - 1)]), k
         assert int(out[1]) == len(valid)
+
+
+def test_fused_adam_matches_torch_adam():
+    """npp_amd.optim.FusedAdam (one launch over a device job table) vs torch.optim.Adam on ragged tensor sizes, two
+    parameter groups with their own lr / weight decay, several steps."""
+    from npp_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    shapes = [(64, 32, 3, 3), (7,), (1,), (4099,), (128, 128), (33, 5)]
+    pa = [torch.randn(s, device=dev).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    groups = lambda ps: [{"params": ps[:3], "lr": 1e-2, "weight_decay": 1e-3}, {"params": ps[3:], "lr": 3e-3}]
+    oa = torch.optim.Adam(groups(pa), betas=(0.9, 0.99), eps=1e-8)
+    ob = FusedAdam(groups(pb), betas=(0.9, 0.99), eps=1e-8)
+    for it in range(4):
+        grads = [torch.randn(s, device=dev) for s in shapes]
+        for p, q, g in zip(pa, pb, grads):
+            p.grad = g.clone()
+            q.grad = g.clone()
+        oa.step()
+        ob.step()
+    torch.cuda.synchronize()
+    assert ob.device_step_count() == 4
+    for p, q in zip(pa, pb):
+        assert torch.allclose(p, q, rtol=2e-6, atol=2e-7), float((p - q).abs().max())
