@@ -226,6 +226,15 @@ int npp_ce_pixel_grad_up(const NppTensor* logits, const int64_t* labels, int H, 
 /* edge class weights from label counts, core/criterion.py:161-166: w = [pos/(pos+neg), neg/(pos+neg)] */
 int npp_edge_weights(const int64_t* labels, int64_t n, double* counts /*[2] zeroed by caller*/, void* stream);
 
+/* ---- evaluation -------------------------------------------------------------------------------
+ * validate_sync's parsing path on the device (core/function.py:925-967 + utils/utils.py:190-216): counts[l*C + p] +=
+ * #pixels with label l (!= ignore) and arg-max p of 0.5*(up(pred) + mirror(swap(up(flip_pred)))), `up` = bilinear,
+ * align_corners=False, to H x W.  flip_pred may be NULL (no TTA: arg-max of up(pred)).  alias_swap = 1 reproduces the
+ * reference's aliased left/right swap (channels 14/16/18 <- 15/17/19, 15/17/19 unchanged), 0 is a true swap.
+ * label: int64 [N][H][W]; counts: int64 [C][C], accumulated (zero it before the first batch). */
+int npp_parsing_confusion(const NppTensor* pred, const NppTensor* flip_pred, const int64_t* label, int H, int W,
+                          int ignore, int alias_swap, int64_t* counts, void* stream);
+
 /* ---- optimizer --------------------------------------------------------------------------------
  * torch.optim.Adam(params, lr, betas, eps, weight_decay) of augment_lip_sync.py:210-213 as ONE launch over a
  * device-resident table: param / exp_avg / exp_avg_sq are f32 and updated in place, grad is f32.  `chunks` holds

@@ -97,6 +97,7 @@ _SIGS = {
     "npp_ce_pixel_grad_up": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P],
     "npp_edge_weights": [_P, C.c_int64, _P, _P],
     "npp_adam_step": [_P, _P, C.c_int, _P, _P],
+    "npp_parsing_confusion": [_T, _T, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_packed_weight_elems", "npp_reduce_blocks",
                                  "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems"])

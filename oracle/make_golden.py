@@ -28,6 +28,7 @@ sys.path.insert(0, "/root/reference")
 sys.path.insert(1, REPO)
 
 import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
 
 torch.Tensor.cuda = lambda self, *a, **k: self  # core/criterion.py:192,197 call .cuda() unconditionally
 torch.nn.Module.cuda = lambda self, *a, **k: self
@@ -267,6 +268,43 @@ def gen_search():
     print("search_net.npz", len(out), "arrays; loss", float(loss))
 
 
+def gen_eval():
+    """validate_sync's parsing path (core/function.py:925-943 + utils/utils.py:190-216): flip-TTA logits -> confusion
+    matrix.  The TTA lines are inline in validate_sync (which needs cv2), so they are executed here as the same torch
+    calls; the confusion matrix is the reference's own `get_confusion_matrix`."""
+    np.int = int                          # utils/utils.py:201 uses the alias numpy 2 removed
+    from utils.utils import get_confusion_matrix
+    rng = np.random.default_rng(0xE7A1)
+    n, c, h, H = 2, 20, 32, 128
+    pred = torch.from_numpy(rng.standard_normal((n, c, h, h)).astype(np.float32) * 2.0)
+    flip = torch.from_numpy(rng.standard_normal((n, c, h, h)).astype(np.float32) * 2.0)
+    label = rng.integers(0, c, size=(n, H, H)).astype(np.int64)
+    label[:, :6, :] = 255
+    label[:, :, -5:] = 255
+    size = (n, H, H)
+    a = F.interpolate(input=pred, size=(size[-2], size[-1]), mode='bilinear')
+    b = F.interpolate(input=flip, size=(size[-2], size[-1]), mode='bilinear')
+    tmp = b
+    b[:, 14, :, :] = tmp[:, 15, :, :]
+    b[:, 15, :, :] = tmp[:, 14, :, :]
+    b[:, 16, :, :] = tmp[:, 17, :, :]
+    b[:, 17, :, :] = tmp[:, 16, :, :]
+    b[:, 18, :, :] = tmp[:, 19, :, :]
+    b[:, 19, :, :] = tmp[:, 18, :, :]
+    b = b.flip(3)
+    avg = 0.5 * (a + b)
+    cm = get_confusion_matrix(torch.from_numpy(label), avg, size, c, 255)
+    cm_noflip = get_confusion_matrix(torch.from_numpy(label), a, size, c, 255)
+    # second-largest margin of every pixel: tests may tolerate arg-max flips only where it is at rounding level
+    srt = np.sort(avg.numpy(), axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    out = {"torch_version": np.array(torch.__version__), "pred": pred.numpy(), "flip": flip.numpy(),
+           "label": label.astype(np.uint8), "avg_sub": avg.numpy()[:, :, ::4, ::4].copy(), "confusion": cm, "confusion_noflip": cm_noflip,
+           "near_ties": np.array(int((margin < 1e-5).sum()))}
+    np.savez_compressed(os.path.join(OUT, "eval_parsing.npz"), **out)
+    print("eval_parsing.npz; pixels", int(cm.sum()), "near ties", int((margin < 1e-5).sum()))
+
+
 def gen_full():
     C, size, n = 64, 384, 1
     net, pose_list, par_list, l_par, l_pose, loss, cpose, cpar, images = run_net(C, size, n)
@@ -301,6 +339,6 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["ops", "criteria", "tiny", "search"] + (["full"] if a.full else [])
+    todo = a.only.split(",") if a.only else ["ops", "criteria", "tiny", "search", "eval"] + (["full"] if a.full else [])
     for t in todo:
-        {"ops": gen_ops, "criteria": gen_criteria, "tiny": gen_tiny, "full": gen_full, "search": gen_search}[t]()
+        {"ops": gen_ops, "criteria": gen_criteria, "tiny": gen_tiny, "full": gen_full, "search": gen_search, "eval": gen_eval}[t]()

@@ -21,6 +21,7 @@ import math
 from types import SimpleNamespace
 from typing import Dict, List, Sequence
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -566,3 +567,29 @@ def search_network_forward(tensors, x, layers=16, refine_layers=1, train=True):
             in1, in3, in4 = n1, tmp, n4
         heads(i)
     return pose_list, par_list, c.new_buffers
+
+
+# ---- evaluation: flip-TTA parsing + confusion matrix --------------------------------------------------
+def tta_parsing_logits(pred_par, flip_pred_par, size):
+    """core/function.py:925-943 (`validate_sync`): both logit maps are upsampled with
+    `F.interpolate(mode='bilinear')` (align_corners=False), the flipped prediction's left/right classes are "swapped" through
+    `tmp = flip_pred_par` -- an ALIAS, not a copy (:932-938), so channels 14/16/18 receive 15/17/19 and 15/17/19 keep
+    their own values --, the map is mirrored back (:939) and the two are averaged (:940)."""
+    a = F.interpolate(pred_par, size=(size[-2], size[-1]), mode='bilinear')
+    b = F.interpolate(flip_pred_par, size=(size[-2], size[-1]), mode='bilinear')
+    tmp = b
+    for lo, hi in ((14, 15), (16, 17), (18, 19)):
+        b[:, lo] = tmp[:, hi]
+        b[:, hi] = tmp[:, lo]
+    b = b.flip(3)
+    return 0.5 * (a + b)
+
+
+def confusion_matrix(label, pred, num_class, ignore=255):
+    """utils/utils.py:190-216 `get_confusion_matrix`: arg-max over classes (first maximum), pixels whose label equals
+    `ignore` dropped, counts[label, prediction]."""
+    seg_pred = pred.detach().numpy().transpose(0, 2, 3, 1).argmax(axis=3).astype(np.uint8)
+    seg_gt = label.detach().numpy().astype(np.int64)
+    keep = seg_gt != ignore
+    idx = seg_gt[keep] * num_class + seg_pred[keep]
+    return np.bincount(idx, minlength=num_class * num_class)[:num_class * num_class].reshape(num_class, num_class).astype(np.float64)

@@ -247,3 +247,34 @@ def test_fused_adam_matches_torch_adam():
     assert ob.device_step_count() == 4
     for p, q in zip(pa, pb):
         assert torch.allclose(p, q, rtol=2e-6, atol=2e-7), float((p - q).abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_parsing_tta_confusion_matches_reference(dtype):
+    """validate_sync's parsing path on the device vs the reference's get_confusion_matrix (tests/golden/eval_parsing.npz):
+    integer counts, bit-exact in f32 (a pixel whose top-2 margin is at rounding level may legitimately flip)."""
+    from helpers import load_golden
+    from npp_amd.evaluate import ParsingConfusion
+    from npp_amd import _ops as K
+    g = load_golden("eval_parsing.npz")
+    dev = torch.device("cuda:0")
+    pred = K.cast(torch.from_numpy(g["pred"]).to(dev).contiguous(memory_format=torch.channels_last), dtype)
+    flip = K.cast(torch.from_numpy(g["flip"]).to(dev).contiguous(memory_format=torch.channels_last), dtype)
+    label = torch.from_numpy(g["label"].astype(np.int64)).to(dev)
+    cm = ParsingConfusion(20, 255)
+    cm.update(pred[:1], flip[:1], label[:1])        # two batches: counts accumulate
+    cm.update(pred[1:], flip[1:], label[1:])
+    got = cm.matrix().numpy()
+    ref = g["confusion"]
+    assert got.sum() == ref.sum()                   # every non-ignored pixel counted once
+    if dtype == torch.float32:
+        assert np.abs(got - ref).sum() <= 2 * int(g["near_ties"]), np.abs(got - ref).sum()
+    else:
+        assert np.abs(got - ref).sum() <= 0.02 * ref.sum()     # bf16 logits: ~1 % of arg-maxes move
+    cm2 = ParsingConfusion(20, 255)
+    cm2.update(pred, None, label)
+    if dtype == torch.float32:
+        assert np.abs(cm2.matrix().numpy() - g["confusion_noflip"]).sum() <= 2
+    true_swap = ParsingConfusion(20, 255, alias_swap=False)
+    true_swap.update(pred, flip, label)
+    assert not np.array_equal(true_swap.matrix().numpy(), got)

@@ -215,3 +215,23 @@ def test_search_supernet_matches_reference():
         if k.startswith("train/grad/"):
             pk = k[len("train/grad/"):]
             assert rel_err(t[pk].grad.numpy(), g[k]) < 1e-3, pk
+
+
+def test_eval_parsing_tta_confusion_matches_reference():
+    """validate_sync's parsing path: oracle (flip-TTA with the reference's aliased channel swap + confusion matrix) vs the
+    reference's own get_confusion_matrix on the same logits (tests/golden/eval_parsing.npz)."""
+    g = load_golden("eval_parsing.npz")
+    pred, flip = torch.from_numpy(g["pred"]), torch.from_numpy(g["flip"])
+    label = torch.from_numpy(g["label"].astype(np.int64))
+    avg = O.tta_parsing_logits(pred, flip.clone(), label.shape)
+    assert np.array_equal(avg.numpy()[:, :, ::4, ::4], g["avg_sub"])
+    assert np.array_equal(O.confusion_matrix(label, avg, 20, 255), g["confusion"])
+    up = torch.nn.functional.interpolate(pred, size=label.shape[-2:], mode="bilinear")
+    assert np.array_equal(O.confusion_matrix(label, up, 20, 255), g["confusion_noflip"])
+    # the aliased swap really is what the goldens hold: a true swap gives a different matrix
+    b = torch.nn.functional.interpolate(flip, size=label.shape[-2:], mode="bilinear")
+    t = b.clone()
+    for lo, hi in ((14, 15), (16, 17), (18, 19)):
+        b[:, lo], b[:, hi] = t[:, hi], t[:, lo]
+    true_swap = 0.5 * (up + b.flip(3))
+    assert not np.array_equal(O.confusion_matrix(label, true_swap, 20, 255), g["confusion"])
