@@ -107,7 +107,7 @@ __global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
   const int total_tiles = p.mtiles * p.ntiles * e.splits;
 
   // ---- staging roles (recomputed per tile) -------------------------------------------------------------
-  const T* asrc[APT_MAX];
+  int asrc[APT_MAX];     // element offset of this thread's footprint pieces in x (-1: zero row); host checks < 2^31
   int adst[APT_MAX];
   const T* bsrc[BPT];
   int bdst[BPT];
@@ -146,9 +146,9 @@ __global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
     int y = rem / e.Wp, x = rem - y * e.Wp;
 #pragma unroll
     for (int i = 0; i < APT_MAX; ++i) {
-      const T* src = nullptr;
+      int src = -1;
       if (adst[i] >= 0 && n >= 0 && n < p.N && y < p.H && x < p.W)
-        src = xg + ((long)(n * p.H + y) * p.W + x) * p.ldx + pc8 * VEC;
+        src = (int)(((long)(n * p.H + y) * p.W + x) * p.ldx) + pc8 * VEC;
       asrc[i] = src;
       x += NT / PPR;
       while (x >= e.Wp) { x -= e.Wp; ++y; }
@@ -165,7 +165,7 @@ __global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
 #pragma unroll
     for (int i = 0; i < APT_MAX; ++i) {
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (asrc[i]) v = *reinterpret_cast<const u32x4*>(asrc[i] + (long)(chunk0 + chunk) * KC);
+      if (asrc[i] >= 0) v = *reinterpret_cast<const u32x4*>(xg + asrc[i] + (chunk0 + chunk) * KC);
       ra[i] = v;   // ReLU is applied at store_A: touching the value here would wait for the load
     }
   };
@@ -223,10 +223,6 @@ __global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
   const int nstages = (e.dbg & 1) ? 0 : e.nchunks * e.taps;
 
   // ---- persistent loop over tiles: the first stage of tile i+1 is fetched before the epilogue of tile i ----
-  // BN statistics accumulate in registers across this block's tiles (same output columns) and are reduced once
-  float bsum[VEC], bsq[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) { bsum[j] = 0.f; bsq[j] = 0.f; }
   int tile = blockIdx.x;
   long q0; int n0;
   tile_coords(tile, q0, n0);
@@ -360,9 +356,12 @@ __global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
 
     // ---- epilogue: rounds of 128 rows through an LDS C tile -------------------------------------------------
     const int nbase = n0c + pc * VEC;
-    float bias[VEC];
+    float bsum[VEC], bsq[VEC], bias[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) bias[j] = (p.bias && nbase + j < p.Cout) ? p.bias[nbase + j] : 0.f;
+    for (int j = 0; j < VEC; ++j) {
+      bsum[j] = 0.f; bsq[j] = 0.f;
+      bias[j] = (p.bias && nbase + j < p.Cout) ? p.bias[nbase + j] : 0.f;
+    }
     const bool full_vec = p.vec_io && (nbase + VEC <= p.Cout);
     const int RPR = e.epi_rows;
     const int rounds = BM / RPR;
@@ -442,7 +441,7 @@ __global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
         }
       }
     }
-    if (p.stats && !(e.dbg & 4) && e.splits == 1 && (!more || n0 != n0c)) {
+    if (p.stats && !(e.dbg & 4) && e.splits == 1) {
       lds_barrier();
       float* red = reinterpret_cast<float*>(smem);  // [NT][VEC][2]
 #pragma unroll
@@ -460,13 +459,11 @@ __global__ __launch_bounds__((BM / WM) * (BN >= 128 ? 2 : 1) * 64) void conv_s1_
           sq += red[(tt * VEC + j) * 2 + 1];
         }
         if (n0c + col < p.Cout) {
-          double* st = p.stats + (long)(blockIdx.x % NPP_STAT_REPLICAS) * 2 * p.Cout;
+          double* st = p.stats + (long)((q0c / BM) % NPP_STAT_REPLICAS) * 2 * p.Cout;
           atomicAdd(st + n0c + col, (double)sm);
           atomicAdd(st + p.Cout + n0c + col, (double)sq);
         }
       }
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) { bsum[j] = 0.f; bsq[j] = 0.f; }
     }
     if (!more) break;
     tile = next;
@@ -595,6 +592,7 @@ bool s1_plan(const IgemmParams& p, int dtype, S1Plan& pl) {
   if (p.ph != P || p.pw != P) return false;
   if (p.OH != p.H || p.OW != p.W) return false;
   if (p.Cp != p.Cin) return false;
+  if ((long)p.N * p.H * p.W * p.ldx >= (1L << 31)) return false;      // the kernel keeps 32-bit element offsets into x
   int kcb;
   if (p.Cin % (128 / es) == 0) kcb = 128; else if (p.Cin % (64 / es) == 0) kcb = 64; else return false;
   static const int force_kcb = getenv("NPP_S1_KCB") ? atoi(getenv("NPP_S1_KCB")) : 0;
