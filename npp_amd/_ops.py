@@ -238,7 +238,12 @@ def packed_weight(w: torch.Tensor, for_dgrad: bool, dtype: torch.dtype) -> torch
     per = ent[1]
     hit = per.get(key)
     if hit is not None and hit[0] == ver:
-        return hit[1]
+        # A version counter is not proof of freshness (torch.optim.Adam(fused=True) updates without bumping it).  Images
+        # written by a model's WeightPacker in this forward are marked managed; a free-standing op in a training
+        # forward repacks, and drops its data-gradient image so that backward repacks too.
+        if len(hit) > 2 or for_dgrad or not (torch.is_grad_enabled() and w.requires_grad):
+            return hit[1]
+        per.pop((True, dtype), None)
     co, ci, kh, kw = w.shape
     n = lib().npp_packed_weight_elems(co, ci, kh, kw, int(for_dgrad))
     out = torch.empty(n, dtype=dtype, device=w.device)
@@ -287,7 +292,10 @@ class WeightPacker:
         self.nblocks = blk
         self.key = (dtype, device, tuple(w.data_ptr() for w in self.weights))
 
-    def pack_if_stale(self, dtype, device):
+    def pack_if_stale(self, dtype, device, force=False):
+        """`force`: repack even if no version counter moved.  The network passes its `training` flag: an optimizer may
+        update parameters without bumping `Tensor._version` (torch.optim.Adam(fused=True) does exactly that), and a
+        training forward on stale operand images would silently use the previous step's weights."""
         ws = self.weights
         if not ws:
             return
@@ -298,7 +306,7 @@ class WeightPacker:
                 return        # unusual storage: leave it to the per-call path
             self._build(dtype, device)
             self.sig = None
-        if sig == self.sig:
+        if sig == self.sig and not force:
             return
         check(lib().npp_pack_weights_batched(self.table.data_ptr(), 2 * len(ws), self.nblocks, stream_ptr()),
               "npp_pack_weights_batched")
@@ -311,8 +319,8 @@ class WeightPacker:
                 ent = (weakref.ref(w, lambda _r, _k=wid: _pack_cache.pop(_k, None)), {})
                 _pack_cache[wid] = ent
             ver = (w._version, w.data_ptr())
-            ent[1][(False, dtype)] = (ver, self.outs[k])
-            ent[1][(True, dtype)] = (ver, self.outs[k + 1])
+            ent[1][(False, dtype)] = (ver, self.outs[k], True)
+            ent[1][(True, dtype)] = (ver, self.outs[k + 1], True)
             k += 2
 
 

@@ -376,7 +376,7 @@ class Network(nn.Module):
                     skip.update((id(m.conv1.weight), id(m.conv2.weight)))
             self._packer = K.WeightPacker(m.weight for m in self.modules()
                                           if isinstance(m, nn.Conv2d) and m.groups == 1 and id(m.weight) not in skip)
-        self._packer.pack_if_stale(dt, x.device)
+        self._packer.pack_if_stale(dt, x.device, force=self.training)
         x = K.image_to_nhwc(x, dt)
         # The pose branch runs on the caller's stream ("A"), the parsing branch on a side stream ("B"); the branches
         # meet at the 4 encoder taps, the 3 decoder stages and the refinement cells.  Kernels of one branch that cannot

@@ -292,7 +292,7 @@ class Network(nn.Module):
                     skip.update((id(m.conv1.weight), id(m.conv2.weight)))
             self._packer = K.WeightPacker(m.weight for m in self.modules()
                                           if isinstance(m, nn.Conv2d) and m.groups == 1 and id(m.weight) not in skip)
-        self._packer.pack_if_stale(dt, x.device)
+        self._packer.pack_if_stale(dt, x.device, force=self.training)
         x = K.image_to_nhwc(x, dt)
         # two task branches on two HIP streams, as in model_augment.Network.forward (the pose branch on the caller's)
         from .model_augment import _side_stream, _stream_mode, Network as _AugNet

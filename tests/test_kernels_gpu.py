@@ -278,3 +278,21 @@ def test_parsing_tta_confusion_matches_reference(dtype):
     true_swap = ParsingConfusion(20, 255, alias_swap=False)
     true_swap.update(pred, flip, label)
     assert not np.array_equal(true_swap.matrix().numpy(), got)
+
+
+def test_packed_weights_follow_silent_parameter_updates():
+    """torch.optim.Adam(fused=True) updates parameters without bumping Tensor._version: the MFMA operand images must
+    still be rebuilt for the next training forward, for a free-standing op and for a whole Network."""
+    from npp_amd.operations import OPS
+    dev = torch.device("cuda:0")
+    m = OPS['std_conv_3x3'](32, 1, True).to(dev).train()
+    x = torch.randn(2, 32, 12, 12, device=dev).contiguous(memory_format=torch.channels_last)
+    y0 = m(x).detach().clone()
+    w = m.net[1].weight
+    v = w._version
+    opt = torch.optim.Adam(m.parameters(), lr=0.5, fused=True)
+    m(x).sum().backward()
+    opt.step()                       # big step, no version bump
+    assert w._version == v
+    y1 = m(x).detach()
+    assert float((y1 - y0).abs().max()) > 1e-3        # the forward saw the new weights
