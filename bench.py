@@ -106,7 +106,8 @@ def main():
                     help="exercise the multi-GPU path (process group, SyncBN exchange, bucketed all-reduce) on ONE rank")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("NPP_BENCH_GRAPH", "-1")),
                     help="1: capture the whole step (fwd+loss+bwd+Adam) in one hipGraph and replay it; 0: eager; "
-                         "-1 (default): graph on 1 GPU, eager on N > 1")
+                         "-1 (default): graph for every N (on N > 1 every collective sits on the capture's origin stream); a capture "
+                         "failure falls back to eager")
     args = ap.parse_args()
 
     import torch

@@ -146,6 +146,17 @@ int npp_bn_bwd_sum(const double* partials, int nblocks, double* total /*[2C]*/, 
                    void* stream);
 int npp_bn_bwd_apply(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,
                      const float* coeffs, NppTensor* dy_raw, void* stream);
+/* Two-sided forms for out = BN_a(a) + BN_b(b) (both edges of a cell node, model_augment.py:54-59): the sides share dout
+ * and the ReLU mask, so one pass reads them once.  partials: [nblocks][3C] = [sum dy' | sum dy'*xhat_a | sum dy'*xhat_b];
+ * coeffs2 sums the slabs and emits both sides' coefficient triples (+ dgamma / dbeta); apply2 writes both gradients. */
+int npp_bn_bwd_reduce2(const NppTensor* dout, const NppTensor* ya_raw, const NppTensor* yb_raw, const NppTensor* relu_out,
+                       const float* mean_invstd_a, const float* mean_invstd_b, double* partials /*[nblocks][3C]*/,
+                       int nblocks, void* stream);
+int npp_bn_bwd_coeffs2(const double* sums, int nrep, double count, const float* mean_invstd_a, const float* mean_invstd_b,
+                       const float* gamma_a, const float* gamma_b, float* coeffs_a, float* coeffs_b, float* dgamma_a,
+                       float* dbeta_a, float* dgamma_b, float* dbeta_b, int c, void* stream);
+int npp_bn_bwd_apply2(const NppTensor* dout, const NppTensor* ya_raw, const NppTensor* yb_raw, const NppTensor* relu_out,
+                      const float* coeffs_a, const float* coeffs_b, NppTensor* dya_raw, NppTensor* dyb_raw, void* stream);
 /* eval-mode / plain affine backward: dy = dout * scale * (out>0) */
 int npp_scale_mask(const NppTensor* dout, const float* scale /*[C] or NULL*/, const NppTensor* relu_out,
                    NppTensor* dx, void* stream);

@@ -67,6 +67,9 @@ _SIGS = {
 
     "npp_bn_bwd_coeffs": [_P, C.c_int, C.c_double, _P, _P, _P, _P, _P, C.c_int, _P],
     "npp_bn_bwd_sum": [_P, C.c_int, _P, _P, _P, C.c_int, _P],
+    "npp_bn_bwd_reduce2": [_T, _T, _T, _T, _P, _P, _P, C.c_int, _P],
+    "npp_bn_bwd_coeffs2": [_P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P],
+    "npp_bn_bwd_apply2": [_T, _T, _T, _T, _P, _P, _T, _T, _P],
     "npp_bn_bwd_apply": [_T, _T, _T, _P, _T, _P],
     "npp_scale_mask": [_T, _P, _T, _T, _P],
     "npp_pool3x3_fwd": [_T, _T, _P, C.c_int, C.c_int, _P, _P],

@@ -662,6 +662,30 @@ class _BnAdd(Function):
             return sums, nb
 
         ni = ctx.needs_input_grad
+        if (has_b and bna is not None and bnb is not None and batch_a and batch_b and ni[0] and ni[3]
+                and a.shape == b.shape and a.dtype == b.dtype and cnt_a == cnt_b
+                and _sync_group(bna)[0] is None and _sync_group(bnb)[0] is None):
+            # both edges end in (local) BatchNorm: the two sides share dout and the ReLU mask -> two-sided kernels
+            c = a.shape[1]
+            dev = a.device
+            nb = lib().npp_reduce_blocks(a.shape[0] * a.shape[2] * a.shape[3], c, L.npp_dtype(a.dtype))
+            sums = torch.empty(nb * 3 * c, dtype=torch.float64, device=dev)
+            check(lib().npp_bn_bwd_reduce2(_byref(dout), _byref(a), _byref(b), tref(yrelu), mia.data_ptr(), mib.data_ptr(),
+                                           sums.data_ptr(), nb, s), "npp_bn_bwd_reduce2")
+            co = torch.empty(6 * c, dtype=torch.float32, device=dev)
+            dgb_ = torch.empty(4 * c, dtype=torch.float32, device=dev)
+            ga = bna.weight.detach() if bna.weight is not None else None
+            gb = bnb.weight.detach() if bnb.weight is not None else None
+            check(lib().npp_bn_bwd_coeffs2(sums.data_ptr(), nb, float(cnt_a), mia.data_ptr(), mib.data_ptr(), ptr(ga), ptr(gb),
+                                           co[:3 * c].data_ptr(), co[3 * c:].data_ptr(), dgb_[:c].data_ptr(),
+                                           dgb_[c:2 * c].data_ptr(), dgb_[2 * c:3 * c].data_ptr(), dgb_[3 * c:].data_ptr(), c, s),
+                  "npp_bn_bwd_coeffs2")
+            dxa = new_nhwc(*a.shape, a.dtype, dev)
+            dxb = new_nhwc(*b.shape, b.dtype, dev)
+            check(lib().npp_bn_bwd_apply2(_byref(dout), _byref(a), _byref(b), tref(yrelu), co[:3 * c].data_ptr(),
+                                          co[3 * c:].data_ptr(), _byref(dxa), _byref(dxb), s), "npp_bn_bwd_apply2")
+            return (dxa, dgb_[:c] if ni[1] else None, dgb_[c:2 * c] if ni[2] else None,
+                    dxb, dgb_[2 * c:3 * c] if ni[4] else None, dgb_[3 * c:] if ni[5] else None, None, None, None, None)
         sides = [(a, bna, mia, ssa, batch_a, cnt_a, ni[0], ni[1], ni[2])]
         if has_b:
             sides.append((b, bnb, mib, ssb, batch_b, cnt_b, ni[3], ni[4], ni[5]))

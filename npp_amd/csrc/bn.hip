@@ -373,6 +373,131 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ---- two-sided forms: out = BN_a(a) + BN_b(b) is the common case (both edges of a cell node end in BatchNorm).  The two
+// sides share dout (and the ReLU mask), so one pass reads it once: reduce 4 -> 3 tensor reads, apply 6 -> 5 passes, and
+// half the launches.  sums: slab b = [sum d | sum d*xhat_a | sum d*xhat_b] (3C doubles).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ ya,
+                                                             long lda, const T* __restrict__ yb, long ldb,
+                                                             const T* __restrict__ ro, long ldr, const float* __restrict__ mia,
+                                                             const float* __restrict__ mib, long npix, int C, ColMap m,
+                                                             double* sums) {
+  __shared__ __attribute__((aligned(16))) float red[256 * 3 * V * 2];
+  const int t = threadIdx.x;
+  const bool active = t < m.rows * m.cols_blk;
+  const int col = t % m.cols_blk, row = t / m.cols_blk;
+  const int colg = blockIdx.y * m.cols_blk + col;
+  const bool work = active && colg < m.cv;
+  double acc[3][V];
+  float ma[V], ia[V], mb[V], ib[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    acc[0][j] = 0.0; acc[1][j] = 0.0; acc[2][j] = 0.0;
+    const int ch = colg * V + j;
+    const bool ok = work && ch < C;
+    ma[j] = ok ? mia[ch] : 0.f; ia[j] = ok ? mia[C + ch] : 0.f;
+    mb[j] = ok ? mib[ch] : 0.f; ib[j] = ok ? mib[C + ch] : 0.f;
+  }
+  if (work) {
+    const long step = (long)gridDim.x * m.rows;
+    const long cofs = (long)colg * V;
+    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += step) {
+      float d[V], va[V], vb[V];
+      ldv<T, V>(dout + p * ldd + cofs, d);
+      ldv<T, V>(ya + p * lda + cofs, va);
+      ldv<T, V>(yb + p * ldb + cofs, vb);
+      if (ro) {
+        float o[V];
+        ldv<T, V>(ro + p * ldr + cofs, o);
+#pragma unroll
+        for (int j = 0; j < V; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        acc[0][j] += d[j];
+        acc[1][j] += d[j] * ((va[j] - ma[j]) * ia[j]);
+        acc[2][j] += d[j] * ((vb[j] - mb[j]) * ib[j]);
+      }
+    }
+  }
+  double* rep = sums + (long)blockIdx.x * 3 * C;
+  double* outs[3] = {rep, rep + C, rep + 2 * C};
+  block_col_reduce<3, V, true>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
+}
+
+// coefficients of both sides from the 3-vector slabs (grid.y = side)
+__global__ void bn_bwd_coeffs2_kernel(const double* __restrict__ sums, int nrep, double inv_count, const float* __restrict__ mia,
+                                      const float* __restrict__ mib, const float* __restrict__ ga, const float* __restrict__ gb,
+                                      float* __restrict__ coa, float* __restrict__ cob, float* dga, float* dba, float* dgb,
+                                      float* dbb, int C) {
+  const int side = blockIdx.y;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gid >> 6, sub = gid & 63;
+  const bool live = c < C;
+  const int cc = live ? c : 0;
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = sub; r < nrep; r += 64) {
+    s0 += sums[(long)r * 3 * C + cc];
+    s1 += sums[(long)r * 3 * C + (side + 1) * C + cc];
+  }
+  s0 = wave_sum_d(s0);
+  s1 = wave_sum_d(s1);
+  if (!live || sub != 0) return;
+  const float* mi = side ? mib : mia;
+  const float* gamma = side ? gb : ga;
+  float* co = side ? cob : coa;
+  float* dgamma = side ? dgb : dga;
+  float* dbeta = side ? dbb : dba;
+  const float mean = mi[c], invstd = mi[C + c];
+  const float g = gamma ? gamma[c] : 1.f;
+  const float m0 = (float)(s0 * inv_count), m1 = (float)(s1 * inv_count);
+  const float k1 = g * invstd;
+  co[c] = k1;
+  co[C + c] = -k1 * invstd * m1;
+  co[2 * C + c] = k1 * (mean * invstd * m1 - m0);
+  if (dgamma) dgamma[c] = (float)s1;
+  if (dbeta) dbeta[c] = (float)s0;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ ya,
+                                                            long lda, const T* __restrict__ yb, long ldb,
+                                                            const T* __restrict__ ro, long ldr, const float* __restrict__ coa,
+                                                            const float* __restrict__ cob, T* __restrict__ dya, long ldoa,
+                                                            T* __restrict__ dyb, long ldob, long npix, int C, ColMap m) {
+  const int t = threadIdx.x;
+  if (t >= m.rows * m.cols_blk) return;
+  const int col = t % m.cols_blk, row = t / m.cols_blk;
+  const int colg = blockIdx.y * m.cols_blk + col;
+  if (colg >= m.cv) return;
+  const int c0 = colg * V;
+  float aa[V], ab[V], ac[V], ba[V], bb[V], bc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    aa[j] = coa[c0 + j]; ab[j] = coa[C + c0 + j]; ac[j] = coa[2 * C + c0 + j];
+    ba[j] = cob[c0 + j]; bb[j] = cob[C + c0 + j]; bc[j] = cob[2 * C + c0 + j];
+  }
+  const long step = (long)gridDim.x * m.rows;
+  for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += step) {
+    float d[V], va[V], vb[V], o[V];
+    ldv<T, V>(dout + p * ldd + c0, d);
+    ldv<T, V>(ya + p * lda + c0, va);
+    ldv<T, V>(yb + p * ldb + c0, vb);
+    if (ro) {
+      float r[V];
+      ldv<T, V>(ro + p * ldr + c0, r);
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] = r[j] > 0.f ? d[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = fmaf(aa[j], d[j], fmaf(ab[j], va[j], ac[j]));
+    stv<T, V>(dya + p * ldoa + c0, o);
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = fmaf(ba[j], d[j], fmaf(bb[j], vb[j], bc[j]));
+    stv<T, V>(dyb + p * ldob + c0, o);
+  }
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void scale_mask_kernel(const T* __restrict__ dout, long ldd, const float* __restrict__ scale,
                                                          const T* __restrict__ ro, long ldr, T* __restrict__ dx, long ldo,
@@ -525,6 +650,54 @@ extern "C" int npp_bn_bwd_apply(const NppTensor* dout, const NppTensor* y_raw, c
                        (T*)dy_raw->ptr, (long)dy_raw->ld, (long)npix(dout), (int)dout->c, m);
   });
   return npp_check_launch("bn_bwd_apply");
+}
+
+extern "C" int npp_bn_bwd_reduce2(const NppTensor* dout, const NppTensor* ya, const NppTensor* yb, const NppTensor* relu_out,
+                                  const float* mi_a, const float* mi_b, double* partials, int nblocks, void* stream) {
+  NPP_REQUIRE(dout && ya && yb && mi_a && mi_b && partials && nblocks >= 1, NPP_E_NULL, "npp_bn_bwd_reduce2: bad arguments");
+  NPP_REQUIRE(same_shape(dout, ya) && same_shape(dout, yb) && (!relu_out || same_shape(dout, relu_out)), NPP_E_SHAPE,
+              "npp_bn_bwd_reduce2: shape mismatch");
+  NPP_REQUIRE(dtype_ok(dout) && dout->dtype == ya->dtype && dout->dtype == yb->dtype, NPP_E_DTYPE, "npp_bn_bwd_reduce2: dtype mismatch");
+  const bool vk = vec_ok(dout) && vec_ok(ya) && vec_ok(yb) && (!relu_out || vec_ok(relu_out));
+  ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 3);
+  NPP_DISPATCH_TV(dout->dtype, vk, {
+    ColMap m = col_map(dout->c, V);
+    dim3 grid((unsigned)nblocks, (unsigned)((m.cv + m.cols_blk - 1) / m.cols_blk));
+    hipLaunchKernelGGL((bn_bwd_reduce2_kernel<T, V>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dout->ptr,
+                       (long)dout->ld, (const T*)ya->ptr, (long)ya->ld, (const T*)yb->ptr, (long)yb->ld,
+                       relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, mi_a, mi_b,
+                       (long)npix(dout), (int)dout->c, m, partials);
+  });
+  return npp_check_launch("bn_bwd_reduce2");
+}
+
+extern "C" int npp_bn_bwd_coeffs2(const double* sums, int nrep, double count, const float* mi_a, const float* mi_b,
+                                  const float* gamma_a, const float* gamma_b, float* coeffs_a, float* coeffs_b, float* dgamma_a,
+                                  float* dbeta_a, float* dgamma_b, float* dbeta_b, int c, void* stream) {
+  NPP_REQUIRE(sums && mi_a && mi_b && coeffs_a && coeffs_b && c > 0 && count > 0 && nrep >= 1, NPP_E_NULL,
+              "npp_bn_bwd_coeffs2: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_coeffs2_kernel, dim3((c * 64 + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, sums, nrep,
+                     1.0 / count, mi_a, mi_b, gamma_a, gamma_b, coeffs_a, coeffs_b, dgamma_a, dbeta_a, dgamma_b, dbeta_b, c);
+  return npp_check_launch("bn_bwd_coeffs2");
+}
+
+extern "C" int npp_bn_bwd_apply2(const NppTensor* dout, const NppTensor* ya, const NppTensor* yb, const NppTensor* relu_out,
+                                 const float* coeffs_a, const float* coeffs_b, NppTensor* dya, NppTensor* dyb, void* stream) {
+  NPP_REQUIRE(dout && ya && yb && coeffs_a && coeffs_b && dya && dyb, NPP_E_NULL, "npp_bn_bwd_apply2: null pointer");
+  NPP_REQUIRE(same_shape(dout, ya) && same_shape(dout, yb) && same_shape(dout, dya) && same_shape(dout, dyb) &&
+              (!relu_out || same_shape(dout, relu_out)), NPP_E_SHAPE, "npp_bn_bwd_apply2: shape mismatch");
+  NPP_REQUIRE(dtype_ok(dout) && dout->dtype == ya->dtype && dout->dtype == yb->dtype && dout->dtype == dya->dtype &&
+              dout->dtype == dyb->dtype, NPP_E_DTYPE, "npp_bn_bwd_apply2: dtype mismatch");
+  const bool vk = vec_ok(dout) && vec_ok(ya) && vec_ok(yb) && vec_ok(dya) && vec_ok(dyb) && (!relu_out || vec_ok(relu_out));
+  ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 5);
+  NPP_DISPATCH_TV(dout->dtype, vk, {
+    ColMap m = col_map(dout->c, V);
+    hipLaunchKernelGGL((bn_bwd_apply2_kernel<T, V>), col_grid_ew(m, npix(dout)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)dout->ptr, (long)dout->ld, (const T*)ya->ptr, (long)ya->ld, (const T*)yb->ptr, (long)yb->ld,
+                       relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, coeffs_a, coeffs_b,
+                       (T*)dya->ptr, (long)dya->ld, (T*)dyb->ptr, (long)dyb->ld, (long)npix(dout), (int)dout->c, m);
+  });
+  return npp_check_launch("bn_bwd_apply2");
 }
 
 extern "C" int npp_scale_mask(const NppTensor* dout, const float* scale, const NppTensor* relu_out, NppTensor* dx,
