@@ -122,6 +122,15 @@ int npp_bn_finalize(const double* stats, int nrep, double count, const float* ga
                     float* running_mean, float* running_var, int64_t* num_batches_tracked /* += 1 */,
                     float momentum, float eps,
                     float* scale_shift /*[2C]*/, float* mean_invstd /*[2C]*/, int c, void* stream);
+/* npp_bn_finalize for the two BatchNorms of out = BN_a(a) + BN_b(b) in one launch (same channel count). */
+typedef struct NppBnFinalizeArgs {
+  const double* stats; const float* gamma; const float* beta;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* scale_shift; float* mean_invstd;
+  double count;
+  int32_t nrep; float momentum; float eps; int32_t _pad;
+} NppBnFinalizeArgs;
+int npp_bn_finalize2(const NppBnFinalizeArgs* a, const NppBnFinalizeArgs* b, int c, void* stream);
 /* eval mode: scale/shift from the running statistics */
 int npp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale_shift, int c, void* stream);

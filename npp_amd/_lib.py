@@ -30,6 +30,13 @@ class NppConvGeom(C.Structure):
                 ("pw", C.c_int32), ("dh", C.c_int32), ("dw", C.c_int32), ("uph", C.c_int32), ("upw", C.c_int32), ("relu_in", C.c_int32)]
 
 
+class NppBnFinalizeArgs(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("scale_shift", C.c_void_p),
+                ("mean_invstd", C.c_void_p), ("count", C.c_double), ("nrep", C.c_int32), ("momentum", C.c_float),
+                ("eps", C.c_float), ("_pad", C.c_int32)]
+
+
 class NppAdamJob(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("n", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
@@ -67,6 +74,7 @@ _SIGS = {
 
     "npp_bn_bwd_coeffs": [_P, C.c_int, C.c_double, _P, _P, _P, _P, _P, C.c_int, _P],
     "npp_bn_bwd_sum": [_P, C.c_int, _P, _P, _P, C.c_int, _P],
+    "npp_bn_finalize2": [_P, _P, C.c_int, _P],
     "npp_bn_bwd_reduce2": [_T, _T, _T, _T, _P, _P, _P, C.c_int, _P],
     "npp_bn_bwd_coeffs2": [_P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P],
     "npp_bn_bwd_apply2": [_T, _T, _T, _T, _P, _P, _T, _T, _P],

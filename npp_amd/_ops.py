@@ -576,41 +576,68 @@ def _presync_stats(sides, training: bool):
             sd.synced_ws = ws
 
 
+def _bn_finalize_args(side: BnSide, training: bool, device):
+    """Everything npp_bn_finalize needs for one side that normalises with batch statistics (None otherwise): the
+    argument struct plus the tensors it points to (kept alive by the caller)."""
+    bn = side.bn
+    if not (training or bn.running_mean is None):
+        return None
+    c = side.x.shape[1]
+    if not side.synced_ws:
+        _presync_stats((side,), training)     # SyncBatchNorm: all-reduce (computing the statistics if need be)
+    if side.stats is None:
+        side.stats = channel_stats(side.x)
+    stats = side.stats
+    nrep = stats.numel() // (2 * c)
+    count = float(side.x.shape[0] * side.x.shape[2] * side.x.shape[3])
+    if side.synced_ws:            # all-reduced: the replicas now hold global partial sums
+        count *= side.synced_ws
+    side.count = count
+    ss = torch.empty(2 * c, dtype=torch.float32, device=device)
+    mi = torch.empty(2 * c, dtype=torch.float32, device=device)
+    gamma = bn.weight.detach() if bn.weight is not None else None
+    beta = bn.bias.detach() if bn.bias is not None else None
+    track = bn.track_running_stats and bn.running_mean is not None and training
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
+    args = L.NppBnFinalizeArgs(stats.data_ptr(), ptr(gamma), ptr(beta), ptr(bn.running_mean) if track else None,
+                               ptr(bn.running_var) if track else None, ptr(nbt), ss.data_ptr(), mi.data_ptr(), count, nrep,
+                               float(mom), float(bn.eps), 0)
+    return args, ss, mi, (stats, gamma, beta)
+
+
 def _bn_coeffs(side: BnSide, training: bool, device):
     """scale/shift (+ mean/invstd) for one BN side; updates running stats in train mode."""
     bn = side.bn
     c = side.x.shape[1]
+    prep = _bn_finalize_args(side, training, device)
+    if prep is not None:
+        a, ss, mi, _keep = prep
+        check(lib().npp_bn_finalize(a.stats, a.nrep, a.count, a.gamma, a.beta, a.running_mean, a.running_var,
+                                    a.num_batches_tracked, a.momentum, a.eps, a.scale_shift, a.mean_invstd, c, stream_ptr()),
+              "npp_bn_finalize")
+        return ss, mi, True
     ss = torch.empty(2 * c, dtype=torch.float32, device=device)
     gamma = bn.weight.detach() if bn.weight is not None else None
     beta = bn.bias.detach() if bn.bias is not None else None
-    s = stream_ptr()
-    use_batch = training or bn.running_mean is None
-    if use_batch:
-        if not side.synced_ws:
-            _presync_stats((side,), training)     # SyncBatchNorm: all-reduce (computing the statistics if need be)
-        if side.stats is None:
-            side.stats = channel_stats(side.x)
-        stats = side.stats
-        nrep = stats.numel() // (2 * c)
-        count = float(side.x.shape[0] * side.x.shape[2] * side.x.shape[3])
-        if side.synced_ws:            # all-reduced: the replicas now hold global partial sums
-            count *= side.synced_ws
-        side.count = count
-        mi = torch.empty(2 * c, dtype=torch.float32, device=device)
-        track = bn.track_running_stats and bn.running_mean is not None and training
-        mom = bn.momentum if bn.momentum is not None else 0.1
-        nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
-        check(lib().npp_bn_finalize(stats.data_ptr(), nrep, count, ptr(gamma), ptr(beta),
-                                    ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
-                                    ptr(nbt), float(mom), float(bn.eps), ss.data_ptr(), mi.data_ptr(), c, s),
-              "npp_bn_finalize")
-        return ss, mi, True
     check(lib().npp_bn_eval_coeffs(ptr(gamma), ptr(beta), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                                   float(bn.eps), ss.data_ptr(), c, s), "npp_bn_eval_coeffs")
+                                   float(bn.eps), ss.data_ptr(), c, stream_ptr()), "npp_bn_eval_coeffs")
     mi = None
     if torch.is_grad_enabled():   # mean / invstd for the (rare) backward in eval mode
         mi = torch.cat([bn.running_mean.detach().float(), torch.rsqrt(bn.running_var.detach().float() + bn.eps)])
     return ss, mi, False
+
+
+def _bn_coeffs_pair(sa: BnSide, sb: BnSide, training: bool, device):
+    """Both sides of a two-sided add: one npp_bn_finalize2 launch when both use batch statistics."""
+    use_a = training or sa.bn.running_mean is None
+    use_b = training or sb.bn.running_mean is None
+    if use_a and use_b and sa.x.shape[1] == sb.x.shape[1]:
+        pa = _bn_finalize_args(sa, training, device)
+        pb = _bn_finalize_args(sb, training, device)
+        check(lib().npp_bn_finalize2(C.byref(pa[0]), C.byref(pb[0]), sa.x.shape[1], stream_ptr()), "npp_bn_finalize2")
+        return (pa[1], pa[2], True), (pb[1], pb[2], True)
+    return _bn_coeffs(sa, training, device), _bn_coeffs(sb, training, device)
 
 
 class _BnAdd(Function):
@@ -622,10 +649,13 @@ class _BnAdd(Function):
         ssa = mia = ssb = mib = None
         batch_a = batch_b = False
         _presync_stats((sa, sb), training)
-        if sa.bn is not None:
-            ssa, mia, batch_a = _bn_coeffs(sa, training, dev)
-        if sb is not None and sb.bn is not None:
-            ssb, mib, batch_b = _bn_coeffs(sb, training, dev)
+        if sa.bn is not None and sb is not None and sb.bn is not None:
+            (ssa, mia, batch_a), (ssb, mib, batch_b) = _bn_coeffs_pair(sa, sb, training, dev)
+        else:
+            if sa.bn is not None:
+                ssa, mia, batch_a = _bn_coeffs(sa, training, dev)
+            if sb is not None and sb.bn is not None:
+                ssb, mib, batch_b = _bn_coeffs(sb, training, dev)
         y = new_nhwc(*a.shape, a.dtype, dev)
         check(lib().npp_affine_add(_byref(y), _byref(a), ptr(ssa), tref(b), ptr(ssb), int(relu), stream_ptr()),
               "npp_affine_add")

@@ -172,6 +172,35 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int nrep, d
   }
 }
 
+// both BatchNorms of a two-sided add in one launch (grid.y = side)
+struct Fin2 {
+  NppBnFinalizeArgs s[2];
+};
+__global__ void bn_finalize2_kernel(Fin2 f, int C) {
+  const NppBnFinalizeArgs& a = f.s[blockIdx.y];
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gid >> 4, sub = gid & 15;
+  long* nbt = reinterpret_cast<long*>(a.num_batches_tracked);
+  if (gid == 0 && nbt) nbt[0] += 1;
+  const bool live = c < C;
+  double s0, s1;
+  replica_sum(a.stats, a.nrep, C, live ? c : 0, sub, s0, s1);
+  if (!live || sub != 0) return;
+  const double mean = s0 / a.count;
+  double var = s1 / a.count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)a.eps);
+  const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
+  a.scale_shift[c] = (float)(g * invstd);
+  a.scale_shift[C + c] = (float)(b - mean * g * invstd);
+  if (a.mean_invstd) { a.mean_invstd[c] = (float)mean; a.mean_invstd[C + c] = (float)invstd; }
+  if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+  if (a.running_var) {
+    const double unb = a.count > 1.0 ? var * (a.count / (a.count - 1.0)) : var;
+    a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+  }
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                       float* ss, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -558,6 +587,16 @@ extern "C" int npp_bn_finalize(const double* stats, int nrep, double count, cons
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((c * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, nrep, count, gamma,
                      beta, running_mean, running_var, (long*)num_batches_tracked, momentum, eps, scale_shift, mean_invstd, c);
   return npp_check_launch("bn_finalize");
+}
+
+extern "C" int npp_bn_finalize2(const NppBnFinalizeArgs* a, const NppBnFinalizeArgs* b, int c, void* stream) {
+  NPP_REQUIRE(a && b && a->stats && b->stats && a->scale_shift && b->scale_shift && c > 0 && a->count > 0 && b->count > 0,
+              NPP_E_NULL, "npp_bn_finalize2: bad arguments");
+  Fin2 f;
+  f.s[0] = *a;
+  f.s[1] = *b;
+  hipLaunchKernelGGL(bn_finalize2_kernel, dim3((c * 16 + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, f, c);
+  return npp_check_launch("bn_finalize2");
 }
 
 extern "C" int npp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,

@@ -44,6 +44,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.NppConvGeom) == 44        # 11 x int32
     assert C.sizeof(_lib.NppAdamJob) == 64
     assert C.sizeof(_lib.NppPackJob) == 48
+    assert C.sizeof(_lib.NppBnFinalizeArgs) == 88  # 8 pointers + double + int32 + 2 floats + pad
 
 
 def test_bad_arguments_fail_loudly_without_a_gpu(lib):
