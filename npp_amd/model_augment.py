@@ -387,7 +387,7 @@ class Network(nn.Module):
         # launch ordering adds two-way edges between the user stream and its internal stream, which this ROCm only
         # survives on the origin), and funnelling the side branch's ~430 exchanges through it serialises the branches
         # (measured: 103 ms vs 83 ms).  So multi-rank SyncBN runs single-stream.
-        mode = _stream_mode() if not self._sync_bn_active() else 1
+        mode = _stream_mode() if not self._sync_bn_active() else (3 if os.environ.get("NPP_SYNCBN_STREAMS") == "3" else 1)
         two = mode >= 2
         K._helper_uses = 0
         K._hub_offload = None
