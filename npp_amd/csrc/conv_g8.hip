@@ -1,0 +1,516 @@
+// Stride-1 "same" convolution (1x1 / 3x3 / 5x5, dilation 1), bf16, as ONE deep-pipelined implicit GEMM:
+// the kernel for the large feature maps (>= ~190 output tiles) that carry most of NPPNet's FLOPs -- the 1024->512/384
+// and 512->256 heads, the 512->128 / 384->128 fuse-cell inputs, the 128->128 3x3 cell ops at 96^2 -- forward and
+// data-gradient (the data gradient of a stride-1 conv is the same conv over dy with flipped taps, IgemmParams as for
+// conv_s1.hip).  Replaces: models/operations.py:69-82 (ReLUConvBN conv), model_augment.py:332-398 (head 1x1 convs).
+//
+// Structure (cdna_hip_programming.md section 5, the 256^2 8-phase schedule, re-derived for a conv):
+//   * C[m][n] = sum_k A[m][k] B[n][k]:  m = output pixel, n = output channel, k = (tap, input channel).  A K-tile is 64
+//     channels of ONE tap: its A rows are the pixels of the tile shifted by the tap offset, rows that fall off the
+//     image read a zero page -- a per-lane SOURCE-address select, no mask in the MFMA loop.
+//   * 256 x BN tile (BN = 256: 8 waves as 2(M) x 4(N), 128 x 64 per wave; BN = 128: 4 x 2, 64 x 64 per wave),
+//     v_mfma_f32_16x16x32_bf16, two LDS buffers of one K-tile each.  Every operand goes HBM/L2 -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers, no ds_write); the image is 1-KiB pieces of 8 rows x 128 B whose
+//     16-byte slots are XOR-swizzled by (row & 7) on the SOURCE address and on the fragment read (rule 21), so every
+//     DMA instruction fetches eight whole 128-byte lines and every ds_read_b128 fragment is bank-conflict-free.
+//   * A K-tile is four "half-tiles" (A0/A1: the first/second 32- or 64-row half of every wave's rows; B0/B1: the
+//     first/second 32 columns of every wave's columns) and four phases, one C quadrant each:
+//         p1: read A0,B0   mma(0,0)        p2: read B1      mma(0,1)
+//         p3: read A1      mma(1,1)        p4: (registers)  mma(1,0)
+//     phase = { ds_reads ; one half-tile of LDS-DMA ; counted vmcnt ; s_barrier ; lgkmcnt(0) ; 8/16 MFMA ; s_barrier }.
+//     Half-tile X of K-tile t+2 is re-staged two phases after its last read in K-tile t (p3: A0, p4: B0, next p1: B1,
+//     next p2: A1), so four half-tiles are always in flight across the barriers and the wait is a counted
+//     vmcnt(4 + 2*NB), never 0.  Waves 4-7 (the second wave of every SIMD) run one barrier behind waves 0-3, so one
+//     group's MFMA cluster overlaps the other's reads and DMA issue.
+//   * Persistent over output tiles in XCD-contiguous order, N-tile fastest; the K-tile stream runs straight across
+//     output tiles (the next tile's first two K-tiles are already in flight during the epilogue).
+//   * The MFMA computes C^T (operands swapped), so a lane owns 4 consecutive channels of a pixel; after bf16 packing a
+//     v_permlane16_swap widens that to 8 channels = one 16-byte store: the epilogue touches no LDS and has no barrier.
+//     Bias, rounding, ReLU-backward mask (packed int16 ops) and the BatchNorm sum / sum-of-squares of the STORED values
+//     (DPP row reduction, per-wave LDS accumulators kept across the block's tiles, f64 atomics when the N-tile changes).
+#include "common.h"
+#include "conv_params.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct G8Extra {
+  int taps, nchunks, nk;  // K-tiles per output tile = taps * nchunks
+  int P;                  // (KH-1)/2
+  int HW;
+  int total_tiles;
+  unsigned xbytes, wbytes;  // extents of the two buffer descriptors
+};
+
+#define G8_DMA(rsrc, voff, soff, ldsoff)                                                                  \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (ldsoff)), 16, voff, soff, 0, 0)
+
+NPP_DEV u32x4 relu_bf16x8(u32x4 v) {
+  s16x8 s = __builtin_bit_cast(s16x8, v);
+  const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  s = __builtin_elementwise_max(s, z);
+  return __builtin_bit_cast(u32x4, s);
+}
+
+// BN: output channels per tile; RELU: ReLU on the input operand; TAPS: KxK (per-tap pixel shift + border test)
+// DBG (timing experiments only, NPP_G8_DBG): 1 = no epilogue, 2 = no MFMA, 4 = no DMA, 8 = no fragment reads
+template <int BN, bool RELU, bool TAPS, int DBG = 0>
+__global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) {
+  constexpr int BM = 256;
+  constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N;
+  constexpr int WM = BM / WAVES_M;            // rows per wave: 128 / 64
+  constexpr int HM = WM / 2;                  // rows per wave per A half: 64 / 32
+  constexpr int MQ = HM / 16;                 // m-fragments per quadrant: 4 / 2
+  constexpr int NQ = 2;                       // n-fragments per quadrant (32 columns)
+  constexpr int AH = 128 * 128;               // bytes per A half-tile (128 rows x 128 B)
+  constexpr int BH = WAVES_N * 32 * 128;      // bytes per B half-tile: 16384 / 8192
+  constexpr int BUF = 65536;                  // LDS stride between the two K-tile buffers (a power of two: toggled by XOR)
+  constexpr int NB = BH / 8192;               // DMA instructions per wave per B half: 2 / 1
+  constexpr int STA = 2 * BUF;                // per-wave BatchNorm statistics (8 x 512 B)
+  constexpr int WAITN = 4 + 2 * NB;           // DMA instructions a wave may leave in flight at a counted wait
+  static_assert(2 * AH + 2 * BH <= BUF, "K-tile must fit its buffer");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int grp = wave >> 2;
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, e.wbytes, 0x00020000);
+
+  // ---- fragment read offsets (bytes inside a half-tile) ----------------------------------------------------
+  const int lrow = lane & 15, lk = lane >> 4;
+  const unsigned loff0 = (lrow >> 3) * 1024 + (lrow & 7) * 128 + ((lk ^ (lrow & 7)) << 4);   // k-block 0; k-block 1 = ^64
+  unsigned rdA0 = wm * (HM / 8) * 1024 + loff0;               // + h*AH + mi*2048   (current buffer folded in by XOR)
+  unsigned rdA1 = wm * (HM / 8) * 1024 + (loff0 ^ 64);
+  unsigned rdB0 = 2 * AH + wn * 4096 + loff0;                 // + h*BH + ni*2048
+  unsigned rdB1 = 2 * AH + wn * 4096 + (loff0 ^ 64);
+
+  // ---- staging roles ------------------------------------------------------------------------------------
+  // A half h: DMA instruction i of this wave fills piece c = wave*2+i = half-rows [8c, 8c+8); lane -> half-row 8c + (lane>>3),
+  // 16-byte slot lane&7 holding source piece (lane&7)^(lane>>3).  Half-row hr is tile row (hr/HM)*WM + h*HM + hr%HM.
+  // B half h: piece c = wave*NB+i; half-row hr is tile column (hr/32)*64 + h*32 + hr%32; the four (h,i) rows of a lane
+  // are at constant column distances from the first, so ONE per-lane offset + a scalar offset addresses them all.
+  const int sl = lane >> 3, spb = (((lane & 7) ^ sl) * 16);   // row within piece, source piece (bytes)
+
+  // staging stream state: output tile (descriptors below), K-tile (tap, chunk) inside it
+  int s_tile = blockIdx.x;
+  bool stage_on = (DBG & 4) ? false : (s_tile < e.total_tiles);
+  int s_tap = 0, s_chunk = 0, s_dy = -e.P, s_dx = -e.P;
+  unsigned abyte[2][2];   // byte offset of the row's pixel (+ source piece) in x
+  int ayx[2][2];          // (y << 16) | x of the pixel (TAPS only); y = 0x4000 marks "no such pixel"
+  unsigned bbyte;         // byte offset of the lane's first weight row (+ source piece)
+  int sbuf = 0;           // LDS byte offset of the buffer the NEXT K-tile's first half goes to (toggles per K-tile)
+
+  auto tile_coords = [&](int tile, int& m0, int& n0) {
+    const int xcd = tile & 7, qd = e.total_tiles >> 3, rm = e.total_tiles & 7;
+    const int lid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (tile >> 3);
+    m0 = (lid / p.ntiles) * BM;
+    n0 = (lid % p.ntiles) * BN;
+  };
+  auto setup_stage_tile = [&]() {
+    int m0, n0;
+    tile_coords(s_tile, m0, n0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int hr = (wave * 2 + i) * 8 + sl;
+        int q = m0 + (hr / HM) * WM + h * HM + hr % HM;
+        const bool real = q < p.M;
+        if (!real) q = p.M - 1;                      // rows past the end read a real pixel; they are never stored
+        abyte[h][i] = (unsigned)q * (unsigned)p.ldx * 2u + spb;
+        if (TAPS) {
+          const int rem = q % e.HW;
+          const int y = rem / p.W;
+          ayx[h][i] = real ? ((y << 16) | (rem - y * p.W)) : (0x4000 << 16);
+        }
+      }
+    const int hr0 = wave * NB * 8 + sl;
+    bbyte = (unsigned)(n0 + (hr0 / 32) * 64 + hr0 % 32) * (unsigned)p.Kpad * 2u + spb;
+  };
+  // one half-tile of the staging stream into the buffer at LDS offset `lb`
+  auto stage_A = [&](int lb, int h) {
+    if (!stage_on) return;
+    const int koff = s_chunk * 128 + (TAPS ? (s_dy * p.W + s_dx) * (int)p.ldx * 2 : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned v = abyte[h][i] + (unsigned)koff;
+      if (TAPS) {
+        const int y = (ayx[h][i] >> 16) + s_dy, x = (ayx[h][i] & 0xFFFF) + s_dx;
+        if (!((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)) v = 0xFFFFFFFFu;   // out of range: the DMA writes zeros
+      }
+      G8_DMA(rs_x, v, 0, lb + h * AH + (wave * 2 + i) * 1024);
+    }
+  };
+  auto stage_B = [&](int lb, int h) {
+    if (!stage_on) return;
+    const int koff = (s_tap * p.Cp + s_chunk * 64) * 2;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)     // rows +8*i, +32*h of the lane's first row: a scalar offset
+      G8_DMA(rs_w, bbyte, koff + (h * 32 + i * 8) * p.Kpad * 2, lb + 2 * AH + h * BH + (wave * NB + i) * 1024);
+  };
+  auto stage_advance = [&]() {     // after the last half-tile (A1) of a K-tile
+    if (!stage_on) return;
+    if (++s_chunk == e.nchunks) {
+      s_chunk = 0;
+      ++s_tap;
+      if (++s_dx > e.P) { s_dx = -e.P; ++s_dy; }
+      if (s_tap == e.taps) {
+        s_tap = 0; s_dy = -e.P; s_dx = -e.P;
+        s_tile += gridDim.x;
+        stage_on = s_tile < e.total_tiles;
+        if (stage_on) setup_stage_tile();
+      }
+    }
+  };
+  // counted wait: valid while every phase so far has issued its half-tile; afterwards drain
+  auto stage_wait = [&]() {
+    if (stage_on) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  // ---- compute stream state ------------------------------------------------------------------------------
+  int c_tile = blockIdx.x, c_k = 0;
+  int m0c = 0, n0c = 0;
+  tile_coords(c_tile, m0c, n0c);
+  f32x4v acc[2][2][MQ][NQ];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int mi = 0; mi < MQ; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NQ; ++ni) acc[a][b][mi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  // BatchNorm statistics of the stored values: per wave, per column of the current N-tile, in LDS: [b][ni][16 cols][sum, sq]
+  float* const sta = reinterpret_cast<float*>(smem + STA + wave * 512);
+  sta[lane] = 0.f; sta[lane + 64] = 0.f;
+  int st_n0 = -1;
+
+  auto flush_stats = [&]() {
+    if (st_n0 >= 0) {
+      const int cl = lane;       // column of the wave's 64: (b, ni, lrow) = (cl>>5, (cl>>4)&1, cl&15)
+      const float s = sta[cl * 2], q = sta[cl * 2 + 1];
+      const int col = st_n0 + wn * 64 + cl;
+      if (col < p.Cout) {
+        double* st = p.stats + (long)(blockIdx.x % NPP_STAT_REPLICAS) * 2 * p.Cout;
+        atomicAdd(st + col, (double)s);
+        atomicAdd(st + p.Cout + col, (double)q);
+      }
+      sta[lane] = 0.f; sta[lane + 64] = 0.f;
+    }
+  };
+
+  // Accumulators are C^T fragments (mfma(B, A)): acc[a][b][mi][ni][j] = C[pixel rowbase(a,mi) + lrow][channel
+  // colbase(b,ni) + 4*lk + j]: a lane owns 4 consecutive channels of one pixel per fragment.  After packing to bf16, one
+  // v_permlane16_swap per dword pairs lanes lk <-> lk^1 so that every lane holds 8 consecutive channels (16 bytes):
+  // even lk: channels [4lk, 4lk+8) of the ni=0 fragment, odd lk: [16 + 4(lk-1), +8) of the ni=1 fragment.  No LDS.
+  auto epilogue = [&]() {
+    bf16_t* __restrict__ yg = reinterpret_cast<bf16_t*>(p.y);
+    const bf16_t* __restrict__ mg = reinterpret_cast<const bf16_t*>(p.mask);
+    const bool want_stats = p.stats != nullptr;
+    if (want_stats && st_n0 != n0c) { flush_stats(); st_n0 = n0c; }
+    const int chb = (lk & 1) * 16 + (lk >> 1) * 8;            // channel (within the 32-block) of the lane's 16-byte store
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int cb = n0c + wn * 64 + b * 32;
+      f32x4v bias[NQ];
+#pragma unroll
+      for (int ni = 0; ni < NQ; ++ni)
+        bias[ni] = p.bias ? *reinterpret_cast<const f32x4v*>(p.bias + cb + ni * 16 + lk * 4) : f32x4v{0.f, 0.f, 0.f, 0.f};
+      float ss[NQ][4], sq[NQ][4];
+#pragma unroll
+      for (int ni = 0; ni < NQ; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ss[ni][j] = 0.f; sq[ni][j] = 0.f; }
+      // ReLU-backward mask of this 32-channel block: all 2*MQ loads in flight at once (the main loop's fragment
+      // registers are free here); one load per store would pay the memory latency 2*MQ times per block
+      u32x4 mk[2][MQ];
+      if (mg) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int mi = 0; mi < MQ; ++mi) {
+            const long gm = (long)m0c + wm * WM + a * HM + mi * 16 + lrow;
+            mk[a][mi] = gm < p.M ? *reinterpret_cast<const u32x4*>(mg + gm * p.ldm + cb + chb) : u32x4{0u, 0u, 0u, 0u};
+          }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int mi = 0; mi < MQ; ++mi) {
+          const long gm = (long)m0c + wm * WM + a * HM + mi * 16 + lrow;
+          const bool live = gm < p.M;
+          unsigned pk[NQ][2];
+#pragma unroll
+          for (int ni = 0; ni < NQ; ++ni) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = acc[a][b][mi][ni][j] + bias[ni][j]; acc[a][b][mi][ni][j] = 0.f; }
+            pk[ni][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            pk[ni][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            if (want_stats && live) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float r = __uint_as_float((j & 1) ? (pk[ni][j >> 1] & 0xFFFF0000u) : (pk[ni][j >> 1] << 16));
+                ss[ni][j] += r; sq[ni][j] += r * r;
+              }
+            }
+          }
+          const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+          u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+          if (live) {
+            if (mg) {      // ReLU backward: keep where the forward input was positive (bf16 > 0 <=> int16 > 0)
+              const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+              s16x8 m = __builtin_elementwise_max(__builtin_bit_cast(s16x8, mk[a][mi]), z);
+              m = (z - m) >> 15;                               // 0xFFFF where the mask value was positive
+              o = o & __builtin_bit_cast(u32x4, m);
+            }
+            *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
+          }
+        }
+      if (want_stats) {
+#pragma unroll
+        for (int ni = 0; ni < NQ; ++ni)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float s = ss[ni][j], q = sq[ni][j];
+            // sum over the 16 pixel lanes of the row: quad xor 1, xor 2, half-row mirror, row mirror (all DPP)
+#define G8_DPP_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true))
+            G8_DPP_ADD(s, 0xB1); G8_DPP_ADD(q, 0xB1);
+            G8_DPP_ADD(s, 0x4E); G8_DPP_ADD(q, 0x4E);
+            G8_DPP_ADD(s, 0x141); G8_DPP_ADD(q, 0x141);
+            G8_DPP_ADD(s, 0x140); G8_DPP_ADD(q, 0x140);
+#undef G8_DPP_ADD
+            ss[ni][j] = s; sq[ni][j] = q;
+          }
+        if (lrow == 0) {
+#pragma unroll
+          for (int ni = 0; ni < NQ; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float* d = sta + (b * 32 + ni * 16 + lk * 4 + j) * 2;
+              d[0] += ss[ni][j]; d[1] += sq[ni][j];
+            }
+        }
+      }
+    }
+  };
+
+  // ---- prologue: K-tiles 0 and 1 (first two halves) of the stream -----------------------------------------
+  if (stage_on) setup_stage_tile();
+  stage_A(0, 0); stage_B(0, 0); stage_B(0, 1); stage_A(0, 1); stage_advance();
+  stage_A(BUF, 0); stage_B(BUF, 0);
+  stage_wait();
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+
+  u32x4 fa[MQ][2] = {}, fb0[NQ][2] = {}, fb1[NQ][2] = {};
+
+#define G8_READ_A(h)                                                                                      \
+  if (!(DBG & 8)) _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) {                                                     \
+    fa[mi][0] = *reinterpret_cast<const u32x4*>(smem + rdA0 + (h) * AH + mi * 2048);                      \
+    fa[mi][1] = *reinterpret_cast<const u32x4*>(smem + rdA1 + (h) * AH + mi * 2048);                      \
+  }
+#define G8_READ_B(dst, h)                                                                                 \
+  if (!(DBG & 8)) _Pragma("unroll") for (int ni = 0; ni < NQ; ++ni) {                                                     \
+    dst[ni][0] = *reinterpret_cast<const u32x4*>(smem + rdB0 + (h) * BH + ni * 2048);                     \
+    dst[ni][1] = *reinterpret_cast<const u32x4*>(smem + rdB1 + (h) * BH + ni * 2048);                     \
+  }
+// MFMAs of one quadrant, m-fragment major.  With RELU the packed-int16 max of fragment mi+1 (8 VALU) is pinned into
+// the issue shadow of fragment mi's four MFMAs (2 VALU per MFMA gap) instead of standing in front of the cluster.
+#define G8_MMA(qa, qb, fbx, DO_RELU)                                                                      \
+  if (!(DBG & 2)) {                                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    if (RELU && (DO_RELU)) { fa[0][0] = relu_bf16x8(fa[0][0]); fa[0][1] = relu_bf16x8(fa[0][1]); }        \
+    _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) {                                                   \
+      if (RELU && (DO_RELU) && mi + 1 < MQ) {                                                             \
+        fa[mi + 1][0] = relu_bf16x8(fa[mi + 1][0]); fa[mi + 1][1] = relu_bf16x8(fa[mi + 1][1]);          \
+      }                                                                                                   \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                    \
+        _Pragma("unroll") for (int ni = 0; ni < NQ; ++ni)                                                 \
+          acc[qa][qb][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                  \
+              __builtin_bit_cast(bf16x8, fbx[ni][kb]), __builtin_bit_cast(bf16x8, fa[mi][kb]), acc[qa][qb][mi][ni], 0, 0, 0); \
+    }                                                                                                     \
+    if (RELU && (DO_RELU)) {                                                                              \
+      __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);                                                    \
+      _Pragma("unroll") for (int i = 0; i < 4 * (MQ - 1); ++i) {                                          \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);                                                  \
+      }                                                                                                   \
+      __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);                                                    \
+    }                                                                                                     \
+    __builtin_amdgcn_s_setprio(0);                                                                        \
+  } else {                                                                                                \
+    _Pragma("unroll") for (int mi = 0; mi < MQ; ++mi) asm volatile("" :: "v"(fa[mi][0]), "v"(fa[mi][1]));  \
+    _Pragma("unroll") for (int ni = 0; ni < NQ; ++ni) asm volatile("" :: "v"(fbx[ni][0]), "v"(fbx[ni][1])); \
+  }
+// the fragment reads are waited for by the compiler's own counted lgkmcnt in front of each consuming MFMA; every read of a
+// phase feeds an MFMA of that phase, so all of them have returned before the phase's closing barrier (WAR rule above)
+#define G8_SYNC_READS()                                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                                      \
+  __builtin_amdgcn_s_barrier();                                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+#define G8_END_PHASE()                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                      \
+  __builtin_amdgcn_s_barrier();                                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // one K-tile per iteration out of the buffer folded into rdA*/rdB*; sbuf = LDS offset of the OTHER buffer
+  sbuf = BUF;
+  for (;;) {
+    /* p1: quadrant (0,0) */
+    G8_READ_B(fb0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    G8_READ_A(0)
+    stage_B(sbuf, 1);
+    stage_wait();
+    G8_SYNC_READS()
+    G8_MMA(0, 0, fb0, true)
+    G8_END_PHASE()
+    /* p2: quadrant (0,1) */
+    G8_READ_B(fb1, 1)
+    stage_A(sbuf, 1);
+    stage_advance();
+    stage_wait();
+    G8_SYNC_READS()
+    G8_MMA(0, 1, fb1, false)
+    G8_END_PHASE()
+    /* p3: quadrant (1,1) */
+    G8_READ_A(1)
+    stage_A(sbuf ^ BUF, 0);
+    G8_SYNC_READS()
+    G8_MMA(1, 1, fb1, true)
+    G8_END_PHASE()
+    /* p4: quadrant (1,0) */
+    stage_B(sbuf ^ BUF, 0);
+    stage_wait();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    G8_MMA(1, 0, fb0, false)
+    rdA0 ^= BUF; rdA1 ^= BUF; rdB0 ^= BUF; rdB1 ^= BUF;
+    sbuf ^= BUF;
+    const bool tile_end = (++c_k == e.nk);
+    const bool last = tile_end && (c_tile + (int)gridDim.x >= e.total_tiles);
+    /* the very last phase: waves 4-7 skip the trailing barrier (waves 0-3 are one barrier ahead) */
+    if (!(last && grp == 1)) { G8_END_PHASE() }
+    if (tile_end) {
+      if (!(DBG & 1)) epilogue();
+      else {   // keep the accumulators (and with them the MFMAs) alive
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int mi = 0; mi < MQ; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NQ; ++ni) asm volatile("" :: "v"(acc[a][b][mi][ni]));
+      }
+      if (last) break;
+      c_k = 0;
+      c_tile += gridDim.x;
+      tile_coords(c_tile, m0c, n0c);
+    }
+  }
+  if (p.stats) flush_stats();
+#undef G8_END_PHASE
+#undef G8_SYNC_READS
+#undef G8_MMA
+#undef G8_READ_B
+#undef G8_READ_A
+}
+
+bool g8_raise_lds(const void* fp, size_t bytes) {
+  static thread_local const void* done[24];
+  for (int i = 0; i < 24; ++i)
+    if (done[i] == fp) return true;
+  if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+  for (int i = 0; i < 24; ++i)
+    if (!done[i]) { done[i] = fp; break; }
+  return true;
+}
+
+}  // namespace
+
+// Eligibility + launch.  Returns false when the shape is left to conv_s1 / the generic kernel.
+bool conv_g8_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
+  static const bool disabled = getenv("NPP_DISABLE_G8") != nullptr;
+  if (disabled || dtype != NPP_BF16) return false;
+  if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.uph != 1 || p.upw != 1) return false;
+  if (p.KH != p.KW || (p.KH & 1) == 0 || p.KH > 5) return false;
+  const int P = (p.KH - 1) / 2;
+  // KxK convs: the kernel re-reads every tap's rows from L2 by LDS-DMA (BN = 128: 48 KiB per 32 MFMAs per wave), which
+  // is DMA-issue bound: measured 94 vs 85 us (fwd) on 128->128 3x3 @96^2 against conv_s1's LDS-resident footprint, so
+  // 3x3 / 5x5 stay on conv_s1 unless NPP_G8_MAXK=3|5
+  static const int max_k = getenv("NPP_G8_MAXK") ? atoi(getenv("NPP_G8_MAXK")) : 1;
+  if (p.KH > max_k) return false;
+  if (p.ph != P || p.pw != P || p.OH != p.H || p.OW != p.W) return false;
+  if (p.Cp != p.Cin || p.Cin % 64 != 0 || p.ldx % 8 != 0) return false;
+  if ((long)p.N * p.H * p.W * p.ldx * 2 >= (1L << 32) - 65536) return false;   // 32-bit byte offsets into x
+  if (!p.vec_io || p.Cout % 8 != 0) return false;
+  if (p.mask && p.stats) return false;                                    // never both on this path (fwd: stats, dgrad: mask)
+  if (p.H >= 32768 || p.W >= 32768) return false;
+  const int npad = (p.Cout + 31) / 32 * 32;
+  int bn;
+  if (npad % 256 == 0 && P == 0) bn = 256; else if (npad % 128 == 0) bn = 128; else return false;
+  static const int force_bn = getenv("NPP_G8_BN") ? atoi(getenv("NPP_G8_BN")) : 0;
+  if (force_bn == 128) bn = 128;
+  if ((long)npad * p.Kpad * 2 >= (1L << 31)) return false;                    // 32-bit element offsets into w
+  const int mtiles = (p.M + 255) / 256, ntiles = npad / bn;
+  const int tiles = mtiles * ntiles;
+  static const int min_tiles = getenv("NPP_G8_MIN_TILES") ? atoi(getenv("NPP_G8_MIN_TILES")) : 192;
+  if (tiles < min_tiles) return false;                                    // small maps: conv_s1's split-K fills the chip better
+  G8Extra e;
+  e.taps = p.KH * p.KW; e.nchunks = p.Cin / 64; e.nk = e.taps * e.nchunks; e.P = P; e.HW = p.H * p.W;
+  e.total_tiles = tiles;
+  e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
+  e.wbytes = (unsigned)((long)npad * p.Kpad * 2);
+  IgemmParams q = p;
+  q.mtiles = mtiles; q.ntiles = ntiles;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  const int grid = tiles < ncu ? tiles : ncu;
+#define G8_LAUNCH(BN_, RELU_, TAPS_)                                                                       \
+  do {                                                                                                     \
+    constexpr size_t lds = 2 * 65536 + 8 * 512;                                                            \
+    if (!g8_raise_lds(reinterpret_cast<const void*>(conv_g8_kernel<BN_, RELU_, TAPS_>), lds)) return false; \
+    hipLaunchKernelGGL((conv_g8_kernel<BN_, RELU_, TAPS_>), dim3(grid), dim3(512), lds, stream, q, e);     \
+  } while (0)
+  static const int dbg = getenv("NPP_G8_DBG") ? atoi(getenv("NPP_G8_DBG")) : 0;
+#define G8_LAUNCH_DBG(D_)                                                                                  \
+  do {                                                                                                     \
+    constexpr size_t lds = 2 * 65536 + 8 * 512;                                                            \
+    if (!g8_raise_lds(reinterpret_cast<const void*>(conv_g8_kernel<256, false, false, D_>), lds)) return false; \
+    hipLaunchKernelGGL((conv_g8_kernel<256, false, false, D_>), dim3(grid), dim3(512), lds, stream, q, e); \
+  } while (0)
+  if (dbg && bn == 256 && !p.relu_in) {      // timing experiments (results are garbage)
+    switch (dbg) {
+      case 1: G8_LAUNCH_DBG(1); break;
+      case 2: G8_LAUNCH_DBG(2); break;
+      case 3: G8_LAUNCH_DBG(3); break;
+      case 4: G8_LAUNCH_DBG(4); break;
+      case 5: G8_LAUNCH_DBG(5); break;
+      case 7: G8_LAUNCH_DBG(7); break;
+      case 9: G8_LAUNCH_DBG(9); break;
+      case 13: G8_LAUNCH_DBG(13); break;
+      case 15: G8_LAUNCH_DBG(15); break;
+      default: return false;
+    }
+    return true;
+  }
+#undef G8_LAUNCH_DBG
+  if (bn == 256) { if (p.relu_in) G8_LAUNCH(256, true, false); else G8_LAUNCH(256, false, false); }
+  else if (P == 0) { if (p.relu_in) G8_LAUNCH(128, true, false); else G8_LAUNCH(128, false, false); }
+  else           { if (p.relu_in) G8_LAUNCH(128, true, true); else G8_LAUNCH(128, false, true); }
+#undef G8_LAUNCH
+  return true;
+}

@@ -13,3 +13,5 @@ struct IgemmParams {
 bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream, void* ws, size_t ws_bytes);
 // bytes of caller-owned scratch the fast path wants for this shape (split-K partial tiles); 0 = none
 size_t conv_s1_ws_bytes(const IgemmParams& p, int dtype);
+// deep-pipelined LDS-DMA implicit GEMM for large stride-1 maps, bf16 (conv_g8.hip); false when the shape is not eligible
+bool conv_g8_launch(const IgemmParams& p, int dtype, hipStream_t stream);
