@@ -232,43 +232,49 @@ def main():
     L = _lib.lib()
     import ctypes as C
     dt_code = _lib.NPP_BF16 if dtype == torch.bfloat16 else _lib.NPP_F32
-    if prof and graph is None:
-        L.npp_prof_begin(_lib.FAM["conv_s1"], dt_code)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    # roofline of the dominant kernel: HIP events around every launch of the two MFMA conv families (on the launch stream), in
+    # eager single-stream steps right after the timed region -- a replayed graph cannot carry the event pairs, and with the
+    # two branch streams overlapping an event pair would also time the neighbour's kernels.  The family with the larger
+    # total time is reported as `roofline`, the other one next to it.
     roof = None
-    prof_steps = args.steps
-    if prof and graph is not None:
-        # a replayed graph cannot carry the event pairs: time the same kernels (same shapes, same data) with HIP
-        # events on the launch stream in two eager steps right after the timed region
-        prof_steps = 2
-        # single-stream for these steps: with the two branches overlapping, an event pair would also time the other
-        # branch's kernels sharing the chip
-        os.environ["NPP_STREAMS"] = "1"
-        L.npp_prof_begin(_lib.FAM["conv_s1"], dt_code)
-        for _ in range(prof_steps):
-            eager_step()
-        barrier()
+    roofs = []
     if prof:
-        ms, fl, by, nl = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
-        L.npp_prof_end(C.byref(ms), C.byref(fl), C.byref(by), C.byref(nl))
-        if nl.value > 0 and ms.value > 0:
-            ach = fl.value / (ms.value * 1e-3) / 1e12
-            peak = PEAK_TFLOPS[args.dtype]
-            traffic = None
-            try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
-                with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as fh:
-                    traffic = round(json.load(fh)["traffic_bytes_per_launch"])
-            except Exception:      # noqa: BLE001
-                traffic = None
-            roof = {"bound": "mfma", "kernel": "conv_s1_kernel (stride-1 conv fwd + dgrad on MFMA, both tile heights)",
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC)", "launches_per_step": nl.value // max(prof_steps, 1),
-                    "avg_launch_us": round(ms.value * 1e3 / nl.value, 2),
-                    "algorithmic_gflop_per_launch": round(fl.value / nl.value / 1e9, 4)}
+        os.environ["NPP_STREAMS"] = "1"
+        prof_steps = 2
+        KERNELS = {"conv_s1": "conv_s1_kernel (stride-1 KxK conv fwd + dgrad, LDS-resident footprint, MFMA 32x32x16)",
+                   "conv_g8": "conv_g8_kernel (1x1 conv fwd + dgrad: 8-phase LDS-DMA implicit GEMM, MFMA 16x16x32)"}
+        traffic_db = {}
+        try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
+            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as fh:
+                traffic_db = json.load(fh)
+        except Exception:      # noqa: BLE001
+            traffic_db = {}
+        for fam, label in KERNELS.items():
+            L.npp_prof_begin(_lib.FAM[fam], dt_code)
+            for _ in range(prof_steps):
+                eager_step()
+            barrier()
+            ms, fl, by, nl = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+            L.npp_prof_end(C.byref(ms), C.byref(fl), C.byref(by), C.byref(nl))
+            if nl.value > 0 and ms.value > 0:
+                ach = fl.value / (ms.value * 1e-3) / 1e12
+                peak = PEAK_TFLOPS[args.dtype]
+                rec = traffic_db.get(fam + "_kernel") or (traffic_db if traffic_db.get("kernel") == fam + "_kernel" else None)
+                traffic = round(rec["traffic_bytes_per_launch"]) if rec else None
+                roofs.append({"bound": "mfma", "kernel": label, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                              "frac": round(ach / peak, 4), "traffic": traffic,
+                              "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC)",
+                              "launches_per_step": nl.value // prof_steps, "ms_per_step": round(ms.value / prof_steps, 3),
+                              "avg_launch_us": round(ms.value * 1e3 / nl.value, 2),
+                              "algorithmic_gflop_per_launch": round(fl.value / nl.value / 1e9, 4),
+                              "algorithmic_mbyte_per_launch": round(by.value / nl.value / 1e6, 3)})
+        roofs.sort(key=lambda r: -r["ms_per_step"])
+        roof = roofs[0] if roofs else None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -291,6 +297,8 @@ def main():
     }
     if roof is not None:
         out["roofline"] = roof
+        if len(roofs) > 1:
+            out["roofline_other_kernels"] = roofs[1:]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size)
     if use_dist:

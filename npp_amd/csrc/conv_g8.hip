@@ -460,11 +460,15 @@ bool conv_g8_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (npad % 256 == 0 && P == 0) bn = 256; else if (npad % 128 == 0) bn = 128; else return false;
   static const int force_bn = getenv("NPP_G8_BN") ? atoi(getenv("NPP_G8_BN")) : 0;
   if (force_bn == 128) bn = 128;
+  // small maps: the narrower tile doubles the number of blocks when the wide one cannot fill half the chip
+  if (bn == 256 && ((p.M + 255) / 256) * (npad / 256) < 128) bn = 128;
   if ((long)npad * p.Kpad * 2 >= (1L << 31)) return false;                    // 32-bit element offsets into w
   const int mtiles = (p.M + 255) / 256, ntiles = npad / bn;
   const int tiles = mtiles * ntiles;
-  static const int min_tiles = getenv("NPP_G8_MIN_TILES") ? atoi(getenv("NPP_G8_MIN_TILES")) : 192;
-  if (tiles < min_tiles) return false;                                    // small maps: conv_s1's split-K fills the chip better
+  // measured against conv_s1 (split-K + finish kernel) on the 48^2 / 24^2 / 12^2 1x1 convs of the network: this kernel is
+  // 1.3-2.3x faster down to ~18 tiles (e.g. 512->512 @24^2: 22 vs 42 us); below that too few CUs work
+  static const int min_tiles = getenv("NPP_G8_MIN_TILES") ? atoi(getenv("NPP_G8_MIN_TILES")) : 16;
+  if (tiles < min_tiles) return false;
   G8Extra e;
   e.taps = p.KH * p.KW; e.nchunks = p.Cin / 64; e.nk = e.taps * e.nchunks; e.P = P; e.HW = p.H * p.W;
   e.total_tiles = tiles;

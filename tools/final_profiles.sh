@@ -2,7 +2,7 @@
 # GPU box: the profiling artefacts judged for a round -> gpurun_out/final/ (copy into profiles/ afterwards)
 #   1. rocprofv3 --kernel-trace --stats of the default bench command (hipGraph, two branch streams)
 #   2. the same for the eager single-stream run (per-kernel durations without overlap)
-#   3. two --pmc passes (FETCH_SIZE, WRITE_SIZE) of the eager single-stream run -> HBM bytes per conv_s1 launch
+#   3. two --pmc passes (FETCH_SIZE, WRITE_SIZE) of the eager single-stream run -> HBM bytes per conv_s1 / conv_g8 launch
 tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/final; mkdir -p $out
@@ -25,4 +25,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 ff=$(find /tmp/fp_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 fw=$(find /tmp/fp_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_traffic.py "$ff" "$fw" conv_s1_kernel $out/${tag}_pmc_traffic.json
+python3 tools/pmc_traffic.py "$ff" "$fw" conv_s1_kernel,conv_g8_kernel $out/${tag}_pmc_traffic.json

@@ -7,6 +7,8 @@ dev = torch.device("cuda:0")
 N, iters = 16, 10
 SHAPES = [(1024, 512, 1, 96), (1024, 384, 1, 96), (512, 256, 1, 96), (512, 128, 1, 96), (384, 128, 1, 96), (128, 128, 1, 96),
           (128, 128, 3, 96), (384, 128, 3, 96)]
+if os.environ.get('NPP_TIME_SET') == 'small':
+    SHAPES = [(256, 256, 1, 48), (256, 128, 1, 48), (256, 64, 1, 48), (512, 512, 1, 24), (512, 256, 1, 24), (512, 128, 1, 24), (128, 128, 1, 24), (1024, 256, 1, 12)]
 for cin, cout, k, H in SHAPES:
     x = K.cast(torch.randn(N, cin, H, H, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16).requires_grad_(True)
     w = torch.randn(cout, cin, k, k, device=dev) * 0.05
