@@ -201,6 +201,9 @@ int npp_bilinear_bwd(const NppTensor* dy, NppTensor* dx, void* stream);
 
 /* ---- layout / elementwise plumbing -------------------------------------------------------------- */
 int npp_copy(const NppTensor* x, NppTensor* y, void* stream);                /* cast + channel-slice copy (cat) */
+/* y = xs[0] + ... + xs[n-1], 1 <= n <= 8, same shape/dtype, any pixel strides: one-pass accumulation of the gradients of a
+ * tensor with several consumers (replaces the autograd engine's chain of binary at::add, model_augment.py:48-62 fan-outs) */
+int npp_add_n(const NppTensor* const* xs, int n, NppTensor* y, void* stream);
 int npp_nchw_to_nhwc(const float* src, int n, int c, int h, int w, NppTensor* dst, void* stream); /* pads channels with 0 */
 int npp_nhwc_to_nchw(const NppTensor* src, float* dst, void* stream);
 int npp_channel_sum(const NppTensor* x, double* out /*[R][C], added*/, void* stream);      /* conv bias grad */

@@ -93,6 +93,7 @@ _SIGS = {
     "npp_bilinear_fwd": [_T, _T, _P],
     "npp_bilinear_bwd": [_T, _T, _P],
     "npp_copy": [_T, _T, _P],
+    "npp_add_n": [_P, C.c_int, _T, _P],
     "npp_nchw_to_nhwc": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _T, _P],
     "npp_nhwc_to_nchw": [_T, _P, _P],
     "npp_nearest": [_T, _T, C.c_float, C.c_float, C.c_int, _P],

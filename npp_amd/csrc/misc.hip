@@ -105,6 +105,72 @@ extern "C" int npp_nhwc_to_nchw(const NppTensor* src, float* dst, void* stream) 
   return npp_check_launch("nhwc_to_nchw");
 }
 
+// y = x0 + x1 + ... + x(n-1) (n <= 8), f32 accumulation, one rounding: the gradient accumulation of a tensor with several
+// consumers (npp_amd/_ops.py:_FanOut) in one pass instead of n-1 binary adds.
+namespace {
+struct AddNArgs {
+  const void* x[8];
+  long ld[8];
+  int n;
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void add_n_kernel(AddNArgs a, T* __restrict__ y, long ldy, long npix, int cv) {
+  const unsigned total = (unsigned)(npix * cv);
+  const FastDiv fd((unsigned)cv);
+  const unsigned stride = gridDim.x * 256;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += 2 * stride) {
+    const unsigned i2 = i + stride;
+    const bool two = i2 < total;
+    unsigned p, c, p2 = 0, c2 = 0;
+    fast_divmod(i, fd, p, c);
+    if (two) fast_divmod(i2, fd, p2, c2);
+    float acc[V], acc2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { acc[j] = 0.f; acc2[j] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < a.n) {
+        float v[V];
+        ldv<T, V>(reinterpret_cast<const T*>(a.x[k]) + (long)p * a.ld[k] + c * V, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += v[j];
+        if (two) {
+          ldv<T, V>(reinterpret_cast<const T*>(a.x[k]) + (long)p2 * a.ld[k] + c2 * V, v);
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc2[j] += v[j];
+        }
+      }
+    }
+    stv<T, V>(y + (long)p * ldy + c * V, acc);
+    if (two) stv<T, V>(y + (long)p2 * ldy + c2 * V, acc2);
+  }
+}
+}  // namespace
+
+extern "C" int npp_add_n(const NppTensor* const* xs, int n, NppTensor* y, void* stream) {
+  NPP_REQUIRE(xs && y && y->ptr && n >= 1 && n <= 8, NPP_E_NULL, "npp_add_n: need 1..8 sources");
+  NPP_REQUIRE(dtype_ok(y), NPP_E_DTYPE, "npp_add_n: bad dtype");
+  AddNArgs a;
+  bool vk = vec_ok(y);
+  for (int k = 0; k < 8; ++k) { a.x[k] = nullptr; a.ld[k] = 0; }
+  for (int k = 0; k < n; ++k) {
+    NPP_REQUIRE(xs[k] && xs[k]->ptr && same_shape(xs[k], y) && xs[k]->dtype == y->dtype, NPP_E_SHAPE,
+                "npp_add_n: source %d does not match the output", k);
+    a.x[k] = xs[k]->ptr; a.ld[k] = xs[k]->ld;
+    vk = vk && vec_ok(xs[k]);
+  }
+  a.n = n;
+  NPP_REQUIRE(npix(y) * y->c < (1L << 31), NPP_E_SHAPE, "npp_add_n: tensor too large");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(NPP_FAM_ELTWISE, y->dtype, s, 0, (double)npix(y) * y->c * esize(y->dtype) * (n + 1));
+  NPP_DISPATCH_TV(y->dtype, vk, {
+    const int cv = (int)(y->c / V);
+    hipLaunchKernelGGL((add_n_kernel<T, V>), dim3(grid_for(npix(y) * cv / 2 + 1)), dim3(256), 0, s, a, (T*)y->ptr, (long)y->ld,
+                       (long)npix(y), cv);
+  });
+  return npp_check_launch("add_n");
+}
+
 // ---- search-supernet plumbing (model_search_interact.py:22-74): nearest resample, PC-DARTS mixed sum, channel shuffle ----
 namespace {
 

@@ -368,6 +368,7 @@ class Network(nn.Module):
             raise RuntimeError("npp_amd.Network runs on the MI355X HIP kernels only: move the input to cuda "
                                "(there is no CPU fallback)")
         dt = _compute_dtype
+        K.fan_reset()
         if self._packer is None:
             from .operations import SE_Block
             skip = set()
@@ -535,6 +536,7 @@ class Network(nn.Module):
             for pair in par_list + (pose_list if mode == 3 else []):
                 for t in pair:
                     t.record_stream(so)
+        K.fan_reset()
         return pose_list, par_list
 
     def _sync_bn_active(self) -> bool:

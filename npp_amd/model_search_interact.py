@@ -284,6 +284,7 @@ class Network(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("npp_amd supernet runs on the MI355X HIP kernels only (no CPU fallback)")
         dt = get_compute_dtype()
+        K.fan_reset()
         if self._packer is None:
             from .operations import SE_Block
             skip = set()
@@ -390,6 +391,7 @@ class Network(nn.Module):
             for pair in par_list:
                 for t in pair:
                     t.record_stream(sa)
+        K.fan_reset()
         return pose_list, par_list
 
     # -- genotype extraction (:913-1052; host-side numpy on the architecture tensors) --------------------------------
