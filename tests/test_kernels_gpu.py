@@ -230,6 +230,43 @@ def test_batchnorm_fused_add(C, H, N, relu, two, dtype, tol):
         assert rel_err(bns[1].weight.grad.cpu().numpy(), ref[1].weight.grad.numpy()) < tol * 5
 
 
+def test_add_n_and_fanout_gradient_accumulation():
+    """npp_add_n (strided sources, 2..8 terms) and the _FanOut node: a tensor with four consumers gets the same gradient
+    as with the autograd engine's own accumulation."""
+    from npp_amd import _ops as K
+    dev = _dev()
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-2)):
+        srcs_cpu = [_rand((2, 24, 9, 11), 10 + i) for i in range(5)]
+        srcs = [_to_dev(t, dtype, slice_pad=8 if i % 2 else 0) for i, t in enumerate(srcs_cpu)]
+        for n in (2, 3, 5):
+            out = K.add_n(srcs[:n])
+            ref = sum(t.to(torch.bfloat16).float() if dtype == torch.bfloat16 else t for t in srcs_cpu[:n])
+            assert rel_err(out.float().cpu().numpy(), ref.numpy()) < tol
+    # fan-out: y = pool(x') + pool(x') + bilinear(x') + x'  with x' = 2*x (so that x' has a grad_fn)
+    assert K.FANOUT
+    x_cpu = _rand((2, 32, 12, 12), 3)
+    g_cpu = _rand((2, 32, 12, 12), 4)
+
+    def run(fan):
+        K.FANOUT = fan
+        K.fan_reset()
+        x = _to_dev(x_cpu, torch.float32).detach().requires_grad_(True)
+        xp = K.add(x, x)
+        a, _ = K.pool3x3(xp, is_avg=True)
+        b, _ = K.pool3x3(xp, is_avg=False)
+        c = K.bilinear(K.bilinear(xp, 24, 24), 12, 12)
+        y = K.add(K.add(a, b), K.add(c, xp))
+        y.backward(_to_dev(g_cpu, torch.float32))
+        torch.cuda.synchronize()
+        return x.grad.float().cpu().numpy()
+    try:
+        g_fan, g_eng = run(True), run(False)
+    finally:
+        K.FANOUT = True
+        K.fan_reset()
+    assert rel_err(g_fan, g_eng) < 1e-5
+
+
 def test_concat_and_slice_views_roundtrip():
     from npp_amd import _ops as K
     xs = [_rand((2, c, 8, 8), 20 + i) for i, c in enumerate((8, 16, 8, 32))]
