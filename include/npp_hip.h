@@ -259,6 +259,24 @@ int npp_edge_weights(const int64_t* labels, int64_t n, double* counts /*[2] zero
 int npp_parsing_confusion(const NppTensor* pred, const NppTensor* flip_pred, const int64_t* label, int H, int W,
                           int ignore, int alias_swap, int64_t* counts, void* stream);
 
+/* ---- input hand-off ----------------------------------------------------------------------------
+ * The per-sample host work of LIPDataset.__getitem__ after the geometric augmentation, batched on the device.
+ * npp_pose_targets: dataset/target_generation.py:94-117,145-168 -- maps [N][J+1][grid_y][grid_x] f32: channel j < J =
+ *   exp(-d2/(2 sigma^2)) at grid cell centres stride/2 - 0.5 + g*stride where the exponent is <= 4.6052 and joint j is
+ *   visible, else 0; channel J = 1 - max_j.  joints: f32 [N][J][2] (x, y) in input pixels, visible: u8 [N][J].  The aux
+ *   target of gen_pose_target(aux=True) is the same call with 2*sigma.
+ * npp_edge_target: target_generation.py:210-239 + data_loader.py:281-285 -- label u8 [N][H][W] -> edge u8: 1 where the label
+ *   differs from the pixel above / right / below-right / below-left (neither being `ignore`), dilated by an edge_width^2 box
+ *   (odd), and, with mark_ignore, `ignore` wherever the label is `ignore`.
+ * npp_normalize_image: transforms.ToTensor + Normalize (augment_lip_sync.py:127-130) -- u8 RGB [N][H][W][3] -> NHWC `out`
+ *   (c = 3, rows zero-padded to ld), (v/255 - mean) / std. */
+int npp_pose_targets(const float* joints, const uint8_t* visible, int n, int j, int grid_x, int grid_y, float stride,
+                     float sigma, float* maps, void* stream);
+int npp_edge_target(const uint8_t* label, int n, int h, int w, int edge_width, int ignore, int mark_ignore, uint8_t* edge,
+                    void* stream);
+int npp_normalize_image(const uint8_t* img, int n, int h, int w, const float* mean3, const float* std3, NppTensor* out,
+                        void* stream);
+
 /* ---- optimizer --------------------------------------------------------------------------------
  * torch.optim.Adam(params, lr, betas, eps, weight_decay) of augment_lip_sync.py:210-213 as ONE launch over a
  * device-resident table: param / exp_avg / exp_avg_sq are f32 and updated in place, grad is f32.  `chunks` holds

@@ -1,9 +1,10 @@
-"""Which Python lines issue torch (ATen) kernels during one eager training step: counts of aten::fill_/zero_/copy_/add/... by
-caller frame (torch.profiler with_stack)."""
-import os, sys, collections
+"""Which Python lines issue torch (ATen) work during one eager training step: TorchDispatchMode counts aten ops that launch
+kernels, keyed by the innermost npp_amd / bench frame."""
+import os, sys, collections, traceback
 os.environ["NPP_STREAMS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from torch.utils._python_dispatch import TorchDispatchMode
 import bench
 from npp_amd.model_augment import Network, set_compute_dtype
 from npp_amd.criterion import Criterion_par, Criterion_pose
@@ -27,14 +28,22 @@ def step():
     opt.step()
     torch.cuda.synchronize()
 step(); step()
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=False) as prof:
-    step()
+SKIP = ("aten.view", "aten.detach", "aten.alias", "aten.permute", "aten.slice", "aten.empty", "aten.as_strided", "aten.reshape",
+        "aten._unsafe_view", "aten.unsqueeze", "aten.select", "aten.expand", "aten.t.", "aten.transpose", "aten.squeeze",
+        "aten.empty_strided", "aten.new_empty", "aten._local_scalar_dense", "aten.is_", "aten.stride", "aten.size", "aten.sym_")
 cnt = collections.Counter()
-for ev in prof.events():
-    if ev.name in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::add", "aten::add_", "aten::sum", "aten::cat", "aten::mul", "aten::div",
-                   "aten::empty", "aten::zeros", "aten::to", "aten::_to_copy", "aten::clone", "aten::contiguous"):
-        frames = [f for f in (ev.stack or []) if "npp_amd" in f or "bench" in f or "tools" in f]
-        cnt[(ev.name, frames[0] if frames else "?")] += 1
-for (name, fr), n in cnt.most_common(40):
-    print(f"{n:5d} {name:16s} {fr}")
+class Mode(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not name.startswith(SKIP):
+            fr = "?"
+            for f in reversed(traceback.extract_stack()[:-1]):
+                if ("npp_amd" in f.filename or "bench" in f.filename or "aten_sites" in f.filename) and "aten_sites.py" not in f.filename:
+                    fr = f"{os.path.basename(f.filename)}:{f.lineno}"
+                    break
+            cnt[(name, fr)] += 1
+        return func(*args, **(kwargs or {}))
+with Mode():
+    step()
+for (name, fr), n in cnt.most_common(45):
+    print(f"{n:5d} {name:34s} {fr}")
