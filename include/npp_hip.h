@@ -62,7 +62,8 @@ const char* npp_last_error(void);
 enum { NPP_FAM_NONE = 0, NPP_FAM_CONV_IGEMM = 1, NPP_FAM_CONV_WGRAD = 2, NPP_FAM_DWCONV = 3,
        NPP_FAM_BN = 4, NPP_FAM_ELTWISE = 5, NPP_FAM_POOL = 6, NPP_FAM_BILINEAR = 7, NPP_FAM_LOSS = 8,
        NPP_FAM_CONV_S1 = 9 /* the stride-1 fast path only (conv_s1_kernel) */,
-       NPP_FAM_CONV_G8 = 10 /* the 8-phase LDS-DMA implicit GEMM for large maps (conv_g8_kernel) */ };
+       NPP_FAM_CONV_G8 = 10 /* the 8-phase LDS-DMA implicit GEMM for large maps (conv_g8_kernel) */,
+       NPP_FAM_CONV_G4 = 11 /* 64x64-tile LDS-DMA conv for small maps / 64-channel layers (conv_g4_kernel) */ };
 int npp_prof_begin(int family, int dtype_filter /* -1 = any */);
 int npp_prof_end(double* ms_total, double* flops_total, double* bytes_total, int64_t* launches);
 

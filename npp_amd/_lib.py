@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libnpp_hip.so")
 NPP_F32, NPP_BF16 = 0, 1
 STAT_REPLICAS = 16   # NPP_STAT_REPLICAS in include/npp_hip.h
 FAM = {"none": 0, "conv_igemm": 1, "conv_wgrad": 2, "dwconv": 3, "bn": 4, "eltwise": 5, "pool": 6,
-       "bilinear": 7, "loss": 8, "conv_s1": 9, "conv_g8": 10}
+       "bilinear": 7, "loss": 8, "conv_s1": 9, "conv_g8": 10, "conv_g4": 11}
 
 
 class NppTensor(C.Structure):

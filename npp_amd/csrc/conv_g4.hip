@@ -1,0 +1,276 @@
+// Stride-1 "same" convolution (1x1 / 3x3 / 5x5), bf16, for SMALL problems: the 24x24 / 12x12 cell convs (128->128, 256->256
+// 3x3: M = 9216 / 2304 pixels) and the 64-channel convs of the second encoder stage (64->64 3x3 @48^2, 256->64 1x1).
+// These are latency-, not FLOP-bound: conv_s1's 128/256-row tiles leave 3/4 of the chip idle unless it splits K and runs a
+// second "finish" launch, and the generic gather kernel pays a per-tap gather.  Here the tile is 64 pixels x 64 channels
+// (4.5x-18x more blocks), several blocks share a CU (64 KiB of LDS, ~70 VGPRs), and the operands travel by LDS-DMA exactly
+// as in conv_g8.hip: K-tile = 64 channels of one tap, 1-KiB pieces of 8 rows x 128 B XOR-swizzled on the source address
+// and on the fragment read, out-of-image rows of a tap = out-of-range buffer offset (the DMA writes zeros).
+//   * ring of 4 K-tile buffers (A 8 KiB + B 8 KiB each), three K-tiles in flight, ONE barrier per K-tile:
+//       wait vmcnt(8) (tile t landed, t+1 and t+2 still flying) ; s_barrier ; issue tile t+3 into the buffer tile t-1 used ;
+//       8 fragment reads ; 8 MFMA 16x16x32 per wave (2 x 2 fragments, K = 64)
+//     -- a wave that reaches barrier t has issued the MFMAs of tile t-1, hence has all its fragments: the buffer is free.
+//   * no persistence, no wave stagger: co-resident blocks hide each other's prologue and barrier waits.
+//   * epilogue as conv_g8 (C^T accumulators, v_permlane16_swap -> 16-byte stores, packed-int16 ReLU-backward mask, BN sum /
+//     sum-of-squares of the stored values by DPP row reduction), statistics combined across the two M-waves in LDS and
+//     flushed with one f64 atomic per (block, channel).
+// Replaces the same reference call sites as conv_s1.hip / conv_igemm.hip (models/operations.py:69-82, 202-220).
+#include "common.h"
+#include "conv_params.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+struct G4Extra {
+  int taps, nchunks, nk, P, HW;
+  unsigned xbytes, wbytes;
+};
+
+#define G4_DMA(rsrc, voff, soff, ldsoff)                                                                  \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (ldsoff)), 16, voff, soff, 0, 0)
+
+NPP_DEV u32x4 relu_bf16x8_g4(u32x4 v) {
+  s16x8 s = __builtin_bit_cast(s16x8, v);
+  const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  s = __builtin_elementwise_max(s, z);
+  return __builtin_bit_cast(u32x4, s);
+}
+
+template <bool RELU, bool TAPS>
+__global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) {
+  constexpr int R = 4;                 // ring depth
+  constexpr int KT = 16384;            // bytes per K-tile buffer: A [64 rows][128 B] then B [64 rows][128 B]
+  constexpr int RED = R * KT;          // statistics exchange [2 wm][64 ch][2] floats
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, e.wbytes, 0x00020000);
+
+  // XCD-contiguous tile order, N-tile fastest
+  const int total = p.mtiles * p.ntiles;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qd = total >> 3, rm = total & 7;
+  const int lid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  const int m0 = (lid / p.ntiles) * 64, n0 = (lid % p.ntiles) * 64;
+
+  const int lrow = lane & 15, lk = lane >> 4;
+  const unsigned loff0 = (lrow >> 3) * 1024 + (lrow & 7) * 128 + ((lk ^ (lrow & 7)) << 4);
+  const unsigned rdA0 = wm * 4096 + loff0, rdA1 = wm * 4096 + (loff0 ^ 64);                 // + mi*2048 + ring offset
+  const unsigned rdB0 = 8192 + wn * 4096 + loff0, rdB1 = 8192 + wn * 4096 + (loff0 ^ 64);   // + ni*2048 + ring offset
+
+  // staging: this wave fills pieces 2*wave, 2*wave+1 of A and of B; lane -> row 8*piece + (lane>>3), source piece (lane&7)^(lane>>3)
+  const int sl = lane >> 3, spb = ((lane & 7) ^ sl) * 16;
+  unsigned abyte[2];
+  int ayx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int q = m0 + (wave * 2 + i) * 8 + sl;
+    const bool real = q < p.M;
+    if (!real) q = p.M - 1;
+    abyte[i] = (unsigned)q * (unsigned)p.ldx * 2u + spb;
+    ayx[i] = 0;
+    if (TAPS) {
+      const int rem = q % e.HW;
+      const int y = rem / p.W;
+      ayx[i] = real ? ((y << 16) | (rem - y * p.W)) : (0x4000 << 16);
+    }
+  }
+  const unsigned bbyte = (unsigned)(n0 + wave * 16 + sl) * (unsigned)p.Kpad * 2u + spb;   // second piece: +8 rows (scalar offset)
+
+  int s_tap = 0, s_chunk = 0, s_dy = -e.P, s_dx = -e.P, s_kt = 0;
+  auto issue = [&]() {     // K-tile s_kt of the stream into ring slot s_kt % R
+    const int lb = (s_kt & (R - 1)) * KT;
+    const int koffA = s_chunk * 128 + (TAPS ? (s_dy * p.W + s_dx) * (int)p.ldx * 2 : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned v = abyte[i] + (unsigned)koffA;
+      if (TAPS) {
+        const int y = (ayx[i] >> 16) + s_dy, x = (ayx[i] & 0xFFFF) + s_dx;
+        if (!((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)) v = 0xFFFFFFFFu;
+      }
+      G4_DMA(rs_x, v, 0, lb + (wave * 2 + i) * 1024);
+    }
+    const int koffB = (s_tap * p.Cp + s_chunk * 64) * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) G4_DMA(rs_w, bbyte, koffB + i * 8 * p.Kpad * 2, lb + 8192 + (wave * 2 + i) * 1024);
+    ++s_kt;
+    if (++s_chunk == e.nchunks) {
+      s_chunk = 0; ++s_tap;
+      if (++s_dx > e.P) { s_dx = -e.P; ++s_dy; }
+    }
+  };
+
+  f32x4w acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4w{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = e.nk;
+  for (int i = 0; i < R - 1 && i < nk; ++i) issue();
+  for (int kt = 0; kt < nk; ++kt) {
+    // tiles 0 .. min(nk, kt+R-1)-1 are issued; tile kt must have landed, the (up to) R-2 after it may still fly
+    if (kt + R - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (R - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + R - 1 < nk) issue();
+    const unsigned ro = (unsigned)(kt & (R - 1)) * KT;
+    u32x4 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      fb[ni][0] = *reinterpret_cast<const u32x4*>(smem + ro + rdB0 + ni * 2048);
+      fb[ni][1] = *reinterpret_cast<const u32x4*>(smem + ro + rdB1 + ni * 2048);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      fa[mi][0] = *reinterpret_cast<const u32x4*>(smem + ro + rdA0 + mi * 2048);
+      fa[mi][1] = *reinterpret_cast<const u32x4*>(smem + ro + rdA1 + mi * 2048);
+      if (RELU) { fa[mi][0] = relu_bf16x8_g4(fa[mi][0]); fa[mi][1] = relu_bf16x8_g4(fa[mi][1]); }
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ni][kb]),
+                                                                __builtin_bit_cast(bf16x8, fa[mi][kb]), acc[mi][ni], 0, 0, 0);
+  }
+
+  // ---- epilogue (see conv_g8.hip): acc[mi][ni][j] = C[pixel m0 + wm*32 + mi*16 + lrow][channel n0 + wn*32 + ni*16 + 4*lk + j]
+  bf16_t* __restrict__ yg = reinterpret_cast<bf16_t*>(p.y);
+  const bf16_t* __restrict__ mg = reinterpret_cast<const bf16_t*>(p.mask);
+  const bool want_stats = p.stats != nullptr;
+  const int cb = n0 + wn * 32;
+  const int chb = (lk & 1) * 16 + (lk >> 1) * 8;
+  f32x4w bias[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+    bias[ni] = p.bias ? *reinterpret_cast<const f32x4w*>(p.bias + cb + ni * 16 + lk * 4) : f32x4w{0.f, 0.f, 0.f, 0.f};
+  u32x4 mk[2];
+  if (mg) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const long gm = (long)m0 + wm * 32 + mi * 16 + lrow;
+      mk[mi] = gm < p.M ? *reinterpret_cast<const u32x4*>(mg + gm * p.ldm + cb + chb) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  float ss[2][4], sq[2][4];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ss[ni][j] = 0.f; sq[ni][j] = 0.f; }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const long gm = (long)m0 + wm * 32 + mi * 16 + lrow;
+    const bool live = gm < p.M;
+    unsigned pk[2][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j] + bias[ni][j];
+      pk[ni][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+      pk[ni][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+      if (want_stats && live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float r = __uint_as_float((j & 1) ? (pk[ni][j >> 1] & 0xFFFF0000u) : (pk[ni][j >> 1] << 16));
+          ss[ni][j] += r; sq[ni][j] += r * r;
+        }
+      }
+    }
+    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+    u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+    if (live) {
+      if (mg) {
+        const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        s16x8 m = __builtin_elementwise_max(__builtin_bit_cast(s16x8, mk[mi]), z);
+        m = (z - m) >> 15;
+        o = o & __builtin_bit_cast(u32x4, m);
+      }
+      *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
+    }
+  }
+  if (want_stats) {
+    float* red = reinterpret_cast<float*>(smem + RED);     // [wm][64 channels][2]
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = ss[ni][j], q = sq[ni][j];
+#define G4_DPP_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true))
+        G4_DPP_ADD(s, 0xB1); G4_DPP_ADD(q, 0xB1);
+        G4_DPP_ADD(s, 0x4E); G4_DPP_ADD(q, 0x4E);
+        G4_DPP_ADD(s, 0x141); G4_DPP_ADD(q, 0x141);
+        G4_DPP_ADD(s, 0x140); G4_DPP_ADD(q, 0x140);
+#undef G4_DPP_ADD
+        if (lrow == 0) {
+          float* d = red + ((wm * 64) + wn * 32 + ni * 16 + lk * 4 + j) * 2;
+          d[0] = s; d[1] = q;
+        }
+      }
+    __syncthreads();
+    if (t < 64 && n0 + t < p.Cout) {
+      const float s = red[t * 2] + red[(64 + t) * 2], q = red[t * 2 + 1] + red[(64 + t) * 2 + 1];
+      double* st = p.stats + (long)(bid % NPP_STAT_REPLICAS) * 2 * p.Cout;
+      atomicAdd(st + n0 + t, (double)s);
+      atomicAdd(st + p.Cout + n0 + t, (double)q);
+    }
+  }
+}
+
+bool g4_raise_lds(const void* fp, size_t bytes) {
+  static thread_local const void* done[8];
+  for (int i = 0; i < 8; ++i)
+    if (done[i] == fp) return true;
+  if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+  for (int i = 0; i < 8; ++i)
+    if (!done[i]) { done[i] = fp; break; }
+  return true;
+}
+
+}  // namespace
+
+// Eligibility + launch; false = the shape stays with conv_s1 / the generic kernel.
+bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
+  static const bool disabled = getenv("NPP_DISABLE_G4") != nullptr;
+  if (disabled || dtype != NPP_BF16) return false;
+  if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.uph != 1 || p.upw != 1) return false;
+  if (p.KH != p.KW || (p.KH & 1) == 0 || p.KH > 5) return false;
+  const int P = (p.KH - 1) / 2;
+  if (p.ph != P || p.pw != P || p.OH != p.H || p.OW != p.W) return false;
+  if (p.Cp != p.Cin || p.Cin % 64 != 0 || p.ldx % 8 != 0 || p.Cout % 64 != 0) return false;
+  if ((long)p.N * p.H * p.W * p.ldx * 2 >= (1L << 32) - 65536) return false;
+  if (!p.vec_io || (p.mask && p.stats)) return false;
+  if (p.H >= 16384 || p.W >= 16384) return false;
+  const long wbytes = (long)p.Cout * p.Kpad * 2;
+  if (wbytes >= (1L << 31)) return false;
+  // 64 x 64 tiles re-read the weights once per M-tile and the pixels once per N-tile: only where both stay small.
+  static const long max_w = getenv("NPP_G4_MAX_WBYTES") ? atol(getenv("NPP_G4_MAX_WBYTES")) : (5L << 19);   // 2.5 MiB
+  static const int max_m = getenv("NPP_G4_MAX_M") ? atoi(getenv("NPP_G4_MAX_M")) : 40000;
+  if (wbytes > max_w || p.M > max_m) return false;
+  G4Extra e;
+  e.taps = p.KH * p.KW; e.nchunks = p.Cin / 64; e.nk = e.taps * e.nchunks; e.P = P; e.HW = p.H * p.W;
+  e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
+  e.wbytes = (unsigned)wbytes;
+  IgemmParams q = p;
+  q.mtiles = (p.M + 63) / 64; q.ntiles = p.Cout / 64;
+  const int grid = q.mtiles * q.ntiles;
+  constexpr size_t lds = 4 * 16384 + 1024;
+#define G4_LAUNCH(RELU_, TAPS_)                                                                            \
+  do {                                                                                                     \
+    if (!g4_raise_lds(reinterpret_cast<const void*>(conv_g4_kernel<RELU_, TAPS_>), lds)) return false;     \
+    hipLaunchKernelGGL((conv_g4_kernel<RELU_, TAPS_>), dim3(grid), dim3(256), lds, stream, q, e);          \
+  } while (0)
+  if (P == 0) { if (p.relu_in) G4_LAUNCH(true, false); else G4_LAUNCH(false, false); }
+  else        { if (p.relu_in) G4_LAUNCH(true, true);  else G4_LAUNCH(false, true); }
+#undef G4_LAUNCH
+  return true;
+}

@@ -434,6 +434,11 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
     prof0.cancel();
   }
   {
+    ProfScope prof2(NPP_FAM_CONV_G4, x->dtype, s, flops, bytes);
+    if (conv_g4_launch(p, x->dtype, s)) return npp_check_launch("conv_g4");
+    prof2.cancel();
+  }
+  {
     ProfScope prof1(NPP_FAM_CONV_S1, x->dtype, s, flops, bytes);
     if (conv_s1_launch(p, x->dtype, s, ws, ws_bytes)) return npp_check_launch("conv_s1");
     prof1.cancel();    // not taken: the generic kernel below is a different family

@@ -15,3 +15,5 @@ bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream, void* w
 size_t conv_s1_ws_bytes(const IgemmParams& p, int dtype);
 // deep-pipelined LDS-DMA implicit GEMM for large stride-1 maps, bf16 (conv_g8.hip); false when the shape is not eligible
 bool conv_g8_launch(const IgemmParams& p, int dtype, hipStream_t stream);
+// 64x64-tile LDS-DMA conv for small problems (conv_g4.hip); false when the shape is not eligible
+bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream);
