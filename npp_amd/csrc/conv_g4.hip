@@ -18,6 +18,10 @@
 #include "conv_params.h"
 #include <stdlib.h>
 
+#ifndef G4_RING
+#define G4_RING 2
+#endif
+
 namespace {
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
@@ -39,7 +43,7 @@ NPP_DEV u32x4 relu_bf16x8_g4(u32x4 v) {
 
 template <bool RELU, bool TAPS>
 __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) {
-  constexpr int R = 4;                 // ring depth
+  constexpr int R = G4_RING;           // ring depth
   constexpr int KT = 16384;            // bytes per K-tile buffer: A [64 rows][128 B] then B [64 rows][128 B]
   constexpr int RED = R * KT;          // statistics exchange [2 wm][64 ch][2] floats
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -81,9 +85,9 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
   }
   const unsigned bbyte = (unsigned)(n0 + wave * 16 + sl) * (unsigned)p.Kpad * 2u + spb;   // second piece: +8 rows (scalar offset)
 
-  int s_tap = 0, s_chunk = 0, s_dy = -e.P, s_dx = -e.P, s_kt = 0;
+  int s_tap = 0, s_chunk = 0, s_dy = -e.P, s_dx = -e.P, s_slot = 0;
   auto issue = [&]() {     // K-tile s_kt of the stream into ring slot s_kt % R
-    const int lb = (s_kt & (R - 1)) * KT;
+    const int lb = s_slot * KT;
     const int koffA = s_chunk * 128 + (TAPS ? (s_dy * p.W + s_dx) * (int)p.ldx * 2 : 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
     const int koffB = (s_tap * p.Cp + s_chunk * 64) * 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) G4_DMA(rs_w, bbyte, koffB + i * 8 * p.Kpad * 2, lb + 8192 + (wave * 2 + i) * 1024);
-    ++s_kt;
+    if (++s_slot == R) s_slot = 0;
     if (++s_chunk == e.nchunks) {
       s_chunk = 0; ++s_tap;
       if (++s_dx > e.P) { s_dx = -e.P; ++s_dy; }
@@ -112,14 +116,16 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
 
   const int nk = e.nk;
   for (int i = 0; i < R - 1 && i < nk; ++i) issue();
+  int c_slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // tiles 0 .. min(nk, kt+R-1)-1 are issued; tile kt must have landed, the (up to) R-2 after it may still fly
-    if (kt + R - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (R - 2)) : "memory");
+    if (R > 2 && kt + R - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (R > 2 ? R - 2 : 0)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (kt + R - 1 < nk) issue();
-    const unsigned ro = (unsigned)(kt & (R - 1)) * KT;
+    const unsigned ro = (unsigned)c_slot * KT;
+    if (++c_slot == R) c_slot = 0;
     u32x4 fa[2][2], fb[2][2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
@@ -252,10 +258,19 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.H >= 16384 || p.W >= 16384) return false;
   const long wbytes = (long)p.Cout * p.Kpad * 2;
   if (wbytes >= (1L << 31)) return false;
-  // 64 x 64 tiles re-read the weights once per M-tile and the pixels once per N-tile: only where both stay small.
-  static const long max_w = getenv("NPP_G4_MAX_WBYTES") ? atol(getenv("NPP_G4_MAX_WBYTES")) : (5L << 19);   // 2.5 MiB
+  // Where this kernel is used (all measured at N = 16, bf16, graph-replayed, us; this kernel vs the other one):
+  //   3x3, small maps : 128->128 @24^2 12 vs 25 (conv_s1 split-K), 256->256 @12^2 17 vs 29, 64->64 @48^2 10.5 vs 17 (generic),
+  //                     256->256 @48^2 77 vs 116, 512->512 @24^2 87 vs 138, 1024->1024 @12^2 93 vs 132
+  //   3x3 @96^2       : 128->128 fwd 81 vs 86, dgrad 67 vs 91 (taken); 384->128 205 vs 198 (left to conv_s1: weight limit)
+  //   1x1             : 512->128 @96^2 41 vs 50 (conv_g8), 128->128 @96^2 21 vs 28, 128->128 @24^2 4.5 vs 9.1, 1024->256 @12^2
+  //                     8.9 vs 24, 512->512 @24^2 14 vs 18; the deep and wide ones stay on conv_g8's 256-wide tiles
+  //                     (1024->512 @96^2 302 vs 190, its dgrad 371 vs 269, 512->256 dgrad 133 vs 110)
+  static const long max_w = getenv("NPP_G4_MAX_WBYTES") ? atol(getenv("NPP_G4_MAX_WBYTES")) : (64L << 20);
   static const int max_m = getenv("NPP_G4_MAX_M") ? atoi(getenv("NPP_G4_MAX_M")) : 40000;
-  if (wbytes > max_w || p.M > max_m) return false;
+  static const bool g8_off = getenv("NPP_DISABLE_G8") != nullptr;
+  if (wbytes > max_w) return false;
+  if (P > 0 && p.M > max_m && wbytes > (640L << 10)) return false;
+  if (P == 0 && !g8_off && p.Cin >= 256 && p.Cout >= 256 && p.Cout % 128 == 0 && p.M >= 65536) return false;
   G4Extra e;
   e.taps = p.KH * p.KW; e.nchunks = p.Cin / 64; e.nk = e.taps * e.nchunks; e.P = P; e.HW = p.H * p.W;
   e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
@@ -263,7 +278,7 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   IgemmParams q = p;
   q.mtiles = (p.M + 63) / 64; q.ntiles = p.Cout / 64;
   const int grid = q.mtiles * q.ntiles;
-  constexpr size_t lds = 4 * 16384 + 1024;
+  constexpr size_t lds = G4_RING * 16384 + 1024;
 #define G4_LAUNCH(RELU_, TAPS_)                                                                            \
   do {                                                                                                     \
     if (!g4_raise_lds(reinterpret_cast<const void*>(conv_g4_kernel<RELU_, TAPS_>), lds)) return false;     \

@@ -429,14 +429,14 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
   const double flops = 2.0 * (double)M * p.Cout * (double)(g->kh * g->kw) * p.Cin;
   const double bytes = ((double)x->n * x->h * x->w * x->c + (double)M * y->c + (double)p.Cout * g->kh * g->kw * p.Cin) * esize(x->dtype);
   {
-    ProfScope prof0(NPP_FAM_CONV_G8, x->dtype, s, flops, bytes);
-    if (conv_g8_launch(p, x->dtype, s)) return npp_check_launch("conv_g8");
-    prof0.cancel();
-  }
-  {
     ProfScope prof2(NPP_FAM_CONV_G4, x->dtype, s, flops, bytes);
     if (conv_g4_launch(p, x->dtype, s)) return npp_check_launch("conv_g4");
     prof2.cancel();
+  }
+  {
+    ProfScope prof0(NPP_FAM_CONV_G8, x->dtype, s, flops, bytes);
+    if (conv_g8_launch(p, x->dtype, s)) return npp_check_launch("conv_g8");
+    prof0.cancel();
   }
   {
     ProfScope prof1(NPP_FAM_CONV_S1, x->dtype, s, flops, bytes);

@@ -9,7 +9,7 @@ import torch
 
 import test_kernels_gpu as T
 
-assert os.environ.get("NPP_G8_MAXK") == "3"
+assert os.environ.get("NPP_G8_MAXK") == "3" and os.environ.get("NPP_DISABLE_G4") == "1"
 n = 0
 for case in T.CONV_CASES:
     cin, cout, k, stride, pad, dil, H, W, N = case[:9]
@@ -17,5 +17,5 @@ for case in T.CONV_CASES:
         T.test_conv_fwd_bwd(case, torch.bfloat16, 3e-2)
         n += 1
 assert n >= 2
-assert T._g8_launch_count(128, 128, 3) == 2, "3x3 did not run on conv_g8_kernel"
+assert T._g8_launch_count(128, 128, 3, "conv_g8", 160) == 2, "3x3 did not run on conv_g8_kernel"
 print("g8 taps ok", n)

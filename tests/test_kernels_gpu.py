@@ -51,10 +51,11 @@ CONV_CASES = [
     (256, 20, 1, 1, 0, 1, 12, 12, 2, False, True, 0),      # parsing head: Cout = 20 + bias
     (128, 16, 1, 1, 0, 1, 12, 12, 2, False, True, 0),      # pose head
     (32, 32, 3, 1, 2, 2, 16, 16, 2, True, False, 0),       # dense dilated (DilConv)
-    # large maps (>= 192 output tiles): 1x1 on the 8-phase LDS-DMA kernel (conv_g8.hip) in bf16, conv_s1 otherwise
+    # large maps: bf16 runs on the LDS-DMA kernels (conv_g4.hip 64x64 tiles / conv_g8.hip 256-wide tiles), f32 on conv_s1
     (64, 128, 1, 1, 0, 1, 160, 160, 2, True, True, 0),     # g8 BN=128, 1x1 + bias, one K-tile per output tile
     (128, 256, 1, 1, 0, 1, 225, 225, 1, True, False, 8),   # g8 BN=256, ragged M, channel-slice input; dgrad with mask
-    (256, 128, 1, 1, 0, 1, 160, 160, 2, False, False, 0),  # g8 BN=128 fwd, BN=256 dgrad without mask, 4 K-tiles
+    (256, 256, 1, 1, 0, 1, 192, 192, 2, False, False, 0),  # g8 BN=256 fwd + dgrad without mask, 4 K-tiles (deep and wide: not g4)
+    (256, 128, 1, 1, 0, 1, 160, 160, 2, False, False, 0),  # g4 on a large map, dgrad N=256
     (64, 128, 3, 1, 1, 1, 225, 225, 1, True, False, 0),    # 3x3 on a large map, ragged M (g8 when NPP_G8_MAXK=3: see below)
     (128, 128, 3, 1, 1, 1, 160, 160, 2, False, True, 0),   # 3x3 + bias, two channel chunks; dgrad without mask
 ]
@@ -102,35 +103,39 @@ def test_conv_fwd_bwd(case, dtype, tol):
         assert rel_err(b.grad.cpu().numpy(), br.grad.numpy()) < tol
 
 
-def _g8_launch_count(cin, cout, k):
-    """fwd + dgrad of one large-map conv in bf16 -> number of conv_g8_kernel launches (profiler family counter)."""
+def _g8_launch_count(cin, cout, k, fam="conv_g8", hw=192):
+    """fwd + dgrad of one conv in bf16 -> number of launches of the given conv kernel family (profiler family counter)."""
     import ctypes as C
     from npp_amd import _ops as K
     from npp_amd import _lib
     L = _lib.lib()
     dev = _dev()
-    x = K.cast(torch.randn(2, cin, 160, 160, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16)
+    x = K.cast(torch.randn(2, cin, hw, hw, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16)
     x.requires_grad_(True)
     w = (torch.randn(cout, cin, k, k, device=dev) * 0.03).requires_grad_(True)
-    L.npp_prof_begin(_lib.FAM["conv_g8"], _lib.NPP_BF16)
+    L.npp_prof_begin(_lib.FAM[fam], _lib.NPP_BF16)
     y, _ = K.conv2d(x, w, None, 1, k // 2, 1, relu_in=True, want_stats=True)
-    y.backward(K.cast(torch.randn(2, cout, 160, 160, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16))
+    y.backward(K.cast(torch.randn(2, cout, hw, hw, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16))
     torch.cuda.synchronize()
     ms, fl, by, nl = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
     L.npp_prof_end(C.byref(ms), C.byref(fl), C.byref(by), C.byref(nl))
     return nl.value
 
 
-def test_large_maps_take_the_g8_kernel():
-    """The large-map 1x1 cases above must run on conv_g8_kernel in bf16 (fwd and dgrad), not on a fallback."""
-    assert _g8_launch_count(128, 256, 1) == 2
+def test_shapes_take_their_lds_dma_kernels():
+    """Deep and wide 1x1 convs on large maps run on conv_g8_kernel, small maps / 64-channel layers / the 128->128 3x3 on
+    conv_g4_kernel (fwd and dgrad), in bf16 -- not on a fallback."""
+    assert _g8_launch_count(256, 256, 1, "conv_g8", 192) == 2
+    assert _g8_launch_count(128, 128, 3, "conv_g4", 24) == 2
+    assert _g8_launch_count(64, 64, 3, "conv_g4", 48) == 2
+    assert _g8_launch_count(128, 128, 3, "conv_g4", 160) == 2
 
 
 def test_g8_taps_variant_in_subprocess():
     """The KxK (per-tap shift, zero border by out-of-range DMA) variant of conv_g8_kernel is opt-in (NPP_G8_MAXK=3, read once
     per process): run the large-map 3x3 parity cases on it in ONE child process."""
     import os, subprocess, sys
-    env = dict(os.environ, NPP_G8_MAXK="3")
+    env = dict(os.environ, NPP_G8_MAXK="3", NPP_DISABLE_G4="1")
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "g8_taps_worker.py")], env=env, capture_output=True, text=True,
                        timeout=600)

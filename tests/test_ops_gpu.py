@@ -308,9 +308,10 @@ def test_two_stream_forward_equals_single_stream(monkeypatch):
         res[mode] = (ev, [_f32(t) for pair in p + q for t in pair],
                      {k: _f32(v.grad) for k, v in net.named_parameters() if v.grad is not None})
     for other in ("2", "3"):
-        for a, b in zip(res["1"][0], res[other][0]):
-            assert rel_err(a, b) < 1e-5       # not bit-equal: the SE squeeze (global average) sums with float atomics
-        for a, b in zip(res["1"][1], res[other][1]):
-            assert rel_err(a, b) < 1e-5
+        for i, (a, b) in enumerate(zip(res["1"][0], res[other][0])):
+            # not bit-equal: the SE squeeze (global average) sums with float atomics
+            assert rel_err(a, b) < 1e-5, ("eval output", other, i, rel_err(a, b))
+        for i, (a, b) in enumerate(zip(res["1"][1], res[other][1])):
+            assert rel_err(a, b) < 1e-5, ("train output", other, i, rel_err(a, b))
         for k, a in res["1"][2].items():
-            assert rel_err(res[other][2][k], a) < 1e-3 or np.abs(a).max() < 1e-6, (other, k)
+            assert rel_err(res[other][2][k], a) < 1e-3 or np.abs(a).max() < 1e-6, ("grad", other, k, rel_err(res[other][2][k], a))
