@@ -2,12 +2,14 @@
 // 3x3: M = 9216 / 2304 pixels) and the 64-channel convs of the second encoder stage (64->64 3x3 @48^2, 256->64 1x1).
 // These are latency-, not FLOP-bound: conv_s1's 128/256-row tiles leave 3/4 of the chip idle unless it splits K and runs a
 // second "finish" launch, and the generic gather kernel pays a per-tap gather.  Here the tile is 64 pixels x 64 channels
-// (4.5x-18x more blocks), several blocks share a CU (64 KiB of LDS, ~70 VGPRs), and the operands travel by LDS-DMA exactly
+// (4.5x-18x more blocks; 128 x 128 once that alone gives a block per CU), several blocks share a CU (32-64 KiB of LDS, 54-117
+// VGPRs) -- occupancy, not in-block pipelining, hides the latencies: a ring of 2 beats 3, 4 and 8 -- and the operands travel
+// by LDS-DMA exactly
 // as in conv_g8.hip: K-tile = 64 channels of one tap, 1-KiB pieces of 8 rows x 128 B XOR-swizzled on the source address
 // and on the fragment read, out-of-image rows of a tap = out-of-range buffer offset (the DMA writes zeros).
-//   * ring of 4 K-tile buffers (A 8 KiB + B 8 KiB each), three K-tiles in flight, ONE barrier per K-tile:
-//       wait vmcnt(8) (tile t landed, t+1 and t+2 still flying) ; s_barrier ; issue tile t+3 into the buffer tile t-1 used ;
-//       8 fragment reads ; 8 MFMA 16x16x32 per wave (2 x 2 fragments, K = 64)
+//   * ring of G4_RING (2) K-tile buffers, ONE barrier per K-tile:
+//       wait for tile t (counted vmcnt when the ring is deeper than 2) ; s_barrier ; issue tile t+R-1 into the buffer tile t-1
+//       used ; fragment reads ; MFMA 16x16x32 (2 x 2 or 4 x 4 fragments per wave, K = 64)
 //     -- a wave that reaches barrier t has issued the MFMAs of tile t-1, hence has all its fragments: the buffer is free.
 //   * no persistence, no wave stagger: co-resident blocks hide each other's prologue and barrier waits.
 //   * epilogue as conv_g8 (C^T accumulators, v_permlane16_swap -> 16-byte stores, packed-int16 ReLU-backward mask, BN sum /
@@ -41,11 +43,15 @@ NPP_DEV u32x4 relu_bf16x8_g4(u32x4 v) {
   return __builtin_bit_cast(u32x4, s);
 }
 
-template <bool RELU, bool TAPS>
+// BM x BN output tile (64 or 128 each), 4 waves as 2 x 2, each (BM/2) x (BN/2)
+template <int BM, int BN, bool RELU, bool TAPS>
 __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) {
   constexpr int R = G4_RING;           // ring depth
-  constexpr int KT = 16384;            // bytes per K-tile buffer: A [64 rows][128 B] then B [64 rows][128 B]
-  constexpr int RED = R * KT;          // statistics exchange [2 wm][64 ch][2] floats
+  constexpr int AB = BM * 128;         // bytes of the A part of a K-tile buffer: [BM rows][128 B]
+  constexpr int KT = (BM + BN) * 128;  // bytes per K-tile buffer: A then B [BN rows][128 B]
+  constexpr int RED = R * KT;          // statistics exchange [2 wm][BN ch][2] floats
+  constexpr int MI = BM / 32, NI = BN / 32;      // 16 x 16 fragments per wave
+  constexpr int PA = BM / 32, PB = BN / 32;      // DMA instructions (1-KiB pieces) per wave per K-tile
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   const int t = threadIdx.x, lane = t & 63;
@@ -59,20 +65,20 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
   const int bid = blockIdx.x;
   const int xcd = bid & 7, qd = total >> 3, rm = total & 7;
   const int lid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-  const int m0 = (lid / p.ntiles) * 64, n0 = (lid % p.ntiles) * 64;
+  const int m0 = (lid / p.ntiles) * BM, n0 = (lid % p.ntiles) * BN;
 
   const int lrow = lane & 15, lk = lane >> 4;
   const unsigned loff0 = (lrow >> 3) * 1024 + (lrow & 7) * 128 + ((lk ^ (lrow & 7)) << 4);
-  const unsigned rdA0 = wm * 4096 + loff0, rdA1 = wm * 4096 + (loff0 ^ 64);                 // + mi*2048 + ring offset
-  const unsigned rdB0 = 8192 + wn * 4096 + loff0, rdB1 = 8192 + wn * 4096 + (loff0 ^ 64);   // + ni*2048 + ring offset
+  const unsigned rdA0 = wm * (BM / 2) * 128 + loff0, rdA1 = wm * (BM / 2) * 128 + (loff0 ^ 64);            // + mi*2048 + ring offset
+  const unsigned rdB0 = AB + wn * (BN / 2) * 128 + loff0, rdB1 = AB + wn * (BN / 2) * 128 + (loff0 ^ 64);  // + ni*2048 + ring offset
 
-  // staging: this wave fills pieces 2*wave, 2*wave+1 of A and of B; lane -> row 8*piece + (lane>>3), source piece (lane&7)^(lane>>3)
+  // staging: this wave fills pieces PA*wave .. PA*wave+PA-1 of A (PB of B); lane -> row 8*piece + (lane>>3), source piece (lane&7)^(lane>>3)
   const int sl = lane >> 3, spb = ((lane & 7) ^ sl) * 16;
-  unsigned abyte[2];
-  int ayx[2];
+  unsigned abyte[PA];
+  int ayx[PA];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int q = m0 + (wave * 2 + i) * 8 + sl;
+  for (int i = 0; i < PA; ++i) {
+    int q = m0 + (wave * PA + i) * 8 + sl;
     const bool real = q < p.M;
     if (!real) q = p.M - 1;
     abyte[i] = (unsigned)q * (unsigned)p.ldx * 2u + spb;
@@ -83,24 +89,24 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
       ayx[i] = real ? ((y << 16) | (rem - y * p.W)) : (0x4000 << 16);
     }
   }
-  const unsigned bbyte = (unsigned)(n0 + wave * 16 + sl) * (unsigned)p.Kpad * 2u + spb;   // second piece: +8 rows (scalar offset)
+  const unsigned bbyte = (unsigned)(n0 + wave * PB * 8 + sl) * (unsigned)p.Kpad * 2u + spb;   // further pieces: +8 rows each (scalar offset)
 
   int s_tap = 0, s_chunk = 0, s_dy = -e.P, s_dx = -e.P, s_slot = 0;
   auto issue = [&]() {     // K-tile s_kt of the stream into ring slot s_kt % R
     const int lb = s_slot * KT;
     const int koffA = s_chunk * 128 + (TAPS ? (s_dy * p.W + s_dx) * (int)p.ldx * 2 : 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < PA; ++i) {
       unsigned v = abyte[i] + (unsigned)koffA;
       if (TAPS) {
         const int y = (ayx[i] >> 16) + s_dy, x = (ayx[i] & 0xFFFF) + s_dx;
         if (!((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)) v = 0xFFFFFFFFu;
       }
-      G4_DMA(rs_x, v, 0, lb + (wave * 2 + i) * 1024);
+      G4_DMA(rs_x, v, 0, lb + (wave * PA + i) * 1024);
     }
     const int koffB = (s_tap * p.Cp + s_chunk * 64) * 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) G4_DMA(rs_w, bbyte, koffB + i * 8 * p.Kpad * 2, lb + 8192 + (wave * 2 + i) * 1024);
+    for (int i = 0; i < PB; ++i) G4_DMA(rs_w, bbyte, koffB + i * 8 * p.Kpad * 2, lb + AB + (wave * PB + i) * 1024);
     if (++s_slot == R) s_slot = 0;
     if (++s_chunk == e.nchunks) {
       s_chunk = 0; ++s_tap;
@@ -108,32 +114,32 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
     }
   };
 
-  f32x4w acc[2][2];
+  f32x4w acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4w{0.f, 0.f, 0.f, 0.f};
 
   const int nk = e.nk;
   for (int i = 0; i < R - 1 && i < nk; ++i) issue();
   int c_slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // tiles 0 .. min(nk, kt+R-1)-1 are issued; tile kt must have landed, the (up to) R-2 after it may still fly
-    if (R > 2 && kt + R - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (R > 2 ? R - 2 : 0)) : "memory");
+    if (R > 2 && kt + R - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PA + PB) * (R > 2 ? R - 2 : 0)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (kt + R - 1 < nk) issue();
     const unsigned ro = (unsigned)c_slot * KT;
     if (++c_slot == R) c_slot = 0;
-    u32x4 fa[2][2], fb[2][2];
+    u32x4 fa[MI][2], fb[NI][2];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
       fb[ni][0] = *reinterpret_cast<const u32x4*>(smem + ro + rdB0 + ni * 2048);
       fb[ni][1] = *reinterpret_cast<const u32x4*>(smem + ro + rdB1 + ni * 2048);
     }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
       fa[mi][0] = *reinterpret_cast<const u32x4*>(smem + ro + rdA0 + mi * 2048);
       fa[mi][1] = *reinterpret_cast<const u32x4*>(smem + ro + rdA1 + mi * 2048);
       if (RELU) { fa[mi][0] = relu_bf16x8_g4(fa[mi][0]); fa[mi][1] = relu_bf16x8_g4(fa[mi][1]); }
@@ -141,90 +147,96 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ni][kb]),
                                                                 __builtin_bit_cast(bf16x8, fa[mi][kb]), acc[mi][ni], 0, 0, 0);
   }
 
-  // ---- epilogue (see conv_g8.hip): acc[mi][ni][j] = C[pixel m0 + wm*32 + mi*16 + lrow][channel n0 + wn*32 + ni*16 + 4*lk + j]
+  // ---- epilogue (see conv_g8.hip): acc[mi][ni][j] = C[pixel m0 + wm*BM/2 + mi*16 + lrow][channel n0 + wn*BN/2 + ni*16 + 4*lk + j];
+  // fragments ni = 2*nb, 2*nb+1 form a 32-channel block whose lanes pair up (v_permlane16_swap) into 16-byte stores
   bf16_t* __restrict__ yg = reinterpret_cast<bf16_t*>(p.y);
   const bf16_t* __restrict__ mg = reinterpret_cast<const bf16_t*>(p.mask);
   const bool want_stats = p.stats != nullptr;
-  const int cb = n0 + wn * 32;
   const int chb = (lk & 1) * 16 + (lk >> 1) * 8;
-  f32x4w bias[2];
+  float* red = reinterpret_cast<float*>(smem + RED);     // [wm][BN channels][2]
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-    bias[ni] = p.bias ? *reinterpret_cast<const f32x4w*>(p.bias + cb + ni * 16 + lk * 4) : f32x4w{0.f, 0.f, 0.f, 0.f};
-  u32x4 mk[2];
-  if (mg) {
+  for (int nb = 0; nb < NI / 2; ++nb) {
+    const int cb = n0 + wn * (BN / 2) + nb * 32;
+    f32x4w bias[2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const long gm = (long)m0 + wm * 32 + mi * 16 + lrow;
-      mk[mi] = gm < p.M ? *reinterpret_cast<const u32x4*>(mg + gm * p.ldm + cb + chb) : u32x4{0u, 0u, 0u, 0u};
+    for (int h = 0; h < 2; ++h)
+      bias[h] = p.bias ? *reinterpret_cast<const f32x4w*>(p.bias + cb + h * 16 + lk * 4) : f32x4w{0.f, 0.f, 0.f, 0.f};
+    u32x4 mk[MI];
+    if (mg) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const long gm = (long)m0 + wm * (BM / 2) + mi * 16 + lrow;
+        mk[mi] = gm < p.M ? *reinterpret_cast<const u32x4*>(mg + gm * p.ldm + cb + chb) : u32x4{0u, 0u, 0u, 0u};
+      }
     }
-  }
-  float ss[2][4], sq[2][4];
+    float ss[2][4], sq[2][4];
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { ss[ni][j] = 0.f; sq[ni][j] = 0.f; }
+      for (int j = 0; j < 4; ++j) { ss[h][j] = 0.f; sq[h][j] = 0.f; }
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const long gm = (long)m0 + wm * 32 + mi * 16 + lrow;
-    const bool live = gm < p.M;
-    unsigned pk[2][2];
+    for (int mi = 0; mi < MI; ++mi) {
+      const long gm = (long)m0 + wm * (BM / 2) + mi * 16 + lrow;
+      const bool live = gm < p.M;
+      unsigned pk[2][2];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      float v[4];
+      for (int h = 0; h < 2; ++h) {
+        float v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j] + bias[ni][j];
-      pk[ni][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-      pk[ni][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-      if (want_stats && live) {
+        for (int j = 0; j < 4; ++j) v[j] = acc[mi][nb * 2 + h][j] + bias[h][j];
+        pk[h][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        pk[h][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        if (want_stats && live) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float r = __uint_as_float((j & 1) ? (pk[ni][j >> 1] & 0xFFFF0000u) : (pk[ni][j >> 1] << 16));
-          ss[ni][j] += r; sq[ni][j] += r * r;
+          for (int j = 0; j < 4; ++j) {
+            const float r = __uint_as_float((j & 1) ? (pk[h][j >> 1] & 0xFFFF0000u) : (pk[h][j >> 1] << 16));
+            ss[h][j] += r; sq[h][j] += r * r;
+          }
         }
       }
-    }
-    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-    u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-    if (live) {
-      if (mg) {
-        const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        s16x8 m = __builtin_elementwise_max(__builtin_bit_cast(s16x8, mk[mi]), z);
-        m = (z - m) >> 15;
-        o = o & __builtin_bit_cast(u32x4, m);
+      const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+      u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+      if (live) {
+        if (mg) {
+          const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+          s16x8 m = __builtin_elementwise_max(__builtin_bit_cast(s16x8, mk[mi]), z);
+          m = (z - m) >> 15;
+          o = o & __builtin_bit_cast(u32x4, m);
+        }
+        *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
       }
-      *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
+    }
+    if (want_stats) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float s = ss[h][j], q = sq[h][j];
+#define G4_DPP_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true))
+          G4_DPP_ADD(s, 0xB1); G4_DPP_ADD(q, 0xB1);
+          G4_DPP_ADD(s, 0x4E); G4_DPP_ADD(q, 0x4E);
+          G4_DPP_ADD(s, 0x141); G4_DPP_ADD(q, 0x141);
+          G4_DPP_ADD(s, 0x140); G4_DPP_ADD(q, 0x140);
+#undef G4_DPP_ADD
+          if (lrow == 0) {
+            float* d = red + ((wm * BN) + wn * (BN / 2) + nb * 32 + h * 16 + lk * 4 + j) * 2;
+            d[0] = s; d[1] = q;
+          }
+        }
     }
   }
   if (want_stats) {
-    float* red = reinterpret_cast<float*>(smem + RED);     // [wm][64 channels][2]
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float s = ss[ni][j], q = sq[ni][j];
-#define G4_DPP_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true))
-        G4_DPP_ADD(s, 0xB1); G4_DPP_ADD(q, 0xB1);
-        G4_DPP_ADD(s, 0x4E); G4_DPP_ADD(q, 0x4E);
-        G4_DPP_ADD(s, 0x141); G4_DPP_ADD(q, 0x141);
-        G4_DPP_ADD(s, 0x140); G4_DPP_ADD(q, 0x140);
-#undef G4_DPP_ADD
-        if (lrow == 0) {
-          float* d = red + ((wm * 64) + wn * 32 + ni * 16 + lk * 4 + j) * 2;
-          d[0] = s; d[1] = q;
-        }
-      }
     __syncthreads();
-    if (t < 64 && n0 + t < p.Cout) {
-      const float s = red[t * 2] + red[(64 + t) * 2], q = red[t * 2 + 1] + red[(64 + t) * 2 + 1];
+    if (t < BN && n0 + t < p.Cout) {
+      const float s = red[t * 2] + red[(BN + t) * 2], q = red[t * 2 + 1] + red[(BN + t) * 2 + 1];
       double* st = p.stats + (long)(bid % NPP_STAT_REPLICAS) * 2 * p.Cout;
       atomicAdd(st + n0 + t, (double)s);
       atomicAdd(st + p.Cout + n0 + t, (double)q);
@@ -233,11 +245,11 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
 }
 
 bool g4_raise_lds(const void* fp, size_t bytes) {
-  static thread_local const void* done[8];
-  for (int i = 0; i < 8; ++i)
+  static thread_local const void* done[16];
+  for (int i = 0; i < 16; ++i)
     if (done[i] == fp) return true;
   if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 16; ++i)
     if (!done[i]) { done[i] = fp; break; }
   return true;
 }
@@ -261,7 +273,7 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   // Where this kernel is used (all measured at N = 16, bf16, graph-replayed, us; this kernel vs the other one):
   //   3x3, small maps : 128->128 @24^2 12 vs 25 (conv_s1 split-K), 256->256 @12^2 17 vs 29, 64->64 @48^2 10.5 vs 17 (generic),
   //                     256->256 @48^2 77 vs 116, 512->512 @24^2 87 vs 138, 1024->1024 @12^2 93 vs 132
-  //   3x3 @96^2       : 128->128 fwd 81 vs 86, dgrad 67 vs 91 (taken); 384->128 205 vs 198 (left to conv_s1: weight limit)
+  //   3x3 @96^2       : 128->128 fwd 63 vs 86, dgrad 62 vs 91; 384->128 fwd 179 vs 198, dgrad 158 vs 210 (128 x 128 tiles)
   //   1x1             : 512->128 @96^2 41 vs 50 (conv_g8), 128->128 @96^2 21 vs 28, 128->128 @24^2 4.5 vs 9.1, 1024->256 @12^2
   //                     8.9 vs 24, 512->512 @24^2 14 vs 18; the deep and wide ones stay on conv_g8's 256-wide tiles
   //                     (1024->512 @96^2 302 vs 190, its dgrad 371 vs 269, 512->256 dgrad 133 vs 110)
@@ -269,23 +281,38 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   static const int max_m = getenv("NPP_G4_MAX_M") ? atoi(getenv("NPP_G4_MAX_M")) : 40000;
   static const bool g8_off = getenv("NPP_DISABLE_G8") != nullptr;
   if (wbytes > max_w) return false;
-  if (P > 0 && p.M > max_m && wbytes > (640L << 10)) return false;
+  if (P > 0 && p.M > max_m && wbytes > (2L << 20)) return false;
   if (P == 0 && !g8_off && p.Cin >= 256 && p.Cout >= 256 && p.Cout % 128 == 0 && p.M >= 65536) return false;
   G4Extra e;
   e.taps = p.KH * p.KW; e.nchunks = p.Cin / 64; e.nk = e.taps * e.nchunks; e.P = P; e.HW = p.H * p.W;
   e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
   e.wbytes = (unsigned)wbytes;
+  // tile: 128 x 128 halves the operand bytes per MAC (2 blocks per CU); 64 x 64 gives 4x the blocks (4 per CU).  Measured
+  // (128 vs 64, us): 128->128 3x3 @96^2 63 vs 76 (conv_s1: 86), 384->128 3x3 179 vs 192, 512->512 @24^2 74 vs 86 (288 large
+  // tiles), 256->256 @48^2 73 vs 78 (576); 256->256 @24^2 32 vs 24 (144), 128->128 @24^2 18 vs 12 (72): the large tile from
+  // one block per CU on.
+  static const int force_tile = getenv("NPP_G4_TILE") ? atoi(getenv("NPP_G4_TILE")) : 0;
+  static const int big_min_tiles = getenv("NPP_G4_BIG_MIN_TILES") ? atoi(getenv("NPP_G4_BIG_MIN_TILES")) : 256;
+  int bm = 64, bn = 64;
+  if (p.Cout % 128 == 0 && (long)((p.M + 127) / 128) * (p.Cout / 128) >= big_min_tiles) { bm = 128; bn = 128; }
+  if (force_tile == 64) { bm = 64; bn = 64; }
+  if (force_tile == 128 && p.Cout % 128 == 0) { bm = 128; bn = 128; }
   IgemmParams q = p;
-  q.mtiles = (p.M + 63) / 64; q.ntiles = p.Cout / 64;
+  q.mtiles = (p.M + bm - 1) / bm; q.ntiles = p.Cout / bn;
   const int grid = q.mtiles * q.ntiles;
-  constexpr size_t lds = G4_RING * 16384 + 1024;
-#define G4_LAUNCH(RELU_, TAPS_)                                                                            \
+#define G4_LAUNCH(BM_, BN_, RELU_, TAPS_)                                                                  \
   do {                                                                                                     \
-    if (!g4_raise_lds(reinterpret_cast<const void*>(conv_g4_kernel<RELU_, TAPS_>), lds)) return false;     \
-    hipLaunchKernelGGL((conv_g4_kernel<RELU_, TAPS_>), dim3(grid), dim3(256), lds, stream, q, e);          \
+    constexpr size_t lds = G4_RING * (BM_ + BN_) * 128 + 2 * BN_ * 2 * 4;                                   \
+    if (!g4_raise_lds(reinterpret_cast<const void*>(conv_g4_kernel<BM_, BN_, RELU_, TAPS_>), lds)) return false; \
+    hipLaunchKernelGGL((conv_g4_kernel<BM_, BN_, RELU_, TAPS_>), dim3(grid), dim3(256), lds, stream, q, e); \
   } while (0)
-  if (P == 0) { if (p.relu_in) G4_LAUNCH(true, false); else G4_LAUNCH(false, false); }
-  else        { if (p.relu_in) G4_LAUNCH(true, true);  else G4_LAUNCH(false, true); }
+#define G4_PICK(BM_, BN_)                                                                                  \
+  do {                                                                                                     \
+    if (P == 0) { if (p.relu_in) G4_LAUNCH(BM_, BN_, true, false); else G4_LAUNCH(BM_, BN_, false, false); } \
+    else        { if (p.relu_in) G4_LAUNCH(BM_, BN_, true, true);  else G4_LAUNCH(BM_, BN_, false, true); }  \
+  } while (0)
+  if (bm == 128) G4_PICK(128, 128); else G4_PICK(64, 64);
+#undef G4_PICK
 #undef G4_LAUNCH
   return true;
 }
