@@ -43,20 +43,25 @@ NPP_DEV u32x4 relu_bf16x8_g4(u32x4 v) {
   return __builtin_bit_cast(u32x4, s);
 }
 
-// BM x BN output tile (64 or 128 each), 4 waves as 2 x 2, each (BM/2) x (BN/2)
-template <int BM, int BN, bool RELU, bool TAPS>
+// BM x BN output tile, 4 waves as WM_ x (4 / WM_): 64 x 64 and 128 x 128 as 2 x 2, 64 x 32 (32 output channels) as 4 x 1.
+// HALF: 32 input channels -- a K-tile is then TWO taps x 32 channels (source piece 0-3 = tap 2t, 4-7 = tap 2t+1, selected per
+// lane; the packed weight rows are already contiguous in (tap, channel)), the last one zero-filled when the tap count is odd.
+template <int BM, int BN, int WM_, bool RELU, bool TAPS, bool HALF>
 __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) {
+  constexpr int WN_ = 4 / WM_;
+  constexpr int TM = BM / WM_, TN = BN / WN_;    // per-wave tile
   constexpr int R = G4_RING;           // ring depth
   constexpr int AB = BM * 128;         // bytes of the A part of a K-tile buffer: [BM rows][128 B]
   constexpr int KT = (BM + BN) * 128;  // bytes per K-tile buffer: A then B [BN rows][128 B]
-  constexpr int RED = R * KT;          // statistics exchange [2 wm][BN ch][2] floats
-  constexpr int MI = BM / 32, NI = BN / 32;      // 16 x 16 fragments per wave
+  constexpr int RED = R * KT;          // statistics exchange [WM_][BN ch][2] floats
+  constexpr int MI = TM / 16, NI = TN / 16;      // 16 x 16 fragments per wave
+  static_assert(NI >= 2 && NI % 2 == 0 && MI >= 1, "the epilogue pairs N fragments");
   constexpr int PA = BM / 32, PB = BN / 32;      // DMA instructions (1-KiB pieces) per wave per K-tile
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN_, wn = wave % WN_;
   const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
   const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, e.wbytes, 0x00020000);
 
@@ -69,11 +74,13 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
 
   const int lrow = lane & 15, lk = lane >> 4;
   const unsigned loff0 = (lrow >> 3) * 1024 + (lrow & 7) * 128 + ((lk ^ (lrow & 7)) << 4);
-  const unsigned rdA0 = wm * (BM / 2) * 128 + loff0, rdA1 = wm * (BM / 2) * 128 + (loff0 ^ 64);            // + mi*2048 + ring offset
-  const unsigned rdB0 = AB + wn * (BN / 2) * 128 + loff0, rdB1 = AB + wn * (BN / 2) * 128 + (loff0 ^ 64);  // + ni*2048 + ring offset
+  const unsigned rdA0 = wm * TM * 128 + loff0, rdA1 = wm * TM * 128 + (loff0 ^ 64);            // + mi*2048 + ring offset
+  const unsigned rdB0 = AB + wn * TN * 128 + loff0, rdB1 = AB + wn * TN * 128 + (loff0 ^ 64);  // + ni*2048 + ring offset
 
   // staging: this wave fills pieces PA*wave .. PA*wave+PA-1 of A (PB of B); lane -> row 8*piece + (lane>>3), source piece (lane&7)^(lane>>3)
-  const int sl = lane >> 3, spb = ((lane & 7) ^ sl) * 16;
+  const int sl = lane >> 3, sp = (lane & 7) ^ sl, spb = sp * 16;
+  const int spa = HALF ? (sp & 3) * 16 : spb;     // channel bytes of the lane's piece inside its pixel
+  const bool tap_hi = HALF && (sp >> 2);          // HALF: the lane stages the second tap of the pair
   unsigned abyte[PA];
   int ayx[PA];
 #pragma unroll
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
     int q = m0 + (wave * PA + i) * 8 + sl;
     const bool real = q < p.M;
     if (!real) q = p.M - 1;
-    abyte[i] = (unsigned)q * (unsigned)p.ldx * 2u + spb;
+    abyte[i] = (unsigned)q * (unsigned)p.ldx * 2u + spa;
     ayx[i] = 0;
     if (TAPS) {
       const int rem = q % e.HW;
@@ -91,27 +98,50 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
   }
   const unsigned bbyte = (unsigned)(n0 + wave * PB * 8 + sl) * (unsigned)p.Kpad * 2u + spb;   // further pieces: +8 rows each (scalar offset)
 
-  int s_tap = 0, s_chunk = 0, s_dy = -e.P, s_dx = -e.P, s_slot = 0;
-  auto issue = [&]() {     // K-tile s_kt of the stream into ring slot s_kt % R
+  int s_tap = 0, s_chunk = 0, s_dy = -e.P, s_dx = -e.P, s_slot = 0, s_kt = 0;
+  auto issue = [&]() {     // the next K-tile of the stream into ring slot s_slot
     const int lb = s_slot * KT;
-    const int koffA = s_chunk * 128 + (TAPS ? (s_dy * p.W + s_dx) * (int)p.ldx * 2 : 0);
+    if constexpr (!HALF) {
+      const int koffA = s_chunk * 128 + (TAPS ? (s_dy * p.W + s_dx) * (int)p.ldx * 2 : 0);
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      unsigned v = abyte[i] + (unsigned)koffA;
-      if (TAPS) {
-        const int y = (ayx[i] >> 16) + s_dy, x = (ayx[i] & 0xFFFF) + s_dx;
-        if (!((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)) v = 0xFFFFFFFFu;
+      for (int i = 0; i < PA; ++i) {
+        unsigned v = abyte[i] + (unsigned)koffA;
+        if (TAPS) {
+          const int y = (ayx[i] >> 16) + s_dy, x = (ayx[i] & 0xFFFF) + s_dx;
+          if (!((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)) v = 0xFFFFFFFFu;
+        }
+        G4_DMA(rs_x, v, 0, lb + (wave * PA + i) * 1024);
       }
-      G4_DMA(rs_x, v, 0, lb + (wave * PA + i) * 1024);
-    }
-    const int koffB = (s_tap * p.Cp + s_chunk * 64) * 2;
+      const int koffB = (s_tap * p.Cp + s_chunk * 64) * 2;
 #pragma unroll
-    for (int i = 0; i < PB; ++i) G4_DMA(rs_w, bbyte, koffB + i * 8 * p.Kpad * 2, lb + AB + (wave * PB + i) * 1024);
-    if (++s_slot == R) s_slot = 0;
-    if (++s_chunk == e.nchunks) {
-      s_chunk = 0; ++s_tap;
-      if (++s_dx > e.P) { s_dx = -e.P; ++s_dy; }
+      for (int i = 0; i < PB; ++i) G4_DMA(rs_w, bbyte, koffB + i * 8 * p.Kpad * 2, lb + AB + (wave * PB + i) * 1024);
+      if (++s_chunk == e.nchunks) {
+        s_chunk = 0; ++s_tap;
+        if (++s_dx > e.P) { s_dx = -e.P; ++s_dy; }
+      }
+    } else {
+      const int t0 = 2 * s_kt, t1 = t0 + 1;
+      const int dy0 = t0 / p.KW - e.P, dx0 = t0 % p.KW - e.P, dy1 = t1 / p.KW - e.P, dx1 = t1 % p.KW - e.P;
+      const int my_dy = tap_hi ? dy1 : dy0, my_dx = tap_hi ? dx1 : dx0;
+      const bool tap_ok = (tap_hi ? t1 : t0) < e.taps;
+      const int shift = (my_dy * p.W + my_dx) * (int)p.ldx * 2;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        unsigned v = abyte[i] + (unsigned)shift;
+        bool ok = tap_ok;
+        if (TAPS) {
+          const int y = (ayx[i] >> 16) + my_dy, x = (ayx[i] & 0xFFFF) + my_dx;
+          ok = ok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        }
+        if (!ok) v = 0xFFFFFFFFu;
+        G4_DMA(rs_x, v, 0, lb + (wave * PA + i) * 1024);
+      }
+      const int koffB = s_kt * 128;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) G4_DMA(rs_w, bbyte, koffB + i * 8 * p.Kpad * 2, lb + AB + (wave * PB + i) * 1024);
+      ++s_kt;
     }
+    if (++s_slot == R) s_slot = 0;
   };
 
   f32x4w acc[MI][NI];
@@ -160,10 +190,10 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
   const bf16_t* __restrict__ mg = reinterpret_cast<const bf16_t*>(p.mask);
   const bool want_stats = p.stats != nullptr;
   const int chb = (lk & 1) * 16 + (lk >> 1) * 8;
-  float* red = reinterpret_cast<float*>(smem + RED);     // [wm][BN channels][2]
+  float* red = reinterpret_cast<float*>(smem + RED);     // [WM_][BN channels][2]
 #pragma unroll
   for (int nb = 0; nb < NI / 2; ++nb) {
-    const int cb = n0 + wn * (BN / 2) + nb * 32;
+    const int cb = n0 + wn * TN + nb * 32;
     f32x4w bias[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -172,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
     if (mg) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const long gm = (long)m0 + wm * (BM / 2) + mi * 16 + lrow;
+        const long gm = (long)m0 + wm * TM + mi * 16 + lrow;
         mk[mi] = gm < p.M ? *reinterpret_cast<const u32x4*>(mg + gm * p.ldm + cb + chb) : u32x4{0u, 0u, 0u, 0u};
       }
     }
@@ -183,7 +213,7 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
       for (int j = 0; j < 4; ++j) { ss[h][j] = 0.f; sq[h][j] = 0.f; }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      const long gm = (long)m0 + wm * (BM / 2) + mi * 16 + lrow;
+      const long gm = (long)m0 + wm * TM + mi * 16 + lrow;
       const bool live = gm < p.M;
       unsigned pk[2][2];
 #pragma unroll
@@ -227,7 +257,7 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
           G4_DPP_ADD(s, 0x140); G4_DPP_ADD(q, 0x140);
 #undef G4_DPP_ADD
           if (lrow == 0) {
-            float* d = red + ((wm * BN) + wn * (BN / 2) + nb * 32 + h * 16 + lk * 4 + j) * 2;
+            float* d = red + ((wm * BN) + wn * TN + nb * 32 + h * 16 + lk * 4 + j) * 2;
             d[0] = s; d[1] = q;
           }
         }
@@ -236,7 +266,9 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
   if (want_stats) {
     __syncthreads();
     if (t < BN && n0 + t < p.Cout) {
-      const float s = red[t * 2] + red[(BN + t) * 2], q = red[t * 2 + 1] + red[(BN + t) * 2 + 1];
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM_; ++w) { s += red[(w * BN + t) * 2]; q += red[(w * BN + t) * 2 + 1]; }
       double* st = p.stats + (long)(bid % NPP_STAT_REPLICAS) * 2 * p.Cout;
       atomicAdd(st + n0 + t, (double)s);
       atomicAdd(st + p.Cout + n0 + t, (double)q);
@@ -245,11 +277,11 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
 }
 
 bool g4_raise_lds(const void* fp, size_t bytes) {
-  static thread_local const void* done[16];
-  for (int i = 0; i < 16; ++i)
+  static thread_local const void* done[32];
+  for (int i = 0; i < 32; ++i)
     if (done[i] == fp) return true;
   if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
-  for (int i = 0; i < 16; ++i)
+  for (int i = 0; i < 32; ++i)
     if (!done[i]) { done[i] = fp; break; }
   return true;
 }
@@ -264,7 +296,8 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.KH != p.KW || (p.KH & 1) == 0 || p.KH > 5) return false;
   const int P = (p.KH - 1) / 2;
   if (p.ph != P || p.pw != P || p.OH != p.H || p.OW != p.W) return false;
-  if (p.Cp != p.Cin || p.Cin % 64 != 0 || p.ldx % 8 != 0 || p.Cout % 64 != 0) return false;
+  const bool half = p.Cin == 32;                      // two taps per K-tile
+  if (p.Cp != p.Cin || (p.Cin % 64 != 0 && !half) || p.ldx % 8 != 0 || (p.Cout % 64 != 0 && p.Cout != 32)) return false;
   if ((long)p.N * p.H * p.W * p.ldx * 2 >= (1L << 32) - 65536) return false;
   if (!p.vec_io || (p.mask && p.stats)) return false;
   if (p.H >= 16384 || p.W >= 16384) return false;
@@ -284,7 +317,7 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (P > 0 && p.M > max_m && wbytes > (2L << 20)) return false;
   if (P == 0 && !g8_off && p.Cin >= 256 && p.Cout >= 256 && p.Cout % 128 == 0 && p.M >= 65536) return false;
   G4Extra e;
-  e.taps = p.KH * p.KW; e.nchunks = p.Cin / 64; e.nk = e.taps * e.nchunks; e.P = P; e.HW = p.H * p.W;
+  e.taps = p.KH * p.KW; e.nchunks = half ? 1 : p.Cin / 64; e.nk = half ? (e.taps + 1) / 2 : e.taps * e.nchunks; e.P = P; e.HW = p.H * p.W;
   e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
   e.wbytes = (unsigned)wbytes;
   // tile: 128 x 128 halves the operand bytes per MAC (2 blocks per CU); 64 x 64 gives 4x the blocks (4 per CU).  Measured
@@ -293,25 +326,27 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   // one block per CU on.
   static const int force_tile = getenv("NPP_G4_TILE") ? atoi(getenv("NPP_G4_TILE")) : 0;
   static const int big_min_tiles = getenv("NPP_G4_BIG_MIN_TILES") ? atoi(getenv("NPP_G4_BIG_MIN_TILES")) : 256;
-  int bm = 64, bn = 64;
-  if (p.Cout % 128 == 0 && (long)((p.M + 127) / 128) * (p.Cout / 128) >= big_min_tiles) { bm = 128; bn = 128; }
-  if (force_tile == 64) { bm = 64; bn = 64; }
-  if (force_tile == 128 && p.Cout % 128 == 0) { bm = 128; bn = 128; }
+  int bm = 64, bn = p.Cout == 32 ? 32 : 64;
+  if (!half && p.Cout % 128 == 0 && (long)((p.M + 127) / 128) * (p.Cout / 128) >= big_min_tiles) { bm = 128; bn = 128; }
+  if (force_tile == 64 && bn != 32) { bm = 64; bn = 64; }
+  if (force_tile == 128 && p.Cout % 128 == 0 && !half) { bm = 128; bn = 128; }
   IgemmParams q = p;
   q.mtiles = (p.M + bm - 1) / bm; q.ntiles = p.Cout / bn;
   const int grid = q.mtiles * q.ntiles;
-#define G4_LAUNCH(BM_, BN_, RELU_, TAPS_)                                                                  \
+#define G4_LAUNCH(BM_, BN_, WM__, RELU_, TAPS_, HALF_)                                                     \
   do {                                                                                                     \
-    constexpr size_t lds = G4_RING * (BM_ + BN_) * 128 + 2 * BN_ * 2 * 4;                                   \
-    if (!g4_raise_lds(reinterpret_cast<const void*>(conv_g4_kernel<BM_, BN_, RELU_, TAPS_>), lds)) return false; \
-    hipLaunchKernelGGL((conv_g4_kernel<BM_, BN_, RELU_, TAPS_>), dim3(grid), dim3(256), lds, stream, q, e); \
+    constexpr size_t lds = G4_RING * (BM_ + BN_) * 128 + WM__ * BN_ * 2 * 4;                                \
+    if (!g4_raise_lds(reinterpret_cast<const void*>(conv_g4_kernel<BM_, BN_, WM__, RELU_, TAPS_, HALF_>), lds)) return false; \
+    hipLaunchKernelGGL((conv_g4_kernel<BM_, BN_, WM__, RELU_, TAPS_, HALF_>), dim3(grid), dim3(256), lds, stream, q, e); \
   } while (0)
-#define G4_PICK(BM_, BN_)                                                                                  \
+#define G4_PICK(BM_, BN_, WM__, HALF_)                                                                     \
   do {                                                                                                     \
-    if (P == 0) { if (p.relu_in) G4_LAUNCH(BM_, BN_, true, false); else G4_LAUNCH(BM_, BN_, false, false); } \
-    else        { if (p.relu_in) G4_LAUNCH(BM_, BN_, true, true);  else G4_LAUNCH(BM_, BN_, false, true); }  \
+    if (P == 0) { if (p.relu_in) G4_LAUNCH(BM_, BN_, WM__, true, false, HALF_); else G4_LAUNCH(BM_, BN_, WM__, false, false, HALF_); } \
+    else        { if (p.relu_in) G4_LAUNCH(BM_, BN_, WM__, true, true, HALF_);  else G4_LAUNCH(BM_, BN_, WM__, false, true, HALF_); }  \
   } while (0)
-  if (bm == 128) G4_PICK(128, 128); else G4_PICK(64, 64);
+  if (bm == 128) G4_PICK(128, 128, 2, false);
+  else if (bn == 32) { if (half) G4_PICK(64, 32, 4, true); else G4_PICK(64, 32, 4, false); }
+  else { if (half) G4_PICK(64, 64, 2, true); else G4_PICK(64, 64, 2, false); }
 #undef G4_PICK
 #undef G4_LAUNCH
   return true;

@@ -51,6 +51,8 @@ CONV_CASES = [
     (256, 20, 1, 1, 0, 1, 12, 12, 2, False, True, 0),      # parsing head: Cout = 20 + bias
     (128, 16, 1, 1, 0, 1, 12, 12, 2, False, True, 0),      # pose head
     (32, 32, 3, 1, 2, 2, 16, 16, 2, True, False, 0),       # dense dilated (DilConv)
+    (32, 32, 3, 1, 1, 1, 40, 40, 2, True, True, 0),        # conv_g4 64x32 tile, two taps per K-tile (Cin = 32), odd tap count, bias
+    (128, 32, 1, 1, 0, 1, 24, 24, 2, True, False, 8),      # conv_g4 64x32 tile fwd; dgrad K = 32 (one half-filled K-tile) + mask
     # large maps: bf16 runs on the LDS-DMA kernels (conv_g4.hip 64x64 tiles / conv_g8.hip 256-wide tiles), f32 on conv_s1
     (64, 128, 1, 1, 0, 1, 160, 160, 2, True, True, 0),     # g8 BN=128, 1x1 + bias, one K-tile per output tile
     (128, 256, 1, 1, 0, 1, 225, 225, 1, True, False, 8),   # g8 BN=256, ragged M, channel-slice input; dgrad with mask
@@ -129,6 +131,8 @@ def test_shapes_take_their_lds_dma_kernels():
     assert _g8_launch_count(128, 128, 3, "conv_g4", 24) == 2
     assert _g8_launch_count(64, 64, 3, "conv_g4", 48) == 2
     assert _g8_launch_count(128, 128, 3, "conv_g4", 160) == 2
+    assert _g8_launch_count(32, 32, 3, "conv_g4", 96) == 2
+    assert _g8_launch_count(128, 32, 1, "conv_g4", 96) == 2
 
 
 def test_g8_taps_variant_in_subprocess():

@@ -9,6 +9,8 @@ SHAPES = [(1024, 512, 1, 96), (1024, 384, 1, 96), (512, 256, 1, 96), (512, 128, 
           (128, 128, 3, 96), (384, 128, 3, 96)]
 if os.environ.get('NPP_TIME_SET') == 'g4b':
     SHAPES = [(256, 256, 3, 48), (128, 128, 3, 48), (128, 128, 3, 24), (256, 256, 3, 12), (64, 64, 3, 48), (512, 512, 3, 24), (256, 256, 3, 24)]
+if os.environ.get('NPP_TIME_SET') == 'c32':
+    SHAPES = [(32, 32, 3, 96), (128, 32, 1, 96), (32, 32, 1, 96), (64, 64, 3, 48)]
 if os.environ.get('NPP_TIME_SET') == 'g4':
     SHAPES = [(128, 128, 3, 24), (256, 256, 3, 12), (64, 64, 3, 48), (256, 64, 1, 48), (64, 64, 1, 48), (128, 128, 1, 24), (512, 512, 1, 24), (1024, 256, 1, 12), (256, 256, 1, 48)]
 if os.environ.get('NPP_TIME_SET') == 'small':
