@@ -259,6 +259,7 @@ extern "C" int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw
   const double flops = 2.0 * (double)P * p.Cout * (double)p.taps * p.Cin;
   const double bytes = ((double)x->n * x->h * x->w * x->c + (double)P * dy->c) * esize(x->dtype);
   ProfScope prof(NPP_FAM_CONV_WGRAD, x->dtype, s, flops, bytes);
+  if (conv_wgrad_g4_launch(p, x->dtype, s)) return npp_check_launch("conv_wgrad_g4");
   if (conv_wgrad_tap_launch(p, x->dtype, s)) return npp_check_launch("conv_wgrad_tap");
   dim3 grid(tiles, splits);
 #define LAUNCH(T, TM_) hipLaunchKernelGGL((conv_wgrad_kernel<T, TM_>), grid, dim3(256), 0, s, p)

@@ -1,0 +1,240 @@
+// Convolution weight gradient, bf16, stride-1 "same" KxK (or 1x1), Cin % 128 == 0 and Cout % 128 == 0: the structure of
+// conv_g4.hip applied to the GEMM whose reduction axis is the pixel axis,
+//     dWp[co][tap*Cin + ci] += sum_p dy[p][co] * relu?(x)[p shifted by tap][ci].
+// Replaces the weight-gradient half of nn.Conv2d backward (models/operations.py:69-82, model_augment.py:332-398).
+//   * block tile = 128 output channels x 128 input channels of ONE tap over a range of pixels (grid = tiles x pixel splits);
+//     4 waves as 2 x 2, 64 x 64 each (4 x 4 MFMA 16x16x32 fragments); K-tile = 64 pixels.
+//   * both operands are pixel-major in memory ([p][c]) -- K is the slow axis -- so they are staged pixel-major by LDS-DMA
+//     (1-KiB pieces of 4 pixel rows x 256 B) and read back TRANSPOSED with ds_read_b64_tr_b16: a lane gets 4 consecutive
+//     pixels of its channel, two reads = one 8-deep MFMA operand.  The 16-byte chunks of a row are XOR-swizzled with
+//     ((row&3)<<2)|((row>>2)&3) on the DMA source address and on the read (image (b) of cdna_hip_programming.md T10:
+//     conflict-free for the 16x16x32 operand, whose two 16-lane groups of a half read blocks 8 rows apart).
+//   * out-of-image pixels of a tap and pixels past the end are out-of-range buffer offsets: the DMA writes zeros.
+//   * ring of 2 K-tile buffers (64 KiB), one barrier per K-tile, 2 blocks per CU (occupancy hides the latencies, as measured
+//     for conv_g4).
+//   * epilogue: f32 atomics into the packed gradient; v_permlane32_swap pairs two neighbouring 16-column fragments so that one
+//     atomic instruction covers two rows x 128 contiguous bytes (the full-rate shape, MI355X_MICROARCH.md "Global float atomics").
+#include "common.h"
+#include "conv_wgrad_params.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
+
+struct WG4Extra {
+  int P;                 // (KH-1)/2
+  int HW;
+  int coltiles;          // taps * Cin / 128
+  int ktiles_per_split, nktiles;
+  unsigned xbytes, dybytes;
+};
+
+#define WG4_DMA(rsrc, voff, ldsoff)                                                                       \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (ldsoff)), 16, voff, 0, 0, 0)
+
+template <bool RELU, bool TAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Extra e) {
+  constexpr int KT = 32768;            // bytes per K-tile buffer: dy [64 px][256 B] then x [64 px][256 B]
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
+  const auto rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, e.dybytes, 0x00020000);
+
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int cotile = tile % p.rowtiles, coltile = tile / p.rowtiles;
+  const int co0 = cotile * 128;
+  const int tap = (coltile * 128) / p.Cin, ci0 = coltile * 128 - tap * p.Cin;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int dy_ = kh - e.P, dx_ = kw - e.P;                 // input pixel = output pixel + (dy_, dx_)
+  const int kt_begin = split * e.ktiles_per_split;
+  int kt_end = kt_begin + e.ktiles_per_split;
+  if (kt_end > e.nktiles) kt_end = e.nktiles;
+  if (kt_begin >= kt_end) return;
+
+  // ---- staging: wave w fills pieces 4w .. 4w+3 of each operand; lane -> row 4*piece + (lane>>4), slot lane&15 ----------
+  const int srow = lane >> 4, slot = lane & 15;
+  unsigned dyb[4], xb[4];      // byte offset of (first K-tile's pixel, source chunk) in dy / x; advanced by 64 pixels per K-tile
+  int yx[4];                   // (y << 16) | x of the row's OUTPUT pixel (TAPS), (0x4000 << 16) once past the end
+  int pix[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 4 + srow;
+    const int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    const int q = kt_begin * 64 + row;
+    pix[j] = q;
+    dyb[j] = (unsigned)q * (unsigned)p.ldy * 2u + (unsigned)(co0 * 2 + chunk * 16);
+    xb[j] = (unsigned)q * (unsigned)p.ldx * 2u + (unsigned)(ci0 * 2 + chunk * 16) + (unsigned)((dy_ * p.W + dx_) * (int)p.ldx * 2);
+    yx[j] = 0;
+    if (TAPS) {
+      const int rem = q % e.HW;
+      const int y = rem / p.W;
+      yx[j] = (y << 16) | (rem - y * p.W);
+    }
+  }
+  const unsigned dy_step = 64u * (unsigned)p.ldy * 2u, x_step = 64u * (unsigned)p.ldx * 2u;
+  auto issue = [&](int slot_) {
+    const int lb = slot_ * KT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool live = pix[j] < p.P;
+      WG4_DMA(rs_dy, live ? dyb[j] : 0xFFFFFFFFu, lb + (wave * 4 + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bool ok = pix[j] < p.P;
+      if (TAPS) {
+        const int y = (yx[j] >> 16) + dy_, x = (yx[j] & 0xFFFF) + dx_;
+        ok = ok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      }
+      WG4_DMA(rs_x, ok ? xb[j] : 0xFFFFFFFFu, lb + 16384 + (wave * 4 + j) * 1024);
+    }
+    // advance this lane's rows by one K-tile (64 pixels)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pix[j] += 64; dyb[j] += dy_step; xb[j] += x_step;
+      if (TAPS) {
+        int y = yx[j] >> 16, x = (yx[j] & 0xFFFF) + 64;
+        while (x >= p.W) { x -= p.W; ++y; }
+        while (y >= p.H) y -= p.H;
+        yx[j] = (y << 16) | x;
+      }
+    }
+  };
+
+  // ---- transposed fragment reads ------------------------------------------------------------------------------------
+  // lane (g = lane>>4, i = lane&15, q = i>>2, pq = i&3) supplies the address of row  ks*32 + g*8 + h*4 + q  (h = which half of
+  // the 8-deep operand), columns 4*pq .. 4*pq+3 of the fragment's 16 channels: chunk16 = cbase + (pq>>1), +8 bytes for odd pq
+  const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pq = i16 & 3;
+  unsigned offA[4][2], offB[4][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = g * 8 + h * 4 + q4;                       // + ks*32
+    const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      offA[f][h] = 256 * row + 16 * (((wm * 8 + f * 2 + (pq >> 1)) ^ sw)) + 8 * (pq & 1);
+      offB[f][h] = 16384 + 256 * row + 16 * (((wn * 8 + f * 2 + (pq >> 1)) ^ sw)) + 8 * (pq & 1);
+    }
+  }
+
+  f32x4g acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4g{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  int c_slot = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < kt_end) issue(c_slot ^ 1);
+    const unsigned ro = (unsigned)c_slot * KT;
+    c_slot ^= 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      s16x8 fa[4], fb[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offA[f][0] + ks * 8192));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offA[f][1] + ks * 8192));
+        fa[f] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offB[f][0] + ks * 8192));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offB[f][1] + ks * 8192));
+        s16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (RELU) {
+          const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+          b = __builtin_elementwise_max(b, z);
+        }
+        fb[f] = b;
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]),
+                                                                acc[mi][ni], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: acc[mi][ni][j] = dW[co0 + wm*64 + mi*16 + 4*g + j][col0 + wn*64 + ni*16 + i16] ----------------------------
+  // After v_permlane32_swap(X = fragment 2nb, Y = fragment 2nb+1): X' = {X g0, X g1, Y g0, Y g1} = rows {j, 4+j} x 32 columns,
+  // Y' = {X g2, X g3, Y g2, Y g3} = rows {8+j, 12+j} x 32 columns: two rows x 128 contiguous bytes per atomic instruction.
+  const int colbase = coltile * 128 + wn * 64;
+  const int half = lane >> 5, gg = (lane >> 4) & 1;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][2 * nb][j]), __float_as_uint(acc[mi][2 * nb + 1][j]),
+                                                         false, false);
+        const int col = colbase + (2 * nb + half) * 16 + i16;
+        const int row0 = co0 + wm * 64 + mi * 16 + gg * 4 + j;
+        atomicAdd(p.dwp + (long)row0 * p.Kpad + col, __uint_as_float(sw[0]));
+        atomicAdd(p.dwp + (long)(row0 + 8) * p.Kpad + col, __uint_as_float(sw[1]));
+      }
+}
+
+bool wg4_raise_lds(const void* fp, size_t bytes) {
+  static thread_local const void* done[8];
+  for (int i = 0; i < 8; ++i)
+    if (done[i] == fp) return true;
+  if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+  for (int i = 0; i < 8; ++i)
+    if (!done[i]) { done[i] = fp; break; }
+  return true;
+}
+
+}  // namespace
+
+bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
+  static const bool disabled = getenv("NPP_DISABLE_WG4") != nullptr;
+  if (disabled || dtype != NPP_BF16) return false;
+  if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1) return false;
+  if (p.KH != p.KW || (p.KH & 1) == 0 || p.KH > 5) return false;
+  const int P = (p.KH - 1) / 2;
+  if (p.ph != P || p.pw != P || p.OH != p.H || p.OW != p.W) return false;
+  if (p.Cin % 128 != 0 || p.Cout % 128 != 0 || p.Cp != p.Cin || !p.vec_dy || p.ldx % 8 != 0) return false;
+  if ((long)p.P * p.ldx * 2 >= (1L << 32) - (1L << 24) || (long)p.P * p.ldy * 2 >= (1L << 32) - (1L << 24)) return false;
+  if (p.H >= 16384 || p.W >= 16384) return false;
+  // Measured against conv_wgrad_kernel / wgrad_tap_kernel (N = 16, us): 1024->512 1x1 @96^2 249 vs 317, 1024->256 @12^2 19.7 vs
+  // 21.9, 512->512 1x1 @24^2 33 vs 35, 512->128 @96^2 64 vs 67; equal on 128->128 3x3 @96^2 (104 vs 105: the per-CU LDS-DMA
+  // rate plus 33 MB of split-K atomics), slower on 384->128 3x3 (282 vs 223) and 1024->384 (351 vs 283).  Default: the deep
+  // 1x1 shapes only; NPP_WG4_ALL=1 takes every eligible shape.
+  static const bool all = getenv("NPP_WG4_ALL") != nullptr;
+  if (!all && !(P == 0 && p.Cin >= 512 && p.Cout % 256 == 0)) return false;
+  WG4Extra e;
+  e.P = P; e.HW = p.H * p.W;
+  e.coltiles = p.taps * p.Cin / 128;
+  e.nktiles = (p.P + 63) / 64;
+  e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
+  e.dybytes = (unsigned)((long)p.P * p.ldy * 2);
+  WgradParams q = p;
+  q.rowtiles = p.Cout / 128;
+  const int tiles = q.rowtiles * e.coltiles;
+  static const int target_blocks = getenv("NPP_WG4_BLOCKS") ? atoi(getenv("NPP_WG4_BLOCKS")) : 512;
+  int splits = (target_blocks + tiles - 1) / tiles;
+  if (splits < 1) splits = 1;
+  if (splits > e.nktiles) splits = e.nktiles;
+  e.ktiles_per_split = (e.nktiles + splits - 1) / splits;
+  splits = (e.nktiles + e.ktiles_per_split - 1) / e.ktiles_per_split;
+  if (splits > 65535) return false;
+  constexpr size_t lds = 2 * 32768;
+  dim3 grid(tiles, splits);
+#define WG4_LAUNCH(RELU_, TAPS_)                                                                            \
+  do {                                                                                                      \
+    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g4_kernel<RELU_, TAPS_>), lds)) return false; \
+    hipLaunchKernelGGL((conv_wgrad_g4_kernel<RELU_, TAPS_>), grid, dim3(256), lds, stream, q, e);           \
+  } while (0)
+  if (P == 0) { if (p.relu_in) WG4_LAUNCH(true, false); else WG4_LAUNCH(false, false); }
+  else        { if (p.relu_in) WG4_LAUNCH(true, true);  else WG4_LAUNCH(false, true); }
+#undef WG4_LAUNCH
+  return true;
+}

@@ -13,3 +13,5 @@ struct WgradParams {
 };
 // tap-stationary 3x3 stride-1 kernel (conv_wgrad_s1.hip); false when the shape is not eligible
 bool conv_wgrad_tap_launch(const WgradParams& p, int dtype, hipStream_t stream);
+// LDS-DMA + transposing-read kernel for Cin % 128 == 0, Cout % 128 == 0, bf16 (conv_wgrad_g4.hip); false when not eligible
+bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream);
