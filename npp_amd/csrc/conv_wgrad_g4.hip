@@ -204,12 +204,6 @@ bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   if (p.Cin % 128 != 0 || p.Cout % 128 != 0 || p.Cp != p.Cin || !p.vec_dy || p.ldx % 8 != 0) return false;
   if ((long)p.P * p.ldx * 2 >= (1L << 32) - (1L << 24) || (long)p.P * p.ldy * 2 >= (1L << 32) - (1L << 24)) return false;
   if (p.H >= 16384 || p.W >= 16384) return false;
-  // Measured against conv_wgrad_kernel / wgrad_tap_kernel (N = 16, us): 1024->512 1x1 @96^2 249 vs 317, 1024->256 @12^2 19.7 vs
-  // 21.9, 512->512 1x1 @24^2 33 vs 35, 512->128 @96^2 64 vs 67; equal on 128->128 3x3 @96^2 (104 vs 105: the per-CU LDS-DMA
-  // rate plus 33 MB of split-K atomics), slower on 384->128 3x3 (282 vs 223) and 1024->384 (351 vs 283).  Default: the deep
-  // 1x1 shapes only; NPP_WG4_ALL=1 takes every eligible shape.
-  static const bool all = getenv("NPP_WG4_ALL") != nullptr;
-  if (!all && !(P == 0 && p.Cin >= 512 && p.Cout % 256 == 0)) return false;
   WG4Extra e;
   e.P = P; e.HW = p.H * p.W;
   e.coltiles = p.taps * p.Cin / 128;
@@ -219,8 +213,17 @@ bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   WgradParams q = p;
   q.rowtiles = p.Cout / 128;
   const int tiles = q.rowtiles * e.coltiles;
-  static const int target_blocks = getenv("NPP_WG4_BLOCKS") ? atoi(getenv("NPP_WG4_BLOCKS")) : 512;
-  int splits = (target_blocks + tiles - 1) / tiles;
+  // Pixel splits.  Two blocks fit a CU (512 slots): never more blocks than slots (513 blocks = a second, empty round: 104 vs
+  // 98 us on 128->128 3x3 @96^2), and every block ends with 64 KiB of atomics, so the split count also balances the atomic
+  // traffic (blocks x 64 KiB at ~1.3 TB/s) against the K-tiles left per block: S ~ sqrt(10 * K-tiles / tiles).
+  // Measured with this rule against conv_wgrad_kernel / wgrad_tap_kernel (N = 16, us): 128->128 3x3 @96^2 98 vs 105, 384->128 3x3
+  // 208 vs 223, 1024->512 1x1 249 vs 317, 512->128 57 vs 67, 256->256 3x3 @48^2 87 vs 99, 512->512 3x3 @24^2 88 vs 105,
+  // 128->128 3x3 @24^2 21 vs 29, 256->256 @12^2 23 vs 30, 512->512 1x1 @24^2 25 vs 35, 1024->256 @12^2 12 vs 22.
+  static const int force_blocks = getenv("NPP_WG4_BLOCKS") ? atoi(getenv("NPP_WG4_BLOCKS")) : 0;
+  int splits = 1;
+  while ((long)(splits + 1) * (splits + 1) * tiles <= 10L * e.nktiles) ++splits;
+  if (force_blocks > 0) splits = (force_blocks + tiles - 1) / tiles;
+  if (splits > 512 / tiles) splits = 512 / tiles;
   if (splits < 1) splits = 1;
   if (splits > e.nktiles) splits = e.nktiles;
   e.ktiles_per_split = (e.nktiles + splits - 1) / splits;

@@ -1,6 +1,5 @@
-"""Child process of tests in test_kernels_gpu.py that need a per-process environment switch:
-   (no argument)  NPP_G8_MAXK=3 NPP_DISABLE_G4=1: the large-map 3x3 parity cases, bf16, through conv_g8_kernel's KxK variant;
-   wgrad          NPP_WG4_ALL=1: every bf16 conv parity case whose weight gradient conv_wgrad_g4_kernel can take."""
+"""Child process of test_kernels_gpu.test_g8_taps_variant_in_subprocess (NPP_G8_MAXK=3 NPP_DISABLE_G4=1 in the environment):
+the large-map 3x3 parity cases, bf16, through conv_g8_kernel's KxK variant."""
 import os
 import sys
 
@@ -9,18 +8,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import test_kernels_gpu as T
-
-if len(sys.argv) > 1 and sys.argv[1] == "wgrad":
-    assert os.environ.get("NPP_WG4_ALL") == "1"
-    n = 0
-    for case in T.CONV_CASES:
-        cin, cout, k, stride, pad, dil = case[:6]
-        if stride == 1 and dil == 1 and cin % 128 == 0 and cout % 128 == 0:
-            T.test_conv_fwd_bwd(case, torch.bfloat16, 3e-2)
-            n += 1
-    assert n >= 5
-    print("wg4 ok", n)
-    sys.exit(0)
 
 assert os.environ.get("NPP_G8_MAXK") == "3" and os.environ.get("NPP_DISABLE_G4") == "1"
 n = 0

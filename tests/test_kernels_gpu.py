@@ -45,7 +45,7 @@ CONV_CASES = [
     (128, 128, 3, 1, 1, 1, 24, 24, 1, True, False, 0),     # BN=128
     (128, 256, 1, 1, 0, 1, 12, 12, 3, True, True, 0),      # 1x1 + bias, 2 N-tiles
     (512, 128, 1, 1, 0, 1, 12, 12, 2, True, False, 0),     # long K
-    (512, 256, 1, 1, 0, 1, 20, 20, 2, True, False, 0),     # deep 1x1: weight gradient on conv_wgrad_g4 (LDS-DMA, transposing reads)
+    (512, 256, 1, 1, 0, 1, 20, 20, 2, True, False, 0),     # deep 1x1; Cin, Cout % 128 == 0: weight gradient on conv_wgrad_g4
     (64, 128, 3, 2, 1, 1, 20, 20, 2, False, False, 0),     # stem-like stride 2
     (3, 16, 3, 2, 1, 1, 32, 32, 2, False, False, 0),       # image stem: Cin = 3 (padded to 8 in memory)
     (384, 6, 3, 1, 1, 1, 12, 12, 2, True, False, 0),       # edge head: Cout = 6
@@ -134,18 +134,6 @@ def test_shapes_take_their_lds_dma_kernels():
     assert _g8_launch_count(128, 128, 3, "conv_g4", 160) == 2
     assert _g8_launch_count(32, 32, 3, "conv_g4", 96) == 2
     assert _g8_launch_count(128, 32, 1, "conv_g4", 96) == 2
-
-
-def test_wgrad_g4_all_shapes_in_subprocess():
-    """conv_wgrad_g4_kernel (LDS-DMA + transposing reads) takes only the deep 1x1 shapes by default; NPP_WG4_ALL=1 (read once
-    per process) routes every eligible weight gradient through it: run the conv parity cases that way in ONE child process."""
-    import os, subprocess, sys
-    env = dict(os.environ, NPP_WG4_ALL="1")
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "g8_taps_worker.py"), "wgrad"], env=env, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "wg4 ok" in r.stdout
 
 
 def test_g8_taps_variant_in_subprocess():
