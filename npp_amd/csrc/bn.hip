@@ -213,7 +213,10 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 
 // Column-persistent elementwise mapping: a thread owns ONE 16-byte channel group (its per-channel coefficients
 // live in registers for the whole kernel) and walks pixels, two per iteration to keep more loads in flight.
-template <typename T, int V>
+// HAS_B / SSA / SSB are compile-time: a load behind a runtime pointer test makes hipcc branch around it and wait vmcnt(0)
+// right after (cdna_hip_programming.md 5, trap 4c) -- the first version of this kernel had two loads in flight and ran at
+// 3.0 TB/s where bn_bwd_apply, same traffic, ran at 6.1 (37.7 MB tensors); all four loads of an iteration are now issued first.
+template <typename T, int V, bool HAS_B, bool SSA, bool SSB>
 __global__ __launch_bounds__(256) void affine_add_kernel(T* __restrict__ out, long ldo, const T* __restrict__ a, long lda,
                                                          const float* __restrict__ ssa, const T* __restrict__ b, long ldb,
                                                          const float* __restrict__ ssb, int relu, long npix, int C, ColMap m) {
@@ -226,42 +229,41 @@ __global__ __launch_bounds__(256) void affine_add_kernel(T* __restrict__ out, lo
   float sa[V], ta[V], sb[V], tb[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) {
-    sa[j] = ssa ? ssa[c0 + j] : 1.f;
-    ta[j] = ssa ? ssa[C + c0 + j] : 0.f;
-    sb[j] = ssb ? ssb[c0 + j] : 1.f;
-    tb[j] = ssb ? ssb[C + c0 + j] : 0.f;
+    sa[j] = SSA ? ssa[c0 + j] : 1.f;
+    ta[j] = SSA ? ssa[C + c0 + j] : 0.f;
+    sb[j] = (HAS_B && SSB) ? ssb[c0 + j] : 1.f;
+    tb[j] = (HAS_B && SSB) ? ssb[C + c0 + j] : 0.f;
   }
   const long step = (long)gridDim.x * m.rows;
+  const long last = npix - 1;
   for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += 2 * step) {
     const long p2 = p + step;
     const bool two = p2 < npix;
+    const long q2 = two ? p2 : last;          // the second pixel's loads are unconditional (a real pixel), its store is not
     float va[V], vb[V], wa[V], wb[V], o[V], o2[V];
     ldv<T, V>(a + p * lda + c0, va);
-    if (b) ldv<T, V>(b + p * ldb + c0, vb);
-    if (two) {
-      ldv<T, V>(a + p2 * lda + c0, wa);
-      if (b) ldv<T, V>(b + p2 * ldb + c0, wb);
+    ldv<T, V>(a + q2 * lda + c0, wa);
+    if (HAS_B) {
+      ldv<T, V>(b + p * ldb + c0, vb);
+      ldv<T, V>(b + q2 * ldb + c0, wb);
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       o[j] = fmaf(va[j], sa[j], ta[j]);
-      if (b) o[j] += fmaf(vb[j], sb[j], tb[j]);
-      if (relu) o[j] = fmaxf(o[j], 0.f);
+      o2[j] = fmaf(wa[j], sa[j], ta[j]);
+      if (HAS_B) {
+        o[j] += fmaf(vb[j], sb[j], tb[j]);
+        o2[j] += fmaf(wb[j], sb[j], tb[j]);
+      }
+      if (relu) { o[j] = fmaxf(o[j], 0.f); o2[j] = fmaxf(o2[j], 0.f); }
     }
     stv<T, V>(out + p * ldo + c0, o);
-    if (two) {
-#pragma unroll
-      for (int j = 0; j < V; ++j) {
-        o2[j] = fmaf(wa[j], sa[j], ta[j]);
-        if (b) o2[j] += fmaf(wb[j], sb[j], tb[j]);
-        if (relu) o2[j] = fmaxf(o2[j], 0.f);
-      }
-      stv<T, V>(out + p2 * ldo + c0, o2);
-    }
+    if (two) stv<T, V>(out + p2 * ldo + c0, o2);
   }
 }
 
-template <typename T, int V>
+// HAS_RO compile-time and unconditional (index-clamped) coefficient loads: see affine_add_kernel
+template <typename T, int V, bool HAS_RO>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
                                                             long ldy, const T* __restrict__ ro, long ldr,
                                                             const float* __restrict__ mi, long npix, int C, ColMap m,
@@ -278,8 +280,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   for (int j = 0; j < V; ++j) {
     acc[0][j] = 0.0; acc[1][j] = 0.0;
     const int ch = colg * V + j;
-    mean[j] = (work && ch < C) ? mi[ch] : 0.f;
-    invstd[j] = (work && ch < C) ? mi[C + ch] : 0.f;
+    const int chc = (work && ch < C) ? ch : 0;     // clamp the index, not the load (a channel past C is never stored)
+    mean[j] = mi[chc];
+    invstd[j] = mi[C + chc];
   }
   if (work) {
     const long step = (long)gridDim.x * m.rows;
@@ -287,29 +290,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += 2 * step) {
       const long p2 = p + step;
       const bool two = p2 < npix;
+      const long q2 = two ? p2 : p;           // unconditional loads of a real pixel; its terms are dropped below
       float d[V], v[V], d2[V], v2[V];
       ldv<T, V>(dout + p * ldd + cofs, d);
       ldv<T, V>(y + p * ldy + cofs, v);
-      if (two) {
-        ldv<T, V>(dout + p2 * ldd + cofs, d2);
-        ldv<T, V>(y + p2 * ldy + cofs, v2);
-      }
-      if (ro) {
-        float o[V];
+      ldv<T, V>(dout + q2 * ldd + cofs, d2);
+      ldv<T, V>(y + q2 * ldy + cofs, v2);
+      if (HAS_RO) {
+        float o[V], o2[V];
         ldv<T, V>(ro + p * ldr + cofs, o);
+        ldv<T, V>(ro + q2 * ldr + cofs, o2);
 #pragma unroll
-        for (int j = 0; j < V; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
-        if (two) {
-          ldv<T, V>(ro + p2 * ldr + cofs, o);
-#pragma unroll
-          for (int j = 0; j < V; ++j) d2[j] = o[j] > 0.f ? d2[j] : 0.f;
+        for (int j = 0; j < V; ++j) {
+          d[j] = o[j] > 0.f ? d[j] : 0.f;
+          d2[j] = o2[j] > 0.f ? d2[j] : 0.f;
         }
       }
       // pairs are summed in f32 (two terms), the running sums stay f64
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        float a0 = d[j], a1 = d[j] * ((v[j] - mean[j]) * invstd[j]);
-        if (two) { a0 += d2[j]; a1 += d2[j] * ((v2[j] - mean[j]) * invstd[j]); }
+        const float e2 = two ? d2[j] : 0.f;
+        const float a0 = d[j] + e2;
+        const float a1 = d[j] * ((v[j] - mean[j]) * invstd[j]) + e2 * ((v2[j] - mean[j]) * invstd[j]);
         acc[0][j] += a0;
         acc[1][j] += a1;
       }
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // ---- two-sided forms: out = BN_a(a) + BN_b(b) is the common case (both edges of a cell node end in BatchNorm).  The two
 // sides share dout (and the ReLU mask), so one pass reads it once: reduce 4 -> 3 tensor reads, apply 6 -> 5 passes, and
 // half the launches.  sums: slab b = [sum d | sum d*xhat_a | sum d*xhat_b] (3C doubles).
-template <typename T, int V>
+template <typename T, int V, bool HAS_RO>
 __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ ya,
                                                              long lda, const T* __restrict__ yb, long ldb,
                                                              const T* __restrict__ ro, long ldr, const float* __restrict__ mia,
@@ -423,29 +425,40 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const T* __restrict
   for (int j = 0; j < V; ++j) {
     acc[0][j] = 0.0; acc[1][j] = 0.0; acc[2][j] = 0.0;
     const int ch = colg * V + j;
-    const bool ok = work && ch < C;
-    ma[j] = ok ? mia[ch] : 0.f; ia[j] = ok ? mia[C + ch] : 0.f;
-    mb[j] = ok ? mib[ch] : 0.f; ib[j] = ok ? mib[C + ch] : 0.f;
+    const int chc = (work && ch < C) ? ch : 0;
+    ma[j] = mia[chc]; ia[j] = mia[C + chc];
+    mb[j] = mib[chc]; ib[j] = mib[C + chc];
   }
   if (work) {
     const long step = (long)gridDim.x * m.rows;
     const long cofs = (long)colg * V;
-    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += step) {
-      float d[V], va[V], vb[V];
+    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += 2 * step) {
+      const long p2 = p + step;
+      const bool two = p2 < npix;
+      const long q2 = two ? p2 : p;
+      float d[V], va[V], vb[V], d2[V], va2[V], vb2[V];
       ldv<T, V>(dout + p * ldd + cofs, d);
       ldv<T, V>(ya + p * lda + cofs, va);
       ldv<T, V>(yb + p * ldb + cofs, vb);
-      if (ro) {
-        float o[V];
+      ldv<T, V>(dout + q2 * ldd + cofs, d2);
+      ldv<T, V>(ya + q2 * lda + cofs, va2);
+      ldv<T, V>(yb + q2 * ldb + cofs, vb2);
+      if (HAS_RO) {
+        float o[V], o2[V];
         ldv<T, V>(ro + p * ldr + cofs, o);
+        ldv<T, V>(ro + q2 * ldr + cofs, o2);
 #pragma unroll
-        for (int j = 0; j < V; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+        for (int j = 0; j < V; ++j) {
+          d[j] = o[j] > 0.f ? d[j] : 0.f;
+          d2[j] = o2[j] > 0.f ? d2[j] : 0.f;
+        }
       }
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        acc[0][j] += d[j];
-        acc[1][j] += d[j] * ((va[j] - ma[j]) * ia[j]);
-        acc[2][j] += d[j] * ((vb[j] - mb[j]) * ib[j]);
+        const float e2 = two ? d2[j] : 0.f;
+        acc[0][j] += d[j] + e2;
+        acc[1][j] += d[j] * ((va[j] - ma[j]) * ia[j]) + e2 * ((va2[j] - ma[j]) * ia[j]);
+        acc[2][j] += d[j] * ((vb[j] - mb[j]) * ib[j]) + e2 * ((vb2[j] - mb[j]) * ib[j]);
       }
     }
   }
@@ -607,6 +620,10 @@ extern "C" int npp_bn_eval_coeffs(const float* gamma, const float* beta, const f
   return npp_check_launch("bn_eval_coeffs");
 }
 
+#define AFF(HB, SA, SB)                                                                                               \
+    hipLaunchKernelGGL((affine_add_kernel<T, V, HB, SA, SB>), col_grid_ew(m, npix(out)), dim3(256), 0, (hipStream_t)stream, \
+                       (T*)out->ptr, (long)out->ld, (const T*)a->ptr, (long)a->ld, ss_a, b ? (const T*)b->ptr : nullptr,   \
+                       b ? (long)b->ld : 0L, ss_b, relu, (long)npix(out), (int)out->c, m)
 extern "C" int npp_affine_add(NppTensor* out, const NppTensor* a, const float* ss_a, const NppTensor* b,
                               const float* ss_b, int relu, void* stream) {
   NPP_REQUIRE(out && a && out->ptr && a->ptr, NPP_E_NULL, "npp_affine_add: null pointer");
@@ -618,12 +635,16 @@ extern "C" int npp_affine_add(NppTensor* out, const NppTensor* a, const float* s
   ProfScope prof(NPP_FAM_ELTWISE, out->dtype, (hipStream_t)stream, 0, (double)npix(out) * out->c * esize(out->dtype) * nt);
   NPP_DISPATCH_TV(out->dtype, vk, {
     ColMap m = col_map(out->c, V);
-    hipLaunchKernelGGL((affine_add_kernel<T, V>), col_grid_ew(m, npix(out)), dim3(256), 0, (hipStream_t)stream,
-                       (T*)out->ptr, (long)out->ld, (const T*)a->ptr, (long)a->ld, ss_a, b ? (const T*)b->ptr : nullptr,
-                       b ? (long)b->ld : 0L, ss_b, relu, (long)npix(out), (int)out->c, m);
+    if (b) {
+      if (ss_a) { if (ss_b) AFF(true, true, true); else AFF(true, true, false); }
+      else      { if (ss_b) AFF(true, false, true); else AFF(true, false, false); }
+    } else {
+      if (ss_a) AFF(false, true, false); else AFF(false, false, false);
+    }
   });
   return npp_check_launch("affine_add");
 }
+#undef AFF
 
 static inline int reduce_blocks(long npix, long c, int dtype) {
   const int v = dtype == NPP_BF16 ? 8 : 4;
@@ -648,10 +669,14 @@ extern "C" int npp_bn_bwd_reduce(const NppTensor* dout, const NppTensor* y_raw, 
   NPP_DISPATCH_TV(dout->dtype, vk, {
     ColMap m = col_map(dout->c, V);
     dim3 grid((unsigned)nblocks, (unsigned)((m.cv + m.cols_blk - 1) / m.cols_blk));
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, V>), grid, dim3(256), 0, (hipStream_t)stream,
-                       (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
-                       relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, mean_invstd,
-                       (long)npix(dout), (int)dout->c, m, partials);
+    if (relu_out)
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, V, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                         (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
+                         (const T*)relu_out->ptr, (long)relu_out->ld, mean_invstd, (long)npix(dout), (int)dout->c, m, partials);
+    else
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, V, false>), grid, dim3(256), 0, (hipStream_t)stream,
+                         (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
+                         (const T*)nullptr, 0L, mean_invstd, (long)npix(dout), (int)dout->c, m, partials);
   });
   return npp_check_launch("bn_bwd_reduce");
 }
@@ -702,10 +727,14 @@ extern "C" int npp_bn_bwd_reduce2(const NppTensor* dout, const NppTensor* ya, co
   NPP_DISPATCH_TV(dout->dtype, vk, {
     ColMap m = col_map(dout->c, V);
     dim3 grid((unsigned)nblocks, (unsigned)((m.cv + m.cols_blk - 1) / m.cols_blk));
-    hipLaunchKernelGGL((bn_bwd_reduce2_kernel<T, V>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dout->ptr,
-                       (long)dout->ld, (const T*)ya->ptr, (long)ya->ld, (const T*)yb->ptr, (long)yb->ld,
-                       relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, mi_a, mi_b,
-                       (long)npix(dout), (int)dout->c, m, partials);
+    if (relu_out)
+      hipLaunchKernelGGL((bn_bwd_reduce2_kernel<T, V, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dout->ptr,
+                         (long)dout->ld, (const T*)ya->ptr, (long)ya->ld, (const T*)yb->ptr, (long)yb->ld,
+                         (const T*)relu_out->ptr, (long)relu_out->ld, mi_a, mi_b, (long)npix(dout), (int)dout->c, m, partials);
+    else
+      hipLaunchKernelGGL((bn_bwd_reduce2_kernel<T, V, false>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dout->ptr,
+                         (long)dout->ld, (const T*)ya->ptr, (long)ya->ld, (const T*)yb->ptr, (long)yb->ld,
+                         (const T*)nullptr, 0L, mi_a, mi_b, (long)npix(dout), (int)dout->c, m, partials);
   });
   return npp_check_launch("bn_bwd_reduce2");
 }
