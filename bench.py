@@ -248,7 +248,7 @@ def main():
         prof_steps = 2
         KERNELS = {"conv_s1": "conv_s1_kernel (stride-1 KxK conv fwd + dgrad, LDS-resident footprint, MFMA 32x32x16)",
                    "conv_g8": "conv_g8_kernel (1x1 conv fwd + dgrad: 8-phase LDS-DMA implicit GEMM, MFMA 16x16x32)",
-                   "conv_g4": "conv_g4_kernel (small-map / 64-channel conv fwd + dgrad: 64x64-tile LDS-DMA ring, MFMA 16x16x32)"}
+                   "conv_g4": "conv_g4_kernel (stride-1 conv fwd + dgrad, 1x1 / 3x3: 64x64 / 128x128 / 64x32 tiles, LDS-DMA ring of 2, 2-4 blocks per CU, MFMA 16x16x32)"}
         traffic_db = {}
         try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
             with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as fh:
