@@ -5,6 +5,7 @@
 // Replaces nn.BatchNorm2d forward/backward (operations.py:61,78,153,216,241; model_augment.py:246-395)
 // and the `h1 + h2` / `s1 + z1` adds (model_augment.py:58,100,443-444).
 #include "vecio.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -650,7 +651,12 @@ static inline int reduce_blocks(long npix, long c, int dtype) {
   const int v = dtype == NPP_BF16 ? 8 : 4;
   ColMap m = col_map(c, (c % v == 0) ? v : 1);
   long bx = (npix + 2L * m.rows - 1) / (2L * m.rows);
-  if (bx > 1024) bx = 1024;
+  // one block per CU (two for tensors beyond ~64 MB): the per-block start-up and reduction tail dominate small tensors, and the
+  // coefficient kernel reads one slab per block (measured, reduce + coeffs us at 1024 / 512 / 256 blocks: C=32 @96^2 16.3 / 11.7 /
+  // 10.0; C=128 @96^2 24.4 / 21.3 / 20.4; C=512 @96^2 63.7 / 55.0 / 70.7)
+  static const long cap_env = getenv("NPP_REDUCE_CAP") ? atol(getenv("NPP_REDUCE_CAP")) : 0;
+  const long cap = cap_env > 0 ? cap_env : ((npix * c * (dtype == NPP_BF16 ? 2 : 4) > (64L << 20)) ? 512 : 256);
+  if (bx > cap) bx = cap;
   if (bx < 1) bx = 1;
   return (int)bx;
 }

@@ -314,4 +314,7 @@ def test_two_stream_forward_equals_single_stream(monkeypatch):
         for i, (a, b) in enumerate(zip(res["1"][1], res[other][1])):
             assert rel_err(a, b) < 1e-5, ("train output", other, i, rel_err(a, b))
         for k, a in res["1"][2].items():
-            assert rel_err(res[other][2][k], a) < 1e-3 or np.abs(a).max() < 1e-6, ("grad", other, k, rel_err(res[other][2][k], a))
+            # gradients of the first cells sit behind ~500 layers of backward: the float-atomic summation order of the SE squeeze
+            # (1e-7 on the activations) reaches them as ~1e-3 (observed up to 1.3e-3 on cells1.0.preprocess1's BN gamma, run to
+            # run); a missing cross-stream dependency is a gross (O(1)) difference
+            assert rel_err(res[other][2][k], a) < 5e-3 or np.abs(a).max() < 1e-6, ("grad", other, k, rel_err(res[other][2][k], a))

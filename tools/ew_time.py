@@ -36,7 +36,10 @@ for c, h in [(32, 96), (128, 96), (64, 48), (256, 48), (128, 24), (256, 12), (51
     t_aff = timeit(lambda: check(L.npp_affine_add(K._byref(o), K._byref(a), ss.data_ptr(), K._byref(b), ss.data_ptr(), 0, s()), "aff"))
     t_red = timeit(lambda: check(L.npp_bn_bwd_reduce(K._byref(a), K._byref(b), None, mi.data_ptr(), sums.data_ptr(), nb, s()), "red"))
     t_app = timeit(lambda: check(L.npp_bn_bwd_apply(K._byref(a), K._byref(b), None, co.data_ptr(), K._byref(o), s()), "app"))
+    dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    gam = torch.ones(c, device=dev)
+    t_co = timeit(lambda: check(L.npp_bn_bwd_coeffs(sums.data_ptr(), nb, float(N * h * h), mi.data_ptr(), gam.data_ptr(), co.data_ptr(), dg.data_ptr(), db.data_ptr(), c, s()), "co"))
     t_add = timeit(lambda: K.add_n([a, b]))
     t_cpy = timeit(lambda: check(L.npp_copy(K._byref(a), K._byref(o), s()), "cpy"))
     print(f"C={c:4d} {h:3d}^2 {mb:6.1f} MB | affine_add {t_aff:6.1f} us {3*mb/t_aff:5.2f} TB/s | bwd_reduce {t_red:6.1f} us {2*mb/t_red:5.2f} | "
-          f"bwd_apply {t_app:6.1f} us {3*mb/t_app:5.2f} | add_n(2) {t_add:6.1f} us {3*mb/t_add:5.2f} | copy {t_cpy:6.1f} us {2*mb/t_cpy:5.2f}", flush=True)
+          f"coeffs(nb={nb}) {t_co:5.1f} us | bwd_apply {t_app:6.1f} us {3*mb/t_app:5.2f} | add_n(2) {t_add:6.1f} us {3*mb/t_add:5.2f} | copy {t_cpy:6.1f} us {2*mb/t_cpy:5.2f}", flush=True)
