@@ -202,6 +202,8 @@ int npp_bilinear_bwd(const NppTensor* dy, NppTensor* dx, void* stream);
 
 /* ---- layout / elementwise plumbing -------------------------------------------------------------- */
 int npp_copy(const NppTensor* x, NppTensor* y, void* stream);                /* cast + channel-slice copy (cat) */
+/* torch.cat along channels in one launch: xs[k] ([N,c_k,H,W], any pixel stride) -> channel slice of y, sum c_k == y->c, n <= 8 */
+int npp_concat(const NppTensor* const* xs, int n, NppTensor* y, void* stream);
 /* y = xs[0] + ... + xs[n-1], 1 <= n <= 8, same shape/dtype, any pixel strides: one-pass accumulation of the gradients of a
  * tensor with several consumers (replaces the autograd engine's chain of binary at::add, model_augment.py:48-62 fan-outs) */
 int npp_add_n(const NppTensor* const* xs, int n, NppTensor* y, void* stream);

@@ -94,6 +94,7 @@ _SIGS = {
     "npp_bilinear_bwd": [_T, _T, _P],
     "npp_copy": [_T, _T, _P],
     "npp_add_n": [_P, C.c_int, _T, _P],
+    "npp_concat": [_P, C.c_int, _T, _P],
     "npp_pose_targets": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P],
     "npp_edge_target": [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
     "npp_normalize_image": [_P, C.c_int, C.c_int, C.c_int, _P, _P, _T, _P],

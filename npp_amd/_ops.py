@@ -1080,11 +1080,16 @@ class _Concat(Function):
         ctot = sum(x.shape[1] for x in xs)
         y = new_nhwc(n, ctot, h, w, xs[0].dtype, xs[0].device)
         s = stream_ptr()
-        off = 0
-        for x in xs:
-            c = x.shape[1]
-            check(lib().npp_copy(_byref(x), _byref(y[:, off:off + c]), s), "npp_copy")
-            off += c
+        if len(xs) <= 8 and all(x.dtype == y.dtype for x in xs):
+            descs = [desc(x) for x in xs]
+            arr = (C.POINTER(L.NppTensor) * len(xs))(*[C.pointer(d) for d in descs])
+            check(lib().npp_concat(arr, len(xs), _byref(y), s), "npp_concat")
+        else:
+            off = 0
+            for x in xs:
+                c = x.shape[1]
+                check(lib().npp_copy(_byref(x), _byref(y[:, off:off + c]), s), "npp_copy")
+                off += c
         ctx.splits = [x.shape[1] for x in xs]
         return y
 

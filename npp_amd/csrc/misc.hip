@@ -105,6 +105,68 @@ extern "C" int npp_nhwc_to_nchw(const NppTensor* src, float* dst, void* stream) 
   return npp_check_launch("nhwc_to_nchw");
 }
 
+// torch.cat along channels in ONE launch: source k goes to the channel slice [off_k, off_k + c_k) of y (model_augment.py:62, 106,
+// 171-172, 539-543).  Replaces n npp_copy launches per concat (4 per cell: 214 -> ~60 launches per step).
+namespace {
+struct ConcatArgs {
+  const void* x[8];
+  long ld[8];
+  int cv_end[8];      // running end of each source in 16-byte (or scalar) column units
+  int n;
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void concat_kernel(ConcatArgs a, T* __restrict__ y, long ldy, long npix, int cvt) {
+  const unsigned total = (unsigned)(npix * cvt);
+  const FastDiv fd((unsigned)cvt);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    unsigned p, c;
+    fast_divmod(i, fd, p, c);
+    int k = 0, c0 = 0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+      if (q + 1 < a.n && (int)c >= a.cv_end[q]) { k = q + 1; c0 = a.cv_end[q]; }
+    const T* src = reinterpret_cast<const T*>(a.x[k]) + (long)p * a.ld[k] + ((int)c - c0) * V;
+    T* dst = y + (long)p * ldy + c * V;
+    if constexpr (V == 1) *dst = *src;
+    else *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+  }
+}
+}  // namespace
+
+extern "C" int npp_concat(const NppTensor* const* xs, int n, NppTensor* y, void* stream) {
+  NPP_REQUIRE(xs && y && y->ptr && n >= 1 && n <= 8, NPP_E_NULL, "npp_concat: need 1..8 sources");
+  NPP_REQUIRE(dtype_ok(y), NPP_E_DTYPE, "npp_concat: bad dtype");
+  const int v = y->dtype == NPP_BF16 ? 8 : 4;
+  bool vk = vec_ok(y);
+  long ctot = 0;
+  for (int k = 0; k < n; ++k) {
+    NPP_REQUIRE(xs[k] && xs[k]->ptr && xs[k]->n == y->n && xs[k]->h == y->h && xs[k]->w == y->w && xs[k]->dtype == y->dtype,
+                NPP_E_SHAPE, "npp_concat: source %d does not match the output", k);
+    vk = vk && vec_ok(xs[k]);
+    ctot += xs[k]->c;
+  }
+  NPP_REQUIRE(ctot == y->c, NPP_E_SHAPE, "npp_concat: channel counts do not add up (%ld vs %ld)", ctot, (long)y->c);
+  NPP_REQUIRE(npix(y) * y->c < (1L << 31), NPP_E_SHAPE, "npp_concat: tensor too large");
+  ConcatArgs a;
+  const int V = vk ? v : 1;
+  int run = 0;
+  for (int k = 0; k < 8; ++k) { a.x[k] = nullptr; a.ld[k] = 0; a.cv_end[k] = 0x7fffffff; }
+  for (int k = 0; k < n; ++k) {
+    a.x[k] = xs[k]->ptr; a.ld[k] = xs[k]->ld;
+    run += (int)(xs[k]->c / V);
+    a.cv_end[k] = run;
+  }
+  a.n = n;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(NPP_FAM_ELTWISE, y->dtype, s, 0, (double)npix(y) * y->c * esize(y->dtype) * 2);
+  const int cvt = run;
+#define CC(T, V_) hipLaunchKernelGGL((concat_kernel<T, V_>), dim3(grid_for(npix(y) * cvt)), dim3(256), 0, s, a, (T*)y->ptr, (long)y->ld, (long)npix(y), cvt)
+  if (y->dtype == NPP_BF16) { if (vk) CC(bf16_t, 8); else CC(bf16_t, 1); }
+  else { if (vk) CC(float, 4); else CC(float, 1); }
+#undef CC
+  return npp_check_launch("concat");
+}
+
 // y = x0 + x1 + ... + x(n-1) (n <= 8), f32 accumulation, one rounding: the gradient accumulation of a tensor with several
 // consumers (npp_amd/_ops.py:_FanOut) in one pass instead of n-1 binary adds.
 namespace {
