@@ -49,9 +49,11 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__
 
 NPP_DEV void contrib_range(float scale, int i, int out_size, int& lo, int& hi) {
   if (scale <= 0.f) { lo = 0; hi = out_size - 1; return; }
+  // outputs o with source coordinate scale*o in [i-1, i+1): floor / ceil already leave one candidate of slack on each side
+  // (its weight is recomputed exactly and comes out 0); every extra candidate is an extra 16-byte load per lane
   const float inv = 1.f / scale;
-  lo = (int)floorf(((float)i - 1.f) * inv) - 1;
-  hi = (int)ceilf(((float)i + 1.f) * inv) + 1;
+  lo = (int)floorf(((float)i - 1.f) * inv);
+  hi = (int)ceilf(((float)i + 1.f) * inv);
   if (lo < 0) lo = 0;
   if (hi > out_size - 1) hi = out_size - 1;
 }
@@ -84,17 +86,23 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    // four output columns per step, loads first and unconditional (a column past the range re-reads the last one with
+    // weight 0): a load behind `if (weight != 0)` is serialised by the compiler (one load in flight per lane)
     for (int oh = hlo; oh <= hhi; ++oh) {
       const float wh = contrib_weight(sh, oh, ih, H);
-      if (wh == 0.f) continue;
-      for (int ow = wlo; ow <= whi; ++ow) {
-        const float ww = contrib_weight(sw, ow, iw, W);
-        if (ww == 0.f) continue;
-        float d[V];
-        ldv<T, V>(dy + ((long)(n * OH + oh) * OW + ow) * ldy + c0, d);
-        const float w = wh * ww;
+      const T* row = dy + ((long)(n * OH + oh) * OW) * ldy + c0;
+      for (int ow = wlo; ow <= whi; ow += 4) {
+        float d[4][V], w4[4];
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] += w * d[j];
+        for (int u = 0; u < 4; ++u) {
+          const int o = ow + u <= whi ? ow + u : whi;
+          w4[u] = (ow + u <= whi) ? wh * contrib_weight(sw, o, iw, W) : 0.f;
+          ldv<T, V>(row + (long)o * ldy, d[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += w4[u] * d[u][j];
       }
     }
     stv<T, V>(dx + p * ldx + c0, acc);

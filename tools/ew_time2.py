@@ -48,3 +48,11 @@ for c, h in [(32, 96), (128, 96), (64, 48), (128, 24), (256, 12)]:
     t_bl = timeit(lambda: K.bilinear(a, 2 * h, 2 * h)) if h <= 48 else 0.0
     print(f"C={c:4d} {h:3d}^2 {mb:6.1f} MB | reduce2 {t_r2:6.1f} us {3*mb/t_r2:5.2f} TB/s | apply2 {t_a2:6.1f} {5*mb/t_a2:5.2f} | scale_ch {t_sc:6.1f} {2*mb/t_sc:5.2f} | "
           f"se_bwd_red {t_sr:6.1f} {2*mb/t_sr:5.2f} | se_bwd_app {t_sa:6.1f} {2*mb/t_sa:5.2f} | stats {t_cs:6.1f} {mb/t_cs:5.2f} | dw3x3d2 {t_dw:6.1f} {2*mb/t_dw:5.2f} | bilin x2 {t_bl:6.1f} {5*mb/max(t_bl,1e-9):5.2f}", flush=True)
+# bilinear backward (x2 and x4 upsampling gradients)
+for c, h, f in [(64, 48, 2), (128, 24, 4), (256, 12, 8), (128, 48, 2)]:
+    x = T(c, h).requires_grad_(True)
+    y = K.bilinear(x, f * h, f * h)
+    gy = T(c, f * h)
+    dx = K.new_nhwc(N, c, h, h, x.dtype, dev)
+    t_b = timeit(lambda: check(L.npp_bilinear_bwd(K._byref(gy), K._byref(dx), s()), "bb"))
+    print(f"bilinear_bwd C={c} {h}->{f*h}: {t_b:6.1f} us  {(gy.numel() + dx.numel()) * 2 / 1e6 / t_b:5.2f} TB/s", flush=True)
