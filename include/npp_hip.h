@@ -83,7 +83,13 @@ typedef struct NppPackJob {
   int32_t cout, cin, kh, kw, for_dgrad, dtype;
   int64_t first_block;
 } NppPackJob;
+/* blocks job (cout, cin, kh, kw, for_dgrad) occupies in the batched launch: first_block of job k = sum over the jobs before it.
+ * The batched kernel writes real elements only: zero the (padded) images once when they are allocated. */
+int64_t npp_pack_job_blocks(int cout, int cin, int kh, int kw, int for_dgrad);
 int npp_pack_weights_batched(const NppPackJob* jobs_dev, int njobs, int64_t total_blocks, void* stream);
+/* the same with a host-built block -> job index (int32 [total_blocks], device): saves the per-block binary search */
+int npp_pack_weights_batched_map(const NppPackJob* jobs_dev, int njobs, const int32_t* block_job_dev, int64_t total_blocks,
+                                 void* stream);
 /* y = conv(relu?(x)) + bias; optional per-channel sum / sum-of-squares of y added into
  * stats[r][0..C) / stats[r][C..2C), r < NPP_STAT_REPLICAS (the BatchNorm batch statistics, operations.py:78);
  * optional mask: y *= (mask > 0) (ReLU backward when this call is a dgrad). */

@@ -58,6 +58,7 @@ _SIGS = {
     "npp_prof_end": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "npp_pack_weight": [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
     "npp_pack_weights_batched": [_P, C.c_int, C.c_int64, _P],
+    "npp_pack_weights_batched_map": [_P, C.c_int, _P, C.c_int64, _P],
     "npp_conv_fwd": [_T, _P, _P, _T, _T, _P, _G, _P],
     "npp_conv_fwd_ws": [_T, _P, _P, _T, _T, _P, _G, _P, C.c_int64, _P],
     "npp_conv_wgrad": [_T, _T, _P, _G, _P],
@@ -115,7 +116,7 @@ _SIGS = {
     "npp_adam_step": [_P, _P, C.c_int, _P, _P],
     "npp_parsing_confusion": [_T, _T, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
 }
-EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_packed_weight_elems", "npp_reduce_blocks",
+EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_packed_weight_elems", "npp_pack_job_blocks", "npp_reduce_blocks",
                                  "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems"])
 
 
@@ -132,6 +133,8 @@ def lib():
         L.npp_last_error.restype = C.c_char_p
         L.npp_packed_weight_elems.restype = C.c_int64
         L.npp_packed_weight_elems.argtypes = [C.c_int] * 5
+        L.npp_pack_job_blocks.restype = C.c_int64
+        L.npp_pack_job_blocks.argtypes = [C.c_int] * 5
         L.npp_dwconv_bwd_weight_ws.restype = C.c_int64
         L.npp_dwconv_bwd_weight_ws.argtypes = [_T, _G]
         L.npp_adam_chunk_elems.restype = C.c_int

@@ -345,19 +345,23 @@ class WeightPacker:
         import numpy as np
         jobs = (L.NppPackJob * (2 * len(self.weights)))()
         outs = []
+        counts = []
         blk = 0
         i = 0
         for w in self.weights:
             co, ci, kh, kw = w.shape
             for dg in (0, 1):
                 n = lib().npp_packed_weight_elems(co, ci, kh, kw, dg)
-                out = torch.empty(n, dtype=dtype, device=device)
+                out = torch.zeros(n, dtype=dtype, device=device)      # padding stays zero: the kernel writes real elements only
                 outs.append(out)
                 jobs[i] = L.NppPackJob(w.data_ptr(), out.data_ptr(), co, ci, kh, kw, dg, L.npp_dtype(dtype), blk)
-                blk += (n + 255) // 256
+                nb = int(lib().npp_pack_job_blocks(co, ci, kh, kw, dg))
+                counts.append(nb)
+                blk += nb
                 i += 1
         raw = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()
         self.table = torch.from_numpy(raw).to(device)
+        self.block_job = torch.from_numpy(np.repeat(np.arange(len(counts), dtype=np.int32), counts)).to(device)
         self.outs = outs
         self.nblocks = blk
         self.key = (dtype, device, tuple(w.data_ptr() for w in self.weights))
@@ -378,8 +382,8 @@ class WeightPacker:
             self.sig = None
         if sig == self.sig and not force:
             return
-        check(lib().npp_pack_weights_batched(self.table.data_ptr(), 2 * len(ws), self.nblocks, stream_ptr()),
-              "npp_pack_weights_batched")
+        check(lib().npp_pack_weights_batched_map(self.table.data_ptr(), 2 * len(ws), self.block_job.data_ptr(), self.nblocks,
+                                                 stream_ptr()), "npp_pack_weights_batched_map")
         self.sig = sig
         k = 0
         for w in ws:
