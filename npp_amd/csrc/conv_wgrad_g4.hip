@@ -1,4 +1,4 @@
-// Convolution weight gradient, bf16, stride-1 "same" KxK (or 1x1), Cin % 128 == 0 and Cout % 128 == 0: the structure of
+// Convolution weight gradient, bf16, stride-1 "same" KxK (or 1x1), Cin and Cout in {32, 64, 128k}: the structure of
 // conv_g4.hip applied to the GEMM whose reduction axis is the pixel axis,
 //     dWp[co][tap*Cin + ci] += sum_p dy[p][co] * relu?(x)[p shifted by tap][ci].
 // Replaces the weight-gradient half of nn.Conv2d backward (models/operations.py:69-82, model_augment.py:332-398).
@@ -34,7 +34,10 @@ struct WG4Extra {
 #define WG4_DMA(rsrc, voff, ldsoff)                                                                       \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (ldsoff)), 16, voff, 0, 0, 0)
 
-template <bool RELU, bool TAPS>
+// R: ring depth.  2 (64 KiB: two blocks per CU) when the launch has more blocks than CUs, 4 (three K-tiles in flight, one block per
+// CU) when it has not.  Measured: no difference on any shape of the network (the K-tile time is set by the 8 DMA issues per wave,
+// not by their latency); kept because it costs nothing.
+template <bool RELU, bool TAPS, int R>
 __global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Extra e) {
   constexpr int KT = 32768;            // bytes per K-tile buffer: dy [64 px][256 B] then x [64 px][256 B]
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -47,9 +50,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Ex
   const int tile = blockIdx.x, split = blockIdx.y;
   const int cotile = tile % p.rowtiles, coltile = tile / p.rowtiles;
   const int co0 = cotile * 128;
-  const int tap = (coltile * 128) / p.Cin, ci0 = coltile * 128 - tap * p.Cin;
-  const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const int dy_ = kh - e.P, dx_ = kw - e.P;                 // input pixel = output pixel + (dy_, dx_)
+  // A column tile is 128 consecutive columns of the flattened (tap, ci) axis: one tap's 128 channels when Cin % 128 == 0, two taps
+  // x 64 or four taps x 32 channels otherwise; a 16-byte chunk never straddles taps (Cin % 8 == 0), so every lane decodes the tap and
+  // channel of ITS source chunk.  Columns past taps*Cin and output channels past Cout are out-of-range offsets (zeros).
   const int kt_begin = split * e.ktiles_per_split;
   int kt_end = kt_begin + e.ktiles_per_split;
   if (kt_end > e.nktiles) kt_end = e.nktiles;
@@ -58,16 +61,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Ex
   // ---- staging: wave w fills pieces 4w .. 4w+3 of each operand; lane -> row 4*piece + (lane>>4), slot lane&15 ----------
   const int srow = lane >> 4, slot = lane & 15;
   unsigned dyb[4], xb[4];      // byte offset of (first K-tile's pixel, source chunk) in dy / x; advanced by 64 pixels per K-tile
-  int yx[4];                   // (y << 16) | x of the row's OUTPUT pixel (TAPS), (0x4000 << 16) once past the end
+  int yx[4];                   // (y << 16) | x of the row's OUTPUT pixel (TAPS)
   int pix[4];
+  int tdx[4];                  // (dy_ << 8 | dx_ & 0xFF) of the lane's tap for row j, bit 30: column exists, bit 29: output channel exists
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int row = (wave * 4 + j) * 4 + srow;
     const int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
     const int q = kt_begin * 64 + row;
     pix[j] = q;
+    const int col = coltile * 128 + chunk * 8;
+    const int tap = col / p.Cin, ci = col - tap * p.Cin;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int dy_ = kh - e.P, dx_ = kw - e.P;                 // input pixel = output pixel + (dy_, dx_)
+    const bool col_ok = tap < p.taps, co_ok = co0 + chunk * 8 < p.Cout;
+    tdx[j] = ((dy_ & 0xFF) << 8) | (dx_ & 0xFF) | (col_ok ? (1 << 30) : 0) | (co_ok ? (1 << 29) : 0);
     dyb[j] = (unsigned)q * (unsigned)p.ldy * 2u + (unsigned)(co0 * 2 + chunk * 16);
-    xb[j] = (unsigned)q * (unsigned)p.ldx * 2u + (unsigned)(ci0 * 2 + chunk * 16) + (unsigned)((dy_ * p.W + dx_) * (int)p.ldx * 2);
+    xb[j] = (unsigned)q * (unsigned)p.ldx * 2u + (unsigned)(ci * 2) + (unsigned)((dy_ * p.W + dx_) * (int)p.ldx * 2);
     yx[j] = 0;
     if (TAPS) {
       const int rem = q % e.HW;
@@ -80,14 +90,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Ex
     const int lb = slot_ * KT;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool live = pix[j] < p.P;
+      const bool live = pix[j] < p.P && (tdx[j] & (1 << 29));
       WG4_DMA(rs_dy, live ? dyb[j] : 0xFFFFFFFFu, lb + (wave * 4 + j) * 1024);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      bool ok = pix[j] < p.P;
+      bool ok = pix[j] < p.P && (tdx[j] & (1 << 30));
       if (TAPS) {
-        const int y = (yx[j] >> 16) + dy_, x = (yx[j] & 0xFFFF) + dx_;
+        const int y = (yx[j] >> 16) + (int)(signed char)((tdx[j] >> 8) & 0xFF), x = (yx[j] & 0xFFFF) + (int)(signed char)(tdx[j] & 0xFF);
         ok = ok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
       }
       WG4_DMA(rs_x, ok ? xb[j] : 0xFFFFFFFFu, lb + 16384 + (wave * 4 + j) * 1024);
@@ -127,15 +137,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Ex
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4g{0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
-  int c_slot = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int nk = kt_end - kt_begin;
+  int s_slot = 0, c_slot = 0;
+  for (int i = 0; i < R - 1 && i < nk; ++i) { issue(s_slot); if (++s_slot == R) s_slot = 0; }
+  for (int kt = 0; kt < nk; ++kt) {
+    // tiles 0 .. min(nk, kt+R-1)-1 are issued (8 DMA instructions per wave each); tile kt must have landed
+    if (R > 2 && kt + R - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (R > 2 ? R - 2 : 0)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < kt_end) issue(c_slot ^ 1);
+    if (kt + R - 1 < nk) { issue(s_slot); if (++s_slot == R) s_slot = 0; }
     const unsigned ro = (unsigned)c_slot * KT;
-    c_slot ^= 1;
+    if (++c_slot == R) c_slot = 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       s16x8 fa[4], fb[4];
@@ -166,6 +179,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Ex
   // After v_permlane32_swap(X = fragment 2nb, Y = fragment 2nb+1): X' = {X g0, X g1, Y g0, Y g1} = rows {j, 4+j} x 32 columns,
   // Y' = {X g2, X g3, Y g2, Y g3} = rows {8+j, 12+j} x 32 columns: two rows x 128 contiguous bytes per atomic instruction.
   const int colbase = coltile * 128 + wn * 64;
+  const int kcols = p.taps * p.Cin;
   const int half = lane >> 5, gg = (lane >> 4) & 1;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -177,17 +191,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Ex
                                                          false, false);
         const int col = colbase + (2 * nb + half) * 16 + i16;
         const int row0 = co0 + wm * 64 + mi * 16 + gg * 4 + j;
-        atomicAdd(p.dwp + (long)row0 * p.Kpad + col, __uint_as_float(sw[0]));
-        atomicAdd(p.dwp + (long)(row0 + 8) * p.Kpad + col, __uint_as_float(sw[1]));
+        if (col < kcols) {
+          if (row0 < p.Cout) atomicAdd(p.dwp + (long)row0 * p.Kpad + col, __uint_as_float(sw[0]));
+          if (row0 + 8 < p.Cout) atomicAdd(p.dwp + (long)(row0 + 8) * p.Kpad + col, __uint_as_float(sw[1]));
+        }
       }
 }
 
 bool wg4_raise_lds(const void* fp, size_t bytes) {
-  static thread_local const void* done[8];
-  for (int i = 0; i < 8; ++i)
+  static thread_local const void* done[16];
+  for (int i = 0; i < 16; ++i)
     if (done[i] == fp) return true;
   if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 16; ++i)
     if (!done[i]) { done[i] = fp; break; }
   return true;
 }
@@ -201,17 +217,24 @@ bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   if (p.KH != p.KW || (p.KH & 1) == 0 || p.KH > 5) return false;
   const int P = (p.KH - 1) / 2;
   if (p.ph != P || p.pw != P || p.OH != p.H || p.OW != p.W) return false;
-  if (p.Cin % 128 != 0 || p.Cout % 128 != 0 || p.Cp != p.Cin || !p.vec_dy || p.ldx % 8 != 0) return false;
+  // channel counts: multiples of 128 fill the 128 x 128 tile; 64 / 32 leave part of it zero (those layers are latency-, not
+  // FLOP-bound: 2.7 GFLOP per launch)
+  const bool cin_ok = p.Cin % 128 == 0 || p.Cin == 64 || p.Cin == 32, cout_ok = p.Cout % 128 == 0 || p.Cout == 64 || p.Cout == 32;
+  if (!cin_ok || !cout_ok || p.Cp != p.Cin || !p.vec_dy || p.ldx % 8 != 0 || p.ldy % 8 != 0) return false;
+  // measured against conv_wgrad_kernel (us): 64->128 3x3 @96^2 61 vs 75, 256->64 1x1 16 vs 18, 64->64 1x1 12.5 vs 15.4, 32->32 1x1 17.5
+  // vs 20; but 64->64 3x3 @48^2 28 vs 24, 32->32 3x3 @96^2 36 vs 29, 128->32 1x1 23 vs 21: the narrow-output KxK layers stay there
+  static const bool all = getenv("NPP_WG4_ALL") != nullptr;
+  if (!all && ((p.Cout <= 64 && p.taps > 1) || (p.Cout == 32 && p.Cin >= 128))) return false;
   if ((long)p.P * p.ldx * 2 >= (1L << 32) - (1L << 24) || (long)p.P * p.ldy * 2 >= (1L << 32) - (1L << 24)) return false;
   if (p.H >= 16384 || p.W >= 16384) return false;
   WG4Extra e;
   e.P = P; e.HW = p.H * p.W;
-  e.coltiles = p.taps * p.Cin / 128;
+  e.coltiles = (p.taps * p.Cin + 127) / 128;
   e.nktiles = (p.P + 63) / 64;
   e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
   e.dybytes = (unsigned)((long)p.P * p.ldy * 2);
   WgradParams q = p;
-  q.rowtiles = p.Cout / 128;
+  q.rowtiles = (p.Cout + 127) / 128;
   const int tiles = q.rowtiles * e.coltiles;
   // Pixel splits.  Two blocks fit a CU (512 slots): never more blocks than slots (513 blocks = a second, empty round: 104 vs
   // 98 us on 128->128 3x3 @96^2), and every block ends with 64 KiB of atomics, so the split count also balances the atomic
@@ -229,15 +252,22 @@ bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   e.ktiles_per_split = (e.nktiles + splits - 1) / splits;
   splits = (e.nktiles + e.ktiles_per_split - 1) / e.ktiles_per_split;
   if (splits > 65535) return false;
-  constexpr size_t lds = 2 * 32768;
   dim3 grid(tiles, splits);
-#define WG4_LAUNCH(RELU_, TAPS_)                                                                            \
+  static const int force_ring = getenv("NPP_WG4_RING") ? atoi(getenv("NPP_WG4_RING")) : 0;
+  const bool deep = force_ring ? force_ring == 4 : (tiles * splits <= 256);
+#define WG4_LAUNCH(RELU_, TAPS_, R_)                                                                        \
   do {                                                                                                      \
-    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g4_kernel<RELU_, TAPS_>), lds)) return false; \
-    hipLaunchKernelGGL((conv_wgrad_g4_kernel<RELU_, TAPS_>), grid, dim3(256), lds, stream, q, e);           \
+    constexpr size_t lds = (size_t)R_ * 32768;                                                              \
+    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g4_kernel<RELU_, TAPS_, R_>), lds)) return false; \
+    hipLaunchKernelGGL((conv_wgrad_g4_kernel<RELU_, TAPS_, R_>), grid, dim3(256), lds, stream, q, e);       \
   } while (0)
-  if (P == 0) { if (p.relu_in) WG4_LAUNCH(true, false); else WG4_LAUNCH(false, false); }
-  else        { if (p.relu_in) WG4_LAUNCH(true, true);  else WG4_LAUNCH(false, true); }
+#define WG4_PICK(R_)                                                                                        \
+  do {                                                                                                      \
+    if (P == 0) { if (p.relu_in) WG4_LAUNCH(true, false, R_); else WG4_LAUNCH(false, false, R_); }          \
+    else        { if (p.relu_in) WG4_LAUNCH(true, true, R_);  else WG4_LAUNCH(false, true, R_); }           \
+  } while (0)
+  if (deep) WG4_PICK(4); else WG4_PICK(2);
+#undef WG4_PICK
 #undef WG4_LAUNCH
   return true;
 }

@@ -10,6 +10,8 @@ N, iters = 16, 10
 SHAPES = [(128, 128, 3, 96), (384, 128, 3, 96), (1024, 512, 1, 96), (1024, 384, 1, 96), (512, 256, 1, 96), (512, 128, 1, 96),
           (384, 128, 1, 96), (128, 128, 1, 96), (256, 256, 3, 48), (128, 128, 3, 24), (256, 256, 3, 12), (512, 512, 3, 24),
           (512, 512, 1, 24), (256, 256, 1, 48), (1024, 256, 1, 12)]
+if os.environ.get('NPP_TIME_SET') == 'narrow':
+    SHAPES = [(64, 64, 3, 48), (32, 32, 3, 96), (128, 32, 1, 96), (256, 64, 1, 48), (64, 64, 1, 48), (32, 32, 1, 96), (64, 128, 3, 96)]
 for cin, cout, k, H in SHAPES:
     x = K.cast(torch.randn(N, cin, H, H, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16)
     gy = K.cast(torch.randn(N, cout, H, H, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16)
