@@ -174,56 +174,29 @@ def main():
     lpar = [torch.from_numpy(a).to(dev) for a in lpar]
     lpose = [torch.from_numpy(a[:, :-1].copy()).to(dev) for a in lpose]
 
+    # the step is the product's own callable (npp_amd/train_step.py; core/function.py:72-107): eager calls first, then one
+    # hipGraph capture of the static step (~5000 launches and, for N > 1, the SyncBN and gradient collectives
+    # become one replay); any capture failure falls back to eager on every rank
+    from npp_amd.train_step import TrainStep
+    from npp_amd import _ops as K
+    train_step = TrainStep(net, crit_pose, crit_par, opt, reducer=reducer, graph=use_graph, warmup=2)
+
     def step():
-        pose_list, par_list = net(images)
-        loss = (crit_par(par_list, lpar).unsqueeze(0) + crit_pose(pose_list, lpose).unsqueeze(0)).mean()
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        if reducer is not None:
-            reducer.finish()
-        opt.step()
-        return loss
+        return train_step(images, lpar, lpose)
+
+    def eager_step():
+        return train_step._eager(images, lpar, lpose, None)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    graph = None
-    eager_step = step
     if use_graph:
-        # hipGraph capture of the static step: ~7000 launches (and, for N > 1, the SyncBN and gradient
-        # collectives) become one replay.  Any capture failure falls back to eager on every rank.
-        from npp_amd import _ops as K
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    step()
-            torch.cuda.current_stream().wait_stream(side)
-            barrier()
-            if use_dist:
-                # the ProcessGroup watchdog thread polls the events of the eager collectives above; let it retire them
-                # before capture starts, and capture in thread-local mode so that its polling (a different thread) can
-                # never be an illegal call inside a global-mode capture
-                time.sleep(1.0)
-            K.reset_pools()
-            opt.zero_grad(set_to_none=True)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                static_loss = step()
-            K.reset_pools()
-            graph = g
-        except Exception as exc:      # noqa: BLE001
-            sys.stderr.write(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager\n")
-            graph = None
-            K.reset_pools()
-            torch.cuda.synchronize()
-        if graph is not None:
-            def step():      # noqa: F811
-                graph.replay()
-                return static_loss
+        for _ in range(3):      # two eager calls, then capture + first replay: all before the W warm-up steps
+            step()
+        barrier()
+    graph = train_step.graph
 
     for _ in range(args.warmup):
         step()

@@ -32,6 +32,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._pin = None          # (pinned jobs, pinned chunks)
         self._dev = None          # (device jobs, device chunks)
         self._step = None         # device int64
+        self._captured_pin = None # index of the pinned image a hipGraph capture uploads from
+        self._retired = []
 
     def _state_for(self, p):
         st = self.state[p]
@@ -65,7 +67,10 @@ class FusedAdam(torch.optim.Optimizer):
         # two pinned images of the job table, used alternately: the host never waits for the upload of the previous step
         pjs = [torch.empty(n * _JOB.itemsize, dtype=torch.uint8).pin_memory() for _ in range(2)]
         pc = torch.from_numpy(chunks.reshape(-1).copy()).pin_memory()
+        if self._pin is not None and self._captured_pin is not None:
+            self._retired.append((self._pin, self._dev))      # a captured graph still uploads from / into the old tables
         self._pin = (pjs, pc)
+        self._captured_pin = None
         self._pin_ev = [None, None]
         self._pin_i = 0
         self._dev = (torch.empty(pjs[0].numel(), dtype=torch.uint8, device=dev), torch.empty(pc.numel(), dtype=torch.int32, device=dev))
@@ -92,20 +97,30 @@ class FusedAdam(torch.optim.Optimizer):
         if not plist:
             return loss
         same = self._plist is not None and len(plist) == len(self._plist) and all(a is b for a, b in zip(plist, self._plist))
-        if not same or hyper != self._hyper:
+        if not same:
             if self._plist is not None and torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("FusedAdam: the parameter set / hyper-parameters changed inside a hipGraph capture "
+                raise RuntimeError("FusedAdam: the parameter set changed inside a hipGraph capture "
                                    "(run one eager step with the same set first: pinned tables are allocated there)")
             self._rebuild(plist, hyper, plist[0].device)
+        elif hyper != self._hyper:
+            self._apply_hyper(hyper)
         for p in plist:
             g = p.grad
             if g.dtype != torch.float32 or not g.is_contiguous():
                 p.grad = g.float().contiguous()
         gp = np.fromiter((p.grad.data_ptr() for p in plist), dtype=np.uint64, count=len(plist))
-        if self._grad_ptrs is None or not np.array_equal(gp, self._grad_ptrs):
-            capturing = torch.cuda.is_current_stream_capturing()
-            i = self._pin_i
-            self._pin_i ^= 1
+        capturing = torch.cuda.is_current_stream_capturing()
+        # under capture the upload is always recorded: a replay re-reads the pinned image, which is how refresh_hyper()
+        # reaches a captured step
+        cap = self._captured_pin
+        if capturing or cap is not None or self._grad_ptrs is None or not np.array_equal(gp, self._grad_ptrs):
+            # once a step has been captured its pinned image belongs to the graph (every replay uploads it, so the device
+            # table must also be re-uploaded by every eager step): eager steps keep to the other image
+            if cap is not None and not capturing:
+                i = 1 - cap
+            else:
+                i = self._pin_i
+                self._pin_i ^= 1
             if self._pin_ev[i] is not None and not capturing:
                 self._pin_ev[i].synchronize()         # the upload issued two steps ago has read this pinned image
             self._jobs["grad"] = gp
@@ -115,10 +130,44 @@ class FusedAdam(torch.optim.Optimizer):
                 self._pin_ev[i] = torch.cuda.Event()
                 self._pin_ev[i].record()
             self._grad_ptrs = gp
+            if capturing:
+                self._captured_pin = i
         check(lib().npp_adam_step(self._dev[0].data_ptr(), self._dev[1].data_ptr(), self._nchunks, self._step.data_ptr(),
                                   stream_ptr()), "npp_adam_step")
         torch.autograd.graph.increment_version(plist)   # in-place update behind autograd's back: derived caches must see it
         return loss
+
+    def _apply_hyper(self, hyper):
+        """New lr / betas / eps / weight decay for the SAME parameter set: rewrite the columns of the job table in place
+        (no reallocation: a captured hipGraph keeps uploading from the same pinned image into the same device table)."""
+        h = np.asarray(hyper, dtype=np.float32)
+        j = self._jobs
+        j["lr"], j["beta1"], j["beta2"], j["eps"], j["weight_decay"] = h[:, 0], h[:, 1], h[:, 2], h[:, 3], h[:, 4]
+        self._hyper = hyper
+        self._grad_ptrs = None                 # the next eager step uploads
+        cap = self._captured_pin
+        if cap is not None and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize()           # no replay may be reading the pinned image while it is rewritten
+            keep = self._pin[0][cap].numpy().view(_JOB)["grad"].copy()      # the graph's own gradient addresses
+            img = j.copy()
+            img["grad"] = keep
+            self._pin[0][cap].numpy()[:] = img.view(np.uint8)
+
+    def refresh_hyper(self):
+        """Carry changed param_group hyper-parameters (a learning-rate schedule, augment_lip_sync.py:213,249) into a step
+        that was captured in a hipGraph: the captured upload copies the pinned job table at every replay, so rewriting the
+        lr / betas / eps / weight-decay columns of that pinned image is enough.  The parameter set must be unchanged."""
+        if self._plist is None:
+            return
+        hyper = []
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            h = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]))
+            hyper.extend(h for p in group["params"] if p.grad is not None)
+        if len(hyper) != len(self._plist):
+            raise RuntimeError("FusedAdam.refresh_hyper: the set of parameters with gradients changed since the last step")
+        if hyper != self._hyper:
+            self._apply_hyper(hyper)
 
     def device_step_count(self) -> int:
         return int(self._step.item()) if self._step is not None else 0

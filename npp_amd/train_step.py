@@ -1,0 +1,171 @@
+"""One optimisation step of the reference's training loop as a callable, replayed as a hipGraph.
+
+Counterpart of the loop body of `train()` (core/function.py:72-107):
+
+    output_pose, output_par = model(images)
+    loss = (criterion_par(output_par, labels_par).unsqueeze(0)
+            + criterion_pose(output_pose, labels_pose, target_weight=pose_weight).unsqueeze(0)).mean()
+    model.zero_grad(); loss.backward(); optimizer.step()
+
+A step of NPPNet is ~5 000 kernel launches; issued eagerly from Python the host is the bottleneck (~115 img/s at batch 16 on
+an MI355X, where the GPU alone does ~290).  The step is static -- fixed genotype, fixed shapes, no host decision between
+launches -- so `TrainStep` runs the first `warmup` calls eagerly (they are real steps on real batches; they also size
+every pool), captures the next call into ONE hipGraph (forward, both criteria, backward, the gradient all-reduce and the
+SyncBatchNorm exchanges when a process group is active, and the optimizer) and from then on copies the batch into the
+graph's static input buffers and replays it.  Learning-rate changes (`MultiStepLR`, augment_lip_sync.py:213,249) reach the
+replayed graph through `FusedAdam.refresh_hyper()`: the captured table upload re-reads pinned memory at every replay.
+
+A call with different input shapes (the last, short batch of an epoch) runs eagerly.  If capture fails the step stays
+eager and says so once on stderr; `NPP_TRAIN_GRAPH=0` forces that.  The returned loss is a 0-dim device tensor (a static
+buffer of the graph: `.item()` / `reduce_tensor` it before the next call, as the reference's loop does).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import _ops as K
+
+
+class TrainStep:
+    def __init__(self, model, criterion_pose, criterion_par, optimizer, reducer=None, graph: Optional[bool] = None,
+                 warmup: int = 2):
+        self.model, self.criterion_pose, self.criterion_par = model, criterion_pose, criterion_par
+        self.optimizer, self.reducer = optimizer, reducer
+        if graph is None:
+            graph = os.environ.get("NPP_TRAIN_GRAPH", "1") != "0"
+        self.use_graph = bool(graph)
+        self.warmup = max(int(warmup), 1)      # at least one eager step: pools, pinned optimizer tables, packed weights
+        self.calls = 0
+        self.graph = None
+        self._static_in: Optional[List[torch.Tensor]] = None
+        self._static_loss = None
+        self._sig = None
+        self._hyper = None
+        self._side = None
+
+    # -- the step itself (what gets captured) ---------------------------------------------------------------------
+    def _eager(self, images, labels_par, labels_pose, pose_weight):
+        output_pose, output_par = self.model(images)
+        losses_par = self.criterion_par(output_par, labels_par).unsqueeze(0)
+        if pose_weight is not None:
+            losses_pose = self.criterion_pose(output_pose, labels_pose, target_weight=pose_weight).unsqueeze(0)
+        else:
+            losses_pose = self.criterion_pose(output_pose, labels_pose).unsqueeze(0)
+        loss = (losses_par + losses_pose).mean()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        return loss
+
+    # -- static buffers -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def _flatten(images, labels_par, labels_pose, pose_weight):
+        lp = list(labels_pose) if isinstance(labels_pose, (list, tuple)) else [labels_pose]
+        flat = [images] + list(labels_par) + lp + ([pose_weight] if pose_weight is not None else [])
+        layout = (len(labels_par), len(lp), isinstance(labels_pose, (list, tuple)), pose_weight is not None)
+        return flat, layout
+
+    @staticmethod
+    def _unflatten(flat: Sequence[torch.Tensor], layout):
+        npar, npose, pose_is_list, has_w = layout
+        images = flat[0]
+        labels_par = list(flat[1:1 + npar])
+        lp = list(flat[1 + npar:1 + npar + npose])
+        labels_pose = lp if pose_is_list else lp[0]
+        pose_weight = flat[1 + npar + npose] if has_w else None
+        return images, labels_par, labels_pose, pose_weight
+
+    @staticmethod
+    def _signature(flat, layout):
+        return layout, tuple((tuple(t.shape), t.dtype, t.device) for t in flat)
+
+    def _hyper_now(self):
+        return [(float(g["lr"]), tuple(float(b) for b in g["betas"]), float(g["eps"]), float(g["weight_decay"]))
+                for g in self.optimizer.param_groups]
+
+    def _barrier(self):
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # -- capture ------------------------------------------------------------------------------------------------------
+    def _capture(self, flat, layout):
+        """Capture one step on static copies of `flat`.  Nothing executes during capture: the caller replays."""
+        self._static_in = [t.clone() for t in flat]
+        args = self._unflatten(self._static_in, layout)
+        collectives = dist.is_available() and dist.is_initialized()
+        torch.cuda.synchronize()
+        if collectives:
+            # the ProcessGroup watchdog polls the events of the eager collectives issued so far from its own thread; let it
+            # retire them, and capture in thread-local mode so its polling can never be an illegal call inside the capture
+            dist.barrier()
+            time.sleep(1.0)
+        K.reset_pools()
+        self.optimizer.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._static_loss = self._eager(*args)
+        finally:
+            K.reset_pools()        # chunks handed out during capture belong to the graph's private pool
+        self.graph = g
+        self._sig = self._signature(flat, layout)
+        self._hyper = self._hyper_now()
+
+    def __call__(self, images, labels_par, labels_pose, pose_weight=None):
+        self.calls += 1
+        flat, layout = self._flatten(images, labels_par, labels_pose, pose_weight)
+        if not self.use_graph:
+            return self._eager(images, labels_par, labels_pose, pose_weight)
+        if self.graph is None:
+            if self.calls <= self.warmup:
+                # eager warm-up on a side stream (allocations of these steps must not land in the capture's pool)
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                self._side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._side):
+                    loss = self._eager(images, labels_par, labels_pose, pose_weight)
+                torch.cuda.current_stream().wait_stream(self._side)
+                return loss
+            try:
+                self._capture(flat, layout)
+            except Exception as exc:      # noqa: BLE001 -- any capture failure: stay eager, on every rank alike
+                sys.stderr.write(f"[npp_amd.TrainStep] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager\n")
+                self.graph, self.use_graph, self._static_in = None, False, None
+                K.reset_pools()
+                torch.cuda.synchronize()
+                return self._eager(images, labels_par, labels_pose, pose_weight)
+            self.graph.replay()            # the captured step has not run yet: this executes it on this batch
+            return self._static_loss
+        if self._signature(flat, layout) != self._sig:
+            return self._eager(images, labels_par, labels_pose, pose_weight)       # e.g. the short last batch
+        for dst, src in zip(self._static_in, flat):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        hyper = self._hyper_now()
+        if hyper != self._hyper:
+            refresh = getattr(self.optimizer, "refresh_hyper", None)
+            if refresh is None:
+                raise RuntimeError("TrainStep: optimizer hyper-parameters changed after capture and the optimizer has no "
+                                   "refresh_hyper() (use npp_amd.optim.FusedAdam)")
+            refresh()
+            self._hyper = hyper
+        self.graph.replay()
+        return self._static_loss
+
+    @property
+    def static_inputs(self):
+        """The graph's input buffers (None before capture): a loader may fill them in place to skip the per-call copy."""
+        return self._static_in
+
+    @property
+    def graphed(self) -> bool:
+        return self.graph is not None

@@ -69,3 +69,28 @@ def test_product_path_refuses_cpu_tensors():
     net = Network(cfg)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(1, 3, 64, 64))
+
+
+def test_train_step_batch_plumbing_is_shape_exact():
+    """TrainStep's static-input plumbing (host logic only): the reference's batch tuple (core/function.py:72-84) survives
+    flatten -> unflatten in both pose-label forms, and the signature that decides replay-vs-eager sees shapes and dtypes."""
+    import torch
+    from npp_amd.train_step import TrainStep
+    im = torch.zeros(2, 3, 8, 8)
+    lpar = [torch.zeros(2, 8, 8, dtype=torch.int64), torch.ones(2, 8, 8, dtype=torch.int64)]
+    lpose = [torch.zeros(2, 16, 2, 2), torch.ones(2, 16, 2, 2)]
+    w = torch.ones(2, 16, 1)
+    for pose, weight in ((lpose, w), (lpose[0], None), (tuple(lpose), None)):
+        flat, layout = TrainStep._flatten(im, lpar, pose, weight)
+        assert len(flat) == 1 + 2 + (1 if torch.is_tensor(pose) else 2) + (weight is not None)
+        im2, lpar2, pose2, w2 = TrainStep._unflatten(flat, layout)
+        assert im2 is im and lpar2[0] is lpar[0] and lpar2[1] is lpar[1] and (w2 is weight)
+        if torch.is_tensor(pose):
+            assert pose2 is pose
+        else:
+            assert isinstance(pose2, list) and pose2[0] is pose[0] and pose2[1] is pose[1]
+    flat, layout = TrainStep._flatten(im, lpar, lpose, None)
+    sig = TrainStep._signature(flat, layout)
+    flat_b, layout_b = TrainStep._flatten(im[:1], [a[:1] for a in lpar], [a[:1] for a in lpose], None)
+    assert TrainStep._signature(flat_b, layout_b) != sig
+    assert TrainStep._signature(*TrainStep._flatten(im.clone(), lpar, lpose, None)) == sig

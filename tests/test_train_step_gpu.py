@@ -1,0 +1,124 @@
+"""npp_amd.train_step.TrainStep (the loop body of core/function.py:72-107): the hipGraph-replayed step must follow the same
+trajectory as the eager step -- same losses, same parameters after several optimiser steps -- including a learning-rate
+change after capture (augment_lip_sync.py:213,249) and a batch of another shape (runs eagerly)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(C):
+    from types import SimpleNamespace as NS
+    return NS(DATASET=NS(NUM_CLASSES=20, NUM_JOINTS=16), TRAIN=NS(LAYERS=16, INIT_CHANNELS=C),
+              MODEL=NS(DECONV_WITH_BIAS=False, HEAD='PSP', REFINE_LAYERS=1))
+
+
+def _batch(n, size, seed, dev):
+    from npp_amd.synth import synth_batch
+    images, lpar, lpose, meta = synth_batch(n, size, seed=seed)
+    return (torch.from_numpy(images).to(dev), [torch.from_numpy(a).to(dev) for a in lpar],
+            [torch.from_numpy(a[:, :-1].copy()).to(dev) for a in lpose], torch.from_numpy(meta["pose_weight"]).to(dev))
+
+
+def _make(dev, graph, state=None):
+    from npp_amd.criterion import Criterion_par, Criterion_pose
+    from npp_amd.model_augment import Network, set_compute_dtype
+    from npp_amd.optim import FusedAdam
+    from npp_amd.train_step import TrainStep
+    set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    net = Network(_cfg(8)).to(dev).train()
+    if state is not None:
+        net.load_state_dict(state)
+    cp, cq = Criterion_pose(out_len=2).to(dev), Criterion_par(out_len=2).to(dev)
+    opt = FusedAdam(list(net.parameters()) + list(cp.parameters()) + list(cq.parameters()), lr=1e-3)
+    return net, opt, TrainStep(net, cp, cq, opt, graph=graph, warmup=1)
+
+
+def _sync_state(src, dst):
+    """Parameters, buffers and Adam state of (net, criteria, optimizer) `src` -> `dst`, in place."""
+    (net_s, cp_s, cq_s, opt_s), (net_d, cp_d, cq_d, opt_d) = src, dst
+    with torch.no_grad():
+        for ms, md in ((net_s, net_d), (cp_s, cp_d), (cq_s, cq_d)):
+            for a, b in zip(list(ms.parameters()) + list(ms.buffers()), list(md.parameters()) + list(md.buffers())):
+                b.copy_(a)
+        for gs, gd in zip(opt_s.param_groups, opt_d.param_groups):
+            for a, b in zip(gs["params"], gd["params"]):
+                if "exp_avg" in opt_s.state.get(a, {}):
+                    opt_d._state_for(b)
+                    opt_d.state[b]["exp_avg"].copy_(opt_s.state[a]["exp_avg"])
+                    opt_d.state[b]["exp_avg_sq"].copy_(opt_s.state[a]["exp_avg_sq"])
+        if opt_s._step is not None and opt_d._step is not None:
+            opt_d._step.copy_(opt_s._step)
+
+
+def test_graphed_step_equals_the_eager_step():
+    """Every step starts from identical state (copied graphed -> eager), so the two runs can only differ by float-atomic
+    summation order: equal losses, and equal Adam updates except where a near-zero gradient's sign is noise."""
+    dev = torch.device("cuda:0")
+    net_e, opt_e, step_e = _make(dev, graph=False)
+    net_g, opt_g, step_g = _make(dev, graph=True)
+    eager = (net_e, step_e.criterion_pose, step_e.criterion_par, opt_e)
+    graphed = (net_g, step_g.criterion_pose, step_g.criterion_par, opt_g)
+    batches = [_batch(2, 128, s, dev) for s in range(6)]
+    short = _batch(2, 96, 99, dev)
+    pe, pg = dict(net_e.named_parameters()), dict(net_g.named_parameters())
+    lr = 1e-3
+
+    def both(batch, i):
+        if i > 0:
+            _sync_state(graphed, eager)
+        before = {k: v.detach().clone() for k, v in pg.items()}
+        im, lpar, lpose, _ = batch
+        le = float(step_e(im, list(lpar), list(lpose)).detach())
+        lg = float(step_g(im, list(lpar), list(lpose)).detach())
+        assert abs(le - lg) <= 2e-5 * abs(le), (i, le, lg)
+        off = tot = 0
+        biggest = 0.0
+        for k in pg:
+            de, dg = pe[k].detach() - before[k], pg[k].detach() - before[k]
+            off += int(((de - dg).abs() > 0.02 * lr).sum())
+            tot += de.numel()
+            biggest = max(biggest, float(dg.abs().max()))
+        assert off <= 2e-3 * tot, (i, off, tot)
+        return biggest
+
+    for i, batch in enumerate(batches):
+        if i == 4:                       # MultiStepLR milestone after capture (augment_lip_sync.py:213,249)
+            lr = 1e-4
+            for opt in (opt_e, opt_g):
+                for grp in opt.param_groups:
+                    grp["lr"] = lr
+        biggest = both(batch, i)
+        assert 0.2 * lr < biggest < 3.5 * lr, (i, biggest, lr)      # the replayed graph steps with the CURRENT lr
+        if i == 2:                       # a batch of another shape in between: runs eagerly, the graph survives it
+            both(short, 100)
+    assert step_g.graphed and not step_e.graphed
+    assert opt_g.device_step_count() == opt_e.device_step_count() == 7
+
+
+def test_pose_weight_argument_and_static_inputs():
+    dev = torch.device("cuda:0")
+    from npp_amd.criterion import Criterion_par, Criterion_pose
+    from npp_amd.model_augment import Network, set_compute_dtype
+    from npp_amd.optim import FusedAdam
+    from npp_amd.train_step import TrainStep
+    set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    net = Network(_cfg(8)).to(dev).train()
+    cp, cq = Criterion_pose(out_len=2).to(dev), Criterion_par(out_len=2).to(dev)
+    opt = FusedAdam(list(net.parameters()) + list(cp.parameters()) + list(cq.parameters()), lr=1e-3)
+    step = TrainStep(net, cp, cq, opt, warmup=1)
+    im, lpar, lpose, w = _batch(2, 64, 3, dev)
+    l0 = float(step(im, lpar, lpose, w).detach())
+    l1 = float(step(im, lpar, lpose, w).detach())
+    l2 = float(step(im, lpar, lpose, w).detach())
+    assert step.graphed and len(step.static_inputs) == 6
+    assert np.isfinite([l0, l1, l2]).all() and l2 < l0

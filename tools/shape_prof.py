@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 FWD_K = ("conv_s1_kernel", "conv_igemm_kernel", "conv_g8_kernel", "conv_g4_kernel")
 FIN_K = "conv_s1_finish_kernel"
-WG_K = ("wgrad_tap_kernel", "conv_wgrad_kernel")
+WG_K = ("wgrad_tap_kernel", "conv_wgrad_kernel", "conv_wgrad_g4_kernel")
 
 
 def run(path, steps=3):
