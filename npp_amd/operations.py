@@ -165,7 +165,7 @@ class SE_Block(nn.Module):
     def pending(self, x):
         out = self._gate(x)
         if self.stride == 1:
-            return BnSide(out)
+            return BnSide(out, private=True)
         y, st = K.pool2x2(out, True, want_stats=_use_batch_stats(self.bn))
         return BnSide(y, self.bn, st)
 
@@ -227,7 +227,8 @@ class FacConv(_BnOp):
     def pending(self, x):
         c1, c2, bn = self.net[1], self.net[2], self.net[3]
         y, _ = K.conv2d(x, c1.weight, None, c1.stride, c1.padding, 1, relu_in=True)
-        y, st = K.conv2d(y, c2.weight, None, c2.stride, c2.padding, 1, relu_in=False, want_stats=_use_batch_stats(bn))
+        y, st = K.conv2d(y, c2.weight, None, c2.stride, c2.padding, 1, relu_in=False, want_stats=_use_batch_stats(bn),
+                         private_in=True)
         return BnSide(y, bn, st)
 
 
@@ -245,7 +246,7 @@ class DilConvS(_BnOp):
     def pending(self, x):
         dw, pw, bn = self.net[1], self.net[2], self.net[3]
         y = K.dwconv2d(x, dw.weight, dw.stride[0], dw.padding[0], dw.dilation[0], relu_in=True)
-        y, st = K.conv2d(y, pw.weight, None, 1, 0, 1, relu_in=False, want_stats=_use_batch_stats(bn))
+        y, st = K.conv2d(y, pw.weight, None, 1, 0, 1, relu_in=False, want_stats=_use_batch_stats(bn), private_in=True)
         return BnSide(y, bn, st)
 
 
