@@ -102,11 +102,12 @@ class TrainStep:
         self._static_in = [t.clone() for t in flat]
         args = self._unflatten(self._static_in, layout)
         collectives = dist.is_available() and dist.is_initialized()
+        if collectives:
+            dist.barrier()
         torch.cuda.synchronize()
         if collectives:
             # the ProcessGroup watchdog polls the events of the eager collectives issued so far from its own thread; let it
             # retire them, and capture in thread-local mode so its polling can never be an illegal call inside the capture
-            dist.barrier()
             time.sleep(1.0)
         K.reset_pools()
         self.optimizer.zero_grad(set_to_none=True)
