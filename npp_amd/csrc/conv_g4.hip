@@ -23,6 +23,10 @@
 #ifndef G4_RING
 #define G4_RING 2
 #endif
+// ablation builds (tools/pw_ab.sh): 1 = no output stores, 2 = no operand DMA, 4 = no MFMA.  Results are wrong by design.
+#ifndef G4_DBG
+#define G4_DBG 0
+#endif
 
 namespace {
 
@@ -46,7 +50,10 @@ NPP_DEV u32x4 relu_bf16x8_g4(u32x4 v) {
 // BM x BN output tile, 4 waves as WM_ x (4 / WM_): 64 x 64 and 128 x 128 as 2 x 2, 64 x 32 (32 output channels) as 4 x 1.
 // HALF: 32 input channels -- a K-tile is then TWO taps x 32 channels (source piece 0-3 = tap 2t, 4-7 = tap 2t+1, selected per
 // lane; the packed weight rows are already contiguous in (tap, channel)), the last one zero-filled when the tap count is odd.
-template <int BM, int BN, int WM_, bool RELU, bool TAPS, bool HALF>
+// PERS: persistent over output tiles (grid = resident slots): the K-tile stream runs on across tiles, so the first K-tile of
+// the next tile is in flight during the epilogue of this one and no block start-up sits between two tiles -- for the
+// memory-bound 1x1 shapes (K = 128..512: 2..8 K-tiles per tile) whose tile time is a chain of latencies, not work.
+template <int BM, int BN, int WM_, bool RELU, bool TAPS, bool HALF, bool PERS>
 __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) {
   constexpr int WN_ = 4 / WM_;
   constexpr int TM = BM / WM_, TN = BN / WN_;    // per-wave tile
@@ -65,12 +72,16 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
   const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
   const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, e.wbytes, 0x00020000);
 
-  // XCD-contiguous tile order, N-tile fastest
+  // XCD-contiguous tile order, N-tile fastest.  Tile index tl -> XCD tl & 7 (block bid runs tiles bid, bid + G, ...: G is a
+  // multiple of 8 whenever a block runs more than one tile, so all of them sit in its XCD's contiguous range)
   const int total = p.mtiles * p.ntiles;
   const int bid = blockIdx.x;
-  const int xcd = bid & 7, qd = total >> 3, rm = total & 7;
-  const int lid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-  const int m0 = (lid / p.ntiles) * BM, n0 = (lid % p.ntiles) * BN;
+  const int G = PERS ? (int)gridDim.x : total;
+  auto tile_of = [&](int tl, int& m0_, int& n0_) {
+    const int xcd = tl & 7, qd = total >> 3, rm = total & 7;
+    const int lid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (tl >> 3);
+    m0_ = (lid / p.ntiles) * BM; n0_ = (lid % p.ntiles) * BN;
+  };
 
   const int lrow = lane & 15, lk = lane >> 4;
   const unsigned loff0 = (lrow >> 3) * 1024 + (lrow & 7) * 128 + ((lk ^ (lrow & 7)) << 4);
@@ -83,25 +94,34 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
   const bool tap_hi = HALF && (sp >> 2);          // HALF: the lane stages the second tap of the pair
   unsigned abyte[PA];
   int ayx[PA];
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    int q = m0 + (wave * PA + i) * 8 + sl;
-    const bool real = q < p.M;
-    if (!real) q = p.M - 1;
-    abyte[i] = (unsigned)q * (unsigned)p.ldx * 2u + spa;
-    ayx[i] = 0;
-    if (TAPS) {
-      const int rem = q % e.HW;
-      const int y = rem / p.W;
-      ayx[i] = real ? ((y << 16) | (rem - y * p.W)) : (0x4000 << 16);
-    }
-  }
-  const unsigned bbyte = (unsigned)(n0 + wave * PB * 8 + sl) * (unsigned)p.Kpad * 2u + spb;   // further pieces: +8 rows each (scalar offset)
-
+  unsigned bbyte = 0;
   int s_tap = 0, s_chunk = 0, s_dy = -e.P, s_dx = -e.P, s_slot = 0, s_kt = 0;
+  auto setup = [&](int tl) {      // staging state of output tile tl
+    int m0_, n0_;
+    tile_of(tl, m0_, n0_);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      int q = m0_ + (wave * PA + i) * 8 + sl;
+      const bool real = q < p.M;
+      if (!real) q = p.M - 1;
+      abyte[i] = (unsigned)q * (unsigned)p.ldx * 2u + spa;
+      ayx[i] = 0;
+      if (TAPS) {
+        const int rem = q % e.HW;
+        const int y = rem / p.W;
+        ayx[i] = real ? ((y << 16) | (rem - y * p.W)) : (0x4000 << 16);
+      }
+    }
+    bbyte = (unsigned)(n0_ + wave * PB * 8 + sl) * (unsigned)p.Kpad * 2u + spb;   // further pieces: +8 rows each (scalar offset)
+    s_tap = 0; s_chunk = 0; s_dy = -e.P; s_dx = -e.P; s_kt = 0;
+  };
+  int s_tl = bid, s_k = 0;        // output tile / K-tile the staging stream stands at
+  setup(s_tl);
+
   auto issue = [&]() {     // the next K-tile of the stream into ring slot s_slot
     const int lb = s_slot * KT;
-    if constexpr (!HALF) {
+    if constexpr ((G4_DBG & 2) != 0) {
+    } else if constexpr (!HALF) {
       const int koffA = s_chunk * 128 + (TAPS ? (s_dy * p.W + s_dx) * (int)p.ldx * 2 : 0);
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
@@ -142,24 +162,42 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
       ++s_kt;
     }
     if (++s_slot == R) s_slot = 0;
+    if (PERS && ++s_k == e.nk) {      // the stream moves on to this block's next output tile
+      s_k = 0;
+      s_tl += G;
+      if (s_tl < total) setup(s_tl);
+    }
   };
 
+  const int nk = e.nk;
+  // the K-tile stream of this block: nk K-tiles per output tile, over all of its tiles
+  const int stream_total = PERS ? ((total - bid + G - 1) / G) * nk : nk;
+  int issued = 0;
+  for (int i = 0; i < R - 1 && issued < stream_total; ++i) { issue(); ++issued; }
+  int c_slot = 0;
+  bf16_t* __restrict__ yg = reinterpret_cast<bf16_t*>(p.y);
+  const bf16_t* __restrict__ mg = reinterpret_cast<const bf16_t*>(p.mask);
+  const bool want_stats = p.stats != nullptr;
+  const int chb = (lk & 1) * 16 + (lk >> 1) * 8;
+  float* red = reinterpret_cast<float*>(smem + RED);     // [WM_][BN channels][2]
+
+  for (int tl = bid; tl < total; tl += G) {
+  int m0, n0;
+  tile_of(tl, m0, n0);
   f32x4w acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4w{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = e.nk;
-  for (int i = 0; i < R - 1 && i < nk; ++i) issue();
-  int c_slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // tiles 0 .. min(nk, kt+R-1)-1 are issued; tile kt must have landed, the (up to) R-2 after it may still fly
-    if (R > 2 && kt + R - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PA + PB) * (R > 2 ? R - 2 : 0)) : "memory");
+    // K-tiles up to the (R-1)-th after this one are issued; this one must have landed, the (up to) R-2 after it may still
+    // fly.  PERS: the epilogue's stores sit in the same counter and complete out of order with the loads: always vmcnt(0).
+    if (!PERS && R > 2 && kt + R - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PA + PB) * (R > 2 ? R - 2 : 0)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + R - 1 < nk) issue();
+    if (issued < stream_total) { issue(); ++issued; }
     const unsigned ro = (unsigned)c_slot * KT;
     if (++c_slot == R) c_slot = 0;
     u32x4 fa[MI][2], fb[NI][2];
@@ -180,17 +218,15 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ni][kb]),
-                                                                __builtin_bit_cast(bf16x8, fa[mi][kb]), acc[mi][ni], 0, 0, 0);
+          if constexpr ((G4_DBG & 4) == 0)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ni][kb]),
+                                                                  __builtin_bit_cast(bf16x8, fa[mi][kb]), acc[mi][ni], 0, 0, 0);
+          else
+            asm volatile("" :: "v"(fb[ni][kb]), "v"(fa[mi][kb]));
   }
 
   // ---- epilogue (see conv_g8.hip): acc[mi][ni][j] = C[pixel m0 + wm*BM/2 + mi*16 + lrow][channel n0 + wn*BN/2 + ni*16 + 4*lk + j];
   // fragments ni = 2*nb, 2*nb+1 form a 32-channel block whose lanes pair up (v_permlane16_swap) into 16-byte stores
-  bf16_t* __restrict__ yg = reinterpret_cast<bf16_t*>(p.y);
-  const bf16_t* __restrict__ mg = reinterpret_cast<const bf16_t*>(p.mask);
-  const bool want_stats = p.stats != nullptr;
-  const int chb = (lk & 1) * 16 + (lk >> 1) * 8;
-  float* red = reinterpret_cast<float*>(smem + RED);     // [WM_][BN channels][2]
 #pragma unroll
   for (int nb = 0; nb < NI / 2; ++nb) {
     const int cb = n0 + wn * TN + nb * 32;
@@ -241,7 +277,8 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
           m = (z - m) >> 15;
           o = o & __builtin_bit_cast(u32x4, m);
         }
-        *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
+        if constexpr ((G4_DBG & 1) == 0) *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
+        else asm volatile("" :: "v"(o));
       }
     }
     if (want_stats) {
@@ -273,15 +310,17 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
       atomicAdd(st + n0 + t, (double)s);
       atomicAdd(st + p.Cout + n0 + t, (double)q);
     }
+    // (PERS) the next tile's K loop has a barrier between these reads of `red` and its epilogue's writes
   }
+  }  // tile loop
 }
 
 bool g4_raise_lds(const void* fp, size_t bytes) {
-  static thread_local const void* done[32];
-  for (int i = 0; i < 32; ++i)
+  static thread_local const void* done[64];
+  for (int i = 0; i < 64; ++i)
     if (done[i] == fp) return true;
   if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
-  for (int i = 0; i < 32; ++i)
+  for (int i = 0; i < 64; ++i)
     if (!done[i]) { done[i] = fp; break; }
   return true;
 }
@@ -332,21 +371,31 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (force_tile == 128 && p.Cout % 128 == 0 && !half) { bm = 128; bn = 128; }
   IgemmParams q = p;
   q.mtiles = (p.M + bm - 1) / bm; q.ntiles = p.Cout / bn;
-  const int grid = q.mtiles * q.ntiles;
-#define G4_LAUNCH(BM_, BN_, WM__, RELU_, TAPS_, HALF_)                                                     \
+  const int total = q.mtiles * q.ntiles;
+  // Persistent form (grid = resident slots) where a block would otherwise run several rounds of short tiles: NPP_G4_PERS = 0
+  // never, 1 (default) the 1x1 shapes on 128 x 128 tiles, 2 every 1x1 shape, 3 everything
+  static const int pers_mode = getenv("NPP_G4_PERS") ? atoi(getenv("NPP_G4_PERS")) : 1;
+  const int per_cu = bm == 128 ? 2 : (bn == 32 ? 6 : 4);
+  const int slots = per_cu * 256;
+  const bool pers = total > slots && (pers_mode >= 3 || (pers_mode == 2 && P == 0) || (pers_mode == 1 && P == 0 && bm == 128));
+  const int grid = pers ? slots : total;
+#define G4_LAUNCH(BM_, BN_, WM__, RELU_, TAPS_, HALF_, PERS_)                                              \
   do {                                                                                                     \
     constexpr size_t lds = G4_RING * (BM_ + BN_) * 128 + WM__ * BN_ * 2 * 4;                                \
-    if (!g4_raise_lds(reinterpret_cast<const void*>(conv_g4_kernel<BM_, BN_, WM__, RELU_, TAPS_, HALF_>), lds)) return false; \
-    hipLaunchKernelGGL((conv_g4_kernel<BM_, BN_, WM__, RELU_, TAPS_, HALF_>), dim3(grid), dim3(256), lds, stream, q, e); \
+    if (!g4_raise_lds(reinterpret_cast<const void*>(conv_g4_kernel<BM_, BN_, WM__, RELU_, TAPS_, HALF_, PERS_>), lds)) return false; \
+    hipLaunchKernelGGL((conv_g4_kernel<BM_, BN_, WM__, RELU_, TAPS_, HALF_, PERS_>), dim3(grid), dim3(256), lds, stream, q, e); \
+  } while (0)
+#define G4_PICK2(BM_, BN_, WM__, HALF_, PERS_)                                                             \
+  do {                                                                                                     \
+    if (P == 0) { if (p.relu_in) G4_LAUNCH(BM_, BN_, WM__, true, false, HALF_, PERS_); else G4_LAUNCH(BM_, BN_, WM__, false, false, HALF_, PERS_); } \
+    else        { if (p.relu_in) G4_LAUNCH(BM_, BN_, WM__, true, true, HALF_, PERS_);  else G4_LAUNCH(BM_, BN_, WM__, false, true, HALF_, PERS_); }  \
   } while (0)
 #define G4_PICK(BM_, BN_, WM__, HALF_)                                                                     \
-  do {                                                                                                     \
-    if (P == 0) { if (p.relu_in) G4_LAUNCH(BM_, BN_, WM__, true, false, HALF_); else G4_LAUNCH(BM_, BN_, WM__, false, false, HALF_); } \
-    else        { if (p.relu_in) G4_LAUNCH(BM_, BN_, WM__, true, true, HALF_);  else G4_LAUNCH(BM_, BN_, WM__, false, true, HALF_); }  \
-  } while (0)
+  do { if (pers) G4_PICK2(BM_, BN_, WM__, HALF_, true); else G4_PICK2(BM_, BN_, WM__, HALF_, false); } while (0)
   if (bm == 128) G4_PICK(128, 128, 2, false);
   else if (bn == 32) { if (half) G4_PICK(64, 32, 4, true); else G4_PICK(64, 32, 4, false); }
   else { if (half) G4_PICK(64, 64, 2, true); else G4_PICK(64, 64, 2, false); }
+#undef G4_PICK2
 #undef G4_PICK
 #undef G4_LAUNCH
   return true;

@@ -28,6 +28,7 @@ struct WG4Extra {
   int HW;
   int coltiles;          // taps * Cin / 128
   int ktiles_per_split, nktiles;
+  int ntiles, nblocks;   // output tiles (rowtiles * coltiles); blocks = ntiles * pixel splits
   unsigned xbytes, dybytes;
 };
 
@@ -47,7 +48,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Ex
   const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
   const auto rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, e.dybytes, 0x00020000);
 
-  const int tile = blockIdx.x, split = blockIdx.y;
+  // The tiles of one pixel split read the same dy rows (and, for a KxK conv, the same x rows shifted by a tap): they must
+  // share an L2.  Workgroups go to the 8 XCDs round-robin by linear id, so block b -> XCD b & 7 takes the (b >> 3)-th item of
+  // that XCD's CONTIGUOUS range of the (split-major, tile-minor) work list: the 9 taps of a split run side by side on one
+  // XCD.  (Before: grid (tiles, splits), neighbours in x on 8 different XCDs -- rocprofv3 FETCH_SIZE showed 3.5x the
+  // algorithmic bytes per launch on 128->128 3x3 @96^2, every XCD fetching every operand row.)
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qd = e.nblocks >> 3, rm = e.nblocks & 7;
+  const int work = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  const int split = work / e.ntiles, tile = work - split * e.ntiles;
   const int cotile = tile % p.rowtiles, coltile = tile / p.rowtiles;
   const int co0 = cotile * 128;
   // A column tile is 128 consecutive columns of the flattened (tap, ci) axis: one tap's 128 channels when Cin % 128 == 0, two taps
@@ -251,8 +260,8 @@ bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   if (splits > e.nktiles) splits = e.nktiles;
   e.ktiles_per_split = (e.nktiles + splits - 1) / splits;
   splits = (e.nktiles + e.ktiles_per_split - 1) / e.ktiles_per_split;
-  if (splits > 65535) return false;
-  dim3 grid(tiles, splits);
+  e.ntiles = tiles; e.nblocks = tiles * splits;
+  dim3 grid(tiles * splits);
   static const int force_ring = getenv("NPP_WG4_RING") ? atoi(getenv("NPP_WG4_RING")) : 0;
   const bool deep = force_ring ? force_ring == 4 : (tiles * splits <= 256);
 #define WG4_LAUNCH(RELU_, TAPS_, R_)                                                                        \

@@ -61,6 +61,8 @@ CONV_CASES = [
     (256, 128, 1, 1, 0, 1, 160, 160, 2, False, False, 0),  # g4 on a large map, dgrad N=256
     (64, 128, 3, 1, 1, 1, 225, 225, 1, True, False, 0),    # 3x3 on a large map, ragged M (g8 when NPP_G8_MAXK=3: see below)
     (128, 128, 3, 1, 1, 1, 160, 160, 2, False, True, 0),   # 3x3 + bias, two channel chunks; dgrad without mask
+    (128, 256, 1, 1, 0, 1, 200, 201, 2, True, True, 0),    # g4 persistent form: 1258 tiles of 128x128 over 512 slots, ragged M,
+                                                           # bias + statistics; dgrad (629 tiles) with the ReLU mask
 ]
 
 
