@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__
                                                            int N, int H, int W, int OH, int OW, int cv, float sh, float sw) {
   const long total = (long)N * OH * OW * cv;
   const FastDiv fd((unsigned)cv);
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+  for (unsigned i = xcd_block() * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned p, pr_;
     fast_divmod(i, fd, p, pr_);
     const int c0 = (int)pr_ * V;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
                                                            int N, int H, int W, int OH, int OW, int cv, float sh, float sw) {
   const long total = (long)N * H * W * cv;
   const FastDiv fd((unsigned)cv);
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+  for (unsigned i = xcd_block() * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned p, pr_;
     fast_divmod(i, fd, p, pr_);
     const int c0 = (int)pr_ * V;

@@ -68,6 +68,16 @@ template <> struct Vec16<bf16_t> {
   }
 };
 
+// Workgroups go to the 8 XCDs (8 separate L2s) round-robin by blockIdx.x.  A kernel whose neighbouring blocks read
+// overlapping rows (3x3 windows, bilinear taps, dilated depthwise taps) wants neighbours on ONE XCD, or every XCD fetches
+// the shared rows from HBM for itself: virtual block id = the (blockIdx.x >> 3)-th block of XCD (blockIdx.x & 7)'s contiguous
+// share of the grid.  A bijection on [0, gridDim.x) for any grid size.
+NPP_DEV unsigned xcd_block() {
+  const unsigned g = gridDim.x, b = blockIdx.x;
+  const unsigned q = g >> 3, r = g & 7, x = b & 7, j = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
 NPP_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -57,10 +57,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int rowtile = blockIdx.x % p.rowtiles, coltile = blockIdx.x / p.rowtiles;
+  // 1-D grid in XCD-contiguous (split-major, tile-minor) order: the tiles of one pixel split read the same dy / x rows and
+  // must share an L2 (see conv_wgrad_g4.hip)
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qd = p.nblocks >> 3, rm = p.nblocks & 7;
+  const int work = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  const int split = work / p.ntiles, tile = work - split * p.ntiles;
+  const int rowtile = tile % p.rowtiles, coltile = tile / p.rowtiles;
   const int co0 = rowtile * TM;
   const int colbase = coltile * 128 + wave * 32;
-  const int ch_begin = blockIdx.y * p.chunks_per_split;
+  const int ch_begin = split * p.chunks_per_split;
   int ch_end = ch_begin + p.chunks_per_split;
   if (ch_end > p.nchunks) ch_end = p.nchunks;
   if (ch_begin >= ch_end) return;
@@ -261,7 +267,8 @@ extern "C" int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw
   ProfScope prof(NPP_FAM_CONV_WGRAD, x->dtype, s, flops, bytes);
   if (conv_wgrad_g4_launch(p, x->dtype, s)) return npp_check_launch("conv_wgrad_g4");
   if (conv_wgrad_tap_launch(p, x->dtype, s)) return npp_check_launch("conv_wgrad_tap");
-  dim3 grid(tiles, splits);
+  p.ntiles = tiles; p.nblocks = tiles * splits;
+  dim3 grid(tiles * splits);
 #define LAUNCH(T, TM_) hipLaunchKernelGGL((conv_wgrad_kernel<T, TM_>), grid, dim3(256), 0, s, p)
   if (x->dtype == NPP_BF16) {
     if (tm == 128) LAUNCH(bf16_t, 128); else if (tm == 64) LAUNCH(bf16_t, 64); else LAUNCH(bf16_t, 32);

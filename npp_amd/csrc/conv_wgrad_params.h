@@ -10,6 +10,7 @@ struct WgradParams {
   int chunks_per_split, nchunks;
   int rowtiles;
   int vec_dy;
+  int ntiles, nblocks;   // conv_wgrad_kernel: output tiles, and blocks = tiles x pixel splits (1-D grid, XCD-contiguous order)
 };
 // tap-stationary 3x3 stride-1 kernel (conv_wgrad_s1.hip); false when the shape is not eligible
 bool conv_wgrad_tap_launch(const WgradParams& p, int dtype, hipStream_t stream);

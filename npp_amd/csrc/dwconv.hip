@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
   stage_weights(w, swt, p.C, taps);
   const long total = (long)p.N * p.OH * p.OW * p.cv;
   const FastDiv fd((unsigned)p.cv);
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+  for (unsigned i = xcd_block() * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned pix, pr_;
     fast_divmod(i, fd, pix, pr_);
     const int c0 = (int)pr_ * V;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T* __restric
   stage_weights(w, swt, p.C, taps);
   const long total = (long)p.N * p.H * p.W * p.cv;
   const FastDiv fd((unsigned)p.cv);
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+  for (unsigned i = xcd_block() * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned pix, pr_;
     fast_divmod(i, fd, pix, pr_);
     const int c0 = (int)pr_ * V;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void dw3_run_fwd_kernel(const T* __restrict__ 
   }
   __syncthreads();
   const unsigned total = (unsigned)g.N * g.OH * g.delta * g.nseg * g.cv;
-  for (unsigned gi = blockIdx.x * 256 + threadIdx.x; gi < total; gi += gridDim.x * 256) {
+  for (unsigned gi = xcd_block() * 256 + threadIdx.x; gi < total; gi += gridDim.x * 256) {
     const RunIdx r = run_decode(gi, g);
     const int c0 = r.cg * V;
     float wr[9][V];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void dw3_run_wgrad_kernel(const T* __restrict_
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[t][j] = 0.f;
   const unsigned total = (unsigned)g.N * g.OH * g.delta * g.nseg * g.cv;
-  for (unsigned gi = blockIdx.x * 256 + threadIdx.x; gi < total; gi += gridDim.x * 256) {
+  for (unsigned gi = xcd_block() * 256 + threadIdx.x; gi < total; gi += gridDim.x * 256) {
     const RunIdx r = run_decode(gi, g);
     const int c0 = r.cg * V;
     const T* rows[3];
