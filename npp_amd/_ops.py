@@ -732,7 +732,9 @@ class _BnAdd(Function):
     """out = relu?( [BN_a](a) + [BN_b](b) ).  Tensor args: a, gamma_a, beta_a, b, gamma_b, beta_b."""
 
     @staticmethod
-    def forward(ctx, a, ga, ba, b, gb, bb, sa: BnSide, sb: Optional[BnSide], relu: bool, training: bool):
+    def forward(ctx, a, ga, ba, b, gb, bb, sa: BnSide, sb: Optional[BnSide], relu: bool, training: bool, out=None):
+        # out: None, or a 1-element list holding the tensor to write (a channel slice of a cell's output buffer, see
+        # ConcatBuffer); wrapped so that autograd does not see an in-place write into a view
         dev = a.device
         ssa = mia = ssb = mib = None
         batch_a = batch_b = False
@@ -744,7 +746,7 @@ class _BnAdd(Function):
                 ssa, mia, batch_a = _bn_coeffs(sa, training, dev)
             if sb is not None and sb.bn is not None:
                 ssb, mib, batch_b = _bn_coeffs(sb, training, dev)
-        y = new_nhwc(*a.shape, a.dtype, dev)
+        y = out[0] if out is not None else new_nhwc(*a.shape, a.dtype, dev)
         check(lib().npp_affine_add(_byref(y), _byref(a), ptr(ssa), tref(b), ptr(ssb), int(relu), stream_ptr()),
               "npp_affine_add")
         ctx.relu = relu
@@ -803,7 +805,7 @@ class _BnAdd(Function):
             check(lib().npp_bn_bwd_apply2(_byref(dout), _byref(a), _byref(b), tref(yrelu), co[:3 * c].data_ptr(),
                                           co[3 * c:].data_ptr(), _byref(dxa), _byref(dxb), s), "npp_bn_bwd_apply2")
             return (dxa, dgb_[:c] if ni[1] else None, dgb_[c:2 * c] if ni[2] else None,
-                    dxb, dgb_[2 * c:3 * c] if ni[4] else None, dgb_[3 * c:] if ni[5] else None, None, None, None, None)
+                    dxb, dgb_[2 * c:3 * c] if ni[4] else None, dgb_[3 * c:] if ni[5] else None, None, None, None, None, None)
         sides = [(a, bna, mia, ssa, batch_a, cnt_a, ni[0], ni[1], ni[2])]
         if has_b:
             sides.append((b, bnb, mib, ssb, batch_b, cnt_b, ni[3], ni[4], ni[5]))
@@ -871,11 +873,12 @@ class _BnAdd(Function):
         dbx = dgb = dbb = None
         if has_b:
             dbx, dgb, dbb = outs[1]
-        return da, dga, dba, dbx, dgb, dbb, None, None, None, None
+        return da, dga, dba, dbx, dgb, dbb, None, None, None, None, None
 
 
-def bn_add(sa: BnSide, sb: Optional[BnSide] = None, relu: bool = False, training: bool = True):
-    """Fused BN-apply (+ second operand, BN'd or plain) (+ ReLU)."""
+def bn_add(sa: BnSide, sb: Optional[BnSide] = None, relu: bool = False, training: bool = True, out=None):
+    """Fused BN-apply (+ second operand, BN'd or plain) (+ ReLU).  out: a ConcatBuffer slot (callable shape -> tensor or
+    None) to write the result into instead of a fresh tensor."""
     a = to_nhwc(sa.x if sa.private else take(sa.x))
     sa.x = a
     ga = sa.bn.weight if sa.bn is not None else None
@@ -889,7 +892,12 @@ def bn_add(sa: BnSide, sb: Optional[BnSide] = None, relu: bool = False, training
             sb.x = b
         if sb.bn is not None:
             gb, bb = sb.bn.weight, sb.bn.bias
-    return _BnAdd.apply(a, ga, ba, b, gb, bb, sa, sb, bool(relu), bool(training))
+    holder = None
+    if out is not None:
+        y = out(a)
+        if y is not None:
+            holder = [y]
+    return _BnAdd.apply(a, ga, ba, b, gb, bb, sa, sb, bool(relu), bool(training), holder)
 
 
 def add(a, b):
@@ -1124,6 +1132,83 @@ class _Concat(Function):
 
 def concat(xs: Sequence[torch.Tensor]):
     return _Concat.apply(*[take(x) for x in xs])
+
+
+def _alias(base: torch.Tensor, c0: int, c: int) -> torch.Tensor:
+    """Channels [c0, c0 + c) of the NHWC buffer `base` as a tensor of its own (same storage, no view relation: autograd
+    must not see the producers' writes as in-place updates of a view of the buffer)."""
+    n, _, h, w = base.shape
+    sn, sc, sh, sw = base.stride()
+    t = torch.empty(0, dtype=base.dtype, device=base.device)
+    return t.set_(base.untyped_storage(), base.storage_offset() + c0, (n, c, h, w), (sn, sc, sh, sw))
+
+
+class _ConcatAlias(Function):
+    """The cell output whose parts already sit in their channel slices: no data moves forward, backward hands every part
+    its slice of the gradient (views)."""
+
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        buf = holder[0]
+        ctx.splits = [x.shape[1] for x in parts]
+        return _alias(buf, 0, buf.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = to_nhwc(dy)
+        outs, off = [None], 0
+        for c in ctx.splits:
+            outs.append(dy[:, off:off + c])
+            off += c
+        return tuple(outs)
+
+
+class ConcatBuffer:
+    """torch.cat(states, dim=1) of a cell (model_augment.py:62, 106, 172, 229) without the copy: the buffer of the
+    concatenated output is allocated when the first part is about to be produced, every part is WRITTEN into its channel
+    slice by the kernel that produces it (bn_add's out=), and result() ties the buffer to the parts for autograd.  58
+    concat launches and 5.8 GB of HBM traffic per training step (batch 16, 384 x 384) were exactly this copy.
+    NPP_CONCAT_INPLACE=0 restores npp_concat."""
+
+    ENABLED = os.environ.get("NPP_CONCAT_INPLACE", "1") != "0"
+
+    def __init__(self, nparts: int):
+        self.nparts = nparts
+        self.buf = None
+        self.parts: List[Optional[torch.Tensor]] = [None] * nparts
+        self.c = None
+
+    def slot(self, k: int):
+        """out= argument for the producer of part k."""
+        def make(like: torch.Tensor):
+            if not ConcatBuffer.ENABLED or like.dim() != 4:
+                return None
+            n, c, h, w = like.shape
+            if self.buf is None:
+                if c % 8 != 0:
+                    return None
+                self.c = c
+                self.buf = new_nhwc(n, c * self.nparts, h, w, like.dtype, like.device)
+            b = self.buf
+            if (c != self.c or b.shape[0] != n or b.shape[2] != h or b.shape[3] != w or b.dtype != like.dtype
+                    or b.device != like.device):
+                return None
+            return _alias(b, k * c, c)
+        return make
+
+    def result(self, parts: Sequence[torch.Tensor]) -> torch.Tensor:
+        """The concatenation of `parts` (the tensors the producers returned, in order)."""
+        ok = self.buf is not None and len(parts) == self.nparts
+        if ok:
+            base = self.buf.data_ptr()
+            esz = self.buf.element_size()
+            for k, t in enumerate(parts):
+                if t.data_ptr() != base + k * self.c * esz or t.shape[1] != self.c:
+                    ok = False
+                    break
+        if not ok:
+            return concat(parts)
+        return _ConcatAlias.apply([self.buf], *[take(t) for t in parts])
 
 
 class _ImageToNhwc(Function):

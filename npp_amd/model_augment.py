@@ -114,11 +114,22 @@ class _DagCell(nn.Module):
             self._ops += [op]
         self._indices = indices
 
-    def _run(self, states):
+    def _run(self, states, concat=None):
+        """Runs the nodes; with `concat` (state indices, all of them node outputs) also returns their concatenation, whose
+        parts the nodes write in place (K.ConcatBuffer)."""
+        first = len(states)
+        cb = None
+        if concat is not None and all(i >= first for i in concat) and len(set(concat)) == len(concat):
+            cb = K.ConcatBuffer(len(concat))
+            pos = {idx: k for k, idx in enumerate(concat)}
         for i in range(self._steps):
             i1, i2 = self._indices[2 * i], self._indices[2 * i + 1]
-            states.append(fused_sum(self._ops[2 * i], states[i1], self._ops[2 * i + 1], states[i2]))
-        return states
+            out = cb.slot(pos[len(states)]) if cb is not None and len(states) in pos else None
+            states.append(fused_sum(self._ops[2 * i], states[i1], self._ops[2 * i + 1], states[i2], out=out))
+        if concat is None:
+            return states
+        parts = [states[i] for i in concat]
+        return states, (cb.result(parts) if cb is not None else K.concat(parts))
 
 
 class Cell(_DagCell):
@@ -136,8 +147,8 @@ class Cell(_DagCell):
         self._build(C, edges, concat, lambda idx: 2 if reduction and idx < 2 else 1, lambda idx: None)
 
     def forward(self, s0, s1):
-        st = self._run([self.preprocess0(s0), self.preprocess1(s1)])
-        return K.concat([st[i] for i in self._concat])
+        _, out = self._run([self.preprocess0(s0), self.preprocess1(s1)], self._concat)
+        return out
 
 
 class Upsample(_DagCell):
@@ -150,8 +161,8 @@ class Upsample(_DagCell):
         self._build(C_prev // 4, upsample, upsample_concat, lambda idx: 1, lambda idx: 2 if idx == 0 else None)
 
     def forward(self, s0, s1):
-        st = self._run([self.preprocess0(s0), self.preprocess1(s1)])
-        return K.concat([st[i] for i in self._concat])
+        _, out = self._run([self.preprocess0(s0), self.preprocess1(s1)], self._concat)
+        return out
 
 
 class _FuseCell(_DagCell):
@@ -186,12 +197,11 @@ class _FuseCell(_DagCell):
             outs[foreign].record_stream(cur)
         else:
             outs = [pre[i](ins[i]) for i in range(3)]
-        st = self._run(outs)
         if self.order == 0:
             # F.interpolate(scale_factor=4/2) with the default (nearest) mode, model_augment.py:167-169
             raise NotImplementedError("order == 0 fuse cells are never built by Network (model_augment.py:357-363)")
+        st, fea2 = self._run(outs, self._concat)
         fea1 = K.concat(st[0:3])
-        fea2 = K.concat([st[i] for i in self._concat])
         return fea1, fea2
 
 

@@ -51,8 +51,8 @@ def _is_trivial(op) -> bool:
     return isinstance(op, (Identity, Zero))
 
 
-def fused_sum(op1, h1, op2, h2):
-    """`op1(h1) + op2(h2)` (model_augment.py:54-59) with both BN-applies folded into the add."""
+def fused_sum(op1, h1, op2, h2, out=None):
+    """`op1(h1) + op2(h2)` (model_augment.py:54-59) with both BN-applies folded into the add.  out: ConcatBuffer slot."""
     helper = K.helper_stream_for_edge() if not (_is_trivial(op1) or _is_trivial(op2)) else None
     if helper is None:
         a, b = pending_of(op1, h1), pending_of(op2, h2)
@@ -71,7 +71,7 @@ def fused_sum(op1, h1, op2, h2):
     if a.bn is None and b.bn is not None:
         a, b = b, a
     training = a.bn.training if a.bn is not None else False
-    return K.bn_add(a, b, relu=False, training=training)
+    return K.bn_add(a, b, relu=False, training=training, out=out)
 
 
 class Zero(nn.Module):

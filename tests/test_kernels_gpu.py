@@ -387,3 +387,42 @@ def test_packed_weights_follow_silent_parameter_updates():
     assert w._version == v
     y1 = m(x).detach()
     assert float((y1 - y0).abs().max()) > 1e-3        # the forward saw the new weights
+
+
+def test_concat_buffer_parts_written_in_place():
+    """K.ConcatBuffer (torch.cat of a cell's node outputs, model_augment.py:62): the producers write their channel slices,
+    no copy launch; values and gradients equal torch.cat over separately produced parts, also when a part is consumed again."""
+    import torch.nn as nn
+    from npp_amd import _ops as K
+    dev = _dev()
+    torch.manual_seed(0)
+    n, c, h, w = 2, 16, 9, 7
+    bns = [nn.BatchNorm2d(c).to(dev).train() for _ in range(3)]
+    for bn in bns:
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_(0, 0.1)
+    xs = [torch.randn(n, c, h, w, device=dev).contiguous(memory_format=torch.channels_last) for _ in range(4)]
+
+    def run(inplace):
+        K.fan_reset()
+        ins = [x.clone().requires_grad_(True) for x in xs]
+        cb = K.ConcatBuffer(3) if inplace else None
+        parts = []
+        for k in range(3):
+            sa = K.BnSide(ins[k] * 1.0, bns[k], None)             # batch statistics computed on demand
+            sb = K.BnSide(ins[3] if k != 1 else parts[0])         # plain side; part 0 is consumed again by part 1
+            parts.append(K.bn_add(sa, sb, relu=(k == 2), training=True, out=cb.slot(k) if cb else None))
+        y = cb.result(parts) if cb else K.concat(parts)
+        for bn in bns:
+            bn.zero_grad()
+        (y.float() * torch.arange(y.numel(), device=dev).view_as(y).float().cos()).sum().backward()
+        return y.detach().clone(), [t.grad.clone() for t in ins], [bn.weight.grad.clone() for bn in bns], parts
+
+    y0, g0, w0, _ = run(False)
+    y1, g1, w1, parts = run(True)
+    assert parts[1].data_ptr() == parts[0].data_ptr() + c * parts[0].element_size()      # really in place
+    assert torch.equal(y0, y1)
+    for a, b in zip(g0 + w0, g1 + w1):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    ref = torch.cat([p.detach() for p in parts], 1)
+    assert torch.equal(ref, y1)
