@@ -1171,6 +1171,8 @@ class ConcatBuffer:
     NPP_CONCAT_INPLACE=0 restores npp_concat."""
 
     ENABLED = os.environ.get("NPP_CONCAT_INPLACE", "1") != "0"
+    MINC = int(os.environ.get("NPP_CONCAT_MINC", "0"))          # bisection aids: part widths that take the in-place path
+    MAXC = int(os.environ.get("NPP_CONCAT_MAXC", "1000000"))
 
     def __init__(self, nparts: int):
         self.nparts = nparts
@@ -1185,7 +1187,7 @@ class ConcatBuffer:
                 return None
             n, c, h, w = like.shape
             if self.buf is None:
-                if c % 8 != 0:
+                if c % 8 != 0 or not (ConcatBuffer.MINC <= c <= ConcatBuffer.MAXC):
                     return None
                 self.c = c
                 self.buf = new_nhwc(n, c * self.nparts, h, w, like.dtype, like.device)

@@ -3,6 +3,8 @@
 #include <mutex>
 #include <vector>
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -14,6 +16,17 @@ void npp_set_error(const char* fmt, ...) {
 }
 
 int npp_check_launch(const char* what) {
+  // debugging aids: NPP_TRACE_LAUNCH=1 names every launch on stderr, NPP_SYNC_LAUNCH=1 waits for it (a fault then points at
+  // its kernel).  Never set inside a hipGraph capture.
+  static const bool trace = getenv("NPP_TRACE_LAUNCH") != nullptr, sync = getenv("NPP_SYNC_LAUNCH") != nullptr;
+  if (trace) { fprintf(stderr, "[npp] %s\n", what); fflush(stderr); }
+  if (sync) {
+    hipError_t se = hipDeviceSynchronize();
+    if (se != hipSuccess) {
+      npp_set_error("%s: failed at synchronisation: %s", what, hipGetErrorString(se));
+      return NPP_E_HIP;
+    }
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     npp_set_error("%s: launch failed: %s", what, hipGetErrorString(e));

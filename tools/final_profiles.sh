@@ -19,9 +19,11 @@ run() {  # name, extra env assignment string, bench args...
 run bs16_bf16_graph --steps 10 --warmup 3 --no-cpu-baseline
 export NPP_STREAMS=1
 run bs16_bf16_eager_1stream --steps 5 --warmup 2 --no-cpu-baseline --graph 0
+# (NPP_SYNC_LAUNCH: see tools/pmc_step.sh)
+export NPP_SYNC_LAUNCH=1
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/fp_pmc_$c
-  rocprofv3 --pmc $c --output-format csv -d /tmp/fp_pmc_$c -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --graph 0 > /dev/null 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d /tmp/fp_pmc_$c -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --graph 0 > /dev/null 2>&1
 done
 ff=$(find /tmp/fp_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 fw=$(find /tmp/fp_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
