@@ -185,6 +185,7 @@ class _FuseCell(_DagCell):
         op that consumes it runs on the hub stream, so that the two branch streams never wait on each other directly."""
         pre = [self.preprocess0, self.preprocess1, self.preprocess2]
         ins = [s0, s1, s2]
+        cb1 = None
         if hub is not None and foreign is not None:
             outs = [None, None, None]
             cur = torch.cuda.current_stream()
@@ -196,12 +197,14 @@ class _FuseCell(_DagCell):
             cur.wait_stream(hub)
             outs[foreign].record_stream(cur)
         else:
-            outs = [pre[i](ins[i]) for i in range(3)]
+            # the three preprocessed inputs are returned concatenated (fea1): they are written into that buffer directly
+            cb1 = K.ConcatBuffer(3) if all(isinstance(m, ReLUConvBN) for m in pre) else None
+            outs = [pre[i](ins[i], out=cb1.slot(i)) if cb1 is not None else pre[i](ins[i]) for i in range(3)]
         if self.order == 0:
             # F.interpolate(scale_factor=4/2) with the default (nearest) mode, model_augment.py:167-169
             raise NotImplementedError("order == 0 fuse cells are never built by Network (model_augment.py:357-363)")
         st, fea2 = self._run(outs, self._concat)
-        fea1 = K.concat(st[0:3])
+        fea1 = cb1.result(st[0:3]) if cb1 is not None else K.concat(st[0:3])
         return fea1, fea2
 
 

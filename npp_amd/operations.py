@@ -35,9 +35,10 @@ class _BnOp(nn.Module):
     def pending(self, x) -> BnSide:
         raise NotImplementedError
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out: K.ConcatBuffer slot -- the normalised output is written into its channel slice of a concatenation."""
         side = self.pending(x)
-        return K.bn_add(side, None, relu=False, training=side.bn.training)
+        return K.bn_add(side, None, relu=False, training=side.bn.training, out=out)
 
 
 def pending_of(op, x) -> BnSide:
