@@ -7,6 +7,12 @@
 // and nn.UpsamplingBilinear2d at operations.py:242-244 (ATen upsample_bilinear2d fwd/bwd).
 #include "vecio.h"
 
+#ifdef NPP_BIL_NO_XCD
+#define VBLOCK blockIdx.x
+#else
+#define VBLOCK xcd_block()
+#endif
+
 namespace {
 
 NPP_DEV void src_index(float scale, int o, int in_size, int& i0, int& i1p, float& l0, float& l1) {
@@ -23,7 +29,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__
                                                            int N, int H, int W, int OH, int OW, int cv, float sh, float sw) {
   const long total = (long)N * OH * OW * cv;
   const FastDiv fd((unsigned)cv);
-  for (unsigned i = xcd_block() * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+  for (unsigned i = VBLOCK * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned p, pr_;
     fast_divmod(i, fd, p, pr_);
     const int c0 = (int)pr_ * V;
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
                                                            int N, int H, int W, int OH, int OW, int cv, float sh, float sw) {
   const long total = (long)N * H * W * cv;
   const FastDiv fd((unsigned)cv);
-  for (unsigned i = xcd_block() * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+  for (unsigned i = VBLOCK * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned p, pr_;
     fast_divmod(i, fd, p, pr_);
     const int c0 = (int)pr_ * V;

@@ -7,6 +7,12 @@
 // the BatchNorm that follows, operations.py:61,129) so no extra pass over the tensor is needed.
 #include "vecio.h"
 
+#ifdef NPP_POOL_NO_XCD
+#define VBLOCK blockIdx.x
+#else
+#define VBLOCK xcd_block()
+#endif
+
 namespace {
 
 template <typename T, int V>
@@ -15,7 +21,7 @@ __global__ __launch_bounds__(256) void pool3x3_fwd_kernel(const T* __restrict__ 
                                                           int OW, int C, int cv, int is_avg, int stride) {
   const long total = (long)N * OH * OW * cv;
   const FastDiv fd((unsigned)cv);
-  for (unsigned i = xcd_block() * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+  for (unsigned i = VBLOCK * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned p, pr_;
     fast_divmod(i, fd, p, pr_);
     const int c0 = (int)pr_ * V;
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256) void pool3x3_bwd_kernel(const T* __restrict__ 
   // gather form: every input pixel sums the windows that contain it (no atomics)
   const long total = (long)N * H * W * cv;
   const FastDiv fd((unsigned)cv);
-  for (unsigned i = xcd_block() * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+  for (unsigned i = VBLOCK * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned p, pr_;
     fast_divmod(i, fd, p, pr_);
     const int c0 = (int)pr_ * V;
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void pool2x2_fwd_kernel(const T* __restrict__ 
                                                           int N, int H, int W, int OH, int OW, int cv, int is_avg) {
   const long total = (long)N * OH * OW * cv;
   const FastDiv fd((unsigned)cv);
-  for (unsigned i = xcd_block() * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+  for (unsigned i = VBLOCK * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned p, pr_;
     fast_divmod(i, fd, p, pr_);
     const int c0 = (int)pr_ * V;
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256) void pool2x2_bwd_kernel(const T* __restrict__ 
   // beyond 2*OH / 2*OW (odd extents) are zeroed by the caller.
   const long total = (long)N * OH * OW * cv;
   const FastDiv fd((unsigned)cv);
-  for (unsigned i = xcd_block() * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+  for (unsigned i = VBLOCK * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned p, pr_;
     fast_divmod(i, fd, p, pr_);
     const int c0 = (int)pr_ * V;
