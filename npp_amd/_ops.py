@@ -144,6 +144,8 @@ class _PerStream:
         return list(self.pools.values())
 
 
+GRAPH_TOPOLOGY = False  # set by train_step.TrainStep while its steps are (to be) replayed as a hipGraph: Network.forward then
+                        # picks the stream topology that pays off under replay (SyncBN: hub streams + lockstep issue)
 _hub_stream = None     # the stream Network.forward was called on while it runs its branches on two streams
 
 

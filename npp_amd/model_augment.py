@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import _ops as K
 from . import genotypes as gt
 from ._ops import BnSide
-from .operations import OPS, FactorizedReduce, ReLUConvBN, fused_sum, _use_batch_stats  # noqa: F401
+from .operations import OPS, FactorizedReduce, ReLUConvBN, fused_sum, fused_sum_stages, _use_batch_stats  # noqa: F401
 from .operations import *  # noqa: F401,F403  (reference does `from models.operations import *`)
 
 BN_MOMENTUM = 0.1
@@ -150,6 +150,31 @@ class Cell(_DagCell):
         _, out = self._run([self.preprocess0(s0), self.preprocess1(s1)], self._concat)
         return out
 
+    def stages(self, s0, s1, result):
+        """forward() as a generator that pauses after every stage (each preprocess, each node): Network.forward steps the
+        two branches' cells alternately, so that the host issues -- and, under SyncBatchNorm, the one communicator orders --
+        their work interleaved at node granularity instead of cell by cell.  result: 1-element list for the output."""
+        states = [self.preprocess0(s0)]
+        yield
+        states.append(self.preprocess1(s1))
+        yield
+        concat = self._concat
+        first = len(states)
+        cb = pos = None
+        if all(i >= first for i in concat) and len(set(concat)) == len(concat):
+            cb = K.ConcatBuffer(len(concat))
+            pos = {idx: k for k, idx in enumerate(concat)}
+        for i in range(self._steps):
+            i1, i2 = self._indices[2 * i], self._indices[2 * i + 1]
+            out = cb.slot(pos[len(states)]) if cb is not None and len(states) in pos else None
+            node = [None]
+            yield from fused_sum_stages(self._ops[2 * i], states[i1], self._ops[2 * i + 1], states[i2], node, out=out)
+            states.append(node[0])
+            if i + 1 < self._steps:
+                yield
+        parts = [states[i] for i in concat]
+        result[0] = cb.result(parts) if cb is not None else K.concat(parts)
+
 
 class Upsample(_DagCell):
     """Decoder cell, model_augment.py:64-106: ops fed from input 0 are followed by a x2 bilinear."""
@@ -207,6 +232,46 @@ class _FuseCell(_DagCell):
         fea1 = cb1.result(st[0:3]) if cb1 is not None else K.concat(st[0:3])
         return fea1, fea2
 
+    def stages(self, s0, s1, s2, foreign, hub, result):
+        """forward() as a generator pausing after every preprocess and every edge (see Cell.stages); result[0] = (fea1, fea2)."""
+        if self.order == 0:
+            raise NotImplementedError("order == 0 fuse cells are never built by Network (model_augment.py:357-363)")
+        pre = [self.preprocess0, self.preprocess1, self.preprocess2]
+        ins = [s0, s1, s2]
+        cb1 = K.ConcatBuffer(3) if all(isinstance(m, ReLUConvBN) for m in pre) else None
+        outs = [None, None, None]
+        order = [i for i in range(3) if i != foreign] + ([foreign] if foreign is not None else [])
+        for i in order:
+            slot = cb1.slot(i) if cb1 is not None else None
+            if hub is not None and i == foreign:
+                cur = torch.cuda.current_stream()
+                with torch.cuda.stream(hub):
+                    outs[i] = pre[i](ins[i], out=slot) if slot is not None else pre[i](ins[i])
+                cur.wait_stream(hub)
+                outs[i].record_stream(cur)
+            else:
+                outs[i] = pre[i](ins[i], out=slot) if slot is not None else pre[i](ins[i])
+            yield
+        states = list(outs)
+        concat = self._concat
+        first = len(states)
+        cb = pos = None
+        if all(i >= first for i in concat) and len(set(concat)) == len(concat):
+            cb = K.ConcatBuffer(len(concat))
+            pos = {idx: k for k, idx in enumerate(concat)}
+        for i in range(self._steps):
+            i1, i2 = self._indices[2 * i], self._indices[2 * i + 1]
+            out = cb.slot(pos[len(states)]) if cb is not None and len(states) in pos else None
+            node = [None]
+            yield from fused_sum_stages(self._ops[2 * i], states[i1], self._ops[2 * i + 1], states[i2], node, out=out)
+            states.append(node[0])
+            if i + 1 < self._steps:
+                yield
+        parts = [states[i] for i in concat]
+        fea2 = cb.result(parts) if cb is not None else K.concat(parts)
+        fea1 = cb1.result(states[0:3]) if cb1 is not None else K.concat(states[0:3])
+        result[0] = (fea1, fea2)
+
 
 class PoseCell1(_FuseCell):
     """model_augment.py:119-172"""
@@ -234,6 +299,37 @@ def _side_stream(device, which=0):
         if which == 0:
             K._branch_b_streams.add(st.cuda_stream)
     return st
+
+
+_DONE = object()
+
+
+def _alternate(g1, ctx1, g2, ctx2):
+    """Step two stage generators alternately, each under its own stream context, until both are exhausted."""
+    live1 = live2 = True
+    while live1 or live2:
+        if live1:
+            with ctx1():
+                live1 = next(g1, _DONE) is not _DONE
+        if live2:
+            with ctx2():
+                live2 = next(g2, _DONE) is not _DONE
+
+
+def _lockstep(mode: int, sync_bn: bool) -> bool:
+    """Step the two encoders' cells alternately, stage by stage (Cell.stages)?  NPP_LOCKSTEP=1 / 0 forces it; default: only
+    when the branches run on their own streams AND SyncBatchNorm funnels their exchanges through one stream."""
+    v = os.environ.get("NPP_LOCKSTEP")
+    if v is not None:
+        return v != "0"
+    return mode == 3 and sync_bn
+
+
+def _syncbn_stream_mode() -> int:
+    v = os.environ.get("NPP_SYNCBN_STREAMS")
+    if v in ("1", "3"):
+        return int(v)
+    return 3 if K.GRAPH_TOPOLOGY else 1
 
 
 def _stream_mode() -> int:
@@ -399,9 +495,16 @@ class Network(nn.Module):
         # its forward.
         # SyncBatchNorm across ranks: every collective must sit on one stream (the hipGraph capture's origin; RCCL's own
         # launch ordering adds two-way edges between the user stream and its internal stream, which this ROCm only
-        # survives on the origin), and funnelling the side branch's ~430 exchanges through it serialises the branches
-        # (measured: 103 ms vs 83 ms).  So multi-rank SyncBN runs single-stream.
-        mode = _stream_mode() if not self._sync_bn_active() else (3 if os.environ.get("NPP_SYNCBN_STREAMS") == "3" else 1)
+        # survives on the origin).  One communicator orders its collectives totally, in host issue order: issued cell by
+        # cell, a branch's exchanges wait for the whole previous cell of the other branch and the two branches run one
+        # after the other (hub topology 219 img/s = single stream 217, 1-rank exercise).  So under SyncBN the branches get
+        # their own streams (hub topology, 3) AND are issued in lockstep, edge by edge (Cell.stages / _alternate): the
+        # exchanges alternate A, B, A, B and each one's latency hides behind the other branch's kernels -- 253 img/s.
+        # That is the topology of a step that will be replayed as a hipGraph (TrainStep asks for it); issued eagerly its
+        # ~2000 stream switches and event pairs cost the host more than the overlap returns (59 vs ~100 img/s), so plain
+        # eager SyncBN steps stay on one stream.  NPP_SYNCBN_STREAMS=1 / 3 forces either.
+        sync_bn = self._sync_bn_active()
+        mode = _stream_mode() if not sync_bn else _syncbn_stream_mode()
         two = mode >= 2
         K._helper_uses = 0
         K._hub_offload = None
@@ -453,11 +556,18 @@ class Network(nn.Module):
             s3 = self.stem5(s2 := self.stem4(self.stem3(x)))
         f1, f2 = [], []
         k1 = k2 = stage = 0
+        lockstep = _lockstep(mode, sync_bn)
         for i, (cell1, cell2) in enumerate(zip(self.cells1, self.cells2)):
-            with on_a():
-                s0, s1 = s1, cell1(s0, s1)
-            with on_b():
-                s2, s3 = s3, cell2(s2, s3)
+            if lockstep:
+                r1, r2 = [None], [None]
+                _alternate(cell1.stages(s0, s1, r1), on_a, cell2.stages(s2, s3, r2), on_b)
+                s0, s1 = s1, r1[0]
+                s2, s3 = s3, r2[0]
+            else:
+                with on_a():
+                    s0, s1 = s1, cell1(s0, s1)
+                with on_b():
+                    s2, s3 = s3, cell2(s2, s3)
             if i in self._taps:
                 f1.append(s1)
                 f2.append(s3)
@@ -520,12 +630,14 @@ class Network(nn.Module):
             in2, in4 = self.edge_layer(x2), self.par_layer(x2)
         pose_list, par_list = [], []
 
-        def heads(i):
+        def heads(i):      # issued alternately (see _lockstep); the streams make the order irrelevant otherwise
             with on_a():
                 pose_aux = self.pose_auxnet[i](in1)
-                pose_map = self.pose_head[i](in3)
             with on_b():
                 edge = self.edge_head[i](in2)
+            with on_a():
+                pose_map = self.pose_head[i](in3)
+            with on_b():
                 par_map = self.par_head[i](in4)
             pose_list.append([pose_map, pose_aux])
             par_list.append([par_map, edge])
@@ -535,10 +647,16 @@ class Network(nn.Module):
             for j in range(3):
                 m = 2 * (i - 1) + j
                 meet(in1, in2, in3, in4)
-                with on_a():
-                    n1, tmp = self.pose_net[m](in1, in3, in4, foreign=2, hub=hub)     # in4 comes from the parsing branch
-                with on_b():
-                    in2, n4 = self.par_net[m](in2, in3, in4, foreign=1, hub=hub)      # in3 from the pose branch
+                if lockstep:
+                    r1, r2 = [None], [None]
+                    _alternate(self.pose_net[m].stages(in1, in3, in4, 2, hub, r1), on_a,
+                               self.par_net[m].stages(in2, in3, in4, 1, hub, r2), on_b)
+                    (n1, tmp), (in2, n4) = r1[0], r2[0]
+                else:
+                    with on_a():
+                        n1, tmp = self.pose_net[m](in1, in3, in4, foreign=2, hub=hub)     # in4 comes from the parsing branch
+                    with on_b():
+                        in2, n4 = self.par_net[m](in2, in3, in4, foreign=1, hub=hub)      # in3 from the pose branch
                 in1, in3, in4 = n1, tmp, n4
             heads(i)
         K._hub_offload = None

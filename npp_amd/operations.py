@@ -75,6 +75,20 @@ def fused_sum(op1, h1, op2, h2, out=None):
     return K.bn_add(a, b, relu=False, training=training, out=out)
 
 
+def fused_sum_stages(op1, h1, op2, h2, result, out=None):
+    """fused_sum as a generator pausing after each edge (see model_augment.Cell.stages); result: 1-element list."""
+    a = pending_of(op1, h1)
+    if not _is_trivial(op1):
+        yield
+    b = pending_of(op2, h2)
+    if not _is_trivial(op2):
+        yield
+    if a.bn is None and b.bn is not None:
+        a, b = b, a
+    training = a.bn.training if a.bn is not None else False
+    result[0] = K.bn_add(a, b, relu=False, training=training, out=out)
+
+
 class Zero(nn.Module):
     """operations.py:31-41"""
 

@@ -40,6 +40,7 @@ class TrainStep:
         if graph is None:
             graph = os.environ.get("NPP_TRAIN_GRAPH", "1") != "0"
         self.use_graph = bool(graph)
+        K.GRAPH_TOPOLOGY = self.use_graph      # warm-up steps must already run the topology that gets captured
         self.warmup = max(int(warmup), 1)      # at least one eager step: pools, pinned optimizer tables, packed weights
         self.calls = 0
         self.graph = None
@@ -141,6 +142,7 @@ class TrainStep:
             except Exception as exc:      # noqa: BLE001 -- any capture failure: stay eager, on every rank alike
                 sys.stderr.write(f"[npp_amd.TrainStep] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager\n")
                 self.graph, self.use_graph, self._static_in = None, False, None
+                K.GRAPH_TOPOLOGY = False
                 K.reset_pools()
                 torch.cuda.synchronize()
                 return self._eager(images, labels_par, labels_pose, pose_weight)

@@ -120,9 +120,12 @@ def _oracle_grads():
     return {k: t[k].grad.numpy() for k in GRAD_KEYS}
 
 
-@pytest.mark.parametrize("world", [1, 2])
-def test_syncbn_ranks_equal_full_batch(world, tmp_path):
+@pytest.mark.parametrize("world,streams", [(1, "3"), (2, "3"), (2, "1")])
+def test_syncbn_ranks_equal_full_batch(world, streams, tmp_path, monkeypatch):
+    """streams: NPP_SYNCBN_STREAMS -- 3 (default) = branches on side streams, exchanges on the caller's stream, the two
+    branches issued in lockstep (model_augment._lockstep); 1 = everything on one stream."""
     from helpers import load_golden, rel_err
+    monkeypatch.setenv("NPP_SYNCBN_STREAMS", streams)      # inherited by the spawned ranks
     g = load_golden("tiny_net.npz")
     res = _run(world, tmp_path)
     per = int(g["n"]) // world
