@@ -15,12 +15,22 @@
 
 namespace {
 
-template <typename T, int V>
+// All 9 taps are fetched unconditionally (row / column clamped into the image, a validity bit decides what the value
+// counts for): a load behind a runtime test makes hipcc branch around it and wait vmcnt(0) right after -- the first
+// version (`continue` on out-of-image taps) had one load in flight at a time.
+// STATS: the BatchNorm batch statistics (sum / sum of squares of the values AS STORED) are accumulated here, per thread over
+// its grid-stride pixels (a thread keeps its channel group: 256 and the grid stride are multiples of cv), combined across
+// the block in LDS and flushed with one f64 atomic per (block, channel) into replica blockIdx.x % NPP_STAT_REPLICAS -- the
+// stand-alone channel_stats pass over y (one more read of the tensor, one more launch) is gone.
+template <typename T, int V, bool AVG, bool STATS>
 __global__ __launch_bounds__(256) void pool3x3_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
                                                           unsigned char* __restrict__ amax, int N, int H, int W, int OH,
-                                                          int OW, int C, int cv, int is_avg, int stride) {
+                                                          int OW, int C, int cv, int stride, double* __restrict__ stats) {
   const long total = (long)N * OH * OW * cv;
   const FastDiv fd((unsigned)cv);
+  float ss[V], sq[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { ss[j] = 0.f; sq[j] = 0.f; }
   for (unsigned i = VBLOCK * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned p, pr_;
     fast_divmod(i, fd, p, pr_);
@@ -28,53 +38,103 @@ __global__ __launch_bounds__(256) void pool3x3_fwd_kernel(const T* __restrict__ 
     const int ow = (int)(p % OW);
     const long t2 = p / OW;
     const int oh = (int)(t2 % OH), n = (int)(t2 / OH);
-    float acc[V];
-    int arg[V];
+    const int ih0 = oh * stride - 1, iw0 = ow * stride - 1;
+    float v[9][V];
+    bool ok[9];
 #pragma unroll
-    for (int j = 0; j < V; ++j) { acc[j] = is_avg ? 0.f : -INFINITY; arg[j] = 0; }
-    int cnt = 0;
-    bool first = true;
     for (int kh = 0; kh < 3; ++kh) {
-      const int ih = oh * stride - 1 + kh;
-      if (ih < 0 || ih >= H) continue;
+      const int ih = ih0 + kh;
+      const bool rok = ih >= 0 && ih < H;
+      const int ihc = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+#pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const int iw = ow * stride - 1 + kw;
-        if (iw < 0 || iw >= W) continue;
-        float v[V];
-        ldv<T, V>(x + ((long)(n * H + ih) * W + iw) * ldx + c0, v);
-        if (is_avg) {
-#pragma unroll
-          for (int j = 0; j < V; ++j) acc[j] += v[j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < V; ++j) {
-            // ATen max_pool2d: take the first maximum in scan order (val > max) or NaN
-            if (first || v[j] > acc[j] || v[j] != v[j]) { acc[j] = v[j]; arg[j] = kh * 3 + kw; }
-          }
-        }
-        first = false;
-        ++cnt;
+        const int iw = iw0 + kw;
+        ok[kh * 3 + kw] = rok && iw >= 0 && iw < W;
+        const int iwc = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+        ldv<T, V>(x + ((long)(n * H + ihc) * W + iwc) * ldx + c0, v[kh * 3 + kw]);
       }
     }
-    if (is_avg) {
-      const float inv = 1.f / (float)cnt;
+    float acc[V];
+    int arg[V];
+    if (AVG) {
+      int cnt = 0;
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        cnt += ok[t] ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += ok[t] ? v[t][j] : 0.f;
+      }
 #pragma unroll
       for (int j = 0; j < V; ++j) acc[j] = acc[j] / (float)cnt;
-      (void)inv;
+    } else {
+      // ATen max_pool2d: index starts at the first tap inside the image, value at -inf; a tap replaces them when
+      // (val > max) or val is NaN
+      const int first = (ih0 < 0 ? 3 : 0) + (iw0 < 0 ? 1 : 0);
+#pragma unroll
+      for (int j = 0; j < V; ++j) { acc[j] = -INFINITY; arg[j] = first; }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const bool upd = ok[t] && (v[t][j] > acc[j] || v[t][j] != v[t][j]);
+          acc[j] = upd ? v[t][j] : acc[j];
+          arg[j] = upd ? t : arg[j];
+        }
+      }
     }
     stv<T, V>(y + p * ldy + c0, acc);
-    if (amax) {
+    if (STATS) {
 #pragma unroll
-      for (int j = 0; j < V; ++j) amax[p * C + c0 + j] = (unsigned char)arg[j];
+      for (int j = 0; j < V; ++j) {
+        const float r = Elt<T>::round(acc[j]);
+        ss[j] += r;
+        sq[j] = fmaf(r, r, sq[j]);
+      }
+    }
+    if (!AVG && amax) {      // one packed store of the V tap ids (the first version: V byte stores per lane)
+      if constexpr (V == 8) {
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lo |= (unsigned)arg[j] << (8 * j); hi |= (unsigned)arg[4 + j] << (8 * j); }
+        *reinterpret_cast<uint2*>(amax + p * C + c0) = make_uint2(lo, hi);
+      } else if constexpr (V == 4) {
+        unsigned lo = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lo |= (unsigned)arg[j] << (8 * j);
+        *reinterpret_cast<unsigned*>(amax + p * C + c0) = lo;
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) amax[p * C + c0 + j] = (unsigned char)arg[j];
+      }
+    }
+  }
+  if (STATS) {
+    __shared__ float red[256 * 2 * V];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { red[t * 2 * V + j] = ss[j]; red[t * 2 * V + V + j] = sq[j]; }
+    __syncthreads();
+    // thread t < cv * 2V sums column (group g = t % cv, entry e = t / cv) over the 256 / cv threads of that group
+    const int ncol = cv * 2 * V;
+    for (int col = t; col < ncol; col += 256) {
+      const int g = col % cv, e = col / cv;
+      double s = 0.0;
+      for (int r = g; r < 256; r += cv) s += (double)red[r * 2 * V + e];
+      const int ch = g * V + (e < V ? e : e - V);
+      double* st = stats + (long)(blockIdx.x % NPP_STAT_REPLICAS) * 2 * C + (e < V ? 0 : C);
+      if (s != 0.0) atomicAdd(st + ch, s);
     }
   }
 }
 
-template <typename T, int V>
+template <typename T, int V, bool AVG>
 __global__ __launch_bounds__(256) void pool3x3_bwd_kernel(const T* __restrict__ dy, long ldy,
                                                           const unsigned char* __restrict__ amax, T* __restrict__ dx,
                                                           long ldx, int N, int H, int W, int OH, int OW, int C, int cv,
-                                                          int is_avg, int stride) {
+                                                          int stride) {
+  constexpr bool is_avg = AVG;
   // gather form: every input pixel sums the windows that contain it (no atomics)
   const long total = (long)N * H * W * cv;
   const FastDiv fd((unsigned)cv);
@@ -85,35 +145,53 @@ __global__ __launch_bounds__(256) void pool3x3_bwd_kernel(const T* __restrict__ 
     const int iw = (int)(p % W);
     const long t2 = p / W;
     const int ih = (int)(t2 % H), n = (int)(t2 / H);
-    float acc[V];
+    // all (up to 9) windows that contain this pixel are fetched unconditionally (clamped window index + validity bit; see
+    // pool3x3_fwd_kernel), the tap ids of a window as ONE packed load
+    float d[9][V];
+    unsigned long long tid9[9];
+    bool ok[9];
+    float inv[9];
 #pragma unroll
-    for (int j = 0; j < V; ++j) acc[j] = 0.f;
     for (int kh = 0; kh < 3; ++kh) {
       const int th = ih + 1 - kh;
-      if (th < 0 || th % stride) continue;
-      const int oh = th / stride;
-      if (oh >= OH) continue;
+      const int ohr = th / stride;
+      const bool hok = th >= 0 && th % stride == 0 && ohr < OH;
+      const int oh = hok ? ohr : 0;
+#pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int tw = iw + 1 - kw;
-        if (tw < 0 || tw % stride) continue;
-        const int ow = tw / stride;
-        if (ow >= OW) continue;
+        const int owr = tw / stride;
+        const bool wok = tw >= 0 && tw % stride == 0 && owr < OW;
+        const int ow = wok ? owr : 0;
+        const int t = kh * 3 + kw;
+        ok[t] = hok && wok;
         const long op = (long)(n * OH + oh) * OW + ow;
-        float d[V];
-        ldv<T, V>(dy + op * ldy + c0, d);
-        if (is_avg) {
+        ldv<T, V>(dy + op * ldy + c0, d[t]);
+        tid9[t] = 0;
+        inv[t] = 0.f;
+        if constexpr (AVG) {
           // divisor = number of in-bounds taps of that window (count_include_pad=False)
           const int h0 = oh * stride - 1, w0 = ow * stride - 1;
           const int nh = (h0 + 3 < H ? h0 + 3 : H) - (h0 > 0 ? h0 : 0);
           const int nw = (w0 + 3 < W ? w0 + 3 : W) - (w0 > 0 ? w0 : 0);
-          const float inv = 1.f / (float)(nh * nw);
-#pragma unroll
-          for (int j = 0; j < V; ++j) acc[j] += d[j] * inv;
+          inv[t] = 1.f / (float)(nh * nw);
         } else {
-          const int tap = kh * 3 + kw;
-#pragma unroll
-          for (int j = 0; j < V; ++j) acc[j] += (amax[op * C + c0 + j] == tap) ? d[j] : 0.f;
+          if constexpr (V == 8) tid9[t] = *reinterpret_cast<const unsigned long long*>(amax + op * C + c0);
+          else if constexpr (V == 4) tid9[t] = *reinterpret_cast<const unsigned*>(amax + op * C + c0);
+          else tid9[t] = amax[op * C + c0];
         }
+      }
+    }
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const bool hit = is_avg ? true : ((unsigned)((tid9[t] >> (8 * j)) & 0xFF) == (unsigned)t);
+        const float w = is_avg ? inv[t] : 1.f;
+        acc[j] += (ok[t] && hit) ? d[t][j] * w : 0.f;
       }
     }
     stv<T, V>(dx + p * ldx + c0, acc);
@@ -409,6 +487,12 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const T* __restrict
 
 }  // namespace
 
+// (defined outside the function: a #define cannot sit inside NPP_DISPATCH_TV's argument)
+#define POOL_LAUNCH(AVG_, ST_)                                                                                          \
+      hipLaunchKernelGGL((pool3x3_fwd_kernel<T, V, AVG_, ST_>), dim3(grid), dim3(256), 0, s, (const T*)x->ptr,          \
+                         (long)x->ld, (T*)y->ptr, (long)y->ld, is_avg ? nullptr : argmax, (int)x->n, (int)x->h, (int)x->w, \
+                         (int)y->h, (int)y->w, (int)x->c, cv, stride, stats)
+
 extern "C" int npp_pool3x3_fwd(const NppTensor* x, NppTensor* y, uint8_t* argmax, int is_avg, int stride, double* stats,
                                void* stream) {
   NPP_REQUIRE(x && y && x->ptr && y->ptr, NPP_E_NULL, "npp_pool3x3_fwd: null pointer");
@@ -417,17 +501,21 @@ extern "C" int npp_pool3x3_fwd(const NppTensor* x, NppTensor* y, uint8_t* argmax
               NPP_E_SHAPE, "npp_pool3x3_fwd: shape mismatch");
   const bool vk = vec_ok(x) && vec_ok(y);
   hipStream_t s = (hipStream_t)stream;
+  bool fused = false;
   {
     ProfScope prof(NPP_FAM_POOL, x->dtype, s, 0, (double)(npix(x) + npix(y)) * x->c * esize(x->dtype));
     NPP_DISPATCH_TV(x->dtype, vk, {
       const int cv = (int)(x->c / V);
-      hipLaunchKernelGGL((pool3x3_fwd_kernel<T, V>), dim3(grid_for(npix(y) * cv)), dim3(256), 0, s, (const T*)x->ptr,
-                         (long)x->ld, (T*)y->ptr, (long)y->ld, is_avg ? nullptr : argmax, (int)x->n, (int)x->h, (int)x->w,
-                         (int)y->h, (int)y->w, (int)x->c, cv, is_avg, stride);
+      // statistics in the kernel need a thread to keep its channel group over the grid-stride loop (256 % cv == 0) and want
+      // few blocks (one f64 atomic per block and channel)
+      fused = stats != nullptr && cv > 0 && 256 % cv == 0 && x->c % V == 0;
+      const int grid = grid_for(npix(y) * cv, 256, fused ? 1024 : 4096);
+      if (is_avg) { if (fused) POOL_LAUNCH(true, true); else POOL_LAUNCH(true, false); }
+      else        { if (fused) POOL_LAUNCH(false, true); else POOL_LAUNCH(false, false); }
     });
   }
   int rc = npp_check_launch("pool3x3_fwd");
-  if (rc == NPP_OK && stats) rc = npp_channel_stats(y, stats, stream);
+  if (rc == NPP_OK && stats && !fused) rc = npp_channel_stats(y, stats, stream);
   return rc;
 }
 
@@ -442,9 +530,14 @@ extern "C" int npp_pool3x3_bwd(const NppTensor* dy, const uint8_t* argmax, NppTe
   ProfScope prof(NPP_FAM_POOL, dy->dtype, s, 0, (double)(npix(dx) + npix(dy)) * dx->c * esize(dx->dtype));
   NPP_DISPATCH_TV(dy->dtype, vk, {
     const int cv = (int)(dx->c / V);
-    hipLaunchKernelGGL((pool3x3_bwd_kernel<T, V>), dim3(grid_for(npix(dx) * cv)), dim3(256), 0, s, (const T*)dy->ptr,
-                       (long)dy->ld, argmax, (T*)dx->ptr, (long)dx->ld, (int)dx->n, (int)dx->h, (int)dx->w, (int)dy->h,
-                       (int)dy->w, (int)dx->c, cv, is_avg, stride);
+    if (is_avg)
+      hipLaunchKernelGGL((pool3x3_bwd_kernel<T, V, true>), dim3(grid_for(npix(dx) * cv)), dim3(256), 0, s, (const T*)dy->ptr,
+                         (long)dy->ld, argmax, (T*)dx->ptr, (long)dx->ld, (int)dx->n, (int)dx->h, (int)dx->w, (int)dy->h,
+                         (int)dy->w, (int)dx->c, cv, stride);
+    else
+      hipLaunchKernelGGL((pool3x3_bwd_kernel<T, V, false>), dim3(grid_for(npix(dx) * cv)), dim3(256), 0, s, (const T*)dy->ptr,
+                         (long)dy->ld, argmax, (T*)dx->ptr, (long)dx->ld, (int)dx->n, (int)dx->h, (int)dx->w, (int)dy->h,
+                         (int)dy->w, (int)dx->c, cv, stride);
   });
   return npp_check_launch("pool3x3_bwd");
 }

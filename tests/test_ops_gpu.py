@@ -316,5 +316,7 @@ def test_two_stream_forward_equals_single_stream(monkeypatch):
         for k, a in res["1"][2].items():
             # gradients of the first cells sit behind ~500 layers of backward: the float-atomic summation order of the SE squeeze
             # (1e-7 on the activations) reaches them as ~1e-3 (observed up to 1.3e-3 on cells1.0.preprocess1's BN gamma, run to
-            # run); a missing cross-stream dependency is a gross (O(1)) difference
-            assert rel_err(res[other][2][k], a) < 5e-3 or np.abs(a).max() < 1e-6, ("grad", other, k, rel_err(res[other][2][k], a))
+            # run), and it can flip one arg-max / ReLU decision on these tiny maps: tools/mode_noise.py shows the gradients of
+            # IDENTICAL runs (same mode, same process) falling into one of two states 1.25e-2 apart (par_head.1.1.weight,
+            # cells1.1._ops.1.conv1.*); a missing cross-stream dependency is a gross (O(1)) difference
+            assert rel_err(res[other][2][k], a) < 3e-2 or np.abs(a).max() < 1e-6, ("grad", other, k, rel_err(res[other][2][k], a))
