@@ -109,6 +109,10 @@ int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw_packed, co
                    void* stream);
 /* packed f32 gradient -> the state-dict layout [cout][cin][kh][kw] */
 int npp_unpack_wgrad(const float* dw_packed, int cout, int cin, int kh, int kw, float* dw_oihw, void* stream);
+/* out[i] = (float) sum over r < nrep of in[r][i] (i < n): collapses NPP_STAT_REPLICAS f64 accumulator slabs (conv bias gradient
+ * from npp_channel_sum, the arch-weight gradient of npp_weighted_sum_bwd) to the f32 vector autograd takes.  Replaces the
+ * `.sum(0).float()` pair of torch kernels at core of nn.Conv2d's bias gradient (models/operations.py:230, model_augment.py:332-398). */
+int npp_sum_replicas(const double* in, int nrep, int n, float* out, void* stream);
 
 /* ---- depthwise (dilated) convolution: nn.Conv2d(groups=C), operations.py:213-214 -------------- */
 int npp_dwconv_fwd(const NppTensor* x, const float* w /*[C][kh*kw]*/, NppTensor* y,

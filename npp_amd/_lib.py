@@ -63,6 +63,7 @@ _SIGS = {
     "npp_conv_fwd_ws": [_T, _P, _P, _T, _T, _P, _G, _P, C.c_int64, _P],
     "npp_conv_wgrad": [_T, _T, _P, _G, _P],
     "npp_unpack_wgrad": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
+    "npp_sum_replicas": [_P, C.c_int, C.c_int, _P, _P],
     "npp_dwconv_fwd": [_T, _P, _T, _G, _P],
     "npp_dwconv_bwd_data": [_T, _P, _T, _T, _G, _P],
     "npp_dwconv_bwd_weight": [_T, _T, _P, _P, _G, _P],

@@ -525,7 +525,8 @@ class _Conv2d(Function):
         if has_bias and ctx.needs_input_grad[2]:
             acc = zeros_f64(R * co, x.device)
             check(lib().npp_channel_sum(_byref(dy), acc.data_ptr(), s), "npp_channel_sum")
-            db = acc.view(R, co).sum(0).float()
+            db = torch.empty(co, dtype=torch.float32, device=x.device)
+            check(lib().npp_sum_replicas(acc.data_ptr(), R, co, db.data_ptr(), s), "npp_sum_replicas")
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -1412,7 +1413,11 @@ class _WeightedSum(Function):
         dw = zeros_f64(R * 8, dout.device)
         check(lib().npp_weighted_sum_bwd(ya, da, k, wf.data_ptr(), _byref(dout), dw.data_ptr(), stream_ptr()),
               "npp_weighted_sum_bwd")
-        gw = dw.view(R, 8).sum(0)[:k].to(ctx.wdtype) if need[0] else None
+        gw = None
+        if need[0]:
+            gw = torch.empty(8, dtype=torch.float32, device=dout.device)
+            check(lib().npp_sum_replicas(dw.data_ptr(), R, 8, gw.data_ptr(), stream_ptr()), "npp_sum_replicas")
+            gw = gw[:k] if ctx.wdtype == torch.float32 else gw[:k].to(ctx.wdtype)
         return (gw, *dys)
 
 

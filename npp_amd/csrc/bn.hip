@@ -569,6 +569,25 @@ __global__ __launch_bounds__(256) void scale_mask_kernel(const T* __restrict__ d
 
 }  // namespace
 
+namespace {
+// out[i] = (float) sum_r in[r][i]: the f64 replica slabs of a per-channel accumulator collapsed to the f32 vector autograd
+// wants (conv bias gradient, arch-weight gradient) -- one launch instead of an ATen sum + cast pair
+__global__ void sum_replicas_kernel(const double* __restrict__ in, int nrep, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int r = 0; r < nrep; ++r) s += in[(long)r * n + i];
+  out[i] = (float)s;
+}
+}  // namespace
+
+extern "C" int npp_sum_replicas(const double* in, int nrep, int n, float* out, void* stream) {
+  NPP_REQUIRE(in && out, NPP_E_NULL, "npp_sum_replicas: null pointer");
+  NPP_REQUIRE(nrep >= 1 && n >= 1, NPP_E_SHAPE, "npp_sum_replicas: bad extents %d x %d", nrep, n);
+  hipLaunchKernelGGL(sum_replicas_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, nrep, n, out);
+  return npp_check_launch("sum_replicas");
+}
+
 extern "C" int npp_channel_stats(const NppTensor* x, double* stats, void* stream) {
   NPP_REQUIRE(x && x->ptr && stats, NPP_E_NULL, "npp_channel_stats: null pointer");
   NPP_REQUIRE(dtype_ok(x), NPP_E_DTYPE, "npp_channel_stats: bad dtype");
