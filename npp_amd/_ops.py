@@ -1137,6 +1137,50 @@ def concat(xs: Sequence[torch.Tensor]):
     return _Concat.apply(*[take(x) for x in xs])
 
 
+class _SplitHalf(Function):
+    """x -> (x[:, :C/2], x[:, C/2:]) as channel-slice views (the PC-DARTS partial-channel split, model_search_interact.py:59-60).
+    autograd's own slicing materialises, per half, a full-size zero tensor + a copy and then adds the two (5 full passes and
+    5 launches per MixedOp); here the backward is ONE npp_concat of the two half gradients."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = to_nhwc(x)
+        c = x.shape[1]
+        ctx.c = c
+        ctx.set_materialize_grads(False)
+        return _alias_slice(x, 0, c // 2), _alias_slice(x, c // 2, c - c // 2)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None and g2 is None:
+            return None
+        ref = g1 if g1 is not None else g2
+        n, _, h, w = ref.shape
+        c = ctx.c
+        parts = []
+        for g, cc in ((g1, c // 2), (g2, c - c // 2)):
+            parts.append(to_nhwc(g) if g is not None else new_nhwc(n, cc, h, w, ref.dtype, ref.device, zero=True))
+        if parts[0].dtype != parts[1].dtype:
+            parts[1] = cast(parts[1], parts[0].dtype)
+        y = new_nhwc(n, c, h, w, parts[0].dtype, ref.device)
+        descs = [desc(t) for t in parts]
+        arr = (C.POINTER(L.NppTensor) * 2)(*[C.pointer(d) for d in descs])
+        check(lib().npp_concat(arr, 2, _byref(y), stream_ptr()), "npp_concat")
+        return y
+
+
+def _alias_slice(x: torch.Tensor, c0: int, c: int) -> torch.Tensor:
+    """Channels [c0, c0 + c) of the NHWC tensor x as a tensor of its own (same storage; see _alias)."""
+    n, _, h, w = x.shape
+    t = torch.empty(0, dtype=x.dtype, device=x.device)
+    return t.set_(x.untyped_storage(), x.storage_offset() + c0 * x.stride(1), (n, c, h, w), x.stride())
+
+
+def split_half(x):
+    """(x[:, :C/2], x[:, C/2:]) without autograd's slice-backward passes."""
+    return _SplitHalf.apply(take(x))
+
+
 def _alias(base: torch.Tensor, c0: int, c: int) -> torch.Tensor:
     """Channels [c0, c0 + c) of the NHWC buffer `base` as a tensor of its own (same storage, no view relation: autograd
     must not see the producers' writes as in-place updates of a view of the buffer)."""

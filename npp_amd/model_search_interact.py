@@ -67,8 +67,7 @@ class MixedOp(nn.Module):
         self.extra_conv = extra_conv
 
     def forward(self, x, weights):
-        c = x.shape[1]
-        xtemp, xtemp2 = x[:, :c // 2], x[:, c // 2:]
+        xtemp, xtemp2 = K.split_half(x)
         temp1 = K.weighted_sum(weights, [op(xtemp) for op in self._ops])
         if self.up_scale:
             xtemp2 = K.nearest(xtemp2, self.up_scale)       # F.interpolate default mode (:63-64)
