@@ -221,7 +221,8 @@ def main():
         prof_steps = 2
         KERNELS = {"conv_s1": "conv_s1_kernel (stride-1 KxK conv fwd + dgrad, LDS-resident footprint, MFMA 32x32x16)",
                    "conv_g8": "conv_g8_kernel (1x1 conv fwd + dgrad: 8-phase LDS-DMA implicit GEMM, MFMA 16x16x32)",
-                   "conv_g4": "conv_g4_kernel (stride-1 conv fwd + dgrad, 1x1 / 3x3: 64x64 / 128x128 / 64x32 tiles, LDS-DMA ring of 2, 2-4 blocks per CU, MFMA 16x16x32)"}
+                   "conv_g4": "conv_g4_kernel (stride-1 conv fwd + dgrad, 1x1 / 3x3: 64x64 / 128x128 / 64x32 tiles, LDS-DMA ring of 2, 2-4 blocks per CU, MFMA 16x16x32)",
+                   "conv_wgrad": "weight-gradient family (conv_wgrad_g4_kernel: pixel-major LDS-DMA + transposing reads, MFMA 16x16x32; the 32/64-channel KxK layers on conv_wgrad_kernel)"}
         traffic_db = {}
         try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
             with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as fh:
@@ -238,7 +239,10 @@ def main():
             if nl.value > 0 and ms.value > 0:
                 ach = fl.value / (ms.value * 1e-3) / 1e12
                 peak = PEAK_TFLOPS[args.dtype]
-                rec = traffic_db.get(fam + "_kernel") or (traffic_db if traffic_db.get("kernel") == fam + "_kernel" else None)
+                rec = traffic_db.get({"conv_wgrad": "conv_wgrad_g4_kernel"}.get(fam, fam + "_kernel")) \
+                    or (traffic_db if traffic_db.get("kernel") == fam + "_kernel" else None)
+                if fam == "conv_wgrad":
+                    rec = None      # a mixed family: the PMC average of one of its kernels is not its per-launch traffic
                 traffic = round(rec["traffic_bytes_per_launch"]) if rec else None
                 roofs.append({"bound": "mfma", "kernel": label, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                               "frac": round(ach / peak, 4), "traffic": traffic,

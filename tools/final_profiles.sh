@@ -27,5 +27,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 ff=$(find /tmp/fp_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 fw=$(find /tmp/fp_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_traffic.py "$ff" "$fw" conv_s1_kernel,conv_g8_kernel,conv_g4_kernel $out/${tag}_pmc_traffic.json
+python3 tools/pmc_traffic.py "$ff" "$fw" conv_s1_kernel,conv_g8_kernel,conv_g4_kernel,conv_wgrad_g4_kernel $out/${tag}_pmc_traffic.json
 python3 tools/pmc_step_total.py "$ff" "$fw" 4 > $out/${tag}_pmc_step_total.txt
