@@ -56,6 +56,9 @@ typedef struct NppConvGeom {
 
 const char* npp_version(void);
 const char* npp_last_error(void);
+/* Reads (and thereby clears) HIP's sticky last-error state; returns the hipError_t it held.  For the eager fallback after a
+ * failed hipGraph capture (npp_amd/train_step.py). */
+int npp_clear_hip_error(void);
 
 /* ---- profiling hook (bench.py roofline leg): HIP events around every launch of one kernel family,
  *      recorded on the launch stream; read back after the caller synchronised. ------------------- */

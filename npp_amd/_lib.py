@@ -117,7 +117,7 @@ _SIGS = {
     "npp_adam_step": [_P, _P, C.c_int, _P, _P],
     "npp_parsing_confusion": [_T, _T, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
 }
-EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_packed_weight_elems", "npp_pack_job_blocks", "npp_reduce_blocks",
+EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_clear_hip_error", "npp_packed_weight_elems", "npp_pack_job_blocks", "npp_reduce_blocks",
                                  "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems"])
 
 

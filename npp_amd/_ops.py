@@ -236,6 +236,20 @@ _zpool64 = _PerStream(lambda: _ZeroPool(torch.float64, 1 << 21))
 _zpool32 = _PerStream(lambda: _ZeroPool(torch.float32, 1 << 24))
 
 
+_stream_caches: list = []      # dict / set objects other modules cache HIP streams in (model_augment._side_streams)
+
+
+def forget_streams():
+    """Drop every cached side stream.  After a hipGraph capture that was invalidated half way the streams that had joined it
+    stay in capture mode for good on this ROCm (hipStreamEndCapture fails on them): the eager fallback needs fresh ones."""
+    _helper_streams.clear()
+    _branch_b_streams.clear()
+    for c in _stream_caches:
+        c.clear()
+    for ps in (_zpool64, _zpool32, _sync_pool):
+        ps.pools.clear()
+
+
 def reset_pools():
     """Drop the current scratch chunks (call after CUDA-graph capture: captured chunks belong to the graph)."""
     for pool in _zpool64.all() + _zpool32.all():

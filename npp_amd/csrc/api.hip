@@ -35,6 +35,10 @@ int npp_check_launch(const char* what) {
   return NPP_OK;
 }
 
+// HIP keeps the last error until somebody reads it: after a failed hipGraph capture the next npp_check_launch would report
+// "operation failed due to a previous error during capture" for a perfectly good launch.  The eager fallback calls this.
+extern "C" int npp_clear_hip_error(void) { return (int)hipGetLastError(); }
+
 extern "C" const char* npp_version(void) { return "npp_hip 0.1 (gfx950)"; }
 extern "C" const char* npp_last_error(void) { return g_err; }
 

@@ -289,6 +289,7 @@ class ParCell1(_FuseCell):
 
 # ---- network -----------------------------------------------------------------------------------------
 _side_streams = {}
+K._stream_caches.append(_side_streams)
 
 
 def _side_stream(device, which=0):

@@ -40,6 +40,10 @@ class TrainStep:
         if graph is None:
             graph = os.environ.get("NPP_TRAIN_GRAPH", "1") != "0"
         self.use_graph = bool(graph)
+        if self.use_graph and dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
+            # only RCCL ("nccl") collectives can sit inside a hipGraph; a gloo all-reduce invalidates the capture (and its
+            # own device streams with it: the eager fallback then dies inside gloo)
+            self.use_graph = False
         K.GRAPH_TOPOLOGY = self.use_graph      # warm-up steps must already run the topology that gets captured
         self.warmup = max(int(warmup), 1)      # at least one eager step: pools, pinned optimizer tables, packed weights
         self.calls = 0
@@ -113,9 +117,17 @@ class TrainStep:
         K.reset_pools()
         self.optimizer.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
+        origin = torch.cuda.current_stream()
         try:
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._static_loss = self._eager(*args)
+                if os.environ.get("NPP_TEST_FAIL_CAPTURE"):      # test hook: an illegal call invalidates the capture
+                    torch.cuda.current_stream().synchronize()
+        except BaseException:
+            # torch.cuda.graph.__exit__ raises from capture_end() BEFORE it restores the stream: the current stream would
+            # stay the (invalidated) capture stream and every later launch would fail (tools/capture_recover.py)
+            torch.cuda.set_stream(origin)
+            raise
         finally:
             K.reset_pools()        # chunks handed out during capture belong to the graph's private pool
         self.graph = g
@@ -142,9 +154,20 @@ class TrainStep:
             except Exception as exc:      # noqa: BLE001 -- any capture failure: stay eager, on every rank alike
                 sys.stderr.write(f"[npp_amd.TrainStep] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager\n")
                 self.graph, self.use_graph, self._static_in = None, False, None
+                # the half-captured autograd graph pins AccumulateGrad nodes bound to the dead capture streams: let it go
+                self._static_loss = None
+                self.optimizer.zero_grad(set_to_none=True)
+                import gc
+                gc.collect()
                 K.GRAPH_TOPOLOGY = False
+                K.forget_streams()     # side streams that had joined the capture stay in capture mode: use fresh ones
                 K.reset_pools()
-                torch.cuda.synchronize()
+                try:
+                    torch.cuda.synchronize()
+                except Exception:      # noqa: BLE001 -- the failed capture's error may surface once more here
+                    pass
+                from ._lib import lib as _lib_handle
+                _lib_handle().npp_clear_hip_error()     # HIP's sticky last error would fail the next launch check
                 return self._eager(images, labels_par, labels_pose, pose_weight)
             self.graph.replay()            # the captured step has not run yet: this executes it on this batch
             return self._static_loss

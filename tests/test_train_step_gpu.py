@@ -122,3 +122,15 @@ def test_pose_weight_argument_and_static_inputs():
     l2 = float(step(im, lpar, lpose, w).detach())
     assert step.graphed and len(step.static_inputs) == 6
     assert np.isfinite([l0, l1, l2]).all() and l2 < l0
+
+
+def test_capture_failure_falls_back_to_eager():
+    """A hipGraph capture that is invalidated half way leaves the capture stream current and the side streams stuck in
+    capture mode (tools/capture_recover.py); TrainStep must restore the stream, take fresh side streams and keep stepping
+    eagerly.  Run in a subprocess: torch's own capture bookkeeping stays odd after such a failure."""
+    import subprocess
+    env = dict(os.environ, NPP_TEST_FAIL_CAPTURE="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "capture_fail_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "capture failed" in r.stderr
