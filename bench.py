@@ -87,6 +87,48 @@ def cpu_baseline(size, budget_s=25.0):
                       f"(torch-CPU oracle, {os.cpu_count()} logical CPUs)"}
 
 
+def spawn_ranks(n):
+    """Run this script as `n` fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), relay
+    rank 0's stdout (its last line is the JSON record) and return the worst exit code.  Called before torch is imported:
+    the parent never initialises the GPU, and nothing is re-executed in a process that has."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(s.getsockname()[1])
+        s.close()
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # a rank that dies leaves the others waiting in a collective: end them (by their own PIDs) instead of hanging
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                time.sleep(5.0)
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                break
+            time.sleep(0.2)
+        rcs = [p.wait() for p in procs]
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode(errors="replace"))
+        sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {bad}\n")
+        return max(abs(rc) for _, rc in bad) or 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,14 +150,22 @@ def main():
                     help="1: capture the whole step (fwd+loss+bwd+Adam) in one hipGraph and replay it; 0: eager; "
                          "-1 (default): graph for every N (on N > 1 every collective sits on the capture's origin stream); a capture "
                          "failure falls back to eager")
+    ap.add_argument("--no-comm-ablation", action="store_true",
+                    help="N > 1: skip the second, communication-free timing (local BN statistics, no gradient reducer) "
+                         "that `exposed_comm_ms` is computed from")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: start the N ranks ourselves (one process per GPU, as the reference's
+        # launcher does: augment_lip_sync.py:107-113, README.md:14).  This parent has made no GPU call and makes none.
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("NPP_BENCH_ONE_GPU"):      # rehearsal of the N > 1 flow on a 1-GPU box: every rank on device 0 (with
         local_rank = 0                           # NPP_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device)
@@ -158,9 +208,9 @@ def main():
     crit_pose = Criterion_pose(out_len=2).to(dev)
     crit_par = Criterion_par(out_len=2).to(dev)
     use_graph = args.graph != 0      # default: graph for every N (RCCL collectives are captured too; falls back to eager)
-    # under capture every collective is issued on the capture's origin stream (GradReducer overlap=False, _ops.hub_all_reduce)
-    reducer = GradReducer(net, skip=unused_parameter_names(net), always_reduce=args.force_dist,
-                          overlap=not use_graph) if use_dist else None
+    # buckets go out as they complete: eagerly on the reducer's side stream, under capture on the capture's origin stream
+    # (ddp.GradReducer._target_stream, _ops.hub_all_reduce)
+    reducer = GradReducer(net, skip=unused_parameter_names(net), always_reduce=args.force_dist) if use_dist else None
     arch_ids = {id(a) for a in net.arch_parameters()} if args.model == "search" else set()
     params = [q for q in net.parameters() if id(q) not in arch_ids] + list(crit_pose.parameters()) + list(crit_par.parameters())
     # Adam (augment_lip_sync.py:210-213).  Default: npp_amd.optim.FusedAdam, one launch over a device job table (SURVEY
@@ -223,6 +273,7 @@ def main():
     roof = None
     roofs = []
     if prof:
+        streams_env = os.environ.get("NPP_STREAMS")
         os.environ["NPP_STREAMS"] = "1"
         prof_steps = 2
         KERNELS = {"conv_s1": "conv_s1_kernel (stride-1 KxK conv fwd + dgrad, LDS-resident footprint, MFMA 32x32x16)",
@@ -259,10 +310,40 @@ def main():
                               "algorithmic_mbyte_per_launch": round(by.value / nl.value / 1e6, 3)})
         roofs.sort(key=lambda r: -r["ms_per_step"])
         roof = roofs[0] if roofs else None
+        if streams_env is None:
+            os.environ.pop("NPP_STREAMS", None)
+        else:
+            os.environ["NPP_STREAMS"] = streams_env
+    comm = None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+        # what the communicator itself reports (not the flag): its size, and one all-reduce of ones through it
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        comm = {"backend": dist.get_backend(), "rccl_ranks": int(dist.get_world_size()), "allreduce_of_ones": float(ones)}
+    exposed = None
+    if use_dist and not args.no_comm_ablation:
+        # exposed communication = this step minus the SAME step without any collective: SyncBatchNorm modules on local
+        # statistics (K.SYNC_OFF) and no gradient reducer, captured and timed the same way.  (Ranks drift apart from here
+        # on -- nothing after this uses the parameters.)
+        K.SYNC_OFF = True
+        quiet = TrainStep(net, crit_pose, crit_par, opt, reducer=None, graph=use_graph, warmup=2)
+        if reducer is not None:
+            reducer.remove()
+        for _ in range((3 if use_graph else 1) + args.warmup):
+            quiet(images, lpar, lpose)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            quiet(images, lpar, lpose)
+        barrier()
+        tq = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tq, op=dist.ReduceOp.MAX)
+        if quiet.graphed == train_step.graphed:      # (a capture that fell back to eager would time the host instead)
+            exposed = round((elapsed - float(tq)) / args.steps * 1e3, 3)
+        K.SYNC_OFF = False
     imgs = args.batch * world * args.steps
     value = imgs / elapsed
     out = {
@@ -279,6 +360,9 @@ def main():
         "model_tflops": round(value * 3 * (FWD_GFLOP_PER_IMG.get(args.size, 243.37 * (args.size / 384.0) ** 2)
                                            if args.model == "augment" else 88.70 * (args.size / 384.0) ** 2) / 1e3, 2),
     }
+    if comm is not None:
+        out.update(comm)
+        out["exposed_comm_ms"] = exposed      # ms per step; None with --no-comm-ablation
     if roof is not None:
         out["roofline"] = roof
         if len(roofs) > 1:

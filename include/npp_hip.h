@@ -212,6 +212,10 @@ int npp_se_bwd_apply(const NppTensor* dout, const float* gate, const float* dpoo
  *      nn.UpsamplingBilinear2d, operations.py:242 ----------------------------------------------- */
 int npp_bilinear_fwd(const NppTensor* x, NppTensor* y, void* stream);
 int npp_bilinear_bwd(const NppTensor* dy, NppTensor* dx, void* stream);
+/* the same with the align_corners flag: 0 = F.interpolate(size=, mode='bilinear') with its default align_corners=False, the
+ * resample Criterion_pose applies when heat-map and target sizes differ (core/criterion.py:94-96, 113-115) */
+int npp_bilinear_fwd_ac(const NppTensor* x, NppTensor* y, int align_corners, void* stream);
+int npp_bilinear_bwd_ac(const NppTensor* dy, NppTensor* dx, int align_corners, void* stream);
 
 /* ---- layout / elementwise plumbing -------------------------------------------------------------- */
 int npp_copy(const NppTensor* x, NppTensor* y, void* stream);                /* cast + channel-slice copy (cat) */
@@ -239,6 +243,11 @@ int npp_interleave2(const NppTensor* a, const NppTensor* b, NppTensor* out, int 
 int npp_mse_fwd(const NppTensor* pred, const float* target_nchw, double* sse, void* stream);
 /* grad = 2*(pred - target) * (*gscale) */
 int npp_mse_bwd(const NppTensor* pred, const float* target_nchw, const float* gscale, NppTensor* grad, void* stream);
+/* use_target_weight=True (core/criterion.py:103-108, 122-126): prediction and target of image n, joint c are both multiplied
+ * by weight_nc[n*C + c] (f32; NULL = 1) before the squared difference; grad = 2*w^2*(pred - target) * (*gscale) */
+int npp_mse_w_fwd(const NppTensor* pred, const float* target_nchw, const float* weight_nc, double* sse, void* stream);
+int npp_mse_w_bwd(const NppTensor* pred, const float* target_nchw, const float* weight_nc, const float* gscale, NppTensor* grad,
+                  void* stream);
 /* per-pixel softmax cross-entropy on logits bilinearly upsampled (align_corners) to the label size,
  * core/criterion.py:54-72,181-197.  logits: f32 NHWC [N,h,w,C]; labels: int64 [N,H,W].
  * Writes p_gt (prob of the GT class; -1 where label == ignore) and wnll = -w[gt]*log p_gt (0 if ignored);

@@ -94,6 +94,8 @@ _SIGS = {
     "npp_se_bwd_apply": [_T, _P, _P, _T, _P],
     "npp_bilinear_fwd": [_T, _T, _P],
     "npp_bilinear_bwd": [_T, _T, _P],
+    "npp_bilinear_fwd_ac": [_T, _T, C.c_int, _P],
+    "npp_bilinear_bwd_ac": [_T, _T, C.c_int, _P],
     "npp_copy": [_T, _T, _P],
     "npp_add_n": [_P, C.c_int, _T, _P],
     "npp_concat": [_P, C.c_int, _T, _P],
@@ -108,6 +110,8 @@ _SIGS = {
     "npp_interleave2": [_T, _T, _T, C.c_int, _T, _T, _P],
     "npp_mse_fwd": [_T, _P, _P, _P],
     "npp_mse_bwd": [_T, _P, _P, _T, _P],
+    "npp_mse_w_fwd": [_T, _P, _P, _P, _P],
+    "npp_mse_w_bwd": [_T, _P, _P, _P, _T, _P],
     "npp_ce_pixel_fwd": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P],
     "npp_kth_smallest": [_P, C.c_int64, C.c_int64, _P, _P, _P],
     "npp_ce_reduce": [_P, _P, _P, _P, C.c_int, C.c_int64, _P, C.c_float, C.c_int, _P, _P],

@@ -356,6 +356,51 @@ def clear_caches():
     _pack_cache.clear()
 
 
+# --------------------------------------------------------------------------------------------------
+# gradient slots: where a parameter's gradient is to be written (ddp.GradReducer's pre-flattened buckets)
+# --------------------------------------------------------------------------------------------------
+_GRAD_SLOTS: dict = {}     # parameter data_ptr -> (provider(param, zero) -> tensor or None, weakref to the parameter)
+
+
+def register_grad_slot(p: torch.Tensor, provider):
+    _GRAD_SLOTS[p.data_ptr()] = (provider, weakref.ref(p))
+
+
+def unregister_grad_slot(key):
+    _GRAD_SLOTS.pop(key, None)
+
+
+def grad_out(param, shape=None, zero=False):
+    """The tensor a backward kernel should write the f32 gradient of `param` into: its slot in a gradient bucket when a
+    reducer has registered one and hands it out for this step (zero: the kernel accumulates, the slot must hold zeros --
+    GradReducer.begin_step zeroed the bucket), else None (the caller allocates)."""
+    if not _GRAD_SLOTS or param is None or param.dtype != torch.float32:
+        return None
+    ent = _GRAD_SLOTS.get(param.data_ptr())
+    if ent is None:
+        return None
+    p = ent[1]()
+    if p is None or p.shape != param.shape:
+        return None
+    return ent[0](p, zero)
+
+
+def _grad_buf(param, n, device):
+    """grad_out(param) or a fresh f32 vector of n elements."""
+    t = grad_out(param)
+    return t if t is not None else torch.empty(n, dtype=torch.float32, device=device)
+
+
+TRAIN_EPOCH = 0    # bumped by every training forward of a Network and by every TrainStep replay: "the parameters may have been
+                   # updated since" -- an optimizer can do that without moving Tensor._version (torch.optim.Adam(fused=True)
+                   # never does; FusedAdam's increment_version ran once, at capture, not at the replays)
+
+
+def note_training_step():
+    global TRAIN_EPOCH
+    TRAIN_EPOCH += 1
+
+
 class WeightPacker:
     """Packs every dense-conv weight of a model (forward and data-gradient operand images) with ONE kernel
     launch whenever any of them changed (i.e. once per optimizer step) instead of ~820 tiny launches."""
@@ -363,6 +408,7 @@ class WeightPacker:
     def __init__(self, weights):
         self.weights = list(weights)
         self.sig = None
+        self.epoch = -1            # TRAIN_EPOCH the images were last written at
         self.table = None
         self.outs = None
         self.key = None
@@ -406,11 +452,12 @@ class WeightPacker:
                 return        # unusual storage: leave it to the per-call path
             self._build(dtype, device)
             self.sig = None
-        if sig == self.sig and not force:
-            return
+        if sig == self.sig and not force and self.epoch == TRAIN_EPOCH:
+            return         # (eval forward: no version moved AND no training step ran since the images were written)
         check(lib().npp_pack_weights_batched_map(self.table.data_ptr(), 2 * len(ws), self.block_job.data_ptr(), self.nblocks,
                                                  stream_ptr()), "npp_pack_weights_batched_map")
         self.sig = sig
+        self.epoch = TRAIN_EPOCH
         k = 0
         for w in ws:
             wid = id(w)
@@ -491,7 +538,7 @@ class _Conv2d(Function):
         _conv_launch(x, wp.data_ptr(), ptr(bf), None, y, ptr(stats), g, stream_ptr(), "npp_conv_fwd")
         if SHAPE_LOG is not None:
             SHAPE_LOG.append(("fwd", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (stride, pad, dil, relu_in, bias is not None)
         ctx.set_materialize_grads(False)     # no zero tensor for the (non-differentiable) statistics output
         if stats is not None:
@@ -502,7 +549,7 @@ class _Conv2d(Function):
     def backward(ctx, dy, _dstats):
         if dy is None:
             return (None,) * 9
-        x, weight = ctx.saved_tensors
+        x, weight, bias = ctx.saved_tensors
         stride, pad, dil, relu_in, has_bias = ctx.cfg
         dy = to_nhwc(dy)
         if dy.dtype != x.dtype:
@@ -525,12 +572,16 @@ class _Conv2d(Function):
             g = geom(kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 1, relu_in)
             if kh == 1 and kw == 1 and ci % 64 == 0 and co % 32 == 0:
                 # packed [co][ci] == OIHW: accumulate straight into the gradient tensor
-                dw = zeros_f32(weight.numel(), x.device).view(weight.shape)     # pre-zeroed pool slice: no fill launch
+                dw = grad_out(weight, zero=True)            # the parameter's (zeroed) slot in its gradient bucket, or
+                if dw is None:
+                    dw = zeros_f32(weight.numel(), x.device).view(weight.shape)     # pre-zeroed pool slice: no fill launch
                 check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
             else:
                 dwp = zeros_f32(nel, x.device)
                 check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
-                dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                dw = grad_out(weight)
+                if dw is None:
+                    dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
                 check(lib().npp_unpack_wgrad(dwp.data_ptr(), co, ci, kh, kw, dw.data_ptr(), s), "npp_unpack_wgrad")
             if SHAPE_LOG is not None:
                 SHAPE_LOG.append(("wgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
@@ -539,7 +590,7 @@ class _Conv2d(Function):
         if has_bias and ctx.needs_input_grad[2]:
             acc = zeros_f64(R * co, x.device)
             check(lib().npp_channel_sum(_byref(dy), acc.data_ptr(), s), "npp_channel_sum")
-            db = torch.empty(co, dtype=torch.float32, device=x.device)
+            db = _grad_buf(bias, co, x.device)
             check(lib().npp_sum_replicas(acc.data_ptr(), R, co, db.data_ptr(), s), "npp_sum_replicas")
         return dx, dw, db, None, None, None, None, None, None
 
@@ -597,7 +648,9 @@ class _DwConv2d(Function):
             check(lib().npp_dwconv_bwd_data(_byref(dy), wf.data_ptr(), _byref(x) if relu_in else None, _byref(dx),
                                             C.byref(g), s), "npp_dwconv_bwd_data")
         if ctx.needs_input_grad[1]:
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            dw = grad_out(weight)
+            if dw is None:
+                dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
             nws = lib().npp_dwconv_bwd_weight_ws(_byref(dy), C.byref(g))
             if lib().npp_dwconv_bwd_weight_ws_zeroed(_byref(dy), C.byref(g)):
                 ws = zeros_f32(nws, x.device)
@@ -639,10 +692,13 @@ class BnSide:
 
 
 _SYNC_EVEN_ALONE = False   # test hook: run the SyncBN collectives on a 1-rank group (bench.py --force-dist)
+SYNC_OFF = False           # ablation (bench.py `exposed_comm_ms`, NPP_LOCAL_BN of SURVEY §8e): SyncBatchNorm modules use LOCAL statistics
 
 
 def _sync_group(bn):
     """SyncBatchNorm (augment_lip_sync.py:191) -> the process group to reduce statistics over."""
+    if SYNC_OFF:
+        return None, 1
     if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
         grp = bn.process_group
         ws = dist.get_world_size(grp) if grp is not None else dist.get_world_size()
@@ -811,18 +867,23 @@ class _BnAdd(Function):
                                            sums.data_ptr(), nb, s), "npp_bn_bwd_reduce2")
             co = torch.empty(6 * c, dtype=torch.float32, device=dev)
             dgb_ = torch.empty(4 * c, dtype=torch.float32, device=dev)
+            dgb_ = [dgb_[:c], dgb_[c:2 * c], dgb_[2 * c:3 * c], dgb_[3 * c:]]
+            for i_, prm in enumerate((bna.weight, bna.bias, bnb.weight, bnb.bias)):
+                slot = grad_out(prm) if ni[(1, 2, 4, 5)[i_]] else None
+                if slot is not None:
+                    dgb_[i_] = slot
             ga = bna.weight.detach() if bna.weight is not None else None
             gb = bnb.weight.detach() if bnb.weight is not None else None
             check(lib().npp_bn_bwd_coeffs2(sums.data_ptr(), nb, float(cnt_a), mia.data_ptr(), mib.data_ptr(), ptr(ga), ptr(gb),
-                                           co[:3 * c].data_ptr(), co[3 * c:].data_ptr(), dgb_[:c].data_ptr(),
-                                           dgb_[c:2 * c].data_ptr(), dgb_[2 * c:3 * c].data_ptr(), dgb_[3 * c:].data_ptr(), c, s),
+                                           co[:3 * c].data_ptr(), co[3 * c:].data_ptr(), dgb_[0].data_ptr(),
+                                           dgb_[1].data_ptr(), dgb_[2].data_ptr(), dgb_[3].data_ptr(), c, s),
                   "npp_bn_bwd_coeffs2")
             dxa = new_nhwc(*a.shape, a.dtype, dev)
             dxb = new_nhwc(*b.shape, b.dtype, dev)
             check(lib().npp_bn_bwd_apply2(_byref(dout), _byref(a), _byref(b), tref(yrelu), co[:3 * c].data_ptr(),
                                           co[3 * c:].data_ptr(), _byref(dxa), _byref(dxb), s), "npp_bn_bwd_apply2")
-            return (dxa, dgb_[:c] if ni[1] else None, dgb_[c:2 * c] if ni[2] else None,
-                    dxb, dgb_[2 * c:3 * c] if ni[4] else None, dgb_[3 * c:] if ni[5] else None, None, None, None, None, None)
+            return (dxa, dgb_[0] if ni[1] else None, dgb_[1] if ni[2] else None,
+                    dxb, dgb_[2] if ni[4] else None, dgb_[3] if ni[5] else None, None, None, None, None, None)
         sides = [(a, bna, mia, ssa, batch_a, cnt_a, ni[0], ni[1], ni[2])]
         if has_b:
             sides.append((b, bnb, mib, ssb, batch_b, cnt_b, ni[3], ni[4], ni[5]))
@@ -842,10 +903,13 @@ class _BnAdd(Function):
             tot = torch.empty(sum(2 * c for _, _, c in sync), dtype=torch.float64, device=dout.device)
             off = 0
             for i, grp, c in sync:
-                dgl = torch.empty(2 * c, dtype=torch.float32, device=dout.device)
+                bn_i = sides[i][1]
+                need_g_, need_b_ = sides[i][7], sides[i][8]
+                dgl = (_grad_buf(bn_i.weight if need_g_ else None, c, dout.device),
+                       _grad_buf(bn_i.bias if need_b_ else None, c, dout.device))
                 part = tot[off:off + 2 * c]
-                check(lib().npp_bn_bwd_sum(red[i][0].data_ptr(), red[i][1], part.data_ptr(), dgl[:c].data_ptr(),
-                                           dgl[c:].data_ptr(), c, s), "npp_bn_bwd_sum")
+                check(lib().npp_bn_bwd_sum(red[i][0].data_ptr(), red[i][1], part.data_ptr(), dgl[0].data_ptr(),
+                                           dgl[1].data_ptr(), c, s), "npp_bn_bwd_sum")
                 local[i] = dgl
                 red[i] = (part, 1)
                 off += 2 * c
@@ -867,10 +931,10 @@ class _BnAdd(Function):
             if batch:
                 dgt = dbt = None
                 if local[i] is not None:
-                    dg, db = local[i][:c], local[i][c:]
+                    dg, db = local[i]
                 else:
-                    dgt = torch.empty(c, dtype=torch.float32, device=x.device)
-                    dbt = torch.empty(c, dtype=torch.float32, device=x.device)
+                    dgt = _grad_buf(bn.weight if need_g else None, c, x.device)
+                    dbt = _grad_buf(bn.bias if need_b else None, c, x.device)
                     dg, db = dgt, dbt
                 co = torch.empty(3 * c, dtype=torch.float32, device=x.device)
                 check(lib().npp_bn_bwd_coeffs(sums.data_ptr(), nrep, float(count), mi.data_ptr(), ptr(gamma), co.data_ptr(),
@@ -1022,12 +1086,12 @@ class _SEScale(Function):
                                     hidden.data_ptr(), gate.data_ptr(), n, c, s), "npp_se_gate_fwd")
         y = new_nhwc(n, c, h, w, x.dtype, dev)
         check(lib().npp_scale_channels(_byref(x), gate.data_ptr(), _byref(y), s), "npp_scale_channels")
-        ctx.save_for_backward(x, w1, w2, pooled, hidden, gate)
+        ctx.save_for_backward(x, w1, w2, pooled, hidden, gate, b1, b2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w1, w2, pooled, hidden, gate = ctx.saved_tensors
+        x, w1, w2, pooled, hidden, gate, b1, b2 = ctx.saved_tensors
         dy = to_nhwc(dy)
         if dy.dtype != x.dtype:
             dy = cast(dy, x.dtype)
@@ -1036,10 +1100,10 @@ class _SEScale(Function):
         s = stream_ptr()
         dgate = zeros_f32(n * c, dev).view(n, c)
         check(lib().npp_se_bwd_reduce(_byref(dy), _byref(x), dgate.data_ptr(), s), "npp_se_bwd_reduce")
-        dw1 = torch.empty(w1.shape, dtype=torch.float32, device=dev)
-        db1 = torch.empty(c // 2, dtype=torch.float32, device=dev)
-        dw2 = torch.empty(w2.shape, dtype=torch.float32, device=dev)
-        db2 = torch.empty(c, dtype=torch.float32, device=dev)
+        dw1 = _grad_buf(w1, w1.numel(), dev).view(w1.shape)
+        db1 = _grad_buf(b1, c // 2, dev)
+        dw2 = _grad_buf(w2, w2.numel(), dev).view(w2.shape)
+        db2 = _grad_buf(b2, c, dev)
         dpooled = torch.empty((n, c), dtype=torch.float32, device=dev)
         scratch = torch.empty((n, c + c // 2), dtype=torch.float32, device=dev)
         w1f, w2f = w1.detach().float().contiguous(), w2.detach().float().contiguous()
@@ -1060,29 +1124,29 @@ def se_scale(x, w1, b1, w2, b2):
 # --------------------------------------------------------------------------------------------------
 class _Bilinear(Function):
     @staticmethod
-    def forward(ctx, x, oh, ow):
+    def forward(ctx, x, oh, ow, align_corners):
         x = to_nhwc(x)
         n, c, h, w = x.shape
         y = new_nhwc(n, c, oh, ow, x.dtype, x.device)
-        check(lib().npp_bilinear_fwd(_byref(x), _byref(y), stream_ptr()), "npp_bilinear_fwd")
-        ctx.cfg = (tuple(x.shape), x.dtype)
+        check(lib().npp_bilinear_fwd_ac(_byref(x), _byref(y), int(align_corners), stream_ptr()), "npp_bilinear_fwd")
+        ctx.cfg = (tuple(x.shape), x.dtype, int(align_corners))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xshape, dtype = ctx.cfg
+        xshape, dtype, ac = ctx.cfg
         dy = to_nhwc(dy)
         if dy.dtype != dtype:
             dy = cast(dy, dtype)
         dx = new_nhwc(*xshape, dtype, dy.device)
-        check(lib().npp_bilinear_bwd(_byref(dy), _byref(dx), stream_ptr()), "npp_bilinear_bwd")
-        return dx, None, None
+        check(lib().npp_bilinear_bwd_ac(_byref(dy), _byref(dx), ac, stream_ptr()), "npp_bilinear_bwd")
+        return dx, None, None, None
 
 
-def bilinear(x, oh: int, ow: int):
+def bilinear(x, oh: int, ow: int, align_corners: bool = True):
     if x.shape[2] == oh and x.shape[3] == ow:
-        return x   # align_corners identity resample (Interpolate(1.0), model_augment.py:638-645) is exact
-    return _Bilinear.apply(take(x), int(oh), int(ow))
+        return x   # identity resample (Interpolate(1.0), model_augment.py:638-645) is exact with either convention
+    return _Bilinear.apply(take(x), int(oh), int(ow), bool(align_corners))
 
 
 def interpolate_scale(x, scale: float):
@@ -1306,30 +1370,33 @@ def nhwc_to_nchw_f32(x):
 # loss heads
 # --------------------------------------------------------------------------------------------------
 class _MseSse(Function):
-    """sum((pred - target)^2) as an f32 scalar; target is f32 NCHW-contiguous."""
+    """sum((w * (pred - target))^2) as an f32 scalar; target is f32 NCHW-contiguous, w (optional) f32 [N, C]."""
 
     @staticmethod
-    def forward(ctx, pred, target):
+    def forward(ctx, pred, target, weight):
         pred = to_nhwc(pred)
         tgt = target.detach()
         if tgt.dtype != torch.float32 or not tgt.is_contiguous():
             tgt = tgt.float().contiguous()
+        wt = None
+        if weight is not None:
+            wt = weight.detach().reshape(pred.shape[0], pred.shape[1]).float().contiguous()
         sse = torch.zeros(1, dtype=torch.float64, device=pred.device)
-        check(lib().npp_mse_fwd(_byref(pred), tgt.data_ptr(), sse.data_ptr(), stream_ptr()), "npp_mse_fwd")
-        ctx.save_for_backward(pred, tgt)
+        check(lib().npp_mse_w_fwd(_byref(pred), tgt.data_ptr(), ptr(wt), sse.data_ptr(), stream_ptr()), "npp_mse_fwd")
+        ctx.save_for_backward(pred, tgt, wt)
         return sse.float().reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        pred, tgt = ctx.saved_tensors
+        pred, tgt, wt = ctx.saved_tensors
         gs = g.detach().float().reshape(1).contiguous()
         grad = new_nhwc(*pred.shape, pred.dtype, pred.device)
-        check(lib().npp_mse_bwd(_byref(pred), tgt.data_ptr(), gs.data_ptr(), _byref(grad), stream_ptr()), "npp_mse_bwd")
-        return grad, None
+        check(lib().npp_mse_w_bwd(_byref(pred), tgt.data_ptr(), ptr(wt), gs.data_ptr(), _byref(grad), stream_ptr()), "npp_mse_bwd")
+        return grad, None, None
 
 
-def mse_sse(pred, target):
-    return _MseSse.apply(take(pred), target)
+def mse_sse(pred, target, weight=None):
+    return _MseSse.apply(take(pred), target, weight)
 
 
 class _UpsampledCE(Function):

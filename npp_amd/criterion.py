@@ -54,20 +54,27 @@ class Criterion_pose(nn.Module):
 
     def joint_loss(self, output, target, target_weight=None):
         """sum_j MSE(pred_j, gt_j) over main (+ aux) maps / num_joints, criterion.py:82-128.
-        Every per-joint MSE is a mean over N*H*W elements, so the sum over joints is SSE / (N*H*W)."""
-        if self.use_target_weight:
-            raise NotImplementedError("use_target_weight=True is not used by either launcher "
-                                      "(augment_lip_sync.py:187, search_lip_sync.py) and is not implemented")
-        outs = output if isinstance(output, list) else [output]
-        tgts = target if isinstance(target, list) else [target]
-        if not isinstance(output, list):
-            tgts = tgts[:1]
+        Every per-joint MSE is a mean over N*H*W elements, so the sum over joints is SSE / (N*H*W); with
+        `use_target_weight` prediction and target of (image n, joint j) are both scaled by target_weight[n, j]
+        (criterion.py:103-108).  A heat-map whose size differs from its target's is resampled like
+        `F.interpolate(size=(h, w), mode='bilinear')` (align_corners=False), (h, w) = the MAIN target's size -- also for
+        the auxiliary map, exactly as criterion.py:92-96, 113-115 do."""
+        if isinstance(output, list):
+            outs, tgts = [output[0], output[1]], [target[0], target[1]]
+        else:
+            outs, tgts = [output], [target[0] if isinstance(target, list) else target]
         J = outs[0].size(1)
+        h, w = tgts[0].shape[2:]
+        wt = None
+        if self.use_target_weight:
+            if target_weight is None:
+                raise ValueError("Criterion_pose(use_target_weight=True) needs target_weight [N, num_joints, 1]")
+            wt = target_weight
         loss = 0.
         for o, t in zip(outs, tgts):
             if tuple(o.shape[2:]) != tuple(t.shape[2:]):
-                raise NotImplementedError("heat-map / target size mismatch (criterion.py:95 resamples; unused)")
-            loss = loss + K.mse_sse(o, t) / float(o.size(0) * o.size(2) * o.size(3))
+                o = K.bilinear(o, int(h), int(w), align_corners=False)
+            loss = loss + K.mse_sse(o, t, wt) / float(o.size(0) * o.size(2) * o.size(3))
         return loss / J
 
     def forward(self, output, target, target_weight=None):

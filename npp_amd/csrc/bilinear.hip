@@ -1,4 +1,4 @@
-// Bilinear resampling with align_corners=True (any size ratio, up or down), NHWC channel vectors.
+// Bilinear resampling (align_corners=True, or False for core/criterion.py:95; any size ratio, up or down), NHWC channel vectors.
 // Forward = 4-tap gather.  Backward is ALSO a gather (no atomics, deterministic): every input pixel
 // walks the output pixels whose source coordinate falls within one pixel of it and re-derives the
 // forward weights with the same float arithmetic.
@@ -15,8 +15,11 @@
 
 namespace {
 
-NPP_DEV void src_index(float scale, int o, int in_size, int& i0, int& i1p, float& l0, float& l1) {
-  const float s = scale * (float)o;           // area_pixel_compute_source_index, align_corners=True
+// area_pixel_compute_source_index: align_corners=True: off = 0, scale = (in-1)/(out-1); align_corners=False: off = 0.5,
+// scale = in/out, negative coordinates clamp to 0
+NPP_DEV void src_index(float scale, float off, int o, int in_size, int& i0, int& i1p, float& l0, float& l1) {
+  float s = scale * ((float)o + off) - off;
+  if (s < 0.f) s = 0.f;
   i0 = (int)s;
   if (i0 > in_size - 1) i0 = in_size - 1;
   i1p = (i0 < in_size - 1) ? 1 : 0;
@@ -26,7 +29,7 @@ NPP_DEV void src_index(float scale, int o, int in_size, int& i0, int& i1p, float
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
-                                                           int N, int H, int W, int OH, int OW, int cv, float sh, float sw) {
+                                                           int N, int H, int W, int OH, int OW, int cv, float sh, float sw, float off) {
   const long total = (long)N * OH * OW * cv;
   const FastDiv fd((unsigned)cv);
   for (unsigned i = VBLOCK * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
@@ -38,8 +41,8 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__
     const int oh = (int)(t2 % OH), n = (int)(t2 / OH);
     int h0, hp, w0, wp;
     float lh0, lh1, lw0, lw1;
-    src_index(sh, oh, H, h0, hp, lh0, lh1);
-    src_index(sw, ow, W, w0, wp, lw0, lw1);
+    src_index(sh, off, oh, H, h0, hp, lh0, lh1);
+    src_index(sw, off, ow, W, w0, wp, lw0, lw1);
     const T* b = x + ((long)(n * H + h0) * W + w0) * ldx + c0;
     float v00[V], v01[V], v10[V], v11[V], o[V];
     ldv<T, V>(b, v00);
@@ -53,21 +56,22 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__
   }
 }
 
-NPP_DEV void contrib_range(float scale, int i, int out_size, int& lo, int& hi) {
+NPP_DEV void contrib_range(float scale, float off, int i, int out_size, int& lo, int& hi) {
   if (scale <= 0.f) { lo = 0; hi = out_size - 1; return; }
-  // outputs o with source coordinate scale*o in [i-1, i+1): floor / ceil already leave one candidate of slack on each side
-  // (its weight is recomputed exactly and comes out 0); every extra candidate is an extra 16-byte load per lane
+  // outputs o with source coordinate scale*(o+off)-off in [i-1, i+1): floor / ceil already leave one candidate of slack on
+  // each side (its weight is recomputed exactly and comes out 0); every extra candidate is an extra 16-byte load per lane.
+  // (coordinates clamped up to 0 belong to i = 0, whose range starts at 0 anyway)
   const float inv = 1.f / scale;
-  lo = (int)floorf(((float)i - 1.f) * inv);
-  hi = (int)ceilf(((float)i + 1.f) * inv);
+  lo = (int)floorf(((float)i - 1.f + off) * inv - off);
+  hi = (int)ceilf(((float)i + 1.f + off) * inv - off);
   if (lo < 0) lo = 0;
   if (hi > out_size - 1) hi = out_size - 1;
 }
 
-NPP_DEV float contrib_weight(float scale, int o, int i, int in_size) {
+NPP_DEV float contrib_weight(float scale, float off, int o, int i, int in_size) {
   int i0, ip;
   float l0, l1;
-  src_index(scale, o, in_size, i0, ip, l0, l1);
+  src_index(scale, off, o, in_size, i0, ip, l0, l1);
   float w = 0.f;
   if (i0 == i) w += l0;
   if (i0 + ip == i) w += (ip ? l1 : l1);   // ip == 0: the second tap aliases the first (weight l1 on i0)
@@ -76,7 +80,7 @@ NPP_DEV float contrib_weight(float scale, int o, int i, int in_size) {
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ dy, long ldy, T* __restrict__ dx, long ldx,
-                                                           int N, int H, int W, int OH, int OW, int cv, float sh, float sw) {
+                                                           int N, int H, int W, int OH, int OW, int cv, float sh, float sw, float off) {
   const long total = (long)N * H * W * cv;
   const FastDiv fd((unsigned)cv);
   for (unsigned i = VBLOCK * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
@@ -87,22 +91,22 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
     const long t2 = p / W;
     const int ih = (int)(t2 % H), n = (int)(t2 / H);
     int hlo, hhi, wlo, whi;
-    contrib_range(sh, ih, OH, hlo, hhi);
-    contrib_range(sw, iw, OW, wlo, whi);
+    contrib_range(sh, off, ih, OH, hlo, hhi);
+    contrib_range(sw, off, iw, OW, wlo, whi);
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
     // four output columns per step, loads first and unconditional (a column past the range re-reads the last one with
     // weight 0): a load behind `if (weight != 0)` is serialised by the compiler (one load in flight per lane)
     for (int oh = hlo; oh <= hhi; ++oh) {
-      const float wh = contrib_weight(sh, oh, ih, H);
+      const float wh = contrib_weight(sh, off, oh, ih, H);
       const T* row = dy + ((long)(n * OH + oh) * OW) * ldy + c0;
       for (int ow = wlo; ow <= whi; ow += 4) {
         float d[4][V], w4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int o = ow + u <= whi ? ow + u : whi;
-          w4[u] = (ow + u <= whi) ? wh * contrib_weight(sw, o, iw, W) : 0.f;
+          w4[u] = (ow + u <= whi) ? wh * contrib_weight(sw, off, o, iw, W) : 0.f;
           ldv<T, V>(row + (long)o * ldy, d[u]);
         }
 #pragma unroll
@@ -117,11 +121,12 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
 
 }  // namespace
 
-static inline float ac_scale(long in_size, long out_size) {
+static inline float rs_scale(long in_size, long out_size, int align_corners) {
+  if (!align_corners) return (float)in_size / (float)out_size;
   return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
 }
 
-extern "C" int npp_bilinear_fwd(const NppTensor* x, NppTensor* y, void* stream) {
+extern "C" int npp_bilinear_fwd_ac(const NppTensor* x, NppTensor* y, int align_corners, void* stream) {
   NPP_REQUIRE(x && y && x->ptr && y->ptr, NPP_E_NULL, "npp_bilinear_fwd: null pointer");
   NPP_REQUIRE(dtype_ok(x) && x->dtype == y->dtype, NPP_E_DTYPE, "npp_bilinear_fwd: dtype mismatch");
   NPP_REQUIRE(x->n == y->n && x->c == y->c && y->h > 0 && y->w > 0, NPP_E_SHAPE, "npp_bilinear_fwd: shape mismatch");
@@ -132,12 +137,14 @@ extern "C" int npp_bilinear_fwd(const NppTensor* x, NppTensor* y, void* stream) 
     const int cv = (int)(x->c / V);
     hipLaunchKernelGGL((bilinear_fwd_kernel<T, V>), dim3(grid_for(npix(y) * cv)), dim3(256), 0, s, (const T*)x->ptr,
                        (long)x->ld, (T*)y->ptr, (long)y->ld, (int)x->n, (int)x->h, (int)x->w, (int)y->h, (int)y->w, cv,
-                       ac_scale(x->h, y->h), ac_scale(x->w, y->w));
+                       rs_scale(x->h, y->h, align_corners), rs_scale(x->w, y->w, align_corners), align_corners ? 0.f : 0.5f);
   });
   return npp_check_launch("bilinear_fwd");
 }
 
-extern "C" int npp_bilinear_bwd(const NppTensor* dy, NppTensor* dx, void* stream) {
+extern "C" int npp_bilinear_fwd(const NppTensor* x, NppTensor* y, void* stream) { return npp_bilinear_fwd_ac(x, y, 1, stream); }
+
+extern "C" int npp_bilinear_bwd_ac(const NppTensor* dy, NppTensor* dx, int align_corners, void* stream) {
   NPP_REQUIRE(dy && dx && dy->ptr && dx->ptr, NPP_E_NULL, "npp_bilinear_bwd: null pointer");
   NPP_REQUIRE(dtype_ok(dy) && dx->dtype == dy->dtype, NPP_E_DTYPE, "npp_bilinear_bwd: dtype mismatch");
   NPP_REQUIRE(dx->n == dy->n && dx->c == dy->c, NPP_E_SHAPE, "npp_bilinear_bwd: shape mismatch");
@@ -148,7 +155,10 @@ extern "C" int npp_bilinear_bwd(const NppTensor* dy, NppTensor* dx, void* stream
     const int cv = (int)(dx->c / V);
     hipLaunchKernelGGL((bilinear_bwd_kernel<T, V>), dim3(grid_for(npix(dx) * cv)), dim3(256), 0, s, (const T*)dy->ptr,
                        (long)dy->ld, (T*)dx->ptr, (long)dx->ld, (int)dx->n, (int)dx->h, (int)dx->w, (int)dy->h, (int)dy->w,
-                       cv, ac_scale(dx->h, dy->h), ac_scale(dx->w, dy->w));
+                       cv, rs_scale(dx->h, dy->h, align_corners), rs_scale(dx->w, dy->w, align_corners),
+                       align_corners ? 0.f : 0.5f);
   });
   return npp_check_launch("bilinear_bwd");
 }
+
+extern "C" int npp_bilinear_bwd(const NppTensor* dy, NppTensor* dx, void* stream) { return npp_bilinear_bwd_ac(dy, dx, 1, stream); }

@@ -8,16 +8,18 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------- MSE
-template <typename T>
+// WT: per-(image, joint) weights w[n * C + c] multiply prediction and target (use_target_weight, core/criterion.py:104-108)
+template <typename T, bool WT>
 __global__ __launch_bounds__(256) void mse_fwd_kernel(const T* __restrict__ pred, long ld, const float* __restrict__ tgt,
-                                                      int C, long HW, long total, double* sse) {
+                                                      const float* __restrict__ wt, int C, long HW, long total, double* sse) {
   __shared__ double red[4];
   double acc = 0.0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     const long p = i / C;
     const long n = p / HW, hw = p - n * HW;
-    const float d = Elt<T>::ld(pred + p * ld + c) - tgt[(n * C + c) * HW + hw];
+    float d = Elt<T>::ld(pred + p * ld + c) - tgt[(n * C + c) * HW + hw];
+    if (WT) d *= wt[n * C + c];
     acc += (double)d * d;
   }
   acc = wave_sum_d(acc);
@@ -26,16 +28,17 @@ __global__ __launch_bounds__(256) void mse_fwd_kernel(const T* __restrict__ pred
   if (threadIdx.x == 0) atomicAdd(sse, red[0] + red[1] + red[2] + red[3]);
 }
 
-template <typename T>
+template <typename T, bool WT>
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const T* __restrict__ pred, long ld, const float* __restrict__ tgt,
-                                                      const float* __restrict__ gscale, T* __restrict__ grad, long ldg, int C,
-                                                      long HW, long total) {
+                                                      const float* __restrict__ wt, const float* __restrict__ gscale,
+                                                      T* __restrict__ grad, long ldg, int C, long HW, long total) {
   const float g = 2.f * gscale[0];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     const long p = i / C;
     const long n = p / HW, hw = p - n * HW;
-    const float d = Elt<T>::ld(pred + p * ld + c) - tgt[(n * C + c) * HW + hw];
+    float d = Elt<T>::ld(pred + p * ld + c) - tgt[(n * C + c) * HW + hw];
+    if (WT) { const float w = wt[n * C + c]; d *= w * w; }
     Elt<T>::st(grad + p * ldg + c, g * d);
   }
 }
@@ -344,34 +347,43 @@ int ce_geom(CeGeom& g, const NppTensor* lg, int H, int W, const char* who) {
 
 }  // namespace
 
-extern "C" int npp_mse_fwd(const NppTensor* pred, const float* target_nchw, double* sse, void* stream) {
+extern "C" int npp_mse_w_fwd(const NppTensor* pred, const float* target_nchw, const float* weight_nc, double* sse, void* stream) {
   NPP_REQUIRE(pred && pred->ptr && target_nchw && sse, NPP_E_NULL, "npp_mse_fwd: null pointer");
   NPP_REQUIRE(dtype_ok(pred), NPP_E_DTYPE, "npp_mse_fwd: bad dtype");
   const long HW = pred->h * pred->w, total = pred->n * HW * pred->c;
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(NPP_FAM_LOSS, pred->dtype, s, 0, (double)total * (esize(pred->dtype) + 4));
-  if (pred->dtype == NPP_BF16)
-    hipLaunchKernelGGL(mse_fwd_kernel<bf16_t>, dim3(grid_for(total, 256, 1024)), dim3(256), 0, s, (const bf16_t*)pred->ptr,
-                       (long)pred->ld, target_nchw, (int)pred->c, HW, total, sse);
-  else
-    hipLaunchKernelGGL(mse_fwd_kernel<float>, dim3(grid_for(total, 256, 1024)), dim3(256), 0, s, (const float*)pred->ptr,
-                       (long)pred->ld, target_nchw, (int)pred->c, HW, total, sse);
+#define MSE_FWD(T_, WT_)                                                                                                   \
+  hipLaunchKernelGGL((mse_fwd_kernel<T_, WT_>), dim3(grid_for(total, 256, 1024)), dim3(256), 0, s, (const T_*)pred->ptr,   \
+                     (long)pred->ld, target_nchw, weight_nc, (int)pred->c, HW, total, sse)
+  if (pred->dtype == NPP_BF16) { if (weight_nc) MSE_FWD(bf16_t, true); else MSE_FWD(bf16_t, false); }
+  else                         { if (weight_nc) MSE_FWD(float, true);  else MSE_FWD(float, false); }
+#undef MSE_FWD
   return npp_check_launch("mse_fwd");
 }
 
-extern "C" int npp_mse_bwd(const NppTensor* pred, const float* target_nchw, const float* gscale, NppTensor* grad, void* stream) {
+extern "C" int npp_mse_fwd(const NppTensor* pred, const float* target_nchw, double* sse, void* stream) {
+  return npp_mse_w_fwd(pred, target_nchw, nullptr, sse, stream);
+}
+
+extern "C" int npp_mse_w_bwd(const NppTensor* pred, const float* target_nchw, const float* weight_nc, const float* gscale,
+                             NppTensor* grad, void* stream) {
   NPP_REQUIRE(pred && pred->ptr && target_nchw && gscale && grad && grad->ptr, NPP_E_NULL, "npp_mse_bwd: null pointer");
   NPP_REQUIRE(dtype_ok(pred) && pred->dtype == grad->dtype, NPP_E_DTYPE, "npp_mse_bwd: dtype mismatch");
   NPP_REQUIRE(same_shape(pred, grad), NPP_E_SHAPE, "npp_mse_bwd: shape mismatch");
   const long HW = pred->h * pred->w, total = pred->n * HW * pred->c;
   hipStream_t s = (hipStream_t)stream;
-  if (pred->dtype == NPP_BF16)
-    hipLaunchKernelGGL(mse_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)pred->ptr, (long)pred->ld,
-                       target_nchw, gscale, (bf16_t*)grad->ptr, (long)grad->ld, (int)pred->c, HW, total);
-  else
-    hipLaunchKernelGGL(mse_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)pred->ptr, (long)pred->ld,
-                       target_nchw, gscale, (float*)grad->ptr, (long)grad->ld, (int)pred->c, HW, total);
+#define MSE_BWD(T_, WT_)                                                                                                   \
+  hipLaunchKernelGGL((mse_bwd_kernel<T_, WT_>), dim3(grid_for(total)), dim3(256), 0, s, (const T_*)pred->ptr, (long)pred->ld, \
+                     target_nchw, weight_nc, gscale, (T_*)grad->ptr, (long)grad->ld, (int)pred->c, HW, total)
+  if (pred->dtype == NPP_BF16) { if (weight_nc) MSE_BWD(bf16_t, true); else MSE_BWD(bf16_t, false); }
+  else                         { if (weight_nc) MSE_BWD(float, true);  else MSE_BWD(float, false); }
+#undef MSE_BWD
   return npp_check_launch("mse_bwd");
+}
+
+extern "C" int npp_mse_bwd(const NppTensor* pred, const float* target_nchw, const float* gscale, NppTensor* grad, void* stream) {
+  return npp_mse_w_bwd(pred, target_nchw, nullptr, gscale, grad, stream);
 }
 
 extern "C" int npp_ce_pixel_fwd(const NppTensor* logits, const int64_t* labels, int H, int W, const float* class_w, int ignore,

@@ -8,20 +8,30 @@ this node:
     tensors of SE_Block.bn when stride == 1, operations.py:117,126-129), so no per-step graph walk
     (`find_unused_parameters`) is needed;
   * buckets are filled in reverse registration order (~ the order gradients appear in backward) and sized
-    for xGMI rings (default 32 MiB: 8 GPUs x 7 links, per-link bound);
+    for xGMI rings (default 16 MiB: 8 GPUs x 7 links, per-link bound);
+  * every bucket is ONE pre-flattened f32 buffer and the gradients are VIEWS of it: the weight-gradient /
+    BatchNorm / bias kernels of this package write their results straight into the parameter's slot
+    (`_ops.grad_out`), autograd installs that view as `p.grad`, the collective reduces the buffer in place
+    and the optimizer reads the averaged views -- no flatten / un-flatten passes over the 308 MB of
+    gradients (a gradient that did not land in its slot, e.g. one made by plain autograd math, is copied in
+    when its bucket closes);
   * a bucket's all-reduce is issued from the autograd thread the moment its last gradient has been
-    accumulated, on a SIDE HIP stream fenced by an event on the compute stream, so the collective overlaps
-    the rest of backward; `finish()` (before optimizer.step) joins the streams and writes the averaged
-    gradients back.
+    accumulated -- eagerly on a SIDE HIP stream fenced by events on the compute streams; inside a hipGraph
+    capture on the capture's ORIGIN stream (the one stream RCCL may be captured on with this ROCm, see
+    `_ops.hub_all_reduce`), which the two task-branch streams only feed with one-way events -- so the
+    collective overlaps the rest of backward; `finish()` (before optimizer.step) joins and averages.
 
 `torch.distributed` is the transport ("nccl" == RCCL on ROCm; "gloo" in the CPU tests).
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional, Set
 
 import torch
 import torch.distributed as dist
+
+from . import _ops as K
 
 
 def unused_parameter_names(model: torch.nn.Module) -> Set[str]:
@@ -36,7 +46,7 @@ def unused_parameter_names(model: torch.nn.Module) -> Set[str]:
 
 
 class _Bucket:
-    __slots__ = ("params", "offsets", "flat", "pending", "work", "numel", "streams")
+    __slots__ = ("params", "offsets", "flat", "pending", "numel", "streams", "taken", "launched")
 
     def __init__(self, params, device, dtype):
         self.params = params
@@ -44,17 +54,23 @@ class _Bucket:
         off = 0
         for p in params:
             self.offsets.append(off)
-            off += p.numel()
+            off += (p.numel() + 3) // 4 * 4        # 16-byte aligned slots (the kernels store vectors)
         self.numel = off
         self.flat = torch.zeros(off, dtype=dtype, device=device)
         self.pending = len(params)
-        self.work = None
+        self.launched = False
+        self.taken = [False] * len(params)
         self.streams = {}      # compute streams the gradients of this bucket were accumulated on (the network runs
                                # its two task branches, and therefore their backward, on two streams)
 
+    def view(self, i):
+        p = self.params[i]
+        o = self.offsets[i]
+        return self.flat[o:o + p.numel()].view(p.shape)
+
 
 class GradReducer:
-    def __init__(self, module: torch.nn.Module, process_group=None, bucket_mb: float = 32.0,
+    def __init__(self, module: torch.nn.Module, process_group=None, bucket_mb: Optional[float] = None,
                  skip: Optional[Iterable[str]] = None, broadcast_parameters: bool = True, always_reduce: bool = False,
                  overlap: bool = True):
         if not (dist.is_available() and dist.is_initialized()):
@@ -62,10 +78,10 @@ class GradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.always = always_reduce      # run the collectives even on a 1-rank group (single-GPU exercise of the path)
-        # overlap=False: the bucket all-reduces are issued by finish() on the caller's stream instead of from the
-        # autograd hooks on a side stream.  Meant for hipGraph capture, where every collective of the step then sits on
-        # the capture's origin stream (the unoverlapped 308 MB all-reduce is ~2 ms on an 8-GPU xGMI node).
-        self.overlap = overlap
+        # overlap=False: every bucket is reduced by finish() on the caller's stream, after backward (NPP_DDP_OVERLAP=0)
+        self.overlap = overlap and os.environ.get("NPP_DDP_OVERLAP", "1") != "0"
+        if bucket_mb is None:
+            bucket_mb = float(os.environ.get("NPP_DDP_BUCKET_MB", "16"))
         skip = set(skip or ())
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and n not in skip]
         self.skipped = sorted(skip)
@@ -88,14 +104,44 @@ class GradReducer:
             self.buckets.append(_Bucket(cur, cur[0].device, cur[0].dtype))
         self._where = {}
         self._hooks = []
+        self._slot_keys = []
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b.params):
                 self._where[p] = (bi, pi)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                if p.is_cuda:
+                    K.register_grad_slot(p, self._slot)
+                    self._slot_keys.append(p.data_ptr())
         dev = self.buckets[0].flat.device if self.buckets else torch.device("cpu")
         self._cuda = dev.type == "cuda"
         self._side = torch.cuda.Stream(device=dev) if self._cuda else None
-        self._launched = 0
+        self._armed = False
+        backend = dist.get_backend(process_group)
+        self._avg = backend == "nccl"        # RCCL averages in the collective; gloo has no AVG: sum, then one scale pass
+
+    # -- gradient slots: the kernels write a parameter's gradient straight into its place in the bucket ---------------------
+    def begin_step(self):
+        """Call after zero_grad(set_to_none=True), before backward: zeroes the buckets (the 1x1 weight-gradient kernels
+        accumulate with atomics) and lets the backward kernels write into them.  Without it every gradient is copied into its
+        slot when its bucket closes (still correct, one more pass)."""
+        if not self._cuda:
+            return
+        for b in self.buckets:
+            b.flat.zero_()
+            b.taken = [False] * len(b.params)
+        self._armed = True
+
+    def _slot(self, p, zero):
+        """`_ops.grad_out` provider: the view of `p`'s bucket slot, once per step (a second gradient of the same parameter
+        must be ADDED by autograd, not overwrite the first)."""
+        if not self._armed:
+            return None
+        bi, pi = self._where[p]
+        b = self.buckets[bi]
+        if b.taken[pi] or b.launched:
+            return None
+        b.taken[pi] = True
+        return b.view(pi)
 
     # called by autograd (possibly on its own thread) right after p.grad has been accumulated
     def _on_grad(self, p):
@@ -108,56 +154,78 @@ class GradReducer:
         if b.pending == 0 and self.overlap:
             self._launch(b)
 
-    def _launch(self, b: _Bucket):
+    def _target_stream(self):
+        """Stream the collectives go to, or None for the current one.  A step that is (to be) replayed as a hipGraph keeps
+        every collective on the capture's origin stream (= the stream Network.forward was called on, `_ops._hub_stream`)."""
+        if not self._cuda:
+            return None
+        if K.GRAPH_TOPOLOGY or torch.cuda.is_current_stream_capturing():
+            return K._hub_stream
+        return self._side
+
+    def _launch(self, b: _Bucket, target="auto"):
+        import contextlib
+        tgt = self._target_stream() if target == "auto" else target
         if self._cuda:
-            # fence the side stream behind every stream that accumulated one of this bucket's gradients
+            # fence the collective's stream behind every stream that accumulated one of this bucket's gradients
+            dst_stream = tgt if tgt is not None else torch.cuda.current_stream()
             for st in b.streams.values():
-                ev = torch.cuda.Event()
-                ev.record(st)
-                self._side.wait_event(ev)
-            b.streams = {}
-            ctx = torch.cuda.stream(self._side)
-        else:
-            import contextlib
-            ctx = contextlib.nullcontext()
+                if st.cuda_stream != dst_stream.cuda_stream:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    dst_stream.wait_event(ev)
+        b.streams = {}
+        ctx = torch.cuda.stream(tgt) if tgt is not None else contextlib.nullcontext()
         with ctx, torch.no_grad():
-            views = [b.flat[o:o + p.numel()].view_as(p) for o, p in zip(b.offsets, b.params)]
-            torch._foreach_copy_(views, [p.grad for p in b.params])
+            src, dst = [], []
+            for i, p in enumerate(b.params):
+                g = p.grad
+                v = b.view(i)
+                if g.data_ptr() != v.data_ptr() or g.dtype != v.dtype or not g.is_contiguous():
+                    src.append(g)
+                    dst.append(v)
+                    p.grad = v
+            if src:
+                torch._foreach_copy_(dst, src)
             if self.world > 1 or self.always:
-                b.work = dist.all_reduce(b.flat, group=self.group, async_op=True)
-        self._launched += 1
+                # the stream-synchronous form: the collective is ordered after, and joined back into, THIS stream (inside a
+                # capture that keeps RCCL's internal stream in a two-way relation with the capture's origin stream only)
+                dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group)
+        b.launched = True
 
     def finish(self):
-        """Join the collectives and install the averaged gradients.  Call once per step after backward()."""
-        scale = 1.0 / self.world
+        """Join the collectives; afterwards every p.grad is the averaged view of its bucket.  Call once per step after
+        backward() and before optimizer.step()."""
         for b in self.buckets:
             if b.pending != 0:
                 missing = [i for i, p in enumerate(b.params) if p.grad is None]
                 raise RuntimeError(f"GradReducer: a bucket never completed ({b.pending} gradients missing, "
                                    f"{len(missing)} parameters without grad): add them to `skip`")
-            if b.work is not None:
-                b.work.wait()
-                b.work = None
-        if not self.overlap:
+        for b in self.buckets:
+            if not b.launched:
+                self._launch(b, target=None)          # overlap=False: here, on the caller's stream
+        if self._cuda:
+            cur, tgt = torch.cuda.current_stream(), self._target_stream()
+            if tgt is not None and tgt.cuda_stream != cur.cuda_stream:
+                cur.wait_stream(tgt)
+        if (self.world > 1 or self.always) and not self._avg:
             with torch.no_grad():
-                for b in self.buckets:
-                    views = [b.flat[o:o + p.numel()].view_as(p) for o, p in zip(b.offsets, b.params)]
-                    torch._foreach_copy_(views, [p.grad for p in b.params])
-                    if self.world > 1 or self.always:
-                        dist.all_reduce(b.flat, group=self.group)
-                    b.streams = {}
-        elif self._cuda:
-            torch.cuda.current_stream().wait_stream(self._side)
-        with torch.no_grad():
-            for b in self.buckets:
-                if self.world > 1 or self.always:
-                    b.flat.mul_(scale)
-                    views = [b.flat[o:o + p.numel()].view_as(p) for o, p in zip(b.offsets, b.params)]
-                    torch._foreach_copy_([p.grad for p in b.params], views)
-                b.pending = len(b.params)
-        self._launched = 0
+                torch._foreach_mul_([b.flat for b in self.buckets], 1.0 / self.world)
+        self.reset()
+
+    def reset(self):
+        """Forget the per-step state (also after a step that was abandoned half way, e.g. a failed hipGraph capture)."""
+        for b in self.buckets:
+            b.pending = len(b.params)
+            b.streams = {}
+            b.launched = False
+            b.taken = [False] * len(b.params)
+        self._armed = False
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for k in self._slot_keys:
+            K.unregister_grad_slot(k)
+        self._slot_keys = []

@@ -488,6 +488,8 @@ class Network(nn.Module):
             self._packer = K.WeightPacker(m.weight for m in self.modules()
                                           if isinstance(m, nn.Conv2d) and m.groups == 1 and id(m.weight) not in skip)
         self._packer.pack_if_stale(dt, x.device, force=self.training)
+        if self.training:
+            K.note_training_step()      # an optimizer step probably follows: the next eval forward must repack
         x = K.image_to_nhwc(x, dt)
         # The pose branch runs on the caller's stream ("A"), the parsing branch on a side stream ("B"); the branches
         # meet at the 4 encoder taps, the 3 decoder stages and the refinement cells.  Kernels of one branch that cannot
@@ -673,7 +675,7 @@ class Network(nn.Module):
 
     def _sync_bn_active(self) -> bool:
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()):
+        if K.SYNC_OFF or not (dist.is_available() and dist.is_initialized()):
             return False
         if dist.get_world_size() <= 1 and not K._SYNC_EVEN_ALONE:
             return False

@@ -293,6 +293,8 @@ class Network(nn.Module):
             self._packer = K.WeightPacker(m.weight for m in self.modules()
                                           if isinstance(m, nn.Conv2d) and m.groups == 1 and id(m.weight) not in skip)
         self._packer.pack_if_stale(dt, x.device, force=self.training)
+        if self.training:
+            K.note_training_step()
         x = K.image_to_nhwc(x, dt)
         # two task branches on two HIP streams, as in model_augment.Network.forward (the pose branch on the caller's)
         from .model_augment import _side_stream, _stream_mode, Network as _AugNet

@@ -77,7 +77,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._dev[1].copy_(pc, non_blocking=True)
         self._nchunks = int(chunks.shape[0])
         if self._step is None:
-            self._step = torch.zeros(1, dtype=torch.int64, device=dev)
+            self._step = torch.full((1,), int(getattr(self, "_loaded_step", 0)), dtype=torch.int64, device=dev)
         self._grad_ptrs = None
 
     @torch.no_grad()
@@ -171,3 +171,36 @@ class FusedAdam(torch.optim.Optimizer):
 
     def device_step_count(self) -> int:
         return int(self._step.item()) if self._step is not None else 0
+
+    # -- checkpointing (augment_lip_sync.py:235,268-278 / search_lip_sync.py:309 save and resume the optimizer) ---------------
+    def state_dict(self):
+        """torch.optim.Adam's layout: the step count lives on the device (`_step`, one counter for all parameters); it is
+        written into every `state[p]['step']` here, so that a checkpoint resumes with the right bias correction -- in this
+        class and in `torch.optim.Adam`."""
+        n = self.device_step_count()
+        for st in self.state.values():
+            if "exp_avg" in st:
+                st["step"] = torch.tensor(float(n), dtype=torch.float32)
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        """Restores moments AND the step count; the job table is rebuilt at the next step (it pointed at the old moment
+        tensors).  A step captured in a hipGraph before this call keeps the old tensors: capture after loading."""
+        super().load_state_dict(state_dict)
+        steps = [float(st["step"]) for st in self.state.values() if "step" in st]
+        dev = None
+        for st in self.state.values():
+            if "exp_avg" in st:
+                dev = st["exp_avg"].device
+                st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32).cpu() if "step" in st else \
+                    torch.zeros((), dtype=torch.float32)
+        n = int(round(max(steps))) if steps else 0
+        if self._step is not None:
+            self._step.fill_(n)
+        elif dev is not None and dev.type == "cuda":
+            self._step = torch.full((1,), n, dtype=torch.int64, device=dev)
+        else:
+            self._loaded_step = n          # parameters not on the GPU yet: applied when the table is first built
+        self._plist = None
+        self._jobs = None
+        self._grad_ptrs = None

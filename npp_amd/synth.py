@@ -107,3 +107,12 @@ def synth_batch(n: int, size: int = 384, num_classes: int = 20, num_joints: int 
     hm_aux, _ = _gauss_maps(r, n, num_joints, hm, 2.0 * sig)
     meta = {"pose_weight": np.ones((n, num_joints, 1), dtype=np.float32)}
     return images, [par, edge], [hm_main, hm_aux], meta
+
+
+def synth_batch_hw(n: int, h: int, w: int, seed: int = 0, rank: int = 0):
+    """A non-square batch: the top-left h x w window of the square batch of side max(h, w) (heat-maps: h/4 x w/4)."""
+    size = max(h, w)
+    images, (par, edge), (hm_main, hm_aux), meta = synth_batch(n, size, seed=seed, rank=rank)
+    return (np.ascontiguousarray(images[:, :, :h, :w]),
+            [np.ascontiguousarray(par[:, :h, :w]), np.ascontiguousarray(edge[:, :h, :w])],
+            [np.ascontiguousarray(hm_main[:, :, :h // 4, :w // 4]), np.ascontiguousarray(hm_aux[:, :, :h // 4, :w // 4])], meta)

@@ -64,6 +64,8 @@ class TrainStep:
             losses_pose = self.criterion_pose(output_pose, labels_pose).unsqueeze(0)
         loss = (losses_par + losses_pose).mean()
         self.optimizer.zero_grad(set_to_none=True)
+        if self.reducer is not None:
+            self.reducer.begin_step()      # the backward kernels write the gradients straight into the reducer's buckets
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
@@ -149,27 +151,26 @@ class TrainStep:
                     loss = self._eager(images, labels_par, labels_pose, pose_weight)
                 torch.cuda.current_stream().wait_stream(self._side)
                 return loss
+            err = None
             try:
                 self._capture(flat, layout)
-            except Exception as exc:      # noqa: BLE001 -- any capture failure: stay eager, on every rank alike
-                sys.stderr.write(f"[npp_amd.TrainStep] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager\n")
-                self.graph, self.use_graph, self._static_in = None, False, None
-                # the half-captured autograd graph pins AccumulateGrad nodes bound to the dead capture streams: let it go
-                self._static_loss = None
-                self.optimizer.zero_grad(set_to_none=True)
-                import gc
-                gc.collect()
-                K.GRAPH_TOPOLOGY = False
-                K.forget_streams()     # side streams that had joined the capture stay in capture mode: use fresh ones
-                K.reset_pools()
-                try:
-                    torch.cuda.synchronize()
-                except Exception:      # noqa: BLE001 -- the failed capture's error may surface once more here
-                    pass
-                from ._lib import lib as _lib_handle
-                _lib_handle().npp_clear_hip_error()     # HIP's sticky last error would fail the next launch check
+            except Exception as exc:      # noqa: BLE001 -- any capture failure: stay eager
+                err = exc
+            # Every rank must take the SAME path from here on: a rank that fell back to eager runs the single-stream issue
+            # order of the SyncBatchNorm exchanges while a replaying rank runs the lockstep order -- mismatched collectives,
+            # i.e. a hang.  So the ranks agree (MIN over a "captured OK" flag, outside any capture) and all fall back if one
+            # of them failed.
+            if err is not None:
+                self._abandon_capture(True)
+            ok = self._all_ranks_ok(err is None)
+            if not ok:
+                if err is None:
+                    err = RuntimeError("another rank failed to capture")
+                    self._abandon_capture(False)
+                sys.stderr.write(f"[npp_amd.TrainStep] hipGraph capture failed ({type(err).__name__}: {err}); running eager\n")
                 return self._eager(images, labels_par, labels_pose, pose_weight)
             self.graph.replay()            # the captured step has not run yet: this executes it on this batch
+            K.note_training_step()
             return self._static_loss
         if self._signature(flat, layout) != self._sig:
             return self._eager(images, labels_par, labels_pose, pose_weight)       # e.g. the short last batch
@@ -185,7 +186,40 @@ class TrainStep:
             refresh()
             self._hyper = hyper
         self.graph.replay()
+        K.note_training_step()         # parameters changed behind Tensor._version: derived images (packed weights) are stale
         return self._static_loss
+
+    def _abandon_capture(self, failed_here: bool):
+        """Back to the eager path for good (on every rank alike, see __call__)."""
+        self.graph, self.use_graph, self._static_in = None, False, None
+        # the half-captured autograd graph pins AccumulateGrad nodes bound to the dead capture streams: let it go
+        self._static_loss = None
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.reducer is not None:
+            self.reducer.reset()       # bucket counters of the abandoned backward
+        import gc
+        gc.collect()
+        K.GRAPH_TOPOLOGY = False
+        if failed_here:
+            K.forget_streams()         # side streams that had joined the capture stay in capture mode: use fresh ones
+        K.reset_pools()
+        try:
+            torch.cuda.synchronize()
+        except Exception:      # noqa: BLE001 -- the failed capture's error may surface once more here
+            pass
+        from ._lib import lib as _lib_handle
+        _lib_handle().npp_clear_hip_error()     # HIP's sticky last error would fail the next launch check
+
+    def _all_ranks_ok(self, ok_here: bool) -> bool:
+        """True iff EVERY rank of the default process group reports ok_here (single process: ok_here)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() <= 1:
+            return ok_here
+        if dist.get_backend() == "nccl":
+            flag = torch.tensor([1 if ok_here else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            flag = torch.tensor([1 if ok_here else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
 
     @property
     def static_inputs(self):

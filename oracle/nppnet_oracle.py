@@ -243,6 +243,29 @@ def fuse_cell(c, pre, s0, s1, s2, geno):
     return torch.cat(st[0:3], dim=1), torch.cat(st[3:7], dim=1)
 
 
+def cell_case(c, pre, spec, xs):
+    """One entry of oracle/cases.py CELL_CASES on the inputs `xs` (None where the case has no such input); returns the list
+    of outputs.  `pre` is the state-dict prefix of the block."""
+    kind = spec["kind"]
+    if kind == "cell":
+        a = spec["args"]
+        return [cell(c, pre, xs[0], xs[1], a[3], a[4])]
+    if kind == "upsample":
+        return [upsample_cell(c, pre, xs[0], xs[1], DEC_UP1 if spec["which"] == 1 else DEC_UP2)]
+    if kind in ("pose", "par"):
+        return list(fuse_cell(c, pre, xs[0], xs[1], xs[2], FUSE_POSE if kind == "pose" else FUSE_PAR))
+    geno = {1: INTER_T1, 2: INTER_T2, 3: INTER_T3, 4: INTER_T4}[spec["task"]][spec["stage"]]
+    st = spec["stage"]
+    res = [1, 1 / 2, 1 / 4, 1 / 8, 1 / 4, 1 / 2, 1]
+    z = 0
+    for j, (name, ind) in enumerate(geno):
+        if kind == "inter":            # Network._compile, model_augment.py:576-599
+            z = z + _inter_op(c, f'{pre}{j}.', name, xs[ind], ind != st, 1 / 2 ** (st - ind))
+        else:                          # Network._compile3, model_augment.py:626-649
+            z = z + _inter_op(c, f'{pre}{j}.', name, xs[ind], ind != 4 + st, res[4 + st] / res[ind])
+    return [z]
+
+
 # ---- network (models/model_augment.py:231-574) -------------------------------------------
 def _stem(c, pre, x, stride, relu):
     y = bn(c, pre + '1.', F.conv2d(x, c[pre + '0.weight'], None, stride, 1))
@@ -394,23 +417,31 @@ def criterion_par(par_list, target, lamda, **kw):
     return loss
 
 
-def joint_loss(output, target):
-    """Criterion_pose.joint_loss, core/criterion.py:82-128 with use_target_weight=False:
-    sum over joints of MSE(mean over batch*pixels), main + aux, / num_joints."""
+def joint_loss(output, target, target_weight=None):
+    """Criterion_pose.joint_loss, core/criterion.py:82-128: sum over joints of MSE(mean over batch*pixels), main + aux,
+    / num_joints.  target_weight [N, J, 1] (use_target_weight=True, :103-108): prediction and target of (n, j) are both
+    multiplied by it.  A map whose size differs from its target's is resampled to the MAIN target's size with
+    F.interpolate(mode='bilinear') (align_corners=False), :92-96 and :113-115."""
     J = output[0].shape[1]
+    h, w = target[0].shape[2:]
     loss = 0.
     for o, t in zip(output, target):
+        if o.shape[2:] != t.shape[2:]:
+            o = F.interpolate(o, size=(h, w), mode='bilinear')
         n = o.shape[0]
         for j in range(J):
-            loss = loss + F.mse_loss(o[:, j].reshape(n, -1).squeeze(), t[:, j].reshape(n, -1).squeeze())
+            a, b = o[:, j].reshape(n, -1), t[:, j].reshape(n, -1)
+            if target_weight is not None:
+                a, b = a * target_weight[:, j], b * target_weight[:, j]
+            loss = loss + F.mse_loss(a.squeeze(), b.squeeze())
     return loss / J
 
 
-def criterion_pose(pose_list, target, lamda):
+def criterion_pose(pose_list, target, lamda, target_weight=None):
     """Criterion_pose.forward, core/criterion.py:130-145."""
     loss = 0.
     for i, p in enumerate(pose_list):
-        loss = loss + joint_loss(p, target) * torch.exp(-lamda[i]) + lamda[i]
+        loss = loss + joint_loss(p, target, target_weight) * torch.exp(-lamda[i]) + lamda[i]
     return loss
 
 

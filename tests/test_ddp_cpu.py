@@ -81,3 +81,24 @@ def test_unused_parameter_names_cover_se_block_bn():
     g = load_golden("tiny_net.npz")
     assert names == set(str(k) for k in g["train/no_grad_keys"])   # the reference's never-produced gradients
     assert len(names) == 116
+
+
+def _agree_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from npp_amd.train_step import TrainStep
+    ts = TrainStep.__new__(TrainStep)           # only the agreement helper is exercised here (no GPU in this test)
+    got = [ts._all_ranks_ok(True), ts._all_ranks_ok(rank != 1), ts._all_ranks_ok(False)]
+    torch.save(got, f"{out}/a{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_capture_agreement_is_unanimous(tmp_path):
+    """TrainStep's "captured OK" vote (train_step.py:_all_ranks_ok): one failing rank sends EVERY rank to the eager path --
+    a rank replaying the lockstep collective order next to a rank issuing the single-stream order would hang."""
+    world, port = 2, 31500 + os.getpid() % 1000
+    mp.spawn(_agree_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.load(f"{tmp_path}/a{r}.pt") == [True, False, False]

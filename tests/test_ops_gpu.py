@@ -19,7 +19,8 @@ OPS_NAMES = ['none', 'avg_pool_3x3', 'max_pool_3x3', 'skip_connect', 'std_conv_3
 
 
 def _dev():
-    assert torch.cuda.is_available(), "these tests need the MI355X"
+    if not torch.cuda.is_available():
+        pytest.skip("these tests need the MI355X (no GPU visible)")
     return torch.device("cuda:0")
 
 
@@ -320,3 +321,231 @@ def test_two_stream_forward_equals_single_stream(monkeypatch):
             # IDENTICAL runs (same mode, same process) falling into one of two states 1.25e-2 apart (par_head.1.1.weight,
             # cells1.1._ops.1.conv1.*); a missing cross-stream dependency is a gross (O(1)) difference
             assert rel_err(res[other][2][k], a) < 3e-2 or np.abs(a).max() < 1e-6, ("grad", other, k, rel_err(res[other][2][k], a))
+
+
+# ---- composite blocks, extended criteria, config 4, the benched mode at full size (oracle/cases.py) --------------------------
+def _build_case_module(spec):
+    """Our counterpart of oracle/make_golden.py:build_cell_case."""
+    from npp_amd import genotypes as G
+    from npp_amd.model_augment import Cell, Upsample, PoseCell1, ParCell1, Network
+    kind = spec["kind"]
+    if kind == "cell":
+        return Cell(G.ENCODER, *spec["args"]), None
+    if kind == "upsample":
+        w = spec["which"]
+        return Upsample(getattr(G.DECODER, f"upsample{w}"), getattr(G.DECODER, f"upsample_concat{w}"), *spec["args"]), None
+    if kind == "pose":
+        return PoseCell1(G.FUSION.pose, G.FUSION.pose_concat, *spec["args"]), None
+    if kind == "par":
+        return ParCell1(G.FUSION.par, G.FUSION.par_concat, *spec["args"]), None
+    geno = getattr(G.INTER, f"task{spec['task']}")
+    if kind == "inter":
+        indices, ops = Network._compile(Network, geno, spec["widths"])
+    else:
+        C = spec["C"]
+        resolution = [1, 1 / 2, 1 / 4, 1 / 8, 1 / 4, 1 / 2, 1]
+        indices, ops = Network._compile3(Network, geno, resolution, [int(2 * C / r) for r in resolution])
+    base = sum(len(ix) for ix in indices[:spec["stage"]])
+    idx = indices[spec["stage"]]
+    return torch.nn.ModuleList(ops[base:base + len(idx)]), idx
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", list(__import__("oracle.cases", fromlist=["CELL_CASES"]).CELL_CASES))
+def test_cell_block_matches_reference(name, dtype):
+    """Cell (normal / reduction / after a reduction), Upsample, PoseCell1, ParCell1 and the cross-task edge groups against the
+    reference's own modules (tests/golden/cells_golden.npz; N=4, 48x48: >= 2304 samples per BatchNorm channel): outputs,
+    input gradients, EVERY parameter gradient, running statistics.  These blocks are where this repo's fan-out nodes, two-sided
+    BatchNorm backward and in-place concatenation compose; f32 must hold 1e-3 throughout."""
+    from oracle.cases import CELL_CASES, N
+    from test_oracle_golden import cell_inputs, check_cell_case
+    from npp_amd import _ops as K
+    from npp_amd.model_augment import set_compute_dtype
+    g = load_golden("cells_golden.npz")
+    spec = CELL_CASES[name]
+    dev = _dev()
+    set_compute_dtype(dtype)
+    try:
+        m, idx = _build_case_module(spec)
+        assert list(m.state_dict().keys()) == [str(k) for k in g[f"{name}/sd_keys"]]
+        _load_synth_module(m, f"cells.{name}.")
+        m = m.to(dev).train()
+        xs = []
+        for x in cell_inputs(name, spec):
+            if x is None:
+                xs.append(None)
+                continue
+            x = K.cast(x.to(dev).contiguous(memory_format=torch.channels_last), dtype)
+            xs.append(x.detach().requires_grad_(True))
+        K.fan_reset()
+        if idx is None:
+            ys = m(*[x for x in xs if x is not None])
+            ys = list(ys) if isinstance(ys, (tuple, list)) else [ys]
+        else:
+            ys = [Network_cross(m, idx, xs)]
+        loss = 0.
+        for k, y in enumerate(ys):
+            gy = torch.from_numpy(_rng(f"gy{k}.cells.{name}").standard_normal(tuple(y.shape)).astype(np.float32)).to(dev)
+            loss = loss + (y.float() * gy.contiguous(memory_format=torch.channels_last)).sum()
+        loss.backward()
+        K.fan_reset()
+        torch.cuda.synchronize()
+        grads = {k: (_f32(p.grad) if p.grad is not None else None) for k, p in m.named_parameters()}
+        bufs = {k: _f32(b) for k, b in m.named_buffers() if b.is_floating_point()}
+        if dtype == torch.float32:
+            check_cell_case(g, name, [_f32(y) for y in ys], [None if x is None else _f32(x.grad) for x in xs], grads, bufs,
+                            1e-3, 1e-3)
+        else:
+            check_cell_case(g, name, [_f32(y) for y in ys], [None if x is None else _f32(x.grad) for x in xs], grads, None,
+                            2e-2, 5e-2, norm=rel_l2)
+    finally:
+        set_compute_dtype(torch.float32)
+
+
+def Network_cross(ops, idx, feats):
+    from npp_amd.model_augment import Network
+    return Network._cross(ops, 0, idx, feats)
+
+
+@pytest.mark.parametrize("name", list(__import__("oracle.cases", fromlist=["POSE_CASES"]).POSE_CASES))
+def test_criterion_pose_weights_and_resample_match_reference(name):
+    """Criterion_pose(use_target_weight=True) and heat-maps of another size than their targets (resampled like
+    F.interpolate(size=, mode='bilinear'), align_corners=False): core/criterion.py:92-96, 103-108, 113-115."""
+    from oracle.cases import POSE_CASES
+    from test_oracle_golden import pose_case_inputs
+    from npp_amd.criterion import Criterion_pose
+    g = load_golden("criteria2.npz")
+    dev = _dev()
+    spec = POSE_CASES[name]
+    preds, tw, tgt = pose_case_inputs(name, spec)
+    preds = [p.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True) for p in preds]
+    crit = Criterion_pose(out_len=2, use_target_weight=spec["use_target_weight"]).to(dev)
+    with torch.no_grad():
+        crit.lamda.copy_(torch.tensor([-2.5, -1.0]))
+    loss = crit([[preds[0], preds[1]], [preds[2], preds[3]]], [t.to(dev) for t in tgt], target_weight=tw.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g[f"{name}/loss"])) < 1e-5 * abs(float(g[f"{name}/loss"]))
+    assert rel_err(_f32(crit.lamda.grad), g[f"{name}/grad_lamda"]) < 1e-4
+    for i, p in enumerate(preds):
+        assert rel_err(_f32(p.grad), g[f"{name}/grad/{i}"]) < 1e-4, i
+
+
+def _train_step_hw(net, s, dev):
+    from npp_amd.criterion import Criterion_par, Criterion_pose
+    from npp_amd.synth import synth_batch_hw
+    images, lpar, lpose, _ = synth_batch_hw(s["n"], s["h"], s["w"], seed=0)
+    crit_pose, crit_par = Criterion_pose(out_len=2).to(dev), Criterion_par(out_len=2).to(dev)
+    pose_list, par_list = net(torch.from_numpy(images).to(dev))
+    l_par = crit_par(par_list, [torch.from_numpy(a).to(dev) for a in lpar])
+    l_pose = crit_pose(pose_list, [torch.from_numpy(a[:, :-1].copy()).to(dev) for a in lpose])
+    loss = (l_par.unsqueeze(0) + l_pose.unsqueeze(0)).mean()
+    return pose_list, par_list, loss
+
+
+def test_cfg4_small_network_160x224_matches_reference():
+    """A C=16 network on 2 x 3 x 160 x 224 (40x56 ... 5x7 maps: ragged tiles in every kernel): outputs, loss, gradients."""
+    from oracle.cases import CFG4_SMALL
+    g = load_golden("cfg4_net.npz")
+    dev = _dev()
+    net = _build_net(CFG4_SMALL["C"], torch.float32, g).train()
+    pose_list, par_list, loss = _train_step_hw(net, CFG4_SMALL, dev)
+    net.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    for i in range(2):
+        for nm, o in (("pose_map", pose_list[i][0]), ("pose_aux", pose_list[i][1]), ("par_map", par_list[i][0]),
+                      ("edge", par_list[i][1])):
+            assert rel_err(_f32(o), g[f"small/{nm}{i}"]) < 1e-3, (nm, i)
+    assert abs(float(loss.detach()) - float(g["small/loss"])) < 1e-3 * abs(float(g["small/loss"]))
+    params = dict(net.named_parameters())
+    for k in g.files:
+        if k.startswith("small/grad/"):
+            e = rel_err(_f32(params[k[11:]].grad), g[k])
+            assert e < 4e-2, (k, e)          # OHEM conditioning: test_tiny_network_train_step_matches_reference
+    keys = [str(s) for s in g["small/grad_norm_keys"]]
+    norms = np.array([float(params[k].grad.double().norm()) for k in keys])
+    assert np.abs(norms - g["small/grad_norms"]).max() / g["small/grad_norms"].max() < 3e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cfg4_full_network_512_matches_reference(dtype):
+    """BASELINE config 4's input size on the full network: C=64, 1 x 3 x 512 x 512, train-mode forward + both losses."""
+    from oracle.cases import CFG4_FULL
+    from npp_amd.model_augment import set_compute_dtype
+    g = load_golden("cfg4_net.npz")
+    dev = _dev()
+
+    class G2(dict):
+        pass
+    gold = {"sd_keys": g["full/sd_keys"], "sd_shapes": g["full/sd_shapes"]}
+    try:
+        net = _build_net(CFG4_FULL["C"], dtype, gold).train()
+        with torch.no_grad():
+            pose_list, par_list, loss = _train_step_hw(net, CFG4_FULL, dev)
+        torch.cuda.synchronize()
+        pm, qm = _f32(pose_list[1][0])[:, :, ::2, ::2], _f32(par_list[1][0])[:, :, ::2, ::2]
+        el = abs(float(loss) - float(g["full/loss"])) / abs(float(g["full/loss"]))
+        if dtype == torch.float32:
+            assert rel_err(pm, g["full/pose_map1"]) < 1e-3 and rel_err(qm, g["full/par_map1"]) < 1e-3 and el < 1e-3
+        else:
+            e1, e2 = rel_l2(pm, g["full/pose_map1"]), rel_l2(qm, g["full/par_map1"])
+            print(f"bf16 512x512: rel-L2 pose {e1:.3e} par {e2:.3e} loss {el:.3e}")
+            assert e1 < BF16_FULL_L2 and e2 < BF16_FULL_L2 and el < BF16_FULL_LOSS, (e1, e2, el)
+    finally:
+        set_compute_dtype(torch.float32)
+
+
+# the benched mode (bf16 storage, f32 accumulate) against the reference at FULL size; bounds = 2x what the MI355X run shows
+BF16_FULL_L2 = 6e-2
+BF16_FULL_LOSS = 2e-2
+
+
+def test_full_network_384_bf16_close_to_reference():
+    """The mode bench.py times -- bf16, C=64, 384x384, the shapes that take conv_g8 / conv_g4<128,128> / conv_wgrad_g4
+    in-network -- against the reference's f32 outputs (full_net.npz): final parsing logits / pose heat-maps (rel-L2), the
+    loss, and every gradient norm."""
+    from npp_amd.model_augment import set_compute_dtype
+    g = load_golden("full_net.npz")
+    dev = _dev()
+    try:
+        net = _build_net(64, torch.bfloat16, g).train()
+        pose_list, par_list, l_par, l_pose, loss, _, _ = _train_step(net, 1, 384, dev)
+        e1 = rel_l2(_f32(pose_list[1][0]), g["train/pose_map1"])
+        e2 = rel_l2(_f32(par_list[1][0]), g["train/par_map1"])
+        el = abs(float(loss.detach()) - float(g["train/loss"])) / abs(float(g["train/loss"]))
+        params = dict(net.named_parameters())
+        keys = [str(s) for s in g["train/grad_norm_keys"]]
+        norms = np.array([float(params[k].grad.double().norm()) for k in keys])
+        en = np.abs(norms - g["train/grad_norms"]).max() / g["train/grad_norms"].max()
+        rel = np.abs(norms - g["train/grad_norms"]) / np.maximum(g["train/grad_norms"], 1e-3 * g["train/grad_norms"].max())
+        print(f"bf16 384x384: rel-L2 pose {e1:.3e} par {e2:.3e} loss {el:.3e} grad-norm max {en:.3e} "
+              f"median rel {np.median(rel):.3e} 99% {np.quantile(rel, 0.99):.3e}")
+        assert e1 < BF16_FULL_L2 and e2 < BF16_FULL_L2 and el < BF16_FULL_LOSS, (e1, e2, el)
+        assert en < 0.1 and np.median(rel) < 0.05, (en, float(np.median(rel)))
+    finally:
+        set_compute_dtype(torch.float32)
+
+
+def test_full_network_named_gradients_match_reference():
+    """Per-tensor gradients of the full configuration (C=64, 1x3x384x384, f32; BatchNorm has >= 144 samples per channel) against
+    the reference's: 20 tensors from the stems to the heads, first 2048 elements + norm each."""
+    from oracle.cases import FULL_GRAD_KEYS, FULL_GRAD_ELEMS
+    g = load_golden("full_net_grads.npz")
+    gf = load_golden("full_net.npz")
+    dev = _dev()
+    net = _build_net(64, torch.float32, gf).train()
+    _train_step(net, 1, 384, dev)
+    params = dict(net.named_parameters())
+    worst = {}
+    for k in FULL_GRAD_KEYS:
+        gr = params[k].grad
+        e = rel_err(_f32(gr.reshape(-1)[:FULL_GRAD_ELEMS]), g[f"grad/{k}"])
+        en = abs(float(gr.double().norm()) - float(g[f"norm/{k}"])) / float(g[f"norm/{k}"])
+        worst[k] = (round(e, 5), round(en, 5))
+    print("full-size gradient errors (elements, norm):", worst)
+    for k, (e, en) in worst.items():
+        assert e < FULL_GRAD_TOL and en < FULL_GRAD_TOL, (k, e, en)
+
+
+FULL_GRAD_TOL = 3e-2      # OHEM's discrete pixel set (test_oracle_golden.py::test_gradient_conditioning); tightened to 2x observed

@@ -235,3 +235,173 @@ def test_eval_parsing_tta_confusion_matches_reference():
         b[:, lo], b[:, hi] = t[:, hi], t[:, lo]
     true_swap = 0.5 * (up + b.flip(3))
     assert not np.array_equal(O.confusion_matrix(label, true_swap, 20, 255), g["confusion"])
+
+
+# ---- composite blocks, extended criteria, config 4 (oracle/cases.py) -----------------------------------------------------
+from oracle.cases import CELL_CASES, N as CELL_N, SUB, POSE_CASES, POSE_N, POSE_J, POSE_HM, CFG4_SMALL, CFG4_FULL, \
+    FULL_GRAD_KEYS, FULL_GRAD_ELEMS  # noqa: E402
+
+
+def _case_template(g, name):
+    keys = [str(k) for k in g[f"{name}/sd_keys"]]
+    shapes = [tuple(int(d) for d in str(s).split(",") if d != "") for s in g[f"{name}/sd_shapes"]]
+
+    class S:
+        def __init__(self, s):
+            self.shape = s
+    return {k: S(s) for k, s in zip(keys, shapes)}
+
+
+def cell_inputs(name, spec):
+    xs = []
+    for i, shp in enumerate(spec["inputs"]):
+        xs.append(None if shp is None else
+                  torch.from_numpy(_rng(f"x{i}.cells.{name}").standard_normal((CELL_N,) + tuple(shp)).astype(np.float32)))
+    return xs
+
+
+def check_cell_case(g, name, ys, dxs, grads, bufs, tol, tol_grad, norm=rel_err):
+    """Outputs / input gradients (stored subsampled by SUB + whole-tensor [sum, abs-max, norm]), parameter gradients and
+    running statistics of one cell case against cells_golden.npz."""
+    for k, y in enumerate(ys):
+        assert tuple(y.shape) == tuple(g[f"{name}/y{k}_shape"])
+        assert norm(y[:, :, ::SUB, ::SUB], g[f"{name}/y{k}"]) < tol, (name, "y", k)
+        st = g[f"{name}/y{k}_stats"]
+        assert abs(np.linalg.norm(y.astype(np.float64)) - st[2]) < tol * st[2], (name, "y norm", k)
+    for i, dx in enumerate(dxs):
+        if dx is None:
+            continue
+        assert norm(dx[:, :, ::SUB, ::SUB], g[f"{name}/dx{i}"]) < tol_grad, (name, "dx", i, norm(dx[:, :, ::SUB, ::SUB], g[f"{name}/dx{i}"]))
+        st = g[f"{name}/dx{i}_stats"]
+        assert abs(np.linalg.norm(dx.astype(np.float64)) - st[2]) < tol_grad * st[2], (name, "dx norm", i)
+    n = 0
+    for k in g.files:
+        if k.startswith(name + "/grad/"):
+            pk = k[len(name) + 6:]
+            assert pk in grads and grads[pk] is not None, (name, pk)
+            ref = g[k]
+            if np.abs(ref).max() < 1e-6 * max(1.0, float(np.abs(grads[pk]).max())) or pk.endswith("bias") and np.abs(ref).max() < 1e-4:
+                continue       # exact-zero gradients (a conv bias in front of BatchNorm): rounding residue on both sides
+            assert norm(grads[pk], ref) < tol_grad, (name, pk, norm(grads[pk], ref))
+            n += 1
+        if k.startswith(name + "/buf/") and bufs is not None:
+            pk = k[len(name) + 5:]
+            if pk not in bufs:
+                continue       # SE_Block.bn at stride 1 is never executed (operations.py:117,126-129): statistics untouched
+            assert rel_err(bufs[pk], g[k]) < max(tol, 1e-5), (name, pk)
+    assert n >= 8, (name, n)
+
+
+@pytest.mark.parametrize("name", list(CELL_CASES))
+def test_cell_blocks_match_reference(name):
+    g = load_golden("cells_golden.npz")
+    spec = CELL_CASES[name]
+    t = synth_tensors(_case_template(g, name), 0, prefix=f"cells.{name}.")
+    for k, v in t.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    xs = cell_inputs(name, spec)
+    for x in xs:
+        if x is not None:
+            x.requires_grad_(True)
+    c = O.Ctx(t, True)
+    ys = O.cell_case(c, "", spec, xs)
+    loss = 0.
+    for k, y in enumerate(ys):
+        gy = torch.from_numpy(_rng(f"gy{k}.cells.{name}").standard_normal(tuple(y.shape)).astype(np.float32))
+        loss = loss + (y * gy).sum()
+    loss.backward()
+    check_cell_case(g, name, [y.detach().numpy() for y in ys], [None if x is None else x.grad.numpy() for x in xs],
+                    {k: (v.grad.numpy() if v.grad is not None else None) for k, v in t.items() if v.requires_grad},
+                    {k: v.numpy() for k, v in c.new_buffers.items()}, 2e-5, 5e-5)
+
+
+def pose_case_inputs(name, spec):
+    r = _rng("crit2." + name)
+    preds = []
+    for stage in range(2):
+        for (h, w) in spec["sizes"]:
+            preds.append(torch.from_numpy((r.standard_normal((POSE_N, POSE_J, h, w)) * 0.3).astype(np.float32)))
+    tw = torch.from_numpy(r.uniform(0.0, 1.5, (POSE_N, POSE_J, 1)).astype(np.float32))
+    _, _, lpose, _ = synth_batch(POSE_N, POSE_HM * 4, seed=3)
+    tgt = [torch.from_numpy(a[:, :-1].copy()) for a in lpose]
+    return preds, tw, tgt
+
+
+@pytest.mark.parametrize("name", list(POSE_CASES))
+def test_criterion_pose_weights_and_resample_match_reference(name):
+    g = load_golden("criteria2.npz")
+    spec = POSE_CASES[name]
+    preds, tw, tgt = pose_case_inputs(name, spec)
+    for p in preds:
+        p.requires_grad_(True)
+    lam = torch.tensor([-2.5, -1.0], requires_grad=True)
+    loss = O.criterion_pose([[preds[0], preds[1]], [preds[2], preds[3]]], tgt, lam, tw if spec["use_target_weight"] else None)
+    loss.backward()
+    assert rel_err(loss.detach().numpy(), g[f"{name}/loss"]) < 1e-6
+    assert rel_err(lam.grad.numpy(), g[f"{name}/grad_lamda"]) < 1e-5
+    for i, p in enumerate(preds):
+        assert rel_err(p.grad.numpy(), g[f"{name}/grad/{i}"]) < 1e-5, i
+
+
+def _cfg4_batch(s):
+    from npp_amd.synth import synth_batch_hw
+    images, lpar, lpose, _ = synth_batch_hw(s["n"], s["h"], s["w"], seed=0)
+    return (torch.from_numpy(images), [torch.from_numpy(a) for a in lpar], [torch.from_numpy(a[:, :-1].copy()) for a in lpose])
+
+
+def test_cfg4_small_matches_reference():
+    """C=16 network on a 160 x 224 batch (BASELINE config 4's non-square cousin): outputs, losses, gradients."""
+    g = load_golden("cfg4_net.npz")
+    t = synth_tensors(template_from_golden(g), 0)
+    for k, v in t.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    images, lpar, lpose = _cfg4_batch(CFG4_SMALL)
+    lam_pose, lam_par = torch.full((2,), -2.5), torch.full((2,), 2.3)
+    loss, pose_list, par_list, _ = O.train_step_loss(t, images, lpar, lpose, lam_pose, lam_par)
+    loss.backward()
+    for i in range(2):
+        for nm, o in (("pose_map", pose_list[i][0]), ("pose_aux", pose_list[i][1]), ("par_map", par_list[i][0]),
+                      ("edge", par_list[i][1])):
+            assert rel_err(o.detach().numpy(), g[f"small/{nm}{i}"]) < 1e-4, (nm, i)
+    assert rel_err(loss.detach().numpy(), g["small/loss"]) < 1e-5
+    for k in g.files:
+        if k.startswith("small/grad/"):
+            assert rel_err(t[k[11:]].grad.numpy(), g[k]) < 2e-2, k       # (OHEM's discrete set: test_gradient_conditioning)
+
+
+@pytest.mark.slow
+def test_cfg4_full_512_matches_reference():
+    g = load_golden("cfg4_net.npz")
+    keys = [str(k) for k in g["full/sd_keys"]]
+    shapes = [tuple(int(d) for d in str(s).split(",") if d != "") for s in g["full/sd_shapes"]]
+
+    class S:
+        def __init__(self, s):
+            self.shape = s
+    t = synth_tensors({k: S(s) for k, s in zip(keys, shapes)}, 0)
+    images, lpar, lpose = _cfg4_batch(CFG4_FULL)
+    with torch.no_grad():
+        loss, pose_list, par_list, _ = O.train_step_loss(t, images, lpar, lpose, torch.full((2,), -2.5), torch.full((2,), 2.3))
+    assert rel_err(pose_list[1][0][:, :, ::2, ::2].numpy(), g["full/pose_map1"]) < 1e-4
+    assert rel_err(par_list[1][0][:, :, ::2, ::2].numpy(), g["full/par_map1"]) < 1e-4
+    assert rel_err(loss.numpy(), g["full/loss"]) < 1e-5
+
+
+@pytest.mark.slow
+def test_full_net_named_gradients_match_reference():
+    g = load_golden("full_net_grads.npz")
+    gf = load_golden("full_net.npz")
+    t = synth_tensors(template_from_golden(gf), 0)
+    for k in FULL_GRAD_KEYS:
+        t[k].requires_grad_(True)
+    images, lpar, lpose, _ = synth_batch(1, 384, seed=0)
+    loss, _, _, _ = O.train_step_loss(t, torch.from_numpy(images), [torch.from_numpy(a) for a in lpar],
+                                      [torch.from_numpy(a[:, :-1].copy()) for a in lpose], torch.full((2,), -2.5),
+                                      torch.full((2,), 2.3))
+    loss.backward()
+    for k in FULL_GRAD_KEYS:
+        got = t[k].grad.reshape(-1)[:FULL_GRAD_ELEMS].numpy()
+        assert rel_err(got, g[f"grad/{k}"]) < 2e-2, (k, rel_err(got, g[f"grad/{k}"]))
+        assert abs(float(t[k].grad.double().norm()) - float(g[f"norm/{k}"])) < 2e-2 * float(g[f"norm/{k}"]), k

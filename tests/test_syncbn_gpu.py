@@ -36,7 +36,7 @@ def _outputs(pose_list, par_list):
             par_list[0][0], par_list[0][1], par_list[1][0], par_list[1][1]]
 
 
-def _worker(rank, world, port, out, sync=True):
+def _worker(rank, world, port, out, sync=True, reducer=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -59,6 +59,13 @@ def _worker(rank, world, port, out, sync=True):
             orig(h, *a, **kw)
             t.copy_(h)
         dist.all_reduce = staged
+        orig_b = dist.broadcast
+
+        def staged_b(t, *a, **kw):
+            h = t.detach().cpu()
+            orig_b(h, *a, **kw)
+            t.copy_(h)
+        dist.broadcast = staged_b
     K._SYNC_EVEN_ALONE = True
     g = load_golden("tiny_net.npz")
     set_compute_dtype(torch.float32)
@@ -67,21 +74,46 @@ def _worker(rank, world, port, out, sync=True):
     if sync:
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
     net = net.to(dev).train()
+    red = None
+    if reducer:
+        # the product's DDP replacement on the REAL network (augment_lip_sync.py:206-208): several buckets, the 116 never-used
+        # parameters skipped statically, gradients written straight into the bucket slots by the backward kernels
+        from npp_amd.ddp import GradReducer, unused_parameter_names
+        red = GradReducer(net, skip=unused_parameter_names(net), bucket_mb=0.5)
+        assert len(red.buckets) >= 4
     n = int(g["n"])
     per = n // world
     images, _, _, _ = synth_batch(n, int(g["size"]), seed=0)
     x = torch.from_numpy(images[rank * per:(rank + 1) * per]).to(dev)
-    pose_list, par_list = net(x)
-    outs = _outputs(pose_list, par_list)
-    loss = sum((o.float() ** 2).sum() for o in outs)
-    net.zero_grad()
-    loss.backward()
-    torch.cuda.synchronize()
     params = dict(net.named_parameters())
     res = {}
+    for it in range(2 if reducer else 1):      # twice: the second step reuses the buckets
+        pose_list, par_list = net(x)
+        outs = _outputs(pose_list, par_list)
+        loss = sum((o.float() ** 2).sum() for o in outs)
+        net.zero_grad(set_to_none=True)
+        if red is not None:
+            red.begin_step()
+        loss.backward()
+        if red is not None:
+            red.finish()
+        torch.cuda.synchronize()
+        if it == 0 and reducer:
+            # running statistics moved in step 0: rewind them so that step 1 repeats step 0 exactly
+            net.load_state_dict(synth_tensors(template_from_golden(g), 0))
+    if red is not None:
+        inplace = 0
+        for b in red.buckets:
+            lo, hi = b.flat.data_ptr(), b.flat.data_ptr() + b.flat.numel() * 4
+            for p in b.params:
+                assert lo <= p.grad.data_ptr() < hi          # every gradient is a view of its bucket
+        res["n_buckets"] = np.array(len(red.buckets))
     for k in GRAD_KEYS:
         gr = params[k].grad.detach().double().cpu()
-        dist.all_reduce(gr)
+        if red is not None:
+            gr = gr * world        # the reducer averages; the goldens hold the gradient of the SUM over the full batch
+        else:
+            dist.all_reduce(gr)
         res["grad/" + k] = gr.numpy()
     sd = net.state_dict()
     for k in g.files:
@@ -95,13 +127,13 @@ def _worker(rank, world, port, out, sync=True):
     dist.destroy_process_group()
 
 
-def _run(world, tmp_path, sync=True):
+def _run(world, tmp_path, sync=True, reducer=False):
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), sync), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), sync, reducer), nprocs=world, join=True)
     return [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
 
 
@@ -152,6 +184,33 @@ def test_syncbn_ranks_equal_full_batch(world, streams, tmp_path, monkeypatch):
     for k in GRAD_KEYS:
         e = rel_err(res[0]["grad/" + k], ref[k])
         assert e < 5e-2, (k, e)
+
+
+def test_grad_reducer_on_the_real_network_two_ranks(tmp_path):
+    """GradReducer + SyncBatchNorm on the tiny NPPNet, 2 ranks x 1 image: world x (averaged gradient) must equal the
+    full-batch gradient -- of the same kernels without the reducer (rank-summed) and of the CPU oracle -- and be identical on
+    both ranks; outputs and running statistics still equal the reference's full-batch goldens."""
+    from helpers import load_golden, rel_err
+    g = load_golden("tiny_net.npz")
+    world = 2
+    res = _run(world, tmp_path, reducer=True)
+    os.makedirs(str(tmp_path / "plain"))
+    plain = _run(world, tmp_path / "plain", reducer=False)
+    per = int(g["n"]) // world
+    for r, rr in enumerate(res):
+        for k in rr.files:
+            if k.startswith("out/"):
+                ref = g["train/" + k[4:]][r * per:(r + 1) * per]
+                assert rel_err(rr[k], ref) < 1e-3 * max(1.0, np.abs(g["train/" + k[4:]]).max() / max(np.abs(ref).max(), 1e-30)), (r, k)
+            if k.startswith("buf/"):
+                assert rel_err(rr[k], g["train/" + k]) < 1e-3, (r, k)
+    ref = _oracle_grads()
+    for k in GRAD_KEYS:
+        assert np.array_equal(res[0]["grad/" + k], res[1]["grad/" + k]), k          # every rank holds the same average
+        e_plain = rel_err(res[0]["grad/" + k], plain[0]["grad/" + k])
+        e_ref = rel_err(res[0]["grad/" + k], ref[k])
+        assert e_plain < 4e-2 and e_ref < 5e-2, (k, e_plain, e_ref)      # (bounds: test_syncbn_ranks_equal_full_batch)
+    assert int(res[0]["n_buckets"]) >= 4
 
 
 def _ops_worker(rank, world, port, out):

@@ -39,7 +39,8 @@ def test_oracle_edge_known_values():
 
 
 def _dev():
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X (no GPU visible)")
     return torch.device("cuda:0")
 
 

@@ -124,6 +124,36 @@ def test_pose_weight_argument_and_static_inputs():
     assert np.isfinite([l0, l1, l2]).all() and l2 < l0
 
 
+def test_eval_after_graph_replays_uses_the_updated_weights():
+    """The replayed graph updates the parameters without any host-side version bump (FusedAdam's increment_version ran once,
+    at capture): an eval forward after N replays must still run on operand images of the CURRENT weights, i.e. equal the eval
+    output of a freshly built model loaded from state_dict() -- and stay right for a second train / eval round."""
+    from npp_amd.model_augment import Network
+    dev = torch.device("cuda:0")
+    net, opt, step = _make(dev, graph=True)
+    for grp in opt.param_groups:
+        grp["lr"] = 2e-2                   # large steps: stale images would be far off
+    im, lpar, lpose, _ = _batch(2, 64, 5, dev)
+
+    def eval_out(model):
+        model.eval()
+        with torch.no_grad():
+            pose, par = model(im)
+        model.train()
+        return pose[1][0].float().clone(), par[1][0].float().clone()
+
+    for rnd in range(2):
+        for _ in range(4):
+            step(im, list(lpar), list(lpose))
+        assert step.graphed
+        got = eval_out(net)
+        fresh = Network(_cfg(8)).to(dev)
+        fresh.load_state_dict(net.state_dict())
+        want = eval_out(fresh)
+        for a, b in zip(got, want):
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), rnd
+
+
 def test_capture_failure_falls_back_to_eager():
     """A hipGraph capture that is invalidated half way leaves the capture stream current and the side streams stuck in
     capture mode (tools/capture_recover.py); TrainStep must restore the stream, take fresh side streams and keep stepping
