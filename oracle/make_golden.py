@@ -505,6 +505,29 @@ def gen_cfg4():
     print("cfg4_net.npz", len(out), "arrays; loss small", float(out["small/loss"]), "full", float(loss))
 
 
+def gen_full_eval():
+    """Eval-mode (running statistics) forward of the full configuration at 384 x 384 and 512 x 512: the pin for the bf16 mode at
+    full size -- in train mode this randomly initialised network amplifies ANY perturbation ~1.3x per cell (f32 rounding
+    1e-7 -> 5e-5 at the heads, bf16 rounding 3e-3 -> 0.7: tools/bf16_drift.py), in eval mode it does not."""
+    from npp_amd.synth import synth_batch_hw
+    out = {"torch_version": np.array(torch.__version__)}
+    torch.manual_seed(0)
+    net = RefNetwork(cfg(64))
+    load_synth(net, 0)
+    net.eval()
+    for size in (384, 512):
+        images, _, _, _ = synth_batch_hw(1, size, size, seed=0)
+        with torch.no_grad():
+            pose_list, par_list = net(torch.from_numpy(images))
+        for i in range(2):
+            for nm, t in (("pose_map", pose_list[i][0]), ("pose_aux", pose_list[i][1]), ("par_map", par_list[i][0]),
+                          ("edge", par_list[i][1])):
+                out[f"{size}/{nm}{i}"] = f32(t[:, :, ::2, ::2])
+                out[f"{size}/{nm}{i}_stats"] = _stats(t)
+    np.savez_compressed(os.path.join(OUT, "full_net_eval.npz"), **out)
+    print("full_net_eval.npz", len(out), "arrays")
+
+
 def gen_full_grads():
     """Named per-tensor gradients of the full configuration (the run of full_net.npz): the first FULL_GRAD_ELEMS elements of
     each + its norm (BatchNorm has >= 144 samples per channel there)."""
@@ -528,7 +551,8 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     todo = a.only.split(",") if a.only else ["ops", "criteria", "tiny", "search", "eval", "cells", "criteria2"] + \
-        (["full", "full_grads", "cfg4"] if a.full else [])
+        (["full", "full_grads", "full_eval", "cfg4"] if a.full else [])
     for t in todo:
         {"ops": gen_ops, "criteria": gen_criteria, "tiny": gen_tiny, "full": gen_full, "search": gen_search, "eval": gen_eval,
-         "cells": gen_cells, "criteria2": gen_criteria2, "cfg4": gen_cfg4, "full_grads": gen_full_grads}[t]()
+         "cells": gen_cells, "criteria2": gen_criteria2, "cfg4": gen_cfg4, "full_grads": gen_full_grads,
+         "full_eval": gen_full_eval}[t]()

@@ -260,36 +260,59 @@ def cell_inputs(name, spec):
     return xs
 
 
-def check_cell_case(g, name, ys, dxs, grads, bufs, tol, tol_grad, norm=rel_err):
+def check_cell_case(g, name, ys, dxs, grads, bufs, tol, tol_grad, norm=rel_err, grad_floor=0.0):
     """Outputs / input gradients (stored subsampled by SUB + whole-tensor [sum, abs-max, norm]), parameter gradients and
-    running statistics of one cell case against cells_golden.npz."""
+    running statistics of one cell case against cells_golden.npz.  Returns the worst (output, gradient) errors seen."""
+    worst_y = worst_g = 0.0
+    bad = []
     for k, y in enumerate(ys):
         assert tuple(y.shape) == tuple(g[f"{name}/y{k}_shape"])
-        assert norm(y[:, :, ::SUB, ::SUB], g[f"{name}/y{k}"]) < tol, (name, "y", k)
         st = g[f"{name}/y{k}_stats"]
-        assert abs(np.linalg.norm(y.astype(np.float64)) - st[2]) < tol * st[2], (name, "y norm", k)
+        e = max(norm(y[:, :, ::SUB, ::SUB], g[f"{name}/y{k}"]), abs(np.linalg.norm(y.astype(np.float64)) - st[2]) / st[2])
+        worst_y = max(worst_y, e)
+        if e >= tol:
+            bad.append(("y", k, e))
     for i, dx in enumerate(dxs):
         if dx is None:
             continue
-        assert norm(dx[:, :, ::SUB, ::SUB], g[f"{name}/dx{i}"]) < tol_grad, (name, "dx", i, norm(dx[:, :, ::SUB, ::SUB], g[f"{name}/dx{i}"]))
         st = g[f"{name}/dx{i}_stats"]
-        assert abs(np.linalg.norm(dx.astype(np.float64)) - st[2]) < tol_grad * st[2], (name, "dx norm", i)
+        e = max(norm(dx[:, :, ::SUB, ::SUB], g[f"{name}/dx{i}"]), abs(np.linalg.norm(dx.astype(np.float64)) - st[2]) / st[2])
+        worst_g = max(worst_g, e)
+        if e >= tol_grad:
+            bad.append(("dx", i, e))
     n = 0
-    for k in g.files:
-        if k.startswith(name + "/grad/"):
+    gkeys = [k for k in g.files if k.startswith(name + "/grad/")]
+    rms = np.median([np.linalg.norm(g[k]) / np.sqrt(g[k].size) for k in gkeys])       # typical gradient element of this block
+    for k in gkeys:
+        if True:
             pk = k[len(name) + 6:]
             assert pk in grads and grads[pk] is not None, (name, pk)
             ref = g[k]
-            if np.abs(ref).max() < 1e-6 * max(1.0, float(np.abs(grads[pk]).max())) or pk.endswith("bias") and np.abs(ref).max() < 1e-4:
-                continue       # exact-zero gradients (a conv bias in front of BatchNorm): rounding residue on both sides
-            assert norm(grads[pk], ref) < tol_grad, (name, pk, norm(grads[pk], ref))
+            if np.linalg.norm(ref) < 1e-4 * rms * np.sqrt(ref.size):
+                # exact-zero gradients (a conv bias in front of BatchNorm): rounding residue on both sides
+                assert np.linalg.norm(grads[pk]) < 1e-2 * rms * np.sqrt(ref.size), (name, pk)
+                continue
+            if grad_floor:
+                # reduced-precision runs: a tensor whose gradient nearly cancels (norm far below its peers') is measured
+                # against the peers' scale, not against its own residue
+                e = np.linalg.norm(grads[pk].astype(np.float64) - ref) / max(np.linalg.norm(ref), grad_floor * rms * np.sqrt(ref.size))
+            else:
+                e = norm(grads[pk], ref)
+            worst_g = max(worst_g, e)
+            if e >= tol_grad:
+                bad.append((pk, e))
             n += 1
+    for k in g.files:
         if k.startswith(name + "/buf/") and bufs is not None:
             pk = k[len(name) + 5:]
             if pk not in bufs:
                 continue       # SE_Block.bn at stride 1 is never executed (operations.py:117,126-129): statistics untouched
-            assert rel_err(bufs[pk], g[k]) < max(tol, 1e-5), (name, pk)
+            e = rel_err(bufs[pk], g[k])
+            if e >= max(tol, 1e-5):
+                bad.append((pk, e))
+    assert not bad, (name, bad)
     assert n >= 8, (name, n)
+    return worst_y, worst_g
 
 
 @pytest.mark.parametrize("name", list(CELL_CASES))
@@ -390,6 +413,22 @@ def test_cfg4_full_512_matches_reference():
 
 
 @pytest.mark.slow
+@pytest.mark.parametrize("size", [384, 512])
+def test_full_net_eval_matches_reference(size):
+    from npp_amd.synth import synth_batch_hw
+    g = load_golden("full_net_eval.npz")
+    gf = load_golden("full_net.npz")
+    t = synth_tensors(template_from_golden(gf), 0)
+    images, _, _, _ = synth_batch_hw(1, size, size, seed=0)
+    with torch.no_grad():
+        pose_list, par_list, _ = O.network_forward(t, torch.from_numpy(images), train=False)
+    for i in range(2):
+        for nm, o in (("pose_map", pose_list[i][0]), ("pose_aux", pose_list[i][1]), ("par_map", par_list[i][0]),
+                      ("edge", par_list[i][1])):
+            assert rel_err(o[:, :, ::2, ::2].numpy(), g[f"{size}/{nm}{i}"]) < 1e-4, (size, nm, i)
+
+
+@pytest.mark.slow
 def test_full_net_named_gradients_match_reference():
     g = load_golden("full_net_grads.npz")
     gf = load_golden("full_net.npz")
@@ -403,5 +442,7 @@ def test_full_net_named_gradients_match_reference():
     loss.backward()
     for k in FULL_GRAD_KEYS:
         got = t[k].grad.reshape(-1)[:FULL_GRAD_ELEMS].numpy()
+        if float(g[f"norm/{k}"]) < 1e-6:
+            continue           # a conv bias in front of BatchNorm (edge_layer.1.bias): exact gradient 0
         assert rel_err(got, g[f"grad/{k}"]) < 2e-2, (k, rel_err(got, g[f"grad/{k}"]))
         assert abs(float(t[k].grad.double().norm()) - float(g[f"norm/{k}"])) < 2e-2 * float(g[f"norm/{k}"]), k
