@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--model", default="augment", choices=["augment", "search"],
                     help="augment: model_augment.Network (the metric's workload); search: the MixedOp supernet of "
                          "BASELINE config 5 (C=32, weights-only train() pass)")
+    ap.add_argument("--alpha-pass", action="store_true",
+                    help="--model search: time the whole train_with_alpha iteration (core/function.py:485-621): the weights pass "
+                         "AND the architecture pass on a second batch (npp_amd.train_step.SearchStep)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of npp_amd.optim.FusedAdam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
@@ -235,10 +238,25 @@ def main():
     # become one replay); any capture failure falls back to eager on every rank
     from npp_amd.train_step import TrainStep
     from npp_amd import _ops as K
-    train_step = TrainStep(net, crit_pose, crit_par, opt, reducer=reducer, graph=use_graph, warmup=2)
+    if args.model == "search" and args.alpha_pass:
+        from npp_amd.train_step import SearchStep
+        from npp_amd.optim import FusedAdam as _FA
+        if reducer is not None:
+            raise SystemExit("--alpha-pass is a single-GPU bench line (the N > 1 search run times the weights pass)")
+        a_opt = _FA(net.arch_parameters(), lr=3e-4, betas=(0.5, 0.999), weight_decay=0.001)     # search_lip_sync.py:279
+        im2, lpar2, lpose2, _ = synth_batch(args.batch, args.size, seed=1, rank=rank)
+        batch2 = (torch.from_numpy(im2).to(dev), [torch.from_numpy(a).to(dev) for a in lpar2],
+                  [torch.from_numpy(a[:, :-1].copy()).to(dev) for a in lpose2])
+        search_step = SearchStep(net, crit_pose, crit_par, opt, a_opt, graph=use_graph, warmup=2)
+        train_step = search_step.weights_pass
 
-    def step():
-        return train_step(images, lpar, lpose)
+        def step():
+            return search_step((images, lpar, lpose), batch2)[0]
+    else:
+        train_step = TrainStep(net, crit_pose, crit_par, opt, reducer=reducer, graph=use_graph, warmup=2)
+
+        def step():
+            return train_step(images, lpar, lpose)
 
     def eager_step():
         return train_step._eager(images, lpar, lpose, None)
@@ -352,7 +370,9 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("model_augment.Network fixed genotype C=64 L=16 R=1" if args.model == "augment" else
-                                "model_search_interact.Network supernet C=32 L=16 (weights pass)") +
+                                "model_search_interact.Network supernet C=32 L=16 " +
+                                ("(train_with_alpha iteration: weights pass + alpha pass on a second batch)" if args.alpha_pass
+                                 else "(weights pass)")) +
                                ", %dx%d, batch %d/GPU, fwd + Criterion_par + Criterion_pose + bwd + Adam step"
                                % (args.size, args.size, args.batch),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,

@@ -272,6 +272,17 @@ class Network(nn.Module):
             en_alphas = en_alphas + en.mean(dim=0)
         return 0.25 * 2 * en_alphas / length
 
+    def entropy_beta(self, n_input, steps, betas):
+        """:898-908: mean over the `steps` nodes of the normalised entropy of the softmax over each node's beta slice (the
+        slices grow by one entry per node, as in `btw`)."""
+        start, n, en = 0, n_input, 0.
+        for _ in range(steps):
+            w = F.softmax(betas[start:start + n], dim=-1)
+            en = en + (-(w * torch.log(w)).sum(-1)) / math.log(n)
+            start += n
+            n += 1
+        return en / steps
+
     # -- forward (:626-770) -------------------------------------------------------------------------------------
     def _mix(self, ops, base, feats, alpha_rows, beta_rows):
         w = F.softmax(alpha_rows, dim=-1)

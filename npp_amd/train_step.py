@@ -55,14 +55,17 @@ class TrainStep:
         self._side = None
 
     # -- the step itself (what gets captured) ---------------------------------------------------------------------
-    def _eager(self, images, labels_par, labels_pose, pose_weight):
+    def _loss(self, images, labels_par, labels_pose, pose_weight):
         output_pose, output_par = self.model(images)
         losses_par = self.criterion_par(output_par, labels_par).unsqueeze(0)
         if pose_weight is not None:
             losses_pose = self.criterion_pose(output_pose, labels_pose, target_weight=pose_weight).unsqueeze(0)
         else:
             losses_pose = self.criterion_pose(output_pose, labels_pose).unsqueeze(0)
-        loss = (losses_par + losses_pose).mean()
+        return (losses_par + losses_pose).mean()
+
+    def _eager(self, images, labels_par, labels_pose, pose_weight):
+        loss = self._loss(images, labels_par, labels_pose, pose_weight)
         self.optimizer.zero_grad(set_to_none=True)
         if self.reducer is not None:
             self.reducer.begin_step()      # the backward kernels write the gradients straight into the reducer's buckets
@@ -229,3 +232,82 @@ class TrainStep:
     @property
     def graphed(self) -> bool:
         return self.graph is not None
+
+
+class _FrozenPass(TrainStep):
+    """A TrainStep whose forward runs with a set of parameters frozen (requires_grad False): their gradients are neither
+    computed (no weight-gradient / BatchNorm-parameter kernels are launched for them) nor accumulated."""
+
+    def __init__(self, *a, frozen=(), **kw):
+        super().__init__(*a, **kw)
+        self._frozen = [p for p in frozen]
+
+    def _thaw(self, flags):
+        for p, f in zip(self._frozen, flags):
+            p.requires_grad_(f)
+
+    def _eager(self, images, labels_par, labels_pose, pose_weight):
+        flags = [p.requires_grad for p in self._frozen]
+        for p in self._frozen:
+            p.requires_grad_(False)
+        try:
+            return super()._eager(images, labels_par, labels_pose, pose_weight)
+        finally:
+            self._thaw(flags)
+
+
+class _AlphaPass(_FrozenPass):
+    """The architecture pass of train_with_alpha (core/function.py:546-616): loss2 = 2 * mean(losses_par + losses_pose
+    [+ 2 * model.loss_entropy() after epoch 70]) on the mini-loader batch, stepped by the architecture optimizer."""
+
+    def __init__(self, *a, entropy=False, **kw):
+        super().__init__(*a, **kw)
+        self.entropy = entropy
+
+    def _loss(self, images, labels_par, labels_pose, pose_weight):
+        output_pose, output_par = self.model(images)
+        losses2 = self.criterion_par(output_par, labels_par).unsqueeze(0)
+        if pose_weight is not None:
+            losses2 = losses2 + self.criterion_pose(output_pose, labels_pose, target_weight=pose_weight).unsqueeze(0)
+        else:
+            losses2 = losses2 + self.criterion_pose(output_pose, labels_pose).unsqueeze(0)
+        if self.entropy:
+            losses2 = losses2 + 2 * self.model.loss_entropy()
+        return 2 * losses2.mean()
+
+
+class SearchStep:
+    """One iteration of the bi-level search loop `train_with_alpha` (core/function.py:485-621) as a callable:
+
+        weights pass : model(images1) -> criterion_par + criterion_pose -> mean -> optimizer (all weights)          :499-531
+        alpha pass   : model(images2) -> 2 * mean(losses [+ 2 * loss_entropy()]) -> a_optimizer (alphas, betas)     :546-616
+
+    Both passes are TrainSteps (eager warm-up, then one hipGraph each).  What differs from the reference's arithmetic: nothing;
+    what differs in work: the weights pass does not compute the architecture gradients the reference throws away
+    (`a_optimizer.zero_grad()` before the alpha backward), and the alpha pass does not compute the ~5000 weight gradients it
+    never uses (`optimizer.zero_grad()` before the next weights backward) -- each pass freezes the other pass's parameters.
+    `reducer` / `a_reducer`: GradReducers over the weights / the architecture tensors (DDP averages both, search_lip_sync.py)."""
+
+    def __init__(self, model, criterion_pose, criterion_par, optimizer, a_optimizer, reducer=None, a_reducer=None,
+                 graph: Optional[bool] = None, warmup: int = 2):
+        arch = list(model.arch_parameters())
+        arch_ids = {id(a) for a in arch}
+        weights = [p for p in list(model.parameters()) + list(criterion_pose.parameters()) + list(criterion_par.parameters())
+                   if id(p) not in arch_ids and p.requires_grad]
+        self.weights_pass = _FrozenPass(model, criterion_pose, criterion_par, optimizer, reducer=reducer, graph=graph,
+                                        warmup=warmup, frozen=arch)
+        self._alpha_args = (model, criterion_pose, criterion_par, a_optimizer)
+        self._alpha_kw = dict(reducer=a_reducer, graph=graph, warmup=warmup, frozen=weights)
+        self._alpha = {}
+
+    def alpha_pass(self, entropy: bool) -> _AlphaPass:
+        st = self._alpha.get(bool(entropy))
+        if st is None:
+            st = self._alpha[bool(entropy)] = _AlphaPass(*self._alpha_args, entropy=bool(entropy), **self._alpha_kw)
+        return st
+
+    def __call__(self, batch1, batch2, entropy: bool = False):
+        """batch = (images, labels_par, labels_pose[, pose_weight]); entropy = `epoch > 70` of core/function.py:608."""
+        loss1 = self.weights_pass(*batch1)
+        loss2 = self.alpha_pass(entropy)(*batch2)
+        return loss1, loss2

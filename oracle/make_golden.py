@@ -505,6 +505,33 @@ def gen_cfg4():
     print("cfg4_net.npz", len(out), "arrays; loss small", float(out["small/loss"]), "full", float(loss))
 
 
+def gen_search_extra():
+    """Host-side architecture read-outs of the search supernet: genotype() (model_search_interact.py:913-1052) and entropy_beta
+    (:898-908) on the non-uniform alphas/betas of search_net.npz."""
+    C = 16
+    torch.manual_seed(0)
+    c = cfg(C)
+    c.SEARCH = NS(LAYERS=16, INIT_CHANNELS=C)
+    net = RefSearchNetwork(c)
+    load_synth(net, 0)
+    with torch.no_grad():
+        for a in net.arch_parameters():
+            a.mul_(8.0)
+    inter, fuse = net.genotype()
+    out = {"torch_version": np.array(torch.__version__)}
+    import json
+
+    def plain(stages):
+        return [[[str(n), int(i)] for n, i in st] for st in stages]
+    out["genotype_inter"] = np.array(json.dumps([plain(t) for t in inter]))
+    out["genotype_fuse"] = np.array(json.dumps([plain([fuse.pose])[0], [int(i) for i in fuse.pose_concat], plain([fuse.par])[0],
+                                                [int(i) for i in fuse.par_concat]]))
+    for name, n_in, steps in (("betas1", 2, 3), ("betas3", 5, 3), ("betas_pose", 3, 4), ("betas_par", 2, 4)):
+        out[f"entropy_beta/{name}"] = np.array([n_in, steps, float(net.entropy_beta(n_in, steps, getattr(net, name)))])
+    np.savez_compressed(os.path.join(OUT, "search_extra.npz"), **out)
+    print("search_extra.npz", str(out["genotype_fuse"])[:120])
+
+
 def gen_full_eval():
     """Eval-mode (running statistics) forward of the full configuration at 384 x 384 and 512 x 512: the pin for the bf16 mode at
     full size -- in train mode this randomly initialised network amplifies ANY perturbation ~1.3x per cell (f32 rounding
@@ -550,9 +577,9 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["ops", "criteria", "tiny", "search", "eval", "cells", "criteria2"] + \
+    todo = a.only.split(",") if a.only else ["ops", "criteria", "tiny", "search", "search_extra", "eval", "cells", "criteria2"] + \
         (["full", "full_grads", "full_eval", "cfg4"] if a.full else [])
     for t in todo:
         {"ops": gen_ops, "criteria": gen_criteria, "tiny": gen_tiny, "full": gen_full, "search": gen_search, "eval": gen_eval,
          "cells": gen_cells, "criteria2": gen_criteria2, "cfg4": gen_cfg4, "full_grads": gen_full_grads,
-         "full_eval": gen_full_eval}[t]()
+         "full_eval": gen_full_eval, "search_extra": gen_search_extra}[t]()

@@ -446,3 +446,33 @@ def test_full_net_named_gradients_match_reference():
             continue           # a conv bias in front of BatchNorm (edge_layer.1.bias): exact gradient 0
         assert rel_err(got, g[f"grad/{k}"]) < 2e-2, (k, rel_err(got, g[f"grad/{k}"]))
         assert abs(float(t[k].grad.double().norm()) - float(g[f"norm/{k}"])) < 2e-2 * float(g[f"norm/{k}"]), k
+
+
+def test_search_genotype_and_entropy_beta_match_reference():
+    """Host-side architecture read-outs of npp_amd's supernet (no GPU involved): genotype() and entropy_beta() on the same
+    non-uniform alphas / betas give exactly the reference's discrete architecture (model_search_interact.py:898-908, 913-1052)."""
+    import json
+    from types import SimpleNamespace as NS
+    from npp_amd.model_search_interact import Network
+    g = load_golden("search_extra.npz")
+    gs = load_golden("search_net.npz")
+    cfg = NS(DATASET=NS(NUM_CLASSES=20, NUM_JOINTS=16), SEARCH=NS(LAYERS=16, INIT_CHANNELS=16),
+             MODEL=NS(DECONV_WITH_BIAS=False, HEAD='PSP', REFINE_LAYERS=1))
+    net = Network(cfg)
+    sd = synth_tensors(template_from_golden(gs), 0)
+    for k in ["alphas1", "alphas2", "alphas3", "alphas4", "alphas_pose", "alphas_par", "betas1", "betas2", "betas3",
+              "betas4", "betas_pose", "betas_par"]:
+        sd[k] = sd[k] * 8.0
+    net.load_state_dict(sd)
+    inter, fuse = net.genotype()
+
+    def plain(stages):
+        return [[[str(n), int(i)] for n, i in st] for st in stages]
+    assert [plain(t) for t in inter] == json.loads(str(g["genotype_inter"]))
+    assert [plain([fuse.pose])[0], [int(i) for i in fuse.pose_concat], plain([fuse.par])[0],
+            [int(i) for i in fuse.par_concat]] == json.loads(str(g["genotype_fuse"]))
+    for k in g.files:
+        if k.startswith("entropy_beta/"):
+            n_in, steps, want = g[k]
+            got = float(net.entropy_beta(int(n_in), int(steps), getattr(net, k.split("/")[1])))
+            assert abs(got - want) < 1e-6, k

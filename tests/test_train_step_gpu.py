@@ -164,3 +164,89 @@ def test_capture_failure_falls_back_to_eager():
                        text=True, timeout=600)
     assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
     assert "capture failed" in r.stderr
+
+
+def _search_setup(dev, seed=0):
+    from types import SimpleNamespace as NS
+    from npp_amd.criterion import Criterion_par, Criterion_pose
+    from npp_amd.model_augment import set_compute_dtype
+    from npp_amd.model_search_interact import Network
+    set_compute_dtype(torch.float32)
+    torch.manual_seed(seed)
+    cfg = NS(DATASET=NS(NUM_CLASSES=20, NUM_JOINTS=16), SEARCH=NS(LAYERS=16, INIT_CHANNELS=8),
+             MODEL=NS(DECONV_WITH_BIAS=False, HEAD='PSP', REFINE_LAYERS=1))
+    net = Network(cfg).to(dev).train()
+    with torch.no_grad():
+        for i, a in enumerate(net.arch_parameters()):      # non-uniform architecture weights
+            a.copy_(torch.linspace(-1, 1, a.numel(), device=dev).reshape(a.shape) * (0.5 + 0.1 * i))
+    cp, cq = Criterion_pose(out_len=2).to(dev), Criterion_par(out_len=2).to(dev)
+    arch_ids = {id(a) for a in net.arch_parameters()}
+    weights = [p for p in net.parameters() if id(p) not in arch_ids] + list(cp.parameters()) + list(cq.parameters())
+    return net, cp, cq, weights
+
+
+def test_search_step_equals_the_reference_loop_body():
+    """SearchStep (train_with_alpha, core/function.py:485-621) against the loop body written out as the reference has it --
+    plain backward of every parameter in both passes, torch.optim.Adam twice -- from identical state: the frozen-parameter
+    passes must change nothing but the work done.  Second iteration with the entropy term (epoch > 70)."""
+    from npp_amd.optim import FusedAdam
+    from npp_amd.train_step import SearchStep
+    dev = torch.device("cuda:0")
+    w_lr, a_lr = 1e-3, 3e-3
+    net_a, cp_a, cq_a, w_a = _search_setup(dev)
+    net_b, cp_b, cq_b, w_b = _search_setup(dev)
+    net_b.load_state_dict(net_a.state_dict())
+    opt_a = FusedAdam(w_a, lr=w_lr)
+    aopt_a = FusedAdam(net_a.arch_parameters(), lr=a_lr, betas=(0.5, 0.999), weight_decay=0.001)
+    opt_b = torch.optim.Adam(w_b, lr=w_lr)
+    aopt_b = torch.optim.Adam(net_b.arch_parameters(), lr=a_lr, betas=(0.5, 0.999), weight_decay=0.001)
+    step = SearchStep(net_a, cp_a, cq_a, opt_a, aopt_a, graph=False)
+    for it in range(2):
+        b1, b2 = _batch(2, 64, 10 + it, dev), _batch(2, 64, 20 + it, dev)
+        entropy = it == 1
+        l1, l2 = step(b1, b2, entropy=entropy)
+        # the reference's loop body on the twin
+        im, lpar, lpose, pw = b1
+        po, pa = net_b(im)
+        loss1 = (cq_b(pa, lpar).unsqueeze(0) + cp_b(po, lpose, target_weight=pw).unsqueeze(0)).mean()
+        opt_b.zero_grad()
+        loss1.backward()
+        opt_b.step()
+        im, lpar, lpose, pw = b2
+        po, pa = net_b(im)
+        losses2 = cq_b(pa, lpar).unsqueeze(0) + cp_b(po, lpose, target_weight=pw).unsqueeze(0)
+        if entropy:
+            losses2 = losses2 + 2 * net_b.loss_entropy()
+        loss2 = 2 * losses2.mean()
+        aopt_b.zero_grad()
+        loss2.backward()
+        aopt_b.step()
+        torch.cuda.synchronize()
+        assert abs(float(l1) - float(loss1)) <= 2e-5 * abs(float(loss1)), (it, float(l1), float(loss1))
+        assert abs(float(l2) - float(loss2)) <= 2e-5 * abs(float(loss2)), (it, float(l2), float(loss2))
+        for a, b in zip(net_a.arch_parameters(), net_b.arch_parameters()):
+            assert float((a - b).abs().max()) <= 0.05 * a_lr, it          # Adam steps are ~lr: same direction, same size
+        off = tot = 0
+        for (k, p), q in zip(net_a.named_parameters(), net_b.parameters()):
+            if p.dim() == 4:
+                off += int(((p - q).abs() > 0.05 * w_lr * (it + 1)).sum())
+                tot += p.numel()
+        assert off <= 2e-3 * tot, (it, off, tot)
+    # the alpha pass left the weights' requires_grad flags as it found them
+    assert all(p.requires_grad for p in w_a) and all(a.requires_grad for a in net_a.arch_parameters())
+
+
+def test_search_step_graphed_runs_and_trains():
+    """Both passes captured (one hipGraph each): losses finite and falling on a repeated batch, architecture tensors moving."""
+    from npp_amd.optim import FusedAdam
+    from npp_amd.train_step import SearchStep
+    dev = torch.device("cuda:0")
+    net, cp, cq, w = _search_setup(dev)
+    before = [a.detach().clone() for a in net.arch_parameters()]
+    step = SearchStep(net, cp, cq, FusedAdam(w, lr=1e-3), FusedAdam(net.arch_parameters(), lr=3e-3, betas=(0.5, 0.999),
+                                                                  weight_decay=0.001), warmup=1)
+    b1, b2 = _batch(2, 64, 1, dev), _batch(2, 64, 2, dev)
+    losses = [tuple(float(x) for x in step(b1, b2)) for _ in range(5)]
+    assert step.weights_pass.graphed and step.alpha_pass(False).graphed
+    assert np.isfinite(losses).all() and losses[-1][0] < losses[0][0]
+    assert all(float((a - b).abs().max()) > 1e-3 for a, b in zip(net.arch_parameters(), before))
