@@ -106,12 +106,20 @@ class _ZeroPool:
         self.dtype, self.chunk = dtype, chunk_elems
         self.buf, self.off = None, 0
 
-    def get(self, n: int, device) -> torch.Tensor:
+    def get(self, n: int, device, own: bool = False) -> torch.Tensor:
         n_al = (n + 63) // 64 * 64
         if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
             self.buf = torch.zeros(max(self.chunk, n_al), dtype=self.dtype, device=device)
             self.off = 0
-        t = self.buf[self.off:self.off + n]
+        if not own:
+            t = self.buf[self.off:self.off + n]
+            self.off += n_al
+            return t
+        # own=True -- not a view: a tensor of its own on the chunk's storage.  Slices handed out here end up saved for backward
+        # (SE squeeze) AND as parameter gradients (1x1 weight gradients); views of one buffer share ONE version counter, so an
+        # in-place `p.grad += g` (a second backward before zero_grad, as the alpha pass of train_with_alpha does,
+        # core/function.py:613-615) would invalidate every saved slice of the chunk
+        t = torch.empty(0, dtype=self.dtype, device=self.buf.device).set_(self.buf.untyped_storage(), self.off, (n,), (1,))
         self.off += n_al
         return t
 
@@ -313,8 +321,9 @@ def stats_buffer(n, device, want_stats):
     return _sync_pool.cur().get(n, device) if want_stats == 2 else _zpool64.cur().get(n, device)
 
 
-def zeros_f32(n, device):
-    return _zpool32.cur().get(n, device)
+def zeros_f32(n, device, own=False):
+    """own: the slice will be saved for backward or become a parameter gradient (see _ZeroPool.get)."""
+    return _zpool32.cur().get(n, device, own)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -574,7 +583,7 @@ class _Conv2d(Function):
                 # packed [co][ci] == OIHW: accumulate straight into the gradient tensor
                 dw = grad_out(weight, zero=True)            # the parameter's (zeroed) slot in its gradient bucket, or
                 if dw is None:
-                    dw = zeros_f32(weight.numel(), x.device).view(weight.shape)     # pre-zeroed pool slice: no fill launch
+                    dw = zeros_f32(weight.numel(), x.device, own=True).view(weight.shape)     # pre-zeroed pool slice: no fill launch
                 check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
             else:
                 dwp = zeros_f32(nel, x.device)
@@ -1077,7 +1086,7 @@ class _SEScale(Function):
         n, c, h, w = x.shape
         dev = x.device
         s = stream_ptr()
-        pooled = zeros_f32(n * c, dev).view(n, c)
+        pooled = zeros_f32(n * c, dev, own=True).view(n, c)
         check(lib().npp_global_avgpool(_byref(x), pooled.data_ptr(), s), "npp_global_avgpool")
         hidden = torch.empty((n, c // 2), dtype=torch.float32, device=dev)
         gate = torch.empty((n, c), dtype=torch.float32, device=dev)

@@ -578,3 +578,31 @@ def test_full_network_named_gradients_match_reference():
 # set (test_oracle_golden.py::test_gradient_conditioning: the reference's own f32 is 1.2e-2 from its f64) and the train-mode
 # network amplifies perturbations (note above)
 FULL_GRAD_TOL, FULL_GRAD_NORM_TOL = 7e-2, 1e-2
+
+
+def test_gradients_accumulate_across_two_backwards():
+    """A second forward/backward WITHOUT zero_grad in between (the alpha pass of train_with_alpha leaves the weights' gradients
+    in place, core/function.py:613-615) accumulates into p.grad in place: no saved tensor may share a version counter with a
+    gradient (both used to be views of one pre-zeroed pool chunk), and the result is twice the single-pass gradient."""
+    g = load_golden("tiny_net.npz")
+    dev = _dev()
+    images, _, _, _ = synth_batch(int(g["n"]), 64, seed=0)
+    x = torch.from_numpy(images).to(dev)
+    net = _build_net(int(g["C"]), torch.float32, g).train()
+
+    def once():
+        p, q = net(x)
+        sum((t.float() ** 2).mean() for pair in p + q for t in pair).backward()
+    once()
+    torch.cuda.synchronize()
+    single = {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None}
+    once()                      # accumulates
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, v in net.named_parameters():
+        if v.grad is None:
+            continue
+        if float(single[k].abs().max()) < 1e-6:
+            continue
+        worst = max(worst, rel_l2(_f32(v.grad), 2 * _f32(single[k])))
+    assert worst < 3e-2, worst          # (run-to-run noise of these tiny maps, see test_two_stream_forward_equals_single_stream)
