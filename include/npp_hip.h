@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-enum { NPP_F32 = 0, NPP_BF16 = 1 };
+enum { NPP_F32 = 0, NPP_BF16 = 1,
+       NPP_MASK8 = 2   /* ReLU sign bit-mask, only as the `mask` of npp_conv_fwd: ptr -> bytes, bit j of byte [pixel][g] set iff
+                          channel 8g + j of that pixel was > 0; c = channels (multiple of 8), ld = BYTES per pixel row */ };
 /* Per-channel f64 accumulators (BN statistics, BN-backward sums, bias gradients) are kept in NPP_STAT_REPLICAS
  * copies: workgroup b adds into copy b % R, so at most (#workgroups / R) float atomics serialise on one address
  * (same-address atomics cost ~100 ns each on gfx950).  Layout [R][len]; consumers take the replica count. */
@@ -153,6 +155,11 @@ int npp_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
  * (identity).  Fuses BN-apply of both branches with the cell's h1 + h2 (model_augment.py:58). */
 int npp_affine_add(NppTensor* out, const NppTensor* a, const float* ss_a, const NppTensor* b,
                    const float* ss_b, int relu, void* stream);
+/* the same, also writing the ReLU bit-mask of the STORED output (NPP_MASK8 layout: byte [pixel * ld_mask + c/8], bf16 outputs
+ * with 16-byte rows only): the data gradient of a `ReLU -> conv` consumer then reads 1/16 of the bytes the bf16 tensor itself
+ * would cost as a mask (operations.py:69-82: nn.ReLU is the first layer of every op) */
+int npp_affine_add_m(NppTensor* out, const NppTensor* a, const float* ss_a, const NppTensor* b, const float* ss_b, int relu,
+                     unsigned char* mask_bits, int64_t ld_mask, void* stream);
 /* partials[b][0..C) = sum dy', partials[b][C..2C) = sum dy' * xhat over block b's pixels, dy' = dout * (out>0 if
  * relu_out given): one private slab per block (written, not added: no atomics, no zero-init).
  * nblocks = npp_reduce_blocks(N*H*W, C, dtype) (or fewer); bn_bwd_coeffs sums the slabs (nrep = nblocks). */
@@ -221,6 +228,8 @@ int npp_bilinear_bwd_ac(const NppTensor* dy, NppTensor* dx, int align_corners, v
 int npp_copy(const NppTensor* x, NppTensor* y, void* stream);                /* cast + channel-slice copy (cat) */
 /* torch.cat along channels in one launch: xs[k] ([N,c_k,H,W], any pixel stride) -> channel slice of y, sum c_k == y->c, n <= 8 */
 int npp_concat(const NppTensor* const* xs, int n, NppTensor* y, void* stream);
+/* + the ReLU bit-mask of y (NPP_MASK8 layout, ld_mask bytes per pixel; bf16, every c_k a multiple of 8) */
+int npp_concat_m(const NppTensor* const* xs, int n, NppTensor* y, unsigned char* mask_bits, int64_t ld_mask, void* stream);
 /* y = xs[0] + ... + xs[n-1], 1 <= n <= 8, same shape/dtype, any pixel strides: one-pass accumulation of the gradients of a
  * tensor with several consumers (replaces the autograd engine's chain of binary at::add, model_augment.py:48-62 fan-outs) */
 int npp_add_n(const NppTensor* const* xs, int n, NppTensor* y, void* stream);

@@ -14,7 +14,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnpp_hip.so")
 
-NPP_F32, NPP_BF16 = 0, 1
+NPP_F32, NPP_BF16, NPP_MASK8 = 0, 1, 2
+NPP_E_UNSUPPORTED = -5
 STAT_REPLICAS = 16   # NPP_STAT_REPLICAS in include/npp_hip.h
 FAM = {"none": 0, "conv_igemm": 1, "conv_wgrad": 2, "dwconv": 3, "bn": 4, "eltwise": 5, "pool": 6,
        "bilinear": 7, "loss": 8, "conv_s1": 9, "conv_g8": 10, "conv_g4": 11}
@@ -72,6 +73,7 @@ _SIGS = {
     "npp_bn_finalize": [_P, C.c_int, C.c_double, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int, _P],
     "npp_bn_eval_coeffs": [_P, _P, _P, _P, C.c_float, _P, C.c_int, _P],
     "npp_affine_add": [_T, _T, _P, _T, _P, C.c_int, _P],
+    "npp_affine_add_m": [_T, _T, _P, _T, _P, C.c_int, _P, C.c_int64, _P],
     "npp_bn_bwd_reduce": [_T, _T, _T, _P, _P, C.c_int, _P],
 
     "npp_bn_bwd_coeffs": [_P, C.c_int, C.c_double, _P, _P, _P, _P, _P, C.c_int, _P],
@@ -99,6 +101,7 @@ _SIGS = {
     "npp_copy": [_T, _T, _P],
     "npp_add_n": [_P, C.c_int, _T, _P],
     "npp_concat": [_P, C.c_int, _T, _P],
+    "npp_concat_m": [_P, C.c_int, _T, _P, C.c_int64, _P],
     "npp_pose_targets": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P],
     "npp_edge_target": [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
     "npp_normalize_image": [_P, C.c_int, C.c_int, C.c_int, _P, _P, _T, _P],

@@ -96,6 +96,41 @@ def take(x):
 def fan_reset():
     """Forget the aliases handed out so far (they keep their base tensors alive); called around every Network.forward."""
     _FAN_REG.clear()
+    _RELU_MASKS.clear()
+
+
+# --------------------------------------------------------------------------------------------------
+# ReLU bit-masks: 1 bit per element, written by the kernel that produces a tensor, read by the data gradient of a
+# `ReLU -> conv` consumer instead of the bf16 tensor itself (1/16 of the bytes; every op starts with nn.ReLU, operations.py:69-82)
+# --------------------------------------------------------------------------------------------------
+RELU_BITS = os.environ.get("NPP_RELU_BITS", "1") != "0"
+MASK_STATS = [0, 0, 0]      # data gradients that read a bit-mask / found one but ran on a kernel without support / found none
+_RELU_MASKS: dict = {}      # (data_ptr, channels) -> (weakref to the produced tensor, mask bytes, byte offset, bytes per pixel)
+
+
+def _mask_wanted(like: torch.Tensor) -> bool:
+    return (RELU_BITS and like.dtype == torch.bfloat16 and like.dim() == 4 and like.shape[1] % 8 == 0
+            and torch.is_grad_enabled())
+
+
+def _register_mask(t: torch.Tensor, spec):
+    if spec is not None:
+        if len(_RELU_MASKS) > 4096:
+            _RELU_MASKS.clear()
+        _RELU_MASKS[(t.data_ptr(), t.shape[1])] = (weakref.ref(t), spec[0], spec[1], spec[2])
+
+
+def relu_mask_of(x: torch.Tensor):
+    """NppTensor descriptor (+ the tensor that owns the bytes) of the bit-mask of `x`, if its producer wrote one."""
+    ent = _RELU_MASKS.get((x.data_ptr(), x.shape[1]))      # (part 0 of a concatenation starts where the whole does)
+    if ent is None:
+        return None
+    t = ent[0]()
+    # the producer's tensor object must still be alive (else the address may belong to someone else by now) and be this tensor
+    if t is None or t.data_ptr() != x.data_ptr() or t.shape != x.shape or t.stride() != x.stride():
+        return None
+    n, c, h, w = x.shape
+    return L.NppTensor(ent[1].data_ptr() + ent[2], n, h, w, c, ent[3], L.NPP_MASK8, 0), ent[1]
 
 
 class _ZeroPool:
@@ -508,8 +543,9 @@ def _conv_out(h, k, s, p, d):
 _conv_ws_cache = {}
 
 
-def _conv_launch(x, wp, bf, mask, y, stats, g, s, what):
-    """npp_conv_fwd with the split-K scratch the library asks for on small feature maps (queried once per shape)."""
+def _conv_launch(x, wp, bf, mask, y, stats, g, s, what, soft=False):
+    """npp_conv_fwd with the split-K scratch the library asks for on small feature maps (queried once per shape).
+    soft: return NPP_E_UNSUPPORTED instead of raising (a bit-mask on a shape whose kernel cannot read one)."""
     key = (tuple(x.shape), L.nhwc_ld(x), tuple(y.shape), L.nhwc_ld(y), x.dtype, g.kh, g.kw, g.sh, g.sw,
            g.ph, g.pw, g.dh, g.dw, g.uph, g.upw)
     nbytes = _conv_ws_cache.get(key)
@@ -517,9 +553,13 @@ def _conv_launch(x, wp, bf, mask, y, stats, g, s, what):
         nbytes = _conv_ws_cache[key] = int(lib().npp_conv_fwd_ws_bytes(_byref(x), _byref(y), C.byref(g)))
     if nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        check(lib().npp_conv_fwd_ws(_byref(x), wp, bf, mask, _byref(y), stats, C.byref(g), ws.data_ptr(), nbytes, s), what)
+        rc = lib().npp_conv_fwd_ws(_byref(x), wp, bf, mask, _byref(y), stats, C.byref(g), ws.data_ptr(), nbytes, s)
     else:
-        check(lib().npp_conv_fwd(_byref(x), wp, bf, mask, _byref(y), stats, C.byref(g), s), what)
+        rc = lib().npp_conv_fwd(_byref(x), wp, bf, mask, _byref(y), stats, C.byref(g), s)
+    if soft and rc == L.NPP_E_UNSUPPORTED:
+        return rc
+    check(rc, what)
+    return 0
 
 
 SHAPE_LOG = None     # tools/shape_prof.py: list of (kind, n, ci, h, w, co, kh, stride, dil) in launch order
@@ -548,6 +588,9 @@ class _Conv2d(Function):
         if SHAPE_LOG is not None:
             SHAPE_LOG.append(("fwd", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
         ctx.save_for_backward(x, weight, bias)
+        ctx.mask_bits = relu_mask_of(x) if (relu_in and RELU_BITS and x.dtype == torch.bfloat16) else None
+        if relu_in and ctx.mask_bits is None and RELU_BITS and x.dtype == torch.bfloat16:
+            MASK_STATS[2] += 1
         ctx.cfg = (stride, pad, dil, relu_in, bias is not None)
         ctx.set_materialize_grads(False)     # no zero tensor for the (non-differentiable) statistics output
         if stats is not None:
@@ -573,7 +616,13 @@ class _Conv2d(Function):
             g = geom(kh, kw, 1, 1, dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1], dil[0], dil[1],
                      (stride[0], stride[1]), 0)
             wp = packed_weight(weight, True, x.dtype)
-            _conv_launch(dy, wp.data_ptr(), None, _byref(x) if relu_in else None, dx, None, g, s, "npp_conv_fwd(dgrad)")
+            done = False
+            if relu_in and ctx.mask_bits is not None:      # the producer of x left a bit-mask: 1/16 of the mask bytes
+                done = _conv_launch(dy, wp.data_ptr(), None, C.byref(ctx.mask_bits[0]), dx, None, g, s, "npp_conv_fwd(dgrad)",
+                                    soft=True) == 0
+                MASK_STATS[0 if done else 1] += 1
+            if not done:
+                _conv_launch(dy, wp.data_ptr(), None, _byref(x) if relu_in else None, dx, None, g, s, "npp_conv_fwd(dgrad)")
             if SHAPE_LOG is not None:
                 SHAPE_LOG.append(("dgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
         if ctx.needs_input_grad[1]:
@@ -814,7 +863,7 @@ class _BnAdd(Function):
     """out = relu?( [BN_a](a) + [BN_b](b) ).  Tensor args: a, gamma_a, beta_a, b, gamma_b, beta_b."""
 
     @staticmethod
-    def forward(ctx, a, ga, ba, b, gb, bb, sa: BnSide, sb: Optional[BnSide], relu: bool, training: bool, out=None):
+    def forward(ctx, a, ga, ba, b, gb, bb, sa: BnSide, sb: Optional[BnSide], relu: bool, training: bool, out=None, mk=None):
         # out: None, or a 1-element list holding the tensor to write (a channel slice of a cell's output buffer, see
         # ConcatBuffer); wrapped so that autograd does not see an in-place write into a view
         dev = a.device
@@ -829,8 +878,12 @@ class _BnAdd(Function):
             if sb is not None and sb.bn is not None:
                 ssb, mib, batch_b = _bn_coeffs(sb, training, dev)
         y = out[0] if out is not None else new_nhwc(*a.shape, a.dtype, dev)
-        check(lib().npp_affine_add(_byref(y), _byref(a), ptr(ssa), tref(b), ptr(ssb), int(relu), stream_ptr()),
-              "npp_affine_add")
+        if mk is not None:      # (mask bytes, byte offset, bytes per pixel): the kernel also writes y's ReLU bit-mask
+            check(lib().npp_affine_add_m(_byref(y), _byref(a), ptr(ssa), tref(b), ptr(ssb), int(relu),
+                                         mk[0].data_ptr() + mk[1], mk[2], stream_ptr()), "npp_affine_add_m")
+        else:
+            check(lib().npp_affine_add(_byref(y), _byref(a), ptr(ssa), tref(b), ptr(ssb), int(relu), stream_ptr()),
+                  "npp_affine_add")
         ctx.relu = relu
         ctx.sides = (sa.bn, sb.bn if sb is not None else None, batch_a, batch_b, sa.count, sb.count if sb else None,
                      b is not None)
@@ -892,7 +945,7 @@ class _BnAdd(Function):
             check(lib().npp_bn_bwd_apply2(_byref(dout), _byref(a), _byref(b), tref(yrelu), co[:3 * c].data_ptr(),
                                           co[3 * c:].data_ptr(), _byref(dxa), _byref(dxb), s), "npp_bn_bwd_apply2")
             return (dxa, dgb_[0] if ni[1] else None, dgb_[1] if ni[2] else None,
-                    dxb, dgb_[2] if ni[4] else None, dgb_[3] if ni[5] else None, None, None, None, None, None)
+                    dxb, dgb_[2] if ni[4] else None, dgb_[3] if ni[5] else None, None, None, None, None, None, None)
         sides = [(a, bna, mia, ssa, batch_a, cnt_a, ni[0], ni[1], ni[2])]
         if has_b:
             sides.append((b, bnb, mib, ssb, batch_b, cnt_b, ni[3], ni[4], ni[5]))
@@ -963,7 +1016,7 @@ class _BnAdd(Function):
         dbx = dgb = dbb = None
         if has_b:
             dbx, dgb, dbb = outs[1]
-        return da, dga, dba, dbx, dgb, dbb, None, None, None, None, None
+        return da, dga, dba, dbx, dgb, dbb, None, None, None, None, None, None
 
 
 def bn_add(sa: BnSide, sb: Optional[BnSide] = None, relu: bool = False, training: bool = True, out=None):
@@ -982,12 +1035,18 @@ def bn_add(sa: BnSide, sb: Optional[BnSide] = None, relu: bool = False, training
             sb.x = b
         if sb.bn is not None:
             gb, bb = sb.bn.weight, sb.bn.bias
-    holder = None
+    holder = mk = None
     if out is not None:
         y = out(a)
         if y is not None:
             holder = [y]
-    return _BnAdd.apply(a, ga, ba, b, gb, bb, sa, sb, bool(relu), bool(training), holder)
+            mk = out.mask_spec() if hasattr(out, "mask_spec") else None
+    if mk is None and holder is None and _mask_wanted(a):
+        n, c, h, w = a.shape
+        mk = (torch.empty(n * h * w * (c // 8), dtype=torch.uint8, device=a.device), 0, c // 8)
+    res = _BnAdd.apply(a, ga, ba, b, gb, bb, sa, sb, bool(relu), bool(training), holder, mk)
+    _register_mask(res, mk)
+    return res
 
 
 def add(a, b):
@@ -1190,7 +1249,7 @@ def cast(x, dtype):
 
 class _Concat(Function):
     @staticmethod
-    def forward(ctx, *xs):
+    def forward(ctx, want_mask, *xs):
         xs = [to_nhwc(x) for x in xs]
         n, _, h, w = xs[0].shape
         ctot = sum(x.shape[1] for x in xs)
@@ -1199,7 +1258,13 @@ class _Concat(Function):
         if len(xs) <= 8 and all(x.dtype == y.dtype for x in xs):
             descs = [desc(x) for x in xs]
             arr = (C.POINTER(L.NppTensor) * len(xs))(*[C.pointer(d) for d in descs])
-            check(lib().npp_concat(arr, len(xs), _byref(y), s), "npp_concat")
+            if want_mask and all(x.shape[1] % 8 == 0 and L.nhwc_ld(x) % 8 == 0 for x in xs):
+                mk = torch.empty(n * h * w * (ctot // 8), dtype=torch.uint8, device=y.device)
+                check(lib().npp_concat_m(arr, len(xs), _byref(y), mk.data_ptr(), ctot // 8, s), "npp_concat_m")
+                _Concat.last_mask = (mk, 0, ctot // 8)
+            else:
+                _Concat.last_mask = None
+                check(lib().npp_concat(arr, len(xs), _byref(y), s), "npp_concat")
         else:
             off = 0
             for x in xs:
@@ -1212,7 +1277,7 @@ class _Concat(Function):
     @staticmethod
     def backward(ctx, dy):
         dy = to_nhwc(dy)
-        outs = []
+        outs = [None]
         off = 0
         for c in ctx.splits:
             outs.append(dy[:, off:off + c])   # channel-slice views: consumers take ld, no copy
@@ -1221,7 +1286,11 @@ class _Concat(Function):
 
 
 def concat(xs: Sequence[torch.Tensor]):
-    return _Concat.apply(*[take(x) for x in xs])
+    _Concat.last_mask = None
+    res = _Concat.apply(_mask_wanted(xs[0]), *[take(x) for x in xs])
+    _register_mask(res, _Concat.last_mask)
+    _Concat.last_mask = None
+    return res
 
 
 class _SplitHalf(Function):
@@ -1313,24 +1382,37 @@ class ConcatBuffer:
         self.buf = None
         self.parts: List[Optional[torch.Tensor]] = [None] * nparts
         self.c = None
+        self.mask = None
 
     def slot(self, k: int):
-        """out= argument for the producer of part k."""
-        def make(like: torch.Tensor):
-            if not ConcatBuffer.ENABLED or like.dim() != 4:
-                return None
-            n, c, h, w = like.shape
-            if self.buf is None:
-                if c % 8 != 0 or not (ConcatBuffer.MINC <= c <= ConcatBuffer.MAXC):
+        """out= argument for the producer of part k: slot(like) -> the tensor to write (or None), slot.mask_spec() -> where the
+        part's ReLU bit-mask goes (the buffer owns ONE mask for the whole concatenation: consumers of a part and consumers
+        of the whole both find their bits in it)."""
+        cb = self
+
+        class _Slot:
+            def __call__(self, like: torch.Tensor):
+                if not ConcatBuffer.ENABLED or like.dim() != 4:
                     return None
-                self.c = c
-                self.buf = new_nhwc(n, c * self.nparts, h, w, like.dtype, like.device)
-            b = self.buf
-            if (c != self.c or b.shape[0] != n or b.shape[2] != h or b.shape[3] != w or b.dtype != like.dtype
-                    or b.device != like.device):
-                return None
-            return _alias(b, k * c, c)
-        return make
+                n, c, h, w = like.shape
+                if cb.buf is None:
+                    if c % 8 != 0 or not (ConcatBuffer.MINC <= c <= ConcatBuffer.MAXC):
+                        return None
+                    cb.c = c
+                    cb.buf = new_nhwc(n, c * cb.nparts, h, w, like.dtype, like.device)
+                    if _mask_wanted(like):
+                        cb.mask = torch.empty(n * h * w * (c * cb.nparts // 8), dtype=torch.uint8, device=like.device)
+                b = cb.buf
+                if (c != cb.c or b.shape[0] != n or b.shape[2] != h or b.shape[3] != w or b.dtype != like.dtype
+                        or b.device != like.device):
+                    return None
+                return _alias(b, k * c, c)
+
+            def mask_spec(self):
+                if cb.mask is None:
+                    return None
+                return (cb.mask, k * cb.c // 8, cb.c * cb.nparts // 8)
+        return _Slot()
 
     def result(self, parts: Sequence[torch.Tensor]) -> torch.Tensor:
         """The concatenation of `parts` (the tensors the producers returned, in order)."""
@@ -1344,7 +1426,10 @@ class ConcatBuffer:
                     break
         if not ok:
             return concat(parts)
-        return _ConcatAlias.apply([self.buf], *[take(t) for t in parts])
+        res = _ConcatAlias.apply([self.buf], *[take(t) for t in parts])
+        if self.mask is not None:
+            _register_mask(res, (self.mask, 0, self.c * self.nparts // 8))
+        return res
 
 
 class _ImageToNhwc(Function):

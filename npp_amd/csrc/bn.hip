@@ -217,10 +217,24 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 // HAS_B / SSA / SSB are compile-time: a load behind a runtime pointer test makes hipcc branch around it and wait vmcnt(0)
 // right after (cdna_hip_programming.md 5, trap 4c) -- the first version of this kernel had two loads in flight and ran at
 // 3.0 TB/s where bn_bwd_apply, same traffic, ran at 6.1 (37.7 MB tensors); all four loads of an iteration are now issued first.
-template <typename T, int V, bool HAS_B, bool SSA, bool SSB>
+// bits of a 16-byte bf16 vector that are > 0 (sign clear, not zero), channel j -> bit j: the NPP_MASK8 byte
+NPP_DEV unsigned pos_bits_bf16x8(const u32x4& v) {
+  unsigned r = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int lo = (int)(short)(v[i] & 0xFFFFu), hi = (int)v[i] >> 16;
+    r |= (lo > 0 ? 1u : 0u) << (2 * i);
+    r |= (hi > 0 ? 1u : 0u) << (2 * i + 1);
+  }
+  return r;
+}
+
+// MASK (bf16, V == 8 only): also store the ReLU bit-mask byte of every 16-byte output vector
+template <typename T, int V, bool HAS_B, bool SSA, bool SSB, bool MASK = false>
 __global__ __launch_bounds__(256) void affine_add_kernel(T* __restrict__ out, long ldo, const T* __restrict__ a, long lda,
                                                          const float* __restrict__ ssa, const T* __restrict__ b, long ldb,
-                                                         const float* __restrict__ ssb, int relu, long npix, int C, ColMap m) {
+                                                         const float* __restrict__ ssb, int relu, long npix, int C, ColMap m,
+                                                         unsigned char* __restrict__ mk = nullptr, long ldmk = 0) {
   const int t = threadIdx.x;
   if (t >= m.rows * m.cols_blk) return;
   const int col = t % m.cols_blk, row = t / m.cols_blk;
@@ -258,8 +272,23 @@ __global__ __launch_bounds__(256) void affine_add_kernel(T* __restrict__ out, lo
       }
       if (relu) { o[j] = fmaxf(o[j], 0.f); o2[j] = fmaxf(o2[j], 0.f); }
     }
-    stv<T, V>(out + p * ldo + c0, o);
-    if (two) stv<T, V>(out + p2 * ldo + c0, o2);
+    if constexpr (MASK) {
+      u32x4 w, w2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        w[i] = (unsigned)f2bf(o[2 * i]) | ((unsigned)f2bf(o[2 * i + 1]) << 16);
+        w2[i] = (unsigned)f2bf(o2[2 * i]) | ((unsigned)f2bf(o2[2 * i + 1]) << 16);
+      }
+      *reinterpret_cast<u32x4*>(out + p * ldo + c0) = w;
+      mk[p * ldmk + colg] = (unsigned char)pos_bits_bf16x8(w);
+      if (two) {
+        *reinterpret_cast<u32x4*>(out + p2 * ldo + c0) = w2;
+        mk[p2 * ldmk + colg] = (unsigned char)pos_bits_bf16x8(w2);
+      }
+    } else {
+      stv<T, V>(out + p * ldo + c0, o);
+      if (two) stv<T, V>(out + p2 * ldo + c0, o2);
+    }
   }
 }
 
@@ -640,30 +669,48 @@ extern "C" int npp_bn_eval_coeffs(const float* gamma, const float* beta, const f
   return npp_check_launch("bn_eval_coeffs");
 }
 
-#define AFF(HB, SA, SB)                                                                                               \
-    hipLaunchKernelGGL((affine_add_kernel<T, V, HB, SA, SB>), col_grid_ew(m, npix(out)), dim3(256), 0, (hipStream_t)stream, \
+#define AFF(HB, SA, SB, MK)                                                                                           \
+    hipLaunchKernelGGL((affine_add_kernel<T, V, HB, SA, SB, MK>), col_grid_ew(m, npix(out)), dim3(256), 0, (hipStream_t)stream, \
                        (T*)out->ptr, (long)out->ld, (const T*)a->ptr, (long)a->ld, ss_a, b ? (const T*)b->ptr : nullptr,   \
-                       b ? (long)b->ld : 0L, ss_b, relu, (long)npix(out), (int)out->c, m)
-extern "C" int npp_affine_add(NppTensor* out, const NppTensor* a, const float* ss_a, const NppTensor* b,
-                              const float* ss_b, int relu, void* stream) {
+                       b ? (long)b->ld : 0L, ss_b, relu, (long)npix(out), (int)out->c, m, mask_bits, (long)ld_mask)
+#define AFF_ALL(MK)                                                                                                   \
+    do {                                                                                                              \
+      if (b) {                                                                                                        \
+        if (ss_a) { if (ss_b) AFF(true, true, true, MK); else AFF(true, true, false, MK); }                           \
+        else      { if (ss_b) AFF(true, false, true, MK); else AFF(true, false, false, MK); }                         \
+      } else {                                                                                                        \
+        if (ss_a) AFF(false, true, false, MK); else AFF(false, false, false, MK);                                     \
+      }                                                                                                               \
+    } while (0)
+extern "C" int npp_affine_add_m(NppTensor* out, const NppTensor* a, const float* ss_a, const NppTensor* b, const float* ss_b,
+                                int relu, unsigned char* mask_bits, int64_t ld_mask, void* stream) {
   NPP_REQUIRE(out && a && out->ptr && a->ptr, NPP_E_NULL, "npp_affine_add: null pointer");
   NPP_REQUIRE(same_shape(out, a) && (!b || same_shape(out, b)), NPP_E_SHAPE, "npp_affine_add: shape mismatch");
   NPP_REQUIRE(dtype_ok(out) && out->dtype == a->dtype && (!b || b->dtype == a->dtype), NPP_E_DTYPE,
               "npp_affine_add: dtype mismatch");
   const bool vk = vec_ok(out) && vec_ok(a) && (!b || vec_ok(b));
+  NPP_REQUIRE(!mask_bits || (vk && out->dtype == NPP_BF16 && ld_mask >= out->c / 8), NPP_E_UNSUPPORTED,
+              "npp_affine_add_m: the bit-mask needs bf16 tensors with 16-byte rows and ld_mask >= c/8");
   const int nt = b ? 3 : 2;
   ProfScope prof(NPP_FAM_ELTWISE, out->dtype, (hipStream_t)stream, 0, (double)npix(out) * out->c * esize(out->dtype) * nt);
-  NPP_DISPATCH_TV(out->dtype, vk, {
+  if (mask_bits) {
+    typedef bf16_t T;
+    constexpr int V = 8;
     ColMap m = col_map(out->c, V);
-    if (b) {
-      if (ss_a) { if (ss_b) AFF(true, true, true); else AFF(true, true, false); }
-      else      { if (ss_b) AFF(true, false, true); else AFF(true, false, false); }
-    } else {
-      if (ss_a) AFF(false, true, false); else AFF(false, false, false);
-    }
-  });
+    AFF_ALL(true);
+  } else {
+    NPP_DISPATCH_TV(out->dtype, vk, {
+      ColMap m = col_map(out->c, V);
+      AFF_ALL(false);
+    });
+  }
   return npp_check_launch("affine_add");
 }
+extern "C" int npp_affine_add(NppTensor* out, const NppTensor* a, const float* ss_a, const NppTensor* b,
+                              const float* ss_b, int relu, void* stream) {
+  return npp_affine_add_m(out, a, ss_a, b, ss_b, relu, nullptr, 0, stream);
+}
+#undef AFF_ALL
 #undef AFF
 
 static inline int reduce_blocks(long npix, long c, int dtype) {

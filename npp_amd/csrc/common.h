@@ -68,6 +68,15 @@ template <> struct Vec16<bf16_t> {
   }
 };
 
+// NPP_MASK8 byte -> AND-mask of a 16-byte bf16 vector: bit j set keeps channel j
+NPP_DEV u32x4 mask8_expand(unsigned b) {
+  u32x4 m;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    m[i] = ((unsigned)__builtin_amdgcn_sbfe((int)b, 2 * i, 1) & 0xFFFFu) | ((unsigned)__builtin_amdgcn_sbfe((int)b, 2 * i + 1, 1) & 0xFFFF0000u);
+  return m;
+}
+
 // Workgroups go to the 8 XCDs (8 separate L2s) round-robin by blockIdx.x.  A kernel whose neighbouring blocks read
 // overlapping rows (3x3 windows, bilinear taps, dilated depthwise taps) wants neighbours on ONE XCD, or every XCD fetches
 // the shared rows from HBM for itself: virtual block id = the (blockIdx.x >> 3)-th block of XCD (blockIdx.x & 7)'s contiguous

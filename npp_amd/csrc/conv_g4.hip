@@ -235,11 +235,21 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
     for (int h = 0; h < 2; ++h)
       bias[h] = p.bias ? *reinterpret_cast<const f32x4w*>(p.bias + cb + h * 16 + lk * 4) : f32x4w{0.f, 0.f, 0.f, 0.f};
     u32x4 mk[MI];
+    unsigned mkb[MI];
     if (mg) {
+      if (p.mask_bits) {      // NPP_MASK8: one byte covers the lane's 8 channels
+        const unsigned char* mg8 = reinterpret_cast<const unsigned char*>(p.mask);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const long gm = (long)m0 + wm * TM + mi * 16 + lrow;
-        mk[mi] = gm < p.M ? *reinterpret_cast<const u32x4*>(mg + gm * p.ldm + cb + chb) : u32x4{0u, 0u, 0u, 0u};
+        for (int mi = 0; mi < MI; ++mi) {
+          const long gm = (long)m0 + wm * TM + mi * 16 + lrow;
+          mkb[mi] = gm < p.M ? (unsigned)mg8[gm * p.ldm + ((cb + chb) >> 3)] : 0u;
+        }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const long gm = (long)m0 + wm * TM + mi * 16 + lrow;
+          mk[mi] = gm < p.M ? *reinterpret_cast<const u32x4*>(mg + gm * p.ldm + cb + chb) : u32x4{0u, 0u, 0u, 0u};
+        }
       }
     }
     float ss[2][4], sq[2][4];
@@ -272,10 +282,14 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
       u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
       if (live) {
         if (mg) {
-          const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-          s16x8 m = __builtin_elementwise_max(__builtin_bit_cast(s16x8, mk[mi]), z);
-          m = (z - m) >> 15;
-          o = o & __builtin_bit_cast(u32x4, m);
+          if (p.mask_bits) {
+            o = o & mask8_expand(mkb[mi]);
+          } else {
+            const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            s16x8 m = __builtin_elementwise_max(__builtin_bit_cast(s16x8, mk[mi]), z);
+            m = (z - m) >> 15;
+            o = o & __builtin_bit_cast(u32x4, m);
+          }
         }
         if constexpr ((G4_DBG & 1) == 0) *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
         else asm volatile("" :: "v"(o));

@@ -255,14 +255,26 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
       // ReLU-backward mask of this 32-channel block: all 2*MQ loads in flight at once (the main loop's fragment
       // registers are free here); one load per store would pay the memory latency 2*MQ times per block
       u32x4 mk[2][MQ];
+      unsigned mkb[2][MQ];
       if (mg) {
+        if (p.mask_bits) {      // NPP_MASK8: one byte covers the lane's 8 channels (1/16 of the bytes)
+          const unsigned char* mg8 = reinterpret_cast<const unsigned char*>(p.mask);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+          for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int mi = 0; mi < MQ; ++mi) {
-            const long gm = (long)m0c + wm * WM + a * HM + mi * 16 + lrow;
-            mk[a][mi] = gm < p.M ? *reinterpret_cast<const u32x4*>(mg + gm * p.ldm + cb + chb) : u32x4{0u, 0u, 0u, 0u};
-          }
+            for (int mi = 0; mi < MQ; ++mi) {
+              const long gm = (long)m0c + wm * WM + a * HM + mi * 16 + lrow;
+              mkb[a][mi] = gm < p.M ? (unsigned)mg8[gm * p.ldm + ((cb + chb) >> 3)] : 0u;
+            }
+        } else {
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int mi = 0; mi < MQ; ++mi) {
+              const long gm = (long)m0c + wm * WM + a * HM + mi * 16 + lrow;
+              mk[a][mi] = gm < p.M ? *reinterpret_cast<const u32x4*>(mg + gm * p.ldm + cb + chb) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -291,10 +303,14 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
           u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
           if (live) {
             if (mg) {      // ReLU backward: keep where the forward input was positive (bf16 > 0 <=> int16 > 0)
-              const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-              s16x8 m = __builtin_elementwise_max(__builtin_bit_cast(s16x8, mk[a][mi]), z);
-              m = (z - m) >> 15;                               // 0xFFFF where the mask value was positive
-              o = o & __builtin_bit_cast(u32x4, m);
+              if (p.mask_bits) {
+                o = o & mask8_expand(mkb[a][mi]);
+              } else {
+                const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                s16x8 m = __builtin_elementwise_max(__builtin_bit_cast(s16x8, mk[a][mi]), z);
+                m = (z - m) >> 15;                               // 0xFFFF where the mask value was positive
+                o = o & __builtin_bit_cast(u32x4, m);
+              }
             }
             *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
           }

@@ -445,8 +445,11 @@ extern "C" int64_t npp_conv_fwd_ws_bytes(const NppTensor* x, const NppTensor* y,
 static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask, NppTensor* y,
                          double* stats, const NppConvGeom* g, void* ws, size_t ws_bytes, void* stream, size_t* ws_query) {
   NPP_REQUIRE(x && w_packed && y && g && x->ptr && y->ptr, NPP_E_NULL, "npp_conv_fwd: null pointer");
-  NPP_REQUIRE(x->dtype == y->dtype && (!mask || mask->dtype == y->dtype), NPP_E_DTYPE,
+  const bool mask_bits = mask && mask->dtype == NPP_MASK8;
+  NPP_REQUIRE(x->dtype == y->dtype && (!mask || mask_bits || mask->dtype == y->dtype), NPP_E_DTYPE,
               "npp_conv_fwd: x/y/mask dtypes must match (%d,%d)", x->dtype, y->dtype);
+  NPP_REQUIRE(!mask_bits || (y->dtype == NPP_BF16 && mask->c % 8 == 0 && mask->ld >= mask->c / 8 && mask->ptr), NPP_E_UNSUPPORTED,
+              "npp_conv_fwd: a bit-mask needs bf16 outputs and c %% 8 == 0");
   NPP_REQUIRE(x->dtype == NPP_F32 || x->dtype == NPP_BF16, NPP_E_DTYPE, "npp_conv_fwd: bad dtype");
   const int vec = x->dtype == NPP_BF16 ? 8 : 4;
   const int cp = round_up((int)x->c, 8);
@@ -475,8 +478,9 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
   const long M = (long)y->n * y->h * y->w;
   NPP_REQUIRE(M > 0 && M < (1L << 30) && (long)x->n * x->h * x->w < (1L << 30), NPP_E_SHAPE, "npp_conv_fwd: too many pixels");
   p.M = (int)M;
+  p.mask_bits = mask_bits ? 1 : 0;
   p.vec_io = (y->ld % vec == 0) && (((uintptr_t)y->ptr & 15) == 0) &&
-             (!mask || ((mask->ld % vec == 0) && (((uintptr_t)mask->ptr & 15) == 0)));
+             (!mask || mask_bits || ((mask->ld % vec == 0) && (((uintptr_t)mask->ptr & 15) == 0)));
   const int npad = round_up(p.Cout, 32);
   const int bn = (npad % 128 == 0) ? 128 : (npad % 64 == 0 ? 64 : 32);
   p.mtiles = (p.M + BM - 1) / BM;
@@ -498,6 +502,10 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
     ProfScope prof0(NPP_FAM_CONV_G8, x->dtype, s, flops, bytes);
     if (conv_g8_launch(p, x->dtype, s)) return npp_check_launch("conv_g8");
     prof0.cancel();
+  }
+  if (p.mask_bits) {      // only the LDS-DMA kernels above read bit-masks: the caller retries with the bf16 tensor as mask
+    npp_set_error("npp_conv_fwd: this shape runs on a kernel without bit-mask support");
+    return NPP_E_UNSUPPORTED;
   }
   {
     ProfScope prof1(NPP_FAM_CONV_S1, x->dtype, s, flops, bytes);

@@ -8,6 +8,7 @@ struct IgemmParams {
   int KH, KW, sh, sw, ph, pw, dh, dw, uph, upw, relu_in;
   int M, mtiles, ntiles;
   int vec_io;
+  int mask_bits;   // `mask` is an NPP_MASK8 bit-mask (ldm in BYTES per pixel): conv_g4 / conv_g8 only
 };
 // stride-1 "same" convolution fast path (conv_s1.hip); returns false when the shape is not eligible
 bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream, void* ws, size_t ws_bytes);

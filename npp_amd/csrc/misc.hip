@@ -114,8 +114,9 @@ struct ConcatArgs {
   int cv_end[8];      // running end of each source in 16-byte (or scalar) column units
   int n;
 };
-template <typename T, int V>
-__global__ __launch_bounds__(256) void concat_kernel(ConcatArgs a, T* __restrict__ y, long ldy, long npix, int cvt) {
+template <typename T, int V, bool MASK = false>
+__global__ __launch_bounds__(256) void concat_kernel(ConcatArgs a, T* __restrict__ y, long ldy, long npix, int cvt,
+                                                     unsigned char* __restrict__ mk = nullptr, long ldmk = 0) {
   const unsigned total = (unsigned)(npix * cvt);
   const FastDiv fd((unsigned)cvt);
   for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
@@ -128,12 +129,29 @@ __global__ __launch_bounds__(256) void concat_kernel(ConcatArgs a, T* __restrict
     const T* src = reinterpret_cast<const T*>(a.x[k]) + (long)p * a.ld[k] + ((int)c - c0) * V;
     T* dst = y + (long)p * ldy + c * V;
     if constexpr (V == 1) *dst = *src;
-    else *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+    else {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src);
+      *reinterpret_cast<u32x4*>(dst) = v;
+      if constexpr (MASK) {      // NPP_MASK8 byte of this 16-byte bf16 vector: channel j > 0 -> bit j
+        unsigned r = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int lo = (int)(short)(v[i] & 0xFFFFu), hi = (int)v[i] >> 16;
+          r |= (lo > 0 ? 1u : 0u) << (2 * i);
+          r |= (hi > 0 ? 1u : 0u) << (2 * i + 1);
+        }
+        mk[(long)p * ldmk + c] = (unsigned char)r;
+      }
+    }
   }
 }
 }  // namespace
 
 extern "C" int npp_concat(const NppTensor* const* xs, int n, NppTensor* y, void* stream) {
+  return npp_concat_m(xs, n, y, nullptr, 0, stream);
+}
+
+extern "C" int npp_concat_m(const NppTensor* const* xs, int n, NppTensor* y, unsigned char* mask_bits, int64_t ld_mask, void* stream) {
   NPP_REQUIRE(xs && y && y->ptr && n >= 1 && n <= 8, NPP_E_NULL, "npp_concat: need 1..8 sources");
   NPP_REQUIRE(dtype_ok(y), NPP_E_DTYPE, "npp_concat: bad dtype");
   const int v = y->dtype == NPP_BF16 ? 8 : 4;
@@ -161,6 +179,13 @@ extern "C" int npp_concat(const NppTensor* const* xs, int n, NppTensor* y, void*
   ProfScope prof(NPP_FAM_ELTWISE, y->dtype, s, 0, (double)npix(y) * y->c * esize(y->dtype) * 2);
   const int cvt = run;
 #define CC(T, V_) hipLaunchKernelGGL((concat_kernel<T, V_>), dim3(grid_for(npix(y) * cvt)), dim3(256), 0, s, a, (T*)y->ptr, (long)y->ld, (long)npix(y), cvt)
+  if (mask_bits) {
+    NPP_REQUIRE(vk && y->dtype == NPP_BF16 && ld_mask >= y->c / 8, NPP_E_UNSUPPORTED,
+                "npp_concat_m: the bit-mask needs bf16 tensors with 16-byte rows and ld_mask >= c/8");
+    hipLaunchKernelGGL((concat_kernel<bf16_t, 8, true>), dim3(grid_for(npix(y) * cvt)), dim3(256), 0, s, a, (bf16_t*)y->ptr,
+                       (long)y->ld, (long)npix(y), cvt, mask_bits, (long)ld_mask);
+    return npp_check_launch("concat");
+  }
   if (y->dtype == NPP_BF16) { if (vk) CC(bf16_t, 8); else CC(bf16_t, 1); }
   else { if (vk) CC(float, 4); else CC(float, 1); }
 #undef CC

@@ -477,3 +477,57 @@ def test_concat_buffer_parts_written_in_place():
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
     ref = torch.cat([p.detach() for p in parts], 1)
     assert torch.equal(ref, y1)
+
+
+def test_relu_bit_masks_equal_the_tensor_mask():
+    """The ReLU bit-mask written by the producer of a tensor (npp_affine_add_m / npp_concat_m, NPP_MASK8) and read by the data
+    gradient of its `ReLU -> conv` consumers (conv_g4 / conv_g8) against the bf16 tensor itself as the mask: bit-identical
+    gradients, for a standalone tensor, for the parts and the whole of an in-place concatenation and for npp_concat; shapes on
+    kernels without bit-mask support fall back silently."""
+    from npp_amd import _ops as K
+    from npp_amd.model_augment import set_compute_dtype
+    from npp_amd.operations import ReLUConvBN
+    dev = torch.device("cuda:0")
+    set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(3)
+        N, C, H = 4, 64, 24
+        pre = [ReLUConvBN(C, C, 1, 1, 0).to(dev).train() for _ in range(3)]
+        cons_part = ReLUConvBN(C, C, 3, 1, 1).to(dev).train()            # consumes ONE part of the concatenation (conv_g4)
+        cons_all = ReLUConvBN(3 * C, 2 * C, 1, 1, 0).to(dev).train()     # consumes the whole buffer
+        cons_cat = ReLUConvBN(2 * C, C, 3, 1, 1).to(dev).train()         # consumes an npp_concat result
+        cons_s2 = ReLUConvBN(C, C, 3, 2, 1).to(dev).train()              # stride 2: generic kernel, falls back to the tensor mask
+        x0 = torch.randn(N, C, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+
+        def run(bits):
+            K.RELU_BITS = bits
+            K.MASK_STATS[0] = K.MASK_STATS[1] = 0
+            K.fan_reset()
+            x = K.cast(x0, torch.bfloat16).detach().requires_grad_(True)
+            cb = K.ConcatBuffer(3)
+            parts = [pre[i](x, out=cb.slot(i)) for i in range(3)]
+            whole = cb.result(parts)
+            lone = pre[0](x)                                               # standalone bn_add output
+            cat = K.concat([parts[1], lone])
+            outs = [cons_part(parts[0]), cons_all(whole), cons_cat(cat), cons_s2(lone), cons_part(lone)]
+            loss = sum((o.float() * (i + 1)).sum() for i, o in enumerate(outs))
+            for m in pre + [cons_part, cons_all, cons_cat, cons_s2]:
+                m.zero_grad()
+            loss.backward()
+            K.fan_reset()
+            torch.cuda.synchronize()
+            grads = [x.grad.detach().float().clone()] + [p.grad.detach().clone() for m in pre for p in m.parameters()]
+            return grads, tuple(K.MASK_STATS)
+        try:
+            ref, st0 = run(False)
+            got, st1 = run(True)
+        finally:
+            K.RELU_BITS = True
+        assert st0 == (0, 0)
+        assert st1[0] >= 4 and st1[1] >= 1, st1          # bit path taken by the stride-1 consumers, refused by the stride-2 one
+        for a, b in zip(ref, got):
+            # identical masks -> identical data gradients; the weight gradients behind them differ only by atomics order
+            assert float((a - b).abs().max()) <= 1e-3 * float(a.abs().max()) + 1e-6
+        assert torch.equal(ref[0], got[0]) or float((ref[0] - got[0]).abs().max()) <= 2e-2 * float(ref[0].abs().max())
+    finally:
+        set_compute_dtype(torch.float32)
