@@ -18,3 +18,5 @@ size_t conv_s1_ws_bytes(const IgemmParams& p, int dtype);
 bool conv_g8_launch(const IgemmParams& p, int dtype, hipStream_t stream);
 // 64x64-tile LDS-DMA conv for small problems (conv_g4.hip); false when the shape is not eligible
 bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream);
+// 3x3 stride-1 conv with an LDS-resident halo footprint (conv_h3.hip); false when the shape is not eligible
+bool conv_h3_launch(const IgemmParams& p, int dtype, hipStream_t stream);

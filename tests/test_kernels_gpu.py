@@ -64,7 +64,14 @@ CONV_CASES = [
     (128, 128, 3, 1, 1, 1, 160, 160, 2, False, True, 0),   # 3x3 + bias, two channel chunks; dgrad without mask
     (128, 256, 1, 1, 0, 1, 200, 201, 2, True, True, 0),    # g4 persistent form: 1258 tiles of 128x128 over 512 slots, ragged M,
                                                            # bias + statistics; dgrad (629 tiles) with the ReLU mask
+    # conv_h3.hip: 3x3 with the LDS-resident halo footprint (W % 16 == 0, Cin % 64 == 0, >= 30000 pixels)
+    (64, 64, 3, 1, 1, 1, 48, 48, 16, True, False, 0),      # BN=64 tiles, one chunk: the halo is staged once
+    (128, 128, 3, 1, 1, 1, 100, 96, 4, True, True, 8),     # ragged tile rows (100 % 8 != 0), channel-slice input, bias; dgrad + mask
+    (192, 128, 3, 1, 1, 1, 64, 64, 8, True, False, 0),     # three chunks: the halo double buffer wraps
+    (256, 256, 3, 1, 1, 1, 48, 48, 16, False, False, 0),   # two channel tiles, four chunks, no ReLU / mask
 ]
+H3_CASES = [c for c in CONV_CASES if c[2] == 3 and c[3] == 1 and c[5] == 1 and c[0] % 64 == 0 and c[7] % 16 == 0
+            and c[8] * c[6] * c[7] >= 30000]
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
@@ -134,16 +141,29 @@ def test_shapes_take_their_lds_dma_kernels():
     assert _g8_launch_count(256, 256, 1, "conv_g8", 192) == 2
     assert _g8_launch_count(128, 128, 3, "conv_g4", 24) == 2
     assert _g8_launch_count(64, 64, 3, "conv_g4", 48) == 2
-    assert _g8_launch_count(128, 128, 3, "conv_g4", 160) == 2
+    assert _g8_launch_count(128, 128, 3, "conv_g4", 160) == 2        # (conv_h3 reports under the same family)
     assert _g8_launch_count(32, 32, 3, "conv_g4", 96) == 2
     assert _g8_launch_count(128, 32, 1, "conv_g4", 96) == 2
+
+
+@pytest.mark.parametrize("cfg", ["1", "3", "4"])
+def test_h3_tile_configurations_in_subprocess(cfg):
+    """conv_h3's other tile shapes (NPP_H3_CFG, read once per process): 16-row / 12-row / 8-row tiles with 8 waves -- the
+    halo-footprint parity cases through each of them, and the launches really are conv_h3's."""
+    import os, subprocess, sys
+    env = dict(os.environ, NPP_H3_CFG=cfg)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "h3_cfg_worker.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "h3 cfg ok" in r.stdout
 
 
 def test_g8_taps_variant_in_subprocess():
     """The KxK (per-tap shift, zero border by out-of-range DMA) variant of conv_g8_kernel is opt-in (NPP_G8_MAXK=3, read once
     per process): run the large-map 3x3 parity cases on it in ONE child process."""
     import os, subprocess, sys
-    env = dict(os.environ, NPP_G8_MAXK="3", NPP_DISABLE_G4="1")
+    env = dict(os.environ, NPP_G8_MAXK="3", NPP_DISABLE_G4="1", NPP_DISABLE_H3="1")
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "g8_taps_worker.py")], env=env, capture_output=True, text=True,
                        timeout=600)
@@ -501,7 +521,7 @@ def test_relu_bit_masks_equal_the_tensor_mask():
 
         def run(bits):
             K.RELU_BITS = bits
-            K.MASK_STATS[0] = K.MASK_STATS[1] = 0
+            K.MASK_STATS[0] = K.MASK_STATS[1] = K.MASK_STATS[2] = 0
             K.fan_reset()
             x = K.cast(x0, torch.bfloat16).detach().requires_grad_(True)
             cb = K.ConcatBuffer(3)
@@ -517,7 +537,7 @@ def test_relu_bit_masks_equal_the_tensor_mask():
             K.fan_reset()
             torch.cuda.synchronize()
             grads = [x.grad.detach().float().clone()] + [p.grad.detach().clone() for m in pre for p in m.parameters()]
-            return grads, tuple(K.MASK_STATS)
+            return grads, tuple(K.MASK_STATS[:2])
         try:
             ref, st0 = run(False)
             got, st1 = run(True)

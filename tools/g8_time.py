@@ -19,6 +19,8 @@ if os.environ.get('NPP_TIME_SET') == 'c32':
     SHAPES = [(32, 32, 3, 96), (128, 32, 1, 96), (32, 32, 1, 96), (64, 64, 3, 48)]
 if os.environ.get('NPP_TIME_SET') == 'g4':
     SHAPES = [(128, 128, 3, 24), (256, 256, 3, 12), (64, 64, 3, 48), (256, 64, 1, 48), (64, 64, 1, 48), (128, 128, 1, 24), (512, 512, 1, 24), (1024, 256, 1, 12), (256, 256, 1, 48)]
+if os.environ.get('NPP_TIME_SET') == 'h3':
+    SHAPES = [(128, 128, 3, 96), (384, 128, 3, 96), (256, 256, 3, 48), (64, 64, 3, 48), (128, 128, 3, 48), (512, 512, 3, 48)]
 if os.environ.get('NPP_TIME_SET') == 'small':
     SHAPES = [(256, 256, 1, 48), (256, 128, 1, 48), (256, 64, 1, 48), (512, 512, 1, 24), (512, 256, 1, 24), (512, 128, 1, 24), (128, 128, 1, 24), (1024, 256, 1, 12)]
 if len(sys.argv) > 2 and sys.argv[2] == "one":
