@@ -114,6 +114,14 @@ int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw_packed, co
                    void* stream);
 /* packed f32 gradient -> the state-dict layout [cout][cin][kh][kw] */
 int npp_unpack_wgrad(const float* dw_packed, int cout, int cin, int kh, int kw, float* dw_oihw, void* stream);
+/* Deterministic split-K form of the same gradient for the wide-map 3x3 convs (conv_wgrad_h3.hip: the three horizontal taps of a
+ * kernel row from one staged input tile).  npp_conv_wgrad_splits: number of slabs the kernel wants for this shape, 0 = use
+ * npp_conv_wgrad.  npp_conv_wgrad_slabs: every block STORES its partial tile into its split's slab (slabs: nslabs * Cout * Kpad
+ * floats, caller-owned, need not be zeroed).  npp_unpack_wgrad_sum: packed slabs -> OIHW, summing the slabs in a fixed order
+ * (bit-reproducible; no float atomics anywhere). */
+int npp_conv_wgrad_splits(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g);
+int npp_conv_wgrad_slabs(const NppTensor* x, const NppTensor* dy, float* slabs, int nslabs, const NppConvGeom* g, void* stream);
+int npp_unpack_wgrad_sum(const float* slabs, int nslabs, int cout, int cin, int kh, int kw, float* dw_oihw, void* stream);
 /* out[i] = (float) sum over r < nrep of in[r][i] (i < n): collapses NPP_STAT_REPLICAS f64 accumulator slabs (conv bias gradient
  * from npp_channel_sum, the arch-weight gradient of npp_weighted_sum_bwd) to the f32 vector autograd takes.  Replaces the
  * `.sum(0).float()` pair of torch kernels at core of nn.Conv2d's bias gradient (models/operations.py:230, model_augment.py:332-398). */

@@ -64,6 +64,8 @@ _SIGS = {
     "npp_conv_fwd_ws": [_T, _P, _P, _T, _T, _P, _G, _P, C.c_int64, _P],
     "npp_conv_wgrad": [_T, _T, _P, _G, _P],
     "npp_unpack_wgrad": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
+    "npp_conv_wgrad_slabs": [_T, _T, _P, C.c_int, _G, _P],
+    "npp_unpack_wgrad_sum": [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
     "npp_sum_replicas": [_P, C.c_int, C.c_int, _P, _P],
     "npp_dwconv_fwd": [_T, _P, _T, _G, _P],
     "npp_dwconv_bwd_data": [_T, _P, _T, _T, _G, _P],
@@ -125,7 +127,8 @@ _SIGS = {
     "npp_parsing_confusion": [_T, _T, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_clear_hip_error", "npp_packed_weight_elems", "npp_pack_job_blocks", "npp_reduce_blocks",
-                                 "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems"])
+                                 "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems",
+                                 "npp_conv_wgrad_splits"])
 
 
 def lib():
@@ -151,6 +154,8 @@ def lib():
         L.npp_conv_fwd_ws_bytes.argtypes = [_T, _T, _G]
         L.npp_dwconv_bwd_weight_ws_zeroed.restype = C.c_int
         L.npp_dwconv_bwd_weight_ws_zeroed.argtypes = [_T, _G]
+        L.npp_conv_wgrad_splits.restype = C.c_int
+        L.npp_conv_wgrad_splits.argtypes = [_T, _T, _G]
         L.npp_reduce_blocks.restype = C.c_int
         L.npp_reduce_blocks.argtypes = [C.c_int64, C.c_int64, C.c_int]
         for name, sig in _SIGS.items():

@@ -541,6 +541,7 @@ def _conv_out(h, k, s, p, d):
 # dense conv (MFMA implicit GEMM)
 # --------------------------------------------------------------------------------------------------
 _conv_ws_cache = {}
+_wgrad_splits = {}      # shape key -> slabs wanted by the deterministic split-K weight-gradient kernel (0: not taken)
 
 
 def _conv_launch(x, wp, bf, mask, y, stats, g, s, what, soft=False):
@@ -637,12 +638,21 @@ class _Conv2d(Function):
                     dw = zeros_f32(weight.numel(), x.device, own=True).view(weight.shape)     # pre-zeroed pool slice: no fill launch
                 check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
             else:
-                dwp = zeros_f32(nel, x.device)
-                check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
                 dw = grad_out(weight)
                 if dw is None:
                     dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-                check(lib().npp_unpack_wgrad(dwp.data_ptr(), co, ci, kh, kw, dw.data_ptr(), s), "npp_unpack_wgrad")
+                wkey = (tuple(x.shape), L.nhwc_ld(x), co, L.nhwc_ld(dy), kh, kw, stride, pad, dil, x.dtype)
+                nsl = _wgrad_splits.get(wkey)
+                if nsl is None:
+                    nsl = _wgrad_splits[wkey] = int(lib().npp_conv_wgrad_splits(_byref(x), _byref(dy), C.byref(g)))
+                if nsl > 0:      # deterministic split-K: the kernel stores one slab per split, the unpack sums them
+                    slabs = torch.empty(nsl * nel, dtype=torch.float32, device=x.device)
+                    check(lib().npp_conv_wgrad_slabs(_byref(x), _byref(dy), slabs.data_ptr(), nsl, C.byref(g), s), "npp_conv_wgrad_slabs")
+                    check(lib().npp_unpack_wgrad_sum(slabs.data_ptr(), nsl, co, ci, kh, kw, dw.data_ptr(), s), "npp_unpack_wgrad_sum")
+                else:
+                    dwp = zeros_f32(nel, x.device)
+                    check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
+                    check(lib().npp_unpack_wgrad(dwp.data_ptr(), co, ci, kh, kw, dw.data_ptr(), s), "npp_unpack_wgrad")
             if SHAPE_LOG is not None:
                 SHAPE_LOG.append(("wgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
             if dw.dtype != weight.dtype:

@@ -222,8 +222,8 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 }  // namespace
 
-extern "C" int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw_packed, const NppConvGeom* g,
-                              void* stream) {
+// argument checks + the parameter block every weight-gradient kernel takes
+static int wgrad_setup(const NppTensor* x, const NppTensor* dy, float* dw_packed, const NppConvGeom* g, WgradParams& p) {
   NPP_REQUIRE(x && dy && dw_packed && g && x->ptr && dy->ptr, NPP_E_NULL, "npp_conv_wgrad: null pointer");
   NPP_REQUIRE(x->dtype == dy->dtype && (x->dtype == NPP_F32 || x->dtype == NPP_BF16), NPP_E_DTYPE,
               "npp_conv_wgrad: x/dy dtypes must match");
@@ -237,7 +237,6 @@ extern "C" int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw
   NPP_REQUIRE(x->n == dy->n && lh <= x->h - 1 + (g->ph > 0 ? g->ph : 0) && lw <= x->w - 1 + (g->pw > 0 ? g->pw : 0),
               NPP_E_SHAPE, "npp_conv_wgrad: dy %ldx%ld does not fit input %ldx%ld with this geometry", (long)dy->h,
               (long)dy->w, (long)x->h, (long)x->w);
-  WgradParams p;
   p.x = x->ptr; p.dy = dy->ptr; p.dwp = dw_packed;
   p.N = (int)x->n; p.H = (int)x->h; p.W = (int)x->w; p.Cin = (int)x->c; p.ldx = x->ld;
   p.OH = (int)dy->h; p.OW = (int)dy->w; p.Cout = (int)dy->c; p.ldy = dy->ld;
@@ -248,6 +247,56 @@ extern "C" int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw
   NPP_REQUIRE(P > 0 && P < (1L << 30), NPP_E_SHAPE, "npp_conv_wgrad: too many pixels");
   p.P = (int)P;
   p.vec_dy = (dy->ld % vec == 0) && (((uintptr_t)dy->ptr & 15) == 0);
+  p.chunks_per_split = 0; p.nchunks = 0; p.rowtiles = 0; p.ntiles = 0; p.nblocks = 0;
+  return NPP_OK;
+}
+
+// ---- deterministic split-K path (conv_wgrad_h3.hip): slabs stored by the kernel, summed by the unpack ---------------------
+int conv_wgrad_h3_splits(const WgradParams& p, int dtype);
+bool conv_wgrad_h3_launch(const WgradParams& p, int dtype, int nslabs, hipStream_t stream);
+void unpack_wgrad_sum_launch(const float* slabs, int nslabs, long slab, float* dw, int cout, int cin, int taps, int cp, int kpad,
+                             hipStream_t stream);
+
+extern "C" int npp_conv_wgrad_splits(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g) {
+  if (!x || !dy || !g || !x->ptr || !dy->ptr) return 0;
+  WgradParams p;
+  float dummy;
+  if (wgrad_setup(x, dy, &dummy, g, p) != NPP_OK) return 0;
+  return conv_wgrad_h3_splits(p, x->dtype);
+}
+
+extern "C" int npp_conv_wgrad_slabs(const NppTensor* x, const NppTensor* dy, float* slabs, int nslabs, const NppConvGeom* g,
+                                    void* stream) {
+  WgradParams p;
+  const int rc = wgrad_setup(x, dy, slabs, g, p);
+  if (rc != NPP_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const double flops = 2.0 * (double)p.P * p.Cout * (double)p.taps * p.Cin;
+  const double bytes = ((double)x->n * x->h * x->w * x->c + (double)p.P * dy->c) * esize(x->dtype);
+  ProfScope prof(NPP_FAM_CONV_WGRAD, x->dtype, s, flops, bytes);
+  if (!conv_wgrad_h3_launch(p, x->dtype, nslabs, s)) {
+    prof.cancel();
+    npp_set_error("npp_conv_wgrad_slabs: shape not taken by the slab kernel (ask npp_conv_wgrad_splits first)");
+    return NPP_E_UNSUPPORTED;
+  }
+  return npp_check_launch("conv_wgrad_h3");
+}
+
+extern "C" int npp_unpack_wgrad_sum(const float* slabs, int nslabs, int cout, int cin, int kh, int kw, float* dw_oihw, void* stream) {
+  NPP_REQUIRE(slabs && dw_oihw && nslabs >= 1, NPP_E_NULL, "npp_unpack_wgrad_sum: null pointer");
+  const int cp = round_up(cin, 8), taps = kh * kw, kpad = round_up(taps * cp, 64);
+  unpack_wgrad_sum_launch(slabs, nslabs, (long)cout * kpad, dw_oihw, cout, cin, taps, cp, kpad, (hipStream_t)stream);
+  return npp_check_launch("unpack_wgrad_sum");
+}
+
+extern "C" int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw_packed, const NppConvGeom* g,
+                              void* stream) {
+  WgradParams p;
+  {
+    const int rc = wgrad_setup(x, dy, dw_packed, g, p);
+    if (rc != NPP_OK) return rc;
+  }
+  const long P = p.P;
   const int kp = x->dtype == NPP_BF16 ? 64 : 32;
   p.nchunks = (p.P + kp - 1) / kp;
   const int rows_pad = round_up(p.Cout, 32);

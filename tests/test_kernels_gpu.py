@@ -69,6 +69,7 @@ CONV_CASES = [
     (128, 128, 3, 1, 1, 1, 100, 96, 4, True, True, 8),     # ragged tile rows (100 % 8 != 0), channel-slice input, bias; dgrad + mask
     (192, 128, 3, 1, 1, 1, 64, 64, 8, True, False, 0),     # three chunks: the halo double buffer wraps
     (256, 256, 3, 1, 1, 1, 48, 48, 16, False, False, 0),   # two channel tiles, four chunks, no ReLU / mask
+    (384, 128, 3, 1, 1, 1, 64, 64, 8, True, False, 0),     # conv_wgrad_h3 (W % 32 == 0): three input-channel tiles, two output tiles
 ]
 H3_CASES = [c for c in CONV_CASES if c[2] == 3 and c[3] == 1 and c[5] == 1 and c[0] % 64 == 0 and c[7] % 16 == 0
             and c[8] * c[6] * c[7] >= 30000]
@@ -157,6 +158,18 @@ def test_h3_tile_configurations_in_subprocess(cfg):
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "h3 cfg ok" in r.stdout
+
+
+def test_deterministic_slab_weight_gradient_in_subprocess():
+    """NPP_WGRAD_SLABS=1 (read once per process): the wide-map 3x3 weight gradients through conv_wgrad_h3's split-K slabs +
+    npp_unpack_wgrad_sum -- parity cases, and two runs give bit-identical gradients (no float atomics on that path)."""
+    import os, subprocess, sys
+    env = dict(os.environ, NPP_WGRAD_SLABS="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "wgrad_slabs_worker.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "wgrad slabs ok" in r.stdout
 
 
 def test_g8_taps_variant_in_subprocess():
