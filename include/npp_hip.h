@@ -119,6 +119,14 @@ int npp_unpack_wgrad(const float* dw_packed, int cout, int cin, int kh, int kw, 
  * npp_conv_wgrad.  npp_conv_wgrad_slabs: every block STORES its partial tile into its split's slab (slabs: nslabs * Cout * Kpad
  * floats, caller-owned, need not be zeroed).  npp_unpack_wgrad_sum: packed slabs -> OIHW, summing the slabs in a fixed order
  * (bit-reproducible; no float atomics anywhere). */
+/* All packed KxK weight gradients of a step -> OIHW in ONE launch: job k covers blocks [first_block, first_block + ceil(elems / 1024))
+ * of the grid, block_job[b] = job of block b (both tables on the device); nslabs > 1 sums split-K slabs `slab` floats apart. */
+typedef struct NppUnpackJob {
+  const void* src; void* dst;
+  int32_t cout, cin, taps, cp, kpad, nslabs;
+  int64_t slab, first_block;
+} NppUnpackJob;
+int npp_unpack_wgrad_batched(const NppUnpackJob* jobs_dev, const int32_t* block_job_dev, int64_t total_blocks, void* stream);
 int npp_conv_wgrad_splits(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g);
 int npp_conv_wgrad_slabs(const NppTensor* x, const NppTensor* dy, float* slabs, int nslabs, const NppConvGeom* g, void* stream);
 int npp_unpack_wgrad_sum(const float* slabs, int nslabs, int cout, int cin, int kh, int kw, float* dw_oihw, void* stream);

@@ -65,6 +65,7 @@ _SIGS = {
     "npp_conv_wgrad": [_T, _T, _P, _G, _P],
     "npp_unpack_wgrad": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
     "npp_conv_wgrad_slabs": [_T, _T, _P, C.c_int, _G, _P],
+    "npp_unpack_wgrad_batched": [_P, _P, C.c_int64, _P],
     "npp_unpack_wgrad_sum": [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
     "npp_sum_replicas": [_P, C.c_int, C.c_int, _P, _P],
     "npp_dwconv_fwd": [_T, _P, _T, _G, _P],

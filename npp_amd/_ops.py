@@ -541,6 +541,98 @@ def _conv_out(h, k, s, p, d):
 # dense conv (MFMA implicit GEMM)
 # --------------------------------------------------------------------------------------------------
 _conv_ws_cache = {}
+
+# Deferred, batched unpack of the KxK weight gradients (packed [co][tap][ci] accumulation layout -> OIHW): a weight gradient has
+# no reader before the optimizer, so a step that controls its own sequence (train_step.TrainStep without a reducer) lets the 224
+# unpacks of a step wait and runs them as ONE launch (npp_unpack_wgrad_batched) between backward and optimizer.step().
+DEFER_UNPACK = False
+_pending_unpacks: list = []      # (src tensor, dst tensor, co, ci, taps, cp, kpad, nslabs, slab, stream)
+_UNPACK_JOB = None
+
+
+def _unpack_or_defer(src, dst, co, ci, kh, kw, nslabs, s):
+    taps = kh * kw
+    cp = (ci + 7) // 8 * 8
+    kpad = (taps * cp + 63) // 64 * 64
+    if DEFER_UNPACK:
+        # keep the destination's MEMORY alive through an alias with its own TensorImpl: a second reference to the tensor object
+        # itself would make autograd's AccumulateGrad clone the (still unwritten) gradient instead of adopting it
+        keep = torch.empty(0, dtype=dst.dtype, device=dst.device).set_(dst.untyped_storage(), dst.storage_offset(), dst.shape,
+                                                                       dst.stride())
+        _pending_unpacks.append((src, keep, co, ci, taps, cp, kpad, max(nslabs, 1), co * kpad, torch.cuda.current_stream()))
+        return
+    if nslabs > 0:
+        check(lib().npp_unpack_wgrad_sum(src.data_ptr(), nslabs, co, ci, kh, kw, dst.data_ptr(), s), "npp_unpack_wgrad_sum")
+    else:
+        check(lib().npp_unpack_wgrad(src.data_ptr(), co, ci, kh, kw, dst.data_ptr(), s), "npp_unpack_wgrad")
+
+
+_unpack_bufs = {"pin": None, "dev": None, "ev": None, "keep": []}
+
+
+def flush_unpacks():
+    """Run every deferred unpack in one launch on the current stream (which first waits for the streams they were queued on)."""
+    global _UNPACK_JOB
+    if not _pending_unpacks:
+        return
+    import numpy as np
+    if _UNPACK_JOB is None:
+        _UNPACK_JOB = np.dtype([("src", "<u8"), ("dst", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("taps", "<i4"), ("cp", "<i4"),
+                                ("kpad", "<i4"), ("nslabs", "<i4"), ("slab", "<i8"), ("first_block", "<i8")])
+        assert _UNPACK_JOB.itemsize == 56
+    items = list(_pending_unpacks)
+    _pending_unpacks.clear()
+    cur = torch.cuda.current_stream()
+    seen = {cur.cuda_stream}
+    for it in items:
+        st = it[9]
+        if st.cuda_stream not in seen:
+            seen.add(st.cuda_stream)
+            cur.wait_stream(st)
+    n = len(items)
+    jobs = np.zeros(n, dtype=_UNPACK_JOB)
+    nblk = np.empty(n, dtype=np.int64)
+    for i, (src, dst, co, ci, taps, cp, kpad, nsl, slab, _st) in enumerate(items):
+        jobs[i] = (src.data_ptr(), dst.data_ptr(), co, ci, taps, cp, kpad, nsl, slab, 0)
+        nblk[i] = (co * ci * taps + 1023) // 1024
+    first = np.cumsum(nblk) - nblk
+    jobs["first_block"] = first
+    total = int(nblk.sum())
+    bj = np.repeat(np.arange(n, dtype=np.int32), nblk)
+    raw = np.concatenate([np.frombuffer(jobs.tobytes(), dtype=np.uint8), np.frombuffer(bj.tobytes(), dtype=np.uint8)])
+    nb = raw.size
+    capturing = torch.cuda.is_current_stream_capturing()
+    B = _unpack_bufs
+    if capturing:
+        # pinned memory cannot be allocated inside a capture: take the image the eager warm-up steps used (same job count) and
+        # retire it -- a replayed graph re-reads this pinned image, so it is never rewritten; later eager steps get a new one
+        if B["pin"] is None or B["pin"].numel() < nb:
+            for (src, dst, co, ci, taps, cp, kpad, nsl, slab, _st) in items:      # no warm-up happened: one launch each
+                check(lib().npp_unpack_wgrad_sum(src.data_ptr(), nsl, co, ci, 1, taps, dst.data_ptr(), stream_ptr()),
+                      "npp_unpack_wgrad_sum")
+            return
+        pin, dev = B["pin"], B["dev"]
+        B["keep"].append((pin, dev))
+        B["pin"] = B["dev"] = B["ev"] = None
+    elif B["pin"] is None or B["pin"].numel() < nb:
+        pin = torch.empty(max(nb, 1 << 16), dtype=torch.uint8).pin_memory()
+        dev = torch.empty(pin.numel(), dtype=torch.uint8, device=items[0][1].device)
+        B["pin"], B["dev"], B["ev"] = pin, dev, None
+    else:
+        pin, dev = B["pin"], B["dev"]
+        if B["ev"] is not None:
+            B["ev"].synchronize()             # the previous step's upload has read the pinned image
+    pin.numpy()[:nb] = raw
+    dev[:nb].copy_(pin[:nb], non_blocking=True)
+    if not capturing:
+        B["ev"] = torch.cuda.Event()
+        B["ev"].record()
+    joff = n * _UNPACK_JOB.itemsize
+    check(lib().npp_unpack_wgrad_batched(dev.data_ptr(), dev.data_ptr() + joff, total, stream_ptr()), "npp_unpack_wgrad_batched")
+    for it in items:                          # sources / destinations were allocated on the queuing streams
+        if it[9].cuda_stream != cur.cuda_stream:
+            it[0].record_stream(cur)
+            it[1].record_stream(cur)
 _wgrad_splits = {}      # shape key -> slabs wanted by the deterministic split-K weight-gradient kernel (0: not taken)
 
 
@@ -648,11 +740,11 @@ class _Conv2d(Function):
                 if nsl > 0:      # deterministic split-K: the kernel stores one slab per split, the unpack sums them
                     slabs = torch.empty(nsl * nel, dtype=torch.float32, device=x.device)
                     check(lib().npp_conv_wgrad_slabs(_byref(x), _byref(dy), slabs.data_ptr(), nsl, C.byref(g), s), "npp_conv_wgrad_slabs")
-                    check(lib().npp_unpack_wgrad_sum(slabs.data_ptr(), nsl, co, ci, kh, kw, dw.data_ptr(), s), "npp_unpack_wgrad_sum")
+                    _unpack_or_defer(slabs, dw, co, ci, kh, kw, nsl, s)
                 else:
                     dwp = zeros_f32(nel, x.device)
                     check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
-                    check(lib().npp_unpack_wgrad(dwp.data_ptr(), co, ci, kh, kw, dw.data_ptr(), s), "npp_unpack_wgrad")
+                    _unpack_or_defer(dwp, dw, co, ci, kh, kw, 0, s)
             if SHAPE_LOG is not None:
                 SHAPE_LOG.append(("wgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
             if dw.dtype != weight.dtype:

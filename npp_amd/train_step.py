@@ -69,7 +69,14 @@ class TrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         if self.reducer is not None:
             self.reducer.begin_step()      # the backward kernels write the gradients straight into the reducer's buckets
-        loss.backward()
+        # no gradient exists yet (set_to_none) and nothing reads one before the optimizer: the KxK weight-gradient unpacks of
+        # this backward are collected and run as one launch (a reducer's bucket hooks read gradients during backward: not then)
+        K.DEFER_UNPACK = self.reducer is None
+        try:
+            loss.backward()
+        finally:
+            K.DEFER_UNPACK = False
+        K.flush_unpacks()
         if self.reducer is not None:
             self.reducer.finish()
         self.optimizer.step()

@@ -20,8 +20,8 @@ for case in T.CONV_CASES:
         n += 1
 assert n >= 3, n
 dev = torch.device("cuda:0")
-x = K.cast(torch.randn(4, 128, 64, 64, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16)
-gy = K.cast(torch.randn(4, 128, 64, 64, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16)
+x = K.cast(torch.randn(8, 128, 64, 64, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16)
+gy = K.cast(torch.randn(8, 128, 64, 64, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16)
 geo = K.geom(3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
 assert lib().npp_conv_wgrad_splits(K._byref(x), K._byref(gy), C.byref(geo)) > 0, "the slab kernel did not take the shape"
 w = (torch.randn(128, 128, 3, 3, device=dev) * 0.03).requires_grad_(True)
