@@ -192,24 +192,36 @@ GRAPH_TOPOLOGY = False  # set by train_step.TrainStep while its steps are (to be
 _hub_stream = None     # the stream Network.forward was called on while it runs its branches on two streams
 
 
-def hub_all_reduce(t, group):
+def hub_all_reduce(t, group, producers=None):
     """SyncBatchNorm exchange.  Every collective of the step is issued on ONE stream (the caller's / the hipGraph
     capture's origin stream): a branch running on the side stream hands over with an event each way.  One stream per
     communicator is the topology RCCL-in-hipGraph users run; and the only cross-stream edges this adds to a capture
-    involve its origin stream (see helper_stream for what ROCm 7.0 does otherwise)."""
+    involve its origin stream (see helper_stream for what ROCm 7.0 does otherwise).
+    producers: further streams whose kernels wrote into `t` (a merged exchange of both branches): the hub waits for them too.
+    Returns the event recorded on the hub after the collective (None when everything ran on the current stream)."""
     hub = _hub_stream
     cur = torch.cuda.current_stream() if t.is_cuda else None
-    if hub is None or cur is None or cur.cuda_stream == hub.cuda_stream:
+    if hub is None or cur is None:
         dist.all_reduce(t, group=group)
-        return
-    ev = torch.cuda.Event()
-    ev.record(cur)
-    hub.wait_event(ev)
+        return None
+    same = cur.cuda_stream == hub.cuda_stream
+    waited = {hub.cuda_stream}
+    for st in ([] if same else [cur]) + list(producers or ()):
+        if st is not None and st.cuda_stream not in waited:
+            waited.add(st.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            hub.wait_event(ev)
+    if same and not producers:
+        dist.all_reduce(t, group=group)
+        return None
     with torch.cuda.stream(hub):
         dist.all_reduce(t, group=group)
         back = torch.cuda.Event()
         back.record(hub)
-    cur.wait_event(back)
+    if not same:
+        cur.wait_event(back)
+    return back
 
 
 _helper_streams = {}
@@ -291,6 +303,7 @@ def forget_streams():
         c.clear()
     for ps in (_zpool64, _zpool32, _sync_pool):
         ps.pools.clear()
+    _shared_sync_pool.drop()
 
 
 def reset_pools():
@@ -308,14 +321,23 @@ def zeros_f64(n, device):
 class _SyncStatsPool(_ZeroPool):
     """Statistics of SyncBatchNorm layers live back to back in one chunk, so that every vector produced since the
     last exchange travels in ONE all-reduce of the range [synced_off, off) -- no gather / concat / slice kernels
-    around the collective (augment_lip_sync.py:191 turns all 490 BNs into SyncBatchNorm)."""
+    around the collective (augment_lip_sync.py:191 turns all 490 BNs into SyncBatchNorm).
 
-    def __init__(self, chunk_elems):
+    `shared`: ONE pool for both task-branch streams (lockstep issue under the hub topology, see SYNC_MERGE): the chunk's zero-fill
+    is fenced with an event every other stream waits for before its first kernel writes into the chunk, a flush makes the hub
+    wait for EVERY stream that produced a waiting vector, and a side that finds itself already exchanged by the other branch's
+    flush waits for that flush's completion event."""
+
+    def __init__(self, chunk_elems, shared=False):
         super().__init__(torch.float64, chunk_elems)
         self.synced_off = 0
         self.waiting = []      # BnSides whose statistics sit in the un-exchanged range
         self.group = None
         self.ws = 1
+        self.shared = shared
+        self.fill_ev = None    # zero-fill of the current chunk (shared pools)
+        self.fill_seen = set() # raw handles of the streams ordered behind it
+        self.flushes = 0
 
     def get(self, n, device):
         n_al = (n + 63) // 64 * 64
@@ -324,6 +346,18 @@ class _SyncStatsPool(_ZeroPool):
         if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
             self.buf = torch.zeros(max(self.chunk, n_al), dtype=self.dtype, device=device)
             self.off = self.synced_off = 0
+            if self.shared and device.type == "cuda":
+                cur = torch.cuda.current_stream()
+                self.fill_ev = torch.cuda.Event()
+                self.fill_ev.record(cur)
+                self.fill_seen = {cur.cuda_stream}
+                for st in _known_streams():
+                    self.buf.record_stream(st)
+        if self.shared and self.fill_ev is not None:
+            cur = torch.cuda.current_stream()
+            if cur.cuda_stream not in self.fill_seen:
+                cur.wait_event(self.fill_ev)
+                self.fill_seen.add(cur.cuda_stream)
         return super().get(n, device)
 
     def holds_unsynced(self, t):
@@ -334,11 +368,19 @@ class _SyncStatsPool(_ZeroPool):
 
     def enlist(self, side, grp, ws):
         self.waiting.append(side)
+        side.stream = torch.cuda.current_stream() if (self.shared and side.x.is_cuda) else None
         self.group, self.ws = grp, ws
 
     def flush(self):
         if self.waiting:
-            hub_all_reduce(self.buf[self.synced_off:self.off], self.group)
+            rng = self.buf[self.synced_off:self.off]
+            if self.shared:
+                back = hub_all_reduce(rng, self.group, producers=[sd.stream for sd in self.waiting if sd.stream is not None])
+                for sd in self.waiting:
+                    sd.sync_event = back
+            else:
+                hub_all_reduce(rng, self.group)
+            self.flushes += 1
             for sd in self.waiting:
                 sd.synced_ws = self.ws
             self.waiting = []
@@ -346,9 +388,35 @@ class _SyncStatsPool(_ZeroPool):
 
     def drop(self):
         self.buf, self.off, self.synced_off, self.waiting = None, 0, 0, []
+        self.fill_ev, self.fill_seen = None, set()
 
 
-_sync_pool = _PerStream(lambda: _SyncStatsPool(1 << 21))
+def _known_streams():
+    sts = []
+    if _hub_stream is not None:
+        sts.append(_hub_stream)
+    for c in _stream_caches:
+        sts.extend(v for v in c.values() if isinstance(v, torch.cuda.Stream))
+    return sts
+
+
+# SyncBatchNorm under the lockstep issue order (model_augment._lockstep): the two branches' statistics share one pool, so the
+# exchange a branch triggers also carries what the OTHER branch has produced since the last one -- one collective per lockstep
+# stage instead of one per branch and stage in the forward pass (~490 -> ~245 forward exchanges per step; the backward exchanges
+# stay per node: a node's backward needs its all-reduced sums before the host can even start the other branch's node).
+SYNC_MERGE = False
+_shared_sync_pool = _SyncStatsPool(1 << 21, shared=True)
+
+
+class _SyncPools(_PerStream):
+    def cur(self):
+        return _shared_sync_pool if SYNC_MERGE else super().cur()
+
+    def all(self):
+        return super().all() + [_shared_sync_pool]
+
+
+_sync_pool = _SyncPools(lambda: _SyncStatsPool(1 << 21))
 
 
 def stats_buffer(n, device, want_stats):
@@ -836,7 +904,7 @@ class BnSide:
     """One operand of the fused add.  kind 'bn': `x` is a raw (pre-BN) tensor with f64 stats (train) or a
     BatchNorm holder in eval mode; kind 'plain': `x` is used as is."""
 
-    __slots__ = ("x", "bn", "stats", "count", "synced_ws", "private")
+    __slots__ = ("x", "bn", "stats", "count", "synced_ws", "private", "stream", "sync_event")
 
     def __init__(self, x, bn=None, stats=None, private=None):
         self.x = x
@@ -847,6 +915,8 @@ class BnSide:
         self.stats = stats
         self.count = None
         self.synced_ws = 0
+        self.stream = None          # (shared sync pool) the stream whose kernels produced the statistics
+        self.sync_event = None      # (shared sync pool) completion of the exchange that carried them
         if stats is not None and bn is not None and _sync_pool.cur().holds_unsynced(stats):
             grp, ws = _sync_group(bn)
             if grp is not None:
@@ -882,6 +952,11 @@ def _presync_stats(sides, training: bool):
     fused-add node or fewer, zero glue kernels); anything else (FactorizedReduce's stitched halves, statistics computed
     on demand) is all-reduced on its own."""
     for sd in sides:
+        if sd is not None and sd.synced_ws and sd.sync_event is not None:
+            # exchanged by a merged collective (possibly triggered by the other branch): this stream must see it complete
+            if sd.x.is_cuda:
+                torch.cuda.current_stream().wait_event(sd.sync_event)
+            sd.sync_event = None
         if sd is None or sd.bn is None or sd.synced_ws or not (training or sd.bn.running_mean is None):
             continue
         grp, ws = _sync_group(sd.bn)

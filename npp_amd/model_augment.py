@@ -560,6 +560,9 @@ class Network(nn.Module):
         f1, f2 = [], []
         k1 = k2 = stage = 0
         lockstep = _lockstep(mode, sync_bn)
+        # lockstep + hub topology: the two branches' SyncBatchNorm statistics share one pool and travel in ONE collective per
+        # lockstep stage (K.SYNC_MERGE; NPP_SYNC_MERGE=0 keeps one exchange per branch)
+        K.SYNC_MERGE = bool(lockstep and sync_bn and mode == 3 and os.environ.get("NPP_SYNC_MERGE", "1") != "0")
         for i, (cell1, cell2) in enumerate(zip(self.cells1, self.cells2)):
             if lockstep:
                 r1, r2 = [None], [None]
@@ -663,6 +666,9 @@ class Network(nn.Module):
                 in1, in3, in4 = n1, tmp, n4
             heads(i)
         K._hub_offload = None
+        if K.SYNC_MERGE:
+            K._shared_sync_pool.flush()      # (nothing should be waiting: every BatchNorm has been applied)
+            K.SYNC_MERGE = False
         if two:      # the caller's stream owns every output from here on
             so.wait_stream(sb)
             if mode == 3:

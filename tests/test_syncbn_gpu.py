@@ -119,6 +119,7 @@ def _worker(rank, world, port, out, sync=True, reducer=False):
     for k in g.files:
         if k.startswith("train/buf/"):
             res["buf/" + k[len("train/buf/"):]] = sd[k[len("train/buf/"):]].detach().float().cpu().numpy()
+    res["fwd_exchanges"] = np.array(sum(pl.flushes for pl in K._sync_pool.all()))      # forward SyncBN collectives issued
     names = ["pose_map0", "pose_aux0", "pose_map1", "pose_aux1", "par_map0", "edge0", "par_map1", "edge1"]
     for nm, o in zip(names, outs):
         res["out/" + nm] = o.detach().float().cpu().numpy()
@@ -211,6 +212,24 @@ def test_grad_reducer_on_the_real_network_two_ranks(tmp_path):
         e_ref = rel_err(res[0]["grad/" + k], ref[k])
         assert e_plain < 4e-2 and e_ref < 5e-2, (k, e_plain, e_ref)      # (bounds: test_syncbn_ranks_equal_full_batch)
     assert int(res[0]["n_buckets"]) >= 4
+
+
+def test_merged_syncbn_exchange_halves_the_forward_collectives(tmp_path, monkeypatch):
+    """Lockstep + hub topology: the two branches' statistics share one pool, so one collective per lockstep stage carries both
+    (K.SYNC_MERGE).  Same results as one exchange per branch (NPP_SYNC_MERGE=0), far fewer forward collectives."""
+    from helpers import rel_err
+    monkeypatch.setenv("NPP_SYNCBN_STREAMS", "3")
+    merged = _run(2, tmp_path)
+    monkeypatch.setenv("NPP_SYNC_MERGE", "0")
+    os.makedirs(str(tmp_path / "plain"))
+    plain = _run(2, tmp_path / "plain")
+    n_m, n_p = int(merged[0]["fwd_exchanges"]), int(plain[0]["fwd_exchanges"])
+    print("forward SyncBN exchanges: merged", n_m, "per branch", n_p)
+    assert n_p >= 300 and n_m <= 0.8 * n_p, (n_m, n_p)          # seen: 247 vs 330 (a branch's own pool already merges its two edges)
+    for r in range(2):
+        for k in merged[r].files:
+            if k.startswith("out/") or k.startswith("buf/"):
+                assert rel_err(merged[r][k], plain[r][k]) < 1e-4, (r, k)
 
 
 def _ops_worker(rank, world, port, out):
