@@ -35,7 +35,7 @@ enum { NPP_F32 = 0, NPP_BF16 = 1,
 #define NPP_STAT_REPLICAS 16
 enum {
   NPP_OK = 0, NPP_E_SHAPE = -1, NPP_E_DTYPE = -2, NPP_E_ALIGN = -3, NPP_E_HIP = -4,
-  NPP_E_UNSUPPORTED = -5, NPP_E_NULL = -6
+  NPP_E_UNSUPPORTED = -5, NPP_E_NULL = -6, NPP_E_RCCL = -7
 };
 
 typedef struct NppTensor {
@@ -342,6 +342,26 @@ typedef struct NppAdamJob {
 int npp_adam_chunk_elems(void);
 int npp_adam_step(const NppAdamJob* jobs /*device*/, const int32_t* chunks /*device [nchunks][2]*/, int nchunks,
                   int64_t* step /*device*/, void* stream);
+
+/* ---- collectives ---------------------------------------------------------------------------
+ * RCCL over xGMI, one communicator per process (one process per GPU), bound to the calling thread's current device.  Every
+ * collective is enqueued on the caller's stream with no host synchronisation, so it can be captured into a hipGraph.  librccl
+ * is opened on first use; a single-GPU run never needs it.
+ * npp_comm_unique_id: rank 0 fills 128 bytes and hands them to the other ranks by any side channel (the host side uses the
+ *   torch.distributed store); npp_comm_init joins `world` ranks on that id (collective, blocking).
+ * npp_allreduce_bucket: what DistributedDataParallel's reducer does per gradient bucket (augment_lip_sync.py:206-208):
+ *   in-place all-reduce of `count` elements, dtype NPP_F32 | NPP_BF16, average != 0 -> mean over ranks.
+ * npp_syncbn_exchange: what nn.SyncBatchNorm's forward/backward all_reduce does (augment_lip_sync.py:191): in-place SUM of
+ *   `count` f64 partial sums -- the statistics vectors of every BatchNorm gathered since the last exchange, back to back. */
+/* debugging aid: number of NaN / Inf elements of `t` (synchronises `stream`); < 0 on error */
+int64_t npp_debug_nonfinite(const NppTensor* t, void* stream);
+
+int npp_comm_unique_id(void* id128);
+int npp_comm_init(const void* id128, int rank, int world);
+int npp_comm_world(void);
+int npp_comm_destroy(void);
+int npp_allreduce_bucket(void* buf, int64_t count, int dtype, int average, void* stream);
+int npp_syncbn_exchange(double* stats, int64_t count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import torch
 
@@ -15,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnpp_hip.so")
 
 NPP_F32, NPP_BF16, NPP_MASK8 = 0, 1, 2
-NPP_E_UNSUPPORTED = -5
+NPP_E_SHAPE, NPP_E_DTYPE, NPP_E_ALIGN, NPP_E_HIP, NPP_E_UNSUPPORTED, NPP_E_NULL, NPP_E_RCCL = -1, -2, -3, -4, -5, -6, -7
 STAT_REPLICAS = 16   # NPP_STAT_REPLICAS in include/npp_hip.h
 FAM = {"none": 0, "conv_igemm": 1, "conv_wgrad": 2, "dwconv": 3, "bn": 4, "eltwise": 5, "pool": 6,
        "bilinear": 7, "loss": 8, "conv_s1": 9, "conv_g8": 10, "conv_g4": 11}
@@ -125,11 +126,17 @@ _SIGS = {
     "npp_ce_pixel_grad_up": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P],
     "npp_edge_weights": [_P, C.c_int64, _P, _P],
     "npp_adam_step": [_P, _P, C.c_int, _P, _P],
+    "npp_comm_unique_id": [_P],
+    "npp_comm_init": [_P, C.c_int, C.c_int],
+    "npp_comm_world": [],
+    "npp_comm_destroy": [],
+    "npp_allreduce_bucket": [_P, C.c_int64, C.c_int, C.c_int, _P],
+    "npp_syncbn_exchange": [_P, C.c_int64, _P],
     "npp_parsing_confusion": [_T, _T, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_clear_hip_error", "npp_packed_weight_elems", "npp_pack_job_blocks", "npp_reduce_blocks",
                                  "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems",
-                                 "npp_conv_wgrad_splits"])
+                                 "npp_conv_wgrad_splits", "npp_debug_nonfinite"])
 
 
 def lib():
@@ -159,12 +166,68 @@ def lib():
         L.npp_conv_wgrad_splits.argtypes = [_T, _T, _G]
         L.npp_reduce_blocks.restype = C.c_int
         L.npp_reduce_blocks.argtypes = [C.c_int64, C.c_int64, C.c_int]
+        L.npp_debug_nonfinite.restype = C.c_int64
+        L.npp_debug_nonfinite.argtypes = [_T, _P]
         for name, sig in _SIGS.items():
             f = getattr(L, name)
             f.restype = C.c_int
             f.argtypes = sig
-        _lib = L
+        _lib = _NanChecked(L) if os.environ.get("NPP_NAN_CHECK") else L
     return _lib
+
+
+class _NanChecked:
+    """Debugging aid (NPP_NAN_CHECK=1): after every library call, count the NaN / Inf elements of each NppTensor argument
+    (inputs and outputs alike) and report the first calls that see any -- which kernel made a NaN, or was handed one."""
+
+    def __init__(self, L):
+        self._L, self._left, self._calls = L, int(os.environ.get("NPP_NAN_CHECK_REPORTS", "12")), 0
+
+    def _conv_detail(self, args, stream):
+        """A convolution whose output holds NaN: the row padding of its inputs and its packed weights, and the geometry."""
+        x, y, g = args[0]._obj, args[4]._obj, args[6]._obj
+        wp = args[1] if isinstance(args[1], int) else getattr(args[1], "value", None)
+
+        def count(ptr, c, ld, pixels, dtype):
+            t = NppTensor(ptr, 1, 1, pixels, c, ld, dtype, 0)
+            return self._L.npp_debug_nonfinite(C.byref(t), stream)
+        msg = [f"geom k{g.kh}x{g.kw} s{g.sh} p{g.ph} d{g.dh} up{g.uph} relu_in{g.relu_in}",
+               f"x {x.n}x{x.c}x{x.h}x{x.w} ld {x.ld}: whole rows (with padding) non-finite {count(x.ptr, x.ld, x.ld, x.n * x.h * x.w, x.dtype)}"]
+        m = getattr(args[3], "_obj", None)
+        if isinstance(m, NppTensor) and m.ptr and m.dtype in (NPP_F32, NPP_BF16):
+            msg.append(f"mask c {m.c} ld {m.ld}: whole rows non-finite {count(m.ptr, m.ld, m.ld, m.n * m.h * m.w, m.dtype)}")
+        if wp:
+            cp = (x.c + 7) // 8 * 8
+            kpad = (g.kh * g.kw * cp + 63) // 64 * 64
+            rows = (y.c + 31) // 32 * 32
+            msg.append(f"packed weights [{rows}][{kpad}]: non-finite {count(wp, kpad, kpad, rows, x.dtype)}; "
+                       f"first {y.c} rows {count(wp, kpad, kpad, y.c, x.dtype)}; K columns below {g.kh * g.kw * cp}: "
+                       f"{count(wp, g.kh * g.kw * cp, kpad, rows, x.dtype)}")
+        sys.stderr.write("[npp nan-check]    " + " | ".join(msg) + "\n")
+
+    def __getattr__(self, name):
+        f = getattr(self._L, name)
+        if name not in _SIGS or name.startswith("npp_comm"):
+            return f
+        sig = _SIGS[name]
+
+        def checked(*args):
+            rc = f(*args)
+            self._calls += 1
+            if self._left > 0:
+                stream = args[-1] if sig and sig[-1] is _P and not hasattr(args[-1], "_obj") else None
+                for k, a in enumerate(args):
+                    obj = getattr(a, "_obj", None)
+                    if isinstance(obj, NppTensor) and obj.ptr and obj.dtype in (NPP_F32, NPP_BF16):
+                        bad = self._L.npp_debug_nonfinite(a, stream)
+                        if bad:
+                            self._left -= 1
+                            sys.stderr.write(f"[npp nan-check] call #{self._calls} {name}: argument {k} "
+                                             f"({obj.n}x{obj.c}x{obj.h}x{obj.w} ld {obj.ld}) has {bad} non-finite elements\n")
+                            if name in ("npp_conv_fwd", "npp_conv_fwd_ws") and k == 4:
+                                self._conv_detail(args, stream)
+            return rc
+        return checked
 
 
 def check(rc: int, what: str = ""):

@@ -192,6 +192,15 @@ GRAPH_TOPOLOGY = False  # set by train_step.TrainStep while its steps are (to be
 _hub_stream = None     # the stream Network.forward was called on while it runs its branches on two streams
 
 
+def _sum_all_reduce(t, group):
+    """SUM all-reduce on the current stream: the library's RCCL communicator when it is up (npp_amd.comm), else torch's."""
+    from . import comm
+    if comm.active() and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and group is comm._state["group"]:
+        comm.syncbn_exchange(t)
+    else:
+        dist.all_reduce(t, group=group)
+
+
 def hub_all_reduce(t, group, producers=None):
     """SyncBatchNorm exchange.  Every collective of the step is issued on ONE stream (the caller's / the hipGraph
     capture's origin stream): a branch running on the side stream hands over with an event each way.  One stream per
@@ -202,7 +211,7 @@ def hub_all_reduce(t, group, producers=None):
     hub = _hub_stream
     cur = torch.cuda.current_stream() if t.is_cuda else None
     if hub is None or cur is None:
-        dist.all_reduce(t, group=group)
+        _sum_all_reduce(t, group)
         return None
     same = cur.cuda_stream == hub.cuda_stream
     waited = {hub.cuda_stream}
@@ -213,10 +222,10 @@ def hub_all_reduce(t, group, producers=None):
             ev.record(st)
             hub.wait_event(ev)
     if same and not producers:
-        dist.all_reduce(t, group=group)
+        _sum_all_reduce(t, group)
         return None
     with torch.cuda.stream(hub):
-        dist.all_reduce(t, group=group)
+        _sum_all_reduce(t, group)
         back = torch.cuda.Event()
         back.record(hub)
     if not same:
@@ -590,8 +599,14 @@ def _gemm_ready(x: torch.Tensor) -> torch.Tensor:
     if c % 8 == 0:
         return x
     ld = L.nhwc_ld(x)
-    if ld is not None and ld >= (c + 7) // 8 * 8 and ld % 8 == 0:
-        return x
+    cp = (c + 7) // 8 * 8
+    if ld is not None and ld >= cp and ld % 8 == 0:
+        # a channel slice of a wider buffer (one half of a concatenation's gradient): the group read of the LAST pixel must
+        # still end inside the storage -- [4:8] of an 8-wide buffer would read 16 bytes past its end (a fault when the buffer
+        # closes a mapped segment, NaN x 0 = NaN when the bytes happen to be a NaN pattern)
+        n, _, h, w = x.shape
+        if x.storage_offset() + (n * h * w - 1) * ld + cp <= x.untyped_storage().nbytes() // x.element_size():
+            return x
     y = new_nhwc(*x.shape, x.dtype, x.device)
     check(lib().npp_copy(_byref(x), _byref(y), stream_ptr()), "npp_copy")
     return y

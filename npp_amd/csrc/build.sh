@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libnpp_hip.so
-SRCS="api.hip conv_igemm.hip conv_s1.hip conv_g8.hip conv_g4.hip conv_h3.hip conv_wgrad.hip conv_wgrad_s1.hip conv_wgrad_g4.hip conv_wgrad_h3.hip dwconv.hip bn.hip pool.hip bilinear.hip misc.hip loss.hip optim.hip eval.hip targets.hip"
+SRCS="api.hip conv_igemm.hip conv_s1.hip conv_g8.hip conv_g4.hip conv_h3.hip conv_wgrad.hip conv_wgrad_s1.hip conv_wgrad_g4.hip conv_wgrad_h3.hip dwconv.hip bn.hip pool.hip bilinear.hip misc.hip loss.hip optim.hip eval.hip targets.hip comm.hip"
 OBJS=""
 mkdir -p build
 pids=()
@@ -17,5 +17,5 @@ for s in $SRCS; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS -ldl
 echo "built $OUT"

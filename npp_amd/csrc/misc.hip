@@ -496,3 +496,37 @@ extern "C" int npp_interleave2(const NppTensor* a, const NppTensor* b, NppTensor
 #undef IL
   return npp_check_launch("interleave2");
 }
+
+// ---- debugging aid (NPP_NAN_CHECK=1 in npp_amd/_lib.py): how many elements of a tensor are NaN / Inf.  Synchronises. ----
+namespace {
+template <typename T>
+__global__ void count_nonfinite_kernel(const T* __restrict__ p, long pixels, int c, long ld, unsigned long long* out) {
+  unsigned long long bad = 0;
+  const long total = pixels * c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float v;
+    if constexpr (sizeof(T) == 2) v = __uint_as_float((unsigned)p[(i / c) * ld + (i % c)] << 16);
+    else v = p[(i / c) * ld + (i % c)];
+    bad += !(fabsf(v) <= 3.4e38f);
+  }
+  if (bad) atomicAdd(out, bad);
+}
+}  // namespace
+
+extern "C" int64_t npp_debug_nonfinite(const NppTensor* t, void* stream) {
+  if (!t || !t->ptr || (t->dtype != NPP_F32 && t->dtype != NPP_BF16)) return -1;
+  static unsigned long long* counter = nullptr;
+  if (!counter && hipMalloc(&counter, sizeof(*counter)) != hipSuccess) return -2;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(counter, 0, sizeof(*counter), s) != hipSuccess) return -3;
+  const long pixels = t->n * t->h * t->w;
+  if (pixels * t->c <= 0) return 0;
+  if (t->dtype == NPP_F32)
+    hipLaunchKernelGGL(count_nonfinite_kernel<float>, dim3(256), dim3(256), 0, s, (const float*)t->ptr, pixels, (int)t->c, (long)t->ld, counter);
+  else
+    hipLaunchKernelGGL(count_nonfinite_kernel<bf16_t>, dim3(256), dim3(256), 0, s, (const bf16_t*)t->ptr, pixels, (int)t->c, (long)t->ld, counter);
+  unsigned long long host = 0;
+  if (hipMemcpyAsync(&host, counter, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess) return -4;
+  if (hipStreamSynchronize(s) != hipSuccess) return -5;
+  return (int64_t)host;
+}

@@ -32,6 +32,7 @@ import torch
 import torch.distributed as dist
 
 from . import _ops as K
+from . import comm as _comm
 
 
 def unused_parameter_names(model: torch.nn.Module) -> Set[str]:
@@ -117,7 +118,12 @@ class GradReducer:
         self._side = torch.cuda.Stream(device=dev) if self._cuda else None
         self._armed = False
         backend = dist.get_backend(process_group)
-        self._avg = backend == "nccl"        # RCCL averages in the collective; gloo has no AVG: sum, then one scale pass
+        # transport: the library's own RCCL communicator (npp_amd.comm, NPP_COMM=npp) or torch.distributed's
+        self._npp = False
+        if self._cuda and backend == "nccl" and (_comm.wanted() or _comm.active()):
+            _comm.enable(process_group)
+            self._npp = _comm._state["group"] is process_group
+        self._avg = backend == "nccl" or self._npp   # RCCL averages in the collective; gloo has no AVG: sum, then one scale pass
 
     # -- gradient slots: the kernels write a parameter's gradient straight into its place in the bucket ---------------------
     def begin_step(self):
@@ -190,7 +196,10 @@ class GradReducer:
             if self.world > 1 or self.always:
                 # the stream-synchronous form: the collective is ordered after, and joined back into, THIS stream (inside a
                 # capture that keeps RCCL's internal stream in a two-way relation with the capture's origin stream only)
-                dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group)
+                if self._npp:
+                    _comm.all_reduce_bucket(b.flat, average=True)
+                else:
+                    dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group)
         b.launched = True
 
     def finish(self):

@@ -71,7 +71,7 @@ class TrainStep:
             self.reducer.begin_step()      # the backward kernels write the gradients straight into the reducer's buckets
         # no gradient exists yet (set_to_none) and nothing reads one before the optimizer: the KxK weight-gradient unpacks of
         # this backward are collected and run as one launch (a reducer's bucket hooks read gradients during backward: not then)
-        K.DEFER_UNPACK = self.reducer is None
+        K.DEFER_UNPACK = self.reducer is None and os.environ.get("NPP_DEFER_UNPACK", "1") != "0"
         try:
             loss.backward()
         finally:

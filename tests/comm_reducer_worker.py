@@ -1,0 +1,62 @@
+"""Worker of test_comm_gpu.py::test_training_step_on_the_library_transport.  One rank, backend nccl (= RCCL), SyncBatchNorm
+network: the same captured training steps once with torch.distributed's collectives and once with the library's own
+(NPP_COMM=npp: npp_allreduce_bucket / npp_syncbn_exchange).  A world of one makes every collective an identity, so the two
+trajectories must be bit-identical; what this proves is the plumbing (streams, capture, SyncBN hub, bucket views)."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29631")
+
+import torch
+import torch.distributed as dist
+
+from test_train_step_gpu import _batch, _cfg
+
+
+def run(transport, dev):
+    from npp_amd import _ops as K, comm
+    from npp_amd.criterion import Criterion_par, Criterion_pose
+    from npp_amd.ddp import GradReducer, unused_parameter_names
+    from npp_amd.model_augment import Network, set_compute_dtype
+    from npp_amd.optim import FusedAdam
+    from npp_amd.train_step import TrainStep
+    os.environ["NPP_COMM"] = transport
+    if transport != "npp":
+        comm.disable()
+    K._SYNC_EVEN_ALONE = True
+    set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(Network(_cfg(8))).to(dev).train()
+    cp, cq = Criterion_pose(out_len=2).to(dev), Criterion_par(out_len=2).to(dev)
+    opt = FusedAdam(list(net.parameters()) + list(cp.parameters()) + list(cq.parameters()), lr=1e-3)
+    red = GradReducer(net, skip=unused_parameter_names(net), always_reduce=True, bucket_mb=0.5)
+    assert red._npp == (transport == "npp") and comm.active() == (transport == "npp")
+    step = TrainStep(net, cp, cq, opt, reducer=red, graph=True, warmup=1)
+    batch = _batch(2, 96, 5, dev)
+    losses = [float(step(*batch)) for _ in range(4)]
+    assert step.graph is not None, "the step was not captured"
+    torch.cuda.synchronize()
+    params = [p.detach().clone() for p in net.parameters()]
+    red.remove()
+    return losses, params
+
+
+def main():
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    l_npp, p_npp = run("npp", dev)
+    l_ref, p_ref = run("torch", dev)
+    assert l_npp == l_ref, (l_npp, l_ref)
+    assert all(torch.equal(a, b) for a, b in zip(p_npp, p_ref))
+    assert all(l == l for l in l_npp)
+    print("OK", l_npp)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
