@@ -1,0 +1,51 @@
+"""Uninitialised / out-of-bounds reads.  tools/poison_probe.py runs the tiny training step on an allocator that gives every
+tensor its own hipMalloc filled with 0xFF bytes (NaN as f32 / bf16): a kernel that consumes memory nobody wrote -- the row
+padding of a tensor a producer left unwritten, bytes past the end of a buffer -- turns the loss, a gradient or a parameter into
+NaN.  (Round 2: the data gradient of FactorizedReduce's second conv read 16 bytes past the end of the concatenation's gradient;
+NaN x 0 = NaN, and a fault when the buffer closed a mapped segment.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+pytestmark = pytest.mark.gpu
+
+
+def _probe(args, env_extra):
+    so = os.path.join(REPO, "tools", "libpoison_alloc.so")
+    if not os.path.isfile(so):
+        subprocess.check_call(["hipcc", "-shared", "-fPIC", "-o", so, os.path.join(REPO, "tools", "poison_alloc.cpp")])
+    env = dict(os.environ, PROBE_STEPS="4", **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "poison_probe.py")] + args, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "PROBE_DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    steps = [ln for ln in r.stdout.splitlines() if ln.startswith("step")]
+    assert len(steps) == 4
+    for ln in steps:
+        assert "non-finite grads 0 [] params 0 [] buffers 0 []" in ln and "nan" not in ln.split("non-finite")[0], ln
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("fanout", ["1", "0"])
+def test_training_step_reads_no_unwritten_memory(dtype, fanout):
+    _probe(["bf16"] if dtype == "bf16" else [], {"NPP_FANOUT": fanout})
+
+
+def test_channel_slice_at_the_end_of_a_buffer_is_repacked():
+    """conv inputs are read in groups of 8 channels: the upper half [4:8] of an 8-wide buffer would be read past its end."""
+    from npp_amd import _ops as K
+    buf = torch.randn(2, 6, 6, 8, device="cuda").permute(0, 3, 1, 2)        # logical NCHW over NHWC memory
+    lo, hi = buf[:, 0:4], buf[:, 4:8]
+    assert K._gemm_ready(lo) is lo                      # the group read of the last pixel ends exactly at the buffer's end
+    ready = K._gemm_ready(hi)
+    assert ready is not hi and torch.equal(ready, hi)
+    from npp_amd import _lib as L
+    assert L.nhwc_ld(ready) >= 8
+    whole = torch.randn(2, 6, 6, 16, device="cuda").permute(0, 3, 1, 2)
+    mid = whole[:, 4:8]                                 # a slice with room behind it stays in place
+    assert K._gemm_ready(mid) is mid

@@ -179,9 +179,12 @@ def test_syncbn_ranks_equal_full_batch(world, streams, tmp_path, monkeypatch):
     # which moves single gradients by a few 1e-3 (seen run to run on identical code); two ranks: each conv reduces over
     # half the pixels, and the rounding differences are amplified by the 50-deep BN stack (worst at the stem)
     # (tools/mode_noise.py: identical runs fall into one of two states 1.25e-2 apart on par_head.1.1.weight)
+    ref = _oracle_grads()
+    if not max(errs.values()) < (3e-2 if world == 1 else 4e-2):      # say which of the two runs left the oracle
+        print("sync  vs oracle:", {k: rel_err(res[0]["grad/" + k], ref[k]) for k in GRAD_KEYS})
+        print("local vs oracle:", {k: rel_err(loc["grad/" + k], ref[k]) for k in GRAD_KEYS})
     assert max(errs.values()) < (3e-2 if world == 1 else 4e-2), errs
     # ... and the CPU oracle (loose: BN over 8..2048 samples stacked 50 deep amplifies f32 rounding to ~1e-2 at the stem)
-    ref = _oracle_grads()
     for k in GRAD_KEYS:
         e = rel_err(res[0]["grad/" + k], ref[k])
         assert e < 5e-2, (k, e)
