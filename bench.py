@@ -57,11 +57,13 @@ def cpu_baseline(size, budget_s=25.0):
     ncpu = os.cpu_count() or 8
     best_t, best_dt = None, None
     one()
-    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+    sweep = {}
+    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):      # (ncpu = BASELINE.md section 4's setting)
         torch.set_num_threads(nt)
         t0 = time.time()
         one()
         dt = time.time() - t0
+        sweep[nt] = round(dt, 2)
         if best_dt is None or dt < best_dt:
             best_t, best_dt = nt, dt
     torch.set_num_threads(best_t)
@@ -83,8 +85,9 @@ def cpu_baseline(size, budget_s=25.0):
     times.sort()
     med = times[len(times) // 2]
     return {"value": round(1.0 / med, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"N=1 {size}x{size} fp32 train-mode fwd+losses+bwd, median of {len(times)} iterations after 1 warm-up "
-                      f"(torch-CPU oracle, {os.cpu_count()} logical CPUs)"}
+            "sample": f"N=1 {size}x{size} fp32 train-mode fwd+losses+bwd, median of {len(times)} iterations after "
+                      f"{1 + len(sweep)} warm-up iterations (torch-CPU oracle, {os.cpu_count()} logical CPUs; `cores` = the "
+                      f"fastest of the thread counts tried, seconds per iteration by threads: {sweep})"}
 
 
 def spawn_ranks(n):
@@ -296,14 +299,22 @@ def main():
         prof_steps = 2
         KERNELS = {"conv_s1": "conv_s1_kernel (stride-1 KxK conv fwd + dgrad, LDS-resident footprint, MFMA 32x32x16)",
                    "conv_g8": "conv_g8_kernel (1x1 conv fwd + dgrad: 8-phase LDS-DMA implicit GEMM, MFMA 16x16x32)",
-                   "conv_g4": "conv_g4_kernel (stride-1 conv fwd + dgrad, 1x1 / 3x3: 64x64 / 128x128 / 64x32 tiles, LDS-DMA ring of 2, 2-4 blocks per CU, MFMA 16x16x32)",
+                   "conv_g4": "conv_g4_kernel + conv_h3_kernel (stride-1 conv fwd + dgrad; g4: 1x1 / 3x3 on 64x64 / 128x128 / 64x32 tiles, LDS-DMA ring of 2; h3: 3x3 with an LDS-resident halo footprint on the >= 30k-pixel maps; MFMA 16x16x32)",
                    "conv_wgrad": "weight-gradient family (conv_wgrad_g4_kernel: pixel-major LDS-DMA + transposing reads, MFMA 16x16x32; the 32/64-channel KxK layers on conv_wgrad_kernel)"}
-        traffic_db = {}
-        try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
-            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as fh:
+        # HBM bytes per launch: rocprofv3 --pmc cannot run inside this process, so the counters come from the committed passes
+        # of this same command (tools/final_profiles.sh -> profiles/r02_pmc_traffic.json) -- and only while the kernel sources
+        # still hash to what those passes ran on; otherwise `traffic` is null and `traffic_note` says why
+        traffic_db, traffic_note = {}, None
+        traffic_file = os.path.join("profiles", "r02_pmc_traffic.json")
+        try:
+            with open(os.path.join(REPO, traffic_file)) as fh:
                 traffic_db = json.load(fh)
-        except Exception:      # noqa: BLE001
-            traffic_db = {}
+            if traffic_db.get("source_hash") != _lib.kernel_source_hash():
+                traffic_note = (f"{traffic_file} was collected on kernel sources {traffic_db.get('source_hash')}, this build is "
+                                f"{_lib.kernel_source_hash()}: stale, not reported (re-run tools/final_profiles.sh)")
+                traffic_db = {}
+        except Exception as e:      # noqa: BLE001
+            traffic_db, traffic_note = {}, f"{traffic_file}: {e}"
         for fam, label in KERNELS.items():
             L.npp_prof_begin(_lib.FAM[fam], dt_code)
             for _ in range(prof_steps):
@@ -314,14 +325,12 @@ def main():
             if nl.value > 0 and ms.value > 0:
                 ach = fl.value / (ms.value * 1e-3) / 1e12
                 peak = PEAK_TFLOPS[args.dtype]
-                rec = traffic_db.get({"conv_wgrad": "conv_wgrad_g4_kernel"}.get(fam, fam + "_kernel")) \
-                    or (traffic_db if traffic_db.get("kernel") == fam + "_kernel" else None)
-                if fam == "conv_wgrad":
-                    rec = None      # a mixed family: the PMC average of one of its kernels is not its per-launch traffic
-                traffic = round(rec["traffic_bytes_per_launch"]) if rec else None
+                rec = traffic_db.get(fam)      # the family's own average: every launch of every kernel the family times
+                traffic = round(rec["traffic_bytes_per_launch"]) if rec and rec.get("launches") else None
                 roofs.append({"bound": "mfma", "kernel": label, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                               "frac": round(ach / peak, 4), "traffic": traffic,
                               "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC)",
+                              "traffic_source": traffic_note or f"tools/final_profiles.sh -> {traffic_file} (sources {traffic_db.get('source_hash')})",
                               "launches_per_step": nl.value // prof_steps, "ms_per_step": round(ms.value / prof_steps, 3),
                               "avg_launch_us": round(ms.value * 1e3 / nl.value, 2),
                               "algorithmic_gflop_per_launch": round(fl.value / nl.value / 1e9, 4),

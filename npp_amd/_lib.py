@@ -139,6 +139,21 @@ EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_clear_hip_
                                  "npp_conv_wgrad_splits", "npp_debug_nonfinite"])
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the HIP sources and headers the library is built from (sorted by name): profiles/*_pmc_traffic.json records
+    it, and bench.py prints a measured `traffic` only when the kernels are still the ones the counters were collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = [os.path.join(here, "csrc", f) for f in sorted(os.listdir(os.path.join(here, "csrc"))) if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(os.path.dirname(here), "include", "npp_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def lib():
     """Load (once) and return the C library; raises if it has not been built."""
     global _lib

@@ -3,7 +3,7 @@
 #   1. rocprofv3 --kernel-trace --stats of the default bench command (hipGraph, two branch streams)
 #   2. the same for the eager single-stream run (per-kernel durations without overlap)
 #   3. two --pmc passes (FETCH_SIZE, WRITE_SIZE) of the eager single-stream run -> HBM bytes per conv_s1 / conv_g8 launch
-tag=${1:-r01}
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/final; mkdir -p $out
 run() {  # name, extra env assignment string, bench args...
@@ -13,7 +13,7 @@ run() {  # name, extra env assignment string, bench args...
   f=$(find /tmp/fp_$name -name "*kernel_trace.csv" | head -1)
   python3 tools/prof_summary.py "$f" > $out/${tag}_kernel_trace_${name}.txt 2>&1
   s=$(find /tmp/fp_$name -name "*kernel_stats.csv" | head -1)
-  [ -n "$s" ] && head -40 "$s" > $out/${tag}_kernel_stats_${name}.csv
+  [ -n "$s" ] && cp "$s" $out/${tag}_kernel_stats_${name}.csv      # every row
   tail -1 $out/${tag}_${name}.log | cut -c1-300
 }
 run bs16_bf16_graph --steps 10 --warmup 3 --no-cpu-baseline
@@ -27,5 +27,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 ff=$(find /tmp/fp_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 fw=$(find /tmp/fp_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_traffic.py "$ff" "$fw" conv_s1_kernel,conv_g8_kernel,conv_g4_kernel,conv_wgrad_g4_kernel $out/${tag}_pmc_traffic.json
+FAMS="conv_g4=conv_g4_kernel|conv_h3_kernel,conv_g8=conv_g8_kernel,conv_wgrad=conv_wgrad_g4_kernel|conv_wgrad_kernel|conv_wgrad_s1_kernel|conv_wgrad_h3_kernel,conv_h3_kernel,conv_g4_kernel,conv_wgrad_g4_kernel"
+python3 tools/pmc_traffic.py "$ff" "$fw" "$FAMS" $out/${tag}_pmc_traffic.json
 python3 tools/pmc_step_total.py "$ff" "$fw" 4 > $out/${tag}_pmc_step_total.txt
+#   4. MFMA utilisation per conv family (north_star: "rocprof HBM GB/s and MFMA utilisation")
+rm -rf /tmp/fp_pmc_mfma
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES --output-format csv -d /tmp/fp_pmc_mfma -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --graph 0 > /dev/null 2>&1
+fm=$(find /tmp/fp_pmc_mfma -name "*counter_collection.csv" | head -1)
+python3 tools/pmc_mfma_busy.py "$fm" "$FAMS,bn_bwd,add_n,affine_add,dw" > $out/${tag}_pmc_mfma_busy.txt
+cat $out/${tag}_pmc_mfma_busy.txt
+python3 bench.py > $out/${tag}_bench_line.json 2> /dev/null; tail -c 400 $out/${tag}_bench_line.json
