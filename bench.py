@@ -59,6 +59,9 @@ def cpu_baseline(size, budget_s=25.0):
     one()
     sweep = {}
     for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):      # (ncpu = BASELINE.md section 4's setting)
+        if best_dt is not None and nt > 64 and sweep[max(sweep)] > 1.5 * best_dt:
+            sweep[nt] = "not tried (already 1.5x slower than the best at %d threads)" % max(k for k in sweep if isinstance(k, int))
+            continue
         torch.set_num_threads(nt)
         t0 = time.time()
         one()
