@@ -292,6 +292,9 @@ __global__ __launch_bounds__(256) void affine_add_kernel(T* __restrict__ out, lo
   }
 }
 
+#ifndef RED_U
+#define RED_U 2
+#endif
 // HAS_RO compile-time and unconditional (index-clamped) coefficient loads: see affine_add_kernel
 template <typename T, int V, bool HAS_RO>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
@@ -317,31 +320,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   if (work) {
     const long step = (long)gridDim.x * m.rows;
     const long cofs = (long)colg * V;
-    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += 2 * step) {
-      const long p2 = p + step;
-      const bool two = p2 < npix;
-      const long q2 = two ? p2 : p;           // unconditional loads of a real pixel; its terms are dropped below
-      float d[V], v[V], d2[V], v2[V];
-      ldv<T, V>(dout + p * ldd + cofs, d);
-      ldv<T, V>(y + p * ldy + cofs, v);
-      ldv<T, V>(dout + q2 * ldd + cofs, d2);
-      ldv<T, V>(y + q2 * ldy + cofs, v2);
-      if (HAS_RO) {
-        float o[V], o2[V];
-        ldv<T, V>(ro + p * ldr + cofs, o);
-        ldv<T, V>(ro + q2 * ldr + cofs, o2);
+    // RED_U pixels per iteration (2 * RED_U 16-byte loads in flight per lane).  Measured, graph-replayed, C=128 @96^2 (37.7 MB per
+    // tensor): RED_U 2 / 4 / 8 = 17.0 / 18.2 / 21.4 us (4.4 / 4.2 / 3.5 TB/s) -- more loads in flight do not help, the small
+    // tensors sit at a ~6 us floor set by the block-level f64 reduction tail
+    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += RED_U * step) {
+      float d[RED_U][V], v[RED_U][V];
+      bool ok[RED_U];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          d[j] = o[j] > 0.f ? d[j] : 0.f;
-          d2[j] = o2[j] > 0.f ? d2[j] : 0.f;
+      for (int u = 0; u < RED_U; ++u) {
+        const long q = p + u * step;
+        ok[u] = q < npix;
+        const long qq = ok[u] ? q : p;        // unconditional loads of a real pixel; its terms are dropped below
+        ldv<T, V>(dout + qq * ldd + cofs, d[u]);
+        ldv<T, V>(y + qq * ldy + cofs, v[u]);
+        if (HAS_RO) {
+          float o[V];
+          ldv<T, V>(ro + qq * ldr + cofs, o);
+#pragma unroll
+          for (int j = 0; j < V; ++j) d[u][j] = o[j] > 0.f ? d[u][j] : 0.f;
         }
       }
-      // pairs are summed in f32 (two terms), the running sums stay f64
+      // the RED_U terms are summed in f32, the running sums stay f64
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        const float e2 = two ? d2[j] : 0.f;
-        const float a0 = d[j] + e2;
-        const float a1 = d[j] * ((v[j] - mean[j]) * invstd[j]) + e2 * ((v2[j] - mean[j]) * invstd[j]);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < RED_U; ++u) {
+          const float e = ok[u] ? d[u][j] : 0.f;
+          a0 += e;
+          a1 += e * ((v[u][j] - mean[j]) * invstd[j]);
+        }
         acc[0][j] += a0;
         acc[1][j] += a1;
       }
@@ -462,33 +470,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const T* __restrict
   if (work) {
     const long step = (long)gridDim.x * m.rows;
     const long cofs = (long)colg * V;
-    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += 2 * step) {
-      const long p2 = p + step;
-      const bool two = p2 < npix;
-      const long q2 = two ? p2 : p;
-      float d[V], va[V], vb[V], d2[V], va2[V], vb2[V];
-      ldv<T, V>(dout + p * ldd + cofs, d);
-      ldv<T, V>(ya + p * lda + cofs, va);
-      ldv<T, V>(yb + p * ldb + cofs, vb);
-      ldv<T, V>(dout + q2 * ldd + cofs, d2);
-      ldv<T, V>(ya + q2 * lda + cofs, va2);
-      ldv<T, V>(yb + q2 * ldb + cofs, vb2);
-      if (HAS_RO) {
-        float o[V], o2[V];
-        ldv<T, V>(ro + p * ldr + cofs, o);
-        ldv<T, V>(ro + q2 * ldr + cofs, o2);
+    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += RED_U * step) {
+      float d[RED_U][V], va[RED_U][V], vb[RED_U][V];
+      bool ok[RED_U];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          d[j] = o[j] > 0.f ? d[j] : 0.f;
-          d2[j] = o2[j] > 0.f ? d2[j] : 0.f;
+      for (int u = 0; u < RED_U; ++u) {
+        const long q = p + u * step;
+        ok[u] = q < npix;
+        const long qq = ok[u] ? q : p;
+        ldv<T, V>(dout + qq * ldd + cofs, d[u]);
+        ldv<T, V>(ya + qq * lda + cofs, va[u]);
+        ldv<T, V>(yb + qq * ldb + cofs, vb[u]);
+        if (HAS_RO) {
+          float o[V];
+          ldv<T, V>(ro + qq * ldr + cofs, o);
+#pragma unroll
+          for (int j = 0; j < V; ++j) d[u][j] = o[j] > 0.f ? d[u][j] : 0.f;
         }
       }
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        const float e2 = two ? d2[j] : 0.f;
-        acc[0][j] += d[j] + e2;
-        acc[1][j] += d[j] * ((va[j] - ma[j]) * ia[j]) + e2 * ((va2[j] - ma[j]) * ia[j]);
-        acc[2][j] += d[j] * ((vb[j] - mb[j]) * ib[j]) + e2 * ((vb2[j] - mb[j]) * ib[j]);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < RED_U; ++u) {
+          const float e = ok[u] ? d[u][j] : 0.f;
+          a0 += e;
+          a1 += e * ((va[u][j] - ma[j]) * ia[j]);
+          a2 += e * ((vb[u][j] - mb[j]) * ib[j]);
+        }
+        acc[0][j] += a0;
+        acc[1][j] += a1;
+        acc[2][j] += a2;
       }
     }
   }

@@ -53,11 +53,11 @@ NPP_DEV u32x4 relu_bf16x8_g4(u32x4 v) {
 // PERS: persistent over output tiles (grid = resident slots): the K-tile stream runs on across tiles, so the first K-tile of
 // the next tile is in flight during the epilogue of this one and no block start-up sits between two tiles -- for the
 // memory-bound 1x1 shapes (K = 128..512: 2..8 K-tiles per tile) whose tile time is a chain of latencies, not work.
-template <int BM, int BN, int WM_, bool RELU, bool TAPS, bool HALF, bool PERS>
+template <int BM, int BN, int WM_, bool RELU, bool TAPS, bool HALF, bool PERS, int RING_ = G4_RING>
 __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) {
   constexpr int WN_ = 4 / WM_;
   constexpr int TM = BM / WM_, TN = BN / WN_;    // per-wave tile
-  constexpr int R = G4_RING;           // ring depth
+  constexpr int R = RING_;             // ring depth (2; 4 where fewer blocks than CUs leave nobody to hide a block's DMA latency)
   constexpr int AB = BM * 128;         // bytes of the A part of a K-tile buffer: [BM rows][128 B]
   constexpr int KT = (BM + BN) * 128;  // bytes per K-tile buffer: A then B [BN rows][128 B]
   constexpr int RED = R * KT;          // statistics exchange [WM_][BN ch][2] floats
@@ -406,9 +406,29 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   } while (0)
 #define G4_PICK(BM_, BN_, WM__, HALF_)                                                                     \
   do { if (pers) G4_PICK2(BM_, BN_, WM__, HALF_, true); else G4_PICK2(BM_, BN_, WM__, HALF_, false); } while (0)
-  if (bm == 128) G4_PICK(128, 128, 2, false);
+  // few blocks per CU and a long K loop (256->256 3x3 @12^2: 144 blocks x 36 K-tiles, 128->128 3x3 @24^2: 288 x 18; in the network the
+  // weights are cold): measured in-model (tools/shape_prof.sh, us, ring 2 -> 4) 28.9 -> 18.5, 16.8 -> 15.0, 1024->256 1x1 @12^2 14.1 -> 9.7.  Every K-tile step of a
+  // lone block exposes a full L2/HBM round trip with a ring of 2 -- a ring of 4 keeps three tiles in flight
+  static const int deep_max = getenv("NPP_G4_DEEP_MAX_TILES") ? atoi(getenv("NPP_G4_DEEP_MAX_TILES")) : 1300;
+  const bool deep = !pers && !half && bm == 64 && bn == 64 && total <= deep_max && e.nk >= 6;
+  static const int deep_ring = getenv("NPP_G4_DEEP_RING") ? atoi(getenv("NPP_G4_DEEP_RING")) : 4;
+#define G4_LAUNCH_DEEP_R(RELU_, TAPS_, RG_)                                                                 \
+  do {                                                                                                     \
+    constexpr size_t lds = RG_ * (64 + 64) * 128 + 2 * 64 * 2 * 4;                                          \
+    if (!g4_raise_lds(reinterpret_cast<const void*>(conv_g4_kernel<64, 64, 2, RELU_, TAPS_, false, false, RG_>), lds)) return false; \
+    hipLaunchKernelGGL((conv_g4_kernel<64, 64, 2, RELU_, TAPS_, false, false, RG_>), dim3(grid), dim3(256), lds, stream, q, e); \
+  } while (0)
+#define G4_LAUNCH_DEEP(RELU_, TAPS_)                                                                        \
+  do { if (deep_ring == 8) G4_LAUNCH_DEEP_R(RELU_, TAPS_, 8); else if (deep_ring == 3) G4_LAUNCH_DEEP_R(RELU_, TAPS_, 3); else G4_LAUNCH_DEEP_R(RELU_, TAPS_, 4); } while (0)
+  if (deep) {
+    if (P == 0) { if (p.relu_in) G4_LAUNCH_DEEP(true, false); else G4_LAUNCH_DEEP(false, false); }
+    else        { if (p.relu_in) G4_LAUNCH_DEEP(true, true);  else G4_LAUNCH_DEEP(false, true); }
+  }
+  else if (bm == 128) G4_PICK(128, 128, 2, false);
   else if (bn == 32) { if (half) G4_PICK(64, 32, 4, true); else G4_PICK(64, 32, 4, false); }
   else { if (half) G4_PICK(64, 64, 2, true); else G4_PICK(64, 64, 2, false); }
+#undef G4_LAUNCH_DEEP
+#undef G4_LAUNCH_DEEP_R
 #undef G4_PICK2
 #undef G4_PICK
 #undef G4_LAUNCH
