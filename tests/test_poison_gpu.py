@@ -20,12 +20,12 @@ def _probe(args, env_extra):
     so = os.path.join(REPO, "tools", "libpoison_alloc.so")
     if not os.path.isfile(so):
         subprocess.check_call(["hipcc", "-shared", "-fPIC", "-o", so, os.path.join(REPO, "tools", "poison_alloc.cpp")])
-    env = dict(os.environ, PROBE_STEPS="4", **env_extra)
+    env = dict(os.environ, **{"PROBE_STEPS": "4", **env_extra})
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "poison_probe.py")] + args, env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "PROBE_DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
     steps = [ln for ln in r.stdout.splitlines() if ln.startswith("step")]
-    assert len(steps) == 4
+    assert len(steps) == int(env["PROBE_STEPS"])
     for ln in steps:
         assert "non-finite grads 0 [] params 0 [] buffers 0 []" in ln and "nan" not in ln.split("non-finite")[0], ln
 
@@ -34,6 +34,14 @@ def _probe(args, env_extra):
 @pytest.mark.parametrize("fanout", ["1", "0"])
 def test_training_step_reads_no_unwritten_memory(dtype, fanout):
     _probe(["bf16"] if dtype == "bf16" else [], {"NPP_FANOUT": fanout})
+
+
+@pytest.mark.parametrize("mode,dtype,steps", [("search", "f32", "3"), ("search", "bf16", "3"), ("syncbn", "f32", "3"),
+                                              ("syncbn", "bf16", "3"), ("full", "bf16", "2")])
+def test_other_paths_read_no_unwritten_memory(mode, dtype, steps):
+    """search: SearchStep (weights pass + alpha pass with the entropy term) on the supernet; syncbn: SyncBatchNorm + GradReducer on a
+    1-rank RCCL group; full: the C=64 network at 384 x 384 (the kernels the bench runs: conv_g8, conv_h3, conv_wgrad_g4 ...)."""
+    _probe(["bf16"] if dtype == "bf16" else [], {"PROBE_MODE": mode, "PROBE_STEPS": steps})
 
 
 def test_channel_slice_at_the_end_of_a_buffer_is_repacked():

@@ -15,11 +15,52 @@ import test_train_step_gpu as T      # noqa: E402
 from npp_amd.model_augment import set_compute_dtype      # noqa: E402
 
 dev = torch.device("cuda:0")
-net, opt, step = T._make(dev, graph=False)
-if len(sys.argv) > 1 and sys.argv[1] == "bf16":
-    set_compute_dtype(torch.bfloat16)
-size = int(os.environ.get("PROBE_SIZE", "64"))
-im, lpar, lpose, w = T._batch(2, size, 3, dev)
+mode = os.environ.get("PROBE_MODE", "tiny")      # tiny | full (C=64, 384^2, batch 1) | search | syncbn (1-rank nccl group)
+bf16 = len(sys.argv) > 1 and sys.argv[1] == "bf16"
+if mode == "search":
+    from npp_amd.optim import FusedAdam
+    from npp_amd.train_step import SearchStep
+    net, cp, cq, weights = T._search_setup(dev)
+    opt = FusedAdam(weights, lr=1e-3)
+    sstep = SearchStep(net, cp, cq, opt, FusedAdam(net.arch_parameters(), lr=3e-3, betas=(0.5, 0.999), weight_decay=0.001),
+                       graph=False)
+    if bf16:
+        set_compute_dtype(torch.bfloat16)
+    b1, b2 = T._batch(2, 64, 3, dev), T._batch(2, 64, 4, dev)
+
+    def step(*_a):
+        l1, l2 = sstep(b1[:3], b2[:3], entropy=True)
+        return l1 + l2
+    im = lpar = lpose = None
+elif mode == "syncbn":
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29671")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from npp_amd import _ops as K0
+    from npp_amd.criterion import Criterion_par, Criterion_pose
+    from npp_amd.ddp import GradReducer, unused_parameter_names
+    from npp_amd.model_augment import Network
+    from npp_amd.optim import FusedAdam
+    from npp_amd.train_step import TrainStep
+    K0._SYNC_EVEN_ALONE = True
+    set_compute_dtype(torch.bfloat16 if bf16 else torch.float32)
+    torch.manual_seed(0)
+    net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(Network(T._cfg(8))).to(dev).train()
+    cp, cq = Criterion_pose(out_len=2).to(dev), Criterion_par(out_len=2).to(dev)
+    opt = FusedAdam(list(net.parameters()) + list(cp.parameters()) + list(cq.parameters()), lr=1e-3)
+    red = GradReducer(net, skip=unused_parameter_names(net), always_reduce=True, bucket_mb=0.5)
+    step = TrainStep(net, cp, cq, opt, reducer=red, graph=False, warmup=1)
+    im, lpar, lpose, w = T._batch(2, int(os.environ.get("PROBE_SIZE", "64")), 3, dev)
+else:
+    if mode == "full":
+        T._cfg_small = T._cfg
+        T._cfg = lambda _c: T._cfg_small(64)
+    net, opt, step = T._make(dev, graph=False)
+    if bf16:
+        set_compute_dtype(torch.bfloat16)
+    size = int(os.environ.get("PROBE_SIZE", "384" if mode == "full" else "64"))
+    im, lpar, lpose, w = T._batch(1 if mode == "full" else 2, size, 3, dev)
 steps = int(os.environ.get("PROBE_STEPS", "3"))
 import gc      # noqa: E402
 _gc = os.environ.get("PROBE_GC", "")
