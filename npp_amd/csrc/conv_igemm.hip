@@ -77,7 +77,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
   const int ntile = lid % p.ntiles, mtile = lid / p.ntiles;
-  const int m0 = mtile * BM, n0 = ntile * BN;
+  // Parity mode (data gradient of a stride-2 conv, uph = upw = 2): the zero-upsampled formulation multiplies 3 of 4 taps by
+  // inserted zeros.  Output pixels are grouped by (oh & 1, ow & 1); within a class the taps kh = kh0 + 2i, kw = kw0 + 2j are the
+  // ones that land on real input, ih = ihb + i: a stride-1 conv with ceil(KH/2) x ceil(KW/2) (or fewer, or no) taps -- a 1x1
+  // stride-2 conv's data gradient is three classes of plain zeros and one 1x1 conv.  4x fewer MACs (64->128 3x3 s2 @192^2 dgrad:
+  // 322 -> 9x us).
+  const bool par = p.par != 0;
+  int py = 0, px = 0, kh0 = 0, kw0 = 0, nvw = p.KW, nvt = p.KH * p.KW, OHc = p.OH, OWc = p.OW, Mc = p.M, mt = mtile;
+  if (par) {
+    const int cls = mtile / p.mtiles_c;
+    mt = mtile - cls * p.mtiles_c;
+    py = cls >> 1; px = cls & 1;
+    kh0 = (p.ph - py) & 1; kw0 = (p.pw - px) & 1;
+    const int nvh = kh0 < p.KH ? (p.KH - kh0 + 1) / 2 : 0;
+    nvw = kw0 < p.KW ? (p.KW - kw0 + 1) / 2 : 0;
+    nvt = nvh * nvw;
+    OHc = p.OH >> 1; OWc = p.OW >> 1; Mc = p.N * OHc * OWc;
+  }
+  const int nvw1 = nvw > 0 ? nvw : 1;
+  const int m0 = mt * BM, n0 = ntile * BN;
 
   const int piece = t & 7, row0 = t >> 3;
   // per-row gather bases (4 A rows per thread)
@@ -85,13 +103,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + row0 + 32 * i;
-    if (m < p.M) {
-      const int ow = m % p.OW;
-      const int t2 = m / p.OW;
-      const int oh = t2 % p.OH;
-      const int n = t2 / p.OH;
-      ih0[i] = oh * p.sh - p.ph;
-      iw0[i] = ow * p.sw - p.pw;
+    if (m < Mc) {
+      const int ow = m % OWc;
+      const int t2 = m / OWc;
+      const int oh = t2 % OHc;
+      const int n = t2 / OHc;
+      if (par) {      // (2 oh + py - ph + kh0 is even by the choice of kh0)
+        ih0[i] = (2 * oh + py - p.ph + kh0) / 2;
+        iw0[i] = (2 * ow + px - p.pw + kw0) / 2;
+      } else {
+        ih0[i] = oh * p.sh - p.ph;
+        iw0[i] = ow * p.sw - p.pw;
+      }
       pixb[i] = n * p.H * p.W;
     } else {
       ih0[i] = -(1 << 28);
@@ -108,17 +131,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
   int c = kk - tap * p.Cp;
 
   u32x4 ra[4], rb[BROWS];
-  const int nchunks = p.Kpad / BK;
+  const int nchunks = par ? (nvt * p.Cp + BK - 1) / BK : p.Kpad / BK;
 
   auto load_stage = [&](int chunk) {
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const bool tap_ok = tap < taps;
+    const int kh = par ? tap / nvw1 : tap / p.KW, kw = par ? tap - kh * nvw1 : tap - kh * p.KW;
+    const bool tap_ok = tap < (par ? nvt : taps);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int ih = ih0[i] + kh * p.dh, iw = iw0[i] + kw * p.dw;
+      int ih = ih0[i] + (par ? kh : kh * p.dh), iw = iw0[i] + (par ? kw : kw * p.dw);
       bool ok = tap_ok && ih >= 0 && iw >= 0;
-      if (p.uph > 1) { ok = ok && (ih % p.uph == 0); ih /= p.uph; }
-      if (p.upw > 1) { ok = ok && (iw % p.upw == 0); iw /= p.upw; }
+      if (!par && p.uph > 1) { ok = ok && (ih % p.uph == 0); ih /= p.uph; }
+      if (!par && p.upw > 1) { ok = ok && (iw % p.upw == 0); iw /= p.upw; }
       ok = ok && ih < p.H && iw < p.W;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (ok) {
@@ -127,9 +150,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
       }
       ra[i] = v;
     }
+    // weights: k = tap * Cp + c (= chunk * BK + piece * VEC in the plain mode); parity mode: the REAL tap of this virtual one
+    // (past the class's last tap the A side is zero: any in-range row will do)
+    long koff = (long)chunk * BK + piece * VEC;
+    if (par) {
+      int tr = (kh0 + 2 * kh) * p.KW + kw0 + 2 * kw;
+      if (!tap_ok || tr >= taps) tr = taps - 1;
+      koff = (long)tr * p.Cp + c;
+    }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
-      const long off = (long)(n0 + row0 + 32 * i) * p.Kpad + (long)chunk * BK + piece * VEC;
+      const long off = (long)(n0 + row0 + 32 * i) * p.Kpad + koff;
       rb[i] = *reinterpret_cast<const u32x4*>(wg + off);
     }
     // advance (tap, c) to the next chunk
@@ -210,16 +241,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
   }
   const bool full_vec = p.vec_io && (nbase + VEC <= p.Cout);
   for (int row = pr; row < BM; row += RSTEP) {
-    const int m = m0 + row;
-    if (m >= p.M) break;
+    const int ml = m0 + row;
+    if (ml >= Mc) break;
     if (nbase >= p.Cout) break;
+    long m = ml;          // output pixel index
+    if (par) {
+      const int ow = ml % OWc, t2 = ml / OWc;
+      const int oh = t2 % OHc, n = t2 / OHc;
+      m = ((long)n * p.OH + 2 * oh + py) * p.OW + 2 * ow + px;
+    }
     float v[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) v[j] = sC[row * CP + pc * VEC + j] + bias[j];
     if (full_vec) {
       if (mg) {
         float mk[VEC];
-        Vec16<T>::load(mg + (long)m * p.ldm + nbase, mk);
+        Vec16<T>::load(mg + m * p.ldm + nbase, mk);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[j] = mk[j] > 0.f ? v[j] : 0.f;
       }
@@ -229,16 +266,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
         bsum[j] += v[j];
         bsq[j] += v[j] * v[j];
       }
-      Vec16<T>::store(yg + (long)m * p.ldy + nbase, v);
+      Vec16<T>::store(yg + m * p.ldy + nbase, v);
     } else {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         if (nbase + j < p.Cout) {
-          if (mg && !(Elt<T>::ld(mg + (long)m * p.ldm + nbase + j) > 0.f)) v[j] = 0.f;
+          if (mg && !(Elt<T>::ld(mg + m * p.ldm + nbase + j) > 0.f)) v[j] = 0.f;
           v[j] = Elt<T>::round(v[j]);
           bsum[j] += v[j];
           bsq[j] += v[j] * v[j];
-          Elt<T>::st(yg + (long)m * p.ldy + nbase + j, v[j]);
+          Elt<T>::st(yg + m * p.ldy + nbase + j, v[j]);
         }
       }
     }
@@ -485,6 +522,15 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
   const int bn = (npad % 128 == 0) ? 128 : (npad % 64 == 0 ? 64 : 32);
   p.mtiles = (p.M + BM - 1) / BM;
   p.ntiles = npad / bn;
+  // data gradient of a stride-2 conv on the generic kernel: parity classes (see conv_igemm_kernel)
+  static const bool par_off = getenv("NPP_DISABLE_PARITY") != nullptr;
+  p.par = 0; p.mtiles_c = 0;
+  if (!par_off && g->uph == 2 && g->upw == 2 && g->sh == 1 && g->sw == 1 && g->dh == 1 && g->dw == 1 && y->h % 2 == 0 && y->w % 2 == 0 &&
+      !p.mask_bits) {
+    p.par = 1;
+    p.mtiles_c = (int)((M / 4 + BM - 1) / BM);
+    p.mtiles = 4 * p.mtiles_c;
+  }
   const int grid = p.mtiles * p.ntiles;
   if (ws_query) {
     *ws_query = conv_s1_ws_bytes(p, x->dtype);

@@ -9,6 +9,8 @@ struct IgemmParams {
   int M, mtiles, ntiles;
   int vec_io;
   int mask_bits;   // `mask` is an NPP_MASK8 bit-mask (ldm in BYTES per pixel): conv_g4 / conv_g8 only
+  int par, mtiles_c;   // generic kernel, data gradient of a stride-2 conv (uph = upw = 2): output pixels grouped by parity class,
+                       // each class a stride-1 conv over the taps that do not hit an inserted zero; mtiles_c = M-tiles per class
 };
 // stride-1 "same" convolution fast path (conv_s1.hip); returns false when the shape is not eligible
 bool conv_s1_launch(const IgemmParams& p, int dtype, hipStream_t stream, void* ws, size_t ws_bytes);
