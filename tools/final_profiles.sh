@@ -36,4 +36,7 @@ timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INS
 fm=$(find /tmp/fp_pmc_mfma -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_mfma_busy.py "$fm" "$FAMS,bn_bwd,add_n,affine_add,dw" > $out/${tag}_pmc_mfma_busy.txt
 cat $out/${tag}_pmc_mfma_busy.txt
+#   5. the plain bench line (no profiler, default streams), after copying the fresh traffic file where bench.py reads it
+unset NPP_STREAMS NPP_SYNC_LAUNCH
+cp $out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
 python3 bench.py > $out/${tag}_bench_line.json 2> /dev/null; tail -c 400 $out/${tag}_bench_line.json
