@@ -159,6 +159,10 @@ def main():
                     help="1: capture the whole step (fwd+loss+bwd+Adam) in one hipGraph and replay it; 0: eager; "
                          "-1 (default): graph for every N (on N > 1 every collective sits on the capture's origin stream); a capture "
                          "failure falls back to eager")
+    ap.add_argument("--launcher", default="", choices=["", "eager", "auto"],
+                    help="time the loop body exactly as the UNCHANGED reference launcher issues it (core/function.py:87-107: "
+                         "model(images), criteria, zero_grad, backward, torch.optim.Adam.step) instead of TrainStep: "
+                         "eager = kernel by kernel, auto = with npp_amd.auto_graph (NPP_AUTO_GRAPH=1)")
     ap.add_argument("--no-comm-ablation", action="store_true",
                     help="N > 1: skip the second, communication-free timing (local BN statistics, no gradient reducer) "
                          "that `exposed_comm_ms` is computed from")
@@ -267,12 +271,34 @@ def main():
     def eager_step():
         return train_step._eager(images, lpar, lpose, None)
 
+    if args.launcher:
+        from npp_amd import auto_graph
+        auto_graph.ENABLED = args.launcher == "auto"
+        net._auto_graph_off = False
+        use_graph = False
+        args.no_prof = True
+        K.GRAPH_TOPOLOGY = False                        # (AutoGraph switches it on itself)
+        l_opt = torch.optim.Adam(params, lr=1e-4)       # augment_lip_sync.py:210-213
+        if os.environ.get("NPP_LAUNCHER_FUSED_ADAM"):      # INTEGRATION.md's optional one-line change
+            from npp_amd.optim import FusedAdam as _FA2
+            l_opt = _FA2(params, lr=1e-4)
+
+        def step():
+            output_pose, output_par = net(images)
+            loss = (crit_par(output_par, lpar).unsqueeze(0) + crit_pose(output_pose, lpose).unsqueeze(0)).mean()
+            l_opt.zero_grad()
+            loss.backward()
+            if reducer is not None:
+                reducer.finish()
+            l_opt.step()
+            return loss
+
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if use_graph:
+    if use_graph or args.launcher == "auto":
         for _ in range(3):      # two eager calls, then capture + first replay: all before the W warm-up steps
             step()
         barrier()
@@ -388,7 +414,8 @@ def main():
                                ", %dx%d, batch %d/GPU, fwd + Criterion_par + Criterion_pose + bwd + Adam step"
                                % (args.size, args.size, args.batch),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                   "sync_bn": bool(sync_bn), "hip_graph": graph is not None, "loss": float(loss)},
+                   "sync_bn": bool(sync_bn), "hip_graph": graph is not None or (args.launcher == "auto" and net._auto is not None and net._auto.graph is not None),
+                   "launcher_loop": args.launcher or None, "loss": float(loss.detach())},
         "model_tflops": round(value * 3 * (FWD_GFLOP_PER_IMG.get(args.size, 243.37 * (args.size / 384.0) ** 2)
                                            if args.model == "augment" else 88.70 * (args.size / 384.0) ** 2) / 1e3, 2),
     }

@@ -14,7 +14,12 @@ import types
 __version__ = "0.1.0"
 
 
-def install_as_reference_modules():
+def install_as_reference_modules(auto_graph=None):
+    """auto_graph: True / False switches npp_amd.auto_graph (hipGraph replay of Network.forward + backward for an unchanged
+    launcher) on or off; None leaves it to the NPP_AUTO_GRAPH environment variable."""
+    if auto_graph is not None:
+        from . import auto_graph as _ag
+        _ag.ENABLED = bool(auto_graph)
     from . import criterion, genotypes, model_augment, model_search_interact, operations
     models = types.ModuleType("models")
     models.__path__ = []

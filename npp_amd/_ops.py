@@ -303,6 +303,25 @@ _zpool32 = _PerStream(lambda: _ZeroPool(torch.float32, 1 << 24))
 _stream_caches: list = []      # dict / set objects other modules cache HIP streams in (model_augment._side_streams)
 
 
+def join_capturing_side_streams():
+    """Inside a capture: make the current (origin) stream wait for every cached side stream that has joined the capture.  A
+    backward run by torch.autograd.grad ends on whatever streams its last nodes ran on (the engine joins leaf streams only for
+    AccumulateGrad nodes); ending the capture with a forked stream unjoined is an error (a crash on this ROCm)."""
+    cur = torch.cuda.current_stream()
+    seen = {cur.cuda_stream}
+    streams = list(_helper_streams.values())
+    for c in _stream_caches:
+        streams += list(c.values()) if isinstance(c, dict) else list(c)
+    for st in streams:
+        if not isinstance(st, torch.cuda.Stream) or st.cuda_stream in seen:
+            continue
+        seen.add(st.cuda_stream)
+        with torch.cuda.stream(st):
+            capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            cur.wait_stream(st)
+
+
 def forget_streams():
     """Drop every cached side stream.  After a hipGraph capture that was invalidated half way the streams that had joined it
     stay in capture mode for good on this ROCm (hipStreamEndCapture fails on them): the eager fallback needs fresh ones."""
@@ -442,6 +461,7 @@ def zeros_f32(n, device, own=False):
 # packed-weight cache: f32 OIHW parameter -> MFMA operand image, rebuilt when the parameter changes
 # --------------------------------------------------------------------------------------------------
 _pack_cache = {}   # id(parameter) -> (weakref, {(for_dgrad, dtype): ((version, data_ptr), packed)})
+_pack_by_ptr = {}  # data_ptr -> id(parameter) of the WeightPacker-managed entries (lookup for aliases of a parameter)
 
 
 def packed_weight(w: torch.Tensor, for_dgrad: bool, dtype: torch.dtype) -> torch.Tensor:
@@ -450,8 +470,15 @@ def packed_weight(w: torch.Tensor, for_dgrad: bool, dtype: torch.dtype) -> torch
     wid = id(w)
     ent = _pack_cache.get(wid)
     if ent is None or ent[0]() is not w:
-        ent = (weakref.ref(w, lambda _r, _k=wid: _pack_cache.pop(_k, None)), {})
-        _pack_cache[wid] = ent
+        # an ALIAS of a parameter (auto_graph captures gradients w.r.t. `p.view_as(p)`): same storage, same version counter --
+        # the images the owner's entry holds are the alias's images
+        owner = _pack_cache.get(_pack_by_ptr.get(w.data_ptr(), 0))
+        o = owner[0]() if owner is not None else None
+        if o is not None and o.data_ptr() == w.data_ptr() and o.shape == w.shape and o._version == w._version:
+            ent = owner
+        else:
+            ent = (weakref.ref(w, lambda _r, _k=wid: _pack_cache.pop(_k, None)), {})
+            _pack_cache[wid] = ent
     per = ent[1]
     hit = per.get(key)
     if hit is not None and hit[0] == ver:
@@ -475,6 +502,7 @@ def packed_weight(w: torch.Tensor, for_dgrad: bool, dtype: torch.dtype) -> torch
 
 def clear_caches():
     _pack_cache.clear()
+    _pack_by_ptr.clear()
 
 
 # --------------------------------------------------------------------------------------------------
@@ -587,6 +615,7 @@ class WeightPacker:
                 ent = (weakref.ref(w, lambda _r, _k=wid: _pack_cache.pop(_k, None)), {})
                 _pack_cache[wid] = ent
             ver = (w._version, w.data_ptr())
+            _pack_by_ptr[w.data_ptr()] = wid
             ent[1][(False, dtype)] = (ver, self.outs[k], True)
             ent[1][(True, dtype)] = (ver, self.outs[k + 1], True)
             k += 2

@@ -434,6 +434,7 @@ class Network(nn.Module):
             self.par_head.append(head(4 * Cf, 256, 1, self._num_classes))
             self.edge_head.append(head(3 * Cf, 6, 3, 2, bias1=False))
         self._packer = None
+        self._auto = None          # auto_graph.AutoGraph, created by the first training forward under NPP_AUTO_GRAPH=1
         self._init_params()
 
     # -- construction helpers ---------------------------------------------------------------------------
@@ -474,6 +475,17 @@ class Network(nn.Module):
         return z
 
     def forward(self, x):
+        """model_augment.py:402-574.  With NPP_AUTO_GRAPH=1 a training forward (and its backward) is replayed as hipGraphs after
+        the first calls (npp_amd/auto_graph.py); otherwise -- and always in eval mode, under no_grad or inside a capture -- the
+        kernels are issued one by one."""
+        from . import auto_graph
+        if auto_graph.ENABLED and self.training:
+            if self._auto is None:
+                self._auto = auto_graph.AutoGraph(self)
+            return self._auto(x)
+        return self._forward_eager(x)
+
+    def _forward_eager(self, x):
         if not x.is_cuda:
             raise RuntimeError("npp_amd.Network runs on the MI355X HIP kernels only: move the input to cuda "
                                "(there is no CPU fallback)")
@@ -678,6 +690,12 @@ class Network(nn.Module):
                     t.record_stream(so)
         K.fan_reset()
         return pose_list, par_list
+
+    def __getstate__(self):      # deepcopy / pickle: derived caches (packed weights, captured graphs) stay behind
+        d = self.__dict__.copy()
+        d["_packer"] = None
+        d["_auto"] = None
+        return d
 
     def _sync_bn_active(self) -> bool:
         import torch.distributed as dist

@@ -36,6 +36,9 @@ class TrainStep:
     def __init__(self, model, criterion_pose, criterion_par, optimizer, reducer=None, graph: Optional[bool] = None,
                  warmup: int = 2):
         self.model, self.criterion_pose, self.criterion_par = model, criterion_pose, criterion_par
+        for m in (model, getattr(model, "module", None)):
+            if m is not None:
+                m._auto_graph_off = True      # this step captures the whole loop body itself (npp_amd/auto_graph.py stays out)
         self.optimizer, self.reducer = optimizer, reducer
         if graph is None:
             graph = os.environ.get("NPP_TRAIN_GRAPH", "1") != "0"

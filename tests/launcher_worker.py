@@ -5,6 +5,7 @@ augment_lip_sync.py unchanged" claim of BASELINE.json:north_star.  Run by tests/
 
     python launcher_worker.py cpu    construction, SyncBatchNorm conversion, _init_params, parameter groups, checkpoint loader
     python launcher_worker.py gpu    + .cuda(), DistributedDataParallel(find_unused_parameters=True), Adam + MultiStepLR, one step
+    NPP_AUTO_GRAPH=1 python launcher_worker.py gpu    the same loop with the forward / backward replayed as hipGraphs (6 iterations)
 """
 import os
 import sys
@@ -97,7 +98,8 @@ def main(mode):
     model.train()
     losses = []
     before = {k: v.detach().clone() for k, v in model.module.named_parameters()}
-    for it in range(2):
+    auto = os.environ.get("NPP_AUTO_GRAPH") == "1"
+    for it in range(6 if auto else 2):
         images, labels_par, labels_pose, meta = [torch.from_numpy(a) if not isinstance(a, (list, dict)) else a
                                                  for a in synth_batch(2, 64, seed=it)]
         labels_par = [torch.from_numpy(a) for a in labels_par]
@@ -123,10 +125,12 @@ def main(mode):
     import math
     assert all(math.isfinite(v) for v in losses), losses
     moved = sum(int((before[k] != v).any()) for k, v in model.module.named_parameters())
-    unused = sum(1 for p in model.module.parameters() if p.grad is None)
+    unused = sum(1 for p in model.module.parameters() if p.grad is None or (auto and not bool(p.grad.any())))
+    if auto:      # the replayed step: graph captured at the third call, never-used parameters get zeros (DDP waits for every hook)
+        assert model.module._auto is not None and model.module._auto.graph is not None, "forward was never captured"
     assert unused == 116, unused                                                       # SE_Block.bn at stride 1 (SURVEY TL;DR 7)
     assert moved >= len(before) - 116 - 8, (moved, len(before))
-    assert abs(optimizer.param_groups[0]["lr"] - 0.2 * config.TRAIN.LR * 0.1) < 1e-12   # MultiStepLR fired at step 1
+    assert abs(optimizer.param_groups[0]["lr"] - 0.2 * config.TRAIN.LR * (0.01 if auto else 0.1)) < 1e-12   # MultiStepLR fired at step 1 (and 3)
     sd = model.state_dict()                                                            # DDP keys: `module.` prefix
     torch.save(sd, os.path.join(tmp, "ckpt.pth"))
     fresh = Network(config)

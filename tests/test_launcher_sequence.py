@@ -10,9 +10,9 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(mode):
+def _run(mode, **env):
     return subprocess.run([sys.executable, os.path.join(HERE, "launcher_worker.py"), mode], capture_output=True, text=True,
-                          timeout=900)
+                          timeout=900, env=dict(os.environ, **env))
 
 
 def test_launcher_setup_sequence_cpu():
@@ -23,4 +23,12 @@ def test_launcher_setup_sequence_cpu():
 @pytest.mark.gpu
 def test_launcher_sequence_with_ddp_and_one_step_gpu():
     r = _run("gpu")
+    assert r.returncode == 0 and "LAUNCHER_GPU_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_launcher_sequence_with_auto_graph_gpu():
+    """The same unchanged loop with NPP_AUTO_GRAPH=1: Network.forward + backward replayed as hipGraphs from the third call on
+    (npp_amd/auto_graph.py), under DistributedDataParallel(find_unused_parameters=True), torch.optim.Adam and MultiStepLR."""
+    r = _run("gpu", NPP_AUTO_GRAPH="1", MASTER_PORT="29534")
     assert r.returncode == 0 and "LAUNCHER_GPU_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
