@@ -227,6 +227,7 @@ class Network(nn.Module):
             self.par_head.append(head(4 * Cf, 256, 1, self._num_classes))
             self.edge_head.append(head(3 * Cf, 6, 3, 2, bias1=False))
         self._packer = None
+        self._auto = None
         self.init_weights()
         self._initialize_alphas()
 
@@ -291,6 +292,21 @@ class Network(nn.Module):
         return K.weighted_sum(w2, outs)
 
     def forward(self, x):
+        """model_search_interact.py:626-770.  NPP_AUTO_GRAPH=1: replayed as hipGraphs after the first calls (npp_amd/auto_graph.py)."""
+        from . import auto_graph
+        if auto_graph.ENABLED and self.training:
+            if self._auto is None:
+                self._auto = auto_graph.AutoGraph(self)
+            return self._auto(x)
+        return self._forward_eager(x)
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_packer"] = None
+        d["_auto"] = None
+        return d
+
+    def _forward_eager(self, x):
         if not x.is_cuda:
             raise RuntimeError("npp_amd supernet runs on the MI355X HIP kernels only (no CPU fallback)")
         dt = get_compute_dtype()

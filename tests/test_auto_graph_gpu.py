@@ -128,3 +128,29 @@ def test_eval_other_shapes_and_accumulation(auto_on):
     with torch.no_grad():
         pose2, par2 = fresh(batch[0])
     assert rel_l2(par[-1][0], par2[-1][0]) < 1e-5 and rel_l2(pose[-1][0], pose2[-1][0]) < 1e-5
+
+
+def test_search_supernet_is_replayed_too(auto_on):
+    """model_search_interact.Network behind the same switch: the loop body of train_with_alpha calls model(input) twice per
+    iteration (train batch, mini-loader batch) with every parameter requiring grad -- one graph serves both calls."""
+    import test_train_step_gpu as T
+    dev = torch.device("cuda:0")
+    net, cp, cq, weights = T._search_setup(dev)
+    arch = list(net.arch_parameters())
+    opt = torch.optim.Adam(weights, lr=1e-3)
+    a_opt = torch.optim.Adam(arch, lr=3e-3, betas=(0.5, 0.999), weight_decay=1e-3)
+    b1, b2 = T._batch(2, 64, 3, dev), T._batch(2, 64, 4, dev)
+    seen = []
+    for it in range(4):
+        opt.zero_grad()
+        loss = _loss(net, cp, cq, b1)
+        loss.backward()
+        opt.step()
+        a_opt.zero_grad()
+        loss2 = _loss(net, cp, cq, b2) + 2 * net.loss_entropy()
+        loss2.backward()
+        a_opt.step()
+        seen.append((float(loss.detach()), float(loss2.detach())))
+    assert net._auto is not None and net._auto.graph is not None
+    assert all(a == a and b == b for a, b in seen) and seen[-1][0] < seen[0][0], seen
+    assert all(a.grad is not None and torch.isfinite(a.grad).all() and float(a.grad.abs().sum()) > 0 for a in arch)
