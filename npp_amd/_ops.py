@@ -309,7 +309,7 @@ def join_capturing_side_streams():
     AccumulateGrad nodes); ending the capture with a forked stream unjoined is an error (a crash on this ROCm)."""
     cur = torch.cuda.current_stream()
     seen = {cur.cuda_stream}
-    streams = list(_helper_streams.values())
+    streams = [st for pair in _helper_streams.values() for st in (pair if isinstance(pair, (tuple, list)) else (pair,))]
     for c in _stream_caches:
         streams += list(c.values()) if isinstance(c, dict) else list(c)
     for st in streams:

@@ -328,7 +328,7 @@ def _lockstep(mode: int, sync_bn: bool) -> bool:
 
 def _syncbn_stream_mode() -> int:
     v = os.environ.get("NPP_SYNCBN_STREAMS")
-    if v in ("1", "3"):
+    if v in ("1", "2", "3"):
         return int(v)
     return 3 if K.GRAPH_TOPOLOGY else 1
 
@@ -574,7 +574,7 @@ class Network(nn.Module):
         lockstep = _lockstep(mode, sync_bn)
         # lockstep + hub topology: the two branches' SyncBatchNorm statistics share one pool and travel in ONE collective per
         # lockstep stage (K.SYNC_MERGE; NPP_SYNC_MERGE=0 keeps one exchange per branch)
-        K.SYNC_MERGE = bool(lockstep and sync_bn and mode == 3 and os.environ.get("NPP_SYNC_MERGE", "1") != "0")
+        K.SYNC_MERGE = bool(lockstep and sync_bn and mode >= 2 and os.environ.get("NPP_SYNC_MERGE", "1") != "0")
         for i, (cell1, cell2) in enumerate(zip(self.cells1, self.cells2)):
             if lockstep:
                 r1, r2 = [None], [None]
