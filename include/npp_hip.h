@@ -297,6 +297,10 @@ int npp_ce_pixel_bwd(const NppTensor* logits, const int64_t* labels, int H, int 
 int npp_ce_pixel_grad_up(const NppTensor* logits, const int64_t* labels, int H, int W, const float* class_w,
                          int ignore, const float* p_gt, const float* kth, float thresh, int use_ohem,
                          const float* gscale, float* dup, void* stream);
+/* the same into a tensor descriptor at the label resolution: f32 or bf16 rows (ld >= c, padding zeroed) */
+int npp_ce_pixel_grad_up_t(const NppTensor* logits, const int64_t* labels, const float* class_w, int ignore,
+                           const float* p_gt, const float* kth, float thresh, int use_ohem, const float* gscale,
+                           NppTensor* dup, void* stream);
 /* edge class weights from label counts, core/criterion.py:161-166: w = [pos/(pos+neg), neg/(pos+neg)] */
 int npp_edge_weights(const int64_t* labels, int64_t n, double* counts /*[2] zeroed by caller*/, void* stream);
 

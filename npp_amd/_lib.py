@@ -124,6 +124,7 @@ _SIGS = {
     "npp_ce_reduce": [_P, _P, _P, _P, C.c_int, C.c_int64, _P, C.c_float, C.c_int, _P, _P],
     "npp_ce_pixel_bwd": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _T, _P],
     "npp_ce_pixel_grad_up": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P],
+    "npp_ce_pixel_grad_up_t": [_T, _P, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _T, _P],
     "npp_edge_weights": [_P, C.c_int64, _P, _P],
     "npp_adam_step": [_P, _P, C.c_int, _P, _P],
     "npp_comm_unique_id": [_P],

@@ -279,21 +279,22 @@ __global__ __launch_bounds__(256) void ce_pixel_bwd_kernel(const T* __restrict__
 // d loss / d upsampled-logits at the label resolution, f32 [N*H*W][C] (zero rows for pixels that are not kept).
 // The bilinear transpose down to the logit resolution is then one launch of the (gather-form, atomic-free)
 // bilinear backward kernel -- 20x faster than scattering with atomics from here (1.2 ms -> ~0.1 ms at N=16).
-template <typename T, int CMAX>
+template <typename T, int CMAX, typename TO>
 __global__ __launch_bounds__(256) void ce_pixel_grad_up_kernel(const T* __restrict__ lg, const long* __restrict__ labels,
                                                                const float* __restrict__ cw, int ignore, CeGeom g,
                                                                const float* __restrict__ p_gt, const float* __restrict__ kth,
                                                                float thresh, int use_ohem, const float* __restrict__ gscale,
-                                                               float* __restrict__ dup) {
+                                                               TO* __restrict__ dup, long ldo) {
   const long total = (long)g.N * g.H * g.W;
   const float thr = use_ohem ? fmaxf(kth[0], thresh) : INFINITY;
   const float gs = gscale[0];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    float* out = dup + i * g.C;
+    TO* out = dup + i * ldo;
+    for (int c = g.C; c < ldo; ++c) Elt<TO>::st(out + c, 0.f);      // row padding (bf16 rows are padded to 8 channels)
     const float p = p_gt[i];
     if (!(p >= 0.f && p < thr)) {
 #pragma unroll
-      for (int c = 0; c < CMAX; ++c) if (c < g.C) out[c] = 0.f;
+      for (int c = 0; c < CMAX; ++c) if (c < g.C) Elt<TO>::st(out + c, 0.f);
       continue;
     }
     const long lab = labels[i];
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void ce_pixel_grad_up_kernel(const T* __restri
     const float k = gs * cw[lab];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
-      if (c < g.C) out[c] = k * (v[c] * inv - (c == (int)lab ? 1.f : 0.f));
+      if (c < g.C) Elt<TO>::st(out + c, k * (v[c] * inv - (c == (int)lab ? 1.f : 0.f)));
   }
 }
 
@@ -448,23 +449,43 @@ extern "C" int npp_ce_pixel_bwd(const NppTensor* logits, const int64_t* labels, 
   return npp_check_launch("ce_pixel_bwd");
 }
 
-extern "C" int npp_ce_pixel_grad_up(const NppTensor* logits, const int64_t* labels, int H, int W, const float* class_w,
-                                    int ignore, const float* p_gt, const float* kth, float thresh, int use_ohem,
-                                    const float* gscale, float* dup, void* stream) {
+static int ce_grad_up_impl(const NppTensor* logits, const int64_t* labels, int H, int W, const float* class_w, int ignore,
+                           const float* p_gt, const float* kth, float thresh, int use_ohem, const float* gscale, void* dup,
+                           int dup_dtype, long ldo, void* stream) {
   NPP_REQUIRE(logits && logits->ptr && labels && class_w && p_gt && gscale && dup && (!use_ohem || kth), NPP_E_NULL,
               "npp_ce_pixel_grad_up: null pointer");
   CeGeom g;
   int rc = ce_geom(g, logits, H, W, "npp_ce_pixel_grad_up");
   if (rc) return rc;
+  NPP_REQUIRE(ldo >= g.C && (dup_dtype == NPP_F32 || dup_dtype == NPP_BF16), NPP_E_SHAPE, "npp_ce_pixel_grad_up: bad output rows");
   const long total = (long)g.N * H * W;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope prof(NPP_FAM_LOSS, logits->dtype, s, 0, (double)total * (8 + 4.0 * g.C));
+  ProfScope prof(NPP_FAM_LOSS, logits->dtype, s, 0, (double)total * (8 + (dup_dtype == NPP_F32 ? 4.0 : 2.0) * ldo));
   const dim3 grid(grid_for(total, 256, 8192));
-#define L(T, CM) hipLaunchKernelGGL((ce_pixel_grad_up_kernel<T, CM>), grid, dim3(256), 0, s, (const T*)logits->ptr, (const long*)labels, class_w, ignore, g, p_gt, kth, thresh, use_ohem, gscale, dup)
-  if (logits->dtype == NPP_BF16) { if (g.C <= 2) L(bf16_t, 2); else L(bf16_t, 32); }
-  else { if (g.C <= 2) L(float, 2); else L(float, 32); }
+#define L(T, CM, TO) hipLaunchKernelGGL((ce_pixel_grad_up_kernel<T, CM, TO>), grid, dim3(256), 0, s, (const T*)logits->ptr, (const long*)labels, class_w, ignore, g, p_gt, kth, thresh, use_ohem, gscale, (TO*)dup, ldo)
+#define L2(T, CM) do { if (dup_dtype == NPP_F32) L(T, CM, float); else L(T, CM, bf16_t); } while (0)
+  if (logits->dtype == NPP_BF16) { if (g.C <= 2) L2(bf16_t, 2); else L2(bf16_t, 32); }
+  else { if (g.C <= 2) L2(float, 2); else L2(float, 32); }
+#undef L2
 #undef L
   return npp_check_launch("ce_pixel_grad_up");
+}
+
+extern "C" int npp_ce_pixel_grad_up(const NppTensor* logits, const int64_t* labels, int H, int W, const float* class_w,
+                                    int ignore, const float* p_gt, const float* kth, float thresh, int use_ohem,
+                                    const float* gscale, float* dup, void* stream) {
+  return ce_grad_up_impl(logits, labels, H, W, class_w, ignore, p_gt, kth, thresh, use_ohem, gscale, dup, NPP_F32,
+                         logits ? logits->c : 0, stream);
+}
+
+// the same into a tensor descriptor: f32 or bf16 rows of ld >= c elements at the label resolution (bf16: the throughput mode's
+// gradient image is 113 MB instead of 189 MB at 16 x 384 x 384 x 20, and the bilinear transpose hands back bf16 directly)
+extern "C" int npp_ce_pixel_grad_up_t(const NppTensor* logits, const int64_t* labels, const float* class_w, int ignore,
+                                      const float* p_gt, const float* kth, float thresh, int use_ohem, const float* gscale,
+                                      NppTensor* dup, void* stream) {
+  NPP_REQUIRE(dup && dup->ptr && logits && dup->n == logits->n && dup->c == logits->c, NPP_E_SHAPE, "npp_ce_pixel_grad_up_t: bad output tensor");
+  return ce_grad_up_impl(logits, labels, (int)dup->h, (int)dup->w, class_w, ignore, p_gt, kth, thresh, use_ohem, gscale, dup->ptr,
+                         dup->dtype, dup->ld, stream);
 }
 
 extern "C" int npp_edge_weights(const int64_t* labels, int64_t n, double* counts, void* stream) {
