@@ -283,14 +283,25 @@ def main():
             from npp_amd.optim import FusedAdam as _FA2
             l_opt = _FA2(params, lr=1e-4)
 
-        def step():
+        host = {"forward": 0.0, "criteria": 0.0, "zero_grad": 0.0, "backward": 0.0, "optimizer": 0.0, "n": 0}
+
+        def step():      # (host-side enqueue time per section is kept for NPP_LAUNCHER_HOST_TIMES=1)
+            t0 = time.perf_counter()
             output_pose, output_par = net(images)
+            t1 = time.perf_counter()
             loss = (crit_par(output_par, lpar).unsqueeze(0) + crit_pose(output_pose, lpose).unsqueeze(0)).mean()
+            t2 = time.perf_counter()
             l_opt.zero_grad()
+            t3 = time.perf_counter()
             loss.backward()
             if reducer is not None:
                 reducer.finish()
+            t4 = time.perf_counter()
             l_opt.step()
+            t5 = time.perf_counter()
+            for k, a, b in (("forward", t0, t1), ("criteria", t1, t2), ("zero_grad", t2, t3), ("backward", t3, t4), ("optimizer", t4, t5)):
+                host[k] += b - a
+            host["n"] += 1
             return loss
 
     def barrier():
@@ -311,11 +322,17 @@ def main():
     L = _lib.lib()
     import ctypes as C
     dt_code = _lib.NPP_BF16 if dtype == torch.bfloat16 else _lib.NPP_F32
+    if args.launcher:
+        for k in host:
+            host[k] = 0.0 if k != "n" else 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.launcher and os.environ.get("NPP_LAUNCHER_HOST_TIMES") and rank == 0:
+        sys.stderr.write("host enqueue ms per step (timed region): " + ", ".join(
+            f"{k} {1e3 * v / max(host['n'], 1):.2f}" for k, v in host.items() if k != "n") + "\n")
     # roofline of the dominant kernel: HIP events around every launch of the two MFMA conv families (on the launch stream), in
     # eager single-stream steps right after the timed region -- a replayed graph cannot carry the event pairs, and with the
     # two branch streams overlapping an event pair would also time the neighbour's kernels.  The family with the larger
