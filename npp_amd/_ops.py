@@ -796,8 +796,6 @@ class _Conv2d(Function):
         ctx.mask_bits = relu_mask_of(x) if (relu_in and RELU_BITS and x.dtype == torch.bfloat16) else None
         if relu_in and ctx.mask_bits is None and RELU_BITS and x.dtype == torch.bfloat16:
             MASK_STATS[2] += 1
-        if relu_in and ctx.mask_bits is None and RELU_BITS and x.dtype == torch.bfloat16:
-            MASK_STATS[2] += 1
         ctx.cfg = (stride, pad, dil, relu_in, bias is not None)
         ctx.set_materialize_grads(False)     # no zero tensor for the (non-differentiable) statistics output
         if stats is not None:
