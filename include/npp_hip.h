@@ -127,6 +127,21 @@ typedef struct NppUnpackJob {
   int64_t slab, first_block;
 } NppUnpackJob;
 int npp_unpack_wgrad_batched(const NppUnpackJob* jobs_dev, const int32_t* block_job_dev, int64_t total_blocks, void* stream);
+/* Many SMALL weight gradients in one launch.  The 12x12 / 24x24 layers' weight gradients are ~100 blocks and ~25 us of latency
+ * each and have no reader before the optimizer: a host that controls its own step (npp_amd.train_step.TrainStep) collects them
+ * during backward and runs them together.  Items must pass npp_conv_wgrad_batchable (the LDS-DMA kernel's shapes: bf16, stride-1
+ * "same" 1x1 / KxK, channel counts 32 / 64 / 128k); dw_packed as for npp_conv_wgrad (zeroed, packed layout, accumulated into).
+ * host_pinned / dev: caller-owned scratch of npp_conv_wgrad_batched_ws(n) bytes each (pinned host memory: the call fills it and
+ * enqueues one upload -- inside a hipGraph capture the replay re-reads it, so it must stay as it is while the graph lives). */
+typedef struct NppWgradItem {
+  NppTensor x, dy;
+  float* dw_packed;
+  NppConvGeom g;
+  int32_t _pad;
+} NppWgradItem;
+int npp_conv_wgrad_batchable(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g);
+int64_t npp_conv_wgrad_batched_ws(int n);
+int npp_conv_wgrad_batched(const NppWgradItem* items, int n, void* host_pinned, void* dev, int64_t ws_bytes, void* stream);
 int npp_conv_wgrad_splits(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g);
 int npp_conv_wgrad_slabs(const NppTensor* x, const NppTensor* dy, float* slabs, int nslabs, const NppConvGeom* g, void* stream);
 int npp_unpack_wgrad_sum(const float* slabs, int nslabs, int cout, int cin, int kh, int kw, float* dw_oihw, void* stream);

@@ -679,6 +679,87 @@ def _unpack_or_defer(src, dst, co, ci, kh, kw, nslabs, s):
         check(lib().npp_unpack_wgrad(src.data_ptr(), co, ci, kh, kw, dst.data_ptr(), s), "npp_unpack_wgrad")
 
 
+# Deferred, batched SMALL weight gradients (npp_conv_wgrad_batched): the 12x12 / 24x24 layers' weight gradients are ~100 blocks and
+# ~25 us of latency each (140 launches, 2.9 ms of a step's kernel time) and nobody reads them before the optimizer.  Under TrainStep
+# (no reducer) they are collected during backward -- x and dy stay alive -- and run as one launch per kernel variant before the
+# batched unpack.  Not on the two branch streams at all, and throughput- instead of latency-bound.
+DEFER_WGRAD_MAX_PIX = 0        # > 0: defer the weight gradients of maps with at most this many pixels (TrainStep sets it)
+_pending_wgrads: list = []     # (x, dy, packed accumulator / gradient tensor, NppConvGeom, stream)
+_wgrad_batchable: dict = {}
+_wgrad_bufs = {"pin": None, "dev": None, "ev": None, "keep": []}
+
+
+def _defer_wgrad(x, dy, acc, g, key):
+    """True if this weight gradient was queued for the batched launch (acc: the zeroed packed accumulator it adds into)."""
+    if DEFER_WGRAD_MAX_PIX <= 0 or x.shape[0] * x.shape[2] * x.shape[3] > DEFER_WGRAD_MAX_PIX or x.dtype != torch.bfloat16:
+        return False
+    ok = _wgrad_batchable.get(key)
+    if ok is None:
+        ok = _wgrad_batchable[key] = bool(lib().npp_conv_wgrad_batchable(_byref(x), _byref(dy), C.byref(g)))
+    if not ok:
+        return False
+    # the accumulator's MEMORY is kept through an alias with its own TensorImpl: for a 1x1 conv it IS the gradient tensor handed to
+    # autograd, and a second reference to that object would make AccumulateGrad clone the (still empty) gradient
+    keep = torch.empty(0, dtype=acc.dtype, device=acc.device).set_(acc.untyped_storage(), acc.storage_offset(), acc.shape, acc.stride())
+    _pending_wgrads.append((x, dy, keep, g, torch.cuda.current_stream()))
+    return True
+
+
+def drop_pending():
+    """Forget the deferred launches of a step that was abandoned (a failed hipGraph capture): their tensors are gone."""
+    _pending_wgrads.clear()
+    _pending_unpacks.clear()
+    for B in (_wgrad_bufs, _unpack_bufs):
+        B["ev"] = None
+
+
+def flush_wgrads():
+    """Run every deferred weight gradient in one launch per kernel variant on the current stream (before flush_unpacks)."""
+    if not _pending_wgrads:
+        return
+    items = list(_pending_wgrads)
+    _pending_wgrads.clear()
+    cur = torch.cuda.current_stream()
+    seen = {cur.cuda_stream}
+    for it in items:
+        if it[4].cuda_stream not in seen:
+            seen.add(it[4].cuda_stream)
+            cur.wait_stream(it[4])
+    n = len(items)
+    arr = (L.NppWgradItem * n)()
+    for i, (x, dy, acc, g, _st) in enumerate(items):
+        arr[i].x, arr[i].dy, arr[i].dw_packed, arr[i].g = desc(x), desc(dy), acc.data_ptr(), g
+    nb = int(lib().npp_conv_wgrad_batched_ws(n))
+    capturing = torch.cuda.is_current_stream_capturing()
+    B = _wgrad_bufs
+    if capturing:
+        if B["pin"] is None or B["pin"].numel() < nb:      # no warm-up step sized the tables: one launch each
+            for (x, dy, acc, g, _st) in items:
+                check(lib().npp_conv_wgrad(_byref(x), _byref(dy), acc.data_ptr(), C.byref(g), stream_ptr()), "npp_conv_wgrad")
+            return
+        pin, dev = B["pin"], B["dev"]
+        B["keep"].append((pin, dev))            # the replayed graph re-reads this pinned image: retire it
+        B["pin"] = B["dev"] = B["ev"] = None
+    elif B["pin"] is None or B["pin"].numel() < nb:
+        pin = torch.empty(max(nb, 1 << 16), dtype=torch.uint8).pin_memory()
+        dev = torch.empty(pin.numel(), dtype=torch.uint8, device=items[0][0].device)
+        B["pin"], B["dev"], B["ev"] = pin, dev, None
+    else:
+        pin, dev = B["pin"], B["dev"]
+        if B["ev"] is not None:
+            B["ev"].synchronize()               # the previous step's upload has read the pinned image
+    check(lib().npp_conv_wgrad_batched(C.cast(arr, C.c_void_p), n, pin.data_ptr(), dev.data_ptr(), pin.numel(), stream_ptr()),
+          "npp_conv_wgrad_batched")
+    if not capturing:
+        B["ev"] = torch.cuda.Event()
+        B["ev"].record()
+    for it in items:
+        if it[4].cuda_stream != cur.cuda_stream:
+            it[0].record_stream(cur)
+            it[1].record_stream(cur)
+            it[2].record_stream(cur)
+
+
 _unpack_bufs = {"pin": None, "dev": None, "ev": None, "keep": []}
 
 
@@ -838,7 +919,9 @@ class _Conv2d(Function):
                 dw = grad_out(weight, zero=True)            # the parameter's (zeroed) slot in its gradient bucket, or
                 if dw is None:
                     dw = zeros_f32(weight.numel(), x.device, own=True).view(weight.shape)     # pre-zeroed pool slice: no fill launch
-                check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
+                wkey = (tuple(x.shape), L.nhwc_ld(x), co, L.nhwc_ld(dy), kh, kw, stride, pad, dil, x.dtype)
+                if not _defer_wgrad(x, dy, dw, g, wkey):
+                    check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
             else:
                 dw = grad_out(weight)
                 if dw is None:
@@ -853,7 +936,8 @@ class _Conv2d(Function):
                     _unpack_or_defer(slabs, dw, co, ci, kh, kw, nsl, s)
                 else:
                     dwp = zeros_f32(nel, x.device)
-                    check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
+                    if not (DEFER_UNPACK and _defer_wgrad(x, dy, dwp, g, wkey)):      # (its unpack must be deferred behind it)
+                        check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
                     _unpack_or_defer(dwp, dw, co, ci, kh, kw, 0, s)
             if SHAPE_LOG is not None:
                 SHAPE_LOG.append(("wgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))

@@ -19,6 +19,7 @@
 //
 // Replaces the weight-gradient half of nn.Conv2d backward for every call site listed in conv_igemm.hip.
 #include "common.h"
+#include <vector>
 #include "conv_wgrad_params.h"
 #include <stdlib.h>
 
@@ -309,6 +310,56 @@ extern "C" int npp_unpack_wgrad_sum(const float* slabs, int nslabs, int cout, in
   const int cp = round_up(cin, 8), taps = kh * kw, kpad = round_up(taps * cp, 64);
   unpack_wgrad_sum_launch(slabs, nslabs, (long)cout * kpad, dw_oihw, cout, cin, taps, cp, kpad, (hipStream_t)stream);
   return npp_check_launch("unpack_wgrad_sum");
+}
+
+// ---- many small weight gradients in one launch (include/npp_hip.h) ------------------------------------------------------------
+static const int WGB_MAX_BLOCKS = 64;        // blocks one job may take in a batched launch (its share of the chip)
+
+extern "C" int npp_conv_wgrad_batchable(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g) {
+  if (!x || !dy || !g || !x->ptr || !dy->ptr) return 0;
+  WgradParams p;
+  float dummy;
+  if (wgrad_setup(x, dy, &dummy, g, p) != NPP_OK) return 0;
+  alignas(16) unsigned char job[512];
+  if (conv_wgrad_g4_job_bytes() > sizeof(job)) return 0;
+  int variant = 0, nblocks = 0;
+  return conv_wgrad_g4_batch_prepare(p, x->dtype, job, 0, WGB_MAX_BLOCKS, &variant, &nblocks) ? 1 : 0;
+}
+
+extern "C" int64_t npp_conv_wgrad_batched_ws(int n) {
+  if (n <= 0) return 0;
+  const int64_t jobs = ((int64_t)n * (int64_t)conv_wgrad_g4_job_bytes() + 255) / 256 * 256;
+  return jobs + (int64_t)n * WGB_MAX_BLOCKS * 4;
+}
+
+extern "C" int npp_conv_wgrad_batched(const NppWgradItem* items, int n, void* host_pinned, void* dev, int64_t ws_bytes, void* stream) {
+  NPP_REQUIRE(items && n > 0 && host_pinned && dev, NPP_E_NULL, "npp_conv_wgrad_batched: null pointer");
+  NPP_REQUIRE(ws_bytes >= npp_conv_wgrad_batched_ws(n), NPP_E_SHAPE, "npp_conv_wgrad_batched: scratch too small (%ld < %ld)",
+              (long)ws_bytes, (long)npp_conv_wgrad_batched_ws(n));
+  const int64_t jobs_bytes = ((int64_t)n * (int64_t)conv_wgrad_g4_job_bytes() + 255) / 256 * 256;
+  std::vector<int> variant(n), blocks(n);
+  double flops = 0.0, bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const NppWgradItem& it = items[i];
+    WgradParams p;
+    const int rc = wgrad_setup(&it.x, &it.dy, it.dw_packed, &it.g, p);
+    if (rc != NPP_OK) return rc;
+    if (!conv_wgrad_g4_batch_prepare(p, it.x.dtype, host_pinned, i, WGB_MAX_BLOCKS, &variant[i], &blocks[i])) {
+      npp_set_error("npp_conv_wgrad_batched: item %d is not a shape of the batched kernel (ask npp_conv_wgrad_batchable first)", i);
+      return NPP_E_UNSUPPORTED;
+    }
+    flops += 2.0 * (double)p.P * p.Cout * (double)p.taps * p.Cin;
+    bytes += ((double)it.x.n * it.x.h * it.x.w * it.x.c + (double)p.P * it.dy.c) * esize(it.x.dtype);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(NPP_FAM_CONV_WGRAD, items[0].x.dtype, s, flops, bytes);
+  if (!conv_wgrad_g4_batch_launch(host_pinned, dev, n, reinterpret_cast<int*>(static_cast<char*>(host_pinned) + jobs_bytes),
+                                  reinterpret_cast<const int*>(static_cast<const char*>(dev) + jobs_bytes), variant.data(), blocks.data(), s)) {
+    prof.cancel();
+    npp_set_error("npp_conv_wgrad_batched: upload / launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return NPP_E_HIP;
+  }
+  return npp_check_launch("conv_wgrad_batched");
 }
 
 extern "C" int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw_packed, const NppConvGeom* g,

@@ -39,7 +39,7 @@ struct WG4Extra {
 // CU) when it has not.  Measured: no difference on any shape of the network (the K-tile time is set by the 8 DMA issues per wave,
 // not by their latency); kept because it costs nothing.
 template <bool RELU, bool TAPS, int R>
-__global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Extra e) {
+NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
   constexpr int KT = 32768;            // bytes per K-tile buffer: dy [64 px][256 B] then x [64 px][256 B]
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63;
@@ -53,7 +53,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Ex
   // that XCD's CONTIGUOUS range of the (split-major, tile-minor) work list: the 9 taps of a split run side by side on one
   // XCD.  (Before: grid (tiles, splits), neighbours in x on 8 different XCDs -- rocprofv3 FETCH_SIZE showed 3.5x the
   // algorithmic bytes per launch on 128->128 3x3 @96^2, every XCD fetching every operand row.)
-  const int bid = blockIdx.x;
   const int xcd = bid & 7, qd = e.nblocks >> 3, rm = e.nblocks & 7;
   const int work = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
   const int split = work / e.ntiles, tile = work - split * e.ntiles;
@@ -207,6 +206,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Ex
       }
 }
 
+template <bool RELU, bool TAPS, int R>
+__global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Extra e) {
+  wg4_body<RELU, TAPS, R>(p, e, (int)blockIdx.x);
+}
+
+// Many small weight-gradient problems in ONE launch (npp_conv_wgrad_batched): block b works on job block_job[b] with the block id it
+// would have had in that job's own launch.  The small-map layers (12^2 / 24^2: ~100 blocks and ~25 us of latency each, 140 of them
+// per step) have no reader before the optimizer; run together at the end of backward they are throughput-, not latency-bound.
+struct WG4Job {
+  WgradParams p;
+  WG4Extra e;
+  int first_block, _pad;
+};
+
+template <bool RELU, bool TAPS, int R>
+__global__ __launch_bounds__(256) void conv_wgrad_g4_batched_kernel(const WG4Job* __restrict__ jobs, const int* __restrict__ block_job) {
+  const int j = __builtin_amdgcn_readfirstlane(block_job[blockIdx.x]);
+  const WG4Job* jb = jobs + j;
+  const WgradParams p = jb->p;
+  const WG4Extra e = jb->e;
+  wg4_body<RELU, TAPS, R>(p, e, (int)blockIdx.x - jb->first_block);
+}
+
 bool wg4_raise_lds(const void* fp, size_t bytes) {
   static thread_local const void* done[16];
   for (int i = 0; i < 16; ++i)
@@ -219,7 +241,9 @@ bool wg4_raise_lds(const void* fp, size_t bytes) {
 
 }  // namespace
 
-bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
+// Eligibility + the derived parameters of one problem.  max_blocks: the slots this problem may fill (512 = the whole chip for a
+// launch of its own; a batched launch gives each job a share).  false = the shape stays with the generic kernel.
+static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradParams& q, WG4Extra& e, int& nblocks) {
   static const bool disabled = getenv("NPP_DISABLE_WG4") != nullptr;
   if (disabled || dtype != NPP_BF16) return false;
   if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1) return false;
@@ -236,13 +260,12 @@ bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   if (!all && ((p.Cout <= 64 && p.taps > 1) || (p.Cout == 32 && p.Cin >= 128))) return false;
   if ((long)p.P * p.ldx * 2 >= (1L << 32) - (1L << 24) || (long)p.P * p.ldy * 2 >= (1L << 32) - (1L << 24)) return false;
   if (p.H >= 16384 || p.W >= 16384) return false;
-  WG4Extra e;
   e.P = P; e.HW = p.H * p.W;
   e.coltiles = (p.taps * p.Cin + 127) / 128;
   e.nktiles = (p.P + 63) / 64;
   e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
   e.dybytes = (unsigned)((long)p.P * p.ldy * 2);
-  WgradParams q = p;
+  q = p;
   q.rowtiles = (p.Cout + 127) / 128;
   const int tiles = q.rowtiles * e.coltiles;
   // Pixel splits.  Two blocks fit a CU (512 slots): never more blocks than slots (513 blocks = a second, empty round: 104 vs
@@ -255,12 +278,23 @@ bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   int splits = 1;
   while ((long)(splits + 1) * (splits + 1) * tiles <= 10L * e.nktiles) ++splits;
   if (force_blocks > 0) splits = (force_blocks + tiles - 1) / tiles;
-  if (splits > 512 / tiles) splits = 512 / tiles;
+  if (splits > max_blocks / tiles) splits = max_blocks / tiles;
   if (splits < 1) splits = 1;
   if (splits > e.nktiles) splits = e.nktiles;
   e.ktiles_per_split = (e.nktiles + splits - 1) / splits;
   splits = (e.nktiles + e.ktiles_per_split - 1) / e.ktiles_per_split;
   e.ntiles = tiles; e.nblocks = tiles * splits;
+  nblocks = tiles * splits;
+  return true;
+}
+
+bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
+  WgradParams q;
+  WG4Extra e;
+  int nblocks = 0;
+  if (!wg4_prepare(p, dtype, 512, q, e, nblocks)) return false;
+  const int P = e.P;
+  const int tiles = e.ntiles, splits = nblocks / tiles;
   dim3 grid(tiles * splits);
   static const int force_ring = getenv("NPP_WG4_RING") ? atoi(getenv("NPP_WG4_RING")) : 0;
   const bool deep = force_ring ? force_ring == 4 : (tiles * splits <= 256);
@@ -278,5 +312,54 @@ bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   if (deep) WG4_PICK(4); else WG4_PICK(2);
 #undef WG4_PICK
 #undef WG4_LAUNCH
+  return true;
+}
+
+// ---- batched form ------------------------------------------------------------------------------------------------------------
+// prepare: fills job slot `slot` of the host image (WG4Job array followed by the per-variant block->job maps, built by finish);
+// variant = relu_in | taps > 1 << 1.  finish lays out the maps, uploads the image and launches one kernel per variant present.
+size_t conv_wgrad_g4_job_bytes() { return sizeof(WG4Job); }
+
+bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_host, int slot, int max_blocks, int* variant, int* nblocks) {
+  WG4Job* jb = reinterpret_cast<WG4Job*>(jobs_host) + slot;
+  int nb = 0;
+  if (!wg4_prepare(p, dtype, max_blocks, jb->p, jb->e, nb) || nb > max_blocks) return false;
+  jb->first_block = 0; jb->_pad = 0;
+  *variant = (p.relu_in ? 1 : 0) | (jb->e.P > 0 ? 2 : 0);
+  *nblocks = nb;
+  return true;
+}
+
+// jobs_host / jobs_dev: n jobs; map_host / map_dev: room for the sum of all block counts; variant_of[i], blocks_of[i] from prepare
+bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, int* map_host, const int* map_dev, const int* variant_of,
+                                const int* blocks_of, hipStream_t stream) {
+  WG4Job* jobs = reinterpret_cast<WG4Job*>(jobs_host);
+  long off[5] = {0, 0, 0, 0, 0};
+  for (int v = 0; v < 4; ++v) {
+    long cnt = 0;
+    for (int i = 0; i < n; ++i)
+      if (variant_of[i] == v) {
+        jobs[i].first_block = (int)cnt;
+        for (int b = 0; b < blocks_of[i]; ++b) map_host[off[v] + cnt + b] = i;
+        cnt += blocks_of[i];
+      }
+    off[v + 1] = off[v] + cnt;
+  }
+  if (off[4] == 0) return true;
+  if (hipMemcpyAsync(const_cast<void*>(jobs_dev), jobs_host, (size_t)n * sizeof(WG4Job), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
+  if (hipMemcpyAsync(const_cast<int*>(map_dev), map_host, (size_t)off[4] * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
+  const WG4Job* jd = reinterpret_cast<const WG4Job*>(jobs_dev);
+#define WG4_BATCH(V_, RELU_, TAPS_)                                                                                                \
+  if (off[V_ + 1] > off[V_]) {                                                                                                     \
+    constexpr size_t lds = 2 * 32768;                                                                                              \
+    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g4_batched_kernel<RELU_, TAPS_, 2>), lds)) return false;            \
+    hipLaunchKernelGGL((conv_wgrad_g4_batched_kernel<RELU_, TAPS_, 2>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(256), lds, stream, \
+                       jd, map_dev + off[V_]);                                                                                     \
+  }
+  WG4_BATCH(0, false, false)
+  WG4_BATCH(1, true, false)
+  WG4_BATCH(2, false, true)
+  WG4_BATCH(3, true, true)
+#undef WG4_BATCH
   return true;
 }

@@ -16,3 +16,8 @@ struct WgradParams {
 bool conv_wgrad_tap_launch(const WgradParams& p, int dtype, hipStream_t stream);
 // LDS-DMA + transposing-read kernel for Cin % 128 == 0, Cout % 128 == 0, bf16 (conv_wgrad_g4.hip); false when not eligible
 bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream);
+// batched form of the above (npp_conv_wgrad_batched): see conv_wgrad_g4.hip
+size_t conv_wgrad_g4_job_bytes();
+bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_host, int slot, int max_blocks, int* variant, int* nblocks);
+bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, int* map_host, const int* map_dev, const int* variant_of,
+                                const int* blocks_of, hipStream_t stream);

@@ -75,10 +75,13 @@ class TrainStep:
         # no gradient exists yet (set_to_none) and nothing reads one before the optimizer: the KxK weight-gradient unpacks of
         # this backward are collected and run as one launch (a reducer's bucket hooks read gradients during backward: not then)
         K.DEFER_UNPACK = self.reducer is None and os.environ.get("NPP_DEFER_UNPACK", "1") != "0"
+        K.DEFER_WGRAD_MAX_PIX = int(os.environ.get("NPP_DEFER_WGRAD_MAX_PIX", "9300")) if K.DEFER_UNPACK else 0
         try:
             loss.backward()
         finally:
             K.DEFER_UNPACK = False
+            K.DEFER_WGRAD_MAX_PIX = 0
+        K.flush_wgrads()
         K.flush_unpacks()
         if self.reducer is not None:
             self.reducer.finish()
@@ -216,6 +219,7 @@ class TrainStep:
         if failed_here:
             K.forget_streams()         # side streams that had joined the capture stay in capture mode: use fresh ones
         K.reset_pools()
+        K.drop_pending()
         try:
             torch.cuda.synchronize()
         except Exception:      # noqa: BLE001 -- the failed capture's error may surface once more here

@@ -270,3 +270,49 @@ def test_search_step_graphed_runs_and_trains():
     assert step.weights_pass.graphed and step.alpha_pass(False).graphed
     assert np.isfinite(losses).all() and losses[-1][0] < losses[0][0]
     assert all(float((a - b).abs().max()) > 1e-3 for a, b in zip(net.arch_parameters(), before))
+
+
+def test_batched_small_weight_gradients_equal_the_immediate_ones():
+    """TrainStep collects the weight gradients of the small maps (<= NPP_DEFER_WGRAD_MAX_PIX pixels) and runs them as one
+    npp_conv_wgrad_batched launch per kernel variant before the batched unpack.  Two backward passes over ONE forward (the
+    data-gradient chain is deterministic, so both see bit-identical dy): batched == launched where they arise, up to the order of
+    the f32 sums -- and the batched launch must actually have been used."""
+    from npp_amd import _ops as K
+    from npp_amd.criterion import Criterion_par, Criterion_pose
+    from npp_amd.model_augment import Network, set_compute_dtype
+    dev = torch.device("cuda:0")
+    set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(0)
+        net = Network(_cfg(32)).to(dev).train()
+        net._auto_graph_off = True
+        cp, cq = Criterion_pose(out_len=2).to(dev), Criterion_par(out_len=2).to(dev)
+        im, lpar, lpose, _w = _batch(4, 96, 7, dev)
+        output_pose, output_par = net(im)
+        loss = (cq(output_par, lpar).unsqueeze(0) + cp(output_pose, lpose).unsqueeze(0)).mean()
+        K.DEFER_UNPACK, K.DEFER_WGRAD_MAX_PIX = True, 9300
+        try:
+            loss.backward(retain_graph=True)
+            queued = len(K._pending_wgrads)
+            K.flush_wgrads()
+            K.flush_unpacks()
+        finally:
+            K.DEFER_UNPACK, K.DEFER_WGRAD_MAX_PIX = False, 0
+        torch.cuda.synchronize()
+        batched = {k: p.grad.detach().float().clone() for k, p in net.named_parameters() if p.grad is not None}
+        net.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert queued >= 40, queued
+        worst, worst_k = 0.0, None
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                continue
+            den = float(p.grad.float().norm())
+            if den > 1e-8:
+                e = float((batched[k] - p.grad.float()).norm()) / den
+                if e > worst:
+                    worst, worst_k = e, k
+        assert worst < 1e-4, (worst, worst_k)
+    finally:
+        set_compute_dtype(torch.float32)
