@@ -17,8 +17,10 @@ consumed before the next call (they are static buffers); a second backward befor
 gradients (slower, still correct)."""
 from __future__ import annotations
 
+import gc
 import os
 import sys
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -80,11 +82,15 @@ class AutoGraph:
     """Per-Network state: call counting, capture, replay, fallback."""
 
     def __init__(self, net):
-        self.net = net
-        self.graph = None
+        self._net = weakref.ref(net)       # (no reference cycle: captured graphs must die with the network, by refcount -- a cyclic
+        self.graph = None                  #  collection that destroys a hipGraph or its pool DURING someone's capture aborts)
         self.sig = None
         self.calls = 0
         self.dead = False        # capture failed once: stay eager
+
+    @property
+    def net(self):
+        return self._net()
 
     def _signature(self, x):
         return (tuple(x.shape), x.dtype, x.device, tuple(p.requires_grad for p in self.net.parameters()))
@@ -132,6 +138,9 @@ class AutoGraph:
         origin = torch.cuda.current_stream()
         pool = torch.cuda.graph_pool_handle()
         g.fwd, g.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()          # no cyclic collection inside the capture: freeing a graph / pinned block there is an illegal call
         try:
             try:
                 # Gradients are taken w.r.t. ALIASES of the parameters made inside the capture, not the parameters themselves: a
@@ -155,9 +164,10 @@ class AutoGraph:
                 raise
             finally:
                 K.reset_pools()                    # chunks handed out during capture belong to the graphs' pool
+                if gc_was:
+                    gc.enable()
         except Exception as e:      # noqa: BLE001
             sys.stderr.write(f"[npp_amd.auto_graph] capture failed ({type(e).__name__}: {str(e)[:200]}); staying eager\n")
-            import gc
             del g
             gc.collect()
             K.forget_streams()

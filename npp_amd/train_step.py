@@ -136,7 +136,11 @@ class TrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
         origin = torch.cuda.current_stream()
-        try:
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()       # no cyclic collection inside the capture: destroying another hipGraph, its pool or a pinned block there is
+        try:               # an illegal call (and, thrown from a destructor, an abort)
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._static_loss = self._eager(*args)
                 if os.environ.get("NPP_TEST_FAIL_CAPTURE"):      # test hook: an illegal call invalidates the capture
@@ -148,6 +152,8 @@ class TrainStep:
             raise
         finally:
             K.reset_pools()        # chunks handed out during capture belong to the graph's private pool
+            if gc_was:
+                gc.enable()
         self.graph = g
         self._sig = self._signature(flat, layout)
         self._hyper = self._hyper_now()
