@@ -679,10 +679,11 @@ def _unpack_or_defer(src, dst, co, ci, kh, kw, nslabs, s):
         check(lib().npp_unpack_wgrad(src.data_ptr(), co, ci, kh, kw, dst.data_ptr(), s), "npp_unpack_wgrad")
 
 
-# Deferred, batched SMALL weight gradients (npp_conv_wgrad_batched): the 12x12 / 24x24 layers' weight gradients are ~100 blocks and
-# ~25 us of latency each (140 launches, 2.9 ms of a step's kernel time) and nobody reads them before the optimizer.  Under TrainStep
-# (no reducer) they are collected during backward -- x and dy stay alive -- and run as one launch per kernel variant before the
-# batched unpack.  Not on the two branch streams at all, and throughput- instead of latency-bound.
+# Deferred, batched weight gradients (npp_conv_wgrad_batched): nobody reads a weight gradient before the optimizer, and the small-map
+# ones (12x12 / 24x24: ~100 blocks, ~25 us of latency each) are 140 launches and 2.9 ms of a step's kernel time.  Under TrainStep (no
+# reducer) the weight gradients the LDS-DMA kernel can take are collected during backward -- x and dy stay alive, ~7 GB at batch 16 --
+# and run as one launch per kernel variant before the batched unpack: off the two branch streams, and throughput- instead of
+# latency-bound.  Measured (ms per step, same box) by pixel limit: 0 -> 50.9, 9 300 -> 49.8, 40 000 -> 49.7, 150 000 (all) -> 49.1-49.4.
 DEFER_WGRAD_MAX_PIX = 0        # > 0: defer the weight gradients of maps with at most this many pixels (TrainStep sets it)
 _pending_wgrads: list = []     # (x, dy, packed accumulator / gradient tensor, NppConvGeom, stream)
 _wgrad_batchable: dict = {}

@@ -75,7 +75,7 @@ class TrainStep:
         # no gradient exists yet (set_to_none) and nothing reads one before the optimizer: the KxK weight-gradient unpacks of
         # this backward are collected and run as one launch (a reducer's bucket hooks read gradients during backward: not then)
         K.DEFER_UNPACK = self.reducer is None and os.environ.get("NPP_DEFER_UNPACK", "1") != "0"
-        K.DEFER_WGRAD_MAX_PIX = int(os.environ.get("NPP_DEFER_WGRAD_MAX_PIX", "9300")) if K.DEFER_UNPACK else 0
+        K.DEFER_WGRAD_MAX_PIX = int(os.environ.get("NPP_DEFER_WGRAD_MAX_PIX", "150000")) if K.DEFER_UNPACK else 0
         try:
             loss.backward()
         finally:
