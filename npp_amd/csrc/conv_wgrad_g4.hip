@@ -243,7 +243,7 @@ bool wg4_raise_lds(const void* fp, size_t bytes) {
 
 // Eligibility + the derived parameters of one problem.  max_blocks: the slots this problem may fill (512 = the whole chip for a
 // launch of its own; a batched launch gives each job a share).  false = the shape stays with the generic kernel.
-static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradParams& q, WG4Extra& e, int& nblocks) {
+static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradParams& q, WG4Extra& e, int& nblocks, bool batched = false) {
   static const bool disabled = getenv("NPP_DISABLE_WG4") != nullptr;
   if (disabled || dtype != NPP_BF16) return false;
   if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1) return false;
@@ -256,8 +256,10 @@ static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradPa
   if (!cin_ok || !cout_ok || p.Cp != p.Cin || !p.vec_dy || p.ldx % 8 != 0 || p.ldy % 8 != 0) return false;
   // measured against conv_wgrad_kernel (us): 64->128 3x3 @96^2 61 vs 75, 256->64 1x1 16 vs 18, 64->64 1x1 12.5 vs 15.4, 32->32 1x1 17.5
   // vs 20; but 64->64 3x3 @48^2 28 vs 24, 32->32 3x3 @96^2 36 vs 29, 128->32 1x1 23 vs 21: the narrow-output KxK layers stay there
+  // (in a batched launch the narrow-output layers' disadvantage -- latency of a launch of their own -- is gone: NPP_WGB_NARROW=0 keeps them out)
   static const bool all = getenv("NPP_WG4_ALL") != nullptr;
-  if (!all && ((p.Cout <= 64 && p.taps > 1) || (p.Cout == 32 && p.Cin >= 128))) return false;
+  static const bool narrow_batched = !(getenv("NPP_WGB_NARROW") && atoi(getenv("NPP_WGB_NARROW")) == 0);
+  if (!all && !(batched && narrow_batched) && ((p.Cout <= 64 && p.taps > 1) || (p.Cout == 32 && p.Cin >= 128))) return false;
   if ((long)p.P * p.ldx * 2 >= (1L << 32) - (1L << 24) || (long)p.P * p.ldy * 2 >= (1L << 32) - (1L << 24)) return false;
   if (p.H >= 16384 || p.W >= 16384) return false;
   e.P = P; e.HW = p.H * p.W;
@@ -323,7 +325,7 @@ size_t conv_wgrad_g4_job_bytes() { return sizeof(WG4Job); }
 bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_host, int slot, int max_blocks, int* variant, int* nblocks) {
   WG4Job* jb = reinterpret_cast<WG4Job*>(jobs_host) + slot;
   int nb = 0;
-  if (!wg4_prepare(p, dtype, max_blocks, jb->p, jb->e, nb) || nb > max_blocks) return false;
+  if (!wg4_prepare(p, dtype, max_blocks, jb->p, jb->e, nb, true) || nb > max_blocks) return false;
   jb->first_block = 0; jb->_pad = 0;
   *variant = (p.relu_in ? 1 : 0) | (jb->e.P > 0 ? 2 : 0);
   *nblocks = nb;

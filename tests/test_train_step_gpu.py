@@ -272,8 +272,9 @@ def test_search_step_graphed_runs_and_trains():
     assert all(float((a - b).abs().max()) > 1e-3 for a, b in zip(net.arch_parameters(), before))
 
 
-def test_batched_small_weight_gradients_equal_the_immediate_ones():
-    """TrainStep collects the weight gradients of the small maps (<= NPP_DEFER_WGRAD_MAX_PIX pixels) and runs them as one
+@pytest.mark.parametrize("C,size,batch,max_pix,min_queued", [(32, 96, 4, 9300, 40), (64, 192, 2, 150000, 200)])
+def test_batched_weight_gradients_equal_the_immediate_ones(C, size, batch, max_pix, min_queued):
+    """TrainStep collects the weight gradients (of maps with <= NPP_DEFER_WGRAD_MAX_PIX pixels) and runs them as one
     npp_conv_wgrad_batched launch per kernel variant before the batched unpack.  Two backward passes over ONE forward (the
     data-gradient chain is deterministic, so both see bit-identical dy): batched == launched where they arise, up to the order of
     the f32 sums -- and the batched launch must actually have been used."""
@@ -284,13 +285,13 @@ def test_batched_small_weight_gradients_equal_the_immediate_ones():
     set_compute_dtype(torch.bfloat16)
     try:
         torch.manual_seed(0)
-        net = Network(_cfg(32)).to(dev).train()
+        net = Network(_cfg(C)).to(dev).train()
         net._auto_graph_off = True
         cp, cq = Criterion_pose(out_len=2).to(dev), Criterion_par(out_len=2).to(dev)
-        im, lpar, lpose, _w = _batch(4, 96, 7, dev)
+        im, lpar, lpose, _w = _batch(batch, size, 7, dev)
         output_pose, output_par = net(im)
         loss = (cq(output_par, lpar).unsqueeze(0) + cp(output_pose, lpose).unsqueeze(0)).mean()
-        K.DEFER_UNPACK, K.DEFER_WGRAD_MAX_PIX = True, 9300
+        K.DEFER_UNPACK, K.DEFER_WGRAD_MAX_PIX = True, max_pix
         try:
             loss.backward(retain_graph=True)
             queued = len(K._pending_wgrads)
@@ -303,16 +304,18 @@ def test_batched_small_weight_gradients_equal_the_immediate_ones():
         net.zero_grad(set_to_none=True)
         loss.backward()
         torch.cuda.synchronize()
-        assert queued >= 40, queued
+        assert queued >= min_queued, queued
         worst, worst_k = 0.0, None
+        checked = 0
         for k, p in net.named_parameters():
-            if p.grad is None:
-                continue
+            if p.grad is None or p.dim() != 4 or p.shape[1] == 1:      # dense conv weights: what the batched launch computes
+                continue                                              # (a BN bias behind a conv bias has a pure-noise gradient)
             den = float(p.grad.float().norm())
             if den > 1e-8:
+                checked += 1
                 e = float((batched[k] - p.grad.float()).norm()) / den
                 if e > worst:
                     worst, worst_k = e, k
-        assert worst < 1e-4, (worst, worst_k)
+        assert checked >= min_queued and worst < 1e-4, (checked, worst, worst_k)
     finally:
         set_compute_dtype(torch.float32)
