@@ -127,6 +127,19 @@ typedef struct NppUnpackJob {
   int64_t slab, first_block;
 } NppUnpackJob;
 int npp_unpack_wgrad_batched(const NppUnpackJob* jobs_dev, const int32_t* block_job_dev, int64_t total_blocks, void* stream);
+/* Many depthwise (3x3) weight gradients in one launch + one slab-sum launch: items must pass npp_dwconv_bwd_weight_batchable
+ * (bf16, the run kernel's geometry); dw / ws as for npp_dwconv_bwd_weight (ws of npp_dwconv_bwd_weight_ws elements, not zeroed);
+ * host_pinned / dev: scratch of npp_dwconv_bwd_weight_batched_ws(n) bytes each, as for npp_conv_wgrad_batched. */
+typedef struct NppDwWgradItem {
+  NppTensor x, dy;
+  float* dw;
+  float* ws;
+  NppConvGeom g;
+  int32_t _pad;
+} NppDwWgradItem;
+int npp_dwconv_bwd_weight_batchable(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g);
+int64_t npp_dwconv_bwd_weight_batched_ws(int n);
+int npp_dwconv_bwd_weight_batched(const NppDwWgradItem* items, int n, void* host_pinned, void* dev, int64_t ws_bytes, void* stream);
 /* Many SMALL weight gradients in one launch.  The 12x12 / 24x24 layers' weight gradients are ~100 blocks and ~25 us of latency
  * each and have no reader before the optimizer: a host that controls its own step (npp_amd.train_step.TrainStep) collects them
  * during backward and runs them together.  Items must pass npp_conv_wgrad_batchable (the LDS-DMA kernel's shapes: bf16, stride-1

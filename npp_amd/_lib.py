@@ -36,6 +36,10 @@ class NppWgradItem(C.Structure):
     _fields_ = [("x", NppTensor), ("dy", NppTensor), ("dw_packed", C.c_void_p), ("g", NppConvGeom), ("_pad", C.c_int32)]
 
 
+class NppDwWgradItem(C.Structure):
+    _fields_ = [("x", NppTensor), ("dy", NppTensor), ("dw", C.c_void_p), ("ws", C.c_void_p), ("g", NppConvGeom), ("_pad", C.c_int32)]
+
+
 class NppBnFinalizeArgs(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
                 ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("scale_shift", C.c_void_p),
@@ -132,6 +136,8 @@ _SIGS = {
     "npp_edge_weights": [_P, C.c_int64, _P, _P],
     "npp_adam_step": [_P, _P, C.c_int, _P, _P],
     "npp_conv_wgrad_batchable": [_T, _T, _G],
+    "npp_dwconv_bwd_weight_batchable": [_T, _T, _G],
+    "npp_dwconv_bwd_weight_batched": [_P, C.c_int, _P, _P, C.c_int64, _P],
     "npp_conv_wgrad_batched": [_P, C.c_int, _P, _P, C.c_int64, _P],
     "npp_comm_unique_id": [_P],
     "npp_comm_init": [_P, C.c_int, C.c_int],
@@ -143,7 +149,7 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_clear_hip_error", "npp_packed_weight_elems", "npp_pack_job_blocks", "npp_reduce_blocks",
                                  "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems",
-                                 "npp_conv_wgrad_splits", "npp_debug_nonfinite", "npp_conv_wgrad_batched_ws"])
+                                 "npp_conv_wgrad_splits", "npp_debug_nonfinite", "npp_conv_wgrad_batched_ws", "npp_dwconv_bwd_weight_batched_ws"])
 
 
 def kernel_source_hash() -> str:
@@ -188,6 +194,8 @@ def lib():
         L.npp_conv_wgrad_splits.argtypes = [_T, _T, _G]
         L.npp_reduce_blocks.restype = C.c_int
         L.npp_reduce_blocks.argtypes = [C.c_int64, C.c_int64, C.c_int]
+        L.npp_dwconv_bwd_weight_batched_ws.restype = C.c_int64
+        L.npp_dwconv_bwd_weight_batched_ws.argtypes = [C.c_int]
         L.npp_conv_wgrad_batched_ws.restype = C.c_int64
         L.npp_conv_wgrad_batched_ws.argtypes = [C.c_int]
         L.npp_debug_nonfinite.restype = C.c_int64

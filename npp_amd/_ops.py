@@ -706,16 +706,95 @@ def _defer_wgrad(x, dy, acc, g, key):
     return True
 
 
+_pending_dw_wgrads: list = []      # depthwise: (x, dy, gradient alias, slab scratch, NppConvGeom, stream)
+_dw_batchable: dict = {}
+_dw_wgrad_bufs = {"pin": None, "dev": None, "ev": None, "keep": []}
+
+
+def _defer_dw_wgrad(x, dy, dw, ws, g):
+    """Depthwise twin of _defer_wgrad (npp_dwconv_bwd_weight_batched: one run launch + one slab-sum launch for all of them)."""
+    if DEFER_WGRAD_MAX_PIX <= 0 or x.dtype != torch.bfloat16 or dw.dtype != torch.float32 or not DEFER_DW_WGRAD:
+        return False
+    key = (tuple(x.shape), L.nhwc_ld(x), tuple(dy.shape), L.nhwc_ld(dy), g.kh, g.sh, g.ph, g.dh, g.relu_in)
+    ok = _dw_batchable.get(key)
+    if ok is None:
+        ok = _dw_batchable[key] = bool(lib().npp_dwconv_bwd_weight_batchable(_byref(x), _byref(dy), C.byref(g)))
+    if not ok:
+        return False
+    keep = torch.empty(0, dtype=dw.dtype, device=dw.device).set_(dw.untyped_storage(), dw.storage_offset(), dw.shape, dw.stride())
+    _pending_dw_wgrads.append((x, dy, keep, ws, g, torch.cuda.current_stream()))
+    return True
+
+
+DEFER_DW_WGRAD = os.environ.get("NPP_DEFER_DW_WGRAD", "1") != "0"
+
+
+def _table_bufs(B, nb, device, capturing):
+    """Pinned + device scratch of a batched launch's job table: (pin, dev), or None when a capture finds none sized by a warm-up step.
+    A capture retires the pair (the replayed graph re-reads the pinned image); eager steps wait for the previous upload."""
+    if capturing:
+        if B["pin"] is None or B["pin"].numel() < nb:
+            return None
+        pin, dev = B["pin"], B["dev"]
+        B["keep"].append((pin, dev))
+        B["pin"] = B["dev"] = B["ev"] = None
+        return pin, dev
+    if B["pin"] is None or B["pin"].numel() < nb:
+        pin = torch.empty(max(nb, 1 << 16), dtype=torch.uint8).pin_memory()
+        dev = torch.empty(pin.numel(), dtype=torch.uint8, device=device)
+        B["pin"], B["dev"], B["ev"] = pin, dev, None
+        return pin, dev
+    if B["ev"] is not None:
+        B["ev"].synchronize()
+    return B["pin"], B["dev"]
+
+
+def _flush_dw_wgrads():
+    if not _pending_dw_wgrads:
+        return
+    items = list(_pending_dw_wgrads)
+    _pending_dw_wgrads.clear()
+    cur = torch.cuda.current_stream()
+    seen = {cur.cuda_stream}
+    for it in items:
+        if it[5].cuda_stream not in seen:
+            seen.add(it[5].cuda_stream)
+            cur.wait_stream(it[5])
+    n = len(items)
+    capturing = torch.cuda.is_current_stream_capturing()
+    bufs = _table_bufs(_dw_wgrad_bufs, int(lib().npp_dwconv_bwd_weight_batched_ws(n)), items[0][0].device, capturing)
+    if bufs is None:
+        for (x, dy, dw, ws, g, _st) in items:
+            check(lib().npp_dwconv_bwd_weight(_byref(x), _byref(dy), dw.data_ptr(), ws.data_ptr(), C.byref(g), stream_ptr()),
+                  "npp_dwconv_bwd_weight")
+        return
+    pin, dev = bufs
+    arr = (L.NppDwWgradItem * n)()
+    for i, (x, dy, dw, ws, g, _st) in enumerate(items):
+        arr[i].x, arr[i].dy, arr[i].dw, arr[i].ws, arr[i].g = desc(x), desc(dy), dw.data_ptr(), ws.data_ptr(), g
+    check(lib().npp_dwconv_bwd_weight_batched(C.cast(arr, C.c_void_p), n, pin.data_ptr(), dev.data_ptr(), pin.numel(), stream_ptr()),
+          "npp_dwconv_bwd_weight_batched")
+    if not capturing:
+        _dw_wgrad_bufs["ev"] = torch.cuda.Event()
+        _dw_wgrad_bufs["ev"].record()
+    for it in items:
+        if it[5].cuda_stream != cur.cuda_stream:
+            for t in it[:4]:
+                t.record_stream(cur)
+
+
 def drop_pending():
     """Forget the deferred launches of a step that was abandoned (a failed hipGraph capture): their tensors are gone."""
     _pending_wgrads.clear()
+    _pending_dw_wgrads.clear()
     _pending_unpacks.clear()
-    for B in (_wgrad_bufs, _unpack_bufs):
+    for B in (_wgrad_bufs, _dw_wgrad_bufs, _unpack_bufs):
         B["ev"] = None
 
 
 def flush_wgrads():
     """Run every deferred weight gradient in one launch per kernel variant on the current stream (before flush_unpacks)."""
+    _flush_dw_wgrads()
     if not _pending_wgrads:
         return
     items = list(_pending_wgrads)
@@ -1013,8 +1092,9 @@ class _DwConv2d(Function):
                 ws = zeros_f32(nws, x.device)
             else:
                 ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-            check(lib().npp_dwconv_bwd_weight(_byref(x), _byref(dy), dw.data_ptr(), ws.data_ptr(), C.byref(g), s),
-                  "npp_dwconv_bwd_weight")
+            if not _defer_dw_wgrad(x, dy, dw, ws, g):
+                check(lib().npp_dwconv_bwd_weight(_byref(x), _byref(dy), dw.data_ptr(), ws.data_ptr(), C.byref(g), s),
+                      "npp_dwconv_bwd_weight")
             if dw.dtype != weight.dtype:
                 dw = dw.to(weight.dtype)
         return dx, dw, None, None, None, None

@@ -81,11 +81,11 @@ NPP_DEV u32x4 mask8_expand(unsigned b) {
 // overlapping rows (3x3 windows, bilinear taps, dilated depthwise taps) wants neighbours on ONE XCD, or every XCD fetches
 // the shared rows from HBM for itself: virtual block id = the (blockIdx.x >> 3)-th block of XCD (blockIdx.x & 7)'s contiguous
 // share of the grid.  A bijection on [0, gridDim.x) for any grid size.
-NPP_DEV unsigned xcd_block() {
-  const unsigned g = gridDim.x, b = blockIdx.x;
+NPP_DEV unsigned xcd_block_of(const unsigned b, const unsigned g) {
   const unsigned q = g >> 3, r = g & 7, x = b & 7, j = b >> 3;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
 }
+NPP_DEV unsigned xcd_block() { return xcd_block_of(blockIdx.x, gridDim.x); }
 
 NPP_DEV float wave_sum(float v) {
 #pragma unroll

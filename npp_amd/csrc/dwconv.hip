@@ -338,8 +338,8 @@ __global__ __launch_bounds__(256) void dw3_run_fwd_kernel(const T* __restrict__ 
 // weight gradient over the same runs: acc[kh][kw] += dy * window[kh][kw]; the block folds its threads' sums into an LDS
 // [C][9] image (LDS float atomics) and writes ONE private slab (no global atomics, no zero-init); sum_slabs adds them.
 template <typename T, int V>
-__global__ __launch_bounds__(256) void dw3_run_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                            float* __restrict__ slabs, RunGeom g) {
+NPP_DEV void dw3_run_wgrad_body(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ slabs, const RunGeom& g,
+                                const unsigned bid, const unsigned nblk) {
   // LDS: 4 per-wave images [tap*V + j][cv] (plain stores after an in-wave shuffle reduction; same-address LDS float
   // atomics from the 4..16 lanes that share a channel vector cost 3x the whole main loop)
   extern __shared__ float sdw[];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void dw3_run_wgrad_kernel(const T* __restrict_
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[t][j] = 0.f;
   const unsigned total = (unsigned)g.N * g.OH * g.delta * g.nseg * g.cv;
-  for (unsigned gi = xcd_block() * 256 + threadIdx.x; gi < total; gi += gridDim.x * 256) {
+  for (unsigned gi = xcd_block_of(bid, nblk) * 256 + threadIdx.x; gi < total; gi += nblk * 256) {
     const RunIdx r = run_decode(gi, g);
     const int c0 = r.cg * V;
     const T* rows[3];
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void dw3_run_wgrad_kernel(const T* __restrict_
   // threads of a block keep their channel vector over the grid-stride loop (256 and the grid stride are multiples of
   // cv, a power of two -- the host checks), so one reduction at the end is enough
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cg = (int)((blockIdx.x * 256 + threadIdx.x) % (unsigned)g.cv);
+  const int cg = (int)((bid * 256 + threadIdx.x) % (unsigned)g.cv);
   for (int o = g.cv; o < 64; o <<= 1) {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -418,12 +418,48 @@ __global__ __launch_bounds__(256) void dw3_run_wgrad_kernel(const T* __restrict_
       for (int j = 0; j < V; ++j) mine[(t * V + j) * g.cv + cg] += acc[t][j];
   }
   __syncthreads();
-  float* slab = slabs + (long)blockIdx.x * img;
+  float* slab = slabs + (long)bid * img;
   for (int i = threadIdx.x; i < img; i += 256) {
     const int tj = i / g.cv, c_g = i - tj * g.cv;
     const int t = tj / V, j = tj - t * V;
     slab[(c_g * V + j) * 9 + t] = sdw[i] + sdw[img + i] + sdw[2 * img + i] + sdw[3 * img + i];
   }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dw3_run_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            float* __restrict__ slabs, RunGeom g) {
+  dw3_run_wgrad_body<T, V>(x, dy, slabs, g, blockIdx.x, gridDim.x);
+}
+
+// Many depthwise weight gradients in one launch (npp_dwconv_bwd_weight_batched): nobody reads them before the optimizer, and each
+// is a ~20 us launch plus a slab-sum launch of its own (46 + 46 per step).
+struct DwWgradJob {
+  const void* x; const void* dy; float* slabs; float* dw;
+  RunGeom g;
+  int nblk, first_block, n, first_sum_block;      // n = C * 9 (elements of dw); sum blocks = ceil(n * 64 / 256)
+};
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dw3_run_wgrad_batched_kernel(const DwWgradJob* __restrict__ jobs, const int* __restrict__ block_job) {
+  const int j = __builtin_amdgcn_readfirstlane(block_job[blockIdx.x]);
+  const DwWgradJob* jb = jobs + j;
+  const RunGeom g = jb->g;
+  dw3_run_wgrad_body<T, V>((const T*)jb->x, (const T*)jb->dy, jb->slabs, g, blockIdx.x - (unsigned)jb->first_block, (unsigned)jb->nblk);
+}
+
+__global__ void sum_slabs_batched_kernel(const DwWgradJob* __restrict__ jobs, const int* __restrict__ block_job) {
+  const int j = block_job[blockIdx.x];
+  const DwWgradJob* jb = jobs + j;
+  const int gid = (blockIdx.x - jb->first_sum_block) * blockDim.x + threadIdx.x;
+  const int i = gid >> 6, lane = gid & 63;
+  const int n = jb->n, nslabs = jb->nblk;
+  const float* __restrict__ slabs = jb->slabs;
+  float s = 0.f;
+  if (i < n)
+    for (int b = lane; b < nslabs; b += 64) s += slabs[(long)b * n + i];
+  s = wave_sum(s);
+  if (i < n && lane == 0) jb->dw[i] = s;
 }
 
 // out[i] = sum over slabs: 64 lanes stride over the slabs of one element, then a wave reduction
@@ -636,4 +672,85 @@ extern "C" int npp_dwconv_bwd_weight(const NppTensor* x, const NppTensor* dy, fl
   const int n = p.C * taps;
   hipLaunchKernelGGL(sum_slabs_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, s, ws, NPP_STAT_REPLICAS, n, dw);
   return npp_check_launch("dwconv_bwd_weight");
+}
+
+// ---- many depthwise weight gradients in one launch (include/npp_hip.h) ---------------------------------------------------------
+static const int DWB_MAX_BLOCKS = 2048;      // (run_plan aims at ~768 blocks per problem)
+
+static bool dw_batch_job(const NppDwWgradItem& it, DwWgradJob& jb) {
+  const NppTensor* x = &it.x; const NppTensor* dy = &it.dy; const NppConvGeom* g = &it.g;
+  if (!x->ptr || !dy->ptr || x->dtype != NPP_BF16 || dy->dtype != NPP_BF16 || g->kh != 3 || g->kw != 3) return false;
+  DwParams p;
+  if (fill_params(p, x, dy, g, "npp_dwconv_bwd_weight_batched") != NPP_OK) return false;
+  if (!(vec_ok(x) && vec_ok(dy))) return false;
+  p.cv = p.C / 8;
+  int nb_ws = 0, nb = 0;
+  if (!wgrad_plan(dy, g, nb_ws)) return false;
+  if (!run_plan(p, jb.g, nb, 8) || nb > nb_ws) return false;
+  jb.x = x->ptr; jb.dy = dy->ptr; jb.slabs = it.ws; jb.dw = it.dw;
+  jb.nblk = nb; jb.n = p.C * 9; jb.first_block = 0; jb.first_sum_block = 0;
+  return nb <= DWB_MAX_BLOCKS && (jb.n * 64 + 255) / 256 <= 1200;
+}
+
+extern "C" int npp_dwconv_bwd_weight_batchable(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g) {
+  if (!x || !dy || !g) return 0;
+  NppDwWgradItem it;
+  it.x = *x; it.dy = *dy; it.g = *g; it.dw = nullptr; it.ws = nullptr;
+  DwWgradJob jb;
+  return dw_batch_job(it, jb) ? 1 : 0;
+}
+
+
+extern "C" int64_t npp_dwconv_bwd_weight_batched_ws(int n) {
+  if (n <= 0) return 0;
+  const int64_t jobs = ((int64_t)n * (int64_t)sizeof(DwWgradJob) + 255) / 256 * 256;
+  return jobs + (int64_t)n * (DWB_MAX_BLOCKS + 1200) * 4;      // block -> job maps of the run kernel and of the slab sums
+}
+
+extern "C" int npp_dwconv_bwd_weight_batched(const NppDwWgradItem* items, int n, void* host_pinned, void* dev, int64_t ws_bytes,
+                                             void* stream) {
+  NPP_REQUIRE(items && n > 0 && host_pinned && dev, NPP_E_NULL, "npp_dwconv_bwd_weight_batched: null pointer");
+  NPP_REQUIRE(ws_bytes >= npp_dwconv_bwd_weight_batched_ws(n), NPP_E_SHAPE, "npp_dwconv_bwd_weight_batched: scratch too small");
+  const int64_t jobs_bytes = ((int64_t)n * (int64_t)sizeof(DwWgradJob) + 255) / 256 * 256;
+  DwWgradJob* jobs = reinterpret_cast<DwWgradJob*>(host_pinned);
+  int* map = reinterpret_cast<int*>(static_cast<char*>(host_pinned) + jobs_bytes);
+  long run_blocks = 0, sum_blocks = 0;
+  size_t lds = 0;
+  double flops = 0.0, bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    NPP_REQUIRE(items[i].dw && items[i].ws, NPP_E_NULL, "npp_dwconv_bwd_weight_batched: item %d has no dw / ws", i);
+    if (!dw_batch_job(items[i], jobs[i])) {
+      npp_set_error("npp_dwconv_bwd_weight_batched: item %d is not a shape of the batched kernel", i);
+      return NPP_E_UNSUPPORTED;
+    }
+    jobs[i].first_block = (int)run_blocks;
+    run_blocks += jobs[i].nblk;
+    const size_t l = (size_t)4 * jobs[i].g.C * 9 * sizeof(float);
+    if (l > lds) lds = l;
+    flops += 2.0 * npix(&items[i].dy) * jobs[i].g.C * 9;
+    bytes += (double)(npix(&items[i].x) + npix(&items[i].dy)) * jobs[i].g.C * 2;
+  }
+  for (int i = 0; i < n; ++i)
+    for (int b = 0; b < jobs[i].nblk; ++b) map[jobs[i].first_block + b] = i;
+  int* smap = map + run_blocks;
+  for (int i = 0; i < n; ++i) {
+    const int nb = (jobs[i].n * 64 + 255) / 256;
+    jobs[i].first_sum_block = (int)sum_blocks;
+    for (int b = 0; b < nb; ++b) smap[sum_blocks + b] = i;
+    sum_blocks += nb;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)jobs_bytes + (size_t)(run_blocks + sum_blocks) * sizeof(int);
+  if (hipMemcpyAsync(dev, host_pinned, total, hipMemcpyHostToDevice, s) != hipSuccess) {
+    npp_set_error("npp_dwconv_bwd_weight_batched: upload failed");
+    return NPP_E_HIP;
+  }
+  const DwWgradJob* jd = reinterpret_cast<const DwWgradJob*>(dev);
+  const int* md = reinterpret_cast<const int*>(static_cast<const char*>(dev) + jobs_bytes);
+  ProfScope prof(NPP_FAM_DWCONV, NPP_BF16, s, flops, bytes);
+  int rc = allow_lds(dw3_run_wgrad_batched_kernel<bf16_t, 8>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((dw3_run_wgrad_batched_kernel<bf16_t, 8>), dim3((unsigned)run_blocks), dim3(256), lds, s, jd, md);
+  hipLaunchKernelGGL(sum_slabs_batched_kernel, dim3((unsigned)sum_blocks), dim3(256), 0, s, jd, md + run_blocks);
+  return npp_check_launch("dwconv_bwd_weight_batched");
 }
