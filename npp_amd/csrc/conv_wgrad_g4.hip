@@ -17,6 +17,8 @@
 #include "common.h"
 #include "conv_wgrad_params.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -337,14 +339,22 @@ bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, in
                                 const int* blocks_of, hipStream_t stream) {
   WG4Job* jobs = reinterpret_cast<WG4Job*>(jobs_host);
   long off[5] = {0, 0, 0, 0, 0};
+  // longest blocks first (blocks of one launch start in block-id order): the tail of a launch is then made of short blocks
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  static const bool lpt = !(getenv("NPP_WGB_SORT") && atoi(getenv("NPP_WGB_SORT")) == 0);
+  if (lpt)
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return jobs[a].e.ktiles_per_split > jobs[b].e.ktiles_per_split; });
   for (int v = 0; v < 4; ++v) {
     long cnt = 0;
-    for (int i = 0; i < n; ++i)
+    for (int k = 0; k < n; ++k) {
+      const int i = order[k];
       if (variant_of[i] == v) {
         jobs[i].first_block = (int)cnt;
         for (int b = 0; b < blocks_of[i]; ++b) map_host[off[v] + cnt + b] = i;
         cnt += blocks_of[i];
       }
+    }
     off[v + 1] = off[v] + cnt;
   }
   if (off[4] == 0) return true;
