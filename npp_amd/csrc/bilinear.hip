@@ -27,15 +27,17 @@ NPP_DEV void src_index(float scale, float off, int o, int in_size, int& i0, int&
   l0 = 1.f - l1;
 }
 
-template <typename T, int V>
+// MV channel vectors per thread (k = lane-in-pixel + m * tpp): the index / weight arithmetic of a pixel -- as many instructions as
+// the data movement itself at one 16-byte vector per thread (2.2 TB/s) -- is shared by MV vectors
+template <typename T, int V, int MV>
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
                                                            int N, int H, int W, int OH, int OW, int cv, float sh, float sw, float off) {
-  const long total = (long)N * OH * OW * cv;
-  const FastDiv fd((unsigned)cv);
+  const int tpp = cv / MV;
+  const long total = (long)N * OH * OW * tpp;
+  const FastDiv fd((unsigned)tpp);
   for (unsigned i = VBLOCK * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned p, pr_;
     fast_divmod(i, fd, p, pr_);
-    const int c0 = (int)pr_ * V;
     const int ow = (int)(p % OW);
     const long t2 = p / OW;
     const int oh = (int)(t2 % OH), n = (int)(t2 / OH);
@@ -43,16 +45,26 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__
     float lh0, lh1, lw0, lw1;
     src_index(sh, off, oh, H, h0, hp, lh0, lh1);
     src_index(sw, off, ow, W, w0, wp, lw0, lw1);
-    const T* b = x + ((long)(n * H + h0) * W + w0) * ldx + c0;
-    float v00[V], v01[V], v10[V], v11[V], o[V];
-    ldv<T, V>(b, v00);
-    ldv<T, V>(b + (long)wp * ldx, v01);
-    ldv<T, V>(b + (long)hp * W * ldx, v10);
-    ldv<T, V>(b + ((long)hp * W + wp) * ldx, v11);
+    const float w00 = lh0 * lw0, w01 = lh0 * lw1, w10 = lh1 * lw0, w11 = lh1 * lw1;
+    const T* b0 = x + ((long)(n * H + h0) * W + w0) * ldx;
+    const long o01 = (long)wp * ldx, o10 = (long)hp * W * ldx, o11 = ((long)hp * W + wp) * ldx;
+    float v00[MV][V], v01[MV][V], v10[MV][V], v11[MV][V];
 #pragma unroll
-    for (int j = 0; j < V; ++j)
-      o[j] = lh0 * (lw0 * v00[j] + lw1 * v01[j]) + lh1 * (lw0 * v10[j] + lw1 * v11[j]);
-    stv<T, V>(y + p * ldy + c0, o);
+    for (int m = 0; m < MV; ++m) {
+      const T* b = b0 + ((int)pr_ + m * tpp) * V;
+      ldv<T, V>(b, v00[m]);
+      ldv<T, V>(b + o01, v01[m]);
+      ldv<T, V>(b + o10, v10[m]);
+      ldv<T, V>(b + o11, v11[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < MV; ++m) {
+      float o[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = lh0 * (lw0 * v00[m][j] + lw1 * v01[m][j]) + lh1 * (lw0 * v10[m][j] + lw1 * v11[m][j]);
+      stv<T, V>(y + p * ldy + ((int)pr_ + m * tpp) * V, o);
+    }
+    (void)w00; (void)w01; (void)w10; (void)w11;
   }
 }
 
@@ -78,48 +90,62 @@ NPP_DEV float contrib_weight(float scale, float off, int o, int i, int in_size) 
   return w;
 }
 
-template <typename T, int V>
+template <typename T, int V, int MV>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ dy, long ldy, T* __restrict__ dx, long ldx,
                                                            int N, int H, int W, int OH, int OW, int cv, float sh, float sw, float off) {
-  const long total = (long)N * H * W * cv;
-  const FastDiv fd((unsigned)cv);
+  const int tpp = cv / MV;
+  const long total = (long)N * H * W * tpp;
+  const FastDiv fd((unsigned)tpp);
   for (unsigned i = VBLOCK * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
     unsigned p, pr_;
     fast_divmod(i, fd, p, pr_);
-    const int c0 = (int)pr_ * V;
     const int iw = (int)(p % W);
     const long t2 = p / W;
     const int ih = (int)(t2 % H), n = (int)(t2 / H);
     int hlo, hhi, wlo, whi;
     contrib_range(sh, off, ih, OH, hlo, hhi);
     contrib_range(sw, off, iw, OW, wlo, whi);
-    float acc[V];
+    float acc[MV][V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) acc[j] = 0.f;
-    // four output columns per step, loads first and unconditional (a column past the range re-reads the last one with
+    for (int m = 0; m < MV; ++m)
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[m][j] = 0.f;
+    // COLS output columns per step, loads first and unconditional (a column past the range re-reads the last one with
     // weight 0): a load behind `if (weight != 0)` is serialised by the compiler (one load in flight per lane)
     for (int oh = hlo; oh <= hhi; ++oh) {
       const float wh = contrib_weight(sh, off, oh, ih, H);
-      const T* row = dy + ((long)(n * OH + oh) * OW) * ldy + c0;
-      for (int ow = wlo; ow <= whi; ow += 4) {
-        float d[4][V], w4[4];
+      const T* row = dy + ((long)(n * OH + oh) * OW) * ldy + (int)pr_ * V;
+      constexpr int COLS = MV >= 4 ? 2 : 4;      // output columns per step: 8 loads in flight per lane either way (4 at MV = 1)
+      for (int ow = wlo; ow <= whi; ow += COLS) {
+        float d[COLS][MV][V], w2[COLS];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < COLS; ++u) {
           const int o = ow + u <= whi ? ow + u : whi;
-          w4[u] = (ow + u <= whi) ? wh * contrib_weight(sw, off, o, iw, W) : 0.f;
-          ldv<T, V>(row + (long)o * ldy, d[u]);
+          w2[u] = (ow + u <= whi) ? wh * contrib_weight(sw, off, o, iw, W) : 0.f;
+#pragma unroll
+          for (int m = 0; m < MV; ++m) ldv<T, V>(row + (long)o * ldy + m * tpp * V, d[u][m]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < COLS; ++u)
 #pragma unroll
-          for (int j = 0; j < V; ++j) acc[j] += w4[u] * d[u][j];
+          for (int m = 0; m < MV; ++m)
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[m][j] += w2[u] * d[u][m][j];
       }
     }
-    stv<T, V>(dx + p * ldx + c0, acc);
+#pragma unroll
+    for (int m = 0; m < MV; ++m) stv<T, V>(dx + p * ldx + ((int)pr_ + m * tpp) * V, acc[m]);
   }
 }
 
 }  // namespace
+
+#define BIL_F(MV_) hipLaunchKernelGGL((bilinear_fwd_kernel<T, V, MV_>), dim3(grid_for(npix(y) * (cv / MV_))), dim3(256), 0, s, (const T*)x->ptr, \
+                       (long)x->ld, (T*)y->ptr, (long)y->ld, (int)x->n, (int)x->h, (int)x->w, (int)y->h, (int)y->w, cv,             \
+                       rs_scale(x->h, y->h, align_corners), rs_scale(x->w, y->w, align_corners), align_corners ? 0.f : 0.5f)
+#define BIL_B(MV_) hipLaunchKernelGGL((bilinear_bwd_kernel<T, V, MV_>), dim3(grid_for(npix(dx) * (cv / MV_))), dim3(256), 0, s, (const T*)dy->ptr, \
+                       (long)dy->ld, (T*)dx->ptr, (long)dx->ld, (int)dx->n, (int)dx->h, (int)dx->w, (int)dy->h, (int)dy->w,          \
+                       cv, rs_scale(dx->h, dy->h, align_corners), rs_scale(dx->w, dy->w, align_corners), align_corners ? 0.f : 0.5f)
 
 static inline float rs_scale(long in_size, long out_size, int align_corners) {
   if (!align_corners) return (float)in_size / (float)out_size;
@@ -135,9 +161,8 @@ extern "C" int npp_bilinear_fwd_ac(const NppTensor* x, NppTensor* y, int align_c
   ProfScope prof(NPP_FAM_BILINEAR, x->dtype, s, 0, (double)(npix(x) + npix(y)) * x->c * esize(x->dtype));
   NPP_DISPATCH_TV(x->dtype, vk, {
     const int cv = (int)(x->c / V);
-    hipLaunchKernelGGL((bilinear_fwd_kernel<T, V>), dim3(grid_for(npix(y) * cv)), dim3(256), 0, s, (const T*)x->ptr,
-                       (long)x->ld, (T*)y->ptr, (long)y->ld, (int)x->n, (int)x->h, (int)x->w, (int)y->h, (int)y->w, cv,
-                       rs_scale(x->h, y->h, align_corners), rs_scale(x->w, y->w, align_corners), align_corners ? 0.f : 0.5f);
+    if (V > 1 && cv % 4 == 0 && npix(y) * (cv / 4) >= 65536) BIL_F(4); else if (V > 1 && cv % 2 == 0 && npix(y) * (cv / 2) >= 65536) BIL_F(2); else BIL_F(1);
+
   });
   return npp_check_launch("bilinear_fwd");
 }
@@ -153,10 +178,8 @@ extern "C" int npp_bilinear_bwd_ac(const NppTensor* dy, NppTensor* dx, int align
   ProfScope prof(NPP_FAM_BILINEAR, dy->dtype, s, 0, (double)(npix(dx) + npix(dy)) * dx->c * esize(dx->dtype));
   NPP_DISPATCH_TV(dy->dtype, vk, {
     const int cv = (int)(dx->c / V);
-    hipLaunchKernelGGL((bilinear_bwd_kernel<T, V>), dim3(grid_for(npix(dx) * cv)), dim3(256), 0, s, (const T*)dy->ptr,
-                       (long)dy->ld, (T*)dx->ptr, (long)dx->ld, (int)dx->n, (int)dx->h, (int)dx->w, (int)dy->h, (int)dy->w,
-                       cv, rs_scale(dx->h, dy->h, align_corners), rs_scale(dx->w, dy->w, align_corners),
-                       align_corners ? 0.f : 0.5f);
+    if (V > 1 && cv % 4 == 0 && npix(dx) * (cv / 4) >= 131072) BIL_B(4); else if (V > 1 && cv % 2 == 0 && npix(dx) * (cv / 2) >= 131072) BIL_B(2); else BIL_B(1);
+
   });
   return npp_check_launch("bilinear_bwd");
 }
