@@ -263,6 +263,10 @@ int npp_se_bwd_apply(const NppTensor* dout, const float* gate, const float* dpoo
  *      nn.UpsamplingBilinear2d, operations.py:242 ----------------------------------------------- */
 int npp_bilinear_fwd(const NppTensor* x, NppTensor* y, void* stream);
 int npp_bilinear_bwd(const NppTensor* dy, NppTensor* dx, void* stream);
+/* the same with caller-owned scratch: for up-sampling ratios >= 3 in both directions the transpose runs as two 1-D passes through
+ * an f32 image [N][OH][W][C] (npp_bilinear_bwd_ws_bytes; 0 = no scratch wanted, the call then equals npp_bilinear_bwd_ac) */
+int64_t npp_bilinear_bwd_ws_bytes(const NppTensor* dy, const NppTensor* dx);
+int npp_bilinear_bwd_ws(const NppTensor* dy, NppTensor* dx, int align_corners, void* ws, int64_t ws_bytes, void* stream);
 /* the same with the align_corners flag: 0 = F.interpolate(size=, mode='bilinear') with its default align_corners=False, the
  * resample Criterion_pose applies when heat-map and target sizes differ (core/criterion.py:94-96, 113-115) */
 int npp_bilinear_fwd_ac(const NppTensor* x, NppTensor* y, int align_corners, void* stream);

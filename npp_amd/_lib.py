@@ -135,6 +135,7 @@ _SIGS = {
     "npp_ce_pixel_grad_up_t": [_T, _P, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _T, _P],
     "npp_edge_weights": [_P, C.c_int64, _P, _P],
     "npp_adam_step": [_P, _P, C.c_int, _P, _P],
+    "npp_bilinear_bwd_ws": [_T, _T, C.c_int, _P, C.c_int64, _P],
     "npp_conv_wgrad_batchable": [_T, _T, _G],
     "npp_dwconv_bwd_weight_batchable": [_T, _T, _G],
     "npp_dwconv_bwd_weight_batched": [_P, C.c_int, _P, _P, C.c_int64, _P],
@@ -149,7 +150,7 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_clear_hip_error", "npp_packed_weight_elems", "npp_pack_job_blocks", "npp_reduce_blocks",
                                  "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems",
-                                 "npp_conv_wgrad_splits", "npp_debug_nonfinite", "npp_conv_wgrad_batched_ws", "npp_dwconv_bwd_weight_batched_ws"])
+                                 "npp_conv_wgrad_splits", "npp_debug_nonfinite", "npp_conv_wgrad_batched_ws", "npp_dwconv_bwd_weight_batched_ws", "npp_bilinear_bwd_ws_bytes"])
 
 
 def kernel_source_hash() -> str:
@@ -194,6 +195,8 @@ def lib():
         L.npp_conv_wgrad_splits.argtypes = [_T, _T, _G]
         L.npp_reduce_blocks.restype = C.c_int
         L.npp_reduce_blocks.argtypes = [C.c_int64, C.c_int64, C.c_int]
+        L.npp_bilinear_bwd_ws_bytes.restype = C.c_int64
+        L.npp_bilinear_bwd_ws_bytes.argtypes = [_T, _T]
         L.npp_dwconv_bwd_weight_batched_ws.restype = C.c_int64
         L.npp_dwconv_bwd_weight_batched_ws.argtypes = [C.c_int]
         L.npp_conv_wgrad_batched_ws.restype = C.c_int64

@@ -1593,8 +1593,18 @@ class _Bilinear(Function):
         if dy.dtype != dtype:
             dy = cast(dy, dtype)
         dx = new_nhwc(*xshape, dtype, dy.device)
-        check(lib().npp_bilinear_bwd_ac(_byref(dy), _byref(dx), ac, stream_ptr()), "npp_bilinear_bwd")
+        _bilinear_bwd(dy, dx, ac)
         return dx, None, None, None
+
+
+def _bilinear_bwd(dy, dx, ac):
+    """npp_bilinear_bwd_ws: the transpose of the interpolation, as two 1-D passes through scratch when the library asks for it."""
+    nb = int(lib().npp_bilinear_bwd_ws_bytes(_byref(dy), _byref(dx)))
+    if nb:
+        ws = torch.empty(nb, dtype=torch.uint8, device=dy.device)
+        check(lib().npp_bilinear_bwd_ws(_byref(dy), _byref(dx), int(ac), ws.data_ptr(), nb, stream_ptr()), "npp_bilinear_bwd_ws")
+    else:
+        check(lib().npp_bilinear_bwd_ac(_byref(dy), _byref(dx), int(ac), stream_ptr()), "npp_bilinear_bwd")
 
 
 def bilinear(x, oh: int, ow: int, align_corners: bool = True):
@@ -1934,7 +1944,7 @@ class _UpsampledCE(Function):
                                            float(thresh), int(use_ohem), gs.data_ptr(), _byref(dup[:, :c]), s),
               "npp_ce_pixel_grad_up_t")
         dl = new_nhwc(n, cpad, h, w, logits.dtype, logits.device)
-        check(lib().npp_bilinear_bwd(_byref(dup), _byref(dl), s), "npp_bilinear_bwd")
+        _bilinear_bwd(dup, dl, 1)
         return (dl[:, :c] if cpad != c else dl), None, None, None, None
 
 

@@ -6,6 +6,7 @@
 // Replaces F.interpolate(..., mode='bilinear', align_corners=True) at model_augment.py:109-116,539-543
 // and nn.UpsamplingBilinear2d at operations.py:242-244 (ATen upsample_bilinear2d fwd/bwd).
 #include "vecio.h"
+#include <stdlib.h>
 
 #ifdef NPP_BIL_NO_XCD
 #define VBLOCK blockIdx.x
@@ -138,6 +139,59 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
   }
 }
 
+// One axis of the transpose at a time (npp_bilinear_bwd_ws): the transpose of a separable interpolation is separable.  For an
+// up-sampling ratio r the direct 2-D gather reads ~(2r)^2 candidates per input pixel, the two 1-D passes ~2r each, and the first
+// pass has r times the threads (CE gradient image 16 x 384 x 384 x 24 -> 96 x 96: 229 us direct).
+//   AXIS_W: out[row][i][c] = sum_o w(o, i) * in[row][o][c]             rows = N * OH, in pitch OW, out pitch W
+//   AXIS_H: out[n][i][x][c] = sum_o w(o, i) * in[n][o][x][c]           gathers rows W pixels apart
+// V elements of T: ldv / stv move 16 bytes (8 bf16 or 4 f32); the f32 scratch of the separable passes is accessed in groups of 8
+template <typename T, int V> NPP_DEV void ldw(const T* p, float* o) {
+  if constexpr (sizeof(T) == 4 && V == 8) { Vec16<float>::load(p, o); Vec16<float>::load(p + 4, o + 4); }
+  else ldv<T, V>(p, o);
+}
+template <typename T, int V> NPP_DEV void stw(T* p, const float* o) {
+  if constexpr (sizeof(T) == 4 && V == 8) { Vec16<float>::store(p, o); Vec16<float>::store(p + 4, o + 4); }
+  else stv<T, V>(p, o);
+}
+
+template <typename TI, typename TO, int V, bool AXIS_H>
+__global__ __launch_bounds__(256) void bilinear_bwd_1d_kernel(const TI* __restrict__ in, long ldi, TO* __restrict__ out, long ldo,
+                                                              int rows, int IN, int OUT, int inner, int cv, float scale, float off) {
+  // AXIS_W: rows = N*OH images rows, IN = OW (gathered), OUT = W, inner = 1.   AXIS_H: rows = N, IN = OH, OUT = H, inner = W.
+  const long total = (long)rows * OUT * inner * cv;
+  const FastDiv fd((unsigned)cv);
+  for (unsigned t = VBLOCK * 256 + threadIdx.x; t < (unsigned)total; t += gridDim.x * 256) {
+    unsigned p, pr_;
+    fast_divmod(t, fd, p, pr_);
+    const int c0 = (int)pr_ * V;
+    const int x = (int)(p % inner);
+    const long t2 = p / inner;
+    const int i = (int)(t2 % OUT);
+    const long row = t2 / OUT;
+    int lo, hi;
+    contrib_range(scale, off, i, IN, lo, hi);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    const TI* base = in + ((row * IN) * inner + x) * ldi + c0;
+    const long step = (long)inner * ldi;
+    for (int o = lo; o <= hi; o += 4) {
+      float d[4][V], w4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int oo = o + u <= hi ? o + u : hi;
+        w4[u] = (o + u <= hi) ? contrib_weight(scale, off, oo, i, OUT) : 0.f;
+        ldw<TI, V>(base + (long)oo * step, d[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += w4[u] * d[u][j];
+    }
+    stw<TO, V>(out + ((row * OUT + i) * inner + x) * ldo + c0, acc);
+  }
+}
+
 }  // namespace
 
 #define BIL_F(MV_) hipLaunchKernelGGL((bilinear_fwd_kernel<T, V, MV_>), dim3(grid_for(npix(y) * (cv / MV_))), dim3(256), 0, s, (const T*)x->ptr, \
@@ -182,6 +236,70 @@ extern "C" int npp_bilinear_bwd_ac(const NppTensor* dy, NppTensor* dx, int align
 
   });
   return npp_check_launch("bilinear_bwd");
+}
+
+
+// Separable form of the backward for large up-sampling ratios: scratch = f32 [N][OH][W][round_up(C, vec)] (bytes from
+// npp_bilinear_bwd_ws_bytes; 0 = the direct kernel is used and no scratch is needed).
+static bool bil_separable(const NppTensor* dy, const NppTensor* dx) {
+  static const bool off = getenv("NPP_BILINEAR_SEPARABLE") && atoi(getenv("NPP_BILINEAR_SEPARABLE")) == 0;
+  return !off && dy->h >= 3 * dx->h && dy->w >= 3 * dx->w && dx->h > 1 && dx->w > 1;
+}
+
+extern "C" int64_t npp_bilinear_bwd_ws_bytes(const NppTensor* dy, const NppTensor* dx) {
+  if (!dy || !dx || !bil_separable(dy, dx)) return 0;
+  const int vec = 4;
+  const int64_t cp = (dx->c + vec - 1) / vec * vec;
+  return (int64_t)dy->n * dy->h * dx->w * cp * 4;
+}
+
+extern "C" int npp_bilinear_bwd_ws(const NppTensor* dy, NppTensor* dx, int align_corners, void* ws, int64_t ws_bytes, void* stream) {
+  NPP_REQUIRE(dy && dx && dy->ptr && dx->ptr, NPP_E_NULL, "npp_bilinear_bwd_ws: null pointer");
+  const int64_t need = npp_bilinear_bwd_ws_bytes(dy, dx);
+  if (need == 0 || !ws || ws_bytes < need) return npp_bilinear_bwd_ac(dy, dx, align_corners, stream);
+  NPP_REQUIRE(dtype_ok(dy) && dy->dtype == dx->dtype, NPP_E_DTYPE, "npp_bilinear_bwd_ws: dtype mismatch");
+  NPP_REQUIRE(dy->n == dx->n && dy->c == dx->c, NPP_E_SHAPE, "npp_bilinear_bwd_ws: shape mismatch");
+  hipStream_t s = (hipStream_t)stream;
+  const long cp = (dx->c + 3) / 4 * 4;                 // scratch rows: f32, whole 16-byte groups
+  const float sw = rs_scale(dx->w, dy->w, align_corners), sh = rs_scale(dx->h, dy->h, align_corners);
+  const float off = align_corners ? 0.f : 0.5f;
+  float* tmp = static_cast<float*>(ws);
+  ProfScope prof(NPP_FAM_BILINEAR, dy->dtype, s, 0, (double)(npix(dx) + npix(dy)) * dx->c * esize(dx->dtype));
+  const bool vin = vec_ok(dy), vout = vec_ok(dx);
+  const int rows1 = (int)(dy->n * dy->h);
+  // pass 1: along W.  The scratch has cp channels per pixel; channels past C of a vector group are whatever the input row holds
+  // there (padding, zero by convention) and are never stored to dx
+  if (dy->dtype == NPP_BF16 && vin) {
+    const int cv = (int)(dy->c / 8);
+    // (C % 8 == 0 here: vec_ok)  two f32 groups per bf16 group: out rows have cp == C
+    hipLaunchKernelGGL((bilinear_bwd_1d_kernel<bf16_t, float, 8, false>), dim3(grid_for((long)rows1 * dx->w * cv)), dim3(256), 0, s,
+                       (const bf16_t*)dy->ptr, (long)dy->ld, tmp, cp, rows1, (int)dy->w, (int)dx->w, 1, cv, sw, off);
+  } else if (dy->dtype == NPP_BF16) {
+    hipLaunchKernelGGL((bilinear_bwd_1d_kernel<bf16_t, float, 1, false>), dim3(grid_for((long)rows1 * dx->w * dy->c)), dim3(256), 0, s,
+                       (const bf16_t*)dy->ptr, (long)dy->ld, tmp, cp, rows1, (int)dy->w, (int)dx->w, 1, (int)dy->c, sw, off);
+  } else if (vin) {
+    hipLaunchKernelGGL((bilinear_bwd_1d_kernel<float, float, 4, false>), dim3(grid_for((long)rows1 * dx->w * (dy->c / 4))), dim3(256), 0, s,
+                       (const float*)dy->ptr, (long)dy->ld, tmp, cp, rows1, (int)dy->w, (int)dx->w, 1, (int)(dy->c / 4), sw, off);
+  } else {
+    hipLaunchKernelGGL((bilinear_bwd_1d_kernel<float, float, 1, false>), dim3(grid_for((long)rows1 * dx->w * dy->c)), dim3(256), 0, s,
+                       (const float*)dy->ptr, (long)dy->ld, tmp, cp, rows1, (int)dy->w, (int)dx->w, 1, (int)dy->c, sw, off);
+  }
+  // pass 2: along H, f32 scratch -> dx
+  const int n = (int)dy->n;
+  if (dx->dtype == NPP_BF16 && vout) {
+    hipLaunchKernelGGL((bilinear_bwd_1d_kernel<float, bf16_t, 8, true>), dim3(grid_for(npix(dx) * (dx->c / 8))), dim3(256), 0, s,
+                       tmp, cp, (bf16_t*)dx->ptr, (long)dx->ld, n, (int)dy->h, (int)dx->h, (int)dx->w, (int)(dx->c / 8), sh, off);
+  } else if (dx->dtype == NPP_BF16) {
+    hipLaunchKernelGGL((bilinear_bwd_1d_kernel<float, bf16_t, 1, true>), dim3(grid_for(npix(dx) * dx->c)), dim3(256), 0, s,
+                       tmp, cp, (bf16_t*)dx->ptr, (long)dx->ld, n, (int)dy->h, (int)dx->h, (int)dx->w, (int)dx->c, sh, off);
+  } else if (vout) {
+    hipLaunchKernelGGL((bilinear_bwd_1d_kernel<float, float, 4, true>), dim3(grid_for(npix(dx) * (dx->c / 4))), dim3(256), 0, s,
+                       tmp, cp, (float*)dx->ptr, (long)dx->ld, n, (int)dy->h, (int)dx->h, (int)dx->w, (int)(dx->c / 4), sh, off);
+  } else {
+    hipLaunchKernelGGL((bilinear_bwd_1d_kernel<float, float, 1, true>), dim3(grid_for(npix(dx) * dx->c)), dim3(256), 0, s,
+                       tmp, cp, (float*)dx->ptr, (long)dx->ld, n, (int)dy->h, (int)dx->h, (int)dx->w, (int)dx->c, sh, off);
+  }
+  return npp_check_launch("bilinear_bwd(separable)");
 }
 
 extern "C" int npp_bilinear_bwd(const NppTensor* dy, NppTensor* dx, void* stream) { return npp_bilinear_bwd_ac(dy, dx, 1, stream); }

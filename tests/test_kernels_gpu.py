@@ -212,7 +212,7 @@ def test_dwconv_fwd_bwd(C, k, stride, dil, H, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("C,hin,hout", [(32, 12, 24), (256, 12, 96), (64, 24, 12), (128, 24, 6), (16, 13, 29), (512, 6, 48)])
+@pytest.mark.parametrize("C,hin,hout", [(32, 12, 24), (256, 12, 96), (64, 24, 12), (128, 24, 6), (16, 13, 29), (512, 6, 48), (20, 24, 96), (6, 7, 30)])
 def test_bilinear_fwd_bwd(C, hin, hout, dtype, tol):
     from npp_amd import _ops as K
     x_cpu = _rand((2, C, hin, hin), 8)

@@ -22,13 +22,18 @@ def timeit(fn):
         best = min(best, s.elapsed_time(e) * 1e3 / iters)
     return best
 L = lib()
-for c, lo, hi in [(128, 48, 96), (128, 24, 96), (128, 12, 96), (256, 24, 48), (256, 12, 24), (512, 12, 24), (64, 48, 96), (20, 96, 384)]:
+for c, lo, hi in [(128, 48, 96), (128, 24, 96), (128, 12, 96), (256, 24, 48), (256, 12, 24), (512, 12, 24), (64, 48, 96), (24, 96, 384)]:
     try:
         x, y = T(c, lo), T(c, hi)
         s = K.stream_ptr
         tb = timeit(lambda: check(L.npp_bilinear_bwd(K._byref(y), K._byref(x), s()), "bwd"))
+        nb = int(L.npp_bilinear_bwd_ws_bytes(K._byref(y), K._byref(x)))
+        ts = 0.0
+        if nb:
+            ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            ts = timeit(lambda: check(L.npp_bilinear_bwd_ws(K._byref(y), K._byref(x), 1, ws.data_ptr(), nb, s()), "bwds"))
         tf = timeit(lambda: check(L.npp_bilinear_fwd(K._byref(x), K._byref(y), s()), "fwd"))
         mb = (x.numel() + y.numel()) * 2 / 1e6
-        print(f"C={c:4d} {lo:3d}->{hi:3d}  {mb:7.1f} MB | bwd {tb:7.1f} us {mb / tb:5.2f} TB/s | fwd {tf:7.1f} us {mb / tf:5.2f} TB/s", flush=True)
+        print(f"C={c:4d} {lo:3d}->{hi:3d}  {mb:7.1f} MB | bwd {tb:7.1f} us {mb / tb:5.2f} TB/s | separable {ts:7.1f} us | fwd {tf:7.1f} us {mb / tf:5.2f} TB/s", flush=True)
     except Exception as e:
         print(c, lo, hi, "failed", e)
