@@ -74,7 +74,10 @@ class TrainStep:
             self.reducer.begin_step()      # the backward kernels write the gradients straight into the reducer's buckets
         # no gradient exists yet (set_to_none) and nothing reads one before the optimizer: the KxK weight-gradient unpacks of
         # this backward are collected and run as one launch (a reducer's bucket hooks read gradients during backward: not then)
-        K.DEFER_UNPACK = self.reducer is None and os.environ.get("NPP_DEFER_UNPACK", "1") != "0"
+        # (a reducer that launches its buckets from finish() -- overlap=False, NPP_DDP_OVERLAP=0 -- reads no gradient before that
+        # either: the deferred launches then write straight into its bucket slots and finish() follows them)
+        hooks_read = self.reducer is not None and getattr(self.reducer, "overlap", True)
+        K.DEFER_UNPACK = not hooks_read and os.environ.get("NPP_DEFER_UNPACK", "1") != "0"
         K.DEFER_WGRAD_MAX_PIX = int(os.environ.get("NPP_DEFER_WGRAD_MAX_PIX", "150000")) if K.DEFER_UNPACK else 0
         try:
             loss.backward()

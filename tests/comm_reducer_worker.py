@@ -18,7 +18,7 @@ import torch.distributed as dist
 from test_train_step_gpu import _batch, _cfg
 
 
-def run(transport, dev):
+def run(transport, dev, overlap=True):
     from npp_amd import _ops as K, comm
     from npp_amd.criterion import Criterion_par, Criterion_pose
     from npp_amd.ddp import GradReducer, unused_parameter_names
@@ -34,7 +34,7 @@ def run(transport, dev):
     net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(Network(_cfg(8))).to(dev).train()
     cp, cq = Criterion_pose(out_len=2).to(dev), Criterion_par(out_len=2).to(dev)
     opt = FusedAdam(list(net.parameters()) + list(cp.parameters()) + list(cq.parameters()), lr=1e-3)
-    red = GradReducer(net, skip=unused_parameter_names(net), always_reduce=True, bucket_mb=0.5)
+    red = GradReducer(net, skip=unused_parameter_names(net), always_reduce=True, bucket_mb=0.5, overlap=overlap)
     assert red._npp == (transport == "npp") and comm.active() == (transport == "npp")
     step = TrainStep(net, cp, cq, opt, reducer=red, graph=True, warmup=1)
     batch = _batch(2, 96, 5, dev)
@@ -56,6 +56,12 @@ def main():
     assert all(abs(a - b) < 5e-2 * abs(b) for a, b in zip(l_npp, l_ref)), (l_npp, l_ref)
     assert all(l == l for l in l_npp) and l_npp[-1] < l_npp[0]
     assert all(torch.isfinite(p).all() for p in p_npp)
+    # buckets launched by finish() instead of from the hooks (overlap=False): the step may then defer and batch its weight
+    # gradients, which land in the bucket slots before finish() -- same trajectory up to the order of the f32 sums
+    l_late, p_late = run("torch", dev, overlap=False)
+    assert l_late[0] == l_ref[0] and abs(l_late[1] - l_ref[1]) < 1e-4 * abs(l_ref[1]), (l_late, l_ref)
+    assert all(abs(a - b) < 5e-2 * abs(b) for a, b in zip(l_late, l_ref)), (l_late, l_ref)
+    assert all(torch.isfinite(p).all() for p in p_late)
     print("OK", l_npp)
     dist.destroy_process_group()
 

@@ -93,3 +93,14 @@ def test_training_step_on_the_library_transport():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "comm_reducer_worker.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_deferred_gradients_land_in_the_reducer_buckets():
+    """overlap=False reducer + TrainStep's deferred / batched weight gradients (tools/reducer_defer_check.py): every gradient is a
+    view of its bucket and equals a plain backward's."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "reducer_defer_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "REDUCER_DEFER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
