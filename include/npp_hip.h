@@ -232,6 +232,30 @@ int npp_bn_bwd_coeffs2(const double* sums, int nrep, double count, const float* 
                        float* dbeta_a, float* dgamma_b, float* dbeta_b, int c, void* stream);
 int npp_bn_bwd_apply2(const NppTensor* dout, const NppTensor* ya_raw, const NppTensor* yb_raw, const NppTensor* relu_out,
                       const float* coeffs_a, const float* coeffs_b, NppTensor* dya_raw, NppTensor* dyb_raw, void* stream);
+/* ---- fused forms for LOCAL train-mode BatchNorm (no statistics exchange between the producing kernel and the consumer): the
+ * per-channel arithmetic of npp_bn_finalize / npp_bn_bwd_coeffs(2) runs in the prologue of the elementwise kernel that needs its
+ * result, one launch less per BatchNorm and pass (nn.BatchNorm2d train mode, operations.py:78; ~680 launches of a 5 000-launch step).
+ * npp_bn_fused_ok(x) = 1: tensors laid out like x are taken (16-byte channel vectors, c <= 2048 bf16 / 1024 f32); the entry points
+ * return NPP_E_UNSUPPORTED without launching otherwise.
+ * npp_affine_add_fin: out = relu?( BN_a(a) [+ BN_b(b) | + b] ); fin_a (and fin_b, NULL = b as is) as for npp_bn_finalize2 --
+ *   mean_invstd, running statistics and num_batches_tracked are written, scale_shift is not.
+ * npp_bn_bwd_reduce(2)_acc: as npp_bn_bwd_reduce(2), but the nblocks blocks ADD into sums[NPP_STAT_REPLICAS][2C | 3C] (zeroed by the
+ *   caller) instead of storing nblocks slabs.
+ * npp_bn_bwd_apply(2)_fin: npp_bn_bwd_coeffs(2) + npp_bn_bwd_apply(2) over those nrep slabs; dgamma / dbeta may be NULL. */
+int npp_bn_fused_ok(const NppTensor* x);
+int npp_affine_add_fin(NppTensor* out, const NppTensor* a, const NppBnFinalizeArgs* fin_a, const NppTensor* b,
+                       const NppBnFinalizeArgs* fin_b, int relu, unsigned char* mask_bits, int64_t ld_mask, void* stream);
+int npp_bn_bwd_reduce_acc(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out, const float* mean_invstd,
+                          double* sums, int nblocks, void* stream);
+int npp_bn_bwd_reduce2_acc(const NppTensor* dout, const NppTensor* ya_raw, const NppTensor* yb_raw, const NppTensor* relu_out,
+                           const float* mean_invstd_a, const float* mean_invstd_b, double* sums, int nblocks, void* stream);
+int npp_bn_bwd_apply_fin(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out, const double* sums, int nrep,
+                         double count, const float* mean_invstd, const float* gamma, float* dgamma, float* dbeta,
+                         NppTensor* dy_raw, void* stream);
+int npp_bn_bwd_apply2_fin(const NppTensor* dout, const NppTensor* ya_raw, const NppTensor* yb_raw, const NppTensor* relu_out,
+                          const double* sums, int nrep, double count, const float* mean_invstd_a, const float* mean_invstd_b,
+                          const float* gamma_a, const float* gamma_b, float* dgamma_a, float* dbeta_a, float* dgamma_b,
+                          float* dbeta_b, NppTensor* dya_raw, NppTensor* dyb_raw, void* stream);
 /* eval-mode / plain affine backward: dy = dout * scale * (out>0) */
 int npp_scale_mask(const NppTensor* dout, const float* scale /*[C] or NULL*/, const NppTensor* relu_out,
                    NppTensor* dx, void* stream);

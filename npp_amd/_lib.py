@@ -96,6 +96,12 @@ _SIGS = {
     "npp_bn_bwd_apply2": [_T, _T, _T, _T, _P, _P, _T, _T, _P],
     "npp_bn_bwd_apply": [_T, _T, _T, _P, _T, _P],
     "npp_scale_mask": [_T, _P, _T, _T, _P],
+    "npp_bn_fused_ok": [_T],
+    "npp_affine_add_fin": [_T, _T, _P, _T, _P, C.c_int, _P, C.c_int64, _P],
+    "npp_bn_bwd_reduce_acc": [_T, _T, _T, _P, _P, C.c_int, _P],
+    "npp_bn_bwd_reduce2_acc": [_T, _T, _T, _T, _P, _P, _P, C.c_int, _P],
+    "npp_bn_bwd_apply_fin": [_T, _T, _T, _P, C.c_int, C.c_double, _P, _P, _P, _P, _T, _P],
+    "npp_bn_bwd_apply2_fin": [_T, _T, _T, _T, _P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _T, _T, _P],
     "npp_pool3x3_fwd": [_T, _T, _P, C.c_int, C.c_int, _P, _P],
     "npp_pool3x3_bwd": [_T, _P, _T, C.c_int, C.c_int, _P],
     "npp_pool2x2_fwd": [_T, _T, C.c_int, _P, _P],

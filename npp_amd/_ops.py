@@ -1245,6 +1245,34 @@ def _bn_coeffs_pair(sa: BnSide, sb: BnSide, training: bool, device):
     return _bn_coeffs(sa, training, device), _bn_coeffs(sb, training, device)
 
 
+FUSE_BN_FIN = os.environ.get("NPP_FUSE_BN_FIN", "1") != "0"
+_fused_ok_cache: dict = {}
+
+
+def _fused_layout_ok(t) -> bool:
+    key = (t.shape[1], L.nhwc_ld(t), t.dtype)
+    ok = _fused_ok_cache.get(key)
+    if ok is None:
+        ok = _fused_ok_cache[key] = bool(lib().npp_bn_fused_ok(_byref(t)))
+    return ok
+
+
+def _local_batch_bn(bn, training: bool) -> bool:
+    return bn is not None and (training or bn.running_mean is None) and _sync_group(bn)[0] is None
+
+
+def _fin_fusable(sa, sb, a, b, training: bool) -> bool:
+    """out = BN_a(a) [+ BN_b(b) | + b] with LOCAL batch statistics on every BatchNorm side, in a layout npp_affine_add_fin takes."""
+    if not FUSE_BN_FIN or not _local_batch_bn(sa.bn, training) or not _fused_layout_ok(a):
+        return False
+    if sb is not None:
+        if sb.bn is not None and (not _local_batch_bn(sb.bn, training) or sb.x.shape[1] != sa.x.shape[1]):
+            return False
+        if b is None or b.dtype != a.dtype or b.shape != a.shape or not _fused_layout_ok(b):
+            return False
+    return True
+
+
 class _BnAdd(Function):
     """out = relu?( [BN_a](a) + [BN_b](b) ).  Tensor args: a, gamma_a, beta_a, b, gamma_b, beta_b."""
 
@@ -1256,6 +1284,24 @@ class _BnAdd(Function):
         ssa = mia = ssb = mib = None
         batch_a = batch_b = False
         _presync_stats((sa, sb), training)
+        if _fin_fusable(sa, sb, a, b, training):
+            # local train-mode BatchNorm(s): the finalize arithmetic runs in the prologue of the affine_add kernel
+            pa = _bn_finalize_args(sa, training, dev)
+            pb = _bn_finalize_args(sb, training, dev) if (sb is not None and sb.bn is not None) else None
+            y = out[0] if out is not None else new_nhwc(*a.shape, a.dtype, dev)
+            rc = lib().npp_affine_add_fin(_byref(y), _byref(a), C.byref(pa[0]), tref(b), C.byref(pb[0]) if pb is not None else None,
+                                          int(relu), (mk[0].data_ptr() + mk[1]) if mk is not None else None,
+                                          mk[2] if mk is not None else 0, stream_ptr())
+            if rc == 0:
+                mia = pa[2]
+                mib = pb[2] if pb is not None else None
+                ctx.relu = relu
+                ctx.sides = (sa.bn, sb.bn if sb is not None else None, True, pb is not None, sa.count, sb.count if sb else None,
+                             b is not None)
+                ctx.save_for_backward(a, b, y if relu else None, mia, mib, None, None)
+                return y
+            if rc != -5:      # NPP_E_UNSUPPORTED: nothing was launched, the separate kernels take it
+                check(rc, "npp_affine_add_fin")
         if sa.bn is not None and sb is not None and sb.bn is not None:
             (ssa, mia, batch_a), (ssb, mib, batch_b) = _bn_coeffs_pair(sa, sb, training, dev)
         else:
@@ -1294,9 +1340,14 @@ class _BnAdd(Function):
             check(lib().npp_scale_mask(_byref(dout), None, _byref(yrelu), _byref(dx), s), "npp_scale_mask")
             return dx
 
-        def reduce_side(x, mi):
+        def reduce_side(x, mi, acc=False):
             c = x.shape[1]
             nb = lib().npp_reduce_blocks(x.shape[0] * x.shape[2] * x.shape[3], c, L.npp_dtype(x.dtype))
+            if acc:      # the blocks add into R zeroed slabs: bn_bwd_apply_fin sums them in its prologue
+                sums = zeros_f64(R * 2 * c, x.device)
+                check(lib().npp_bn_bwd_reduce_acc(_byref(dout), _byref(x), tref(yrelu), mi.data_ptr(), sums.data_ptr(), nb, s),
+                      "npp_bn_bwd_reduce_acc")
+                return sums, R
             sums = torch.empty(nb * 2 * c, dtype=torch.float64, device=x.device)   # one slab per block, written
             check(lib().npp_bn_bwd_reduce(_byref(dout), _byref(x), tref(yrelu), mi.data_ptr(), sums.data_ptr(), nb, s),
                   "npp_bn_bwd_reduce")
@@ -1310,10 +1361,16 @@ class _BnAdd(Function):
             c = a.shape[1]
             dev = a.device
             nb = lib().npp_reduce_blocks(a.shape[0] * a.shape[2] * a.shape[3], c, L.npp_dtype(a.dtype))
-            sums = torch.empty(nb * 3 * c, dtype=torch.float64, device=dev)
-            check(lib().npp_bn_bwd_reduce2(_byref(dout), _byref(a), _byref(b), tref(yrelu), mia.data_ptr(), mib.data_ptr(),
-                                           sums.data_ptr(), nb, s), "npp_bn_bwd_reduce2")
-            co = torch.empty(6 * c, dtype=torch.float32, device=dev)
+            fused = (FUSE_BN_FIN and _fused_layout_ok(a) and _fused_layout_ok(b) and _fused_layout_ok(dout)
+                     and (yrelu is None or _fused_layout_ok(yrelu)))
+            if fused:
+                sums = zeros_f64(R * 3 * c, dev)
+                check(lib().npp_bn_bwd_reduce2_acc(_byref(dout), _byref(a), _byref(b), tref(yrelu), mia.data_ptr(), mib.data_ptr(),
+                                                   sums.data_ptr(), nb, s), "npp_bn_bwd_reduce2_acc")
+            else:
+                sums = torch.empty(nb * 3 * c, dtype=torch.float64, device=dev)
+                check(lib().npp_bn_bwd_reduce2(_byref(dout), _byref(a), _byref(b), tref(yrelu), mia.data_ptr(), mib.data_ptr(),
+                                               sums.data_ptr(), nb, s), "npp_bn_bwd_reduce2")
             dgb_ = torch.empty(4 * c, dtype=torch.float32, device=dev)
             dgb_ = [dgb_[:c], dgb_[c:2 * c], dgb_[2 * c:3 * c], dgb_[3 * c:]]
             for i_, prm in enumerate((bna.weight, bna.bias, bnb.weight, bnb.bias)):
@@ -1322,6 +1379,16 @@ class _BnAdd(Function):
                     dgb_[i_] = slot
             ga = bna.weight.detach() if bna.weight is not None else None
             gb = bnb.weight.detach() if bnb.weight is not None else None
+            if fused:
+                dxa = new_nhwc(*a.shape, a.dtype, dev)
+                dxb = new_nhwc(*b.shape, b.dtype, dev)
+                check(lib().npp_bn_bwd_apply2_fin(_byref(dout), _byref(a), _byref(b), tref(yrelu), sums.data_ptr(), R, float(cnt_a),
+                                                  mia.data_ptr(), mib.data_ptr(), ptr(ga), ptr(gb), dgb_[0].data_ptr(),
+                                                  dgb_[1].data_ptr(), dgb_[2].data_ptr(), dgb_[3].data_ptr(), _byref(dxa),
+                                                  _byref(dxb), s), "npp_bn_bwd_apply2_fin")
+                return (dxa, dgb_[0] if ni[1] else None, dgb_[1] if ni[2] else None,
+                        dxb, dgb_[2] if ni[4] else None, dgb_[3] if ni[5] else None, None, None, None, None, None, None)
+            co = torch.empty(6 * c, dtype=torch.float32, device=dev)
             check(lib().npp_bn_bwd_coeffs2(sums.data_ptr(), nb, float(cnt_a), mia.data_ptr(), mib.data_ptr(), ptr(ga), ptr(gb),
                                            co[:3 * c].data_ptr(), co[3 * c:].data_ptr(), dgb_[0].data_ptr(),
                                            dgb_[1].data_ptr(), dgb_[2].data_ptr(), dgb_[3].data_ptr(), c, s),
@@ -1336,7 +1403,10 @@ class _BnAdd(Function):
         if has_b:
             sides.append((b, bnb, mib, ssb, batch_b, cnt_b, ni[3], ni[4], ni[5]))
         # phase 1: local reductions of every BN side
-        red = [reduce_side(x, mi) if bn is not None else None for (x, bn, mi, *_r) in sides]
+        lay_ok = FUSE_BN_FIN and _fused_layout_ok(dout) and (yrelu is None or _fused_layout_ok(yrelu))
+        fin = [bn is not None and batch and lay_ok and need_x and _sync_group(bn)[0] is None and _fused_layout_ok(x)
+               for (x, bn, mi, ss, batch, count, need_x, *_r) in sides]
+        red = [reduce_side(x, mi, fin[i]) if bn is not None else None for i, (x, bn, mi, *_r) in enumerate(sides)]
         # phase 2 (SyncBatchNorm): collapse each side's slabs to one vector (+ the LOCAL dgamma / dbeta, which DDP
         # averages afterwards as torch.nn.SyncBatchNorm does), then ONE all-reduce of the side(s) of this node.
         local = [None] * len(sides)
@@ -1384,6 +1454,13 @@ class _BnAdd(Function):
                     dgt = _grad_buf(bn.weight if need_g else None, c, x.device)
                     dbt = _grad_buf(bn.bias if need_b else None, c, x.device)
                     dg, db = dgt, dbt
+                if fin[i]:
+                    dx = new_nhwc(*x.shape, x.dtype, x.device)
+                    check(lib().npp_bn_bwd_apply_fin(_byref(dout), _byref(x), tref(yrelu), sums.data_ptr(), nrep, float(count),
+                                                     mi.data_ptr(), ptr(gamma), ptr(dgt), ptr(dbt), _byref(dx), s),
+                          "npp_bn_bwd_apply_fin")
+                    outs.append((dx, dg if need_g else None, db if need_b else None))
+                    continue
                 co = torch.empty(3 * c, dtype=torch.float32, device=x.device)
                 check(lib().npp_bn_bwd_coeffs(sums.data_ptr(), nrep, float(count), mi.data_ptr(), ptr(gamma), co.data_ptr(),
                                               ptr(dgt), ptr(dbt), c, s), "npp_bn_bwd_coeffs")

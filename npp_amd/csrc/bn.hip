@@ -292,11 +292,132 @@ __global__ __launch_bounds__(256) void affine_add_kernel(T* __restrict__ out, lo
   }
 }
 
+// ---- affine_add with the BatchNorm finalize in its prologue (npp_affine_add_fin) ---------------------------------------------------
+// A local (non-Sync) train-mode BatchNorm needs nothing between the kernel that produced its statistics and this one but the
+// per-channel arithmetic of bn_finalize_kernel -- ~5 us of launch for 2C numbers, 338 times per step.  Here every block sums the
+// NPP_STAT_REPLICAS slabs of the channels it covers (32 B x nrep per channel, L2 hits), derives scale / shift into LDS and goes on as
+// affine_add_kernel; block 0 also writes mean / invstd for the backward pass and updates the running statistics.  Same arithmetic as
+// bn_finalize_kernel (f64 mean / var / invstd); only the order of the replica sum differs.  FB: side b is a BatchNorm too (else plain).
+struct FinSide {
+  const double* stats; const float* gamma; const float* beta;
+  float* running_mean; float* running_var; long* nbt; float* mi;
+  double count; int nrep; float momentum, eps;
+};
+template <typename T, int V, bool HAS_B, bool FB, bool MASK>
+__global__ __launch_bounds__(256) void affine_add_fin_kernel(T* __restrict__ out, long ldo, const T* __restrict__ a, long lda,
+                                                             const T* __restrict__ b, long ldb, FinSide fa, FinSide fb, int relu,
+                                                             long npix, int C, ColMap m, unsigned char* __restrict__ mk, long ldmk) {
+  extern __shared__ float s_ss[];      // [side][scale C | shift C]
+  const int t = threadIdx.x;
+  constexpr int NS = (HAS_B && FB) ? 2 : 1;
+  // the first pixel pair of this thread is requested BEFORE the prologue: its HBM latency then overlaps the statistics' L2 round trip
+  const bool act = t < m.rows * m.cols_blk;
+  const int col = t % m.cols_blk, row = t / m.cols_blk;
+  const int colg = col;                       // one column block (the host checks cv <= 256)
+  const int c0 = colg * V;
+  const long step = (long)gridDim.x * m.rows;
+  const long last = npix - 1;
+  long p = (long)blockIdx.x * m.rows + row;
+  float va[V], vb[V], wa[V], wb[V];
+  if (act && p < npix) {
+    const long q2 = p + step < npix ? p + step : last;
+    ldv<T, V>(a + p * lda + c0, va);
+    ldv<T, V>(a + q2 * lda + c0, wa);
+    if (HAS_B) {
+      ldv<T, V>(b + p * ldb + c0, vb);
+      ldv<T, V>(b + q2 * ldb + c0, wb);
+    }
+  }
+  for (int idx = t; idx < NS * C; idx += 256) {
+    const int side = idx >= C ? 1 : 0, c = idx - side * C;
+    const FinSide& f = side ? fb : fa;
+    // all 2 x NPP_STAT_REPLICAS loads in flight before the first add (a runtime trip count makes hipcc wait for every load in turn:
+    // 32 L2 round trips in a row, slower than the launch this prologue replaces)
+    double v0[NPP_STAT_REPLICAS], v1[NPP_STAT_REPLICAS];
+#pragma unroll
+    for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { v0[r] = f.stats[(long)r * 2 * C + c]; v1[r] = f.stats[(long)r * 2 * C + C + c]; }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { s0 += v0[r]; s1 += v1[r]; }
+    const double mean = s0 / f.count;
+    double var = s1 / f.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)f.eps);
+    const float g = f.gamma ? f.gamma[c] : 1.f, bt = f.beta ? f.beta[c] : 0.f;
+    s_ss[side * 2 * C + c] = (float)(g * invstd);
+    s_ss[side * 2 * C + C + c] = (float)(bt - mean * g * invstd);
+    if (blockIdx.x == 0) {
+      if (c == 0 && f.nbt) f.nbt[0] += 1;
+      if (f.mi) { f.mi[c] = (float)mean; f.mi[C + c] = (float)invstd; }
+      if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+      if (f.running_var) {
+        const double unb = f.count > 1.0 ? var * (f.count / (f.count - 1.0)) : var;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
+      }
+    }
+  }
+  __syncthreads();
+  if (!act) return;
+  float sa[V], ta[V], sb[V], tb[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    sa[j] = s_ss[c0 + j];
+    ta[j] = s_ss[C + c0 + j];
+    sb[j] = (HAS_B && FB) ? s_ss[2 * C + c0 + j] : 1.f;
+    tb[j] = (HAS_B && FB) ? s_ss[3 * C + c0 + j] : 0.f;
+  }
+  bool first = true;
+  for (; p < npix; p += 2 * step) {
+    const long p2 = p + step;
+    const bool two = p2 < npix;
+    const long q2 = two ? p2 : last;
+    float o[V], o2[V];
+    if (!first) {
+      ldv<T, V>(a + p * lda + c0, va);
+      ldv<T, V>(a + q2 * lda + c0, wa);
+      if (HAS_B) {
+        ldv<T, V>(b + p * ldb + c0, vb);
+        ldv<T, V>(b + q2 * ldb + c0, wb);
+      }
+    }
+    first = false;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      o[j] = fmaf(va[j], sa[j], ta[j]);
+      o2[j] = fmaf(wa[j], sa[j], ta[j]);
+      if (HAS_B) {
+        o[j] += fmaf(vb[j], sb[j], tb[j]);
+        o2[j] += fmaf(wb[j], sb[j], tb[j]);
+      }
+      if (relu) { o[j] = fmaxf(o[j], 0.f); o2[j] = fmaxf(o2[j], 0.f); }
+    }
+    if constexpr (MASK) {
+      u32x4 w, w2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        w[i] = (unsigned)f2bf(o[2 * i]) | ((unsigned)f2bf(o[2 * i + 1]) << 16);
+        w2[i] = (unsigned)f2bf(o2[2 * i]) | ((unsigned)f2bf(o2[2 * i + 1]) << 16);
+      }
+      *reinterpret_cast<u32x4*>(out + p * ldo + c0) = w;
+      mk[p * ldmk + colg] = (unsigned char)pos_bits_bf16x8(w);
+      if (two) {
+        *reinterpret_cast<u32x4*>(out + p2 * ldo + c0) = w2;
+        mk[p2 * ldmk + colg] = (unsigned char)pos_bits_bf16x8(w2);
+      }
+    } else {
+      stv<T, V>(out + p * ldo + c0, o);
+      if (two) stv<T, V>(out + p2 * ldo + c0, o2);
+    }
+  }
+}
+
 #ifndef RED_U
 #define RED_U 2
 #endif
 // HAS_RO compile-time and unconditional (index-clamped) coefficient loads: see affine_add_kernel
-template <typename T, int V, bool HAS_RO>
+// ACC: the block adds its sums into slab blockIdx.x % NPP_STAT_REPLICAS of a zeroed [NPP_STAT_REPLICAS][2C] buffer (f64 atomics)
+// instead of storing a slab of its own: the few slabs are then summed by the prologue of bn_bwd_apply_fin_kernel (no coefficient launch)
+template <typename T, int V, bool HAS_RO, bool ACC = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
                                                             long ldy, const T* __restrict__ ro, long ldr,
                                                             const float* __restrict__ mi, long npix, int C, ColMap m,
@@ -355,9 +476,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       }
     }
   }
-  double* rep = sums + (long)blockIdx.x * 2 * C;      // one partial slab per blockIdx.x
+  double* rep = sums + (long)(ACC ? blockIdx.x % NPP_STAT_REPLICAS : blockIdx.x) * 2 * C;      // one partial slab per blockIdx.x
   double* outs[2] = {rep, rep + C};
-  block_col_reduce<2, V, true>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
+  block_col_reduce<2, V, !ACC>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
 }
 
 __global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums, int nrep, double inv_count, const float* __restrict__ mi,
@@ -445,7 +566,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // ---- two-sided forms: out = BN_a(a) + BN_b(b) is the common case (both edges of a cell node end in BatchNorm).  The two
 // sides share dout (and the ReLU mask), so one pass reads it once: reduce 4 -> 3 tensor reads, apply 6 -> 5 passes, and
 // half the launches.  sums: slab b = [sum d | sum d*xhat_a | sum d*xhat_b] (3C doubles).
-template <typename T, int V, bool HAS_RO>
+template <typename T, int V, bool HAS_RO, bool ACC = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ ya,
                                                              long lda, const T* __restrict__ yb, long ldb,
                                                              const T* __restrict__ ro, long ldr, const float* __restrict__ mia,
@@ -504,9 +625,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const T* __restrict
       }
     }
   }
-  double* rep = sums + (long)blockIdx.x * 3 * C;
+  double* rep = sums + (long)(ACC ? blockIdx.x % NPP_STAT_REPLICAS : blockIdx.x) * 3 * C;
   double* outs[3] = {rep, rep + C, rep + 2 * C};
-  block_col_reduce<3, V, true>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
+  block_col_reduce<3, V, !ACC>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
 }
 
 // coefficients of both sides from the 3-vector slabs (grid.y = side)
@@ -570,6 +691,166 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict_
     if (ro) {
       float r[V];
       ldv<T, V>(ro + p * ldr + c0, r);
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] = r[j] > 0.f ? d[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = fmaf(aa[j], d[j], fmaf(ab[j], va[j], ac[j]));
+    stv<T, V>(dya + p * ldoa + c0, o);
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = fmaf(ba[j], d[j], fmaf(bb[j], vb[j], bc[j]));
+    stv<T, V>(dyb + p * ldob + c0, o);
+  }
+}
+
+// ---- BatchNorm backward apply with the coefficient arithmetic of bn_bwd_coeffs(2)_kernel in the prologue (npp_bn_bwd_apply(2)_fin):
+// sums = the few slabs of the ACC reduce; every block derives the three coefficients of its channels into LDS, block 0 also writes
+// dgamma / dbeta.  One launch less per BatchNorm (pair) and backward pass.
+struct BwdFinSide {
+  const float* mi; const float* gamma; float* dgamma; float* dbeta;
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
+                                                               long ldy, const T* __restrict__ ro, long ldr,
+                                                               const double* __restrict__ sums, int nrep, double inv_count,
+                                                               BwdFinSide f, T* __restrict__ dy, long ldo, long npix, int C, ColMap m) {
+  extern __shared__ float s_co[];      // [k1 C | cb C | cc C]
+  const int t = threadIdx.x;
+  // first pixel pair requested before the prologue (see affine_add_fin_kernel)
+  const bool act = t < m.rows * m.cols_blk;
+  const int col = t % m.cols_blk, row = t / m.cols_blk;
+  const int c0 = col * V;
+  const long step = (long)gridDim.x * m.rows;
+  long p = (long)blockIdx.x * m.rows + row;
+  float d[V], v[V], d2[V], v2[V], r[V], r2[V];
+  if (act && p < npix) {
+    const long q2 = p + step < npix ? p + step : p;
+    ldv<T, V>(dout + p * ldd + c0, d);
+    ldv<T, V>(y + p * ldy + c0, v);
+    ldv<T, V>(dout + q2 * ldd + c0, d2);
+    ldv<T, V>(y + q2 * ldy + c0, v2);
+    if (ro) {
+      ldv<T, V>(ro + p * ldr + c0, r);
+      ldv<T, V>(ro + q2 * ldr + c0, r2);
+    }
+  }
+  for (int c = t; c < C; c += 256) {
+    double v0[NPP_STAT_REPLICAS], v1[NPP_STAT_REPLICAS];
+#pragma unroll
+    for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { v0[r] = sums[(long)r * 2 * C + c]; v1[r] = sums[(long)r * 2 * C + C + c]; }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { s0 += v0[r]; s1 += v1[r]; }
+    const float mean = f.mi[c], invstd = f.mi[C + c];
+    const float g = f.gamma ? f.gamma[c] : 1.f;
+    const float m0 = (float)(s0 * inv_count), m1 = (float)(s1 * inv_count);
+    const float k1 = g * invstd;
+    s_co[c] = k1;
+    s_co[C + c] = -k1 * invstd * m1;
+    s_co[2 * C + c] = k1 * (mean * invstd * m1 - m0);
+    if (blockIdx.x == 0) {
+      if (f.dgamma) f.dgamma[c] = (float)s1;
+      if (f.dbeta) f.dbeta[c] = (float)s0;
+    }
+  }
+  __syncthreads();
+  if (!act) return;
+  float ca[V], cb[V], cc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { ca[j] = s_co[c0 + j]; cb[j] = s_co[C + c0 + j]; cc[j] = s_co[2 * C + c0 + j]; }
+  bool first = true;
+  for (; p < npix; p += 2 * step) {
+    const long p2 = p + step;
+    const bool two = p2 < npix;
+    const long q2 = two ? p2 : p;          // unconditional loads of a real pixel; its store is not
+    float o[V];
+    if (!first) {
+      ldv<T, V>(dout + p * ldd + c0, d);
+      ldv<T, V>(y + p * ldy + c0, v);
+      ldv<T, V>(dout + q2 * ldd + c0, d2);
+      ldv<T, V>(y + q2 * ldy + c0, v2);
+      if (ro) {
+        ldv<T, V>(ro + p * ldr + c0, r);
+        ldv<T, V>(ro + q2 * ldr + c0, r2);
+      }
+    }
+    first = false;
+    if (ro) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) { d[j] = r[j] > 0.f ? d[j] : 0.f; d2[j] = r2[j] > 0.f ? d2[j] : 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = fmaf(ca[j], d[j], fmaf(cb[j], v[j], cc[j]));
+    stv<T, V>(dy + p * ldo + c0, o);
+    if (two) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = fmaf(ca[j], d2[j], fmaf(cb[j], v2[j], cc[j]));
+      stv<T, V>(dy + p2 * ldo + c0, o);
+    }
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply2_fin_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ ya,
+                                                                long lda, const T* __restrict__ yb, long ldb,
+                                                                const T* __restrict__ ro, long ldr, const double* __restrict__ sums,
+                                                                int nrep, double inv_count, BwdFinSide fa, BwdFinSide fb,
+                                                                T* __restrict__ dya, long ldoa, T* __restrict__ dyb, long ldob,
+                                                                long npix, int C, ColMap m) {
+  extern __shared__ float s_co[];      // side a [k1 | cb | cc], side b [k1 | cb | cc]
+  const int t = threadIdx.x;
+  const bool act = t < m.rows * m.cols_blk;
+  const int col = t % m.cols_blk, row = t / m.cols_blk;
+  const int c0 = col * V;
+  const long step = (long)gridDim.x * m.rows;
+  long p = (long)blockIdx.x * m.rows + row;
+  float d[V], va[V], vb[V], r[V];
+  if (act && p < npix) {
+    ldv<T, V>(dout + p * ldd + c0, d);
+    ldv<T, V>(ya + p * lda + c0, va);
+    ldv<T, V>(yb + p * ldb + c0, vb);
+    if (ro) ldv<T, V>(ro + p * ldr + c0, r);
+  }
+  for (int idx = t; idx < 2 * C; idx += 256) {
+    const int side = idx >= C ? 1 : 0, c = idx - side * C;
+    const BwdFinSide& f = side ? fb : fa;
+    double v0[NPP_STAT_REPLICAS], v1[NPP_STAT_REPLICAS];
+#pragma unroll
+    for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { v0[r] = sums[(long)r * 3 * C + c]; v1[r] = sums[(long)r * 3 * C + (side + 1) * C + c]; }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { s0 += v0[r]; s1 += v1[r]; }
+    const float mean = f.mi[c], invstd = f.mi[C + c];
+    const float g = f.gamma ? f.gamma[c] : 1.f;
+    const float m0 = (float)(s0 * inv_count), m1 = (float)(s1 * inv_count);
+    const float k1 = g * invstd;
+    s_co[side * 3 * C + c] = k1;
+    s_co[side * 3 * C + C + c] = -k1 * invstd * m1;
+    s_co[side * 3 * C + 2 * C + c] = k1 * (mean * invstd * m1 - m0);
+    if (blockIdx.x == 0) {
+      if (f.dgamma) f.dgamma[c] = (float)s1;
+      if (f.dbeta) f.dbeta[c] = (float)s0;
+    }
+  }
+  __syncthreads();
+  if (!act) return;
+  float aa[V], ab[V], ac[V], ba[V], bb[V], bc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    aa[j] = s_co[c0 + j]; ab[j] = s_co[C + c0 + j]; ac[j] = s_co[2 * C + c0 + j];
+    ba[j] = s_co[3 * C + c0 + j]; bb[j] = s_co[4 * C + c0 + j]; bc[j] = s_co[5 * C + c0 + j];
+  }
+  bool first = true;
+  for (; p < npix; p += step) {
+    float o[V];
+    if (!first) {
+      ldv<T, V>(dout + p * ldd + c0, d);
+      ldv<T, V>(ya + p * lda + c0, va);
+      ldv<T, V>(yb + p * ldb + c0, vb);
+      if (ro) ldv<T, V>(ro + p * ldr + c0, r);
+    }
+    first = false;
+    if (ro) {
 #pragma unroll
       for (int j = 0; j < V; ++j) d[j] = r[j] > 0.f ? d[j] : 0.f;
     }
@@ -725,6 +1006,57 @@ extern "C" int npp_affine_add(NppTensor* out, const NppTensor* a, const float* s
 #undef AFF_ALL
 #undef AFF
 
+static inline FinSide fin_side(const NppBnFinalizeArgs* f) {
+  FinSide s;
+  s.stats = f->stats; s.gamma = f->gamma; s.beta = f->beta; s.running_mean = f->running_mean; s.running_var = f->running_var;
+  s.nbt = reinterpret_cast<long*>(f->num_batches_tracked); s.mi = f->mean_invstd; s.count = f->count; s.nrep = f->nrep;
+  s.momentum = f->momentum; s.eps = f->eps;
+  return s;
+}
+// out = relu?( BN_a(a) [+ BN_b(b) | + b] ) with the finalize of the BatchNorm side(s) done in the kernel's prologue (fin_a required;
+// fin_b NULL: b, if any, is added as is).  scale_shift of the argument structs is not written.  NPP_E_UNSUPPORTED (nothing launched)
+// for the layouts the fused kernel does not take -- the caller then runs npp_bn_finalize + npp_affine_add.
+extern "C" int npp_affine_add_fin(NppTensor* out, const NppTensor* a, const NppBnFinalizeArgs* fin_a, const NppTensor* b,
+                                  const NppBnFinalizeArgs* fin_b, int relu, unsigned char* mask_bits, int64_t ld_mask, void* stream) {
+  NPP_REQUIRE(out && a && out->ptr && a->ptr && fin_a && fin_a->stats, NPP_E_NULL, "npp_affine_add_fin: null pointer");
+  NPP_REQUIRE(same_shape(out, a) && (!b || same_shape(out, b)), NPP_E_SHAPE, "npp_affine_add_fin: shape mismatch");
+  NPP_REQUIRE(dtype_ok(out) && out->dtype == a->dtype && (!b || b->dtype == a->dtype), NPP_E_DTYPE, "npp_affine_add_fin: dtype mismatch");
+  NPP_REQUIRE(!fin_b || (b && fin_b->stats), NPP_E_NULL, "npp_affine_add_fin: fin_b without b / statistics");
+  NPP_REQUIRE(fin_a->count > 0 && (!fin_b || fin_b->count > 0), NPP_E_SHAPE, "npp_affine_add_fin: empty batch");
+  const bool vk = vec_ok(out) && vec_ok(a) && (!b || vec_ok(b));
+  const int Vv = out->dtype == NPP_BF16 ? 8 : 4;
+  if (!vk || out->c % Vv != 0 || out->c / Vv > 256 || fin_a->nrep != NPP_STAT_REPLICAS || (fin_b && fin_b->nrep != NPP_STAT_REPLICAS)) return NPP_E_UNSUPPORTED;
+  if (mask_bits && !(out->dtype == NPP_BF16 && ld_mask >= out->c / 8)) return NPP_E_UNSUPPORTED;
+  const int nt = b ? 3 : 2;
+  ProfScope prof(NPP_FAM_ELTWISE, out->dtype, (hipStream_t)stream, 0, (double)npix(out) * out->c * esize(out->dtype) * nt);
+  const FinSide fa = fin_side(fin_a), fb = fin_b ? fin_side(fin_b) : fa;
+  const size_t lds = (size_t)(fin_b ? 4 : 2) * out->c * sizeof(float);
+#define AFN(HB, FB_, MK)                                                                                                   \
+    hipLaunchKernelGGL((affine_add_fin_kernel<T, V, HB, FB_, MK>), grid, dim3(256), lds, (hipStream_t)stream, (T*)out->ptr,  \
+                       (long)out->ld, (const T*)a->ptr, (long)a->ld, b ? (const T*)b->ptr : nullptr, b ? (long)b->ld : 0L,  \
+                       fa, fb, relu, (long)npix(out), (int)out->c, m, mask_bits, (long)ld_mask)
+#define AFN_ALL(MK)                                                                                                        \
+    do {                                                                                                                   \
+      ColMap m = col_map(out->c, V);                                                                                       \
+      dim3 grid = col_grid_ew(m, npix(out));                                                                               \
+      if (grid.x > 1024) grid.x = 1024;     /* every block repeats the prologue */                                         \
+      if (b) { if (fin_b) AFN(true, true, MK); else AFN(true, false, MK); }                                                \
+      else AFN(false, false, MK);                                                                                          \
+    } while (0)
+  if (out->dtype == NPP_BF16) {
+    typedef bf16_t T;
+    constexpr int V = 8;
+    if (mask_bits) AFN_ALL(true); else AFN_ALL(false);
+  } else {
+    typedef float T;
+    constexpr int V = 4;
+    AFN_ALL(false);
+  }
+#undef AFN_ALL
+#undef AFN
+  return npp_check_launch("affine_add_fin");
+}
+
 static inline int reduce_blocks(long npix, long c, int dtype) {
   const int v = dtype == NPP_BF16 ? 8 : 4;
   ColMap m = col_map(c, (c % v == 0) ? v : 1);
@@ -866,4 +1198,110 @@ extern "C" int npp_scale_mask(const NppTensor* dout, const float* scale, const N
                        relu_out ? (long)relu_out->ld : 0L, (T*)dx->ptr, (long)dx->ld, (long)npix(dout), cv);
   });
   return npp_check_launch("scale_mask");
+}
+
+// ---- fused forms (see affine_add_fin_kernel / bn_bwd_apply_fin_kernel) ------------------------------------------------------------
+static inline bool fused_ok(const NppTensor* x) {
+  if (!x || !dtype_ok(x) || !vec_ok(x)) return false;
+  const int v = x->dtype == NPP_BF16 ? 8 : 4;
+  return x->c % v == 0 && x->c / v <= 256;
+}
+// 1: the fused BatchNorm kernels (npp_affine_add_fin, npp_bn_bwd_reduce(2)_acc, npp_bn_bwd_apply(2)_fin) take tensors laid out like x
+extern "C" int npp_bn_fused_ok(const NppTensor* x) { return fused_ok(x) ? 1 : 0; }
+
+extern "C" int npp_bn_bwd_reduce_acc(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out,
+                                     const float* mean_invstd, double* sums, int nblocks, void* stream) {
+  NPP_REQUIRE(dout && y_raw && mean_invstd && sums, NPP_E_NULL, "npp_bn_bwd_reduce_acc: null pointer");
+  NPP_REQUIRE(same_shape(dout, y_raw) && (!relu_out || same_shape(dout, relu_out)), NPP_E_SHAPE, "npp_bn_bwd_reduce_acc: shape mismatch");
+  NPP_REQUIRE(dtype_ok(dout) && dout->dtype == y_raw->dtype && (!relu_out || relu_out->dtype == dout->dtype), NPP_E_DTYPE,
+              "npp_bn_bwd_reduce_acc: dtype mismatch");
+  NPP_REQUIRE(nblocks >= 1 && nblocks <= 65535, NPP_E_SHAPE, "npp_bn_bwd_reduce_acc: bad block count %d", nblocks);
+  if (!fused_ok(dout) || !fused_ok(y_raw) || (relu_out && !fused_ok(relu_out))) return NPP_E_UNSUPPORTED;
+  ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 2);
+  NPP_DISPATCH_TV(dout->dtype, true, {
+    ColMap m = col_map(dout->c, V);
+    dim3 grid((unsigned)nblocks, 1);
+    if (relu_out)
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, V, true, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                         (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
+                         (const T*)relu_out->ptr, (long)relu_out->ld, mean_invstd, (long)npix(dout), (int)dout->c, m, sums);
+    else
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, V, false, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                         (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
+                         (const T*)nullptr, 0L, mean_invstd, (long)npix(dout), (int)dout->c, m, sums);
+  });
+  return npp_check_launch("bn_bwd_reduce_acc");
+}
+
+extern "C" int npp_bn_bwd_reduce2_acc(const NppTensor* dout, const NppTensor* ya, const NppTensor* yb, const NppTensor* relu_out,
+                                      const float* mi_a, const float* mi_b, double* sums, int nblocks, void* stream) {
+  NPP_REQUIRE(dout && ya && yb && mi_a && mi_b && sums && nblocks >= 1, NPP_E_NULL, "npp_bn_bwd_reduce2_acc: bad arguments");
+  NPP_REQUIRE(same_shape(dout, ya) && same_shape(dout, yb) && (!relu_out || same_shape(dout, relu_out)), NPP_E_SHAPE,
+              "npp_bn_bwd_reduce2_acc: shape mismatch");
+  NPP_REQUIRE(dtype_ok(dout) && dout->dtype == ya->dtype && dout->dtype == yb->dtype && (!relu_out || relu_out->dtype == dout->dtype),
+              NPP_E_DTYPE, "npp_bn_bwd_reduce2_acc: dtype mismatch");
+  if (!fused_ok(dout) || !fused_ok(ya) || !fused_ok(yb) || (relu_out && !fused_ok(relu_out))) return NPP_E_UNSUPPORTED;
+  ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 3);
+  NPP_DISPATCH_TV(dout->dtype, true, {
+    ColMap m = col_map(dout->c, V);
+    dim3 grid((unsigned)nblocks, 1);
+    if (relu_out)
+      hipLaunchKernelGGL((bn_bwd_reduce2_kernel<T, V, true, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dout->ptr,
+                         (long)dout->ld, (const T*)ya->ptr, (long)ya->ld, (const T*)yb->ptr, (long)yb->ld,
+                         (const T*)relu_out->ptr, (long)relu_out->ld, mi_a, mi_b, (long)npix(dout), (int)dout->c, m, sums);
+    else
+      hipLaunchKernelGGL((bn_bwd_reduce2_kernel<T, V, false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dout->ptr,
+                         (long)dout->ld, (const T*)ya->ptr, (long)ya->ld, (const T*)yb->ptr, (long)yb->ld,
+                         (const T*)nullptr, 0L, mi_a, mi_b, (long)npix(dout), (int)dout->c, m, sums);
+  });
+  return npp_check_launch("bn_bwd_reduce2_acc");
+}
+
+extern "C" int npp_bn_bwd_apply_fin(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out, const double* sums,
+                                    int nrep, double count, const float* mean_invstd, const float* gamma, float* dgamma, float* dbeta,
+                                    NppTensor* dy_raw, void* stream) {
+  NPP_REQUIRE(dout && y_raw && sums && mean_invstd && dy_raw && nrep >= 1 && count > 0, NPP_E_NULL, "npp_bn_bwd_apply_fin: bad arguments");
+  NPP_REQUIRE(same_shape(dout, y_raw) && same_shape(dout, dy_raw) && (!relu_out || same_shape(dout, relu_out)), NPP_E_SHAPE,
+              "npp_bn_bwd_apply_fin: shape mismatch");
+  NPP_REQUIRE(dtype_ok(dout) && dout->dtype == y_raw->dtype && dout->dtype == dy_raw->dtype && (!relu_out || relu_out->dtype == dout->dtype),
+              NPP_E_DTYPE, "npp_bn_bwd_apply_fin: dtype mismatch");
+  if (!fused_ok(dout) || !fused_ok(y_raw) || !fused_ok(dy_raw) || (relu_out && !fused_ok(relu_out)) || nrep != NPP_STAT_REPLICAS) return NPP_E_UNSUPPORTED;
+  ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 3);
+  BwdFinSide f{mean_invstd, gamma, dgamma, dbeta};
+  NPP_DISPATCH_TV(dout->dtype, true, {
+    ColMap m = col_map(dout->c, V);
+    dim3 grid = col_grid_ew(m, npix(dout));
+    if (grid.x > 1024) grid.x = 1024;
+    hipLaunchKernelGGL((bn_bwd_apply_fin_kernel<T, V>), grid, dim3(256), (size_t)3 * dout->c * sizeof(float), (hipStream_t)stream,
+                       (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
+                       relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, sums, nrep, 1.0 / count, f,
+                       (T*)dy_raw->ptr, (long)dy_raw->ld, (long)npix(dout), (int)dout->c, m);
+  });
+  return npp_check_launch("bn_bwd_apply_fin");
+}
+
+extern "C" int npp_bn_bwd_apply2_fin(const NppTensor* dout, const NppTensor* ya, const NppTensor* yb, const NppTensor* relu_out,
+                                     const double* sums, int nrep, double count, const float* mi_a, const float* mi_b,
+                                     const float* gamma_a, const float* gamma_b, float* dgamma_a, float* dbeta_a, float* dgamma_b,
+                                     float* dbeta_b, NppTensor* dya, NppTensor* dyb, void* stream) {
+  NPP_REQUIRE(dout && ya && yb && sums && mi_a && mi_b && dya && dyb && nrep >= 1 && count > 0, NPP_E_NULL,
+              "npp_bn_bwd_apply2_fin: bad arguments");
+  NPP_REQUIRE(same_shape(dout, ya) && same_shape(dout, yb) && same_shape(dout, dya) && same_shape(dout, dyb) &&
+              (!relu_out || same_shape(dout, relu_out)), NPP_E_SHAPE, "npp_bn_bwd_apply2_fin: shape mismatch");
+  NPP_REQUIRE(dtype_ok(dout) && dout->dtype == ya->dtype && dout->dtype == yb->dtype && dout->dtype == dya->dtype &&
+              dout->dtype == dyb->dtype && (!relu_out || relu_out->dtype == dout->dtype), NPP_E_DTYPE, "npp_bn_bwd_apply2_fin: dtype mismatch");
+  if (!fused_ok(dout) || !fused_ok(ya) || !fused_ok(yb) || !fused_ok(dya) || !fused_ok(dyb) || (relu_out && !fused_ok(relu_out)) || nrep != NPP_STAT_REPLICAS)
+    return NPP_E_UNSUPPORTED;
+  ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 5);
+  BwdFinSide fa{mi_a, gamma_a, dgamma_a, dbeta_a}, fb{mi_b, gamma_b, dgamma_b, dbeta_b};
+  NPP_DISPATCH_TV(dout->dtype, true, {
+    ColMap m = col_map(dout->c, V);
+    dim3 grid = col_grid_ew(m, npix(dout));
+    if (grid.x > 1024) grid.x = 1024;
+    hipLaunchKernelGGL((bn_bwd_apply2_fin_kernel<T, V>), grid, dim3(256), (size_t)6 * dout->c * sizeof(float), (hipStream_t)stream,
+                       (const T*)dout->ptr, (long)dout->ld, (const T*)ya->ptr, (long)ya->ld, (const T*)yb->ptr, (long)yb->ld,
+                       relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, sums, nrep, 1.0 / count, fa, fb,
+                       (T*)dya->ptr, (long)dya->ld, (T*)dyb->ptr, (long)dyb->ld, (long)npix(dout), (int)dout->c, m);
+  });
+  return npp_check_launch("bn_bwd_apply2_fin");
 }

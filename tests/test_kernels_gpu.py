@@ -276,6 +276,51 @@ def test_batchnorm_fused_add(C, H, N, relu, two, dtype, tol):
         assert rel_err(bns[1].weight.grad.cpu().numpy(), ref[1].weight.grad.numpy()) < tol * 5
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-4)])
+@pytest.mark.parametrize("C,H,N,relu,mode", [(64, 24, 4, True, "two"), (128, 12, 2, False, "one"), (256, 6, 2, True, "plain_b"),
+                                               (512, 24, 2, True, "two"), (32, 48, 2, False, "plain_b")])
+def test_bn_fused_prologues_equal_the_separate_kernels(C, H, N, relu, mode, dtype, tol):
+    """npp_affine_add_fin / npp_bn_bwd_reduce(2)_acc / npp_bn_bwd_apply(2)_fin (finalize and coefficient arithmetic in the prologue of
+    the elementwise kernels) against npp_bn_finalize(2) + npp_affine_add and npp_bn_bwd_reduce(2) + coeffs(2) + apply(2): same
+    outputs (bit-equal: same arithmetic per element), same running statistics, same gradients up to the f64 summation order."""
+    from npp_amd import _ops as K
+    import copy
+    dev = _dev()
+    a_cpu, b_cpu = _rand((N, C, H, H), 20) * 2 + 0.5, _rand((N, C, H, H), 21)
+    gy = _rand((N, C, H, H), 22)
+    bns0 = [torch.nn.BatchNorm2d(C, momentum=0.1) for _ in range(2)]
+    for i, bn in enumerate(bns0):
+        with torch.no_grad():
+            bn.weight.copy_(_rand((C,), 23 + i) * 0.2 + 1)
+            bn.bias.copy_(_rand((C,), 25 + i) * 0.1)
+
+    def run(fused):
+        K.FUSE_BN_FIN = fused
+        bns = [copy.deepcopy(bn).to(dev) for bn in bns0]
+        a = _to_dev(a_cpu, dtype).detach().requires_grad_(True)
+        b = _to_dev(b_cpu, dtype).detach().requires_grad_(True)
+        sb = None if mode == "one" else (K.BnSide(b, bns[1]) if mode == "two" else K.BnSide(b))
+        y = K.bn_add(K.BnSide(a, bns[0]), sb, relu=relu, training=True)
+        y.backward(_to_dev(gy, dtype))
+        torch.cuda.synchronize()
+        res = [y.detach().float().cpu().numpy(), a.grad.float().cpu().numpy(), bns[0].weight.grad.cpu().numpy(),
+               bns[0].bias.grad.cpu().numpy(), bns[0].running_mean.cpu().numpy(), bns[0].running_var.cpu().numpy()]
+        assert int(bns[0].num_batches_tracked) == 1
+        if mode != "one":
+            res.append(b.grad.float().cpu().numpy())
+        if mode == "two":
+            res += [bns[1].weight.grad.cpu().numpy(), bns[1].running_var.cpu().numpy()]
+            assert int(bns[1].num_batches_tracked) == 1
+        return res
+
+    try:
+        fused, plain = run(True), run(False)
+    finally:
+        K.FUSE_BN_FIN = True
+    for i, (f, q) in enumerate(zip(fused, plain)):
+        assert rel_err(f, q) < tol, (i, rel_err(f, q))
+
+
 def test_add_n_and_fanout_gradient_accumulation():
     """npp_add_n (strided sources, 2..8 terms) and the _FanOut node: a tensor with four consumers gets the same gradient
     as with the autograd engine's own accumulation."""
