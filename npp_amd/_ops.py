@@ -322,6 +322,13 @@ def join_capturing_side_streams():
             cur.wait_stream(st)
 
 
+def note_stream_use(t, stream):
+    """`t` (allocated on some other stream) is about to be read or written by kernels of `stream`: tell the caching allocator, so that
+    the block is not reused before that stream's work is done (Tensor.record_stream; a no-op on the CPU)."""
+    if t is not None and t.is_cuda and stream is not None:
+        t.record_stream(stream)
+
+
 def forget_streams():
     """Drop every cached side stream.  After a hipGraph capture that was invalidated half way the streams that had joined it
     stay in capture mode for good on this ROCm (hipStreamEndCapture fails on them): the eager fallback needs fresh ones."""

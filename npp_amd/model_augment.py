@@ -214,6 +214,7 @@ class _FuseCell(_DagCell):
         if hub is not None and foreign is not None:
             outs = [None, None, None]
             cur = torch.cuda.current_stream()
+            K.note_stream_use(ins[foreign], hub)      # read on the hub stream, forward and backward (see operations.fused_sum)
             with torch.cuda.stream(hub):
                 outs[foreign] = pre[foreign](ins[foreign])
             for i in range(3):
@@ -245,10 +246,12 @@ class _FuseCell(_DagCell):
             slot = cb1.slot(i) if cb1 is not None else None
             if hub is not None and i == foreign:
                 cur = torch.cuda.current_stream()
+                K.note_stream_use(ins[i], hub)        # read on the hub stream, forward and backward (see operations.fused_sum)
                 with torch.cuda.stream(hub):
                     outs[i] = pre[i](ins[i], out=slot) if slot is not None else pre[i](ins[i])
                 cur.wait_stream(hub)
                 outs[i].record_stream(cur)
+                K.note_stream_use(outs[i], hub)       # (a ConcatBuffer slot: the buffer was allocated on `cur` and is written on the hub)
             else:
                 outs[i] = pre[i](ins[i], out=slot) if slot is not None else pre[i](ins[i])
             yield

@@ -62,6 +62,11 @@ def fused_sum(op1, h1, op2, h2, out=None):
         # the fused add (autograd replays the same fork in backward)
         cur = torch.cuda.current_stream()
         helper.wait_stream(cur)
+        # h2 was allocated on another stream and is read on `helper` now AND by this edge's backward (the conv's weight / data
+        # gradient read their saved input there): without this the allocator hands h2's block to the next allocation of its own
+        # stream the moment the last reference goes, while the helper's kernels may not have run yet -- in a captured step that
+        # reuse is baked in (found as a wild weight gradient of the 3x3-map decoder edge: the block had become an f64 scratch)
+        K.note_stream_use(h2, helper)
         with torch.cuda.stream(helper):
             b = pending_of(op2, h2)
         a = pending_of(op1, h1)

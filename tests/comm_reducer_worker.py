@@ -38,10 +38,40 @@ def run(transport, dev, overlap=True):
     assert red._npp == (transport == "npp") and comm.active() == (transport == "npp")
     step = TrainStep(net, cp, cq, opt, reducer=red, graph=True, warmup=1)
     batch = _batch(2, 96, 5, dev)
-    losses = [float(step(*batch)) for _ in range(4)]
+    losses = []
+    for it in range(4):
+        losses.append(float(step(*batch)))
+        if os.environ.get("NPP_WORKER_DIAG"):
+            torch.cuda.synchronize()
+            nb_p = sum(int(not torch.isfinite(p).all()) for p in net.parameters())
+            nb_g = sum(int(p.grad is not None and not torch.isfinite(p.grad).all()) for p in net.parameters())
+            nb_b = sum(int(not torch.isfinite(b.float()).all()) for b in net.buffers())
+            nb_s = sum(int(not torch.isfinite(v).all()) for st in opt.state.values() for v in st.values() if torch.is_tensor(v) and v.is_floating_point())
+            nb_f = [int(not torch.isfinite(b.flat).all()) for b in red.buckets]
+            if nb_s:
+                names = {id(p): n for n, p in list(net.named_parameters()) + [("criterion_pose." + n, p) for n, p in cp.named_parameters()]
+                         + [("criterion_par." + n, p) for n, p in cq.named_parameters()]}
+                print("diag bad adam state:", [(names.get(id(p), "?"), k, tuple(v.shape), v.flatten()[:4].tolist(),
+                                                 None if p.grad is None else p.grad.flatten()[:4].tolist())
+                                                for p, st in opt.state.items() for k, v in st.items()
+                                                if torch.is_tensor(v) and v.is_floating_point() and not torch.isfinite(v).all()][:6], flush=True)
+            if nb_g or nb_p:
+                print("diag bad grads:", [(n, tuple(p.shape)) for n, p in net.named_parameters()
+                                          if p.grad is not None and not torch.isfinite(p.grad).all()][:8], flush=True)
+            print("diag", transport, overlap, "call", it, "loss", losses[-1], "bad params", nb_p, "grads", nb_g, "buffers", nb_b,
+                  "adam state", nb_s, "buckets", sum(nb_f), "of", len(nb_f), "graphed", step.graph is not None, flush=True)
     assert step.graph is not None, "the step was not captured"
     torch.cuda.synchronize()
     params = [p.detach().clone() for p in net.parameters()]
+    # a wild but finite gradient element (a block reused too early and read as another type) overflows g^2: exp_avg_sq = inf, the
+    # update of that element is 0 and neither loss nor parameters show it -- so the optimizer state is part of the check
+    names = {id(p): n for n, p in net.named_parameters()}
+    bad_state = [(names.get(id(p), "?"), k) for p, st in opt.state.items() for k, v in st.items()
+                 if torch.is_tensor(v) and v.is_floating_point() and not torch.isfinite(v).all()]
+    assert not bad_state, ("non-finite optimizer state", transport, overlap, bad_state[:8])
+    bad = [(n, tuple(p.shape)) for n, p in net.named_parameters() if not torch.isfinite(p).all()]
+    if bad:
+        print("non-finite parameters after 4 steps (transport %s, overlap %s):" % (transport, overlap), bad[:12], flush=True)
     red.remove()
     return losses, params
 
