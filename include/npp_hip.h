@@ -256,6 +256,21 @@ int npp_bn_bwd_apply2_fin(const NppTensor* dout, const NppTensor* ya_raw, const 
                           const double* sums, int nrep, double count, const float* mean_invstd_a, const float* mean_invstd_b,
                           const float* gamma_a, const float* gamma_b, float* dgamma_a, float* dbeta_a, float* dgamma_b,
                           float* dbeta_b, NppTensor* dya_raw, NppTensor* dyb_raw, void* stream);
+/* ---- the mixed edge of the search supernet (PC-DARTS MixedOp, model_search_interact.py:39-74): out = sum_k w[k] * f_k(x_k), k <= 8,
+ * f_k = BatchNorm2d(affine=False) with LOCAL batch statistics (mean_invstd != NULL; stats = [NPP_STAT_REPLICAS][2C] sums of x_k) or
+ * the identity (mean_invstd == NULL).  w: k device floats (the softmaxed architecture weights).  Forward: one launch (finalize
+ * of every BatchNorm side in the prologue: mean_invstd, running statistics and num_batches_tracked are written).  Backward: one
+ * reduce + one apply launch: sums = zeroed scratch of NPP_STAT_REPLICAS * (k+1) * C doubles; dx of every side whose dx.ptr != NULL,
+ * dw[k] = sum dout * f_k(x_k).  NPP_E_UNSUPPORTED (nothing launched) for layouts npp_bn_fused_ok rejects. */
+typedef struct NppMixSide {
+  NppTensor x, dx;
+  const double* stats;
+  float* mean_invstd;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float momentum, eps;
+} NppMixSide;
+int npp_mix_bn_fwd(const NppMixSide* sides, int k, const float* w, NppTensor* out, void* stream);
+int npp_mix_bn_bwd(const NppMixSide* sides, int k, const float* w, const NppTensor* dout, double* sums, float* dw, void* stream);
 /* eval-mode / plain affine backward: dy = dout * scale * (out>0) */
 int npp_scale_mask(const NppTensor* dout, const float* scale /*[C] or NULL*/, const NppTensor* relu_out,
                    NppTensor* dx, void* stream);

@@ -47,6 +47,11 @@ class NppBnFinalizeArgs(C.Structure):
                 ("eps", C.c_float), ("_pad", C.c_int32)]
 
 
+class NppMixSide(C.Structure):
+    _fields_ = [("x", NppTensor), ("dx", NppTensor), ("stats", C.c_void_p), ("mean_invstd", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float)]
+
+
 class NppAdamJob(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("n", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
@@ -97,6 +102,8 @@ _SIGS = {
     "npp_bn_bwd_apply": [_T, _T, _T, _P, _T, _P],
     "npp_scale_mask": [_T, _P, _T, _T, _P],
     "npp_bn_fused_ok": [_T],
+    "npp_mix_bn_fwd": [_P, C.c_int, _P, _T, _P],
+    "npp_mix_bn_bwd": [_P, C.c_int, _P, _T, _P, _P, _P],
     "npp_affine_add_fin": [_T, _T, _P, _T, _P, C.c_int, _P, C.c_int64, _P],
     "npp_bn_bwd_reduce_acc": [_T, _T, _T, _P, _P, C.c_int, _P],
     "npp_bn_bwd_reduce2_acc": [_T, _T, _T, _T, _P, _P, _P, C.c_int, _P],

@@ -2126,6 +2126,119 @@ def weighted_sum(w, ys):
     return _WeightedSum.apply(w, *[take(y) for y in ys])
 
 
+# ---- the mixed edge as one N-sided weighted BatchNorm sum (npp_mix_bn_fwd / npp_mix_bn_bwd) -----------------------------------------
+MIX_FUSE = os.environ.get("NPP_MIX_FUSE", "1") != "0"
+
+
+def _mix_side_struct(x, mi, bn, stats, track, dx=None):
+    sd = L.NppMixSide()
+    sd.x = desc(x)
+    if dx is not None:
+        sd.dx = desc(dx)
+    if mi is not None:
+        sd.mean_invstd = mi.data_ptr()
+        sd.stats = stats.data_ptr() if stats is not None else None
+        if track:
+            sd.running_mean, sd.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            sd.num_batches_tracked = bn.num_batches_tracked.data_ptr() if bn.num_batches_tracked is not None else None
+        sd.momentum = float(bn.momentum if bn.momentum is not None else 0.1)
+        sd.eps = float(bn.eps)
+    return sd
+
+
+class _MixBnSum(Function):
+    """out = sum_k w[k] * f_k(x_k), f_k = BatchNorm(affine=False, local batch statistics) of sides[k].bn or the identity."""
+
+    @staticmethod
+    def forward(ctx, w, sides, *xs):
+        k = len(xs)
+        dev = xs[0].device
+        wf = w.detach().float().contiguous()
+        out = new_nhwc(*xs[0].shape, xs[0].dtype, dev)
+        c = xs[0].shape[1]
+        arr = (L.NppMixSide * k)()
+        mis, keep = [], []
+        for i, (sd, x) in enumerate(zip(sides, xs)):
+            mi = None
+            if sd.bn is not None:
+                if sd.stats is None:
+                    sd.stats = channel_stats(x)
+                mi = torch.empty(2 * c, dtype=torch.float32, device=dev)
+                track = sd.bn.track_running_stats and sd.bn.running_mean is not None
+                arr[i] = _mix_side_struct(x, mi, sd.bn, sd.stats, track)
+                keep.append(sd.stats)
+            else:
+                arr[i] = _mix_side_struct(x, None, None, None, False)
+            mis.append(mi)
+        check(lib().npp_mix_bn_fwd(C.cast(arr, C.c_void_p), k, wf.data_ptr(), _byref(out), stream_ptr()), "npp_mix_bn_fwd")
+        ctx.k = k
+        ctx.bn_side = [m is not None for m in mis]
+        ctx.wdtype = w.dtype
+        ctx.save_for_backward(wf, *xs, *[m for m in mis if m is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        k = ctx.k
+        saved = ctx.saved_tensors
+        wf, xs, rest = saved[0], saved[1:1 + k], list(saved[1 + k:])
+        mis = [rest.pop(0) if b else None for b in ctx.bn_side]
+        dout = to_nhwc(dout)
+        if dout.dtype != xs[0].dtype:
+            dout = cast(dout, xs[0].dtype)
+        dout = _gemm_ready(dout)
+        need = ctx.needs_input_grad
+        c = xs[0].shape[1]
+        dxs = [new_nhwc(*x.shape, x.dtype, x.device) if need[2 + i] else None for i, x in enumerate(xs)]
+        arr = (L.NppMixSide * k)()
+        for i, x in enumerate(xs):
+            sd = L.NppMixSide()
+            sd.x = desc(x)
+            if mis[i] is not None:
+                sd.mean_invstd = mis[i].data_ptr()
+            if dxs[i] is not None:
+                sd.dx = desc(dxs[i])
+            arr[i] = sd
+        sums = zeros_f64(R * (k + 1) * c, dout.device)
+        gw = torch.empty(8, dtype=torch.float32, device=dout.device)
+        check(lib().npp_mix_bn_bwd(C.cast(arr, C.c_void_p), k, wf.data_ptr(), _byref(dout), sums.data_ptr(), gw.data_ptr(), stream_ptr()),
+              "npp_mix_bn_bwd")
+        g = None
+        if need[0]:
+            g = gw[:k] if ctx.wdtype == torch.float32 else gw[:k].to(ctx.wdtype)
+        return (g, None, *dxs)
+
+
+def mix_bn_sum(w, sides, training: bool):
+    """sum_k w[k] * BN_k(x_k) for the candidates of a MixedOp given as BnSides (bn=None: the operand is added as is).  One fused
+    launch when every BatchNorm side is affine-free with local batch statistics and the layout allows; otherwise each BatchNorm is
+    applied on its own and the weighted sum follows (the path for SyncBatchNorm, eval mode and odd layouts)."""
+    xs = []
+    ok = MIX_FUSE and 1 <= len(sides) <= 8
+    for sd in sides:
+        x = to_nhwc(sd.x if sd.private else take(sd.x))
+        sd.x = x
+        xs.append(x)
+    if ok:
+        x0 = xs[0]
+        for sd, x in zip(sides, xs):
+            if x.shape != x0.shape or x.dtype != x0.dtype or not _fused_layout_ok(x):
+                ok = False
+            bn = sd.bn
+            if bn is not None and not (_local_batch_bn(bn, training) and training and bn.weight is None and bn.bias is None):
+                ok = False
+    if ok:
+        return _MixBnSum.apply(w, sides, *xs)
+    ys = []
+    for sd, x in zip(sides, xs):
+        if sd.bn is None:
+            ys.append(x)
+        else:
+            sd.private = True
+            ys.append(bn_add(sd, None, relu=False, training=sd.bn.training))
+    return _WeightedSum.apply(w, *[take(y) for y in ys])
+
+
 class _Interleave2(Function):
     """channel_shuffle(torch.cat([a, b], 1), groups=2)  (model_search_interact.py:22-36,71-72)."""
 

@@ -863,6 +863,225 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_fin_kernel(const T* __restr
   }
 }
 
+// ---- N-sided weighted BatchNorm sum (npp_mix_bn_*): the mixed edge of the search supernet ------------------------------------------
+// out = sum_k w[k] * f_k(x_k), f_k = BatchNorm (affine=False, local batch statistics) or the identity: the 7 candidates of a PC-DARTS
+// MixedOp (model_search_interact.py:39-74) end in exactly that, followed by the softmax-weighted sum.  One forward launch replaces 6
+// affine_add + 1 weighted_sum (20 tensor passes -> 8), one reduce + one apply launch replace 6 x (reduce + coeffs + apply) + the
+// weighted-sum backward: 18 900 -> ~15 000 launches per supernet step.  With g_k = w[k] standing in for gamma the backward is the
+// BatchNorm backward: dx_k = w_k inv_k (d - mean(d) - xhat_k mean(d xhat_k)), dw_k = sum d xhat_k (identity sides: mean 0, inv 1).
+struct MixArgs {
+  const void* x[8]; long ld[8];
+  const double* stats[8];       // forward: [R][2C] batch statistics, NULL = identity side
+  float* mi[8];                 // mean | invstd [2C] of a BatchNorm side (written by forward, read by backward), NULL = identity side
+  float* rm[8]; float* rv[8]; long* nbt[8];
+  float momentum[8], eps[8];
+  void* dx[8]; long ldd[8];     // backward outputs (NULL: not needed)
+  double count;
+  int k;
+};
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void mix_bn_fwd_kernel(MixArgs a, const float* __restrict__ w, T* __restrict__ out, long ldo, long npix,
+                                                         int C, ColMap m) {
+  extern __shared__ float s_mix[];      // scale [k][C], shift [k][C]
+  const int t = threadIdx.x, K = a.k;
+  float* s_sc = s_mix;
+  float* s_sh = s_mix + K * C;
+  for (int idx = t; idx < K * C; idx += 256) {
+    const int side = idx / C, c = idx - side * C;
+    const float wk = w[side];
+    float sc = wk, sh = 0.f;
+    if (a.stats[side]) {
+      const double* st = a.stats[side];
+      double v0[NPP_STAT_REPLICAS], v1[NPP_STAT_REPLICAS];
+#pragma unroll
+      for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { v0[r] = st[(long)r * 2 * C + c]; v1[r] = st[(long)r * 2 * C + C + c]; }
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { s0 += v0[r]; s1 += v1[r]; }
+      const double mean = s0 / a.count;
+      double var = s1 / a.count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double invstd = 1.0 / sqrt(var + (double)a.eps[side]);
+      sc = (float)(wk * invstd);
+      sh = (float)(-(double)wk * mean * invstd);
+      if (blockIdx.x == 0) {
+        if (c == 0 && a.nbt[side]) a.nbt[side][0] += 1;
+        a.mi[side][c] = (float)mean; a.mi[side][C + c] = (float)invstd;
+        const float mom = a.momentum[side];
+        if (a.rm[side]) a.rm[side][c] = (1.f - mom) * a.rm[side][c] + mom * (float)mean;
+        if (a.rv[side]) {
+          const double unb = a.count > 1.0 ? var * (a.count / (a.count - 1.0)) : var;
+          a.rv[side][c] = (1.f - mom) * a.rv[side][c] + mom * (float)unb;
+        }
+      }
+    }
+    s_sc[idx] = sc;
+    s_sh[idx] = sh;
+  }
+  __syncthreads();
+  if (t >= m.rows * m.cols_blk) return;
+  const int col = t % m.cols_blk, row = t / m.cols_blk;
+  const int c0 = col * V;
+  float sh[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += s_sh[k * C + c0 + j];
+    sh[j] = s;
+  }
+  const long step = (long)gridDim.x * m.rows;
+  for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += step) {
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = sh[j];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < K) {
+        float v[V];
+        ldv<T, V>(reinterpret_cast<const T*>(a.x[k]) + p * a.ld[k] + c0, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = fmaf(v[j], s_sc[k * C + c0 + j], acc[j]);
+      }
+    }
+    stv<T, V>(out + p * ldo + c0, acc);
+  }
+}
+
+// sums[R][(K+1)][C] += [sum d | sum d xhat_0 | ... | sum d xhat_{K-1}]   (f64 atomics into a zeroed buffer)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void mix_bn_bwd_reduce_kernel(MixArgs a, const T* __restrict__ dout, long ldo, long npix, int C, ColMap m,
+                                                                double* __restrict__ sums) {
+  extern __shared__ float s_mix[];      // mean [k][C], invstd [k][C], then the reduction image [4 * V][256]
+  const int t = threadIdx.x, K = a.k;
+  float* s_mean = s_mix;
+  float* s_inv = s_mix + K * C;
+  float* red = s_mix + 2 * K * C;
+  for (int idx = t; idx < K * C; idx += 256) {
+    const int side = idx / C, c = idx - side * C;
+    s_mean[idx] = a.mi[side] ? a.mi[side][c] : 0.f;
+    s_inv[idx] = a.mi[side] ? a.mi[side][C + c] : 1.f;
+  }
+  __syncthreads();
+  const bool act = t < m.rows * m.cols_blk;
+  const int col = t % m.cols_blk, row = t / m.cols_blk;
+  const int c0 = col * V;
+  float acc[9][V];
+#pragma unroll
+  for (int q = 0; q < 9; ++q)
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[q][j] = 0.f;
+  if (act) {
+    const long step = (long)gridDim.x * m.rows;
+    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += step) {
+      float d[V];
+      ldv<T, V>(dout + p * ldo + c0, d);
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[0][j] += d[j];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k < K) {
+          float v[V];
+          ldv<T, V>(reinterpret_cast<const T*>(a.x[k]) + p * a.ld[k] + c0, v);
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[k + 1][j] = fmaf(d[j], (v[j] - s_mean[k * C + c0 + j]) * s_inv[k * C + c0 + j], acc[k + 1][j]);
+        }
+      }
+    }
+  }
+  // block reduction over the pixel rows, four quantities at a time: red[(ql * V + j) * 256 + t]
+  double* slab = sums + (long)(blockIdx.x % NPP_STAT_REPLICAS) * (K + 1) * C;
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    if (g * 4 > K) break;
+    __syncthreads();
+#pragma unroll
+    for (int ql = 0; ql < 4; ++ql) {
+      const int q = g * 4 + ql;
+      if (q < 9) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) red[(ql * V + j) * 256 + t] = act ? acc[q][j] : 0.f;
+      }
+    }
+    __syncthreads();
+    const int nout = 4 * V * m.cols_blk;
+    for (int o = t; o < nout; o += 256) {
+      const int qj = o / m.cols_blk, cc = o - qj * m.cols_blk;
+      const int ql = qj / V, j = qj - ql * V;
+      const int q = g * 4 + ql;
+      if (q > K) continue;
+      double sum = 0.0;
+      for (int r = 0; r < m.rows; ++r) sum += (double)red[qj * 256 + r * m.cols_blk + cc];
+      atomicAdd(slab + (long)q * C + cc * V + j, sum);
+    }
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void mix_bn_bwd_apply_kernel(MixArgs a, const float* __restrict__ w, const T* __restrict__ dout, long ldo,
+                                                               const double* __restrict__ sums, float* __restrict__ dw, long npix, int C,
+                                                               ColMap m) {
+  extern __shared__ float s_mix[];      // ca [k][C], cb [k][C], cc [k][C], then K doubles (dw accumulators of block 0)
+  const int t = threadIdx.x, K = a.k;
+  float* s_ca = s_mix;
+  float* s_cb = s_mix + K * C;
+  float* s_cc = s_mix + 2 * K * C;
+  double* s_dw = reinterpret_cast<double*>(s_mix + 3 * K * C + ((3 * K * C) & 1));
+  if (t < 8) s_dw[t] = 0.0;
+  __syncthreads();
+  const double inv_count = 1.0 / a.count;
+  for (int idx = t; idx < K * C; idx += 256) {
+    const int side = idx / C, c = idx - side * C;
+    double v0[NPP_STAT_REPLICAS], v1[NPP_STAT_REPLICAS];
+#pragma unroll
+    for (int r = 0; r < NPP_STAT_REPLICAS; ++r) {
+      v0[r] = sums[(long)r * (K + 1) * C + c];
+      v1[r] = sums[(long)r * (K + 1) * C + (long)(side + 1) * C + c];
+    }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { s0 += v0[r]; s1 += v1[r]; }
+    const float wk = w[side];
+    if (a.mi[side]) {
+      const float mean = a.mi[side][c], invstd = a.mi[side][C + c];
+      const float m0 = (float)(s0 * inv_count), m1 = (float)(s1 * inv_count);
+      const float k1 = wk * invstd;
+      s_ca[idx] = k1;
+      s_cb[idx] = -k1 * invstd * m1;
+      s_cc[idx] = k1 * (mean * invstd * m1 - m0);
+    } else {
+      s_ca[idx] = wk; s_cb[idx] = 0.f; s_cc[idx] = 0.f;
+    }
+    if (blockIdx.x == 0) atomicAdd(&s_dw[side], s1);
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && t < K && dw) dw[t] = (float)s_dw[t];
+  if (t >= m.rows * m.cols_blk) return;
+  const int col = t % m.cols_blk, row = t / m.cols_blk;
+  const int c0 = col * V;
+  const long step = (long)gridDim.x * m.rows;
+  for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += step) {
+    float d[V];
+    ldv<T, V>(dout + p * ldo + c0, d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < K && a.dx[k]) {
+        float o[V];
+        if (a.mi[k]) {
+          float v[V];
+          ldv<T, V>(reinterpret_cast<const T*>(a.x[k]) + p * a.ld[k] + c0, v);
+#pragma unroll
+          for (int j = 0; j < V; ++j) o[j] = fmaf(s_ca[k * C + c0 + j], d[j], fmaf(s_cb[k * C + c0 + j], v[j], s_cc[k * C + c0 + j]));
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) o[j] = s_ca[k * C + c0 + j] * d[j];
+        }
+        stv<T, V>(reinterpret_cast<T*>(a.dx[k]) + p * a.ldd[k] + c0, o);
+      }
+    }
+  }
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void scale_mask_kernel(const T* __restrict__ dout, long ldd, const float* __restrict__ scale,
                                                          const T* __restrict__ ro, long ldr, T* __restrict__ dx, long ldo,
@@ -1304,4 +1523,72 @@ extern "C" int npp_bn_bwd_apply2_fin(const NppTensor* dout, const NppTensor* ya,
                        (T*)dya->ptr, (long)dya->ld, (T*)dyb->ptr, (long)dyb->ld, (long)npix(dout), (int)dout->c, m);
   });
   return npp_check_launch("bn_bwd_apply2_fin");
+}
+
+// ---- N-sided weighted BatchNorm sum (the search supernet's mixed edge), see mix_bn_fwd_kernel ---------------------------------------
+static int mix_fill(const NppMixSide* sides, int k, const NppTensor* ref, bool backward, MixArgs& a, const char* who) {
+  a.k = k;
+  a.count = (double)npix(ref);
+  for (int i = 0; i < 8; ++i) {
+    a.x[i] = nullptr; a.ld[i] = 0; a.stats[i] = nullptr; a.mi[i] = nullptr; a.rm[i] = nullptr; a.rv[i] = nullptr; a.nbt[i] = nullptr;
+    a.momentum[i] = 0.f; a.eps[i] = 0.f; a.dx[i] = nullptr; a.ldd[i] = 0;
+  }
+  for (int i = 0; i < k; ++i) {
+    const NppMixSide& sd = sides[i];
+    NPP_REQUIRE(sd.x.ptr && same_shape(&sd.x, ref) && sd.x.dtype == ref->dtype, NPP_E_SHAPE, "%s: side %d does not match the output", who, i);
+    if (!fused_ok(&sd.x)) return NPP_E_UNSUPPORTED;
+    const bool bn = sd.mean_invstd != nullptr;
+    NPP_REQUIRE(backward || !bn || sd.stats, NPP_E_NULL, "%s: BatchNorm side %d without statistics", who, i);
+    a.x[i] = sd.x.ptr; a.ld[i] = sd.x.ld;
+    a.stats[i] = bn ? sd.stats : nullptr; a.mi[i] = sd.mean_invstd;
+    a.rm[i] = sd.running_mean; a.rv[i] = sd.running_var; a.nbt[i] = reinterpret_cast<long*>(sd.num_batches_tracked);
+    a.momentum[i] = sd.momentum; a.eps[i] = sd.eps;
+    if (backward && sd.dx.ptr) {
+      NPP_REQUIRE(same_shape(&sd.dx, ref) && sd.dx.dtype == ref->dtype, NPP_E_SHAPE, "%s: dx %d does not match", who, i);
+      if (!fused_ok(&sd.dx)) return NPP_E_UNSUPPORTED;
+      a.dx[i] = sd.dx.ptr; a.ldd[i] = sd.dx.ld;
+    }
+  }
+  return NPP_OK;
+}
+
+extern "C" int npp_mix_bn_fwd(const NppMixSide* sides, int k, const float* w, NppTensor* out, void* stream) {
+  NPP_REQUIRE(sides && w && out && out->ptr && k >= 1 && k <= 8, NPP_E_NULL, "npp_mix_bn_fwd: bad arguments");
+  if (!fused_ok(out)) return NPP_E_UNSUPPORTED;
+  MixArgs a;
+  const int rc = mix_fill(sides, k, out, false, a, "npp_mix_bn_fwd");
+  if (rc != NPP_OK) return rc;
+  ProfScope prof(NPP_FAM_ELTWISE, out->dtype, (hipStream_t)stream, 0, (double)npix(out) * out->c * esize(out->dtype) * (k + 1));
+  const size_t lds = (size_t)2 * k * out->c * sizeof(float);
+  NPP_DISPATCH_TV(out->dtype, true, {
+    ColMap m = col_map(out->c, V);
+    dim3 grid = col_grid_ew(m, npix(out));
+    if (grid.x > 512) grid.x = 512;
+    hipLaunchKernelGGL((mix_bn_fwd_kernel<T, V>), grid, dim3(256), lds, (hipStream_t)stream, a, w, (T*)out->ptr, (long)out->ld,
+                       (long)npix(out), (int)out->c, m);
+  });
+  return npp_check_launch("mix_bn_fwd");
+}
+
+extern "C" int npp_mix_bn_bwd(const NppMixSide* sides, int k, const float* w, const NppTensor* dout, double* sums, float* dw, void* stream) {
+  NPP_REQUIRE(sides && w && dout && dout->ptr && sums && k >= 1 && k <= 8, NPP_E_NULL, "npp_mix_bn_bwd: bad arguments");
+  if (!fused_ok(dout)) return NPP_E_UNSUPPORTED;
+  MixArgs a;
+  const int rc = mix_fill(sides, k, dout, true, a, "npp_mix_bn_bwd");
+  if (rc != NPP_OK) return rc;
+  ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * (3 * k + 2));
+  const int C = (int)dout->c;
+  NPP_DISPATCH_TV(dout->dtype, true, {
+    ColMap m = col_map(C, V);
+    const int nb = reduce_blocks(npix(dout), C, dout->dtype);
+    const size_t lds_r = (size_t)(2 * k * C + 4 * V * 256) * sizeof(float);
+    hipLaunchKernelGGL((mix_bn_bwd_reduce_kernel<T, V>), dim3((unsigned)nb, 1), dim3(256), lds_r, (hipStream_t)stream, a, (const T*)dout->ptr,
+                       (long)dout->ld, (long)npix(dout), C, m, sums);
+    dim3 grid = col_grid_ew(m, npix(dout));
+    if (grid.x > 512) grid.x = 512;
+    const size_t lds_a = (size_t)(3 * k * C + 2) * sizeof(float) + 8 * sizeof(double);
+    hipLaunchKernelGGL((mix_bn_bwd_apply_kernel<T, V>), grid, dim3(256), lds_a, (hipStream_t)stream, a, w, (const T*)dout->ptr,
+                       (long)dout->ld, (const double*)sums, dw, (long)npix(dout), C, m);
+  });
+  return npp_check_launch("mix_bn_bwd");
 }

@@ -66,9 +66,30 @@ class MixedOp(nn.Module):
         self.up_scale = up_scale
         self.extra_conv = extra_conv
 
+    def _sides(self, xtemp):
+        """The candidates as deferred-BatchNorm operands (the trailing Interpolate of an up-scaling edge left out)."""
+        from .operations import pending_of
+        sides = []
+        for op in self._ops:
+            inner = op[0] if self.up_scale else op
+            if isinstance(inner, _OpThenBN):
+                sides.append(BnSide(inner[0](xtemp), inner[1], None))
+            else:
+                sides.append(pending_of(inner, xtemp))
+        return sides
+
     def forward(self, x, weights):
         xtemp, xtemp2 = K.split_half(x)
-        temp1 = K.weighted_sum(weights, [op(xtemp) for op in self._ops])
+        if K.MIX_FUSE and self.training:
+            # the 7 BatchNorm applies and the weighted sum as ONE launch (K.mix_bn_sum).  On an up-scaling edge every candidate is
+            # followed by the same bilinear Interpolate (:46-47 of the reference): resampling is linear with weights that sum to
+            # one, so it commutes with the per-channel affine of the BatchNorms and with the weighted sum -- one Interpolate of the
+            # mixed low-resolution map instead of seven
+            temp1 = K.mix_bn_sum(weights, self._sides(xtemp), self.training)
+            if self.up_scale:
+                temp1 = self._ops[0][1](temp1)
+        else:
+            temp1 = K.weighted_sum(weights, [op(xtemp) for op in self._ops])
         if self.up_scale:
             xtemp2 = K.nearest(xtemp2, self.up_scale)       # F.interpolate default mode (:63-64)
         if temp1.shape[2] != xtemp2.shape[2]:

@@ -321,6 +321,43 @@ def test_bn_fused_prologues_equal_the_separate_kernels(C, H, N, relu, mode, dtyp
         assert rel_err(f, q) < tol, (i, rel_err(f, q))
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C,H,N,pattern", [(16, 24, 2, "BBPBBBP"), (32, 12, 4, "BPB"), (64, 6, 2, "BBBBBBBB"), (8, 12, 2, "PB")])
+def test_mix_bn_sum_matches_separate_batchnorms_and_weighted_sum(C, H, N, pattern, dtype, tol):
+    """npp_mix_bn_fwd / npp_mix_bn_bwd (the MixedOp edge: sum_k w_k * BN_k(x_k) with affine-free local BatchNorms, 'P' = a plain
+    operand) against torch: nn.BatchNorm2d(affine=False) per side + the weighted sum -- output, every dx, dw, running statistics."""
+    from npp_amd import _ops as K
+    dev = _dev()
+    k = len(pattern)
+    xs_cpu = [_rand((N, C, H, H), 40 + i) * (1 + 0.3 * i) + 0.2 * i for i in range(k)]
+    if dtype == torch.bfloat16:
+        xs_cpu = [x.bfloat16().float() for x in xs_cpu]
+    w_cpu = torch.softmax(_rand((k,), 60), 0)
+    gy = _rand((N, C, H, H), 61)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    ref_bns = [torch.nn.BatchNorm2d(C, affine=False, momentum=0.1) if ch == "B" else None for ch in pattern]
+    xr = [x.clone().requires_grad_(True) for x in xs_cpu]
+    wr = w_cpu.clone().requires_grad_(True)
+    yr = sum(wr[i] * (ref_bns[i](xr[i]) if ref_bns[i] is not None else xr[i]) for i in range(k))
+    yr.backward(gy)
+    bns = [torch.nn.BatchNorm2d(C, affine=False, momentum=0.1).to(dev) if ch == "B" else None for ch in pattern]
+    xs = [_to_dev(x, dtype).detach().requires_grad_(True) for x in xs_cpu]
+    w = w_cpu.to(dev).requires_grad_(True)
+    assert K.MIX_FUSE
+    y = K.mix_bn_sum(w, [K.BnSide(x, bn, None, private=True) for x, bn in zip(xs, bns)], True)
+    y.backward(_to_dev(gy, dtype))
+    torch.cuda.synchronize()
+    assert rel_err(y.detach().float().cpu().numpy(), yr.detach().numpy()) < tol
+    assert rel_err(w.grad.cpu().numpy(), wr.grad.numpy()) < tol * 5
+    for i in range(k):
+        assert rel_err(xs[i].grad.float().cpu().numpy(), xr[i].grad.numpy()) < tol * 5, i
+        if bns[i] is not None:
+            assert rel_err(bns[i].running_mean.cpu().numpy(), ref_bns[i].running_mean.numpy()) < tol
+            assert rel_err(bns[i].running_var.cpu().numpy(), ref_bns[i].running_var.numpy()) < tol
+            assert int(bns[i].num_batches_tracked) == 1
+
+
 def test_add_n_and_fanout_gradient_accumulation():
     """npp_add_n (strided sources, 2..8 terms) and the _FanOut node: a tensor with four consumers gets the same gradient
     as with the autograd engine's own accumulation."""
