@@ -44,15 +44,15 @@ def test_other_paths_read_no_unwritten_memory(mode, dtype, steps):
     _probe(["bf16"] if dtype == "bf16" else [], {"PROBE_MODE": mode, "PROBE_STEPS": steps})
 
 
-@pytest.mark.parametrize("sync,overlap", [("1", "0"), ("1", "1"), ("0", "0")])
-def test_replayed_step_reads_no_recycled_block(sync, overlap):
+@pytest.mark.parametrize("sync,overlap,dtype", [("1", "0", "f32"), ("1", "1", "f32"), ("0", "0", "f32"), ("1", "0", "bf16")])
+def test_replayed_step_reads_no_recycled_block(sync, overlap, dtype):
     """tools/graph_poison_probe.py: the hipGraph-replayed step (SyncBatchNorm + GradReducer on a 1-rank RCCL group: hub streams,
     lockstep issue; or local BatchNorm on two streams) leaves no non-finite value and no wild gradient element behind -- checked on
     gradients, parameters, buffers AND the optimizer state (a wild finite element only shows as exp_avg_sq = inf).  Regression for
     the cross-stream use-after-free of round 2 (an input read on the hub stream without record_stream)."""
     env = dict(os.environ, PROBE_SYNC=sync, PROBE_OVERLAP=overlap, PROBE_GB="2", MASTER_PORT="29637")
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "graph_poison_probe.py")], env=env, capture_output=True, text=True,
-                       timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "graph_poison_probe.py")] + (["bf16"] if dtype == "bf16" else []),
+                       env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "GRAPH_PROBE_DONE" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
