@@ -1268,12 +1268,23 @@ def _local_batch_bn(bn, training: bool) -> bool:
     return bn is not None and (training or bn.running_mean is None) and _sync_group(bn)[0] is None
 
 
+FUSE_BN_SYNC = os.environ.get("NPP_FUSE_BN_SYNC", "1") != "0"      # SyncBatchNorm too: the finalize / coefficients AFTER the exchange
+
+
+def _fusable_batch_bn(bn, training: bool) -> bool:
+    """Batch statistics, local -- or exchanged (SyncBatchNorm): by the time the consumer runs the replicas hold the global sums and
+    the count is the global count, so the same prologue applies."""
+    if bn is None or not (training or bn.running_mean is None):
+        return False
+    return FUSE_BN_SYNC or _sync_group(bn)[0] is None
+
+
 def _fin_fusable(sa, sb, a, b, training: bool) -> bool:
-    """out = BN_a(a) [+ BN_b(b) | + b] with LOCAL batch statistics on every BatchNorm side, in a layout npp_affine_add_fin takes."""
-    if not FUSE_BN_FIN or not _local_batch_bn(sa.bn, training) or not _fused_layout_ok(a):
+    """out = BN_a(a) [+ BN_b(b) | + b] with batch statistics on every BatchNorm side, in a layout npp_affine_add_fin takes."""
+    if not FUSE_BN_FIN or not _fusable_batch_bn(sa.bn, training) or not _fused_layout_ok(a):
         return False
     if sb is not None:
-        if sb.bn is not None and (not _local_batch_bn(sb.bn, training) or sb.x.shape[1] != sa.x.shape[1]):
+        if sb.bn is not None and (not _fusable_batch_bn(sb.bn, training) or sb.x.shape[1] != sa.x.shape[1]):
             return False
         if b is None or b.dtype != a.dtype or b.shape != a.shape or not _fused_layout_ok(b):
             return False
@@ -1413,6 +1424,9 @@ class _BnAdd(Function):
         lay_ok = FUSE_BN_FIN and _fused_layout_ok(dout) and (yrelu is None or _fused_layout_ok(yrelu))
         fin = [bn is not None and batch and lay_ok and need_x and _sync_group(bn)[0] is None and _fused_layout_ok(x)
                for (x, bn, mi, ss, batch, count, need_x, *_r) in sides]
+        # SyncBatchNorm: slabs -> npp_bn_bwd_sum -> all-reduce as before, then the coefficients in the apply's prologue (one vector)
+        fin_sync = [bn is not None and batch and lay_ok and need_x and FUSE_BN_SYNC and _sync_group(bn)[0] is not None
+                    and _fused_layout_ok(x) for (x, bn, mi, ss, batch, count, need_x, *_r) in sides]
         red = [reduce_side(x, mi, fin[i]) if bn is not None else None for i, (x, bn, mi, *_r) in enumerate(sides)]
         # phase 2 (SyncBatchNorm): collapse each side's slabs to one vector (+ the LOCAL dgamma / dbeta, which DDP
         # averages afterwards as torch.nn.SyncBatchNorm does), then ONE all-reduce of the side(s) of this node.
@@ -1461,7 +1475,7 @@ class _BnAdd(Function):
                     dgt = _grad_buf(bn.weight if need_g else None, c, x.device)
                     dbt = _grad_buf(bn.bias if need_b else None, c, x.device)
                     dg, db = dgt, dbt
-                if fin[i]:
+                if fin[i] or (fin_sync[i] and nrep == 1):
                     dx = new_nhwc(*x.shape, x.dtype, x.device)
                     check(lib().npp_bn_bwd_apply_fin(_byref(dout), _byref(x), tref(yrelu), sums.data_ptr(), nrep, float(count),
                                                      mi.data_ptr(), ptr(gamma), ptr(dgt), ptr(dbt), _byref(dx), s),

@@ -735,12 +735,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* __restri
     }
   }
   for (int c = t; c < C; c += 256) {
-    double v0[NPP_STAT_REPLICAS], v1[NPP_STAT_REPLICAS];
-#pragma unroll
-    for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { v0[r] = sums[(long)r * 2 * C + c]; v1[r] = sums[(long)r * 2 * C + C + c]; }
     double s0 = 0.0, s1 = 0.0;
+    if (nrep == 1) {      // SyncBatchNorm: the one vector that came back from the all-reduce
+      s0 = sums[c]; s1 = sums[C + c];
+    } else {
+      double v0[NPP_STAT_REPLICAS], v1[NPP_STAT_REPLICAS];
 #pragma unroll
-    for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { s0 += v0[r]; s1 += v1[r]; }
+      for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { v0[r] = sums[(long)r * 2 * C + c]; v1[r] = sums[(long)r * 2 * C + C + c]; }
+#pragma unroll
+      for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { s0 += v0[r]; s1 += v1[r]; }
+    }
     const float mean = f.mi[c], invstd = f.mi[C + c];
     const float g = f.gamma ? f.gamma[c] : 1.f;
     const float m0 = (float)(s0 * inv_count), m1 = (float)(s1 * inv_count);
@@ -1484,7 +1488,7 @@ extern "C" int npp_bn_bwd_apply_fin(const NppTensor* dout, const NppTensor* y_ra
               "npp_bn_bwd_apply_fin: shape mismatch");
   NPP_REQUIRE(dtype_ok(dout) && dout->dtype == y_raw->dtype && dout->dtype == dy_raw->dtype && (!relu_out || relu_out->dtype == dout->dtype),
               NPP_E_DTYPE, "npp_bn_bwd_apply_fin: dtype mismatch");
-  if (!fused_ok(dout) || !fused_ok(y_raw) || !fused_ok(dy_raw) || (relu_out && !fused_ok(relu_out)) || nrep != NPP_STAT_REPLICAS) return NPP_E_UNSUPPORTED;
+  if (!fused_ok(dout) || !fused_ok(y_raw) || !fused_ok(dy_raw) || (relu_out && !fused_ok(relu_out)) || (nrep != NPP_STAT_REPLICAS && nrep != 1)) return NPP_E_UNSUPPORTED;
   ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 3);
   BwdFinSide f{mean_invstd, gamma, dgamma, dbeta};
   NPP_DISPATCH_TV(dout->dtype, true, {
