@@ -56,6 +56,14 @@ def test_replayed_step_reads_no_recycled_block(sync, overlap, dtype):
     assert r.returncode == 0 and "GRAPH_PROBE_DONE" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_replayed_search_step_reads_no_recycled_block():
+    """The same probe on the supernet under SearchStep (both passes replayed as hipGraphs, two branch streams)."""
+    env = dict(os.environ, PROBE_MODEL="search", PROBE_GB="2")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "graph_poison_probe.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "GRAPH_PROBE_DONE" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_channel_slice_at_the_end_of_a_buffer_is_repacked():
     """conv inputs are read in groups of 8 channels: the upper half [4:8] of an 8-wide buffer would be read past its end."""
     from npp_amd import _ops as K

@@ -19,27 +19,48 @@ from npp_amd.model_augment import Network, set_compute_dtype
 from npp_amd.optim import FusedAdam
 from npp_amd.train_step import TrainStep
 
-sync = os.environ.get("PROBE_SYNC", "1") == "1"
+search = os.environ.get("PROBE_MODEL", "augment") == "search"      # the supernet under SearchStep (two replayed passes)
+sync = os.environ.get("PROBE_SYNC", "1") == "1" and not search
 overlap = os.environ.get("PROBE_OVERLAP", "0") == "1"
 dtype = torch.bfloat16 if "bf16" in sys.argv[1:] else torch.float32
 dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
 set_compute_dtype(dtype)
 torch.manual_seed(0)
-net = Network(_cfg(8))
 red = None
+if search:
+    import test_train_step_gpu as T
+    from npp_amd.train_step import SearchStep
+    net, cp, cq, weights = T._search_setup(dev)
+    if dtype == torch.bfloat16:
+        set_compute_dtype(dtype)
+    opt = FusedAdam(weights, lr=1e-3)
+    a_opt = FusedAdam(net.arch_parameters(), lr=3e-3, betas=(0.5, 0.999), weight_decay=0.001)
+    sstep = SearchStep(net, cp, cq, opt, a_opt, graph=True, warmup=1)
+    b1, b2 = T._batch(2, 64, 3, dev), T._batch(2, 64, 4, dev)
+else:
+    net = Network(_cfg(8))
 if sync:
     from npp_amd.ddp import GradReducer, unused_parameter_names
     dist.init_process_group("nccl", rank=0, world_size=1)
     comm.disable()
     K._SYNC_EVEN_ALONE = True
     net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
-net = net.to(dev).train()
-cp, cq = Criterion_pose(out_len=2).to(dev), Criterion_par(out_len=2).to(dev)
-opt = FusedAdam(list(net.parameters()) + list(cp.parameters()) + list(cq.parameters()), lr=1e-3)
-if sync:
-    red = GradReducer(net, skip=unused_parameter_names(net), always_reduce=True, bucket_mb=0.5, overlap=overlap)
-step = TrainStep(net, cp, cq, opt, reducer=red, graph=os.environ.get("PROBE_GRAPH", "1") == "1", warmup=1)
-batch = _batch(2, 96, 5, dev)
+if search:
+    def step(*_a):
+        l1, l2 = sstep(b1[:3], b2[:3], entropy=True)
+        return l1 + l2
+    step.graph = None
+    batch = ()
+    opts = [opt, a_opt]
+else:
+    net = net.to(dev).train()
+    cp, cq = Criterion_pose(out_len=2).to(dev), Criterion_par(out_len=2).to(dev)
+    opt = FusedAdam(list(net.parameters()) + list(cp.parameters()) + list(cq.parameters()), lr=1e-3)
+    if sync:
+        red = GradReducer(net, skip=unused_parameter_names(net), always_reduce=True, bucket_mb=0.5, overlap=overlap)
+    step = TrainStep(net, cp, cq, opt, reducer=red, graph=os.environ.get("PROBE_GRAPH", "1") == "1", warmup=1)
+    batch = _batch(2, 96, 5, dev)
+    opts = [opt]
 bad_total = 0
 for it in range(4):
     if it == 1:      # the next call captures: poison the pages its pool will be carved from
@@ -56,13 +77,13 @@ for it in range(4):
     bb = [n for n, b in net.named_buffers() if not torch.isfinite(b.float()).all()]
     names = {id(p): n for n, p in net.named_parameters()}
     # a gradient with a wild (but finite) element shows as exp_avg_sq = inf: g^2 overflows, the update is 0 and nothing else notices
-    bs = [(names.get(id(p), "?"), k, int((~torch.isfinite(v)).sum()), v.numel()) for p, st in opt.state.items() for k, v in st.items()
-          if torch.is_tensor(v) and v.is_floating_point() and not torch.isfinite(v).all()]
+    bs = [(names.get(id(p), "?"), k, int((~torch.isfinite(v)).sum()), v.numel()) for o in opts for p, st in o.state.items()
+          for k, v in st.items() if torch.is_tensor(v) and v.is_floating_point() and not torch.isfinite(v).all()]
     wild = [(n, float(p.grad.abs().max())) for n, p in net.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 1e6]
     bad_total += len(bg) + len(bp) + len(bb) + int(loss != loss) + len(bs) + len(wild)
     if bs or wild:
         print("   adam state non-finite:", bs[:6], "wild gradients:", wild[:6], flush=True)
-    print("step", it, "loss", loss, "graphed", step.graph is not None, "non-finite grads", len(bg), bg[:6], "params", len(bp), bp[:4],
+    print("step", it, "loss", loss, "graphed", (sstep.weights_pass.graph is not None) if search else (step.graph is not None), "non-finite grads", len(bg), bg[:6], "params", len(bp), bp[:4],
           "buffers", len(bb), bb[:4], flush=True)
 print("GRAPH_PROBE_DONE" if bad_total == 0 else "GRAPH_PROBE_BAD")
 if sync:
