@@ -366,13 +366,19 @@ def main():
         except Exception as e:      # noqa: BLE001
             traffic_db, traffic_note = {}, f"{traffic_file}: {e}"
         for fam, label in KERNELS.items():
-            L.npp_prof_begin(_lib.FAM[fam], dt_code)
+            # one eager step per measurement, the faster of `prof_steps` measurements is reported: a single stalled launch (seen once:
+            # conv_g8 at 3x its usual time in one of two steps, rocprofv3 of the same run showing nothing) must not set the figure
+            best = None
             for _ in range(prof_steps):
+                L.npp_prof_begin(_lib.FAM[fam], dt_code)
                 eager_step()
-            barrier()
-            ms, fl, by, nl = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
-            L.npp_prof_end(C.byref(ms), C.byref(fl), C.byref(by), C.byref(nl))
-            if nl.value > 0 and ms.value > 0:
+                barrier()
+                ms, fl, by, nl = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+                L.npp_prof_end(C.byref(ms), C.byref(fl), C.byref(by), C.byref(nl))
+                if nl.value > 0 and ms.value > 0 and (best is None or ms.value < best[0].value):
+                    best = (ms, fl, by, nl)
+            if best is not None:
+                ms, fl, by, nl = best
                 ach = fl.value / (ms.value * 1e-3) / 1e12
                 peak = PEAK_TFLOPS[args.dtype]
                 rec = traffic_db.get(fam)      # the family's own average: every launch of every kernel the family times
@@ -381,7 +387,7 @@ def main():
                               "frac": round(ach / peak, 4), "traffic": traffic,
                               "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC)",
                               "traffic_source": traffic_note or f"tools/final_profiles.sh -> {traffic_file} (sources {traffic_db.get('source_hash')})",
-                              "launches_per_step": nl.value // prof_steps, "ms_per_step": round(ms.value / prof_steps, 3),
+                              "launches_per_step": nl.value, "ms_per_step": round(ms.value, 3),
                               "avg_launch_us": round(ms.value * 1e3 / nl.value, 2),
                               "algorithmic_gflop_per_launch": round(fl.value / nl.value / 1e9, 4),
                               "algorithmic_mbyte_per_launch": round(by.value / nl.value / 1e6, 3)})
