@@ -415,6 +415,46 @@ __global__ __launch_bounds__(256) void interleave2_kernel(const T* __restrict__ 
   }
 }
 
+// bf16, 8 channels of each half per thread: two 16-byte loads -> two 16-byte stores (the scalar kernel moves 2 bytes per access; the
+// supernet issues 328 of these per step on 16-channel halves)
+__global__ __launch_bounds__(256) void interleave2_v8_kernel(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, long ldb,
+                                                             bf16_t* __restrict__ out, long ldo, long npix, int cg, int inverse,
+                                                             bf16_t* __restrict__ oa, long ldoa, bf16_t* __restrict__ ob, long ldob) {
+  const FastDiv fd((unsigned)cg);
+  const unsigned total = (unsigned)(npix * cg);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    unsigned p, g;
+    fast_divmod(i, fd, p, g);
+    if (!inverse) {
+      const u32x4 va = *reinterpret_cast<const u32x4*>(a + (long)p * lda + 8 * g);
+      const u32x4 vb = *reinterpret_cast<const u32x4*>(b + (long)p * ldb + 8 * g);
+      u32x4 lo, hi;
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        lo[2 * w] = (va[w] & 0xFFFFu) | (vb[w] << 16);
+        lo[2 * w + 1] = (va[w] >> 16) | (vb[w] & 0xFFFF0000u);
+        hi[2 * w] = (va[w + 2] & 0xFFFFu) | (vb[w + 2] << 16);
+        hi[2 * w + 1] = (va[w + 2] >> 16) | (vb[w + 2] & 0xFFFF0000u);
+      }
+      *reinterpret_cast<u32x4*>(out + (long)p * ldo + 16 * g) = lo;
+      *reinterpret_cast<u32x4*>(out + (long)p * ldo + 16 * g + 8) = hi;
+    } else {
+      const u32x4 lo = *reinterpret_cast<const u32x4*>(out + (long)p * ldo + 16 * g);
+      const u32x4 hi = *reinterpret_cast<const u32x4*>(out + (long)p * ldo + 16 * g + 8);
+      u32x4 va, vb;
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        va[w] = (lo[2 * w] & 0xFFFFu) | (lo[2 * w + 1] << 16);
+        vb[w] = (lo[2 * w] >> 16) | (lo[2 * w + 1] & 0xFFFF0000u);
+        va[w + 2] = (hi[2 * w] & 0xFFFFu) | (hi[2 * w + 1] << 16);
+        vb[w + 2] = (hi[2 * w] >> 16) | (hi[2 * w + 1] & 0xFFFF0000u);
+      }
+      *reinterpret_cast<u32x4*>(oa + (long)p * ldoa + 8 * g) = va;
+      *reinterpret_cast<u32x4*>(ob + (long)p * ldob + 8 * g) = vb;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int npp_nearest(const NppTensor* x, NppTensor* y, float scale_h, float scale_w, int backward, void* stream) {
@@ -487,6 +527,18 @@ extern "C" int npp_interleave2(const NppTensor* a, const NppTensor* b, NppTensor
   if (!inverse) NPP_REQUIRE(a && b && a->c == ch && b->c == ch && a->dtype == out->dtype && b->dtype == out->dtype, NPP_E_SHAPE, "npp_interleave2: operand mismatch");
   else NPP_REQUIRE(oa && ob && oa->c == ch && ob->c == ch && oa->dtype == out->dtype && ob->dtype == out->dtype, NPP_E_SHAPE, "npp_interleave2: operand mismatch");
   const long np_ = npix(out);
+  {
+    const NppTensor* ha = inverse ? oa : a;
+    const NppTensor* hb = inverse ? ob : b;
+    auto al16 = [](const NppTensor* t) { return (((uintptr_t)t->ptr) & 15) == 0 && t->ld % 8 == 0; };
+    if (out->dtype == NPP_BF16 && ch % 8 == 0 && al16(out) && al16(ha) && al16(hb) && np_ * (ch / 8) < (1L << 32)) {
+      hipLaunchKernelGGL(interleave2_v8_kernel, dim3(grid_for(np_ * (ch / 8))), dim3(256), 0, s, inverse ? nullptr : (const bf16_t*)a->ptr,
+                         inverse ? 0L : (long)a->ld, inverse ? nullptr : (const bf16_t*)b->ptr, inverse ? 0L : (long)b->ld,
+                         (bf16_t*)out->ptr, (long)out->ld, np_, ch / 8, inverse, inverse ? (bf16_t*)oa->ptr : nullptr,
+                         inverse ? (long)oa->ld : 0L, inverse ? (bf16_t*)ob->ptr : nullptr, inverse ? (long)ob->ld : 0L);
+      return npp_check_launch("interleave2");
+    }
+  }
 #define IL(T)                                                                                                              \
   hipLaunchKernelGGL(interleave2_kernel<T>, dim3(grid_for(np_ * ch)), dim3(256), 0, s, inverse ? nullptr : (const T*)a->ptr, \
                      inverse ? 0L : (long)a->ld, inverse ? nullptr : (const T*)b->ptr, inverse ? 0L : (long)b->ld,            \

@@ -358,6 +358,29 @@ def test_mix_bn_sum_matches_separate_batchnorms_and_weighted_sum(C, H, N, patter
             assert int(bns[i].num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,H,pad", [(16, 12, 0), (8, 6, 8), (4, 6, 0), (32, 5, 0)])
+def test_interleave2_is_the_channel_shuffle_of_the_concatenation(C, H, pad, dtype):
+    """npp_interleave2 (model_search_interact.py:22-36,71-72: channel_shuffle(cat([a, b], 1), groups=2)) and its backward, scalar
+    kernel (f32, channel counts not divisible by 8, unaligned rows) and the 16-byte bf16 kernel: pure data movement, bit-exact."""
+    from npp_amd import _ops as K
+    a_cpu, b_cpu, g_cpu = _rand((2, C, H, H), 70), _rand((2, C, H, H), 71), _rand((2, 2 * C, H, H), 72)
+    if dtype == torch.bfloat16:
+        a_cpu, b_cpu, g_cpu = a_cpu.bfloat16().float(), b_cpu.bfloat16().float(), g_cpu.bfloat16().float()
+    ar, br = a_cpu.clone().requires_grad_(True), b_cpu.clone().requires_grad_(True)
+    cat = torch.cat([ar, br], 1)
+    n, c2, h, w = cat.shape
+    yr = cat.view(n, 2, c2 // 2, h, w).transpose(1, 2).reshape(n, c2, h, w)
+    yr.backward(g_cpu)
+    a = _to_dev(a_cpu, dtype, slice_pad=pad).detach().requires_grad_(True)
+    b = _to_dev(b_cpu, dtype).detach().requires_grad_(True)
+    y = K.interleave2(a, b)
+    y.backward(_to_dev(g_cpu, dtype))
+    torch.cuda.synchronize()
+    assert torch.equal(y.detach().float().cpu(), yr.detach())
+    assert torch.equal(a.grad.float().cpu(), ar.grad) and torch.equal(b.grad.float().cpu(), br.grad)
+
+
 def test_add_n_and_fanout_gradient_accumulation():
     """npp_add_n (strided sources, 2..8 terms) and the _FanOut node: a tensor with four consumers gets the same gradient
     as with the autograd engine's own accumulation."""
