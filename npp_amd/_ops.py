@@ -2235,6 +2235,8 @@ def mix_bn_sum(w, sides, training: bool):
         xs.append(x)
     if ok:
         x0 = xs[0]
+        # the kernels keep per-(operand, channel) coefficients in LDS next to a 36 KiB reduction image: 8 * k * C + 36 KiB <= 64 KiB
+        ok = len(sides) * x0.shape[1] <= 3072
         for sd, x in zip(sides, xs):
             if x.shape != x0.shape or x.dtype != x0.dtype or not _fused_layout_ok(x):
                 ok = False
