@@ -1,0 +1,62 @@
+"""Algebraic identities the HIP path relies on where it does not follow the reference's order of operations, checked in f64 on the
+CPU with plain torch (no kernel involved):
+
+* MixedOp (model_search_interact.py:39-74): every candidate is `op -> BatchNorm2d(affine=False) [-> Interpolate(bilinear)]` and the
+  edge returns the softmax-weighted sum.  npp_amd runs ONE N-sided kernel `sum_k w_k * BN_k(x_k)` on the un-resampled maps and ONE
+  Interpolate afterwards (npp_amd/model_search_interact.py: MixedOp.forward, npp_amd/_ops.py: mix_bn_sum).
+* its backward takes w_k in gamma's place: d/dx_k and d/dw_k of the fused form equal autograd's through the reference's form.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def _bn(x, eps=1e-5):
+    mean = x.mean((0, 2, 3), keepdim=True)
+    var = x.var((0, 2, 3), unbiased=False, keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps)
+
+
+@pytest.mark.parametrize("scale", [2.0, 4.0, 0.5, 0.25, 1.0])
+def test_bilinear_resampling_commutes_with_the_mixed_edge(scale):
+    torch.manual_seed(0)
+    k, n, c, h = 7, 2, 4, 8
+    xs = [(torch.randn(n, c, h, h, dtype=torch.float64) * (1 + i) + i).requires_grad_(True) for i in range(k)]
+    w = torch.softmax(torch.randn(k, dtype=torch.float64), 0).requires_grad_(True)
+    bn_side = [True, True, False, True, True, True, False]      # se_connect / poled_conv end without a BatchNorm
+
+    def f(x, b):
+        return _bn(x) if b else x
+
+    def interp(t):
+        return F.interpolate(t, scale_factor=scale, mode="bilinear", align_corners=True)
+
+    ref = sum(w[i] * interp(f(xs[i], bn_side[i])) for i in range(k))            # the reference's order
+    fused = interp(sum(w[i] * f(xs[i], bn_side[i]) for i in range(k)))          # ours
+    assert torch.allclose(ref, fused, rtol=1e-12, atol=1e-12)
+    g = torch.randn_like(ref)
+    gr = torch.autograd.grad(ref, [w] + xs, g, retain_graph=True)
+    gf = torch.autograd.grad(fused, [w] + xs, g)
+    for a, b in zip(gr, gf):
+        assert torch.allclose(a, b, rtol=1e-10, atol=1e-12)
+
+
+def test_mixed_edge_backward_is_the_batchnorm_backward_with_w_as_gamma():
+    torch.manual_seed(1)
+    k, n, c, h = 3, 4, 5, 6
+    xs = [(torch.randn(n, c, h, h, dtype=torch.float64) * (1 + i) - i).requires_grad_(True) for i in range(k)]
+    w = torch.softmax(torch.randn(k, dtype=torch.float64), 0).requires_grad_(True)
+    y = sum(w[i] * _bn(xs[i]) for i in range(k))
+    d = torch.randn_like(y)
+    gw, *gx = torch.autograd.grad(y, [w] + xs, d)
+    count = n * h * h
+    s0 = d.sum((0, 2, 3), keepdim=True)
+    for i in range(k):
+        x = xs[i].detach()
+        mean = x.mean((0, 2, 3), keepdim=True)
+        inv = 1 / torch.sqrt(x.var((0, 2, 3), unbiased=False, keepdim=True) + 1e-5)
+        xh = (x - mean) * inv
+        s1 = (d * xh).sum((0, 2, 3), keepdim=True)          # what npp_mix_bn_bwd's reduce accumulates per channel
+        dx = w[i].detach() * inv * (d - s0 / count - xh * s1 / count)
+        assert torch.allclose(dx, gx[i], rtol=1e-10, atol=1e-12)
+        assert torch.allclose(s1.sum(), gw[i], rtol=1e-10, atol=1e-12)
