@@ -60,3 +60,34 @@ def test_mixed_edge_backward_is_the_batchnorm_backward_with_w_as_gamma():
         dx = w[i].detach() * inv * (d - s0 / count - xh * s1 / count)
         assert torch.allclose(dx, gx[i], rtol=1e-10, atol=1e-12)
         assert torch.allclose(s1.sum(), gw[i], rtol=1e-10, atol=1e-12)
+
+
+def test_batchnorm_of_batchnorm_closed_form():
+    """MixedOp's pooling candidates are `PoolBN -> BatchNorm2d(affine=False)` (model_search_interact.py:48-49 around
+    operations.py:44-66): BN2(BN1(p)).  BN1's output has mean 0 and variance v1 = s^2 / (s^2 + eps) per channel exactly, so BN2 needs no
+    statistics pass and the pair collapses to ONE operand of the mixed edge (not built yet -- this pins the algebra):
+      forward   y = (p - mu) * inv1 * inv2,           inv1 = (s^2 + eps)^-1/2, inv2 = (v1 + eps)^-1/2
+      backward  dp = inv1 inv2 (d - mean(d) - kappa * y1 * mean(d y1)),   y1 = (p - mu) inv1,  kappa = 1 + (1 - v1) / (v1 + eps)
+      d/dw of w * y = sum_c inv2[c] * sum d y1."""
+    torch.manual_seed(2)
+    n, c, h, eps = 3, 6, 5, 1e-5
+    p = (torch.randn(n, c, h, h, dtype=torch.float64) * torch.linspace(0.01, 3, c, dtype=torch.float64).view(1, c, 1, 1) + 1.5).requires_grad_(True)
+    y = _bn(_bn(p, eps), eps)
+    d = torch.randn_like(y)
+    (gp,) = torch.autograd.grad(y, p, d)
+    x = p.detach()
+    mu = x.mean((0, 2, 3), keepdim=True)
+    s2 = x.var((0, 2, 3), unbiased=False, keepdim=True)
+    inv1 = (s2 + eps) ** -0.5
+    v1 = s2 * inv1 ** 2
+    inv2 = (v1 + eps) ** -0.5
+    y1 = (x - mu) * inv1
+    assert torch.allclose(y1.mean((0, 2, 3)), torch.zeros(c, dtype=torch.float64), atol=1e-12)
+    assert torch.allclose(y1.var((0, 2, 3), unbiased=False), v1.flatten(), rtol=1e-12)
+    assert torch.allclose(y.detach(), y1 * inv2, rtol=1e-12, atol=1e-12)
+    m0 = d.mean((0, 2, 3), keepdim=True)
+    m1 = (d * y1).mean((0, 2, 3), keepdim=True)
+    kappa = 1 + (1 - v1) / (v1 + eps)
+    dp = inv1 * inv2 * (d - m0 - kappa * y1 * m1)
+    assert torch.allclose(dp, gp, rtol=1e-9, atol=1e-12)
+    assert torch.allclose((d * y.detach()).sum(), (inv2 * (d * y1).sum((0, 2, 3), keepdim=True)).sum(), rtol=1e-12)
