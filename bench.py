@@ -135,6 +135,81 @@ def spawn_ranks(n):
     return 0
 
 
+def _hb(msg):
+    """Progress mark for the rank supervisor (supervise_rank): one line per phase in the heartbeat file."""
+    path = os.environ.get("NPP_BENCH_HB")
+    if path:
+        try:
+            with open(path, "a") as fh:
+                fh.write(f"{time.time():.1f} {msg}\n")
+        except OSError:
+            pass
+
+
+def supervise_rank():
+    """One rank of an N > 1 run (under torchrun, or a child of spawn_ranks): this process never touches the GPU.  It starts the
+    real worker as a CHILD (NPP_BENCH_WORKER=1), watches its heartbeat file, and if the worker dies or makes no progress for
+    NPP_BENCH_STALL_S seconds (a hipGraph capture of RCCL collectives that hangs at N > 1 has never been seen OR ruled out: no
+    multi-GPU box was available to the builder) kills exactly that child and starts a FRESH one with --graph 0 on a fresh
+    rendezvous port -- so that the first real 8-GPU run cannot end with no line at all.  Rank 0's worker writes its JSON record to
+    a result file as soon as the timed region is over; a worker that hangs after that (in the extra communicator queries) does
+    not cost the measurement."""
+    import subprocess
+    import tempfile
+    rank = int(os.environ.get("RANK", "0"))
+    base_port = int(os.environ.get("MASTER_PORT", "29511"))
+    stall_first = float(os.environ.get("NPP_BENCH_STALL_FIRST_S", "420"))      # first progress mark: torch import on a cold box
+    stall = float(os.environ.get("NPP_BENCH_STALL_S", "240"))
+    tmp = tempfile.mkdtemp(prefix=f"npp_bench_r{rank}_")
+    last_rc = 1
+    for attempt in range(2):
+        hb = os.path.join(tmp, f"hb{attempt}")
+        res = os.path.join(tmp, f"result{attempt}.json")
+        open(hb, "w").close()
+        env = dict(os.environ, NPP_BENCH_WORKER="1", NPP_BENCH_HB=hb, NPP_BENCH_RESULT=res, NPP_BENCH_ATTEMPT=str(attempt),
+                   MASTER_PORT=str(base_port + 211 + attempt))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # the workers' rank 0 hosts the store of ITS attempt's port
+        argv = list(sys.argv[1:])
+        if attempt == 1:
+            argv += ["--graph", "0"]
+            env["NPP_BENCH_FALLBACK"] = "the hipGraph attempt died or stalled; this line is from a fresh eager (--graph 0) worker"
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                 stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL)
+        t_last, size_last, seen_any = time.time(), 0, False
+        stalled = False
+        while child.poll() is None:
+            time.sleep(0.5)
+            try:
+                sz = os.path.getsize(hb)
+            except OSError:
+                sz = size_last
+            if sz != size_last:
+                size_last, t_last, seen_any = sz, time.time(), True
+            if time.time() - t_last > (stall if seen_any else stall_first):
+                stalled = True
+                sys.stderr.write(f"bench.py supervisor (rank {rank}): worker {child.pid} made no progress for "
+                                 f"{time.time() - t_last:.0f} s (attempt {attempt}); ending it\n")
+                child.kill()
+                break
+        out = child.stdout.read().decode(errors="replace") if child.stdout is not None else ""
+        last_rc = child.wait()
+        have_result = os.path.isfile(res) and os.path.getsize(res) > 0
+        if last_rc == 0 and not stalled:
+            if rank == 0:
+                sys.stdout.write(out)
+                sys.stdout.flush()
+            return 0
+        if have_result:      # timed region done, the worker was lost afterwards: its record stands
+            if rank == 0:
+                with open(res) as fh:
+                    sys.stdout.write(fh.read().strip() + "\n")
+                sys.stdout.flush()
+            return 0
+        sys.stderr.write(f"bench.py supervisor (rank {rank}): attempt {attempt} ended with rc {last_rc}"
+                         f"{' (stalled)' if stalled else ''}\n")
+    return abs(last_rc) or 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,9 +247,32 @@ def main():
         # `python bench.py --gpus N` with no launcher: start the N ranks ourselves (one process per GPU, as the reference's
         # launcher does: augment_lip_sync.py:107-113, README.md:14).  This parent has made no GPU call and makes none.
         raise SystemExit(spawn_ranks(args.gpus))
+    if (args.gpus > 1 and not os.environ.get("NPP_BENCH_WORKER") and os.environ.get("NPP_BENCH_SUPERVISE", "1") != "0"):
+        raise SystemExit(supervise_rank())      # a rank of an N > 1 run: watchdog parent + worker child (see supervise_rank)
+    _hb("worker started")
+    fake = os.environ.get("NPP_BENCH_FAKE_WORKER")
+    if fake and os.environ.get("NPP_BENCH_WORKER"):
+        # tests/test_bench_supervisor_cpu.py: the watchdog's logic without a GPU.  "hang": the first attempt stops making progress
+        # (as a hung capture would), the --graph 0 attempt answers; "late_hang": the record is written, then the worker hangs
+        attempt = int(os.environ.get("NPP_BENCH_ATTEMPT", "0"))
+        rec = {"metric": "fake", "value": 1.0, "graph_arg": args.graph, "attempt": attempt}
+        if os.environ.get("NPP_BENCH_FALLBACK"):
+            rec["fallback"] = os.environ["NPP_BENCH_FALLBACK"]
+        if fake == "hang" and attempt == 0:
+            time.sleep(3600)
+        if fake == "late_hang":
+            with open(os.environ["NPP_BENCH_RESULT"], "w") as fh:
+                fh.write(json.dumps(rec) + "\n")
+            time.sleep(3600)
+        if fake == "crash" and attempt == 0:
+            raise SystemExit(3)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps(rec), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
+    _hb("torch imported")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -194,6 +292,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    _hb("process group up")
     from npp_amd import _lib
     from npp_amd.model_augment import Network, set_compute_dtype
     from npp_amd.criterion import Criterion_par, Criterion_pose
@@ -226,8 +325,16 @@ def main():
     # Buckets are all-reduced by finish(), after backward (overlap=False): the step can then defer and batch its weight gradients
     # straight into the bucket slots (1-rank exercise: 57.8 vs 62.4 ms with the buckets issued from the hooks during backward; on 8
     # GPUs the 308 MB all-reduce is then exposed, ~2 ms on xGMI).  NPP_DDP_OVERLAP=1 restores the overlapped form.
-    reducer = GradReducer(net, skip=unused_parameter_names(net), always_reduce=args.force_dist,
-                          overlap=os.environ.get("NPP_DDP_OVERLAP", "0") == "1") if use_dist else None
+    # N > 1: BOTH forms are timed for a few steps below (`overlap_ab`) and the faster one runs the timed region; the overlapped form
+    # (north_star) is the default wherever no such measurement exists (1 rank: --force-dist) -- NPP_DDP_OVERLAP=0 / 1 forces either.
+    overlap_env = os.environ.get("NPP_DDP_OVERLAP")
+    overlap_pick = overlap_env != "0" if overlap_env is not None else True
+    overlap_ab = None
+
+    def make_reducer(overlap):
+        return GradReducer(net, skip=unused_parameter_names(net), always_reduce=args.force_dist, overlap=overlap)
+
+    reducer = make_reducer(overlap_pick) if use_dist else None
     arch_ids = {id(a) for a in net.arch_parameters()} if args.model == "search" else set()
     params = [q for q in net.parameters() if id(q) not in arch_ids] + list(crit_pose.parameters()) + list(crit_par.parameters())
     # Adam (augment_lip_sync.py:210-213).  Default: npp_amd.optim.FusedAdam, one launch over a device job table (SURVEY
@@ -267,6 +374,35 @@ def main():
         def step():
             return search_step((images, lpar, lpose), batch2)[0]
     else:
+        if use_dist and world > 1 and overlap_env is None and not args.launcher:
+            # A/B of the two reducer forms on THIS node (a 1-rank run cannot decide it: there is no wire)
+            ab_steps = max(2, min(5, args.steps))
+            overlap_ab = {}
+            for mode in (True, False):
+                if reducer is not None:
+                    reducer.remove()
+                reducer = make_reducer(mode)
+                ts = TrainStep(net, crit_pose, crit_par, opt, reducer=reducer, graph=use_graph, warmup=2)
+                for _ in range(3 if use_graph else 1):
+                    ts(images, lpar, lpose)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t_ab = time.perf_counter()
+                for _ in range(ab_steps):
+                    ts(images, lpar, lpose)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t_ab = torch.tensor([time.perf_counter() - t_ab], dtype=torch.float64, device=dev)
+                dist.all_reduce(t_ab, op=dist.ReduceOp.MAX)
+                overlap_ab["overlapped_ms" if mode else "after_backward_ms"] = round(float(t_ab) / ab_steps * 1e3, 3)
+                overlap_ab["overlapped_graph" if mode else "after_backward_graph"] = bool(ts.graphed)
+                _hb(f"overlap A/B: mode {mode} timed")
+                del ts
+            overlap_pick = overlap_ab["overlapped_ms"] <= overlap_ab["after_backward_ms"]
+            overlap_ab["picked"] = "overlapped" if overlap_pick else "after_backward"
+            overlap_ab["steps_each"] = ab_steps
+            reducer.remove()
+            reducer = make_reducer(overlap_pick)
         train_step = TrainStep(net, crit_pose, crit_par, opt, reducer=reducer, graph=use_graph, warmup=2)
 
         def step():
@@ -313,10 +449,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    _hb("model built")
     if use_graph or args.launcher == "auto":
         for _ in range(3):      # two eager calls, then capture + first replay: all before the W warm-up steps
             step()
+            _hb("pre-warm-up step issued")
         barrier()
+        _hb("captured")
     graph = train_step.graph
 
     for _ in range(args.warmup):
@@ -334,6 +473,7 @@ def main():
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    _hb("timed region done")
     if args.launcher and os.environ.get("NPP_LAUNCHER_HOST_TIMES") and rank == 0:
         sys.stderr.write("host enqueue ms per step (timed region): " + ", ".join(
             f"{k} {1e3 * v / max(host['n'], 1):.2f}" for k, v in host.items() if k != "n") + "\n")
@@ -402,10 +542,15 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-        # what the communicator itself reports (not the flag): its size, and one all-reduce of ones through it
+        # what the transport itself reports: one all-reduce of ones through the process group the step used (= the number of
+        # ranks that took part), and -- further down, after the record is safe -- ncclCommCount of an RCCL communicator
         ones = torch.ones(1, dtype=torch.float32, device=dev)
         dist.all_reduce(ones)
-        comm = {"backend": dist.get_backend(), "rccl_ranks": int(dist.get_world_size()), "allreduce_of_ones": float(ones)}
+        comm = {"backend": dist.get_backend(), "rccl_ranks": int(round(float(ones))), "allreduce_of_ones": float(ones),
+                "rccl_ranks_source": "all-reduce of ones through the step's process group",
+                "ddp_overlap": bool(reducer.overlap) if reducer is not None else None}
+        if overlap_ab is not None:
+            comm["overlap_ab"] = overlap_ab
     exposed = None
     if use_dist and not args.no_comm_ablation:
         # exposed communication = this step minus the SAME step without any collective: SyncBatchNorm modules on local
@@ -453,6 +598,22 @@ def main():
         out["roofline"] = roof
         if len(roofs) > 1:
             out["roofline_other_kernels"] = roofs[1:]
+    if os.environ.get("NPP_BENCH_FALLBACK"):
+        out["fallback"] = os.environ["NPP_BENCH_FALLBACK"]
+    if rank == 0 and os.environ.get("NPP_BENCH_RESULT"):      # the record is safe from here on (supervise_rank)
+        with open(os.environ["NPP_BENCH_RESULT"], "w") as fh:
+            fh.write(json.dumps(out) + "\n")
+    _hb("record written")
+    if use_dist and dist.get_backend() == "nccl":
+        # the communicator's own word: ncclCommCount of the library's RCCL communicator over the same ranks (npp_comm_world)
+        try:
+            from npp_amd import comm as _c
+            if not _c.active():
+                _c.enable()
+            out["rccl_ranks"] = int(_lib.lib().npp_comm_world())
+            out["rccl_ranks_source"] = "ncclCommCount of libnpp_hip's RCCL communicator over the step's ranks (npp_comm_world)"
+        except Exception as e:      # noqa: BLE001
+            out["rccl_ranks_source"] += f"; ncclCommCount unavailable ({type(e).__name__}: {str(e)[:120]})"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size)
     if use_dist:

@@ -297,6 +297,26 @@ int npp_scale_channels(const NppTensor* x, const float* gate /*[N][C]*/, NppTens
 int npp_se_bwd_reduce(const NppTensor* dout, const NppTensor* x, float* dgate /*[N][C], added*/, void* stream);
 /* dx = dout*gate + dpooled/(H*W) */
 int npp_se_bwd_apply(const NppTensor* dout, const float* gate, const float* dpooled, NppTensor* dx, void* stream);
+/* The same SE_Block (operations.py:105-129) in two launches per direction (round 3; the entry points above stay for hosts that
+ * drive the pieces themselves): slab-wise partial sums (no atomics: bit-reproducible), then ONE kernel whose workgroups evaluate
+ * the gate MLP of their image in the prologue and scale their pixels.  ws: npp_se_ws_floats(N, C) floats of scratch;
+ * pooled [N][C], hidden [N][C/2] (post-ReLU), gate [N][C] are written by the forward and read by the backward;
+ * dz [N][C + C/2] = the gate MLP's pre-activation gradients, input of the parameter gradients. */
+int npp_se_supported(int c);
+int64_t npp_se_ws_floats(int n, int c);
+int npp_se_fwd(const NppTensor* x, const float* w1, const float* b1, const float* w2, const float* b2, NppTensor* y,
+               float* pooled, float* hidden, float* gate, float* ws, void* stream);
+int npp_se_bwd(const NppTensor* dout, const NppTensor* x, const float* w1, const float* w2, const float* hidden,
+               const float* gate, NppTensor* dx, float* dz, float* ws, void* stream);
+typedef struct NppSeGradItem {
+  const float* pooled; const float* hidden; const float* dz;
+  float* dw1; float* db1; float* dw2; float* db2;      /* conv1.weight [C/2][C], conv1.bias, conv2.weight [C][C/2], conv2.bias */
+  int32_t n, c;
+} NppSeGradItem;
+int npp_se_param_grads(const NppSeGradItem* item, void* stream);
+/* every SE block's parameter gradients of a step in one launch over a device job table (host_pinned / dev: >= _ws bytes each) */
+int64_t npp_se_param_grads_batched_ws(const NppSeGradItem* items, int n);
+int npp_se_param_grads_batched(const NppSeGradItem* items, int n, void* host_pinned, void* dev, int64_t ws_bytes, void* stream);
 
 /* ---- bilinear resample, align_corners=True: F.interpolate, model_augment.py:109-116, 539-543;
  *      nn.UpsamplingBilinear2d, operations.py:242 ----------------------------------------------- */

@@ -40,6 +40,11 @@ class NppDwWgradItem(C.Structure):
     _fields_ = [("x", NppTensor), ("dy", NppTensor), ("dw", C.c_void_p), ("ws", C.c_void_p), ("g", NppConvGeom), ("_pad", C.c_int32)]
 
 
+class NppSeGradItem(C.Structure):
+    _fields_ = [("pooled", C.c_void_p), ("hidden", C.c_void_p), ("dz", C.c_void_p), ("dw1", C.c_void_p), ("db1", C.c_void_p),
+                ("dw2", C.c_void_p), ("db2", C.c_void_p), ("n", C.c_int32), ("c", C.c_int32)]
+
+
 class NppBnFinalizeArgs(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
                 ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("scale_shift", C.c_void_p),
@@ -119,6 +124,11 @@ _SIGS = {
     "npp_scale_channels": [_T, _P, _T, _P],
     "npp_se_bwd_reduce": [_T, _T, _P, _P],
     "npp_se_bwd_apply": [_T, _P, _P, _T, _P],
+    "npp_se_supported": [C.c_int],
+    "npp_se_fwd": [_T, _P, _P, _P, _P, _T, _P, _P, _P, _P, _P],
+    "npp_se_bwd": [_T, _T, _P, _P, _P, _P, _T, _P, _P, _P],
+    "npp_se_param_grads": [_P, _P],
+    "npp_se_param_grads_batched": [_P, C.c_int, _P, _P, C.c_int64, _P],
     "npp_bilinear_fwd": [_T, _T, _P],
     "npp_bilinear_bwd": [_T, _T, _P],
     "npp_bilinear_fwd_ac": [_T, _T, C.c_int, _P],
@@ -163,7 +173,8 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_clear_hip_error", "npp_packed_weight_elems", "npp_pack_job_blocks", "npp_reduce_blocks",
                                  "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems",
-                                 "npp_conv_wgrad_splits", "npp_debug_nonfinite", "npp_conv_wgrad_batched_ws", "npp_dwconv_bwd_weight_batched_ws", "npp_bilinear_bwd_ws_bytes"])
+                                 "npp_conv_wgrad_splits", "npp_debug_nonfinite", "npp_conv_wgrad_batched_ws", "npp_dwconv_bwd_weight_batched_ws", "npp_bilinear_bwd_ws_bytes",
+                                 "npp_se_ws_floats", "npp_se_param_grads_batched_ws"])
 
 
 def kernel_source_hash() -> str:
@@ -216,6 +227,10 @@ def lib():
         L.npp_conv_wgrad_batched_ws.argtypes = [C.c_int]
         L.npp_debug_nonfinite.restype = C.c_int64
         L.npp_debug_nonfinite.argtypes = [_T, _P]
+        L.npp_se_ws_floats.restype = C.c_int64
+        L.npp_se_ws_floats.argtypes = [C.c_int, C.c_int]
+        L.npp_se_param_grads_batched_ws.restype = C.c_int64
+        L.npp_se_param_grads_batched_ws.argtypes = [_P, C.c_int]
         for name, sig in _SIGS.items():
             f = getattr(L, name)
             f.restype = C.c_int

@@ -669,11 +669,11 @@ _pending_unpacks: list = []      # (src tensor, dst tensor, co, ci, taps, cp, kp
 _UNPACK_JOB = None
 
 
-def _unpack_or_defer(src, dst, co, ci, kh, kw, nslabs, s):
+def _unpack_or_defer(src, dst, co, ci, kh, kw, nslabs, s, defer=None):
     taps = kh * kw
     cp = (ci + 7) // 8 * 8
     kpad = (taps * cp + 63) // 64 * 64
-    if DEFER_UNPACK:
+    if DEFER_UNPACK if defer is None else defer:
         # keep the destination's MEMORY alive through an alias with its own TensorImpl: a second reference to the tensor object
         # itself would make autograd's AccumulateGrad clone the (still unwritten) gradient instead of adopting it
         keep = torch.empty(0, dtype=dst.dtype, device=dst.device).set_(dst.untyped_storage(), dst.storage_offset(), dst.shape,
@@ -697,14 +697,28 @@ _wgrad_batchable: dict = {}
 _wgrad_bufs = {"pin": None, "dev": None, "ev": None, "keep": []}
 
 
-def _defer_wgrad(x, dy, acc, g, key):
+_deferred_params: set = set()      # id() of the parameters with a queued (still unwritten) gradient
+
+
+def _may_defer(weight) -> bool:
+    """A deferred gradient is handed to autograd UNWRITTEN: a cast (weight not f32) or a sum with a second gradient of the same
+    parameter (one weight feeding two convs) would consume it before the flush -- those run immediately."""
+    if weight is None:
+        return True
+    if weight.dtype != torch.float32 or id(weight) in _deferred_params:
+        return False
+    _deferred_params.add(id(weight))
+    return True
+
+
+def _defer_wgrad(x, dy, acc, g, key, weight=None):
     """True if this weight gradient was queued for the batched launch (acc: the zeroed packed accumulator it adds into)."""
     if DEFER_WGRAD_MAX_PIX <= 0 or x.shape[0] * x.shape[2] * x.shape[3] > DEFER_WGRAD_MAX_PIX or x.dtype != torch.bfloat16:
         return False
     ok = _wgrad_batchable.get(key)
     if ok is None:
         ok = _wgrad_batchable[key] = bool(lib().npp_conv_wgrad_batchable(_byref(x), _byref(dy), C.byref(g)))
-    if not ok:
+    if not ok or not _may_defer(weight):
         return False
     # the accumulator's MEMORY is kept through an alias with its own TensorImpl: for a 1x1 conv it IS the gradient tensor handed to
     # autograd, and a second reference to that object would make AccumulateGrad clone the (still empty) gradient
@@ -718,7 +732,7 @@ _dw_batchable: dict = {}
 _dw_wgrad_bufs = {"pin": None, "dev": None, "ev": None, "keep": []}
 
 
-def _defer_dw_wgrad(x, dy, dw, ws, g):
+def _defer_dw_wgrad(x, dy, dw, ws, g, weight=None):
     """Depthwise twin of _defer_wgrad (npp_dwconv_bwd_weight_batched: one run launch + one slab-sum launch for all of them)."""
     if DEFER_WGRAD_MAX_PIX <= 0 or x.dtype != torch.bfloat16 or dw.dtype != torch.float32 or not DEFER_DW_WGRAD:
         return False
@@ -726,7 +740,7 @@ def _defer_dw_wgrad(x, dy, dw, ws, g):
     ok = _dw_batchable.get(key)
     if ok is None:
         ok = _dw_batchable[key] = bool(lib().npp_dwconv_bwd_weight_batchable(_byref(x), _byref(dy), C.byref(g)))
-    if not ok:
+    if not ok or not _may_defer(weight):
         return False
     keep = torch.empty(0, dtype=dw.dtype, device=dw.device).set_(dw.untyped_storage(), dw.storage_offset(), dw.shape, dw.stride())
     _pending_dw_wgrads.append((x, dy, keep, ws, g, torch.cuda.current_stream()))
@@ -747,6 +761,8 @@ def _table_bufs(B, nb, device, capturing):
         B["pin"] = B["dev"] = B["ev"] = None
         return pin, dev
     if B["pin"] is None or B["pin"].numel() < nb:
+        if B["ev"] is not None:      # the library's own copy reads the old pinned image: torch's host allocator knows nothing of it
+            B["ev"].synchronize()
         pin = torch.empty(max(nb, 1 << 16), dtype=torch.uint8).pin_memory()
         dev = torch.empty(pin.numel(), dtype=torch.uint8, device=device)
         B["pin"], B["dev"], B["ev"] = pin, dev, None
@@ -794,14 +810,18 @@ def drop_pending():
     """Forget the deferred launches of a step that was abandoned (a failed hipGraph capture): their tensors are gone."""
     _pending_wgrads.clear()
     _pending_dw_wgrads.clear()
+    _pending_se_grads.clear()
     _pending_unpacks.clear()
-    for B in (_wgrad_bufs, _dw_wgrad_bufs, _unpack_bufs):
+    _deferred_params.clear()
+    for B in (_wgrad_bufs, _dw_wgrad_bufs, _unpack_bufs, _se_grad_bufs):
         B["ev"] = None
 
 
 def flush_wgrads():
     """Run every deferred weight gradient in one launch per kernel variant on the current stream (before flush_unpacks)."""
+    _deferred_params.clear()
     _flush_dw_wgrads()
+    _flush_se_grads()
     if not _pending_wgrads:
         return
     items = list(_pending_wgrads)
@@ -828,6 +848,8 @@ def flush_wgrads():
         B["keep"].append((pin, dev))            # the replayed graph re-reads this pinned image: retire it
         B["pin"] = B["dev"] = B["ev"] = None
     elif B["pin"] is None or B["pin"].numel() < nb:
+        if B["ev"] is not None:
+            B["ev"].synchronize()
         pin = torch.empty(max(nb, 1 << 16), dtype=torch.uint8).pin_memory()
         dev = torch.empty(pin.numel(), dtype=torch.uint8, device=items[0][0].device)
         B["pin"], B["dev"], B["ev"] = pin, dev, None
@@ -853,6 +875,7 @@ _unpack_bufs = {"pin": None, "dev": None, "ev": None, "keep": []}
 def flush_unpacks():
     """Run every deferred unpack in one launch on the current stream (which first waits for the streams they were queued on)."""
     global _UNPACK_JOB
+    _deferred_params.clear()
     if not _pending_unpacks:
         return
     import numpy as np
@@ -895,6 +918,8 @@ def flush_unpacks():
         B["keep"].append((pin, dev))
         B["pin"] = B["dev"] = B["ev"] = None
     elif B["pin"] is None or B["pin"].numel() < nb:
+        if B["ev"] is not None:
+            B["ev"].synchronize()
         pin = torch.empty(max(nb, 1 << 16), dtype=torch.uint8).pin_memory()
         dev = torch.empty(pin.numel(), dtype=torch.uint8, device=items[0][1].device)
         B["pin"], B["dev"], B["ev"] = pin, dev, None
@@ -1007,7 +1032,7 @@ class _Conv2d(Function):
                 if dw is None:
                     dw = zeros_f32(weight.numel(), x.device, own=True).view(weight.shape)     # pre-zeroed pool slice: no fill launch
                 wkey = (tuple(x.shape), L.nhwc_ld(x), co, L.nhwc_ld(dy), kh, kw, stride, pad, dil, x.dtype)
-                if not _defer_wgrad(x, dy, dw, g, wkey):
+                if not _defer_wgrad(x, dy, dw, g, wkey, weight):
                     check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
             else:
                 dw = grad_out(weight)
@@ -1017,15 +1042,16 @@ class _Conv2d(Function):
                 nsl = _wgrad_splits.get(wkey)
                 if nsl is None:
                     nsl = _wgrad_splits[wkey] = int(lib().npp_conv_wgrad_splits(_byref(x), _byref(dy), C.byref(g)))
+                defer_ok = DEFER_UNPACK and _may_defer(weight)      # (dw reaches autograd unwritten when the unpack waits)
                 if nsl > 0:      # deterministic split-K: the kernel stores one slab per split, the unpack sums them
                     slabs = torch.empty(nsl * nel, dtype=torch.float32, device=x.device)
                     check(lib().npp_conv_wgrad_slabs(_byref(x), _byref(dy), slabs.data_ptr(), nsl, C.byref(g), s), "npp_conv_wgrad_slabs")
-                    _unpack_or_defer(slabs, dw, co, ci, kh, kw, nsl, s)
+                    _unpack_or_defer(slabs, dw, co, ci, kh, kw, nsl, s, defer_ok)
                 else:
                     dwp = zeros_f32(nel, x.device)
-                    if not (DEFER_UNPACK and _defer_wgrad(x, dy, dwp, g, wkey)):      # (its unpack must be deferred behind it)
+                    if not (defer_ok and _defer_wgrad(x, dy, dwp, g, wkey)):      # (its unpack must be deferred behind it)
                         check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
-                    _unpack_or_defer(dwp, dw, co, ci, kh, kw, 0, s)
+                    _unpack_or_defer(dwp, dw, co, ci, kh, kw, 0, s, defer_ok)
             if SHAPE_LOG is not None:
                 SHAPE_LOG.append(("wgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
             if dw.dtype != weight.dtype:
@@ -1099,7 +1125,7 @@ class _DwConv2d(Function):
                 ws = zeros_f32(nws, x.device)
             else:
                 ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-            if not _defer_dw_wgrad(x, dy, dw, ws, g):
+            if not _defer_dw_wgrad(x, dy, dw, ws, g, weight):
                 check(lib().npp_dwconv_bwd_weight(_byref(x), _byref(dy), dw.data_ptr(), ws.data_ptr(), C.byref(g), s),
                       "npp_dwconv_bwd_weight")
             if dw.dtype != weight.dtype:
@@ -1622,6 +1648,16 @@ def pool2x2(x, is_avg=True, want_stats=False):
 # --------------------------------------------------------------------------------------------------
 # squeeze-excite gate:  y = x * sigmoid(W2 relu(W1 gap(x) + b1) + b2)
 # --------------------------------------------------------------------------------------------------
+SE_FUSED = os.environ.get("NPP_SE_FUSED", "1") != "0"      # 0: the seven-launch form of rounds 1-2 (float-atomic squeeze sums)
+_pending_se_grads: list = []      # (pooled, hidden, dz, dw1, db1, dw2, db2 aliases, n, c, stream): parameter gradients of the SE gates
+_se_grad_bufs = {"pin": None, "dev": None, "ev": None, "keep": []}
+
+
+def _f32c(t):
+    t = t.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
 class _SEScale(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
@@ -1629,15 +1665,24 @@ class _SEScale(Function):
         n, c, h, w = x.shape
         dev = x.device
         s = stream_ptr()
-        pooled = zeros_f32(n * c, dev, own=True).view(n, c)
-        check(lib().npp_global_avgpool(_byref(x), pooled.data_ptr(), s), "npp_global_avgpool")
-        hidden = torch.empty((n, c // 2), dtype=torch.float32, device=dev)
-        gate = torch.empty((n, c), dtype=torch.float32, device=dev)
-        w1f, b1f, w2f, b2f = (t.detach().float().contiguous() for t in (w1, b1, w2, b2))
-        check(lib().npp_se_gate_fwd(pooled.data_ptr(), w1f.data_ptr(), b1f.data_ptr(), w2f.data_ptr(), b2f.data_ptr(),
-                                    hidden.data_ptr(), gate.data_ptr(), n, c, s), "npp_se_gate_fwd")
+        w1f, b1f, w2f, b2f = (_f32c(t) for t in (w1, b1, w2, b2))
         y = new_nhwc(n, c, h, w, x.dtype, dev)
-        check(lib().npp_scale_channels(_byref(x), gate.data_ptr(), _byref(y), s), "npp_scale_channels")
+        ctx.fused = SE_FUSED and bool(lib().npp_se_supported(c))
+        if ctx.fused:
+            # two launches: slab-wise squeeze sums, then gate MLP (in every workgroup's prologue) + scale (se.hip)
+            st = torch.empty(n * (2 * c + c // 2), dtype=torch.float32, device=dev)
+            pooled, hidden, gate = st[:n * c].view(n, c), st[n * c:n * c + n * (c // 2)].view(n, c // 2), st[n * c + n * (c // 2):].view(n, c)
+            ws = torch.empty(int(lib().npp_se_ws_floats(n, c)), dtype=torch.float32, device=dev)
+            check(lib().npp_se_fwd(_byref(x), w1f.data_ptr(), b1f.data_ptr(), w2f.data_ptr(), b2f.data_ptr(), _byref(y),
+                                   pooled.data_ptr(), hidden.data_ptr(), gate.data_ptr(), ws.data_ptr(), s), "npp_se_fwd")
+        else:
+            pooled = zeros_f32(n * c, dev, own=True).view(n, c)
+            check(lib().npp_global_avgpool(_byref(x), pooled.data_ptr(), s), "npp_global_avgpool")
+            hidden = torch.empty((n, c // 2), dtype=torch.float32, device=dev)
+            gate = torch.empty((n, c), dtype=torch.float32, device=dev)
+            check(lib().npp_se_gate_fwd(pooled.data_ptr(), w1f.data_ptr(), b1f.data_ptr(), w2f.data_ptr(), b2f.data_ptr(),
+                                        hidden.data_ptr(), gate.data_ptr(), n, c, s), "npp_se_gate_fwd")
+            check(lib().npp_scale_channels(_byref(x), gate.data_ptr(), _byref(y), s), "npp_scale_channels")
         ctx.save_for_backward(x, w1, w2, pooled, hidden, gate, b1, b2)
         return y
 
@@ -1650,21 +1695,75 @@ class _SEScale(Function):
         n, c, h, w = x.shape
         dev = x.device
         s = stream_ptr()
-        dgate = zeros_f32(n * c, dev).view(n, c)
-        check(lib().npp_se_bwd_reduce(_byref(dy), _byref(x), dgate.data_ptr(), s), "npp_se_bwd_reduce")
         dw1 = _grad_buf(w1, w1.numel(), dev).view(w1.shape)
         db1 = _grad_buf(b1, c // 2, dev)
         dw2 = _grad_buf(w2, w2.numel(), dev).view(w2.shape)
         db2 = _grad_buf(b2, c, dev)
-        dpooled = torch.empty((n, c), dtype=torch.float32, device=dev)
-        scratch = torch.empty((n, c + c // 2), dtype=torch.float32, device=dev)
-        w1f, w2f = w1.detach().float().contiguous(), w2.detach().float().contiguous()
-        check(lib().npp_se_gate_bwd(pooled.data_ptr(), hidden.data_ptr(), gate.data_ptr(), dgate.data_ptr(),
-                                    w1f.data_ptr(), w2f.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
-                                    db2.data_ptr(), dpooled.data_ptr(), scratch.data_ptr(), n, c, s), "npp_se_gate_bwd")
+        w1f, w2f = _f32c(w1), _f32c(w2)
         dx = new_nhwc(n, c, h, w, x.dtype, dev)
-        check(lib().npp_se_bwd_apply(_byref(dy), gate.data_ptr(), dpooled.data_ptr(), _byref(dx), s), "npp_se_bwd_apply")
+        if ctx.fused:
+            dz = torch.empty((n, c + c // 2), dtype=torch.float32, device=dev)
+            ws = torch.empty(int(lib().npp_se_ws_floats(n, c)), dtype=torch.float32, device=dev)
+            check(lib().npp_se_bwd(_byref(dy), _byref(x), w1f.data_ptr(), w2f.data_ptr(), hidden.data_ptr(), gate.data_ptr(),
+                                   _byref(dx), dz.data_ptr(), ws.data_ptr(), s), "npp_se_bwd")
+            # parameter gradients: nobody reads them before the optimizer -> one batched launch per step under TrainStep
+            if (DEFER_WGRAD_MAX_PIX > 0 and all(t.dtype == torch.float32 for t in (w1, b1, w2, b2))
+                    and _may_defer(w1) and _may_defer(w2) and _may_defer(b1) and _may_defer(b2)):
+                def alias(t):
+                    return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset(), t.shape, t.stride())
+                _pending_se_grads.append((pooled, hidden, dz, alias(dw1), alias(db1), alias(dw2), alias(db2), n, c,
+                                          torch.cuda.current_stream()))
+            else:
+                it = L.NppSeGradItem(pooled.data_ptr(), hidden.data_ptr(), dz.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
+                                     dw2.data_ptr(), db2.data_ptr(), n, c)
+                check(lib().npp_se_param_grads(C.byref(it), s), "npp_se_param_grads")
+        else:
+            dgate = zeros_f32(n * c, dev).view(n, c)
+            check(lib().npp_se_bwd_reduce(_byref(dy), _byref(x), dgate.data_ptr(), s), "npp_se_bwd_reduce")
+            dpooled = torch.empty((n, c), dtype=torch.float32, device=dev)
+            scratch = torch.empty((n, c + c // 2), dtype=torch.float32, device=dev)
+            check(lib().npp_se_gate_bwd(pooled.data_ptr(), hidden.data_ptr(), gate.data_ptr(), dgate.data_ptr(),
+                                        w1f.data_ptr(), w2f.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
+                                        db2.data_ptr(), dpooled.data_ptr(), scratch.data_ptr(), n, c, s), "npp_se_gate_bwd")
+            check(lib().npp_se_bwd_apply(_byref(dy), gate.data_ptr(), dpooled.data_ptr(), _byref(dx), s), "npp_se_bwd_apply")
+        if dw1.dtype != w1.dtype:
+            dw1, db1, dw2, db2 = dw1.to(w1.dtype), db1.to(b1.dtype), dw2.to(w2.dtype), db2.to(b2.dtype)
         return dx, dw1, db1, dw2, db2
+
+
+def _flush_se_grads():
+    if not _pending_se_grads:
+        return
+    items = list(_pending_se_grads)
+    _pending_se_grads.clear()
+    cur = torch.cuda.current_stream()
+    seen = {cur.cuda_stream}
+    for it in items:
+        if it[9].cuda_stream not in seen:
+            seen.add(it[9].cuda_stream)
+            cur.wait_stream(it[9])
+    n = len(items)
+    arr = (L.NppSeGradItem * n)()
+    for i, (pooled, hidden, dz, dw1, db1, dw2, db2, nimg, c, _st) in enumerate(items):
+        arr[i] = L.NppSeGradItem(pooled.data_ptr(), hidden.data_ptr(), dz.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
+                                 dw2.data_ptr(), db2.data_ptr(), nimg, c)
+    nb = int(lib().npp_se_param_grads_batched_ws(C.cast(arr, C.c_void_p), n))
+    capturing = torch.cuda.is_current_stream_capturing()
+    bufs = _table_bufs(_se_grad_bufs, nb, items[0][0].device, capturing) if nb > 0 else None
+    if bufs is None:
+        for i in range(n):
+            check(lib().npp_se_param_grads(C.byref(arr[i]), stream_ptr()), "npp_se_param_grads")
+    else:
+        pin, dev = bufs
+        check(lib().npp_se_param_grads_batched(C.cast(arr, C.c_void_p), n, pin.data_ptr(), dev.data_ptr(), pin.numel(), stream_ptr()),
+              "npp_se_param_grads_batched")
+        if not capturing:
+            _se_grad_bufs["ev"] = torch.cuda.Event()
+            _se_grad_bufs["ev"].record()
+    for it in items:
+        if it[9].cuda_stream != cur.cuda_stream:
+            for t in it[:7]:
+                t.record_stream(cur)
 
 
 def se_scale(x, w1, b1, w2, b2):

@@ -5,7 +5,7 @@
 issued eagerly the ~5000 launches of a step are host-bound (131 img/s).  With `NPP_AUTO_GRAPH=1` (or
 `npp_amd.install_as_reference_modules(auto_graph=True)`) a training `Network` watches its calls: the first ones run eagerly
 (pools, packed weights, allocator warm), then -- for the input signature seen -- the forward is captured into one hipGraph and
-the backward of all outputs w.r.t. all parameters into a second one sharing its memory pool (the scheme of
+the backward of all outputs w.r.t. all parameters into a second one with a pool of its own (the scheme of
 torch.cuda.make_graphed_callables, with this package's stream topology, scratch pools and capture-failure recovery), and
 `forward` becomes an autograd node that copies the batch in, replays, and hands out the static outputs; its backward copies
 the output gradients in, replays, and hands the static parameter gradients to autograd (DDP / GradReducer hooks fire as usual).
@@ -44,6 +44,20 @@ def _unflatten(flat, n_pose):
     return pose, par
 
 
+def _privatize_grads(g) -> bool:
+    """Give every parameter whose .grad still IS a static gradient buffer of the graph a private copy (AccumulateGrad adopts
+    the tensor handed out by _Replay.backward); True if any parameter holds a gradient at all."""
+    held = False
+    with torch.no_grad():
+        for p, b in zip(g.params, g.static_grads):
+            gr = p.grad
+            if gr is not None:
+                held = True
+                if b is not None and gr.data_ptr() == b.data_ptr():
+                    p.grad = gr.clone()
+    return held
+
+
 class _Replay(Function):
     @staticmethod
     def forward(ctx, holder, x, *params):
@@ -63,8 +77,11 @@ class _Replay(Function):
                     s.zero_()
                 else:
                     s.copy_(gr)
+        # a second backward before zero_grad(set_to_none=True): decided BEFORE the replay, and a p.grad that still IS the graph's
+        # static gradient buffer (AccumulateGrad adopted it after the previous backward) gets a private copy first -- the replay
+        # overwrites that buffer, and with it the accumulated gradient (2*g2 instead of g1 + g2)
+        accumulating = _privatize_grads(g)
         g.bwd.replay()
-        accumulating = any(p.grad is not None for p in g.params)      # a second backward before zero_grad(set_to_none=True)
         outs = []
         for b, z in zip(g.static_grads, g.zeros_for_unused):
             if b is None:
@@ -100,8 +117,6 @@ class AutoGraph:
         if (self.dead or not net.training or not torch.is_grad_enabled() or not x.is_cuda
                 or torch.cuda.is_current_stream_capturing() or getattr(net, "_auto_graph_off", False)):
             return net._forward_eager(x)
-        if self.calls == 0:
-            K.GRAPH_TOPOLOGY = True       # the eager warm-up steps already run the stream topology that gets captured
         sig = self._signature(x)
         if self.graph is not None and sig == self.sig:
             g = self.graph
@@ -112,17 +127,30 @@ class AutoGraph:
         if sig != self.sig:
             self.sig, self.calls = sig, 0
         self.calls += 1
-        if self.calls <= WARMUP_CALLS:
-            return net._forward_eager(x)
-        ok = self._capture(x)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
-                                device=x.device if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = bool(int(flag.item()))
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+        def agree(flag: bool) -> bool:      # MIN over the ranks: every rank takes the same path (the collective order depends on it)
+            if not multi:
+                return flag
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=x.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        # The stream topology that gets captured is scoped to this network's warm-up / capture calls (other eager work -- eval
+        # forwards, other networks, a GradReducer's side stream -- keeps the eager topology).  The capture decision is collective:
+        # a rank that restarted its warm-up (another batch shape) keeps every rank eager for this call.
+        ready = agree(self.calls > WARMUP_CALLS)
+        prev_topology = K.GRAPH_TOPOLOGY
+        K.GRAPH_TOPOLOGY = True
+        try:
+            if not ready:
+                return net._forward_eager(x)      # (its backward finds K._hub_stream as this forward left it)
+            ok = agree(self._capture(x))
+            K._hub_stream = None                  # the capture's origin stream: nothing eager may be sent there later
+        finally:
+            K.GRAPH_TOPOLOGY = prev_topology
         if not ok:
             self.graph, self.dead = None, True
-            K.GRAPH_TOPOLOGY = False
             return net._forward_eager(x)
         g = self.graph
         flat = _Replay.apply(self, x, *g.params)
@@ -136,7 +164,10 @@ class AutoGraph:
         torch.cuda.synchronize()
         K.reset_pools()
         origin = torch.cuda.current_stream()
-        pool = torch.cuda.graph_pool_handle()
+        # Two pools: the parameter gradients the backward graph hands out are adopted by AccumulateGrad as p.grad and may be held
+        # across the NEXT forward replay (an accumulation window; a launcher that calls zero_grad after the forward,
+        # core/function.py:105) -- with one shared pool that replay reuses their memory for its temporaries
+        pool, pool_bwd = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
         g.fwd, g.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         gc.collect()
         gc_was = gc.isenabled()
@@ -156,7 +187,11 @@ class AutoGraph:
                 outs = _flatten(pose_list, par_list)
                 g.static_grad_outs = [torch.zeros_like(o) for o in outs]
                 alias_list = [aliases[n] for n, _ in named]
-                with torch.cuda.graph(g.bwd, pool=pool, capture_error_mode="thread_local"):
+                # fresh scratch chunks for the backward graph: a 1x1 conv's gradient IS a slice of a pre-zeroed chunk, and the fill
+                # that zeroes a chunk belongs to the graph that allocated it -- a chunk of the forward graph would be zeroed by the
+                # next forward replay while p.grad still points into it
+                K.reset_pools()
+                with torch.cuda.graph(g.bwd, pool=pool_bwd, capture_error_mode="thread_local"):
                     grads = torch.autograd.grad(outs, alias_list, grad_outputs=g.static_grad_outs, allow_unused=True)
                     K.join_capturing_side_streams()
             except BaseException:

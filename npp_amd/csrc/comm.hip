@@ -16,6 +16,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclComm_t comm = nullptr;
@@ -34,6 +35,7 @@ bool load_rccl() {
   g.GetUniqueId = reinterpret_cast<decltype(g.GetUniqueId)>(dlsym(g.h, "ncclGetUniqueId"));
   g.CommInitRank = reinterpret_cast<decltype(g.CommInitRank)>(dlsym(g.h, "ncclCommInitRank"));
   g.CommDestroy = reinterpret_cast<decltype(g.CommDestroy)>(dlsym(g.h, "ncclCommDestroy"));
+  g.CommCount = reinterpret_cast<decltype(g.CommCount)>(dlsym(g.h, "ncclCommCount"));
   g.AllReduce = reinterpret_cast<decltype(g.AllReduce)>(dlsym(g.h, "ncclAllReduce"));
   g.GetErrorString = reinterpret_cast<decltype(g.GetErrorString)>(dlsym(g.h, "ncclGetErrorString"));
   if (!g.GetUniqueId || !g.CommInitRank || !g.CommDestroy || !g.AllReduce || !g.GetErrorString) {
@@ -75,7 +77,13 @@ extern "C" int npp_comm_init(const void* id128, int rank, int world) {
   return NPP_OK;
 }
 
-extern "C" int npp_comm_world(void) { return g.comm ? g.world : 0; }
+// the number of ranks the COMMUNICATOR reports (ncclCommCount), not the value it was created with; 0 without a communicator
+extern "C" int npp_comm_world(void) {
+  if (!g.comm) return 0;
+  int n = 0;
+  if (g.CommCount && g.CommCount(g.comm, &n) == ncclSuccess) return n;
+  return g.world;
+}
 
 extern "C" int npp_comm_destroy(void) {
   std::lock_guard<std::mutex> lk(g.mu);

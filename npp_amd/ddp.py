@@ -144,7 +144,9 @@ class GradReducer:
             return None
         bi, pi = self._where[p]
         b = self.buckets[bi]
-        if b.taken[pi] or b.launched:
+        if b.taken[pi] or b.launched or p.grad is not None:
+            # p.grad is still set (zero_grad(set_to_none=False), or a second backward of an accumulation window): it may BE this
+            # very slot, and autograd will add the new gradient to it -- the kernel must write somewhere else
             return None
         b.taken[pi] = True
         return b.view(pi)
@@ -157,6 +159,9 @@ class GradReducer:
             st = torch.cuda.current_stream()
             b.streams[st.cuda_stream] = st
         b.pending -= 1
+        if b.pending < 0:
+            raise RuntimeError("GradReducer: a parameter's gradient arrived twice before finish() -- call finish() after every "
+                               "backward (gradient accumulation over several backwards is not supported by this reducer)")
         if b.pending == 0 and self.overlap:
             self._launch(b)
 

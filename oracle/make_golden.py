@@ -532,6 +532,33 @@ def gen_search_extra():
     print("search_extra.npz", str(out["genotype_fuse"])[:120])
 
 
+def gen_search_eval():
+    """Eval-mode (running statistics) forward of the search supernet of search_net.npz (C=16, 2x3x128x128, the same non-uniform
+    alphas / betas): the pin for the supernet's bf16 mode (train-mode outputs of a randomly initialised network amplify storage
+    rounding, see gen_full_eval)."""
+    C, size, n = 16, 128, 2
+    torch.manual_seed(0)
+    c = cfg(C)
+    c.SEARCH = NS(LAYERS=16, INIT_CHANNELS=C)
+    net = RefSearchNetwork(c)
+    load_synth(net, 0)
+    with torch.no_grad():
+        for a in net.arch_parameters():
+            a.mul_(8.0)
+    images, _, _, _ = synth_batch(n, size, seed=0)
+    net.eval()
+    with torch.no_grad():
+        pose_list, par_list = net(torch.from_numpy(images))
+    out = {"torch_version": np.array(torch.__version__), "C": np.array(C), "size": np.array(size), "n": np.array(n)}
+    for i in range(2):
+        out[f"eval/pose_map{i}"] = f32(pose_list[i][0])
+        out[f"eval/pose_aux{i}"] = f32(pose_list[i][1])
+        out[f"eval/par_map{i}"] = f32(par_list[i][0])
+        out[f"eval/edge{i}"] = f32(par_list[i][1])
+    np.savez_compressed(os.path.join(OUT, "search_eval.npz"), **out)
+    print("search_eval.npz", len(out), "arrays")
+
+
 def gen_full_eval():
     """Eval-mode (running statistics) forward of the full configuration at 384 x 384 and 512 x 512: the pin for the bf16 mode at
     full size -- in train mode this randomly initialised network amplifies ANY perturbation ~1.3x per cell (f32 rounding
@@ -577,9 +604,9 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["ops", "criteria", "tiny", "search", "search_extra", "eval", "cells", "criteria2"] + \
+    todo = a.only.split(",") if a.only else ["ops", "criteria", "tiny", "search", "search_extra", "search_eval", "eval", "cells", "criteria2"] + \
         (["full", "full_grads", "full_eval", "cfg4"] if a.full else [])
     for t in todo:
         {"ops": gen_ops, "criteria": gen_criteria, "tiny": gen_tiny, "full": gen_full, "search": gen_search, "eval": gen_eval,
          "cells": gen_cells, "criteria2": gen_criteria2, "cfg4": gen_cfg4, "full_grads": gen_full_grads,
-         "full_eval": gen_full_eval, "search_extra": gen_search_extra}[t]()
+         "full_eval": gen_full_eval, "search_extra": gen_search_extra, "search_eval": gen_search_eval}[t]()

@@ -1,0 +1,39 @@
+"""bench.py's per-rank supervisor (N > 1 runs: VERDICT r2 item 6a) without a GPU: a worker that stops making progress is
+ended (by its own PID) and replaced by a fresh `--graph 0` worker whose record carries `fallback`; a worker lost AFTER it
+has written its record does not cost the measurement; a healthy worker's line is relayed unchanged."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(fake, timeout=60):
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29731",
+               NPP_BENCH_FAKE_WORKER=fake, NPP_BENCH_STALL_S="2", NPP_BENCH_STALL_FIRST_S="2")
+    env.pop("NPP_BENCH_WORKER", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_healthy_worker_is_relayed():
+    r, rec = _run("ok")
+    assert r.returncode == 0 and rec["attempt"] == 0 and "fallback" not in rec
+
+
+@pytest.mark.parametrize("fake", ["hang", "crash"])
+def test_stalled_or_dead_worker_is_replaced_by_an_eager_one(fake):
+    r, rec = _run(fake)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert rec["attempt"] == 1 and rec["graph_arg"] == 0 and "fallback" in rec
+    assert "supervisor" in r.stderr
+
+
+def test_worker_lost_after_its_record_keeps_the_record():
+    r, rec = _run("late_hang")
+    assert r.returncode == 0 and rec["attempt"] == 0

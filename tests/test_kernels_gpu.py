@@ -117,6 +117,75 @@ def test_conv_fwd_bwd(case, dtype, tol):
         assert rel_err(b.grad.cpu().numpy(), br.grad.numpy()) < tol
 
 
+# The shapes bench.py actually runs on the LDS-DMA kernels (BASELINE config 2: N = 16, 96 x 96 maps; models/model_augment.py:
+# 332-351, 371-391): compared with the f32 torch-CPU conv on the same bf16-rounded operands -- forward with input ReLU, bias and the
+# statistics epilogue, the data gradient THROUGH THE PRODUCER'S BIT-MASK (NPP_MASK8), the weight gradient both as an immediate
+# launch and through the deferred batched launch of TrainStep.
+BENCH_CASES = [
+    # cin, cout, k, family the fwd + dgrad launches must be counted under, fwd+dgrad launches
+    (1024, 512, 1, "conv_g8"),     # pose_layer / par_layer: 16 K-tiles, BN = 256
+    (1024, 384, 1, "conv_g8"),     # pose_auxlayer / edge_layer: 384 % 256 != 0 -> the narrower template
+    (512, 256, 1, "conv_g8"),      # pose_head / par_head first conv
+    (512, 128, 1, "conv_g4"),      # PoseCell1 / ParCell1 preprocess (HBM-bound, persistent 128 x 128 tiles)
+    (384, 128, 3, "conv_g4"),      # pose_auxnet (conv_h3, three channel tiles; reports under conv_g4's family)
+    (128, 128, 3, "conv_g4"),      # the 30 refine-cell convs (conv_h3)
+]
+
+
+@pytest.mark.parametrize("batched_wgrad", [False, True])
+@pytest.mark.parametrize("case", BENCH_CASES)
+def test_benched_shapes_match_cpu_reference(case, batched_wgrad):
+    import ctypes as C
+    from npp_amd import _ops as K
+    from npp_amd import _lib
+    cin, cout, k, fam = case
+    N, H, W = 16, 96, 96
+    tol = 3e-2
+    dev = _dev()
+    x_cpu = _rand((N, cin, H, W), 21).bfloat16().float()
+    w_cpu = _rand((cout, cin, k, k), 22) * (1.0 / np.sqrt(cin * k * k))
+    b_cpu = _rand((cout,), 23)
+    xr = x_cpu.clone().requires_grad_(True)
+    wr = w_cpu.clone().requires_grad_(True)
+    br = b_cpu.clone().requires_grad_(True)
+    yr = F.conv2d(F.relu(xr), wr.bfloat16().float(), br, 1, k // 2, 1)
+    gy_cpu = _rand(tuple(yr.shape), 24).bfloat16().float()
+    yr.backward(gy_cpu)
+
+    x0 = _to_dev(x_cpu, torch.bfloat16).detach().requires_grad_(True)
+    x = K.bn_add(K.BnSide(x0))                 # a producer that leaves the ReLU bit-mask of its output (as every cell node does)
+    assert K.relu_mask_of(x) is not None
+    w = w_cpu.to(dev).requires_grad_(True)
+    b = b_cpu.to(dev).requires_grad_(True)
+    L = _lib.lib()
+    masks_before = K.MASK_STATS[0]
+    old = (K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK)
+    try:
+        if batched_wgrad:
+            K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK = 1 << 30, True
+        L.npp_prof_begin(_lib.FAM[fam], _lib.NPP_BF16)
+        y, st = K.conv2d(x, w, b, 1, k // 2, 1, relu_in=True, want_stats=True)
+        y.backward(_to_dev(gy_cpu, torch.bfloat16))
+        if batched_wgrad:
+            K.flush_wgrads()
+            K.flush_unpacks()
+        torch.cuda.synchronize()
+        ms, fl, by, nl = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        L.npp_prof_end(C.byref(ms), C.byref(fl), C.byref(by), C.byref(nl))
+    finally:
+        K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK = old
+        K.drop_pending()
+    assert nl.value == 2, f"{fam}: {nl.value} launches for fwd + dgrad"
+    assert K.MASK_STATS[0] == masks_before + 1, "the data gradient did not read the bit-mask"
+    yf = y.detach().float().cpu()
+    assert rel_err(yf.numpy(), yr.detach().numpy()) < tol
+    s_ref = torch.cat([yf.double().sum((0, 2, 3)), (yf.double() ** 2).sum((0, 2, 3))])
+    assert rel_err(st.view(-1, 2 * cout).sum(0).cpu().numpy(), s_ref.numpy()) < 1e-5
+    assert rel_err(x0.grad.float().cpu().numpy(), xr.grad.numpy()) < tol
+    assert rel_err(w.grad.cpu().numpy(), wr.grad.numpy()) < tol
+    assert rel_err(b.grad.cpu().numpy(), br.grad.numpy()) < tol
+
+
 def _g8_launch_count(cin, cout, k, fam="conv_g8", hw=192):
     """fwd + dgrad of one conv in bf16 -> number of launches of the given conv kernel family (profiler family counter)."""
     import ctypes as C
@@ -230,6 +299,46 @@ def test_bilinear_fwd_bwd(C, hin, hout, dtype, tol):
     torch.cuda.synchronize()
     assert rel_err(y.detach().float().cpu().numpy(), yr.detach().numpy()) < tol
     assert rel_err(x.grad.float().cpu().numpy(), xr.grad.numpy()) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C,H,W,N", [(32, 24, 24, 2), (64, 13, 17, 3), (256, 12, 12, 16), (128, 96, 96, 2), (512, 6, 6, 2), (20, 9, 9, 2)])
+def test_se_gate_matches_torch_and_is_reproducible(C, H, W, N, dtype, tol):
+    """SE_Block's gate (operations.py:118-123) on the two-launch kernels of se.hip vs plain torch: output, dx and the four
+    parameter gradients; two runs give bit-identical results (slab sums in a fixed order, no float atomics)."""
+    from npp_amd import _ops as K
+    dev = _dev()
+    x_cpu = _rand((N, C, H, W), 31) + 0.3
+    if dtype == torch.bfloat16:
+        x_cpu = x_cpu.bfloat16().float()
+    w1 = _rand((C // 2, C, 1, 1), 32) * (1.0 / np.sqrt(C))
+    b1 = _rand((C // 2,), 33) * 0.1
+    w2 = _rand((C, C // 2, 1, 1), 34) * (1.0 / np.sqrt(C // 2))
+    b2 = _rand((C,), 35) * 0.1
+    gy = _rand((N, C, H, W), 36)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    ref = [t.clone().requires_grad_(True) for t in (x_cpu, w1, b1, w2, b2)]
+    g = torch.sigmoid(F.conv2d(F.relu(F.conv2d(ref[0].mean((2, 3), keepdim=True), ref[1], ref[2])), ref[3], ref[4]))
+    (ref[0] * g).backward(gy)
+    yr = (ref[0] * g).detach()
+    runs = []
+    for _ in range(2):
+        x = _to_dev(x_cpu, dtype).detach().requires_grad_(True)
+        ps = [t.to(dev).requires_grad_(True) for t in (w1, b1, w2, b2)]
+        y = K.se_scale(x, *ps)
+        y.backward(_to_dev(gy, dtype))
+        torch.cuda.synchronize()
+        runs.append([y.detach().float().cpu(), x.grad.float().cpu()] + [p.grad.cpu() for p in ps])
+    y, dx, dw1, db1, dw2, db2 = runs[0]
+    assert rel_err(y.numpy(), yr.numpy()) < tol
+    assert rel_err(dx.numpy(), ref[0].grad.numpy()) < tol
+    ptol = tol if dtype == torch.float32 else 5e-2
+    for got, r in zip((dw1, db1, dw2, db2), ref[1:]):
+        assert rel_err(got.numpy(), r.grad.numpy()) < ptol * 5
+    if C % (8 if dtype == torch.bfloat16 else 4) == 0 and K.SE_FUSED:
+        for a, b in zip(runs[0], runs[1]):
+            assert torch.equal(a, b), "SE sums are not reproducible"
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])

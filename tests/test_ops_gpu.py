@@ -530,6 +530,83 @@ def test_full_network_bf16_eval_close_to_reference(size):
         set_compute_dtype(torch.float32)
 
 
+def test_full_network_bf16_eval_batch8_runs_the_head_kernels_and_matches_oracle():
+    """C=64, 8 x 3 x 384 x 384, bf16, eval mode: at this batch the 1x1 heads (1024->512, 1024->384, 512->256 @96^2: M = 73 728)
+    run on conv_g8_kernel and the 3x3 convs of the 96^2 maps on conv_h3_kernel -- the kernels bench.py times -- which the
+    N = 1 network tests never reach (M = 9 216 goes to conv_g4).  All 8 outputs of all 8 images against the CPU oracle
+    (pinned to the reference by tests/test_oracle_golden.py), rel-L2 <= 5e-2 as at N = 1."""
+    import ctypes as C
+    from npp_amd import _lib
+    from npp_amd.model_augment import set_compute_dtype
+    from npp_amd.synth import synth_batch_hw
+    from oracle import nppnet_oracle as O
+    gf = load_golden("full_net.npz")
+    dev = _dev()
+    n, size = 8, 384
+    images, _, _, _ = synth_batch_hw(n, size, size, seed=3)
+    tensors = synth_tensors(template_from_golden(gf), 0)
+    with torch.no_grad():
+        rpose, rpar, _ = O.network_forward(tensors, torch.from_numpy(images), train=False)
+    try:
+        net = _build_net(64, torch.bfloat16, gf).eval()
+        L = _lib.lib()
+        L.npp_prof_begin(_lib.FAM["conv_g8"], _lib.NPP_BF16)
+        with torch.no_grad():
+            pose_list, par_list = net(torch.from_numpy(images).to(dev))
+        torch.cuda.synchronize()
+        ms, fl, by, nl = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        L.npp_prof_end(C.byref(ms), C.byref(fl), C.byref(by), C.byref(nl))
+        assert nl.value >= 8, f"only {nl.value} conv_g8 launches: the heads did not run on the benched kernel"
+        worst = 0.0
+        for i in range(2):
+            for nm, o, r in (("pose_map", pose_list[i][0], rpose[i][0]), ("pose_aux", pose_list[i][1], rpose[i][1]),
+                             ("par_map", par_list[i][0], rpar[i][0]), ("edge", par_list[i][1], rpar[i][1])):
+                e = rel_l2(_f32(o), r.numpy())
+                worst = max(worst, e)
+                assert e < BF16_EVAL_L2, (nm, i, e)
+        print(f"eval 8 x 384 x 384 bf16: worst output error {worst:.3e}, conv_g8 launches {nl.value}")
+    finally:
+        set_compute_dtype(torch.float32)
+
+
+def test_search_supernet_bf16_eval_close_to_reference():
+    """The supernet (config 5 is benched in bf16) in bf16, eval mode, against the reference's f32 eval outputs (search_eval.npz):
+    the in-network check of the bf16 mixed-edge / interleave kernels; f32 on the same path must stay at 1e-3."""
+    from types import SimpleNamespace as NS
+    from npp_amd.model_search_interact import Network
+    from npp_amd.model_augment import set_compute_dtype
+    g = load_golden("search_eval.npz")
+    gs = load_golden("search_net.npz")
+    dev = _dev()
+    C = int(g["C"])
+    cfg = NS(DATASET=NS(NUM_CLASSES=20, NUM_JOINTS=16), SEARCH=NS(LAYERS=16, INIT_CHANNELS=C),
+             MODEL=NS(DECONV_WITH_BIAS=False, HEAD='PSP', REFINE_LAYERS=1))
+    images, _, _, _ = synth_batch(int(g["n"]), int(g["size"]), seed=0)
+    try:
+        for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, BF16_EVAL_L2)):
+            set_compute_dtype(dtype)
+            net = Network(cfg)
+            sd = synth_tensors(template_from_golden(gs), 0)
+            for k in ["alphas1", "alphas2", "alphas3", "alphas4", "alphas_pose", "alphas_par", "betas1", "betas2", "betas3",
+                      "betas4", "betas_pose", "betas_par"]:
+                sd[k] = sd[k] * 8.0
+            net.load_state_dict(sd)
+            net = net.to(dev).eval()
+            with torch.no_grad():
+                pose_list, par_list = net(torch.from_numpy(images).to(dev))
+            worst = 0.0
+            for i in range(2):
+                for nm, o in (("pose_map", pose_list[i][0]), ("pose_aux", pose_list[i][1]), ("par_map", par_list[i][0]),
+                              ("edge", par_list[i][1])):
+                    a, b = _f32(o), g[f"eval/{nm}{i}"]
+                    e = rel_err(a, b) if dtype == torch.float32 else rel_l2(a, b)
+                    worst = max(worst, e)
+                    assert e < tol, (dtype, nm, i, e)
+            print(f"supernet eval {dtype}: worst output error {worst:.3e}")
+    finally:
+        set_compute_dtype(torch.float32)
+
+
 def test_full_network_384_bf16_train_loss_and_gradient_norms():
     """The mode bench.py times -- bf16, C=64, 384x384, train mode -- against the reference (full_net.npz): loss and all 1640
     gradient norms (see the note above for why the outputs themselves are pinned in eval mode)."""

@@ -217,6 +217,24 @@ def test_search_supernet_matches_reference():
             assert rel_err(t[pk].grad.numpy(), g[k]) < 1e-3, pk
 
 
+def test_search_supernet_eval_matches_reference():
+    """The supernet in eval mode (running statistics): oracle vs the reference's outputs (search_eval.npz, the pin of the bf16
+    supernet check of tests/test_ops_gpu.py)."""
+    g = load_golden("search_eval.npz")
+    gs = load_golden("search_net.npz")
+    t = synth_tensors(template_from_golden(gs), 0)
+    for k in ["alphas1", "alphas2", "alphas3", "alphas4", "alphas_pose", "alphas_par", "betas1", "betas2", "betas3",
+              "betas4", "betas_pose", "betas_par"]:
+        t[k] = t[k] * 8.0
+    images, _, _, _ = synth_batch(int(g["n"]), int(g["size"]), seed=0)
+    with torch.no_grad():
+        pose_list, par_list, _ = O.search_network_forward(t, torch.from_numpy(images), train=False)
+    for i in range(2):
+        for nm, o in (("pose_map", pose_list[i][0]), ("pose_aux", pose_list[i][1]), ("par_map", par_list[i][0]),
+                      ("edge", par_list[i][1])):
+            assert rel_err(o.numpy(), g[f"eval/{nm}{i}"]) < 1e-4, (nm, i)
+
+
 def test_eval_parsing_tta_confusion_matches_reference():
     """validate_sync's parsing path: oracle (flip-TTA with the reference's aliased channel swap + confusion matrix) vs the
     reference's own get_confusion_matrix on the same logits (tests/golden/eval_parsing.npz)."""
