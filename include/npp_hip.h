@@ -394,6 +394,18 @@ int npp_ce_pixel_grad_up_t(const NppTensor* logits, const int64_t* labels, const
                            NppTensor* dup, void* stream);
 /* edge class weights from label counts, core/criterion.py:161-166: w = [pos/(pos+neg), neg/(pos+neg)] */
 int npp_edge_weights(const int64_t* labels, int64_t n, double* counts /*[2] zeroed by caller*/, void* stream);
+/* The scalar tail of both criteria (core/criterion.py:139-142, 212-214): loss = sum_i [S_i * exp(-lamda_i) + lamda_i],
+ * S_i = sum over the terms of stage i of coef * acc[num_idx] / (den_idx >= 0 ? acc[den_idx] : 1), in ONE launch; it also stores
+ * scales[t] = coef * exp(-lamda_i) / den and unit[i] = 1 - S_i exp(-lamda_i).  npp_loss_tail_bwd multiplies them by the upstream
+ * gradient g[0]: gs[t] is the `gscale` of term t's backward kernel, dlam[i] the gradient of lamda_i. */
+#define NPP_LOSS_MAX_TERMS 32
+typedef struct NppLossTerm { const double* acc; int32_t num_idx, den_idx; float coef; int32_t stage; } NppLossTerm;
+int npp_loss_tail_fwd(const NppLossTerm* terms, int nterms, const float* lamda, int nstages, float* loss, float* scales,
+                      float* unit, void* stream);
+int npp_loss_tail_bwd(const float* g, const float* scales, const float* unit, int nterms, int nstages, float* gs, float* dlam,
+                      void* stream);
+/* edge class weights [pos/(pos+neg), neg/(pos+neg)] (core/criterion.py:161-166) as f32[2] on the device; counts: zeroed f64[2] */
+int npp_edge_class_weights(const int64_t* labels, int64_t n, double* counts, float* weights, void* stream);
 
 /* ---- evaluation -------------------------------------------------------------------------------
  * validate_sync's parsing path on the device (core/function.py:925-967 + utils/utils.py:190-216): counts[l*C + p] +=
@@ -449,6 +461,8 @@ int npp_adam_step(const NppAdamJob* jobs /*device*/, const int32_t* chunks /*dev
  * npp_syncbn_exchange: what nn.SyncBatchNorm's forward/backward all_reduce does (augment_lip_sync.py:191): in-place SUM of
  *   `count` f64 partial sums -- the statistics vectors of every BatchNorm gathered since the last exchange, back to back. */
 /* debugging aid: number of NaN / Inf elements of `t` (synchronises `stream`); < 0 on error */
+/* diagnostics: store the GPU's 100 MHz wall clock into buf[idx] when `stream` reaches this point (capturable) */
+int npp_stamp(uint64_t* buf, int idx, void* stream);
 int64_t npp_debug_nonfinite(const NppTensor* t, void* stream);
 
 int npp_comm_unique_id(void* id128);

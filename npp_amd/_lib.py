@@ -45,6 +45,10 @@ class NppSeGradItem(C.Structure):
                 ("dw2", C.c_void_p), ("db2", C.c_void_p), ("n", C.c_int32), ("c", C.c_int32)]
 
 
+class NppLossTerm(C.Structure):
+    _fields_ = [("acc", C.c_void_p), ("num_idx", C.c_int32), ("den_idx", C.c_int32), ("coef", C.c_float), ("stage", C.c_int32)]
+
+
 class NppBnFinalizeArgs(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
                 ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("scale_shift", C.c_void_p),
@@ -157,6 +161,10 @@ _SIGS = {
     "npp_ce_pixel_grad_up": [_T, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P],
     "npp_ce_pixel_grad_up_t": [_T, _P, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P, _T, _P],
     "npp_edge_weights": [_P, C.c_int64, _P, _P],
+    "npp_stamp": [_P, C.c_int, _P],
+    "npp_loss_tail_fwd": [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P],
+    "npp_loss_tail_bwd": [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P],
+    "npp_edge_class_weights": [_P, C.c_int64, _P, _P, _P],
     "npp_adam_step": [_P, _P, C.c_int, _P, _P],
     "npp_bilinear_bwd_ws": [_T, _T, C.c_int, _P, C.c_int64, _P],
     "npp_conv_wgrad_batchable": [_T, _T, _G],

@@ -29,6 +29,46 @@ def _byref(t):
 
 
 # --------------------------------------------------------------------------------------------------
+# phase stamps (diagnostics, NPP_STAMPS=1): GPU-side wall-clock marks at phase boundaries of the step, valid inside a captured graph
+# --------------------------------------------------------------------------------------------------
+STAMPS = None      # {"buf": int64 tensor, "names": [(name, raw stream handle)]} while collecting (tools/phase_stamps.py)
+
+
+def stamps_begin(device, n=512):
+    global STAMPS
+    STAMPS = {"buf": torch.zeros(n, dtype=torch.int64, device=device), "names": []}
+
+
+def stamp(name):
+    st = STAMPS
+    if st is None or len(st["names"]) >= st["buf"].numel():
+        return
+    idx = len(st["names"])
+    st["names"].append((name, stream_ptr()))
+    check(lib().npp_stamp(st["buf"].data_ptr(), idx, stream_ptr()), "npp_stamp")
+
+
+class _StampThrough(Function):
+    @staticmethod
+    def forward(ctx, x, name):
+        ctx.name = name
+        stamp(name + " fwd")
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        stamp(ctx.name + " bwd")
+        return g, None
+
+
+def stamp_through(x, name):
+    """Identity on `x` that stamps `name fwd` now and `name bwd` when the gradient passes (on whatever stream autograd runs it)."""
+    if STAMPS is None or not isinstance(x, torch.Tensor):
+        return x
+    return _StampThrough.apply(x, name)
+
+
+# --------------------------------------------------------------------------------------------------
 # fan-out: one-pass gradient accumulation for tensors with several consumers
 # --------------------------------------------------------------------------------------------------
 # A cell state feeds up to four ops (model_augment.py:48-62, genotypes.py:30-54); the autograd engine sums their gradients
@@ -2147,6 +2187,155 @@ class _UpsampledCE(Function):
 
 def upsampled_ce(logits, labels, class_w, ignore=255, ohem=None):
     return _UpsampledCE.apply(take(logits), labels, class_w, int(ignore), ohem)
+
+
+# --------------------------------------------------------------------------------------------------
+# a whole criterion as ONE autograd node: every per-term kernel + the scalar tail (npp_loss_tail_*), no 0-d ATen arithmetic
+# --------------------------------------------------------------------------------------------------
+FUSED_CRITERIA = os.environ.get("NPP_FUSED_CRITERIA", "1") != "0"
+
+
+def _ce_term_fwd(logits, labels, class_w, ignore, ohem):
+    """Forward kernels of one upsampled cross-entropy term; returns (acc f64[3] = [sum, kept, weight sum], den index, saved)."""
+    logits = to_nhwc(logits)
+    n, c, h, w = logits.shape
+    H, W = labels.shape[1], labels.shape[2]
+    dev = logits.device
+    lab = labels.detach()
+    if lab.dtype != torch.int64 or not lab.is_contiguous():
+        lab = lab.long().contiguous()
+    cw = class_w.detach()
+    if cw.dtype != torch.float32 or not cw.is_contiguous():
+        cw = cw.float().contiguous()
+    npx = n * H * W
+    p_gt = torch.empty(npx, dtype=torch.float32, device=dev)
+    wnll = torch.empty(npx, dtype=torch.float32, device=dev)
+    s = stream_ptr()
+    check(lib().npp_ce_pixel_fwd(_byref(logits), lab.data_ptr(), H, W, cw.data_ptr(), ignore, p_gt.data_ptr(), wnll.data_ptr(), s),
+          "npp_ce_pixel_fwd")
+    kth = None
+    thresh = 0.0
+    if ohem is not None:
+        thresh, min_kept = ohem
+        ws = torch.empty(260, dtype=torch.int32, device=dev)
+        kth = torch.empty(2, dtype=torch.float32, device=dev)
+        check(lib().npp_kth_smallest(p_gt.data_ptr(), npx, max(1, int(min_kept)), ws.data_ptr(), kth.data_ptr(), s), "npp_kth_smallest")
+    acc = zeros_f64(3, dev)
+    check(lib().npp_ce_reduce(p_gt.data_ptr(), wnll.data_ptr(), lab.data_ptr(), cw.data_ptr(), ignore, npx, ptr(kth),
+                              float(thresh), int(ohem is not None), acc.data_ptr(), s), "npp_ce_reduce")
+    return acc, (1 if ohem is not None else 2), (logits, lab, cw, p_gt, kth, (ignore, thresh, ohem is not None, H, W))
+
+
+def _ce_term_bwd(saved, gs_ptr):
+    """Backward kernels of one cross-entropy term; gs_ptr: device f32 scalar = upstream gradient / denominator."""
+    logits, lab, cw, p_gt, kth, (ignore, thresh, use_ohem, H, W) = saved
+    n, c, h, w = logits.shape
+    s = stream_ptr()
+    vec = 8 if logits.dtype == torch.bfloat16 else 4
+    cpad = (c + vec - 1) // vec * vec
+    dup = new_nhwc(n, cpad, H, W, logits.dtype, logits.device)
+    check(lib().npp_ce_pixel_grad_up_t(_byref(logits), lab.data_ptr(), cw.data_ptr(), ignore, p_gt.data_ptr(), ptr(kth),
+                                       float(thresh), int(use_ohem), gs_ptr, _byref(dup[:, :c]), s), "npp_ce_pixel_grad_up_t")
+    dl = new_nhwc(n, cpad, h, w, logits.dtype, logits.device)
+    _bilinear_bwd(dup, dl, 1)
+    return dl[:, :c] if cpad != c else dl
+
+
+def _mse_term_fwd(pred, target, weight):
+    pred = to_nhwc(pred)
+    tgt = target.detach()
+    if tgt.dtype != torch.float32 or not tgt.is_contiguous():
+        tgt = tgt.float().contiguous()
+    wt = None
+    if weight is not None:
+        wt = weight.detach().reshape(pred.shape[0], pred.shape[1]).float().contiguous()
+    sse = zeros_f64(1, pred.device)
+    check(lib().npp_mse_w_fwd(_byref(pred), tgt.data_ptr(), ptr(wt), sse.data_ptr(), stream_ptr()), "npp_mse_fwd")
+    return sse, -1, (pred, tgt, wt)
+
+
+def _mse_term_bwd(saved, gs_ptr):
+    pred, tgt, wt = saved
+    grad = new_nhwc(*pred.shape, pred.dtype, pred.device)
+    check(lib().npp_mse_w_bwd(_byref(pred), tgt.data_ptr(), ptr(wt), gs_ptr, _byref(grad), stream_ptr()), "npp_mse_bwd")
+    return grad
+
+
+class _CriterionFused(Function):
+    """loss = sum_i [ (sum_{t in stage i} coef_t * term_t) * exp(-lamda_i) + lamda_i ]  (core/criterion.py:139-142, 212-214).
+    specs[t] = ("ce", labels, class_w, ignore, ohem, coef, stage) | ("mse", target, weight, coef, stage); xs[t] = the logits /
+    heat-map tensor of term t."""
+
+    @staticmethod
+    def forward(ctx, lamda, specs, *xs):
+        dev = xs[0].device
+        nt, ns = len(xs), int(lamda.numel())
+        terms = (L.NppLossTerm * nt)()
+        saved = []
+        keep = []
+        for k, (sp, x) in enumerate(zip(specs, xs)):
+            if sp[0] == "ce":
+                acc, den, sv = _ce_term_fwd(x, sp[1], sp[2], sp[3], sp[4])
+                coef, stage = sp[5], sp[6]
+            else:
+                acc, den, sv = _mse_term_fwd(x, sp[1], sp[2])
+                coef, stage = sp[3], sp[4]
+            terms[k] = L.NppLossTerm(acc.data_ptr(), 0, den, float(coef), int(stage))
+            saved.append((sp[0], sv))
+            keep.append(acc)
+        lam = lamda.detach()
+        if lam.dtype != torch.float32 or not lam.is_contiguous():
+            lam = lam.float().contiguous()
+        out = torch.empty(1 + nt + ns, dtype=torch.float32, device=dev)      # [loss | scales | unit]
+        check(lib().npp_loss_tail_fwd(C.cast(terms, C.c_void_p), nt, lam.data_ptr(), ns, out.data_ptr(), out[1:].data_ptr(),
+                                      out[1 + nt:].data_ptr(), stream_ptr()), "npp_loss_tail_fwd")
+        ctx.terms = saved
+        ctx.keep = keep
+        ctx.tail = out
+        ctx.counts = (nt, ns)
+        ctx.lam_meta = (lamda.shape, lamda.dtype)
+        return out[0]      # 0-d view of the buffer: no kernel
+
+    @staticmethod
+    def backward(ctx, g):
+        nt, ns = ctx.counts
+        out = ctx.tail
+        gg = g.detach()
+        if gg.dtype != torch.float32:
+            gg = gg.float()
+        gg = gg.reshape(1)
+        if not gg.is_contiguous():
+            gg = gg.contiguous()
+        gbuf = torch.empty(nt + ns, dtype=torch.float32, device=out.device)      # [gs per term | dlamda]
+        check(lib().npp_loss_tail_bwd(gg.data_ptr(), out[1:].data_ptr(), out[1 + nt:].data_ptr(), nt, ns, gbuf.data_ptr(),
+                                      gbuf[nt:].data_ptr(), stream_ptr()), "npp_loss_tail_bwd")
+        grads = []
+        for k, (kind, sv) in enumerate(ctx.terms):
+            if not ctx.needs_input_grad[2 + k]:
+                grads.append(None)
+                continue
+            gs_ptr = gbuf.data_ptr() + 4 * k
+            grads.append(_ce_term_bwd(sv, gs_ptr) if kind == "ce" else _mse_term_bwd(sv, gs_ptr))
+        dlam = gbuf[nt:].view(ctx.lam_meta[0])
+        if dlam.dtype != ctx.lam_meta[1]:
+            dlam = dlam.to(ctx.lam_meta[1])
+        ctx.keep_g = gbuf
+        return (dlam if ctx.needs_input_grad[0] else None, None) + tuple(grads)
+
+
+def criterion_fused(lamda, specs, xs):
+    return _CriterionFused.apply(lamda, tuple(specs), *[take(x) for x in xs])
+
+
+def edge_class_weights_dev(labels: torch.Tensor) -> torch.Tensor:
+    """edge_class_weights in two launches of the library (count + finish), no ATen arithmetic."""
+    lab = labels.detach()
+    if lab.dtype != torch.int64 or not lab.is_contiguous():
+        lab = lab.long().contiguous()
+    cnt = zeros_f64(2, lab.device)
+    out = torch.empty(2, dtype=torch.float32, device=lab.device)
+    check(lib().npp_edge_class_weights(lab.data_ptr(), lab.numel(), cnt.data_ptr(), out.data_ptr(), stream_ptr()), "npp_edge_class_weights")
+    return out
 
 
 def edge_class_weights(labels: torch.Tensor) -> torch.Tensor:

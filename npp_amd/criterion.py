@@ -79,12 +79,39 @@ class Criterion_pose(nn.Module):
 
     def forward(self, output, target, target_weight=None):
         loss = 0.
+        if isinstance(output, list) and K.FUSED_CRITERIA and isinstance(target, list):
+            fused = self._fused(output, target, target_weight)
+            if fused is not None:
+                return fused
         if isinstance(output, list):
             for i in range(len(output)):
                 loss = loss + self.joint_loss(output[i], target, target_weight) * torch.exp(-self.lamda[i]) + self.lamda[i]
         else:
             loss = loss + self.joint_loss(output, target, target_weight) * torch.exp(-self.lamda) + self.lamda
         return loss
+
+
+    def _fused(self, output, target, target_weight):
+        """The whole criterion as one autograd node (K.criterion_fused): every MSE term + the scalar tail, same arithmetic."""
+        specs, xs = [], []
+        wt = None
+        if self.use_target_weight:
+            if target_weight is None:
+                raise ValueError("Criterion_pose(use_target_weight=True) needs target_weight [N, num_joints, 1]")
+            wt = target_weight
+        for i, stage_out in enumerate(output):
+            outs = [stage_out[0], stage_out[1]] if isinstance(stage_out, list) else [stage_out]
+            tgts = [target[0], target[1]] if isinstance(stage_out, list) else [target[0] if isinstance(target, list) else target]
+            J = outs[0].size(1)
+            h, w = tgts[0].shape[2:]
+            for o, t in zip(outs, tgts):
+                if tuple(o.shape[2:]) != tuple(t.shape[2:]):
+                    o = K.bilinear(o, int(h), int(w), align_corners=False)
+                specs.append(("mse", t, wt, 1.0 / (float(o.size(0) * o.size(2) * o.size(3)) * J), i))
+                xs.append(o)
+        if len(xs) > 32:
+            return None
+        return K.criterion_fused(self.lamda, specs, xs)
 
 
 class Criterion_par(nn.Module):
@@ -115,8 +142,41 @@ class Criterion_par(nn.Module):
             loss = loss + self.criterion(preds, target[0])
         return loss
 
+    def _fused(self, preds, target):
+        """The whole criterion as one autograd node (K.criterion_fused)."""
+        crit = self.criterion
+        cw = crit.class_weight
+        if cw.device != target[0].device:
+            cw = cw.to(target[0].device)
+            crit.class_weight = cw
+        edge_w = K.edge_class_weights_dev(target[1])
+        specs, xs = [], []
+        ohem = (crit.thresh, crit.min_kept)
+        for i, p in enumerate(preds):
+            if isinstance(p, list):
+                par = p[0]
+                if isinstance(par, list):
+                    specs += [("ce", target[0], cw, crit.ignore_index, ohem, 1.0, i), ("ce", target[0], cw, crit.ignore_index, ohem, 0.4, i)]
+                    xs += [par[0], par[1]]
+                else:
+                    specs.append(("ce", target[0], cw, crit.ignore_index, ohem, 1.0, i))
+                    xs.append(par)
+                for e in (p[1] if isinstance(p[1], list) else [p[1]]):
+                    specs.append(("ce", target[1], edge_w, self.ignore_index, None, 1.0, i))
+                    xs.append(e)
+            else:
+                specs.append(("ce", target[0], cw, crit.ignore_index, ohem, 1.0, i))
+                xs.append(p)
+        if len(xs) > 32:
+            return None
+        return K.criterion_fused(self.lamda, specs, xs)
+
     def forward(self, preds, target):
         loss = 0.
+        if isinstance(preds, list) and K.FUSED_CRITERIA and target[0].is_cuda:
+            fused = self._fused(preds, target)
+            if fused is not None:
+                return fused
         if isinstance(preds, list):
             edge_w = K.edge_class_weights(target[1])
             for i in range(len(preds)):

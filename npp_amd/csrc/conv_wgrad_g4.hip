@@ -213,12 +213,239 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Ex
   wg4_body<RELU, TAPS, R>(p, e, (int)blockIdx.x);
 }
 
+
+// ---- 3x3 layers with Cin, Cout % 128 == 0: THREE horizontal taps per workgroup (round 3) ----------------------------------------
+// The 128 x 128 kernel above stages 32 KiB per K-tile for 32 MFMAs per wave and is bound by the L2 -> LDS DMA rate (~65 GB/s per CU:
+// 4.2 TFLOP/s per CU at best, measured 0.27-0.31 MFMA-pipe utilisation).  Here a workgroup owns 128 output channels x 128 input
+// channels of ALL THREE taps of one kernel row kh: the dy tile [64 px][128 co] is shared by the three taps and so is the x tile --
+// the taps kw = 0, 1, 2 read the SAME pixel-major LDS image one row apart ([66 px][128 ci]: pixel q0 - 1 .. q0 + 64 of the
+// flattened pixel axis, shifted by (kh - 1) image rows; out-of-image rows are out-of-range DMA offsets = zeros).  34 KiB per K-tile
+// for 96 MFMAs per wave: 3x the arithmetic per staged byte.  A row of the flattened axis that wraps around an image row (output
+// pixel x == 0 for the left tap, x == W - 1 for the right tap) is removed by AND-masks on the transposed B fragments, computed per
+// lane from the K-tile's first x coordinate (4 consecutive pixels of a fragment half hold at most one border pixel, W >= 4).
+// Accumulators 3 x 64 x 64 per wave (192 registers): one workgroup per CU, ring of 3 K-tile buffers.
+struct WG3Extra {
+  int HW;
+  int cintiles;          // Cin / 128
+  int ktiles_per_split, nktiles;
+  int ntiles, nblocks;   // output tiles = rowtiles * 3 * cintiles; blocks = ntiles * pixel splits
+  unsigned xbytes, dybytes;
+};
+
+template <bool RELU, int R>
+NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
+  constexpr int XOFF = 16384;            // x image behind the dy tile
+  constexpr int KT = 16384 + 18 * 1024;  // dy [64 px][256 B] + x [72 rows][256 B] (rows 0 .. 65 used)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
+  const auto rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, e.dybytes, 0x00020000);
+
+  const int xcd = bid & 7, qd = e.nblocks >> 3, rm = e.nblocks & 7;
+  const int work = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  const int split = work / e.ntiles, tile = work - split * e.ntiles;
+  const int cotile = tile % p.rowtiles, coltile = tile / p.rowtiles;      // coltile = kh * cintiles + citile
+  const int kh = coltile / e.cintiles, citile = coltile - kh * e.cintiles;
+  const int co0 = cotile * 128, ci0 = citile * 128;
+  const int dyr = kh - 1;                                                 // input row = output row + dyr
+  const int kt_begin = split * e.ktiles_per_split;
+  int kt_end = kt_begin + e.ktiles_per_split;
+  if (kt_end > e.nktiles) kt_end = e.nktiles;
+  if (kt_begin >= kt_end) return;
+
+  // ---- staging: dy pieces 4w .. 4w+3 (4 rows x 256 B each); x pieces w, w+4, w+8, w+12 (+ piece 16 and 17 on waves 0 and 1) ----
+  const int srow = lane >> 4, slot = lane & 15;
+  unsigned dyb[4];
+  int dpix[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 4 + srow;
+    const int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    const int q = kt_begin * 64 + row;
+    dpix[j] = q;
+    dyb[j] = (unsigned)q * (unsigned)p.ldy * 2u + (unsigned)(co0 * 2 + chunk * 16);
+  }
+  unsigned xb[5];
+  int xpix[5], xyx[5];         // xpix: flattened OUTPUT-aligned pixel of the row (q0 - 1 + r); xyx: (y << 16) | x of that pixel
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int piece = j < 4 ? wave + 4 * j : 16 + wave;      // (piece 16 / 17: waves 0 / 1 only)
+    const int row = piece * 4 + srow;
+    const int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    const int q = kt_begin * 64 - 1 + row;
+    xpix[j] = q;
+    const int qq = q < 0 ? q + e.HW : q;                     // (pixel -1: its coordinates are never used, it is zero-filled)
+    const int rem = qq % e.HW, y = rem / p.W;
+    xyx[j] = (y << 16) | (rem - y * p.W);
+    xb[j] = (unsigned)(q + dyr * p.W) * (unsigned)p.ldx * 2u + (unsigned)((ci0 + chunk * 8) * 2);
+  }
+  const unsigned dy_step = 64u * (unsigned)p.ldy * 2u, x_step = 64u * (unsigned)p.ldx * 2u;
+  const int adv_y = 64 / p.W, adv_x = 64 - adv_y * p.W;
+  const bool extra = wave < 2;
+  auto issue = [&](int slot_) {
+    const int lb = slot_ * KT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool live = dpix[j] < p.P;
+      WG4_DMA(rs_dy, live ? dyb[j] : 0xFFFFFFFFu, lb + (wave * 4 + j) * 1024);
+      dpix[j] += 64; dyb[j] += dy_step;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (j == 4 && !extra) break;
+      const int piece = j < 4 ? wave + 4 * j : 16 + wave;
+      const int y = (xyx[j] >> 16) + dyr;
+      const bool ok = xpix[j] >= 0 && xpix[j] < p.P && (unsigned)y < (unsigned)p.H;
+      WG4_DMA(rs_x, ok ? xb[j] : 0xFFFFFFFFu, lb + XOFF + piece * 1024);
+      // advance by one K-tile (64 pixels)
+      xpix[j] += 64;
+      xb[j] += x_step;
+      int yy = (xyx[j] >> 16) + adv_y, xx = (xyx[j] & 0xFFFF) + adv_x;
+      if (xx >= p.W) { xx -= p.W; ++yy; }
+      while (yy >= p.H) yy -= p.H;
+      xyx[j] = (yy << 16) | xx;
+    }
+  };
+
+  // ---- transposed fragment reads (see wg4_body); B of tap s reads row s + k of the x image ------------------------------------
+  const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pq = i16 & 3;
+  unsigned offA[4][2], offB[3][4][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = g * 8 + h * 4 + q4;                       // + ks*32
+    const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) offA[f][h] = 256 * row + 16 * (((wm * 8 + f * 2 + (pq >> 1)) ^ sw)) + 8 * (pq & 1);
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+      const int rb = row + s3;
+      const int swb = ((rb & 3) << 2) | ((rb >> 2) & 3);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) offB[s3][f][h] = XOFF + 256 * rb + 16 * (((wn * 8 + f * 2 + (pq >> 1)) ^ swb)) + 8 * (pq & 1);
+    }
+  }
+  // x coordinate (mod W) of the lane's first pixel of each (ks, half): k0 = ks*32 + g*8 + h*4
+  int c0[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) c0[ks][h] = (ks * 32 + g * 8 + h * 4) % p.W;
+  int xq0 = (kt_begin * 64) % p.W;               // x coordinate of the K-tile's first pixel
+  const int xadv = 64 % p.W;
+
+  f32x4g acc[3][4][4];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[s3][mi][ni] = f32x4g{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = kt_end - kt_begin;
+  int s_slot = 0, c_slot = 0;
+  for (int i = 0; i < R - 1 && i < nk; ++i) { issue(s_slot); if (++s_slot == R) s_slot = 0; }
+  for (int kt = 0; kt < nk; ++kt) {
+    // every wave has issued the same number of DMA instructions per K-tile except the two "extra" waves (9 vs 8): wait for all but the
+    // K-tiles still allowed in flight
+    if (R > 2 && kt + R - 1 <= nk) {
+      if (extra) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(9 * (R > 2 ? R - 2 : 0)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (R > 2 ? R - 2 : 0)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + R - 1 < nk) { issue(s_slot); if (++s_slot == R) s_slot = 0; }
+    const unsigned ro = (unsigned)c_slot * KT;
+    if (++c_slot == R) c_slot = 0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // border masks of this lane's 2 x 4 pixels: 64-bit AND-masks over the 4 bf16 of a fragment half
+      unsigned long long mL[2], mR[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int x0 = xq0 + c0[ks][h];
+        if (x0 >= p.W) x0 -= p.W;
+        const int zl = x0 == 0 ? 0 : p.W - x0;             // element whose x == 0 (>= 4: none)
+        const int zr = p.W - 1 - x0;                       // element whose x == W - 1
+        mL[h] = zl < 4 ? ~(0xFFFFull << (16 * zl)) : ~0ull;
+        mR[h] = zr < 4 ? ~(0xFFFFull << (16 * zr)) : ~0ull;
+      }
+      s16x8 fa[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offA[f][0] + ks * 8192));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offA[f][1] + ks * 8192));
+        fa[f] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        s16x8 fb[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offB[s3][f][0] + ks * 8192));
+          s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offB[s3][f][1] + ks * 8192));
+          if (s3 == 0) {
+            b0 = __builtin_bit_cast(s16x4, __builtin_bit_cast(unsigned long long, b0) & mL[0]);
+            b1 = __builtin_bit_cast(s16x4, __builtin_bit_cast(unsigned long long, b1) & mL[1]);
+          } else if (s3 == 2) {
+            b0 = __builtin_bit_cast(s16x4, __builtin_bit_cast(unsigned long long, b0) & mR[0]);
+            b1 = __builtin_bit_cast(s16x4, __builtin_bit_cast(unsigned long long, b1) & mR[1]);
+          }
+          s16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+          if (RELU) {
+            const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            b = __builtin_elementwise_max(b, z);
+          }
+          fb[f] = b;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[s3][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]),
+                                                                     acc[s3][mi][ni], 0, 0, 0);
+      }
+    }
+    xq0 += xadv;
+    if (xq0 >= p.W) xq0 -= p.W;
+  }
+
+  // ---- epilogue: tap (kh, s3) -> packed columns (kh*3 + s3) * Cin + ci0 + wn*64 + ... (see wg4_body) ---------------------------
+  const int half = lane >> 5, gg = (lane >> 4) & 1;
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) {
+    const int colbase = (kh * 3 + s3) * p.Cin + ci0 + wn * 64;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[s3][mi][2 * nb][j]), __float_as_uint(acc[s3][mi][2 * nb + 1][j]),
+                                                           false, false);
+          const int col = colbase + (2 * nb + half) * 16 + i16;
+          const int row0 = co0 + wm * 64 + mi * 16 + gg * 4 + j;
+          if (row0 < p.Cout) atomicAdd(p.dwp + (long)row0 * p.Kpad + col, __uint_as_float(sw[0]));
+          if (row0 + 8 < p.Cout) atomicAdd(p.dwp + (long)(row0 + 8) * p.Kpad + col, __uint_as_float(sw[1]));
+        }
+  }
+}
+
+template <bool RELU, int R>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_g3_kernel(WgradParams p, WG3Extra e) {
+  wg3_body<RELU, R>(p, e, (int)blockIdx.x);
+}
+
 // Many small weight-gradient problems in ONE launch (npp_conv_wgrad_batched): block b works on job block_job[b] with the block id it
 // would have had in that job's own launch.  The small-map layers (12^2 / 24^2: ~100 blocks and ~25 us of latency each, 140 of them
 // per step) have no reader before the optimizer; run together at the end of backward they are throughput-, not latency-bound.
 struct WG4Job {
   WgradParams p;
   WG4Extra e;
+  WG3Extra e3;           // (the three-tap kernel's view of the same problem: variants 4, 5)
   int first_block, _pad;
 };
 
@@ -229,6 +456,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_batched_kernel(const WG4Job
   const WgradParams p = jb->p;
   const WG4Extra e = jb->e;
   wg4_body<RELU, TAPS, R>(p, e, (int)blockIdx.x - jb->first_block);
+}
+
+template <bool RELU, int R>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_g3_batched_kernel(const WG4Job* __restrict__ jobs, const int* __restrict__ block_job) {
+  const int j = __builtin_amdgcn_readfirstlane(block_job[blockIdx.x]);
+  const WG4Job* jb = jobs + j;
+  const WgradParams p = jb->p;
+  const WG3Extra e = jb->e3;
+  wg3_body<RELU, R>(p, e, (int)blockIdx.x - jb->first_block);
 }
 
 bool wg4_raise_lds(const void* fp, size_t bytes) {
@@ -292,8 +528,62 @@ static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradPa
   return true;
 }
 
+// the three-tap kernel: 3x3, Cin and Cout multiples of 128.  max_blocks: the slots this problem may fill (256 = one workgroup per CU)
+static bool wg3_prepare(const WgradParams& p, int dtype, int max_blocks, WgradParams& q, WG3Extra& e, int& nblocks) {
+  // OPT-IN (NPP_WG3=1).  Measured on MI355X (tools/wgrad_time.py, N = 16, us, this kernel at 256 workgroups vs the 128 x 128 kernel):
+  // 128->128 @96^2 116 vs 83, 384->128 225 vs 191, 256->256 @48^2 102 vs 85, 512->512 @24^2 100 vs 88, 256->256 @12^2 42 vs 26 --
+  // slower on every shape although it stages a third of the bytes per MFMA: with 394 registers there is ONE wave per SIMD, and a
+  // wave alone cannot overlap its DMA issue, its 64 transposed reads and its 96 MFMAs per K-tile (2.9 us per K-tile against
+  // 0.64 us of MFMA time); the 128 x 128 kernel's two co-resident workgroups do.  Kept for the record and for the exactness test.
+  static const bool enabled = getenv("NPP_WG3") != nullptr && atoi(getenv("NPP_WG3")) != 0;
+  if (!enabled || dtype != NPP_BF16) return false;
+  if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.KH != 3 || p.KW != 3) return false;
+  if (p.ph != 1 || p.pw != 1 || p.OH != p.H || p.OW != p.W) return false;
+  if (p.Cin % 128 != 0 || p.Cout % 128 != 0 || p.Cp != p.Cin || !p.vec_dy || p.ldx % 8 != 0 || p.ldy % 8 != 0) return false;
+  if (p.W < 4 || p.H >= 16384 || p.W >= 16384) return false;
+  if ((long)p.P * p.ldx * 2 >= (1L << 32) - (1L << 24) || (long)p.P * p.ldy * 2 >= (1L << 32) - (1L << 24)) return false;
+  e.HW = p.H * p.W;
+  e.cintiles = p.Cin / 128;
+  e.nktiles = (p.P + 63) / 64;
+  e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
+  e.dybytes = (unsigned)((long)p.P * p.ldy * 2);
+  q = p;
+  q.rowtiles = p.Cout / 128;
+  const int tiles = q.rowtiles * 3 * e.cintiles;
+  // pixel splits: every workgroup ends with 192 KiB of atomics (3 taps x 64 KiB); as wg4_prepare, balance them against the K loop:
+  // S ~ sqrt(10 * K-tiles / (3 * tiles)), never more workgroups than slots
+  static const int force_blocks = getenv("NPP_WG3_BLOCKS") ? atoi(getenv("NPP_WG3_BLOCKS")) : 0;
+  int splits = 1;
+  while ((long)(splits + 1) * (splits + 1) * tiles * 3 <= 10L * e.nktiles) ++splits;
+  if (force_blocks > 0) splits = (force_blocks + tiles - 1) / tiles;
+  if (splits > max_blocks / tiles) splits = max_blocks / tiles;
+  if (splits < 1) splits = 1;
+  if (splits > e.nktiles) splits = e.nktiles;
+  e.ktiles_per_split = (e.nktiles + splits - 1) / splits;
+  splits = (e.nktiles + e.ktiles_per_split - 1) / e.ktiles_per_split;
+  e.ntiles = tiles; e.nblocks = tiles * splits;
+  nblocks = tiles * splits;
+  return tiles <= max_blocks;
+}
+
+constexpr size_t WG3_LDS = 3 * (16384 + 18 * 1024);
+
 bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   WgradParams q;
+  {
+    WG3Extra e3;
+    int nb3 = 0;
+    if (wg3_prepare(p, dtype, 256, q, e3, nb3)) {
+      if (p.relu_in) {
+        if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g3_kernel<true, 3>), WG3_LDS)) return false;
+        hipLaunchKernelGGL((conv_wgrad_g3_kernel<true, 3>), dim3(nb3), dim3(256), WG3_LDS, stream, q, e3);
+      } else {
+        if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g3_kernel<false, 3>), WG3_LDS)) return false;
+        hipLaunchKernelGGL((conv_wgrad_g3_kernel<false, 3>), dim3(nb3), dim3(256), WG3_LDS, stream, q, e3);
+      }
+      return true;
+    }
+  }
   WG4Extra e;
   int nblocks = 0;
   if (!wg4_prepare(p, dtype, 512, q, e, nblocks)) return false;
@@ -327,6 +617,15 @@ size_t conv_wgrad_g4_job_bytes() { return sizeof(WG4Job); }
 bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_host, int slot, int max_blocks, int* variant, int* nblocks) {
   WG4Job* jb = reinterpret_cast<WG4Job*>(jobs_host) + slot;
   int nb = 0;
+  memset(&jb->e3, 0, sizeof(jb->e3));
+  // (a job of the three-tap kernel may take half the slots of a 128 x 128 job: one workgroup per CU instead of two)
+  if (wg3_prepare(p, dtype, max_blocks / 2 > 0 ? max_blocks / 2 : 1, jb->p, jb->e3, nb)) {
+    memset(&jb->e, 0, sizeof(jb->e));
+    jb->first_block = 0; jb->_pad = 0;
+    *variant = 4 | (p.relu_in ? 1 : 0);
+    *nblocks = nb;
+    return true;
+  }
   if (!wg4_prepare(p, dtype, max_blocks, jb->p, jb->e, nb, true) || nb > max_blocks) return false;
   jb->first_block = 0; jb->_pad = 0;
   *variant = (p.relu_in ? 1 : 0) | (jb->e.P > 0 ? 2 : 0);
@@ -338,14 +637,15 @@ bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_hos
 bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, int* map_host, const int* map_dev, const int* variant_of,
                                 const int* blocks_of, hipStream_t stream) {
   WG4Job* jobs = reinterpret_cast<WG4Job*>(jobs_host);
-  long off[5] = {0, 0, 0, 0, 0};
+  long off[7] = {0, 0, 0, 0, 0, 0, 0};
   // longest blocks first (blocks of one launch start in block-id order): the tail of a launch is then made of short blocks
   std::vector<int> order(n);
   for (int i = 0; i < n; ++i) order[i] = i;
   static const bool lpt = !(getenv("NPP_WGB_SORT") && atoi(getenv("NPP_WGB_SORT")) == 0);
+  auto klen = [&](int a) { return variant_of[a] >= 4 ? 3 * jobs[a].e3.ktiles_per_split : jobs[a].e.ktiles_per_split; };
   if (lpt)
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return jobs[a].e.ktiles_per_split > jobs[b].e.ktiles_per_split; });
-  for (int v = 0; v < 4; ++v) {
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return klen(a) > klen(b); });
+  for (int v = 0; v < 6; ++v) {
     long cnt = 0;
     for (int k = 0; k < n; ++k) {
       const int i = order[k];
@@ -357,9 +657,9 @@ bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, in
     }
     off[v + 1] = off[v] + cnt;
   }
-  if (off[4] == 0) return true;
+  if (off[6] == 0) return true;
   if (hipMemcpyAsync(const_cast<void*>(jobs_dev), jobs_host, (size_t)n * sizeof(WG4Job), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
-  if (hipMemcpyAsync(const_cast<int*>(map_dev), map_host, (size_t)off[4] * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
+  if (hipMemcpyAsync(const_cast<int*>(map_dev), map_host, (size_t)off[6] * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
   const WG4Job* jd = reinterpret_cast<const WG4Job*>(jobs_dev);
 #define WG4_BATCH(V_, RELU_, TAPS_)                                                                                                \
   if (off[V_ + 1] > off[V_]) {                                                                                                     \
@@ -368,6 +668,16 @@ bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, in
     hipLaunchKernelGGL((conv_wgrad_g4_batched_kernel<RELU_, TAPS_, 2>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(256), lds, stream, \
                        jd, map_dev + off[V_]);                                                                                     \
   }
+  // the three-tap jobs first: their workgroups are the longest of the step
+#define WG3_BATCH(V_, RELU_)                                                                                                       \
+  if (off[V_ + 1] > off[V_]) {                                                                                                     \
+    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g3_batched_kernel<RELU_, 3>), WG3_LDS)) return false;               \
+    hipLaunchKernelGGL((conv_wgrad_g3_batched_kernel<RELU_, 3>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(256), WG3_LDS, stream, \
+                       jd, map_dev + off[V_]);                                                                                     \
+  }
+  WG3_BATCH(4, false)
+  WG3_BATCH(5, true)
+#undef WG3_BATCH
   WG4_BATCH(0, false, false)
   WG4_BATCH(1, true, false)
   WG4_BATCH(2, false, true)

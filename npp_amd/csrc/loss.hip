@@ -494,3 +494,79 @@ extern "C" int npp_edge_weights(const int64_t* labels, int64_t n, double* counts
                      (const long*)labels, (long)n, counts);
   return npp_check_launch("edge_weights");
 }
+
+// ---- scalar tail of the criteria (core/criterion.py:139-142, 212-214) in two 1-thread kernels ---------------------------------
+//   loss = sum_i [ (sum_{t in stage i} coef_t * num_t / den_t) * exp(-lamda_i) + lamda_i ]
+// forward also stores what backward needs: scale_t = coef_t * exp(-lamda_i) / den_t and unit_i = 1 - S_i * exp(-lamda_i);
+// backward multiplies by the upstream gradient: gs_t (read by the per-term backward kernels as their `gscale`) and dlamda_i.
+// Replaces ~100 zero-dimensional ATen launches per step (index, neg, exp, mul, add, div and their autograd twins).
+namespace {
+struct LossTerms { NppLossTerm t[NPP_LOSS_MAX_TERMS]; };
+
+__global__ void loss_tail_fwd_kernel(LossTerms terms, int nterms, const float* __restrict__ lamda, int nstages,
+                                     float* __restrict__ loss, float* __restrict__ scales, float* __restrict__ unit) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double total = 0.0;
+  for (int i = 0; i < nstages; ++i) {
+    const double lam = (double)lamda[i], e = exp(-lam);
+    double S = 0.0;
+    for (int k = 0; k < nterms; ++k) {
+      const NppLossTerm& t = terms.t[k];
+      if (t.stage != i) continue;
+      const double den = t.den_idx >= 0 ? t.acc[t.den_idx] : 1.0;
+      S += (double)t.coef * t.acc[t.num_idx] / den;
+      scales[k] = (float)((double)t.coef * e / den);
+    }
+    unit[i] = (float)(1.0 - S * e);
+    total += S * e + lam;
+  }
+  loss[0] = (float)total;
+}
+
+__global__ void loss_tail_bwd_kernel(const float* __restrict__ g, const float* __restrict__ scales, const float* __restrict__ unit,
+                                     int nterms, int nstages, float* __restrict__ gs, float* __restrict__ dlam) {
+  const int i = threadIdx.x;
+  const float gg = g[0];
+  if (i < nterms) gs[i] = gg * scales[i];
+  if (i < nstages) dlam[i] = gg * unit[i];
+}
+
+__global__ void edge_weights_finish_kernel(const double* __restrict__ cnt, float* __restrict__ out) {
+  const double tot = cnt[0] + cnt[1];
+  out[0] = (float)(cnt[1] / tot);
+  out[1] = (float)(cnt[0] / tot);
+}
+}  // namespace
+
+extern "C" int npp_loss_tail_fwd(const NppLossTerm* terms, int nterms, const float* lamda, int nstages, float* loss, float* scales,
+                                 float* unit, void* stream) {
+  NPP_REQUIRE(terms && lamda && loss && scales && unit, NPP_E_NULL, "npp_loss_tail_fwd: null pointer");
+  NPP_REQUIRE(nterms > 0 && nterms <= NPP_LOSS_MAX_TERMS && nstages > 0 && nstages <= 64, NPP_E_SHAPE,
+              "npp_loss_tail_fwd: %d terms / %d stages", nterms, nstages);
+  LossTerms lt;
+  memset(&lt, 0, sizeof(lt));
+  for (int k = 0; k < nterms; ++k) {
+    NPP_REQUIRE(terms[k].acc && terms[k].num_idx >= 0 && terms[k].stage >= 0 && terms[k].stage < nstages, NPP_E_SHAPE,
+                "npp_loss_tail_fwd: bad term %d", k);
+    lt.t[k] = terms[k];
+  }
+  hipLaunchKernelGGL(loss_tail_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lt, nterms, lamda, nstages, loss, scales, unit);
+  return npp_check_launch("loss_tail_fwd");
+}
+
+extern "C" int npp_loss_tail_bwd(const float* g, const float* scales, const float* unit, int nterms, int nstages, float* gs, float* dlam,
+                                 void* stream) {
+  NPP_REQUIRE(g && scales && unit && gs && dlam, NPP_E_NULL, "npp_loss_tail_bwd: null pointer");
+  NPP_REQUIRE(nterms > 0 && nterms <= NPP_LOSS_MAX_TERMS && nstages > 0 && nstages <= 64, NPP_E_SHAPE, "npp_loss_tail_bwd: bad counts");
+  hipLaunchKernelGGL(loss_tail_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g, scales, unit, nterms, nstages, gs, dlam);
+  return npp_check_launch("loss_tail_bwd");
+}
+
+// [pos / (pos + neg), neg / (pos + neg)] of an edge label map (core/criterion.py:161-166): counts (zeroed f64[2]) -> f32[2]
+extern "C" int npp_edge_class_weights(const int64_t* labels, int64_t n, double* counts, float* weights, void* stream) {
+  NPP_REQUIRE(labels && counts && weights && n > 0, NPP_E_NULL, "npp_edge_class_weights: bad arguments");
+  hipLaunchKernelGGL(edge_count_kernel, dim3(grid_for(n, 256 * 4, 1024)), dim3(256), 0, (hipStream_t)stream,
+                     (const long*)labels, (long)n, counts);
+  hipLaunchKernelGGL(edge_weights_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const double*)counts, weights);
+  return npp_check_launch("edge_class_weights");
+}

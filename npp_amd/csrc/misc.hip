@@ -582,3 +582,18 @@ extern "C" int64_t npp_debug_nonfinite(const NppTensor* t, void* stream) {
   if (hipStreamSynchronize(s) != hipSuccess) return -5;
   return (int64_t)host;
 }
+
+
+// ---- phase stamps (NPP_STAMPS=1, tools/phase_stamps.py): one thread stores the 100 MHz wall clock into buf[idx].  A kernel launch
+// like any other: it can sit inside a captured hipGraph and tells when its stream reached this point in an UNPROFILED replay.
+namespace {
+__global__ void stamp_kernel(unsigned long long* __restrict__ buf, int idx) {
+  if (threadIdx.x == 0) buf[idx] = __builtin_amdgcn_s_memrealtime();
+}
+}  // namespace
+
+extern "C" int npp_stamp(uint64_t* buf, int idx, void* stream) {
+  NPP_REQUIRE(buf && idx >= 0, NPP_E_NULL, "npp_stamp: bad arguments");
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(buf), idx);
+  return npp_check_launch("stamp");
+}

@@ -570,8 +570,10 @@ class Network(nn.Module):
         meet(x)
         with on_a():
             s1 = self.stem2(s0 := self.stem1(self.stem0(x)))
+            s1 = K.stamp_through(s1, "A stems")
         with on_b():
             s3 = self.stem5(s2 := self.stem4(self.stem3(x)))
+            s3 = K.stamp_through(s3, "B stems")
         f1, f2 = [], []
         k1 = k2 = stage = 0
         lockstep = _lockstep(mode, sync_bn)
@@ -590,6 +592,11 @@ class Network(nn.Module):
                 with on_b():
                     s2, s3 = s3, cell2(s2, s3)
             if i in self._taps:
+                if K.STAMPS is not None:
+                    with on_a():
+                        s1 = K.stamp_through(s1, f"A enc{stage}")
+                    with on_b():
+                        s3 = K.stamp_through(s3, f"B enc{stage}")
                 f1.append(s1)
                 f2.append(s3)
                 meet(*f1, *f2)
@@ -618,8 +625,10 @@ class Network(nn.Module):
         for d in range(3):
             with on_a():
                 o1 = self.upsamples1[d](f1[3] if d == 0 else f1[-1], f1[2 - d])
+                o1 = K.stamp_through(o1, f"A dec{d}")
             with on_b():
                 o2 = self.upsamples2[d](f2[3] if d == 0 else f2[-1], f2[2 - d])
+                o2 = K.stamp_through(o2, f"B dec{d}")
             f1.append(o1)
             f2.append(o2)
             meet(*f1, *f2)
@@ -645,10 +654,14 @@ class Network(nn.Module):
         H, W = f1[0].shape[2], f1[0].shape[3]
         with on_a():
             x1 = K.concat([f1[0], f1[6], K.bilinear(f1[5], H, W), K.bilinear(f1[4], H, W)])
+            x1 = K.stamp_through(x1, "A cross+cat")
             in1, in3 = self.pose_auxlayer(x1), self.pose_layer(x1)
+            in3 = K.stamp_through(in3, "A layers")
         with on_b():
             x2 = K.concat([f2[0], f2[6], K.bilinear(f2[5], H, W), K.bilinear(f2[4], H, W)])
+            x2 = K.stamp_through(x2, "B cross+cat")
             in2, in4 = self.edge_layer(x2), self.par_layer(x2)
+            in4 = K.stamp_through(in4, "B layers")
         pose_list, par_list = [], []
 
         def heads(i):      # issued alternately (see _lockstep); the streams make the order irrelevant otherwise
@@ -679,7 +692,13 @@ class Network(nn.Module):
                     with on_b():
                         in2, n4 = self.par_net[m](in2, in3, in4, foreign=1, hub=hub)      # in3 from the pose branch
                 in1, in3, in4 = n1, tmp, n4
+                if K.STAMPS is not None:
+                    with on_a():
+                        in3 = K.stamp_through(in3, f"A refine{j}")
+                    with on_b():
+                        in4 = K.stamp_through(in4, f"B refine{j}")
             heads(i)
+        K.stamp("fwd end (issue order)")
         K._hub_offload = None
         if K.SYNC_MERGE:
             K._shared_sync_pool.flush()      # (nothing should be waiting: every BatchNorm has been applied)

@@ -68,7 +68,9 @@ class TrainStep:
         return (losses_par + losses_pose).mean()
 
     def _eager(self, images, labels_par, labels_pose, pose_weight):
+        K.stamp("step begin")
         loss = self._loss(images, labels_par, labels_pose, pose_weight)
+        K.stamp("loss fwd done")
         self.optimizer.zero_grad(set_to_none=True)
         if self.reducer is not None:
             self.reducer.begin_step()      # the backward kernels write the gradients straight into the reducer's buckets
@@ -84,11 +86,14 @@ class TrainStep:
         finally:
             K.DEFER_UNPACK = False
             K.DEFER_WGRAD_MAX_PIX = 0
+        K.stamp("backward done")
         K.flush_wgrads()
         K.flush_unpacks()
+        K.stamp("weight gradients done")
         if self.reducer is not None:
             self.reducer.finish()
         self.optimizer.step()
+        K.stamp("optimizer done")
         return loss
 
     # -- static buffers -----------------------------------------------------------------------------------------------

@@ -186,6 +186,48 @@ def test_benched_shapes_match_cpu_reference(case, batched_wgrad):
     assert rel_err(b.grad.cpu().numpy(), br.grad.numpy()) < tol
 
 
+@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("cin,cout,k,H,W,N,relu", [
+    (128, 128, 3, 12, 12, 3, True),      # three-tap kernel: several image rows per K-tile, P = 432 (ragged last K-tile)
+    (256, 128, 3, 13, 17, 2, True),      # odd extents: a border pixel at every position of a fragment half
+    (128, 256, 3, 96, 96, 2, False),     # one image row = 1.5 K-tiles
+    (128, 128, 3, 6, 40, 5, True),       # H < 64 / W rows per K-tile, image boundaries inside a K-tile
+    (384, 128, 3, 24, 24, 4, True),      # three input-channel tiles
+    (128, 128, 1, 24, 24, 4, True),      # 1x1 (the 128 x 128 kernel)
+    (64, 64, 3, 24, 24, 4, True),        # narrow layers (zero-filled part of the 128 x 128 tile)
+])
+def test_weight_gradient_is_exact_on_integer_data(cin, cout, k, H, W, N, relu, batched):
+    """Small-integer activations and gradients: every product and every partial sum is exact in f32 whatever the summation
+    order, so the LDS-DMA weight-gradient kernels (conv_wgrad_g4.hip: 128 x 128 tiles, and the three-tap kernel with its
+    border masks) must reproduce the f64 reference bit for bit -- a wrong border pixel cannot hide under a bf16 tolerance."""
+    from npp_amd import _ops as K
+    dev = _dev()
+    rng = np.random.default_rng(77)
+    x_cpu = torch.from_numpy(rng.integers(-2, 3, (N, cin, H, W)).astype(np.float32))
+    gy_cpu = torch.from_numpy(rng.integers(-2, 3, (N, cout, H, W)).astype(np.float32))
+    w_cpu = _rand((cout, cin, k, k), 2) * 0.05
+    xr = x_cpu.double()
+    wr = w_cpu.double().requires_grad_(True)
+    F.conv2d(F.relu(xr) if relu else xr, wr, None, 1, k // 2, 1).backward(gy_cpu.double())
+    x = _to_dev(x_cpu, torch.bfloat16, 8).detach().requires_grad_(True)        # (a channel slice: ld = C + 8)
+    w = w_cpu.to(dev).requires_grad_(True)
+    old = (K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK)
+    try:
+        if batched:
+            K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK = 1 << 30, True
+        y, _ = K.conv2d(x, w, None, 1, k // 2, 1, relu_in=relu, want_stats=False)
+        y.backward(_to_dev(gy_cpu, torch.bfloat16))
+        if batched:
+            K.flush_wgrads()
+            K.flush_unpacks()
+        torch.cuda.synchronize()
+    finally:
+        K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK = old
+        K.drop_pending()
+    got = w.grad.double().cpu()
+    assert torch.equal(got, wr.grad), float((got - wr.grad).abs().max())
+
+
 def _g8_launch_count(cin, cout, k, fam="conv_g8", hw=192):
     """fwd + dgrad of one conv in bf16 -> number of launches of the given conv kernel family (profiler family counter)."""
     import ctypes as C
