@@ -22,3 +22,5 @@ bool conv_g8_launch(const IgemmParams& p, int dtype, hipStream_t stream);
 bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream);
 // 3x3 stride-1 conv with an LDS-resident halo footprint (conv_h3.hip); false when the shape is not eligible
 bool conv_h3_launch(const IgemmParams& p, int dtype, hipStream_t stream);
+// 3x3 stride-1 convs with at most 8 output channels, or at most 8 input channels (conv_thin.hip: the edge head and its data gradient)
+bool conv_thin_launch(const IgemmParams& p, int dtype, hipStream_t stream);

@@ -70,6 +70,10 @@ CONV_CASES = [
     (192, 128, 3, 1, 1, 1, 64, 64, 8, True, False, 0),     # three chunks: the halo double buffer wraps
     (256, 256, 3, 1, 1, 1, 48, 48, 16, False, False, 0),   # two channel tiles, four chunks, no ReLU / mask
     (384, 128, 3, 1, 1, 1, 64, 64, 8, True, False, 0),     # conv_wgrad_h3 (W % 32 == 0): three input-channel tiles, two output tiles
+    # conv_thin.hip / conv_wgrad_thin_kernel: the edge head (384 -> 6, model_augment.py:393-398) and its gradients
+    (384, 6, 3, 1, 1, 1, 96, 96, 2, True, False, 0),       # the benched shape (N = 2)
+    (384, 6, 3, 1, 1, 1, 50, 40, 3, True, False, 8),       # ragged tiles in both directions, channel-slice input
+    (128, 2, 3, 1, 1, 1, 24, 24, 2, False, True, 0),       # two output channels, bias, no input ReLU
 ]
 H3_CASES = [c for c in CONV_CASES if c[2] == 3 and c[3] == 1 and c[5] == 1 and c[0] % 64 == 0 and c[7] % 16 == 0
             and c[8] * c[6] * c[7] >= 30000]
@@ -195,6 +199,9 @@ def test_benched_shapes_match_cpu_reference(case, batched_wgrad):
     (384, 128, 3, 24, 24, 4, True),      # three input-channel tiles
     (128, 128, 1, 24, 24, 4, True),      # 1x1 (the 128 x 128 kernel)
     (64, 64, 3, 24, 24, 4, True),        # narrow layers (zero-filled part of the 128 x 128 tile)
+    (384, 6, 3, 96, 96, 1, True),        # thin-output kernel (edge head): one image row = 1.5 K-tiles
+    (384, 6, 3, 13, 17, 3, True),        # thin-output kernel, odd extents
+    (128, 8, 3, 6, 40, 5, False),        # thin-output kernel, 8 output channels, several images per K-tile
 ])
 def test_weight_gradient_is_exact_on_integer_data(cin, cout, k, H, W, N, relu, batched):
     """Small-integer activations and gradients: every product and every partial sum is exact in f32 whatever the summation
@@ -256,6 +263,7 @@ def test_shapes_take_their_lds_dma_kernels():
     assert _g8_launch_count(128, 128, 3, "conv_g4", 160) == 2        # (conv_h3 reports under the same family)
     assert _g8_launch_count(32, 32, 3, "conv_g4", 96) == 2
     assert _g8_launch_count(128, 32, 1, "conv_g4", 96) == 2
+    assert _g8_launch_count(384, 6, 3, "conv_g4", 96) == 2           # the edge head: conv_thin.hip, same family
 
 
 @pytest.mark.parametrize("cfg", ["1", "3", "4"])
