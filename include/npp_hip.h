@@ -148,11 +148,14 @@ int npp_dwconv_bwd_weight_batched(const NppDwWgradItem* items, int n, void* host
  * enqueues one upload -- inside a hipGraph capture the replay re-reads it, so it must stay as it is while the graph lives). */
 typedef struct NppWgradItem {
   NppTensor x, dy;
-  float* dw_packed;
+  float* dw_packed;      /* nslabs == 0: the zeroed packed accumulator (float atomics); nslabs > 0: nslabs slabs of
+                            npp_packed_weight_elems floats, each written once (plain stores, bit-reproducible): sum them with
+                            npp_unpack_wgrad_sum / npp_unpack_wgrad_batched */
   NppConvGeom g;
-  int32_t _pad;
+  int32_t nslabs;        /* 0, or exactly npp_conv_wgrad_batched_splits(x, dy, g) */
 } NppWgradItem;
 int npp_conv_wgrad_batchable(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g);
+int npp_conv_wgrad_batched_splits(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g);
 int64_t npp_conv_wgrad_batched_ws(int n);
 int npp_conv_wgrad_batched(const NppWgradItem* items, int n, void* host_pinned, void* dev, int64_t ws_bytes, void* stream);
 int npp_conv_wgrad_splits(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g);

@@ -33,7 +33,7 @@ class NppConvGeom(C.Structure):
 
 
 class NppWgradItem(C.Structure):
-    _fields_ = [("x", NppTensor), ("dy", NppTensor), ("dw_packed", C.c_void_p), ("g", NppConvGeom), ("_pad", C.c_int32)]
+    _fields_ = [("x", NppTensor), ("dy", NppTensor), ("dw_packed", C.c_void_p), ("g", NppConvGeom), ("nslabs", C.c_int32)]
 
 
 class NppDwWgradItem(C.Structure):
@@ -168,6 +168,7 @@ _SIGS = {
     "npp_adam_step": [_P, _P, C.c_int, _P, _P],
     "npp_bilinear_bwd_ws": [_T, _T, C.c_int, _P, C.c_int64, _P],
     "npp_conv_wgrad_batchable": [_T, _T, _G],
+    "npp_conv_wgrad_batched_splits": [_T, _T, _G],
     "npp_dwconv_bwd_weight_batchable": [_T, _T, _G],
     "npp_dwconv_bwd_weight_batched": [_P, C.c_int, _P, _P, C.c_int64, _P],
     "npp_conv_wgrad_batched": [_P, C.c_int, _P, _P, C.c_int64, _P],

@@ -751,8 +751,9 @@ def _may_defer(weight) -> bool:
     return True
 
 
-def _defer_wgrad(x, dy, acc, g, key, weight=None):
-    """True if this weight gradient was queued for the batched launch (acc: the zeroed packed accumulator it adds into)."""
+def _defer_wgrad(x, dy, acc, g, key, weight=None, nslabs=0):
+    """True if this weight gradient was queued for the batched launch (acc: the zeroed packed accumulator it adds into, or --
+    nslabs > 0 -- the slab buffer its pixel splits store into)."""
     if DEFER_WGRAD_MAX_PIX <= 0 or x.shape[0] * x.shape[2] * x.shape[3] > DEFER_WGRAD_MAX_PIX or x.dtype != torch.bfloat16:
         return False
     ok = _wgrad_batchable.get(key)
@@ -763,8 +764,29 @@ def _defer_wgrad(x, dy, acc, g, key, weight=None):
     # the accumulator's MEMORY is kept through an alias with its own TensorImpl: for a 1x1 conv it IS the gradient tensor handed to
     # autograd, and a second reference to that object would make AccumulateGrad clone the (still empty) gradient
     keep = torch.empty(0, dtype=acc.dtype, device=acc.device).set_(acc.untyped_storage(), acc.storage_offset(), acc.shape, acc.stride())
-    _pending_wgrads.append((x, dy, keep, g, torch.cuda.current_stream()))
+    _pending_wgrads.append((x, dy, keep, g, torch.cuda.current_stream(), int(nslabs)))
     return True
+
+
+# Slab mode of the batched weight gradients (round 3, OPT-IN: NPP_WGRAD_SLAB_BATCH=1): every pixel split of a job STORES its partial
+# tile into a slab of its own and the (batched) unpack sums the slabs: bit-reproducible weight gradients (no float atomics).
+# Measured A/B/A/B on one MI355X: 48.9 ms per step against 47.9 with the atomics (weight-gradient tail 8.8 vs 8.0-8.3 ms) -- the
+# ~2.3 GB of atomic traffic per step (1.3 TB/s chip-wide) is spread under the MFMA work of the other workgroups, while 2 x 2.3 GB of
+# slab stores + reads and the longer unpack are not.  So the accumulate form stays the default.
+WGRAD_SLABS_BATCHED = os.environ.get("NPP_WGRAD_SLAB_BATCH", "0") == "1"
+_wgrad_batch_splits: dict = {}
+
+
+def _batched_slabs(x, dy, g, key) -> int:
+    """Slabs (= pixel splits) of this problem in the batched launch while slab mode applies, else 0."""
+    if not WGRAD_SLABS_BATCHED or DEFER_WGRAD_MAX_PIX <= 0 or not DEFER_UNPACK or x.dtype != torch.bfloat16:
+        return 0
+    if x.shape[0] * x.shape[2] * x.shape[3] > DEFER_WGRAD_MAX_PIX:
+        return 0
+    n = _wgrad_batch_splits.get(key)
+    if n is None:
+        n = _wgrad_batch_splits[key] = int(lib().npp_conv_wgrad_batched_splits(_byref(x), _byref(dy), C.byref(g)))
+    return n
 
 
 _pending_dw_wgrads: list = []      # depthwise: (x, dy, gradient alias, slab scratch, NppConvGeom, stream)
@@ -874,14 +896,16 @@ def flush_wgrads():
             cur.wait_stream(it[4])
     n = len(items)
     arr = (L.NppWgradItem * n)()
-    for i, (x, dy, acc, g, _st) in enumerate(items):
-        arr[i].x, arr[i].dy, arr[i].dw_packed, arr[i].g = desc(x), desc(dy), acc.data_ptr(), g
+    for i, (x, dy, acc, g, _st, nsl) in enumerate(items):
+        arr[i].x, arr[i].dy, arr[i].dw_packed, arr[i].g, arr[i].nslabs = desc(x), desc(dy), acc.data_ptr(), g, nsl
     nb = int(lib().npp_conv_wgrad_batched_ws(n))
     capturing = torch.cuda.is_current_stream_capturing()
     B = _wgrad_bufs
     if capturing:
         if B["pin"] is None or B["pin"].numel() < nb:      # no warm-up step sized the tables: one launch each
-            for (x, dy, acc, g, _st) in items:
+            for (x, dy, acc, g, _st, nsl) in items:
+                if nsl > 0:      # (slab buffers are not zeroed: the accumulate form adds into the first slab, the others must be zero)
+                    acc.zero_()
                 check(lib().npp_conv_wgrad(_byref(x), _byref(dy), acc.data_ptr(), C.byref(g), stream_ptr()), "npp_conv_wgrad")
             return
         pin, dev = B["pin"], B["dev"]
@@ -1067,13 +1091,23 @@ class _Conv2d(Function):
             nel = lib().npp_packed_weight_elems(co, ci, kh, kw, 0)
             g = geom(kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 1, relu_in)
             if kh == 1 and kw == 1 and ci % 64 == 0 and co % 32 == 0:
-                # packed [co][ci] == OIHW: accumulate straight into the gradient tensor
-                dw = grad_out(weight, zero=True)            # the parameter's (zeroed) slot in its gradient bucket, or
-                if dw is None:
-                    dw = zeros_f32(weight.numel(), x.device, own=True).view(weight.shape)     # pre-zeroed pool slice: no fill launch
                 wkey = (tuple(x.shape), L.nhwc_ld(x), co, L.nhwc_ld(dy), kh, kw, stride, pad, dil, x.dtype)
-                if not _defer_wgrad(x, dy, dw, g, wkey, weight):
-                    check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
+                nsl = _batched_slabs(x, dy, g, wkey)
+                if nsl > 0 and weight.dtype == torch.float32 and _may_defer(weight):
+                    # batched launch in slab mode: the splits store into slabs, the batched unpack sums them into the gradient
+                    slabs = torch.empty(nsl * nel, dtype=torch.float32, device=x.device)
+                    _defer_wgrad(x, dy, slabs, g, wkey, None, nsl)
+                    dw = grad_out(weight)
+                    if dw is None:
+                        dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                    _unpack_or_defer(slabs, dw, co, ci, 1, 1, nsl, s, True)
+                else:
+                    # packed [co][ci] == OIHW: accumulate straight into the gradient tensor
+                    dw = grad_out(weight, zero=True)            # the parameter's (zeroed) slot in its gradient bucket, or
+                    if dw is None:
+                        dw = zeros_f32(weight.numel(), x.device, own=True).view(weight.shape)     # pre-zeroed pool slice: no fill launch
+                    if not _defer_wgrad(x, dy, dw, g, wkey, weight):
+                        check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
             else:
                 dw = grad_out(weight)
                 if dw is None:
@@ -1083,7 +1117,12 @@ class _Conv2d(Function):
                 if nsl is None:
                     nsl = _wgrad_splits[wkey] = int(lib().npp_conv_wgrad_splits(_byref(x), _byref(dy), C.byref(g)))
                 defer_ok = DEFER_UNPACK and _may_defer(weight)      # (dw reaches autograd unwritten when the unpack waits)
-                if nsl > 0:      # deterministic split-K: the kernel stores one slab per split, the unpack sums them
+                bsl = _batched_slabs(x, dy, g, wkey) if (defer_ok and nsl <= 0) else 0
+                if bsl > 0:      # batched launch in slab mode
+                    slabs = torch.empty(bsl * nel, dtype=torch.float32, device=x.device)
+                    _defer_wgrad(x, dy, slabs, g, wkey, None, bsl)
+                    _unpack_or_defer(slabs, dw, co, ci, kh, kw, bsl, s, True)
+                elif nsl > 0:      # deterministic split-K: the kernel stores one slab per split, the unpack sums them
                     slabs = torch.empty(nsl * nel, dtype=torch.float32, device=x.device)
                     check(lib().npp_conv_wgrad_slabs(_byref(x), _byref(dy), slabs.data_ptr(), nsl, C.byref(g), s), "npp_conv_wgrad_slabs")
                     _unpack_or_defer(slabs, dw, co, ci, kh, kw, nsl, s, defer_ok)

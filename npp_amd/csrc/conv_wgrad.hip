@@ -247,6 +247,7 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // argument checks + the parameter block every weight-gradient kernel takes
 static int wgrad_setup(const NppTensor* x, const NppTensor* dy, float* dw_packed, const NppConvGeom* g, WgradParams& p) {
+  p.slab_stride = 0;
   NPP_REQUIRE(x && dy && dw_packed && g && x->ptr && dy->ptr, NPP_E_NULL, "npp_conv_wgrad: null pointer");
   NPP_REQUIRE(x->dtype == dy->dtype && (x->dtype == NPP_F32 || x->dtype == NPP_BF16), NPP_E_DTYPE,
               "npp_conv_wgrad: x/dy dtypes must match");
@@ -327,6 +328,20 @@ extern "C" int npp_conv_wgrad_batchable(const NppTensor* x, const NppTensor* dy,
   return conv_wgrad_g4_batch_prepare(p, x->dtype, job, 0, WGB_MAX_BLOCKS, &variant, &nblocks) ? 1 : 0;
 }
 
+// pixel splits (= slabs) the batched kernel gives this problem; 0 = not a shape of the batched kernel.  In slab mode the caller hands
+// npp_conv_wgrad_batched a buffer of that many slabs of npp_packed_weight_elems floats and sets NppWgradItem.nslabs.
+extern "C" int npp_conv_wgrad_batched_splits(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g) {
+  if (!x || !dy || !g || !x->ptr || !dy->ptr) return 0;
+  WgradParams p;
+  float dummy;
+  if (wgrad_setup(x, dy, &dummy, g, p) != NPP_OK) return 0;
+  alignas(16) unsigned char job[512];
+  if (conv_wgrad_g4_job_bytes() > sizeof(job)) return 0;
+  int variant = 0, nblocks = 0, splits = 0;
+  if (!conv_wgrad_g4_batch_prepare(p, x->dtype, job, 0, WGB_MAX_BLOCKS, &variant, &nblocks, &splits)) return 0;
+  return variant >= 4 ? 0 : splits;      // (the opt-in three-tap kernel keeps its atomics)
+}
+
 extern "C" int64_t npp_conv_wgrad_batched_ws(int n) {
   if (n <= 0) return 0;
   const int64_t jobs = ((int64_t)n * (int64_t)conv_wgrad_g4_job_bytes() + 255) / 256 * 256;
@@ -345,9 +360,16 @@ extern "C" int npp_conv_wgrad_batched(const NppWgradItem* items, int n, void* ho
     WgradParams p;
     const int rc = wgrad_setup(&it.x, &it.dy, it.dw_packed, &it.g, p);
     if (rc != NPP_OK) return rc;
-    if (!conv_wgrad_g4_batch_prepare(p, it.x.dtype, host_pinned, i, WGB_MAX_BLOCKS, &variant[i], &blocks[i])) {
+    int splits = 0;
+    if (it.nslabs > 0) p.slab_stride = (long)round_up(p.Cout, 32) * p.Kpad;      // = npp_packed_weight_elems(...)
+    if (!conv_wgrad_g4_batch_prepare(p, it.x.dtype, host_pinned, i, WGB_MAX_BLOCKS, &variant[i], &blocks[i], &splits)) {
       npp_set_error("npp_conv_wgrad_batched: item %d is not a shape of the batched kernel (ask npp_conv_wgrad_batchable first)", i);
       return NPP_E_UNSUPPORTED;
+    }
+    if (it.nslabs > 0 && (it.nslabs != splits || variant[i] >= 4)) {
+      npp_set_error("npp_conv_wgrad_batched: item %d brings %d slabs, the kernel splits its pixels %d ways (npp_conv_wgrad_batched_splits)",
+                    i, (int)it.nslabs, splits);
+      return NPP_E_SHAPE;
     }
     flops += 2.0 * (double)p.P * p.Cout * (double)p.taps * p.Cin;
     bytes += ((double)it.x.n * it.x.h * it.x.w * it.x.c + (double)p.P * it.dy.c) * esize(it.x.dtype);

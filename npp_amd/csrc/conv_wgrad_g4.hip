@@ -202,8 +202,14 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
         const int col = colbase + (2 * nb + half) * 16 + i16;
         const int row0 = co0 + wm * 64 + mi * 16 + gg * 4 + j;
         if (col < kcols) {
-          if (row0 < p.Cout) atomicAdd(p.dwp + (long)row0 * p.Kpad + col, __uint_as_float(sw[0]));
-          if (row0 + 8 < p.Cout) atomicAdd(p.dwp + (long)(row0 + 8) * p.Kpad + col, __uint_as_float(sw[1]));
+          if (p.slab_stride > 0) {      // one slab per pixel split: plain stores (6 TB/s against 1.3 TB/s of float atomics), deterministic
+            float* slab = p.dwp + (long)split * p.slab_stride;
+            if (row0 < p.Cout) slab[(long)row0 * p.Kpad + col] = __uint_as_float(sw[0]);
+            if (row0 + 8 < p.Cout) slab[(long)(row0 + 8) * p.Kpad + col] = __uint_as_float(sw[1]);
+          } else {
+            if (row0 < p.Cout) atomicAdd(p.dwp + (long)row0 * p.Kpad + col, __uint_as_float(sw[0]));
+            if (row0 + 8 < p.Cout) atomicAdd(p.dwp + (long)(row0 + 8) * p.Kpad + col, __uint_as_float(sw[1]));
+          }
         }
       }
 }
@@ -810,8 +816,10 @@ bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
 // variant = relu_in | taps > 1 << 1.  finish lays out the maps, uploads the image and launches one kernel per variant present.
 size_t conv_wgrad_g4_job_bytes() { return sizeof(WG4Job); }
 
-bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_host, int slot, int max_blocks, int* variant, int* nblocks) {
+bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_host, int slot, int max_blocks, int* variant, int* nblocks,
+                                 int* splits) {
   WG4Job* jb = reinterpret_cast<WG4Job*>(jobs_host) + slot;
+  if (splits) *splits = 0;
   int nb = 0;
   memset(&jb->e3, 0, sizeof(jb->e3));
   // (a job of the three-tap kernel may take half the slots of a 128 x 128 job: one workgroup per CU instead of two)
@@ -826,6 +834,7 @@ bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_hos
   jb->first_block = 0; jb->_pad = 0;
   *variant = (p.relu_in ? 1 : 0) | (jb->e.P > 0 ? 2 : 0);
   *nblocks = nb;
+  if (splits) *splits = nb / jb->e.ntiles;      // every split owns >= 1 K-tile (wg4_prepare recomputes the count from the K-tiles per split)
   return true;
 }
 

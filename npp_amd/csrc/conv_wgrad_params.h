@@ -11,6 +11,8 @@ struct WgradParams {
   int rowtiles;
   int vec_dy;
   int ntiles, nblocks;   // conv_wgrad_kernel: output tiles, and blocks = tiles x pixel splits (1-D grid, XCD-contiguous order)
+  long slab_stride;      // conv_wgrad_g4 (batched): > 0 = every pixel split STORES its partial tile into its own slab (dwp + split *
+                         // slab_stride floats) instead of adding into dwp with float atomics; the unpack sums the slabs
 };
 // tap-stationary 3x3 stride-1 kernel (conv_wgrad_s1.hip); false when the shape is not eligible
 bool conv_wgrad_tap_launch(const WgradParams& p, int dtype, hipStream_t stream);
@@ -18,6 +20,7 @@ bool conv_wgrad_tap_launch(const WgradParams& p, int dtype, hipStream_t stream);
 bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream);
 // batched form of the above (npp_conv_wgrad_batched): see conv_wgrad_g4.hip
 size_t conv_wgrad_g4_job_bytes();
-bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_host, int slot, int max_blocks, int* variant, int* nblocks);
+bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_host, int slot, int max_blocks, int* variant, int* nblocks,
+                                 int* splits = nullptr);
 bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, int* map_host, const int* map_dev, const int* variant_of,
                                 const int* blocks_of, hipStream_t stream);

@@ -6,6 +6,7 @@
 // The forward kernels can add the per-channel sum / sum-of-squares of their output (the statistics of
 // the BatchNorm that follows, operations.py:61,129) so no extra pass over the tensor is needed.
 #include "vecio.h"
+#include <stdlib.h>
 
 #ifdef NPP_POOL_NO_XCD
 #define VBLOCK blockIdx.x
@@ -117,6 +118,134 @@ __global__ __launch_bounds__(256) void pool3x3_fwd_kernel(const T* __restrict__ 
     for (int j = 0; j < V; ++j) { red[t * 2 * V + j] = ss[j]; red[t * 2 * V + V + j] = sq[j]; }
     __syncthreads();
     // thread t < cv * 2V sums column (group g = t % cv, entry e = t / cv) over the 256 / cv threads of that group
+    const int ncol = cv * 2 * V;
+    for (int col = t; col < ncol; col += 256) {
+      const int g = col % cv, e = col / cv;
+      double s = 0.0;
+      for (int r = g; r < 256; r += cv) s += (double)red[r * 2 * V + e];
+      const int ch = g * V + (e < V ? e : e - V);
+      double* st = stats + (long)(blockIdx.x % NPP_STAT_REPLICAS) * 2 * C + (e < V ? 0 : C);
+      if (s != 0.0) atomicAdd(st + ch, s);
+    }
+  }
+}
+
+
+// Max-pool 3x3, stride 1, walking DOWN a column (round 3).  The first version above fetches 9 vectors and runs 9 x V compare /
+// select chains per output (1.0 TB/s on 37.7 MB tensors against 5-6 TB/s of the plain element-wise kernels).  max over the window =
+// max over its three ROW maxima, and the row maximum of input row r at column x serves the outputs (r-1, x), (r, x), (r+1, x): a
+// thread owns (image, column x, channel vector) and a run of `seg` output rows, fetches THREE vectors per output (the new row's
+// x-1, x, x+1; the next row's are in flight while this one is reduced), reduces them to a row maximum + its tap column, and combines
+// three row maxima per output.  ATen's index semantics (first maximum in (kh, kw) scan order, a NaN wins and the LAST NaN stays)
+// survive the split: first column inside each row, then first row.
+template <typename T, int V>
+struct RowMax {
+  float v[V];
+  int kw[V];      // tap column 0..2 of the row maximum
+};
+
+template <typename T, int V, bool STATS>
+__global__ __launch_bounds__(256) void pool3x3_max_col_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
+                                                              unsigned char* __restrict__ amax, int N, int H, int W, int C, int cv,
+                                                              int seg, int nseg, double* __restrict__ stats) {
+  const unsigned total = (unsigned)N * nseg * W * cv;
+  const FastDiv fcv((unsigned)cv), fw((unsigned)W), fs((unsigned)nseg);
+  float ss[V], sq[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { ss[j] = 0.f; sq[j] = 0.f; }
+  for (unsigned i = VBLOCK * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    unsigned r1, cg, r2, xc, n, sg;
+    fast_divmod(i, fcv, r1, cg);
+    fast_divmod(r1, fw, r2, xc);
+    fast_divmod(r2, fs, n, sg);
+    const int c0 = (int)cg * V;
+    const int xl = xc == 0 ? 0 : (int)xc - 1, xr = (int)xc + 1 < W ? (int)xc + 1 : W - 1;
+    const bool okl = xc > 0, okr = (int)xc + 1 < W;
+    const int first_kw = okl ? 0 : 1;
+    const T* img = x + (long)n * H * W * ldx + c0;
+    const int yb = (int)sg * seg, ye = yb + seg < H ? yb + seg : H;
+    auto fetch = [&](int r, float (&a)[V], float (&b)[V], float (&c)[V]) {      // row r clamped into the image
+      const int rc = r < 0 ? 0 : (r >= H ? H - 1 : r);
+      const T* rp = img + (long)rc * W * ldx;
+      ldv<T, V>(rp + (long)xl * ldx, a);
+      ldv<T, V>(rp + (long)xc * ldx, b);
+      ldv<T, V>(rp + (long)xr * ldx, c);
+    };
+    auto reduce = [&](const float (&a)[V], const float (&b)[V], const float (&c)[V], RowMax<T, V>& m) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float acc = -INFINITY;
+        int kw = first_kw;
+        bool u = okl && (a[j] > acc || a[j] != a[j]);
+        acc = u ? a[j] : acc; kw = u ? 0 : kw;
+        u = b[j] > acc || b[j] != b[j];
+        acc = u ? b[j] : acc; kw = u ? 1 : kw;
+        u = okr && (c[j] > acc || c[j] != c[j]);
+        acc = u ? c[j] : acc; kw = u ? 2 : kw;
+        m.v[j] = acc; m.kw[j] = kw;
+      }
+    };
+    RowMax<T, V> m0, m1, m2;
+    float a[V], b[V], c[V];
+    fetch(yb - 1, a, b, c);
+    reduce(a, b, c, m0);
+    fetch(yb, a, b, c);
+    reduce(a, b, c, m1);
+    fetch(yb + 1, a, b, c);                       // in flight across the first output
+    for (int yy = yb; yy < ye; ++yy) {
+      reduce(a, b, c, m2);                        // row yy + 1
+      if (yy + 1 < ye) fetch(yy + 2, a, b, c);    // (uniform per thread run: no divergent wait inside the loop body's loads)
+      const bool ok0 = yy > 0, ok2 = yy + 1 < H;
+      float acc[V];
+      int arg[V];
+      const int first = (ok0 ? 0 : 3) + first_kw;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float av = -INFINITY;
+        int ag = first;
+        bool u = ok0 && (m0.v[j] > av || m0.v[j] != m0.v[j]);
+        av = u ? m0.v[j] : av; ag = u ? m0.kw[j] : ag;
+        u = m1.v[j] > av || m1.v[j] != m1.v[j];
+        av = u ? m1.v[j] : av; ag = u ? 3 + m1.kw[j] : ag;
+        u = ok2 && (m2.v[j] > av || m2.v[j] != m2.v[j]);
+        av = u ? m2.v[j] : av; ag = u ? 6 + m2.kw[j] : ag;
+        acc[j] = av; arg[j] = ag;
+      }
+      const long p = ((long)n * H + yy) * W + xc;
+      stv<T, V>(y + p * ldy + c0, acc);
+      if (STATS) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float r = Elt<T>::round(acc[j]);
+          ss[j] += r;
+          sq[j] = fmaf(r, r, sq[j]);
+        }
+      }
+      if (amax) {
+        if constexpr (V == 8) {
+          unsigned lo = 0, hi = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { lo |= (unsigned)arg[j] << (8 * j); hi |= (unsigned)arg[4 + j] << (8 * j); }
+          *reinterpret_cast<uint2*>(amax + p * C + c0) = make_uint2(lo, hi);
+        } else if constexpr (V == 4) {
+          unsigned lo = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) lo |= (unsigned)arg[j] << (8 * j);
+          *reinterpret_cast<unsigned*>(amax + p * C + c0) = lo;
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) amax[p * C + c0 + j] = (unsigned char)arg[j];
+        }
+      }
+      m0 = m1; m1 = m2;
+    }
+  }
+  if (STATS) {
+    __shared__ float red[256 * 2 * V];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { red[t * 2 * V + j] = ss[j]; red[t * 2 * V + V + j] = sq[j]; }
+    __syncthreads();
     const int ncol = cv * 2 * V;
     for (int col = t; col < ncol; col += 256) {
       const int g = col % cv, e = col / cv;
@@ -510,6 +639,22 @@ extern "C" int npp_pool3x3_fwd(const NppTensor* x, NppTensor* y, uint8_t* argmax
       // few blocks (one f64 atomic per block and channel)
       fused = stats != nullptr && cv > 0 && 256 % cv == 0 && x->c % V == 0;
       const int grid = grid_for(npix(y) * cv, 256, fused ? 1024 : 4096);
+      static const bool col_off = getenv("NPP_POOL_COL") && atoi(getenv("NPP_POOL_COL")) == 0;
+      if (!is_avg && stride == 1 && V > 1 && !col_off && x->h >= 2 && (!stats || fused) && (long)x->n * x->h * x->w * cv < (1L << 31)) {
+        // rows per thread: long runs amortise the two extra row fetches, but the launch wants >= ~128k threads
+        const long cols = (long)x->n * x->w * cv;
+        int seg = 12;
+        while (seg > 2 && cols * ((x->h + seg - 1) / seg) < 131072) seg = seg > 4 ? seg - 4 : 2;
+        if (seg > x->h) seg = (int)x->h;
+        const int nseg = (int)((x->h + seg - 1) / seg);
+        const int g2 = grid_for(cols * nseg, 256, fused ? 1024 : 4096);
+        if (fused)
+          hipLaunchKernelGGL((pool3x3_max_col_kernel<T, V, true>), dim3(g2), dim3(256), 0, s, (const T*)x->ptr, (long)x->ld,
+                             (T*)y->ptr, (long)y->ld, argmax, (int)x->n, (int)x->h, (int)x->w, (int)x->c, cv, seg, nseg, stats);
+        else
+          hipLaunchKernelGGL((pool3x3_max_col_kernel<T, V, false>), dim3(g2), dim3(256), 0, s, (const T*)x->ptr, (long)x->ld,
+                             (T*)y->ptr, (long)y->ld, argmax, (int)x->n, (int)x->h, (int)x->w, (int)x->c, cv, seg, nseg, stats);
+      } else
       if (is_avg) { if (fused) POOL_LAUNCH(true, true); else POOL_LAUNCH(true, false); }
       else        { if (fused) POOL_LAUNCH(false, true); else POOL_LAUNCH(false, false); }
     });

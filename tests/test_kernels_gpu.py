@@ -190,7 +190,7 @@ def test_benched_shapes_match_cpu_reference(case, batched_wgrad):
     assert rel_err(b.grad.cpu().numpy(), br.grad.numpy()) < tol
 
 
-@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("batched", [False, True, "slabs"])
 @pytest.mark.parametrize("cin,cout,k,H,W,N,relu", [
     (128, 128, 3, 12, 12, 3, True),      # three-tap kernel: several image rows per K-tile, P = 432 (ragged last K-tile)
     (256, 128, 3, 13, 17, 2, True),      # odd extents: a border pixel at every position of a fragment half
@@ -218,10 +218,11 @@ def test_weight_gradient_is_exact_on_integer_data(cin, cout, k, H, W, N, relu, b
     F.conv2d(F.relu(xr) if relu else xr, wr, None, 1, k // 2, 1).backward(gy_cpu.double())
     x = _to_dev(x_cpu, torch.bfloat16, 8).detach().requires_grad_(True)        # (a channel slice: ld = C + 8)
     w = w_cpu.to(dev).requires_grad_(True)
-    old = (K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK)
+    old = (K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK, K.WGRAD_SLABS_BATCHED)
     try:
         if batched:
             K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK = 1 << 30, True
+            K.WGRAD_SLABS_BATCHED = batched == "slabs"      # the deterministic form: every pixel split stores a slab of its own
         y, _ = K.conv2d(x, w, None, 1, k // 2, 1, relu_in=relu, want_stats=False)
         y.backward(_to_dev(gy_cpu, torch.bfloat16))
         if batched:
@@ -229,10 +230,34 @@ def test_weight_gradient_is_exact_on_integer_data(cin, cout, k, H, W, N, relu, b
             K.flush_unpacks()
         torch.cuda.synchronize()
     finally:
-        K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK = old
+        K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK, K.WGRAD_SLABS_BATCHED = old
         K.drop_pending()
     got = w.grad.double().cpu()
     assert torch.equal(got, wr.grad), float((got - wr.grad).abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,H,W,N,stride", [(32, 24, 24, 2, 1), (128, 13, 17, 2, 1), (256, 5, 7, 3, 1), (64, 2, 9, 2, 1), (8, 40, 3, 1, 1),
+                                             (32, 24, 24, 2, 2), (20, 9, 9, 2, 1)])
+def test_max_pool_matches_torch_exactly_with_ties(C, H, W, N, stride, dtype):
+    """nn.MaxPool2d(3, stride, 1) (operations.py:55) on heavily quantised data (ties in almost every window): the output AND the
+    routing of the gradient (first maximum in (kh, kw) scan order, as ATen) must equal torch's -- the column-walking kernel
+    (pool3x3_max_col_kernel) splits the window into row maxima and has to keep that order."""
+    from npp_amd import _ops as K
+    rng = np.random.default_rng(5)
+    x_cpu = torch.from_numpy(rng.integers(-3, 4, (N, C, H, W)).astype(np.float32) * 0.5)
+    xr = x_cpu.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, stride, 1)
+    gy = torch.from_numpy(rng.integers(-2, 3, tuple(yr.shape)).astype(np.float32))
+    yr.backward(gy)
+    x = _to_dev(x_cpu, dtype).detach().requires_grad_(True)
+    y, st = K.pool3x3(x, False, stride, want_stats=True)
+    y.backward(_to_dev(gy, dtype))
+    torch.cuda.synchronize()
+    assert torch.equal(y.detach().float().cpu(), yr.detach())
+    assert torch.equal(x.grad.float().cpu(), xr.grad)
+    s_ref = torch.cat([yr.detach().double().sum((0, 2, 3)), (yr.detach().double() ** 2).sum((0, 2, 3))])
+    assert rel_err(st.view(-1, 2 * C).sum(0).cpu().numpy(), s_ref.numpy()) < 1e-6
 
 
 def _g8_launch_count(cin, cout, k, fam="conv_g8", hw=192):
