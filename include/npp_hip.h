@@ -53,7 +53,9 @@ typedef struct NppConvGeom {
   int32_t dh, dw;       /* dilation */
   int32_t uph, upw;     /* 1 = ordinary conv; s>1 = the input is read as if zero-upsampled by s along h / w
                            (dgrad of a stride-s conv expressed as a stride-1 conv) */
-  int32_t relu_in;      /* apply max(x,0) to the input while loading (pre-activation ops) */
+  int32_t relu_in;      /* bit 0: apply max(x,0) to the input while loading (pre-activation ops); bit 1 (npp_conv_fwd as a data
+                           gradient only): ADD the result into y instead of storing it -- y already holds the gradient another
+                           consumer of the same tensor wrote (bf16 LDS-DMA kernels; NPP_E_UNSUPPORTED elsewhere, nothing launched) */
 } NppConvGeom;
 
 const char* npp_version(void);

@@ -77,7 +77,7 @@ def stamp_through(x, name):
 # _FanOut node with several aliasing outputs, each later consumer receives the next alias, and _FanOut.backward adds all
 # incoming gradients in one npp_add_n launch (n reads + 1 write).  NPP_FANOUT=0 restores the engine's accumulation.
 FANOUT = os.environ.get("NPP_FANOUT", "1") != "0"
-_FAN_N = 4                       # aliases per node; the last one is reserved to chain a further node when they run out
+_FAN_N = 6                       # aliases per node (a cell state feeds up to 4 ops + the concatenation); the last one is reserved to chain a further node when they run out
 _FAN_REG: dict = {}              # id(tensor) -> [aliases, handed out, weakref]; dropped by fan_reset() (Network.forward)
 
 
@@ -99,20 +99,82 @@ def add_n(ts: Sequence[torch.Tensor]) -> torch.Tensor:
     return out
 
 
+# Gradient accumulation IN the producers (round 3).  The consumers of a fan-out tensor whose data gradient comes
+# out of an LDS-DMA conv kernel (conv_g4 / conv_h3 / conv_g8 / conv_thin: the preprocess and head convs of the 96 x 96 maps, where
+# the bytes are) share ONE gradient buffer: the first of them stores, the later ones read-add-store in their epilogue (NppConvGeom
+# relu_in bit 1), all on the stream of the first -- the add_n pass over n + 1 tensors (or n of its n + 1) disappears.  Other
+# consumers (pooling, depthwise, SE, plain adds) still hand back tensors of their own and _FanOut.backward adds what is left.
+FAN_ACCUM = os.environ.get("NPP_FAN_ACCUM", "1") != "0"
+FAN_STATS = [0, 0, 0]      # claims that stored / accumulated / fell back to a private tensor
+
+
+class _FanAcc:
+    """Shared data-gradient buffer of one fan-out tensor."""
+    __slots__ = ("buf", "stream")
+
+    def __init__(self):
+        self.buf, self.stream = None, None
+
+    def claim(self, like):
+        """(buffer, accumulate?) for a consumer about to write the gradient of `like` on the current stream, or (None, False)."""
+        cur = stream_ptr()
+        if self.buf is None:
+            self.buf = new_nhwc(*like.shape, like.dtype, like.device)
+            self.stream = cur
+            FAN_STATS[0] += 1
+            return self.buf, False
+        if cur == self.stream and self.buf.dtype == like.dtype:
+            FAN_STATS[1] += 1
+            return self.buf, True
+        FAN_STATS[2] += 1
+        return None, False
+
+
+def take_acc(x):
+    """take(x) plus the shared gradient buffer (_FanAcc) of x's fan-out node -- None when x needs no fan-out node or accumulation
+    is off.  For consumers whose data-gradient kernel can add into an existing tensor."""
+    a = take(x)
+    if not FAN_ACCUM or a is x or not x.is_cuda or x.dtype != torch.bfloat16:
+        return a, None
+    st = _FAN_REG.get(id(x))
+    if st is None or st[2]() is not x or not any(a is o for o in st[0][:-1]):
+        return a, None           # (the alias came from a chained node -- a 4th, 5th ... consumer: a tensor of its own, or the chained
+                                 #  node's sum would contain the shared buffer a second time)
+    if not st[3]:
+        st[3].append(_FanAcc())
+    return a, st[3][0]
+
+
 class _FanOut(Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, holder):
         ctx.set_materialize_grads(False)       # aliases nobody consumed hand back None, not a zero tensor
+        ctx.holder = holder                    # [ _FanAcc ] once a consumer asked for the shared gradient buffer (take_acc)
         return tuple(x.view_as(x) for _ in range(_FAN_N))
 
     @staticmethod
     def backward(ctx, *gs):
-        gs = [g for g in gs if g is not None]
-        if not gs:
-            return None
-        if len(gs) == 1:
-            return gs[0]
-        return add_n(gs)
+        acc = ctx.holder[0] if ctx.holder else None
+        shared = acc.buf if acc is not None else None
+        uniq = []
+        seen_shared = False
+        for g in gs:
+            if g is None:
+                continue
+            # consumers that accumulated all hand back the ONE shared buffer: it counts once (compared by memory, the engine need
+            # not hand back the same Python object); every other gradient is a contribution of its own, equal tensors included
+            if shared is not None and g.data_ptr() == shared.data_ptr() and g.shape == shared.shape and g.stride() == shared.stride():
+                if seen_shared:
+                    continue
+                seen_shared = True
+            uniq.append(g)
+        if acc is not None:
+            acc.buf = acc.stream = None        # a later backward over the same graph (retain_graph) starts a new buffer
+        if not uniq:
+            return None, None
+        if len(uniq) == 1:
+            return uniq[0], None
+        return add_n(uniq), None
 
 
 def take(x):
@@ -124,7 +186,8 @@ def take(x):
     if st is None or st[2]() is not x:         # (a dead Python wrapper's id may be reused by another tensor)
         if len(_FAN_REG) > 8192:               # ops used outside a Network.forward: never grow without bound
             _FAN_REG.clear()
-        st = [_FanOut.apply(x), 0, weakref.ref(x)]
+        holder = []
+        st = [_FanOut.apply(x, holder), 0, weakref.ref(x), holder]
         _FAN_REG[id(x)] = st
     outs, k = st[0], st[1]
     if k < _FAN_N - 1:
@@ -1029,7 +1092,7 @@ SHAPE_LOG = None     # tools/shape_prof.py: list of (kind, n, ci, h, w, co, kh, 
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, relu_in, want_stats, out_hw):
+    def forward(ctx, x, weight, bias, stride, pad, dil, relu_in, want_stats, out_hw, fan=None):
         x = _gemm_ready(to_nhwc(x))
         n, ci, h, w = x.shape
         co, _, kh, kw = weight.shape
@@ -1050,6 +1113,7 @@ class _Conv2d(Function):
         if SHAPE_LOG is not None:
             SHAPE_LOG.append(("fwd", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
         ctx.save_for_backward(x, weight, bias)
+        ctx.fan = fan if x.dtype == torch.bfloat16 else None
         ctx.mask_bits = relu_mask_of(x) if (relu_in and RELU_BITS and x.dtype == torch.bfloat16) else None
         if relu_in and ctx.mask_bits is None and RELU_BITS and x.dtype == torch.bfloat16:
             MASK_STATS[2] += 1
@@ -1062,7 +1126,7 @@ class _Conv2d(Function):
     @staticmethod
     def backward(ctx, dy, _dstats):
         if dy is None:
-            return (None,) * 9
+            return (None,) * 10
         x, weight, bias = ctx.saved_tensors
         stride, pad, dil, relu_in, has_bias = ctx.cfg
         dy = to_nhwc(dy)
@@ -1074,17 +1138,33 @@ class _Conv2d(Function):
         dx = dw = db = None
         s = stream_ptr()
         if ctx.needs_input_grad[0]:
-            dx = new_nhwc(n, ci, h, w, x.dtype, x.device)
-            g = geom(kh, kw, 1, 1, dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1], dil[0], dil[1],
-                     (stride[0], stride[1]), 0)
             wp = packed_weight(weight, True, x.dtype)
+            dx = None
+            acc_flag = 0
+            if ctx.fan is not None and stride == (1, 1):
+                # x feeds several consumers: add into their shared gradient buffer (the first claimant stores)
+                dx, accumulate = ctx.fan.claim(x)
+                acc_flag = 2 if accumulate else 0
+            own = dx is None
+            if own:
+                dx = new_nhwc(n, ci, h, w, x.dtype, x.device)
             done = False
-            if relu_in and ctx.mask_bits is not None:      # the producer of x left a bit-mask: 1/16 of the mask bytes
-                done = _conv_launch(dy, wp.data_ptr(), None, C.byref(ctx.mask_bits[0]), dx, None, g, s, "npp_conv_fwd(dgrad)",
-                                    soft=True) == 0
-                MASK_STATS[0 if done else 1] += 1
-            if not done:
-                _conv_launch(dy, wp.data_ptr(), None, _byref(x) if relu_in else None, dx, None, g, s, "npp_conv_fwd(dgrad)")
+            while not done:
+                g = geom(kh, kw, 1, 1, dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1], dil[0], dil[1],
+                         (stride[0], stride[1]), acc_flag)
+                if relu_in and ctx.mask_bits is not None:      # the producer of x left a bit-mask: 1/16 of the mask bytes
+                    done = _conv_launch(dy, wp.data_ptr(), None, C.byref(ctx.mask_bits[0]), dx, None, g, s, "npp_conv_fwd(dgrad)",
+                                        soft=True) == 0
+                    if not acc_flag or done:
+                        MASK_STATS[0 if done else 1] += 1
+                if not done:
+                    done = _conv_launch(dy, wp.data_ptr(), None, _byref(x) if relu_in else None, dx, None, g, s,
+                                        "npp_conv_fwd(dgrad)", soft=bool(acc_flag)) == 0
+                if not done:      # this shape's kernel cannot accumulate: a tensor of its own, the fan-out node adds it
+                    FAN_STATS[1] -= 1
+                    FAN_STATS[2] += 1
+                    acc_flag = 0
+                    dx = new_nhwc(n, ci, h, w, x.dtype, x.device)
             if SHAPE_LOG is not None:
                 SHAPE_LOG.append(("dgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
         if ctx.needs_input_grad[1]:
@@ -1140,13 +1220,14 @@ class _Conv2d(Function):
             check(lib().npp_channel_sum(_byref(dy), acc.data_ptr(), s), "npp_channel_sum")
             db = _grad_buf(bias, co, x.device)
             check(lib().npp_sum_replicas(acc.data_ptr(), R, co, db.data_ptr(), s), "npp_sum_replicas")
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1, relu_in=False, want_stats=False, private_in=False):
     """y = conv(relu?(x)) + bias, plus (optionally) the f64 [sum | sumsq] statistics of y.  private_in: `x` has no other
     consumer (an intermediate of the calling module), so it needs no fan-out node."""
-    return _Conv2d.apply(x if private_in else take(x), weight, bias, _pair(stride), _pair(pad), _pair(dil), bool(relu_in), int(want_stats), None)
+    xa, fan = (x, None) if private_in else take_acc(x)
+    return _Conv2d.apply(xa, weight, bias, _pair(stride), _pair(pad), _pair(dil), bool(relu_in), int(want_stats), None, fan)
 
 
 def conv2d_crop(x, weight, stride=2, relu_in=False, want_stats=False):

@@ -77,6 +77,18 @@ NPP_DEV u32x4 mask8_expand(unsigned b) {
   return m;
 }
 
+// o + prev on packed bf16x8 vectors (f32 add, one rounding): the accumulate form of a data-gradient epilogue
+NPP_DEV u32x4 add_bf16x8(const u32x4& a, const u32x4& b) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = __uint_as_float(a[i] << 16) + __uint_as_float(b[i] << 16);
+    const float hi = __uint_as_float(a[i] & 0xFFFF0000u) + __uint_as_float(b[i] & 0xFFFF0000u);
+    r[i] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  }
+  return r;
+}
+
 // Workgroups go to the 8 XCDs (8 separate L2s) round-robin by blockIdx.x.  A kernel whose neighbouring blocks read
 // overlapping rows (3x3 windows, bilinear taps, dilated depthwise taps) wants neighbours on ONE XCD, or every XCD fetches
 // the shared rows from HBM for itself: virtual block id = the (blockIdx.x >> 3)-th block of XCD (blockIdx.x & 7)'s contiguous

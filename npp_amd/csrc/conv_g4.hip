@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
             o = o & __builtin_bit_cast(u32x4, m);
           }
         }
+        if (p.accum) o = add_bf16x8(o, *reinterpret_cast<const u32x4*>(yg + gm * p.ldy + cb + chb));
         if constexpr ((G4_DBG & 1) == 0) *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
         else asm volatile("" :: "v"(o));
       }

@@ -312,6 +312,7 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
                 o = o & __builtin_bit_cast(u32x4, m);
               }
             }
+            if (p.accum) o = add_bf16x8(o, *reinterpret_cast<const u32x4*>(yg + gm * p.ldy + cb + chb));
             *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
           }
         }

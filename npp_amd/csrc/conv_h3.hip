@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_h3_kernel(IgemmParams p, 
             o = o & __builtin_bit_cast(u32x4, m);
           }
         }
+        if (p.accum) o = add_bf16x8(o, *reinterpret_cast<const u32x4*>(yg + gm * p.ldy + cb + chb));
         *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
       }
     }

@@ -511,7 +511,8 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
   p.OH = (int)y->h; p.OW = (int)y->w; p.Cout = (int)y->c; p.ldy = y->ld; p.ldm = mask ? mask->ld : 0;
   p.Cp = cp; p.Kpad = round_up(g->kh * g->kw * cp, 64);
   p.KH = g->kh; p.KW = g->kw; p.sh = g->sh; p.sw = g->sw; p.ph = g->ph; p.pw = g->pw; p.dh = g->dh; p.dw = g->dw;
-  p.uph = g->uph; p.upw = g->upw; p.relu_in = g->relu_in;
+  p.uph = g->uph; p.upw = g->upw; p.relu_in = g->relu_in & 1;
+  p.accum = (g->relu_in >> 1) & 1;      // bit 1: accumulate into y (only the LDS-DMA / thin kernels below can)
   const long M = (long)y->n * y->h * y->w;
   NPP_REQUIRE(M > 0 && M < (1L << 30) && (long)x->n * x->h * x->w < (1L << 30), NPP_E_SHAPE, "npp_conv_fwd: too many pixels");
   p.M = (int)M;
@@ -553,6 +554,10 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
   }
   if (p.mask_bits) {      // only the LDS-DMA kernels above read bit-masks: the caller retries with the bf16 tensor as mask
     npp_set_error("npp_conv_fwd: this shape runs on a kernel without bit-mask support");
+    return NPP_E_UNSUPPORTED;
+  }
+  if (p.accum) {          // ... and only they can add into y: the caller writes a tensor of its own instead
+    npp_set_error("npp_conv_fwd: this shape runs on a kernel that cannot accumulate into its output");
     return NPP_E_UNSUPPORTED;
   }
   {

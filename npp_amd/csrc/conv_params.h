@@ -9,6 +9,8 @@ struct IgemmParams {
   int M, mtiles, ntiles;
   int vec_io;
   int mask_bits;   // `mask` is an NPP_MASK8 bit-mask (ldm in BYTES per pixel): conv_g4 / conv_g8 only
+  int accum;       // data gradient of a fan-out tensor: ADD into y instead of storing (NppConvGeom.relu_in bit 1): conv_g4 / conv_h3 /
+                   // conv_g8 / conv_thin epilogues read the 16 bytes they are about to write
   int par, mtiles_c;   // generic kernel, data gradient of a stride-2 conv (uph = upw = 2): output pixels grouped by parity class,
                        // each class a stride-1 conv over the taps that do not hit an inserted zero; mtiles_c = M-tiles per class
 };

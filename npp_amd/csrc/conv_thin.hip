@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(IgemmParams p, int ti
             o = o & __builtin_bit_cast(u32x4, m);
           }
         }
+        if (p.accum) o = add_bf16x8(o, *reinterpret_cast<const u32x4*>(yg + gm * p.ldy + cb + chb));
         *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
       }
     }
@@ -234,7 +235,7 @@ bool conv_thin_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
   const long blocks = (long)p.N * tiles_x * tiles_y;
   if (blocks >= (1L << 31)) return false;
-  if (p.Cout <= 8 && p.Cin % 64 == 0 && p.Cp == p.Cin && !p.mask && p.ldy % 8 == 0 && p.ldy >= 8) {
+  if (p.Cout <= 8 && p.Cin % 64 == 0 && p.Cp == p.Cin && !p.mask && !p.accum && p.ldy % 8 == 0 && p.ldy >= 8) {
     if (p.relu_in) hipLaunchKernelGGL((conv_thin_out_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, stream, p, tiles_x, tiles_y);
     else hipLaunchKernelGGL((conv_thin_out_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, stream, p, tiles_x, tiles_y);
     return true;
