@@ -115,6 +115,13 @@ class _FanAcc:
     def __init__(self):
         self.buf, self.stream = None, None
 
+    def seed(self, grad):
+        """`grad` (an OWNED tensor nobody else reads: a channel slice of a concatenation's gradient) becomes the shared buffer: the
+        consumers that come later add into it, and the slice needs no add_n pass of its own."""
+        if self.buf is None and grad.dtype == torch.bfloat16:
+            self.buf, self.stream = grad, stream_ptr()
+            FAN_STATS[0] += 1
+
     def claim(self, like):
         """(buffer, accumulate?) for a consumer about to write the gradient of `like` on the current stream, or (None, False)."""
         cur = stream_ptr()
@@ -123,7 +130,7 @@ class _FanAcc:
             self.stream = cur
             FAN_STATS[0] += 1
             return self.buf, False
-        if cur == self.stream and self.buf.dtype == like.dtype:
+        if cur == self.stream and self.buf.dtype == like.dtype and self.buf.shape == like.shape:
             FAN_STATS[1] += 1
             return self.buf, True
         FAN_STATS[2] += 1
@@ -143,6 +150,15 @@ def take_acc(x):
     if not st[3]:
         st[3].append(_FanAcc())
     return a, st[3][0]
+
+
+def _mark_owned(t):
+    """`t` is a gradient tensor this layer made for ONE reader (an add_n result, a finished shared buffer): whoever receives it may
+    add into it in place.  Pass-through gradients (a plain add hands the SAME tensor to both operands) never carry the mark."""
+    try:
+        t._npp_own = True
+    except Exception:      # noqa: BLE001
+        pass
 
 
 class _FanOut(Function):
@@ -173,8 +189,12 @@ class _FanOut(Function):
         if not uniq:
             return None, None
         if len(uniq) == 1:
+            if seen_shared:
+                _mark_owned(uniq[0])
             return uniq[0], None
-        return add_n(uniq), None
+        r = add_n(uniq)
+        _mark_owned(r)
+        return r, None
 
 
 def take(x):
@@ -1539,6 +1559,12 @@ class _BnAdd(Function):
             if not need_x:
                 return None
             if yrelu is None:
+                # the incoming gradient itself is handed on (possibly to BOTH operands, and kept by deferred weight gradients
+                # below them): from here on it has several readers, nobody may add into it in place (_mark_owned)
+                try:
+                    dout._npp_own = False
+                except Exception:      # noqa: BLE001
+                    pass
                 return dout
             dx = new_nhwc(*x.shape, x.dtype, x.device)
             check(lib().npp_scale_mask(_byref(dout), None, _byref(yrelu), _byref(dx), s), "npp_scale_mask")
@@ -2107,14 +2133,21 @@ class _ConcatAlias(Function):
     def forward(ctx, holder, *parts):
         buf = holder[0]
         ctx.splits = [x.shape[1] for x in parts]
+        ctx.accs = holder[1] if len(holder) > 1 else None      # the parts' shared gradient buffers (_FanAcc), see backward
         return _alias(buf, 0, buf.shape[1])
 
     @staticmethod
     def backward(ctx, dy):
+        own = getattr(dy, "_npp_own", False) and FAN_ACCUM
         dy = to_nhwc(dy)
         outs, off = [None], 0
-        for c in ctx.splits:
-            outs.append(dy[:, off:off + c])
+        for k, c in enumerate(ctx.splits):
+            v = dy[:, off:off + c]
+            # the concatenation is the LAST consumer of its parts, so this runs before their other consumers' backward: an owned
+            # gradient's slice becomes the part's shared buffer and the convs that read the part add into it (no add_n for the slice)
+            if own and ctx.accs is not None and ctx.accs[k] is not None:
+                ctx.accs[k].seed(v)
+            outs.append(v)
             off += c
         return tuple(outs)
 
@@ -2179,7 +2212,8 @@ class ConcatBuffer:
                     break
         if not ok:
             return concat(parts)
-        res = _ConcatAlias.apply([self.buf], *[take(t) for t in parts])
+        taken = [take_acc(t) for t in parts]
+        res = _ConcatAlias.apply([self.buf, [a for _, a in taken]], *[t for t, _ in taken])
         if self.mask is not None:
             _register_mask(res, (self.mask, 0, self.c * self.nparts // 8))
         return res
