@@ -286,6 +286,9 @@ int npp_pool3x3_fwd(const NppTensor* x, NppTensor* y, uint8_t* argmax /*max only
                     int is_avg, int stride, double* stats, void* stream);
 int npp_pool3x3_bwd(const NppTensor* dy, const uint8_t* argmax, NppTensor* dx, int is_avg, int stride,
                     void* stream);
+/* the same, adding into dx (accumulate != 0): dx holds the gradient another consumer of the pooled tensor wrote */
+int npp_pool3x3_bwd_acc(const NppTensor* dy, const uint8_t* argmax, NppTensor* dx, int is_avg, int stride, int accumulate,
+                        void* stream);
 int npp_pool2x2_fwd(const NppTensor* x, NppTensor* y, int is_avg, double* stats, void* stream);
 int npp_pool2x2_bwd(const NppTensor* dy, const NppTensor* x /*max only*/, NppTensor* dx, int is_avg,
                     void* stream);
@@ -313,6 +316,8 @@ int npp_se_fwd(const NppTensor* x, const float* w1, const float* b1, const float
                float* pooled, float* hidden, float* gate, float* ws, void* stream);
 int npp_se_bwd(const NppTensor* dout, const NppTensor* x, const float* w1, const float* w2, const float* hidden,
                const float* gate, NppTensor* dx, float* dz, float* ws, void* stream);
+int npp_se_bwd_acc(const NppTensor* dout, const NppTensor* x, const float* w1, const float* w2, const float* hidden,
+                   const float* gate, NppTensor* dx, float* dz, float* ws, int accumulate /* dx += */, void* stream);
 typedef struct NppSeGradItem {
   const float* pooled; const float* hidden; const float* dz;
   float* dw1; float* db1; float* dw2; float* db2;      /* conv1.weight [C/2][C], conv1.bias, conv2.weight [C][C/2], conv2.bias */

@@ -120,6 +120,7 @@ _SIGS = {
     "npp_bn_bwd_apply2_fin": [_T, _T, _T, _T, _P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _T, _T, _P],
     "npp_pool3x3_fwd": [_T, _T, _P, C.c_int, C.c_int, _P, _P],
     "npp_pool3x3_bwd": [_T, _P, _T, C.c_int, C.c_int, _P],
+    "npp_pool3x3_bwd_acc": [_T, _P, _T, C.c_int, C.c_int, C.c_int, _P],
     "npp_pool2x2_fwd": [_T, _T, C.c_int, _P, _P],
     "npp_pool2x2_bwd": [_T, _T, _T, C.c_int, _P],
     "npp_global_avgpool": [_T, _P, _P],
@@ -131,6 +132,7 @@ _SIGS = {
     "npp_se_supported": [C.c_int],
     "npp_se_fwd": [_T, _P, _P, _P, _P, _T, _P, _P, _P, _P, _P],
     "npp_se_bwd": [_T, _T, _P, _P, _P, _P, _T, _P, _P, _P],
+    "npp_se_bwd_acc": [_T, _T, _P, _P, _P, _P, _T, _P, _P, C.c_int, _P],
     "npp_se_param_grads": [_P, _P],
     "npp_se_param_grads_batched": [_P, C.c_int, _P, _P, C.c_int64, _P],
     "npp_bilinear_fwd": [_T, _T, _P],

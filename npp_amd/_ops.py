@@ -108,6 +108,14 @@ FAN_ACCUM = os.environ.get("NPP_FAN_ACCUM", "1") != "0"
 FAN_STATS = [0, 0, 0]      # claims that stored / accumulated / fell back to a private tensor
 
 
+class _Like:
+    """shape / dtype / device of a tensor that is not at hand (a backward that saved only the shape of its input)."""
+    __slots__ = ("shape", "dtype", "device")
+
+    def __init__(self, shape, dtype, device):
+        self.shape, self.dtype, self.device = torch.Size(shape), dtype, device
+
+
 class _FanAcc:
     """Shared data-gradient buffer of one fan-out tensor."""
     __slots__ = ("buf", "stream")
@@ -135,6 +143,22 @@ class _FanAcc:
             return self.buf, True
         FAN_STATS[2] += 1
         return None, False
+
+
+def _claim_dx(fan, like):
+    """(dx, accumulate?) for a backward about to write the gradient of `like`: the fan-out node's shared buffer when there is one
+    (first claimant stores, later ones add), else a tensor of its own."""
+    if fan is not None:
+        dx, accumulate = fan.claim(like)
+        if dx is not None:
+            return dx, accumulate
+    return new_nhwc(*like.shape, like.dtype, like.device), False
+
+
+def _unclaim():
+    """The kernel behind an accumulating claim cannot add into its output: the claim is replaced by a private tensor."""
+    FAN_STATS[1] -= 1
+    FAN_STATS[2] += 1
 
 
 def take_acc(x):
@@ -1263,8 +1287,9 @@ def conv2d_crop(x, weight, stride=2, relu_in=False, want_stats=False):
 # --------------------------------------------------------------------------------------------------
 class _DwConv2d(Function):
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, dil, relu_in):
+    def forward(ctx, x, weight, stride, pad, dil, relu_in, fan=None):
         x = to_nhwc(x)
+        ctx.fan = fan if x.dtype == torch.bfloat16 else None
         n, c, h, w = x.shape
         _, _, kh, kw = weight.shape
         oh, ow = _conv_out(h, kh, stride, pad, dil), _conv_out(w, kw, stride, pad, dil)
@@ -1293,9 +1318,18 @@ class _DwConv2d(Function):
             wf = wf.float().contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = new_nhwc(*x.shape, x.dtype, x.device)
-            check(lib().npp_dwconv_bwd_data(_byref(dy), wf.data_ptr(), _byref(x) if relu_in else None, _byref(dx),
-                                            C.byref(g), s), "npp_dwconv_bwd_data")
+            dx, accumulate = _claim_dx(ctx.fan if stride == 1 else None, x)
+            if accumulate:
+                ga = geom(kh, kw, stride, stride, pad, pad, dil, dil, 1, int(relu_in) | 2)
+                rc = lib().npp_dwconv_bwd_data(_byref(dy), wf.data_ptr(), _byref(x) if relu_in else None, _byref(dx), C.byref(ga), s)
+                if rc == L.NPP_E_UNSUPPORTED:
+                    _unclaim()
+                    dx, accumulate = new_nhwc(*x.shape, x.dtype, x.device), False
+                else:
+                    check(rc, "npp_dwconv_bwd_data")
+            if not accumulate:
+                check(lib().npp_dwconv_bwd_data(_byref(dy), wf.data_ptr(), _byref(x) if relu_in else None, _byref(dx),
+                                                C.byref(g), s), "npp_dwconv_bwd_data")
         if ctx.needs_input_grad[1]:
             dw = grad_out(weight)
             if dw is None:
@@ -1310,11 +1344,12 @@ class _DwConv2d(Function):
                       "npp_dwconv_bwd_weight")
             if dw.dtype != weight.dtype:
                 dw = dw.to(weight.dtype)
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 def dwconv2d(x, weight, stride=1, pad=0, dil=1, relu_in=False):
-    return _DwConv2d.apply(take(x), weight, int(stride), int(pad), int(dil), bool(relu_in))
+    xa, fan = take_acc(x)
+    return _DwConv2d.apply(xa, weight, int(stride), int(pad), int(dil), bool(relu_in), fan)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -1761,8 +1796,9 @@ def channel_stats(x: torch.Tensor, level: int = 1) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------------
 class _Pool3x3(Function):
     @staticmethod
-    def forward(ctx, x, is_avg, stride, want_stats):
+    def forward(ctx, x, is_avg, stride, want_stats, fan=None):
         x = to_nhwc(x)
+        ctx.fan = fan if x.dtype == torch.bfloat16 else None
         n, c, h, w = x.shape
         oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
         y = new_nhwc(n, c, oh, ow, x.dtype, x.device)
@@ -1780,19 +1816,26 @@ class _Pool3x3(Function):
     @staticmethod
     def backward(ctx, dy, _):
         if dy is None:
-            return None, None, None, None
+            return None, None, None, None, None
         (amax,) = ctx.saved_tensors
         is_avg, stride, xshape, dtype = ctx.cfg
         dy = to_nhwc(dy)
         if dy.dtype != dtype:
             dy = cast(dy, dtype)
-        dx = new_nhwc(*xshape, dtype, dy.device)
-        check(lib().npp_pool3x3_bwd(_byref(dy), ptr(amax), _byref(dx), int(is_avg), stride, stream_ptr()), "npp_pool3x3_bwd")
-        return dx, None, None, None
+        if ctx.fan is not None:
+            dx, accumulate = ctx.fan.claim(_Like(xshape, dtype, dy.device))
+        else:
+            dx, accumulate = None, False
+        if dx is None:
+            dx, accumulate = new_nhwc(*xshape, dtype, dy.device), False
+        check(lib().npp_pool3x3_bwd_acc(_byref(dy), ptr(amax), _byref(dx), int(is_avg), stride, int(accumulate), stream_ptr()),
+              "npp_pool3x3_bwd")
+        return dx, None, None, None, None
 
 
 def pool3x3(x, is_avg=False, stride=1, want_stats=False):
-    return _Pool3x3.apply(take(x), bool(is_avg), int(stride), int(want_stats))
+    xa, fan = take_acc(x)
+    return _Pool3x3.apply(xa, bool(is_avg), int(stride), int(want_stats), fan)
 
 
 class _Pool2x2(Function):
@@ -1846,8 +1889,9 @@ def _f32c(t):
 
 class _SEScale(Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, fan=None):
         x = to_nhwc(x)
+        ctx.fan = fan if x.dtype == torch.bfloat16 else None
         n, c, h, w = x.shape
         dev = x.device
         s = stream_ptr()
@@ -1886,12 +1930,12 @@ class _SEScale(Function):
         dw2 = _grad_buf(w2, w2.numel(), dev).view(w2.shape)
         db2 = _grad_buf(b2, c, dev)
         w1f, w2f = _f32c(w1), _f32c(w2)
-        dx = new_nhwc(n, c, h, w, x.dtype, dev)
+        dx, accumulate = _claim_dx(ctx.fan if ctx.fused else None, x)
         if ctx.fused:
             dz = torch.empty((n, c + c // 2), dtype=torch.float32, device=dev)
             ws = torch.empty(int(lib().npp_se_ws_floats(n, c)), dtype=torch.float32, device=dev)
-            check(lib().npp_se_bwd(_byref(dy), _byref(x), w1f.data_ptr(), w2f.data_ptr(), hidden.data_ptr(), gate.data_ptr(),
-                                   _byref(dx), dz.data_ptr(), ws.data_ptr(), s), "npp_se_bwd")
+            check(lib().npp_se_bwd_acc(_byref(dy), _byref(x), w1f.data_ptr(), w2f.data_ptr(), hidden.data_ptr(), gate.data_ptr(),
+                                       _byref(dx), dz.data_ptr(), ws.data_ptr(), int(accumulate), s), "npp_se_bwd")
             # parameter gradients: nobody reads them before the optimizer -> one batched launch per step under TrainStep
             if (DEFER_WGRAD_MAX_PIX > 0 and all(t.dtype == torch.float32 for t in (w1, b1, w2, b2))
                     and _may_defer(w1) and _may_defer(w2) and _may_defer(b1) and _may_defer(b2)):
@@ -1914,7 +1958,7 @@ class _SEScale(Function):
             check(lib().npp_se_bwd_apply(_byref(dy), gate.data_ptr(), dpooled.data_ptr(), _byref(dx), s), "npp_se_bwd_apply")
         if dw1.dtype != w1.dtype:
             dw1, db1, dw2, db2 = dw1.to(w1.dtype), db1.to(b1.dtype), dw2.to(w2.dtype), db2.to(b2.dtype)
-        return dx, dw1, db1, dw2, db2
+        return dx, dw1, db1, dw2, db2, None
 
 
 def _flush_se_grads():
@@ -1953,7 +1997,8 @@ def _flush_se_grads():
 
 
 def se_scale(x, w1, b1, w2, b2):
-    return _SEScale.apply(take(x), w1, b1, w2, b2)
+    xa, fan = take_acc(x)
+    return _SEScale.apply(xa, w1, b1, w2, b2, fan)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -191,6 +191,7 @@ struct RunGeom {
   int nseg, seglen;        // every run is cut into nseg pieces of seglen steps (parallelism for small batches)
   long ld_in, ld_out, ld_mask;
   int N, C, cv, relu_in, flip;
+  int accum;               // data gradient of a fan-out tensor: add into `out` (NppConvGeom.relu_in bit 1)
 };
 
 // A 16-byte (or scalar) element vector kept in its storage form until it is used, so that the loads of the NEXT step
@@ -327,6 +328,12 @@ __global__ __launch_bounds__(256) void dw3_run_fwd_kernel(const T* __restrict__ 
           if (mrow) {
 #pragma unroll
             for (int j = 0; j < V; ++j) acc[j] = m[j] > 0.f ? acc[j] : 0.f;
+          }
+          if (g.accum) {
+            float prev[V];
+            ldv<T, V>(orow + (long)(r.ph + g.delta * i) * g.ld_out, prev);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += prev[j];
           }
           stv<T, V>(orow + (long)(r.ph + g.delta * i) * g.ld_out, acc);
         }
@@ -494,7 +501,7 @@ static bool run_plan(const DwParams& p, RunGeom& g, int& nblk, int V) {
   g.IH = p.H; g.IW = p.W; g.OH = p.OH; g.OW = p.OW;
   g.s = p.sh; g.pad_h = p.ph; g.pad_w = p.pw; g.d = p.dh; g.delta = p.dh / p.sh;
   g.ld_in = p.ldx; g.ld_out = p.ldy; g.ld_mask = 0;
-  g.N = p.N; g.C = p.C; g.cv = p.C / V; g.relu_in = p.relu_in; g.flip = 0;
+  g.N = p.N; g.C = p.C; g.cv = p.C / V; g.relu_in = p.relu_in; g.flip = 0; g.accum = 0;
   const int npx = (g.OW + g.delta - 1) / g.delta;
   const long base_threads = (long)g.N * g.OH * g.delta * g.cv;
   int nseg = (int)((256L * 256 * 3 + base_threads - 1) / base_threads);
@@ -559,6 +566,10 @@ extern "C" int npp_dwconv_bwd_data(const NppTensor* dy, const float* w, const Np
                                    const NppConvGeom* g, void* stream) {
   NPP_REQUIRE(dy && w && dx && g && dy->ptr && dx->ptr, NPP_E_NULL, "npp_dwconv_bwd_data: null pointer");
   DwParams p;
+  const int accum = (g->relu_in >> 1) & 1;      // bit 1: add into dx (the run kernel only; NPP_E_UNSUPPORTED otherwise, nothing launched)
+  NppConvGeom g1 = *g;
+  g1.relu_in &= 1;
+  g = &g1;
   int rc = fill_params(p, dx, dy, g, "npp_dwconv_bwd_data");
   if (rc) return rc;
   if (x_mask) {
@@ -582,12 +593,18 @@ extern "C" int npp_dwconv_bwd_data(const NppTensor* dy, const float* w, const Np
       if (q.ph >= 0 && q.pw >= 0 && run_plan(q, rg, nb, V)) {
         rg.flip = 1;
         rg.ld_mask = p.ldm;
+        rg.accum = accum;
         rc = allow_lds(dw3_run_fwd_kernel<T, V>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((dw3_run_fwd_kernel<T, V>), dim3((unsigned)nb), dim3(256), lds, s, (const T*)dy->ptr, w,
                            x_mask ? (const T*)x_mask->ptr : nullptr, (T*)dx->ptr, rg);
         return npp_check_launch("dwconv_bwd_data(run)");
       }
+    }
+    if (accum) {
+      prof.cancel();
+      npp_set_error("npp_dwconv_bwd_data: this geometry runs on a kernel that cannot accumulate into dx");
+      return NPP_E_UNSUPPORTED;
     }
     rc = allow_lds(dwconv_bwd_data_kernel<T, V>, lds);
     if (rc) return rc;

@@ -262,7 +262,7 @@ template <typename T, int V, bool AVG>
 __global__ __launch_bounds__(256) void pool3x3_bwd_kernel(const T* __restrict__ dy, long ldy,
                                                           const unsigned char* __restrict__ amax, T* __restrict__ dx,
                                                           long ldx, int N, int H, int W, int OH, int OW, int C, int cv,
-                                                          int stride) {
+                                                          int stride, int accum) {
   constexpr bool is_avg = AVG;
   // gather form: every input pixel sums the windows that contain it (no atomics)
   const long total = (long)N * H * W * cv;
@@ -322,6 +322,12 @@ __global__ __launch_bounds__(256) void pool3x3_bwd_kernel(const T* __restrict__ 
         const float w = is_avg ? inv[t] : 1.f;
         acc[j] += (ok[t] && hit) ? d[t][j] * w : 0.f;
       }
+    }
+    if (accum) {
+      float prev[V];
+      ldv<T, V>(dx + p * ldx + c0, prev);
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += prev[j];
     }
     stv<T, V>(dx + p * ldx + c0, acc);
   }
@@ -664,8 +670,16 @@ extern "C" int npp_pool3x3_fwd(const NppTensor* x, NppTensor* y, uint8_t* argmax
   return rc;
 }
 
+extern "C" int npp_pool3x3_bwd_acc(const NppTensor* dy, const uint8_t* argmax, NppTensor* dx, int is_avg, int stride, int accumulate,
+                                   void* stream);
 extern "C" int npp_pool3x3_bwd(const NppTensor* dy, const uint8_t* argmax, NppTensor* dx, int is_avg, int stride,
                                void* stream) {
+  return npp_pool3x3_bwd_acc(dy, argmax, dx, is_avg, stride, 0, stream);
+}
+
+// accumulate != 0: dx += the gradient (dx holds what another consumer of the same tensor wrote)
+extern "C" int npp_pool3x3_bwd_acc(const NppTensor* dy, const uint8_t* argmax, NppTensor* dx, int is_avg, int stride, int accumulate,
+                                   void* stream) {
   NPP_REQUIRE(dy && dx && dy->ptr && dx->ptr && (is_avg || argmax), NPP_E_NULL, "npp_pool3x3_bwd: null pointer");
   NPP_REQUIRE(dtype_ok(dy) && dx->dtype == dy->dtype, NPP_E_DTYPE, "npp_pool3x3_bwd: dtype mismatch");
   NPP_REQUIRE(stride >= 1 && dy->h == (dx->h - 1) / stride + 1 && dy->w == (dx->w - 1) / stride + 1 && dx->n == dy->n &&
@@ -678,11 +692,11 @@ extern "C" int npp_pool3x3_bwd(const NppTensor* dy, const uint8_t* argmax, NppTe
     if (is_avg)
       hipLaunchKernelGGL((pool3x3_bwd_kernel<T, V, true>), dim3(grid_for(npix(dx) * cv)), dim3(256), 0, s, (const T*)dy->ptr,
                          (long)dy->ld, argmax, (T*)dx->ptr, (long)dx->ld, (int)dx->n, (int)dx->h, (int)dx->w, (int)dy->h,
-                         (int)dy->w, (int)dx->c, cv, stride);
+                         (int)dy->w, (int)dx->c, cv, stride, accumulate);
     else
       hipLaunchKernelGGL((pool3x3_bwd_kernel<T, V, false>), dim3(grid_for(npix(dx) * cv)), dim3(256), 0, s, (const T*)dy->ptr,
                          (long)dy->ld, argmax, (T*)dx->ptr, (long)dx->ld, (int)dx->n, (int)dx->h, (int)dx->w, (int)dy->h,
-                         (int)dy->w, (int)dx->c, cv, stride);
+                         (int)dy->w, (int)dx->c, cv, stride, accumulate);
   });
   return npp_check_launch("pool3x3_bwd");
 }

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ part, int slabs,
                                                            const float* __restrict__ gate, const float* __restrict__ hidden,
                                                            const float* __restrict__ w1, const float* __restrict__ w2,
-                                                           float* __restrict__ dz_out, int HW, int C, int cv) {
+                                                           float* __restrict__ dz_out, int HW, int C, int cv, int accum) {
   extern __shared__ float sm[];
   const int Ch = C / 2;
   float* dz2 = sm;
@@ -270,6 +270,13 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
     for (int j = 0; j < V; ++j) {
       v[j] = fmaf(v[j], sg[c * V + j], dpl[c * V + j]);
       w[j] = fmaf(w[j], sg[c2 * V + j], dpl[c2 * V + j]);
+    }
+    if (accum) {      // dx already holds the gradient another consumer of x wrote
+      float pv[V], pw[V];
+      ldv<T, V>(dxn + (long)p * lddx + c * V, pv);
+      ldv<T, V>(dxn + (long)p2 * lddx + c2 * V, pw);
+#pragma unroll
+      for (int j = 0; j < V; ++j) { v[j] += pv[j]; w[j] += pw[j]; }
     }
     stv<T, V>(dxn + (long)p * lddx + c * V, v);
     if (two) stv<T, V>(dxn + (long)p2 * lddx + c2 * V, w);
@@ -377,8 +384,16 @@ extern "C" int npp_se_fwd(const NppTensor* x, const float* w1, const float* b1, 
 }
 
 // dx = d(x * gate(x)) / dx applied to dout; dz [N][C + C/2] = the gate MLP's pre-activation gradients (for npp_se_param_grads)
+extern "C" int npp_se_bwd_acc(const NppTensor* dout, const NppTensor* x, const float* w1, const float* w2, const float* hidden,
+                              const float* gate, NppTensor* dx, float* dz, float* ws, int accumulate, void* stream);
 extern "C" int npp_se_bwd(const NppTensor* dout, const NppTensor* x, const float* w1, const float* w2, const float* hidden,
                           const float* gate, NppTensor* dx, float* dz, float* ws, void* stream) {
+  return npp_se_bwd_acc(dout, x, w1, w2, hidden, gate, dx, dz, ws, 0, stream);
+}
+
+// accumulate != 0: dx += the gradient (dx holds what another consumer of x wrote)
+extern "C" int npp_se_bwd_acc(const NppTensor* dout, const NppTensor* x, const float* w1, const float* w2, const float* hidden,
+                              const float* gate, NppTensor* dx, float* dz, float* ws, int accumulate, void* stream) {
   NPP_REQUIRE(dout && x && dx && dout->ptr && x->ptr && dx->ptr && w1 && w2 && hidden && gate && dz && ws, NPP_E_NULL,
               "npp_se_bwd: null pointer");
   NPP_REQUIRE(dtype_ok(x) && x->dtype == dout->dtype && x->dtype == dx->dtype, NPP_E_DTYPE, "npp_se_bwd: dtype mismatch");
@@ -396,7 +411,7 @@ extern "C" int npp_se_bwd(const NppTensor* dout, const NppTensor* x, const float
                        (long)x->ld, ws, HW, C, pl.cv, pl.cols_blk, pl.rows, pl.slabs);
     const int chunks = chunks_for((long)HW * C, N);
     hipLaunchKernelGGL((se_bwd_apply_kernel<T, V>), dim3(chunks, N), dim3(256), lds_bwd(C), s, (const T*)dout->ptr, (long)dout->ld,
-                       (T*)dx->ptr, (long)dx->ld, (const float*)ws, pl.slabs, gate, hidden, w1, w2, dz, HW, C, pl.cv);
+                       (T*)dx->ptr, (long)dx->ld, (const float*)ws, pl.slabs, gate, hidden, w1, w2, dz, HW, C, pl.cv, accumulate);
   });
   return npp_check_launch("se_bwd");
 }

@@ -299,6 +299,42 @@ def test_data_gradients_accumulate_in_the_conv_epilogues():
     assert rel_err(x0.grad.float().cpu().numpy(), xr.grad.numpy()) < 3e-2
 
 
+def test_data_gradients_accumulate_in_the_stencil_and_gate_kernels():
+    """The same shared gradient buffer through the other cell primitives: a dense conv (stores), then the dilated depthwise conv's
+    data gradient, the max-pool backward and the SE gate's backward each ADD into it (NppConvGeom.relu_in bit 1,
+    npp_pool3x3_bwd_acc, npp_se_bwd_acc) -- against the f32 reference of the four branches' sum (model_augment.py:48-62)."""
+    from npp_amd import _ops as K
+    dev = _dev()
+    N, C, H = 4, 128, 48
+    x_cpu = _rand((N, C, H, H), 61).bfloat16().float()
+    wc = _rand((C, C, 3, 3), 62) * (1.0 / np.sqrt(C * 9))
+    wd = _rand((C, 1, 3, 3), 63) * 0.3
+    w1, b1 = _rand((C // 2, C, 1, 1), 64) * (1.0 / np.sqrt(C)), _rand((C // 2,), 65) * 0.1
+    w2, b2 = _rand((C, C // 2, 1, 1), 66) * (1.0 / np.sqrt(C // 2)), _rand((C,), 67) * 0.1
+    xr = x_cpu.clone().requires_grad_(True)
+    ys = [F.conv2d(F.relu(xr), wc.bfloat16().float(), None, 1, 1),
+          F.conv2d(F.relu(xr), wd, None, 1, 2, 2, groups=C),
+          F.max_pool2d(xr, 3, 1, 1),
+          xr * torch.sigmoid(F.conv2d(F.relu(F.conv2d(xr.mean((2, 3), keepdim=True), w1, b1)), w2, b2))]
+    gys = [_rand(tuple(y.shape), 70 + i).bfloat16().float() for i, y in enumerate(ys)]
+    sum((y * g).sum() for y, g in zip(ys, gys)).backward()
+    x0 = _to_dev(x_cpu, torch.bfloat16).detach().requires_grad_(True)
+    x = K.bn_add(K.BnSide(x0))
+    before = list(K.FAN_STATS)
+    P = lambda t: t.to(dev).requires_grad_(True)      # noqa: E731
+    outs = [K.conv2d(x, P(wc), None, 1, 1, 1, relu_in=True)[0],
+            K.dwconv2d(x, P(wd), 1, 2, 2, relu_in=True),
+            K.pool3x3(x, False, 1)[0],
+            K.se_scale(x, P(w1), P(b1), P(w2), P(b2))]
+    for o, r in zip(outs, ys):
+        assert rel_err(o.detach().float().cpu().numpy(), r.detach().numpy()) < 3e-2
+    torch.autograd.backward(outs, [_to_dev(g, torch.bfloat16) for g in gys])
+    torch.cuda.synchronize()
+    stored, added, private = (a - b for a, b in zip(K.FAN_STATS, before))
+    assert (stored, added, private) == (1, 3, 0), (stored, added, private)
+    assert rel_err(x0.grad.float().cpu().numpy(), xr.grad.numpy()) < 3e-2
+
+
 def _g8_launch_count(cin, cout, k, fam="conv_g8", hw=192):
     """fwd + dgrad of one conv in bf16 -> number of launches of the given conv kernel family (profiler family counter)."""
     import ctypes as C
