@@ -492,10 +492,10 @@ def main():
                    "conv_g4": "conv_g4_kernel + conv_h3_kernel (stride-1 conv fwd + dgrad; g4: 1x1 / 3x3 on 64x64 / 128x128 / 64x32 tiles, LDS-DMA ring of 2; h3: 3x3 with an LDS-resident halo footprint on the >= 30k-pixel maps; MFMA 16x16x32)",
                    "conv_wgrad": "weight-gradient family (conv_wgrad_g4_batched_kernel: every LDS-DMA-eligible weight gradient of the step in one launch per variant over a device job table -- pixel-major LDS-DMA + transposing reads, MFMA 16x16x32; strided / odd-channel layers on conv_wgrad_kernel)"}
         # HBM bytes per launch: rocprofv3 --pmc cannot run inside this process, so the counters come from the committed passes
-        # of this same command (tools/final_profiles.sh -> profiles/r02_pmc_traffic.json) -- and only while the kernel sources
+        # of this same command (tools/final_profiles.sh -> profiles/r03_pmc_traffic.json) -- and only while the kernel sources
         # still hash to what those passes ran on; otherwise `traffic` is null and `traffic_note` says why
         traffic_db, traffic_note = {}, None
-        traffic_file = os.path.join("profiles", "r02_pmc_traffic.json")
+        traffic_file = os.path.join("profiles", "r03_pmc_traffic.json")
         try:
             with open(os.path.join(REPO, traffic_file)) as fh:
                 traffic_db = json.load(fh)

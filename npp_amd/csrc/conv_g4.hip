@@ -257,6 +257,14 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ss[h][j] = 0.f; sq[h][j] = 0.f; }
+    u32x4 pv[MI];      // accumulate form: what the 16-byte stores of this 32-channel block will add to -- all MI loads in flight together
+    if (p.accum) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const long gm = (long)m0 + wm * TM + mi * 16 + lrow;
+        pv[mi] = gm < p.M ? *reinterpret_cast<const u32x4*>(yg + gm * p.ldy + cb + chb) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const long gm = (long)m0 + wm * TM + mi * 16 + lrow;
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
             o = o & __builtin_bit_cast(u32x4, m);
           }
         }
-        if (p.accum) o = add_bf16x8(o, *reinterpret_cast<const u32x4*>(yg + gm * p.ldy + cb + chb));
+        if (p.accum) o = add_bf16x8(o, pv[mi]);
         if constexpr ((G4_DBG & 1) == 0) *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
         else asm volatile("" :: "v"(o));
       }

@@ -234,6 +234,15 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_h3_kernel(IgemmParams p, 
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ssum[h][j] = 0.f; ssq[h][j] = 0.f; }
+    u32x4 pv[MI];      // accumulate form: what this 32-channel block's stores will add to -- all MI loads in flight together
+    if (p.accum) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int gy = y0 + wm * MI + mi;
+        const long gm = ((long)img * p.H + gy) * p.W + gx;
+        pv[mi] = (gy < p.H && col_ok) ? *reinterpret_cast<const u32x4*>(yg + gm * p.ldy + cb + chb) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int gy = y0 + wm * MI + mi;
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_h3_kernel(IgemmParams p, 
             o = o & __builtin_bit_cast(u32x4, m);
           }
         }
-        if (p.accum) o = add_bf16x8(o, *reinterpret_cast<const u32x4*>(yg + gm * p.ldy + cb + chb));
+        if (p.accum) o = add_bf16x8(o, pv[mi]);
         *reinterpret_cast<u32x4*>(yg + gm * p.ldy + cb + chb) = o;
       }
     }
