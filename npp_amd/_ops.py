@@ -751,7 +751,7 @@ class WeightPacker:
         sig = tuple(w._version for w in ws)
         key = (dtype, device, tuple(w.data_ptr() for w in ws))
         if self.key != key:
-            if any(w.dtype != torch.float32 or not w.is_contiguous() or w.device != device for w in ws):
+            if any(w.dtype != torch.float32 or not w.is_contiguous() or w.device != device or w.shape[2] * w.shape[3] > 64 for w in ws):
                 return        # unusual storage: leave it to the per-call path
             self._build(dtype, device)
             self.sig = None

@@ -337,11 +337,28 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 //   forward image : block = (co, 64 input channels): reads 64*taps contiguous floats, writes taps runs of 64 elements
 //   dgrad image   : block = (16 co, 16 ci), taps <= 9: reads 16 runs of 16*taps floats, writes 16*taps runs of 16 elements
 constexpr int PACK_FWD_C = 64, PACK_DG_T = 16;   // 9.3 KiB of LDS per block: 36 KiB (32 x 32 dgrad tiles) limited a CU to 4 blocks
+// Round 3: the model's 552 weights made 444 294 blocks of 64 .. 2304 elements (0.54 ms at the head of every step, 1.7 TB/s); the
+// 1x1 layers (two thirds of the blocks) now move 2048 (forward image: a cast, 8 elements per thread) or 64 x 64 (data-gradient
+// image: a transpose) elements per block and the 3x3 forward image 256 input channels (or several output rows) per block.
+constexpr int PACK_FWD_C9 = 256, PACK_DG_T1 = 64, PACK_FLAT = 2048;
+constexpr int PACK_DG_CO = 64, PACK_DG_CI = 8;      // 3x3 data-gradient tiles: runs of 64 output channels (128 B) per (ci, tap) -- 16 x 16
+                                                    // tiles wrote 32-byte runs
+constexpr int PACK_LDS_FLOATS = PACK_DG_CO * (PACK_DG_CI * 9 + 1);      // 4672 >= 64 * 65, 256 * 9, 64 * 25
+
+__host__ __device__ static inline int pack_fwd_rows(int cin) { return cin < PACK_FWD_C9 ? (PACK_FWD_C9 / cin > 0 ? PACK_FWD_C9 / cin : 1) : 1; }
 
 static inline long pack_job_blocks(int cout, int cin, int taps, int for_dgrad) {
-  if (!for_dgrad) return (long)cout * ((cin + PACK_FWD_C - 1) / PACK_FWD_C);
+  if (!for_dgrad) {
+    if (taps == 1) return ((long)cout * cin + PACK_FLAT - 1) / PACK_FLAT;
+    if (taps <= 9) {
+      const int nco = pack_fwd_rows(cin);
+      return (long)((cout + nco - 1) / nco) * ((cin + PACK_FWD_C9 - 1) / PACK_FWD_C9);
+    }
+    return (long)cout * ((cin + PACK_FWD_C - 1) / PACK_FWD_C);
+  }
   if (taps > 9) return ((long)cin * ((taps * ((cout + 7) / 8 * 8) + 63) / 64 * 64) + 255) / 256;   // element-wise fallback
-  return (long)((cout + PACK_DG_T - 1) / PACK_DG_T) * ((cin + PACK_DG_T - 1) / PACK_DG_T);
+  if (taps == 1) return (long)((cout + PACK_DG_T1 - 1) / PACK_DG_T1) * ((cin + PACK_DG_T1 - 1) / PACK_DG_T1);
+  return (long)((cout + PACK_DG_CO - 1) / PACK_DG_CO) * ((cin + PACK_DG_CI - 1) / PACK_DG_CI);
 }
 
 template <typename T>
@@ -349,7 +366,41 @@ NPP_DEV void pack_tile(const NppPackJob& j, long tb, float* lds) {
   const int t = threadIdx.x;
   const int taps = j.kh * j.kw;
   T* __restrict__ out = reinterpret_cast<T*>(j.out);
-  if (!j.for_dgrad) {
+  if (!j.for_dgrad && taps == 1) {
+    // [co][ci] -> [co][kpad]: a cast; 8 consecutive elements per thread (one row when cin % 8 == 0)
+    const int cp = (j.cin + 7) / 8 * 8, kpad = (cp + 63) / 64 * 64;
+    const long total = (long)j.cout * j.cin;
+    const long e0 = tb * PACK_FLAT + (long)t * 8;
+    if (e0 >= total) return;
+    if ((j.cin & 7) == 0 && e0 + 8 <= total) {
+      const int row = (int)(e0 / j.cin), c = (int)(e0 - (long)row * j.cin);
+      const float4 a = *reinterpret_cast<const float4*>(j.w + e0), b4 = *reinterpret_cast<const float4*>(j.w + e0 + 4);
+      T* o = out + (long)row * kpad + c;
+      Elt<T>::st(o + 0, a.x); Elt<T>::st(o + 1, a.y); Elt<T>::st(o + 2, a.z); Elt<T>::st(o + 3, a.w);
+      Elt<T>::st(o + 4, b4.x); Elt<T>::st(o + 5, b4.y); Elt<T>::st(o + 6, b4.z); Elt<T>::st(o + 7, b4.w);
+    } else {
+      for (int k = 0; k < 8 && e0 + k < total; ++k) {
+        const int row = (int)((e0 + k) / j.cin), c = (int)((e0 + k) - (long)row * j.cin);
+        Elt<T>::st(out + (long)row * kpad + c, j.w[e0 + k]);
+      }
+    }
+  } else if (!j.for_dgrad && taps <= 9) {
+    // nco output rows x n input channels (nco > 1 only when the rows are whole: n == cin), [c][tap] -> taps runs of n elements
+    const int cp = (j.cin + 7) / 8 * 8, kpad = (taps * cp + 63) / 64 * 64;
+    const int cchunks = (j.cin + PACK_FWD_C9 - 1) / PACK_FWD_C9;
+    const int nco_full = pack_fwd_rows(j.cin);
+    const int co0 = (int)(tb / cchunks) * nco_full, c0 = (int)(tb % cchunks) * PACK_FWD_C9;
+    const int n = min(PACK_FWD_C9, j.cin - c0), nco = min(nco_full, j.cout - co0);
+    const int per = n * taps;
+    const float* src = j.w + ((long)co0 * j.cin + c0) * taps;          // (nco > 1: c0 == 0 and the rows are contiguous)
+    for (int i = t; i < nco * per; i += 256) lds[i] = src[i];          // [co][c][tap]
+    __syncthreads();
+    for (int i = t; i < nco * per; i += 256) {
+      const int co = i / per, r = i - co * per;
+      const int tap = r / n, c = r - tap * n;
+      Elt<T>::st(out + (long)(co0 + co) * kpad + tap * cp + c0 + c, lds[co * per + c * taps + tap]);
+    }
+  } else if (!j.for_dgrad) {
     const int cp = (j.cin + 7) / 8 * 8, kpad = (taps * cp + 63) / 64 * 64;
     const int cchunks = (j.cin + PACK_FWD_C - 1) / PACK_FWD_C;
     const int co = (int)(tb / cchunks), c0 = (int)(tb % cchunks) * PACK_FWD_C;
@@ -361,12 +412,28 @@ NPP_DEV void pack_tile(const NppPackJob& j, long tb, float* lds) {
       const int tap = i / n, c = i - tap * n;
       Elt<T>::st(out + (long)co * kpad + tap * cp + c0 + c, lds[c * taps + tap]);
     }
+  } else if (taps == 1) {
+    // [co][ci] -> [ci][co]: 64 x 64 transposes
+    const int cop = (j.cout + 7) / 8 * 8, kpad = (cop + 63) / 64 * 64;
+    const int citiles = (j.cin + PACK_DG_T1 - 1) / PACK_DG_T1;
+    const int co0 = (int)(tb / citiles) * PACK_DG_T1, ci0 = (int)(tb % citiles) * PACK_DG_T1;
+    const int nco = min(PACK_DG_T1, j.cout - co0), nci = min(PACK_DG_T1, j.cin - ci0);
+    constexpr int pitch = PACK_DG_T1 + 1;
+    for (int i = t; i < nco * nci; i += 256) {
+      const int co = i / nci, ci = i - co * nci;
+      lds[co * pitch + ci] = j.w[(long)(co0 + co) * j.cin + ci0 + ci];
+    }
+    __syncthreads();
+    for (int i = t; i < nco * nci; i += 256) {
+      const int ci = i / nco, co = i - ci * nco;
+      Elt<T>::st(out + (long)(ci0 + ci) * kpad + co0 + co, lds[co * pitch + ci]);
+    }
   } else if (taps <= 9) {
     const int cop = (j.cout + 7) / 8 * 8, kpad = (taps * cop + 63) / 64 * 64;
-    const int citiles = (j.cin + PACK_DG_T - 1) / PACK_DG_T;
-    const int co0 = (int)(tb / citiles) * PACK_DG_T, ci0 = (int)(tb % citiles) * PACK_DG_T;
-    const int nco = min(PACK_DG_T, j.cout - co0), nci = min(PACK_DG_T, j.cin - ci0);
-    const int run = nci * taps, pitch = PACK_DG_T * taps + 1;          // odd pitch: the co-fastest reads below spread over banks
+    const int citiles = (j.cin + PACK_DG_CI - 1) / PACK_DG_CI;
+    const int co0 = (int)(tb / citiles) * PACK_DG_CO, ci0 = (int)(tb % citiles) * PACK_DG_CI;
+    const int nco = min(PACK_DG_CO, j.cout - co0), nci = min(PACK_DG_CI, j.cin - ci0);
+    const int run = nci * taps, pitch = PACK_DG_CI * taps + 1;         // odd pitch: the co-fastest reads below spread over banks
     for (int i = t; i < nco * run; i += 256) {
       const int co = i / run, e = i - co * run;
       lds[co * pitch + e] = j.w[((long)(co0 + co) * j.cin + ci0) * taps + e];     // e = ci*taps + tap
@@ -390,7 +457,8 @@ NPP_DEV void pack_tile(const NppPackJob& j, long tb, float* lds) {
 
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const NppPackJob* __restrict__ jobs, int njobs,
                                                                    const int32_t* __restrict__ block_job) {
-  __shared__ float lds[(PACK_DG_T * (PACK_DG_T * 9 + 1) > PACK_FWD_C * 25) ? PACK_DG_T * (PACK_DG_T * 9 + 1) : PACK_FWD_C * 25];
+  __shared__ float lds[PACK_LDS_FLOATS];
+  static_assert(PACK_LDS_FLOATS >= PACK_FWD_C9 * 9 && PACK_LDS_FLOATS >= PACK_DG_T1 * (PACK_DG_T1 + 1) && PACK_LDS_FLOATS >= PACK_FWD_C * 25, "");
   const long b = blockIdx.x;
   int lo = 0, hi = njobs - 1;
   if (block_job) {
@@ -565,6 +633,10 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
     if (conv_s1_launch(p, x->dtype, s, ws, ws_bytes)) return npp_check_launch("conv_s1");
     prof1.cancel();    // not taken: the generic kernel below is a different family
   }
+  static const bool trace_generic = getenv("NPP_TRACE_GENERIC") != nullptr;      // shape census of what still runs on the generic kernel
+  if (trace_generic)
+    fprintf(stderr, "npp-generic conv N=%d %dx%d->%dx%d C %d->%d k%dx%d s%d d%d up%d relu%d mask%d stats%d par%d\n", p.N, p.H, p.W, p.OH, p.OW, p.Cin,
+            p.Cout, p.KH, p.KW, p.sh, p.dh, p.uph, p.relu_in, p.mask ? 1 : 0, p.stats ? 1 : 0, p.par);
   ProfScope prof(NPP_FAM_CONV_IGEMM, x->dtype, s, flops, bytes);
 #define LAUNCH(T, BN_) hipLaunchKernelGGL((conv_igemm_kernel<T, BN_>), dim3(grid), dim3(256), 0, s, p)
   if (x->dtype == NPP_BF16) {

@@ -413,6 +413,10 @@ extern "C" int npp_conv_wgrad(const NppTensor* x, const NppTensor* dy, float* dw
   if (conv_wgrad_g4_launch(p, x->dtype, s)) return npp_check_launch("conv_wgrad_g4");
   if (conv_wgrad_tap_launch(p, x->dtype, s)) return npp_check_launch("conv_wgrad_tap");
   p.ntiles = tiles; p.nblocks = tiles * splits;
+  static const bool trace_generic = getenv("NPP_TRACE_GENERIC") != nullptr;
+  if (trace_generic)
+    fprintf(stderr, "npp-generic wgrad N=%d %dx%d->%dx%d C %d->%d k%dx%d s%d d%d relu%d\n", p.N, p.H, p.W, p.OH, p.OW, p.Cin, p.Cout, p.KH, p.KW,
+            p.sh, p.dh, p.relu_in);
   dim3 grid(tiles * splits);
 #define LAUNCH(T, TM_) hipLaunchKernelGGL((conv_wgrad_kernel<T, TM_>), grid, dim3(256), 0, s, p)
   if (x->dtype == NPP_BF16) {

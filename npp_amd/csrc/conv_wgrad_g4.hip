@@ -607,6 +607,162 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgradParams p, WG3
       }
 }
 
+
+// ---- narrow 3x3 layers, Cin = Cout = 32 or 64 (the encoder's first two stages: 43 + 35 weight gradients per step) ------------------
+// On the 128 x 128 tile above these fill 1/16 or 1/4 of the MFMA work they pay for (32 of 128 output channels, 288 of 384 columns)
+// and cost the batched launch as much as fourteen 128 -> 128 layers.  Here a workgroup computes the WHOLE gradient [C][9 x C] of a
+// range of K-tiles, a K-tile = RPT full image rows (RPT x W = 96 or 128 pixels): the rows y-1 .. y+RPT of x are staged with one
+// zero pixel on either side (ReLU applied at the store), so the nine taps read the same pixel-major image through a constant
+// offset and need no border masks; dy is staged pixel-major next to it.  The next K-tile's pieces are fetched into registers
+// under the MFMAs (their addresses are worked out once per workgroup, not per K-tile).  Both operands come back transposed (ds_read_b64_tr_b16);
+// wave w owns the column fragments w, w + 4, ... of the 9 x C / 16.  Plain loads + ds_write (pitch C x 2 + 16 bytes): a few
+// workgroups per CU hide the staging, the kernel's MFMA work is ~1/16 of what the 128 x 128 tile spent on these layers.
+template <int C, bool RELU>
+NPP_DEV void wgn_body(const WgradParams& p, const WG3Extra& e, const int bid) {
+  constexpr int MI = C / 16;               // output-channel fragments
+  constexpr int CG = C / 16;               // input-channel fragments per tap
+  constexpr int NF = 9 * CG;               // column fragments
+  constexpr int NFW = (NF + 3) / 4;        // per wave
+  constexpr int PX = C * 2 + 16;           // bytes per staged pixel
+  constexpr int PCS = C / 8;               // 16-byte pieces per pixel
+  constexpr int NPX = 7, NPD = 3;          // pieces per thread: x image <= 7 x 256, dy <= 3 x 256 (checked by wgn_prepare)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int RPT = e.cintiles, W = p.W, H = p.H, W2 = W + 2;
+  const int KTP = RPT * W;                 // pixels per K-tile (96 or 128)
+  const int KS = KTP / 32;
+  unsigned char* sx = smem;                                  // [(RPT + 2)][W + 2][PX]
+  unsigned char* sd = smem + (RPT + 2) * W2 * PX;            // [KTP][PX]
+  const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
+  const bf16_t* __restrict__ dg = reinterpret_cast<const bf16_t*>(p.dy);
+  const int kt_begin = bid * e.ktiles_per_split;
+  int kt_end = kt_begin + e.ktiles_per_split;
+  if (kt_end > e.nktiles) kt_end = e.nktiles;
+  if (kt_begin >= kt_end) return;
+  const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pq = i16 & 3;
+  // byte offset of the lane's pixel (K index ks*32 + g*8 + h*4 + q4) in the dy image and -- at tap (0, 0) -- in the x image
+  unsigned offd[4][2], offx[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = ks * 32 + g * 8 + h * 4 + q4;
+      const int r = k / W, xx = k - r * W;
+      offd[ks][h] = (unsigned)(k * PX + pq * 8);
+      offx[ks][h] = (unsigned)((r * W2 + xx) * PX + pq * 8);
+    }
+  // the thread's pieces of a K-tile, worked out once: LDS byte offset, element offset from the K-tile's first pixel, image row
+  // relative to the K-tile (-1 .. RPT) or a marker for "always zero" (the halo columns) / "not mine"
+  int xl[NPX], xo[NPX], xr[NPX];
+  const int nxp = (RPT + 2) * W2 * PCS;
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) {
+    const int i = t + 256 * j;
+    const int pc = i % PCS, px = i / PCS;
+    const int rr = px / W2, cc = px - rr * W2;
+    xl[j] = i < nxp ? px * PX + pc * 16 : -1;
+    xo[j] = ((rr - 1) * W + cc - 1) * p.ldx + pc * 8;
+    xr[j] = (cc >= 1 && cc <= W) ? rr - 1 : (1 << 20);
+  }
+  int dl[NPD], dof[NPD];
+  const int ndp = KTP * PCS;
+#pragma unroll
+  for (int j = 0; j < NPD; ++j) {
+    const int i = t + 256 * j;
+    const int pc = i % PCS, k = i / PCS;
+    dl[j] = i < ndp ? k * PX + pc * 16 : -1;
+    dof[j] = k * p.ldy + pc * 8;
+  }
+  f32x4g acc[MI][NFW];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int f = 0; f < NFW; ++f) acc[mi][f] = f32x4g{0.f, 0.f, 0.f, 0.f};
+  const int rows_per_img = H / RPT;
+  u32x4 vx[NPX], vd[NPD];
+  auto fetch = [&](int kt) {
+    const int n = kt / rows_per_img, y0 = (kt - n * rows_per_img) * RPT;
+    const long pix0 = (long)(n * H + y0) * W;
+    const bf16_t* xb = xg + pix0 * p.ldx;
+    const bf16_t* db = dg + pix0 * p.ldy;
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      vx[j] = u32x4{0u, 0u, 0u, 0u};
+      if (xl[j] >= 0 && (unsigned)(y0 + xr[j]) < (unsigned)H) vx[j] = *reinterpret_cast<const u32x4*>(xb + xo[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NPD; ++j)
+      if (dl[j] >= 0) vd[j] = *reinterpret_cast<const u32x4*>(db + dof[j]);
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int j = 0; j < NPX; ++j)
+      if (xl[j] >= 0) {
+        u32x4 v = vx[j];
+        if (RELU) {
+          const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+          v = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
+        }
+        *reinterpret_cast<u32x4*>(sx + xl[j]) = v;
+      }
+#pragma unroll
+    for (int j = 0; j < NPD; ++j)
+      if (dl[j] >= 0) *reinterpret_cast<u32x4*>(sd + dl[j]) = vd[j];
+  };
+  fetch(kt_begin);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    __syncthreads();                       // the previous K-tile's fragments have been read
+    stash();
+    __syncthreads();
+    if (kt + 1 < kt_end) fetch(kt + 1);    // (in flight under the MFMAs below)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks >= KS) break;
+      s16x8 fa[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(sd + offd[ks][0] + mi * 32));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(sd + offd[ks][1] + mi * 32));
+        fa[mi] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int f = 0; f < NFW; ++f) {
+        const int nf = wave + 4 * f;
+        if (nf < NF) {
+          const int tap = nf / CG, cg = nf - tap * CG;
+          const int kh = tap / 3, kw = tap - kh * 3;
+          const unsigned to = (unsigned)((kh * W2 + kw) * PX + cg * 32);
+          const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(sx + offx[ks][0] + to));
+          const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(sx + offx[ks][1] + to));
+          const s16x8 fb = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[mi][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb),
+                                                                acc[mi][f], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // acc[mi][f][j] = dW[co = mi*16 + 4*g + j][col = nf*16 + i16],  col = tap * C + ci
+#pragma unroll
+  for (int f = 0; f < NFW; ++f) {
+    const int nf = wave + 4 * f;
+    if (nf < NF) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          atomicAdd(p.dwp + (long)(mi * 16 + 4 * g + j) * p.Kpad + nf * 16 + i16, acc[mi][f][j]);
+    }
+  }
+}
+
+template <int C, bool RELU>
+__global__ __launch_bounds__(256) void conv_wgrad_narrow_kernel(WgradParams p, WG3Extra e) {
+  wgn_body<C, RELU>(p, e, (int)blockIdx.x);
+}
+
 // Many small weight-gradient problems in ONE launch (npp_conv_wgrad_batched): block b works on job block_job[b] with the block id it
 // would have had in that job's own launch.  The small-map layers (12^2 / 24^2: ~100 blocks and ~25 us of latency each, 140 of them
 // per step) have no reader before the optimizer; run together at the end of backward they are throughput-, not latency-bound.
@@ -633,6 +789,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_g3_batched_kernel(const WG4
   const WgradParams p = jb->p;
   const WG3Extra e = jb->e3;
   wg3_body<RELU, R>(p, e, (int)blockIdx.x - jb->first_block);
+}
+
+template <int C, bool RELU>
+__global__ __launch_bounds__(256) void conv_wgrad_narrow_batched_kernel(const WG4Job* __restrict__ jobs, const int* __restrict__ block_job) {
+  const int j = __builtin_amdgcn_readfirstlane(block_job[blockIdx.x]);
+  const WG4Job* jb = jobs + j;
+  const WgradParams p = jb->p;
+  const WG3Extra e = jb->e3;
+  wgn_body<C, RELU>(p, e, (int)blockIdx.x - jb->first_block);
 }
 
 bool wg4_raise_lds(const void* fp, size_t bytes) {
@@ -736,6 +901,57 @@ static bool wg3_prepare(const WgradParams& p, int dtype, int max_blocks, WgradPa
 
 constexpr size_t WG3_LDS = 3 * (16384 + 18 * 1024);
 
+// the narrow kernel: 3x3, Cin == Cout in {32, 64}, image rows that tile a 96- or 128-pixel K-tile
+static size_t wgn_lds(const WgradParams& p, int rpt) {
+  const int px = p.Cin * 2 + 16;
+  return (size_t)((rpt + 2) * (p.W + 2) + rpt * p.W) * px;
+}
+static bool wgn_prepare(const WgradParams& p, int dtype, int max_blocks, WgradParams& q, WG3Extra& e, int& nblocks, int per_split = 32) {
+  static const bool disabled = getenv("NPP_DISABLE_WGN") != nullptr;
+  if (disabled || dtype != NPP_BF16) return false;
+  if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.KH != 3 || p.KW != 3) return false;
+  if (p.ph != 1 || p.pw != 1 || p.OH != p.H || p.OW != p.W) return false;
+  if (p.Cin != p.Cout || (p.Cin != 32 && p.Cin != 64) || p.Cp != p.Cin || !p.vec_dy || p.ldx % 8 != 0 || p.ldy % 8 != 0) return false;
+  int rpt = 0;
+  if (p.W == 128) rpt = 1;
+  else if (p.W <= 96 && 96 % p.W == 0 && p.W >= 4) rpt = 96 / p.W;
+  if (rpt == 0 || p.H % rpt != 0 || rpt > 8) return false;
+  if (wgn_lds(p, rpt) > 64 * 1024) return false;
+  if ((rpt + 2) * (p.W + 2) * (p.Cin / 8) > 7 * 256 || rpt * p.W * (p.Cin / 8) > 3 * 256) return false;      // (NPX, NPD of wgn_body)
+  e.HW = p.H * p.W;
+  e.cintiles = rpt;
+  e.nktiles = p.N * (p.H / rpt);
+  e.xbytes = 0; e.dybytes = 0;
+  q = p;
+  q.rowtiles = 1;
+  // every workgroup ends with C x 9C atomics (37 / 147 KiB): ~32 K-tiles each, never more than max_blocks
+  static const int env_split = getenv("NPP_WGN_SPLIT") ? atoi(getenv("NPP_WGN_SPLIT")) : 0;
+  if (env_split > 0) per_split = env_split;
+  int blocks = (e.nktiles + per_split - 1) / per_split;
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks < 1) blocks = 1;
+  e.ktiles_per_split = (e.nktiles + blocks - 1) / blocks;
+  blocks = (e.nktiles + e.ktiles_per_split - 1) / e.ktiles_per_split;
+  e.ntiles = 1; e.nblocks = blocks;
+  nblocks = blocks;
+  return true;
+}
+#define WGN_DISPATCH(KERNEL, GRID, ...)                                                                       \
+  do {                                                                                                        \
+    const size_t lds_ = wgn_lds_bytes;                                                                        \
+    if (wgn_c == 32) {                                                                                        \
+      if (wgn_relu) { if (!wg4_raise_lds(reinterpret_cast<const void*>(KERNEL<32, true>), 65536)) return false;  \
+                      hipLaunchKernelGGL((KERNEL<32, true>), dim3(GRID), dim3(256), lds_, stream, __VA_ARGS__); } \
+      else          { if (!wg4_raise_lds(reinterpret_cast<const void*>(KERNEL<32, false>), 65536)) return false; \
+                      hipLaunchKernelGGL((KERNEL<32, false>), dim3(GRID), dim3(256), lds_, stream, __VA_ARGS__); } \
+    } else {                                                                                                  \
+      if (wgn_relu) { if (!wg4_raise_lds(reinterpret_cast<const void*>(KERNEL<64, true>), 65536)) return false;  \
+                      hipLaunchKernelGGL((KERNEL<64, true>), dim3(GRID), dim3(256), lds_, stream, __VA_ARGS__); } \
+      else          { if (!wg4_raise_lds(reinterpret_cast<const void*>(KERNEL<64, false>), 65536)) return false; \
+                      hipLaunchKernelGGL((KERNEL<64, false>), dim3(GRID), dim3(256), lds_, stream, __VA_ARGS__); } \
+    }                                                                                                         \
+  } while (0)
+
 // the thin-output kernel: 3x3, Cout <= 8 (dy rows of 16 bytes), Cin % 128 == 0
 static bool wgt_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   static const bool disabled = getenv("NPP_DISABLE_THIN") != nullptr;
@@ -772,6 +988,17 @@ static bool wgt_launch(const WgradParams& p, int dtype, hipStream_t stream) {
 bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   if (wgt_launch(p, dtype, stream)) return true;
   WgradParams q;
+  {
+    WG3Extra en;
+    int nbn = 0;
+    if (wgn_prepare(p, dtype, 512, q, en, nbn, 6)) {      // (a launch of its own: fill the chip)
+      const size_t wgn_lds_bytes = wgn_lds(p, en.cintiles);
+      const int wgn_c = p.Cin;
+      const bool wgn_relu = p.relu_in != 0;
+      WGN_DISPATCH(conv_wgrad_narrow_kernel, nbn, q, en);
+      return true;
+    }
+  }
   {
     WG3Extra e3;
     int nb3 = 0;
@@ -822,6 +1049,13 @@ bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_hos
   if (splits) *splits = 0;
   int nb = 0;
   memset(&jb->e3, 0, sizeof(jb->e3));
+  if (wgn_prepare(p, dtype, max_blocks, jb->p, jb->e3, nb)) {
+    memset(&jb->e, 0, sizeof(jb->e));
+    jb->first_block = 0; jb->_pad = 0;
+    *variant = 6 + (p.Cin == 64 ? 2 : 0) + (p.relu_in ? 1 : 0);      // 6, 7: C = 32; 8, 9: C = 64
+    *nblocks = nb;
+    return true;
+  }
   // (a job of the three-tap kernel may take half the slots of a 128 x 128 job: one workgroup per CU instead of two)
   if (wg3_prepare(p, dtype, max_blocks / 2 > 0 ? max_blocks / 2 : 1, jb->p, jb->e3, nb)) {
     memset(&jb->e, 0, sizeof(jb->e));
@@ -842,15 +1076,23 @@ bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_hos
 bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, int* map_host, const int* map_dev, const int* variant_of,
                                 const int* blocks_of, hipStream_t stream) {
   WG4Job* jobs = reinterpret_cast<WG4Job*>(jobs_host);
-  long off[7] = {0, 0, 0, 0, 0, 0, 0};
+  long off[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  size_t lds_narrow[4] = {0, 0, 0, 0};      // largest LDS footprint among the jobs of each narrow variant
   // longest blocks first (blocks of one launch start in block-id order): the tail of a launch is then made of short blocks
   std::vector<int> order(n);
   for (int i = 0; i < n; ++i) order[i] = i;
   static const bool lpt = !(getenv("NPP_WGB_SORT") && atoi(getenv("NPP_WGB_SORT")) == 0);
-  auto klen = [&](int a) { return variant_of[a] >= 4 ? 3 * jobs[a].e3.ktiles_per_split : jobs[a].e.ktiles_per_split; };
+  auto klen = [&](int a) {
+    return variant_of[a] >= 6 ? jobs[a].e3.ktiles_per_split : variant_of[a] >= 4 ? 3 * jobs[a].e3.ktiles_per_split : jobs[a].e.ktiles_per_split;
+  };
+  for (int i = 0; i < n; ++i)
+    if (variant_of[i] >= 6) {
+      const size_t l = wgn_lds(jobs[i].p, jobs[i].e3.cintiles);
+      if (l > lds_narrow[variant_of[i] - 6]) lds_narrow[variant_of[i] - 6] = l;
+    }
   if (lpt)
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return klen(a) > klen(b); });
-  for (int v = 0; v < 6; ++v) {
+  for (int v = 0; v < 10; ++v) {
     long cnt = 0;
     for (int k = 0; k < n; ++k) {
       const int i = order[k];
@@ -862,9 +1104,9 @@ bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, in
     }
     off[v + 1] = off[v] + cnt;
   }
-  if (off[6] == 0) return true;
+  if (off[10] == 0) return true;
   if (hipMemcpyAsync(const_cast<void*>(jobs_dev), jobs_host, (size_t)n * sizeof(WG4Job), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
-  if (hipMemcpyAsync(const_cast<int*>(map_dev), map_host, (size_t)off[6] * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
+  if (hipMemcpyAsync(const_cast<int*>(map_dev), map_host, (size_t)off[10] * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
   const WG4Job* jd = reinterpret_cast<const WG4Job*>(jobs_dev);
 #define WG4_BATCH(V_, RELU_, TAPS_)                                                                                                \
   if (off[V_ + 1] > off[V_]) {                                                                                                     \
@@ -883,6 +1125,17 @@ bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, in
   WG3_BATCH(4, false)
   WG3_BATCH(5, true)
 #undef WG3_BATCH
+#define WGN_BATCH(V_, C_, RELU_)                                                                                                    \
+  if (off[V_ + 1] > off[V_]) {                                                                                                     \
+    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_narrow_batched_kernel<C_, RELU_>), 65536)) return false;            \
+    hipLaunchKernelGGL((conv_wgrad_narrow_batched_kernel<C_, RELU_>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(256),          \
+                       lds_narrow[V_ - 6], stream, jd, map_dev + off[V_]);                                                         \
+  }
+  WGN_BATCH(6, 32, false)
+  WGN_BATCH(7, 32, true)
+  WGN_BATCH(8, 64, false)
+  WGN_BATCH(9, 64, true)
+#undef WGN_BATCH
   WG4_BATCH(0, false, false)
   WG4_BATCH(1, true, false)
   WG4_BATCH(2, false, true)

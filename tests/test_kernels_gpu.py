@@ -198,7 +198,12 @@ def test_benched_shapes_match_cpu_reference(case, batched_wgrad):
     (128, 128, 3, 6, 40, 5, True),       # H < 64 / W rows per K-tile, image boundaries inside a K-tile
     (384, 128, 3, 24, 24, 4, True),      # three input-channel tiles
     (128, 128, 1, 24, 24, 4, True),      # 1x1 (the 128 x 128 kernel)
-    (64, 64, 3, 24, 24, 4, True),        # narrow layers (zero-filled part of the 128 x 128 tile)
+    (64, 64, 3, 24, 24, 4, True),        # narrow-layer kernel: four image rows per K-tile
+    (32, 32, 3, 96, 96, 2, True),        # narrow-layer kernel: one image row per K-tile (the encoder's first stage)
+    (64, 64, 3, 48, 48, 2, False),       # narrow-layer kernel: two rows per K-tile (second stage), no ReLU
+    (32, 32, 3, 12, 12, 5, True),        # narrow-layer kernel: eight rows per K-tile, more K-tiles than one workgroup takes
+    (32, 32, 3, 6, 128, 3, True),        # narrow-layer kernel: 128-pixel rows
+    (64, 64, 3, 13, 17, 2, True),        # narrow channels at an extent the narrow kernel refuses (128 x 128 tile, zero-filled)
     (384, 6, 3, 96, 96, 1, True),        # thin-output kernel (edge head): one image row = 1.5 K-tiles
     (384, 6, 3, 13, 17, 3, True),        # thin-output kernel, odd extents
     (128, 8, 3, 6, 40, 5, False),        # thin-output kernel, 8 output channels, several images per K-tile
@@ -835,6 +840,35 @@ def test_packed_weights_follow_silent_parameter_updates():
     assert w._version == v
     y1 = m(x).detach()
     assert float((y1 - y0).abs().max()) > 1e-3        # the forward saw the new weights
+
+
+def test_batched_weight_packing_equals_the_per_weight_kernel():
+    """K.WeightPacker (every operand image of a model in ONE launch; tiles of 2048 / 64 x 64 / 256 x taps elements) against
+    npp_pack_weight (one thread per element), forward and data-gradient images, bf16 and f32, bit for bit -- shapes cover the
+    ragged edges of every tile form: cin not a multiple of 8 (scalar cast), < 256 (several rows per block), > 256, 5x5 / 7x7."""
+    import ctypes as C
+    from npp_amd import _ops as K
+    from npp_amd._lib import lib, check, npp_dtype
+    dev = _dev()
+    shapes = [(32, 32, 3), (64, 64, 1), (20, 256, 1), (6, 384, 3), (128, 384, 3), (100, 70, 3), (7, 5, 1), (130, 100, 1), (512, 1024, 1),
+              (48, 3, 3), (16, 24, 5), (8, 3, 7), (33, 300, 3), (256, 16, 1), (1, 40, 3)]
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn(co, ci, k, k, generator=g).to(dev) for co, ci, k in shapes]
+    for dtype in (torch.bfloat16, torch.float32):
+        packer = K.WeightPacker(ws)
+        packer.pack_if_stale(dtype, dev, force=True)
+        torch.cuda.synchronize()
+        assert packer.outs is not None and len(packer.outs) == 2 * len(ws)
+        for i, w in enumerate(ws):
+            co, ci, kh, kw = w.shape
+            for dg in (0, 1):
+                n = int(lib().npp_packed_weight_elems(co, ci, kh, kw, dg))
+                ref = torch.zeros(n, dtype=dtype, device=dev)
+                check(lib().npp_pack_weight(w.data_ptr(), co, ci, kh, kw, dg, npp_dtype(dtype), ref.data_ptr(), K.stream_ptr()))
+                torch.cuda.synchronize()
+                got = packer.outs[2 * i + dg]
+                assert torch.equal(got.view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
+                                   ref.view(torch.int16 if dtype == torch.bfloat16 else torch.int32)), (tuple(w.shape), dg, dtype)
 
 
 def test_concat_buffer_parts_written_in_place():

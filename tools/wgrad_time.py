@@ -11,7 +11,7 @@ from npp_amd._lib import lib, check, desc, geom
 
 dev = torch.device("cuda:0")
 SHAPES = [(128, 128, 3, 96, 16), (384, 128, 3, 96, 16), (256, 256, 3, 48, 16), (512, 512, 3, 24, 16), (256, 256, 3, 12, 16),
-          (128, 128, 3, 24, 16), (1024, 512, 1, 96, 16), (512, 128, 1, 96, 16), (384, 6, 3, 96, 16)]
+          (128, 128, 3, 24, 16), (1024, 512, 1, 96, 16), (512, 128, 1, 96, 16), (384, 6, 3, 96, 16), (32, 32, 3, 96, 16), (64, 64, 3, 48, 16)]
 for cin, cout, k, hw, n in SHAPES:
     x = K.cast(torch.randn(n, cin, hw, hw, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16)
     dy = K.cast(torch.randn(n, cout, hw, hw, device=dev).contiguous(memory_format=torch.channels_last), torch.bfloat16)
