@@ -261,6 +261,20 @@ int npp_bn_bwd_apply2_fin(const NppTensor* dout, const NppTensor* ya_raw, const 
                           const double* sums, int nrep, double count, const float* mean_invstd_a, const float* mean_invstd_b,
                           const float* gamma_a, const float* gamma_b, float* dgamma_a, float* dbeta_a, float* dgamma_b,
                           float* dbeta_b, NppTensor* dya_raw, NppTensor* dyb_raw, void* stream);
+/* BatchNorm backward of a small bf16 map in ONE launch (csrc/bn_one.hip): npp_bn_bwd_reduce(2)_acc + npp_bn_bwd_apply(2)_fin with
+ * the tensors held in registers across a grid-wide barrier (no ReLU mask: the cell nodes and the ReLU-Conv-BN blocks of
+ * operations.py:70-79 have none after the BatchNorm).  npp_bn_bwd_one_blocks: grid size the kernel would use, 0 = not a shape of
+ * this kernel (the two-launch form applies).  sums: zeroed [NPP_STAT_REPLICAS][2C | 3C] doubles.  barrier: NPP_BN_ONE_BARRIER_WORDS zero-initialised
+ * 64-bit counters owned by ONE stream (the launches that share them must be stream-ordered); they are never reset.
+ * Returns NPP_E_UNSUPPORTED (nothing launched) when the shape or layout is not the kernel's. */
+#define NPP_BN_ONE_BARRIER_WORDS (24 * 257)
+int npp_bn_bwd_one_blocks(int64_t npix, int64_t c, int dtype, int two_sided);
+int npp_bn_bwd_one(const NppTensor* dout, const NppTensor* y_raw, double* sums, double count, const float* mean_invstd,
+                   const float* gamma, float* dgamma, float* dbeta, NppTensor* dy_raw, void* barrier, void* stream);
+int npp_bn_bwd_one2(const NppTensor* dout, const NppTensor* ya_raw, const NppTensor* yb_raw, double* sums, double count,
+                    const float* mean_invstd_a, const float* mean_invstd_b, const float* gamma_a, const float* gamma_b,
+                    float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b, NppTensor* dya_raw, NppTensor* dyb_raw,
+                    void* barrier, void* stream);
 /* ---- the mixed edge of the search supernet (PC-DARTS MixedOp, model_search_interact.py:39-74): out = sum_k w[k] * f_k(x_k), k <= 8,
  * f_k = BatchNorm2d(affine=False) with LOCAL batch statistics (mean_invstd != NULL; stats = [NPP_STAT_REPLICAS][2C] sums of x_k) or
  * the identity (mean_invstd == NULL).  w: k device floats (the softmaxed architecture weights).  Forward: one launch (finalize

@@ -118,6 +118,9 @@ _SIGS = {
     "npp_bn_bwd_reduce2_acc": [_T, _T, _T, _T, _P, _P, _P, C.c_int, _P],
     "npp_bn_bwd_apply_fin": [_T, _T, _T, _P, C.c_int, C.c_double, _P, _P, _P, _P, _T, _P],
     "npp_bn_bwd_apply2_fin": [_T, _T, _T, _T, _P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _T, _T, _P],
+    "npp_bn_bwd_one_blocks": [C.c_int64, C.c_int64, C.c_int, C.c_int],
+    "npp_bn_bwd_one": [_T, _T, _P, C.c_double, _P, _P, _P, _P, _T, _P, _P],
+    "npp_bn_bwd_one2": [_T, _T, _T, _P, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _T, _T, _P, _P],
     "npp_pool3x3_fwd": [_T, _T, _P, C.c_int, C.c_int, _P, _P],
     "npp_pool3x3_bwd": [_T, _P, _T, C.c_int, C.c_int, _P],
     "npp_pool3x3_bwd_acc": [_T, _P, _T, C.c_int, C.c_int, C.c_int, _P],

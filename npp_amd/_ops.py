@@ -1532,6 +1532,41 @@ def _fin_fusable(sa, sb, a, b, training: bool) -> bool:
     return True
 
 
+# BatchNorm backward of a small map in one launch (csrc/bn_one.hip): the grid barrier's counters belong to ONE stream (its launches
+# are stream-ordered) and are never reset; allocated outside any graph capture on first use (TrainStep warms up eagerly first).
+# OPT-IN (NPP_BN_ONE=1).  Measured on one MI355X, 50 dependent two-sided BatchNorm backwards replayed from a hipGraph, N = 16
+# (tools/bn_time.py; us per backward, two launches / one launch / one launch with the barrier compiled out):
+#     32 ch @96^2  17.7 / 36.1 / 20.8      64 ch @48^2  14.4 / 26.3 / 12.2      128 ch @24^2  15.8 / 20.3 / 10.9      256 ch @12^2  16.9 / 18.9 / 13.3
+# and the whole step 47.3 ms against 46.4.  A grid-wide barrier is a chain of device-scope round trips through the fabric that links
+# the 8 XCDs (the blocks' f64 atomics must have landed, arrive, poll, read the sums back: ~1.5-2 us each), 6-14 us in all, whether
+# the arrivals go to one counter or to a two-level tree -- a kernel boundary costs ~3 us.  The two-launch form stays the default.
+BN_ONE = os.environ.get("NPP_BN_ONE", "0") == "1"
+_bn_one_ctr: dict = {}
+_bn_one_plan: dict = {}
+BN_ONE_STATS = [0, 0]      # launches of the one-sided / two-sided kernel (tests)
+
+
+def _bn_one_blocks(x, two):
+    if not BN_ONE or x.dtype != torch.bfloat16:
+        return 0
+    key = (x.shape[0] * x.shape[2] * x.shape[3], x.shape[1], two)
+    nb = _bn_one_plan.get(key)
+    if nb is None:
+        nb = _bn_one_plan[key] = int(lib().npp_bn_bwd_one_blocks(key[0], key[1], L.NPP_BF16, 1 if two else 0))
+    return nb
+
+
+def _bn_one_barrier(device):
+    st = torch.cuda.current_stream()
+    key = (device.index, st.cuda_stream)
+    buf = _bn_one_ctr.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None      # (never allocate the counters from a graph's private pool)
+        buf = _bn_one_ctr[key] = torch.zeros(24 * 257, dtype=torch.int64, device=device)
+    return buf
+
+
 class _BnAdd(Function):
     """out = relu?( [BN_a](a) + [BN_b](b) ).  Tensor args: a, gamma_a, beta_a, b, gamma_b, beta_b."""
 
@@ -1628,7 +1663,12 @@ class _BnAdd(Function):
             nb = lib().npp_reduce_blocks(a.shape[0] * a.shape[2] * a.shape[3], c, L.npp_dtype(a.dtype))
             fused = (FUSE_BN_FIN and _fused_layout_ok(a) and _fused_layout_ok(b) and _fused_layout_ok(dout)
                      and (yrelu is None or _fused_layout_ok(yrelu)))
-            if fused:
+            one = None
+            if fused and yrelu is None and _bn_one_blocks(a, True) > 0:
+                one = _bn_one_barrier(dev)
+            if one is not None:
+                sums = zeros_f64(R * 3 * c, dev)
+            elif fused:
                 sums = zeros_f64(R * 3 * c, dev)
                 check(lib().npp_bn_bwd_reduce2_acc(_byref(dout), _byref(a), _byref(b), tref(yrelu), mia.data_ptr(), mib.data_ptr(),
                                                    sums.data_ptr(), nb, s), "npp_bn_bwd_reduce2_acc")
@@ -1644,6 +1684,16 @@ class _BnAdd(Function):
                     dgb_[i_] = slot
             ga = bna.weight.detach() if bna.weight is not None else None
             gb = bnb.weight.detach() if bnb.weight is not None else None
+            if one is not None:
+                dxa = new_nhwc(*a.shape, a.dtype, dev)
+                dxb = new_nhwc(*b.shape, b.dtype, dev)
+                check(lib().npp_bn_bwd_one2(_byref(dout), _byref(a), _byref(b), sums.data_ptr(), float(cnt_a), mia.data_ptr(),
+                                            mib.data_ptr(), ptr(ga), ptr(gb), dgb_[0].data_ptr(), dgb_[1].data_ptr(),
+                                            dgb_[2].data_ptr(), dgb_[3].data_ptr(), _byref(dxa), _byref(dxb), one.data_ptr(), s),
+                      "npp_bn_bwd_one2")
+                BN_ONE_STATS[1] += 1
+                return (dxa, dgb_[0] if ni[1] else None, dgb_[1] if ni[2] else None,
+                        dxb, dgb_[2] if ni[4] else None, dgb_[3] if ni[5] else None, None, None, None, None, None, None)
             if fused:
                 dxa = new_nhwc(*a.shape, a.dtype, dev)
                 dxb = new_nhwc(*b.shape, b.dtype, dev)
@@ -1674,7 +1724,14 @@ class _BnAdd(Function):
         # SyncBatchNorm: slabs -> npp_bn_bwd_sum -> all-reduce as before, then the coefficients in the apply's prologue (one vector)
         fin_sync = [bn is not None and batch and lay_ok and need_x and FUSE_BN_SYNC and _sync_group(bn)[0] is not None
                     and _fused_layout_ok(x) for (x, bn, mi, ss, batch, count, need_x, *_r) in sides]
-        red = [reduce_side(x, mi, fin[i]) if bn is not None else None for i, (x, bn, mi, *_r) in enumerate(sides)]
+        # a small map with a local BatchNorm and no ReLU mask: reduce + apply in one launch (csrc/bn_one.hip)
+        one_bar = [None] * len(sides)
+        if yrelu is None:
+            for i, (x, bn, mi, ss, batch, count, need_x, *_r) in enumerate(sides):
+                if fin[i] and _bn_one_blocks(x, False) > 0:
+                    one_bar[i] = _bn_one_barrier(x.device)
+        red = [((zeros_f64(R * 2 * x.shape[1], x.device), R) if one_bar[i] is not None else reduce_side(x, mi, fin[i]))
+               if bn is not None else None for i, (x, bn, mi, *_r) in enumerate(sides)]
         # phase 2 (SyncBatchNorm): collapse each side's slabs to one vector (+ the LOCAL dgamma / dbeta, which DDP
         # averages afterwards as torch.nn.SyncBatchNorm does), then ONE all-reduce of the side(s) of this node.
         local = [None] * len(sides)
@@ -1722,6 +1779,13 @@ class _BnAdd(Function):
                     dgt = _grad_buf(bn.weight if need_g else None, c, x.device)
                     dbt = _grad_buf(bn.bias if need_b else None, c, x.device)
                     dg, db = dgt, dbt
+                if one_bar[i] is not None:
+                    dx = new_nhwc(*x.shape, x.dtype, x.device)
+                    check(lib().npp_bn_bwd_one(_byref(dout), _byref(x), sums.data_ptr(), float(count), mi.data_ptr(), ptr(gamma),
+                                               ptr(dgt), ptr(dbt), _byref(dx), one_bar[i].data_ptr(), s), "npp_bn_bwd_one")
+                    BN_ONE_STATS[0] += 1
+                    outs.append((dx, dg if need_g else None, db if need_b else None))
+                    continue
                 if fin[i] or (fin_sync[i] and nrep == 1):
                     dx = new_nhwc(*x.shape, x.dtype, x.device)
                     check(lib().npp_bn_bwd_apply_fin(_byref(dout), _byref(x), tref(yrelu), sums.data_ptr(), nrep, float(count),

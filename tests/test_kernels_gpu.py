@@ -585,6 +585,114 @@ def test_bn_fused_prologues_equal_the_separate_kernels(C, H, N, relu, mode, dtyp
         assert rel_err(f, q) < tol, (i, rel_err(f, q))
 
 
+@pytest.mark.parametrize("C,H,W,N,mode,pad", [
+    (32, 96, 96, 16, "two", 0),      # 9 items per thread, 256 blocks (the encoder's first stage at the bench's batch)
+    (32, 96, 96, 16, "one", 0),
+    (64, 48, 48, 16, "two", 8),      # operands that are channel slices (ld = C + 8)
+    (128, 24, 24, 16, "two", 0),     # 5 items per thread
+    (256, 12, 12, 16, "one", 0),
+    (512, 12, 12, 2, "two", 0),      # 64 column vectors: one wave per pixel row
+    (8, 5, 7, 3, "two", 0),          # one column vector, a handful of items: one block
+    (16, 13, 17, 2, "one", 8),
+])
+def test_batchnorm_backward_in_one_launch_equals_the_two_launch_form(C, H, W, N, mode, pad):
+    """npp_bn_bwd_one / npp_bn_bwd_one2 (csrc/bn_one.hip: reduce + grid barrier + apply, tensors held in registers) against
+    npp_bn_bwd_reduce(2)_acc + npp_bn_bwd_apply(2)_fin on the same inputs: dx bit-equal up to the f64 summation order of the sums
+    (bf16 outputs: equal or one ulp apart), dgamma / dbeta to 1e-5; and against the f64 torch BatchNorm backward.  Every call is
+    repeated so that the barrier counter is used by several launches in a row."""
+    from npp_amd import _ops as K
+    import copy
+    dev = _dev()
+    dtype = torch.bfloat16
+    a_cpu, b_cpu = (_rand((N, C, H, W), 20) * 2 + 0.5).bfloat16().float(), _rand((N, C, H, W), 21).bfloat16().float()
+    gy = _rand((N, C, H, W), 22).bfloat16().float()
+    bns0 = [torch.nn.BatchNorm2d(C, momentum=0.1) for _ in range(2)]
+    for i, bn in enumerate(bns0):
+        with torch.no_grad():
+            bn.weight.copy_(_rand((C,), 23 + i) * 0.2 + 1)
+            bn.bias.copy_(_rand((C,), 25 + i) * 0.1)
+
+    def run(one):
+        K.BN_ONE = one
+        res = None
+        for _rep in range(3):
+            bns = [copy.deepcopy(bn).to(dev) for bn in bns0]
+            a = _to_dev(a_cpu, dtype, pad).detach().requires_grad_(True)
+            b = _to_dev(b_cpu, dtype, pad).detach().requires_grad_(True)
+            sb = K.BnSide(b, bns[1]) if mode == "two" else None
+            y = K.bn_add(K.BnSide(a, bns[0]), sb, relu=False, training=True)
+            y.backward(_to_dev(gy, dtype))
+            torch.cuda.synchronize()
+            cur = [a.grad.float().cpu(), bns[0].weight.grad.cpu(), bns[0].bias.grad.cpu()]
+            if mode == "two":
+                cur += [b.grad.float().cpu(), bns[1].weight.grad.cpu(), bns[1].bias.grad.cpu()]
+            if res is not None:
+                for q, r in zip(cur, res):
+                    assert rel_err(q.numpy(), r.numpy()) < 1e-5
+            res = cur
+        return res
+
+    before = list(K.BN_ONE_STATS)
+    try:
+        one, two = run(True), run(False)
+    finally:
+        K.BN_ONE = False
+    k = 1 if mode == "two" else 0
+    assert K.BN_ONE_STATS[k] == before[k] + 3 and K.BN_ONE_STATS[1 - k] == before[1 - k], "the one-launch kernel did not run"
+    for i, (f, q) in enumerate(zip(one, two)):
+        big = i in (0, 3)
+        assert rel_err(f.numpy(), q.numpy()) < (2e-3 if big else 1e-5), (i, rel_err(f.numpy(), q.numpy()))
+        if big:      # bf16 outputs of the same f32 arithmetic: almost all elements identical
+            assert float((f != q).float().mean()) < 0.02
+    # f64 reference
+    ar, br = a_cpu.double().requires_grad_(True), b_cpu.double().requires_grad_(True)
+    ref = [copy.deepcopy(bn).double() for bn in bns0]
+    yr = ref[0](ar) + (ref[1](br) if mode == "two" else 0)
+    yr.backward(gy.double())
+    assert rel_err(one[0].numpy(), ar.grad.numpy()) < 1e-2
+    assert rel_err(one[1].numpy(), ref[0].weight.grad.numpy()) < 2e-3
+    if mode == "two":
+        assert rel_err(one[3].numpy(), br.grad.numpy()) < 1e-2
+
+
+def test_batchnorm_one_launch_kernels_of_two_streams_do_not_wait_on_each_other():
+    """Two streams run the grid-barrier kernel at the same time, 200 launches each (every stream has barrier counters of its own):
+    all blocks of both launches must be resident together (csrc/bn_one.hip's register / grid-size bound) -- a deadlock would hang
+    here -- and every launch gives the result of the first."""
+    from npp_amd import _ops as K
+    dev = _dev()
+    C, H, N = 32, 96, 16
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    torch.cuda.synchronize()
+    for si, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            bna, bnb = torch.nn.BatchNorm2d(C).to(dev), torch.nn.BatchNorm2d(C).to(dev)
+            a = _to_dev(_rand((N, C, H, H), 30 + si), torch.bfloat16).detach().requires_grad_(True)
+            b = _to_dev(_rand((N, C, H, H), 32 + si), torch.bfloat16).detach().requires_grad_(True)
+            g = _to_dev(_rand((N, C, H, H), 34 + si), torch.bfloat16)
+            outs.append((a, b, g, bna, bnb, []))
+    torch.cuda.synchronize()
+    before = K.BN_ONE_STATS[1]
+    K.BN_ONE = True
+    try:
+        for it in range(200):
+            for si, st in enumerate(streams):
+                a, b, g, bna, bnb, got = outs[si]
+                with torch.cuda.stream(st):
+                    a.grad = None
+                    y = K.bn_add(K.BnSide(a, bna), K.BnSide(b, bnb), relu=False, training=True)
+                    y.backward(g)
+                    if it in (0, 199):
+                        got.append(a.grad.clone())
+        torch.cuda.synchronize()
+    finally:
+        K.BN_ONE = False
+    assert K.BN_ONE_STATS[1] == before + 400
+    for a, b, g, bna, bnb, got in outs:
+        assert rel_err(got[1].float().cpu().numpy(), got[0].float().cpu().numpy()) < 1e-3
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("C,H,N,pattern", [(16, 24, 2, "BBPBBBP"), (32, 12, 4, "BPB"), (64, 6, 2, "BBBBBBBB"), (8, 12, 2, "PB")])
 def test_mix_bn_sum_matches_separate_batchnorms_and_weighted_sum(C, H, N, pattern, dtype, tol):
