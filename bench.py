@@ -551,6 +551,11 @@ def main():
                 "ddp_overlap": bool(reducer.overlap) if reducer is not None else None}
         if overlap_ab is not None:
             comm["overlap_ab"] = overlap_ab
+        from npp_amd import comm as _cm
+        comm["syncbn_transport"] = ("p2p mailboxes (csrc/p2p.hip), %d exchanges issued by the host, peers %s" %
+                                    (_cm._p2p["count"], "all present" if _cm.p2p_ok() else "MISSING (a poll timed out: numbers void)")
+                                    ) if _cm.p2p_active() else "all-reduce through the process group"
+        comm["syncbn_streams"] = "two branch streams, exchanges in place" if K.P2P_DIRECT else "hub stream + lockstep issue"
     exposed = None
     if use_dist and not args.no_comm_ablation:
         # exposed communication = this step minus the SAME step without any collective: SyncBatchNorm modules on local

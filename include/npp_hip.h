@@ -495,6 +495,25 @@ int npp_comm_world(void);
 int npp_comm_destroy(void);
 int npp_allreduce_bucket(void* buf, int64_t count, int dtype, int average, void* stream);
 int npp_syncbn_exchange(double* stats, int64_t count, void* stream);
+/* ---- one-shot peer-to-peer statistics exchange inside one node (csrc/p2p.hip): the same in-place SUM as npp_syncbn_exchange, as
+ * ONE small kernel -- every rank stores its vector into a mailbox in each peer's HBM (hipIpc-mapped, xGMI peer stores), raises a
+ * flag, polls its own flags and sums in rank order (bit-identical results on all ranks).  Replaces the ~980 latency-bound RCCL
+ * all-reduces per step that SyncBatchNorm (augment_lip_sync.py:191, search_lip_sync.py:268-271) costs; RCCL stays the fallback.
+ *   npp_p2p_alloc   allocate this rank's mailboxes (`channels` independent exchange sequences, vectors of <= cap_doubles) and
+ *                   write the allocation's IPC handle (npp_p2p_handle_bytes() bytes) to handle_out; the host exchanges the handles
+ *                   (any side channel) and passes all of them, in rank order, to
+ *   npp_p2p_open    which maps the peers' mailboxes.  NPP_E_UNSUPPORTED when the runtime refuses IPC / peer access.
+ *   npp_p2p_exchange  enqueue one exchange of channel `channel` on `stream` (capturable; every rank issues the same sequence per
+ *                   channel; exchanges of one channel must be stream-ordered).  NPP_E_UNSUPPORTED for count > capacity.
+ *   npp_p2p_status  1 if a poll ever timed out (NPP_P2P_TIMEOUT_MS, default 20 s: a peer died), else 0.  Synchronises. */
+int npp_p2p_handle_bytes(void);
+int npp_p2p_alloc(int rank, int world, int64_t cap_doubles, int channels, void* handle_out);
+int npp_p2p_open(const void* handles);
+int64_t npp_p2p_capacity(void);
+int npp_p2p_channels(void);
+int npp_p2p_exchange(double* stats, int64_t count, int channel, void* stream);
+int npp_p2p_status(void);
+int npp_p2p_close(void);
 
 #ifdef __cplusplus
 }

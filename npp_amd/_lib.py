@@ -183,12 +183,19 @@ _SIGS = {
     "npp_comm_destroy": [],
     "npp_allreduce_bucket": [_P, C.c_int64, C.c_int, C.c_int, _P],
     "npp_syncbn_exchange": [_P, C.c_int64, _P],
+    "npp_p2p_handle_bytes": [],
+    "npp_p2p_alloc": [C.c_int, C.c_int, C.c_int64, C.c_int, _P],
+    "npp_p2p_open": [_P],
+    "npp_p2p_channels": [],
+    "npp_p2p_exchange": [_P, C.c_int64, C.c_int, _P],
+    "npp_p2p_status": [],
+    "npp_p2p_close": [],
     "npp_parsing_confusion": [_T, _T, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_clear_hip_error", "npp_packed_weight_elems", "npp_pack_job_blocks", "npp_reduce_blocks",
                                  "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems",
                                  "npp_conv_wgrad_splits", "npp_debug_nonfinite", "npp_conv_wgrad_batched_ws", "npp_dwconv_bwd_weight_batched_ws", "npp_bilinear_bwd_ws_bytes",
-                                 "npp_se_ws_floats", "npp_se_param_grads_batched_ws"])
+                                 "npp_se_ws_floats", "npp_se_param_grads_batched_ws", "npp_p2p_capacity"])
 
 
 def kernel_source_hash() -> str:
@@ -245,6 +252,8 @@ def lib():
         L.npp_se_ws_floats.argtypes = [C.c_int, C.c_int]
         L.npp_se_param_grads_batched_ws.restype = C.c_int64
         L.npp_se_param_grads_batched_ws.argtypes = [_P, C.c_int]
+        L.npp_p2p_capacity.restype = C.c_int64
+        L.npp_p2p_capacity.argtypes = []
         for name, sig in _SIGS.items():
             f = getattr(L, name)
             f.restype = C.c_int

@@ -339,9 +339,17 @@ GRAPH_TOPOLOGY = False  # set by train_step.TrainStep while its steps are (to be
 _hub_stream = None     # the stream Network.forward was called on while it runs its branches on two streams
 
 
+P2P_DIRECT = False     # set by Network.forward: the SyncBatchNorm exchanges go through the peer-to-peer mailboxes (csrc/p2p.hip), each on
+                       # the stream of the kernels that need it -- no hub stream, no lockstep (an exchange is an ordinary kernel)
+
+
 def _sum_all_reduce(t, group):
     """SUM all-reduce on the current stream: the library's RCCL communicator when it is up (npp_amd.comm), else torch's."""
     from . import comm
+    if t.is_cuda and not comm.p2p_active():
+        comm.ensure_p2p(group)      # first exchange of this group: every rank is at the same point of the program
+    if comm.p2p_active() and comm.p2p_exchange(t, group):      # one-shot peer-to-peer exchange (csrc/p2p.hip), one node
+        return
     if comm.active() and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and group is comm._state["group"]:
         comm.syncbn_exchange(t)
     else:
@@ -357,7 +365,7 @@ def hub_all_reduce(t, group, producers=None):
     Returns the event recorded on the hub after the collective (None when everything ran on the current stream)."""
     hub = _hub_stream
     cur = torch.cuda.current_stream() if t.is_cuda else None
-    if hub is None or cur is None:
+    if hub is None or cur is None or (P2P_DIRECT and not producers):
         _sum_all_reduce(t, group)
         return None
     same = cur.cuda_stream == hub.cuda_stream

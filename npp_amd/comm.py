@@ -7,6 +7,10 @@ would use, and `NPP_COMM=npp` (or `comm.enable()`) switches the
 
 torch.distributed is still the side channel for the 128-byte unique id (replaces ProcessGroupNCCL's store exchange behind
 augment_lip_sync.py:68 init_process_group).
+
+Second transport, for the SyncBatchNorm statistics only (csrc/p2p.hip, `enable_p2p`): a one-shot peer-to-peer exchange through
+hipIpc-mapped mailboxes -- one small kernel per exchange instead of an all-reduce; on by default for N > 1 ranks of one node
+(`NPP_SYNCBN_P2P=0` keeps the collectives), every rank falls back to the collective together if any rank cannot set it up.
 """
 import os
 
@@ -71,3 +75,107 @@ def syncbn_exchange(stats):
     assert stats.is_cuda and stats.is_contiguous() and stats.dtype == torch.float64
     _lib.check(_lib.lib().npp_syncbn_exchange(stats.data_ptr(), stats.numel(), torch.cuda.current_stream().cuda_stream),
                "npp_syncbn_exchange")
+
+
+# ---- one-shot peer-to-peer exchange of the SyncBatchNorm statistics (csrc/p2p.hip) ----------------------------------------------
+_p2p = {"world": 0, "group": None, "cap": 0, "channels": {}, "nchan": 0, "count": 0}
+P2P_CAP_DOUBLES = int(os.environ.get("NPP_P2P_CAP", str(1 << 15)))      # 256 KiB per (slot, source rank): a merged exchange of a whole
+                                                                         # lockstep stage of model_augment at C = 64 is < 100 KiB
+
+
+def p2p_active():
+    return _p2p["world"] > 0
+
+
+def p2p_wanted():
+    return os.environ.get("NPP_SYNCBN_P2P", "1") != "0"
+
+
+def enable_p2p(group=None, channels=2):
+    """Collective over `group`: allocate the mailboxes, exchange the IPC handles through torch.distributed, map the peers.
+    Returns True if EVERY rank succeeded (the ranks agree through a MIN all-reduce; otherwise all of them close their mailboxes
+    and keep the collective transport).  Ranks of different hosts: not attempted."""
+    if p2p_active():
+        return True
+    if not (torch.cuda.is_available() and dist.is_available() and dist.is_initialized()):
+        return False
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world > 16 or (world < 2 and os.environ.get("NPP_P2P_ALONE") != "1"):      # (a 1-rank group: rehearsal of the kernel chain only)
+        return False
+    import ctypes
+    import socket
+    lib = _lib.lib()
+    nb = int(lib.npp_p2p_handle_bytes())
+    buf = ctypes.create_string_buffer(nb)
+    ok = 1
+    try:
+        _lib.check(lib.npp_p2p_alloc(rank, world, P2P_CAP_DOUBLES, channels, buf), "npp_p2p_alloc")
+    except Exception:      # noqa: BLE001  (no IPC on this runtime: every rank learns it below)
+        ok = 0
+    mine = (socket.gethostname(), bytes(buf.raw) if ok else b"")
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine, group=group)
+    if ok and (any(h != mine[0] for h, _ in everyone) or any(len(b) != nb for _, b in everyone)):
+        ok = 0
+    if ok:
+        try:
+            _lib.check(lib.npp_p2p_open(b"".join(b for _, b in everyone)), "npp_p2p_open")
+        except Exception:      # noqa: BLE001
+            ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32)
+    backend = dist.get_backend(group)
+    if backend == "nccl":
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) != 1:
+        lib.npp_p2p_close()
+        return False
+    # nobody starts exchanging before everybody has mapped everybody (the all-reduce above is that barrier)
+    _p2p.update(world=world, group=group, cap=int(lib.npp_p2p_capacity()), channels={}, nchan=int(lib.npp_p2p_channels()), count=0)
+    return True
+
+
+_p2p_tried: set = set()
+
+
+def ensure_p2p(group=None) -> bool:
+    """p2p_active() after ONE attempt per group to set the mailboxes up (a collective: call it where every rank is at the same
+    point of the program -- the first SyncBatchNorm forward; never inside a hipGraph capture)."""
+    if p2p_active():
+        return group is _p2p["group"]
+    if not p2p_wanted() or id(group) in _p2p_tried or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return False
+    _p2p_tried.add(id(group))
+    return enable_p2p(group)
+
+
+def disable_p2p():
+    if _p2p["world"]:
+        torch.cuda.synchronize()
+        _lib.lib().npp_p2p_close()
+        _p2p.update(world=0, group=None, cap=0, channels={}, nchan=0)
+
+
+def p2p_exchange(stats, group=None):
+    """In-place SUM over the ranks on the current stream; False if this tensor / stream is not the mailboxes' (the caller then
+    uses the collective).  Every stream gets a channel of its own in order of first use -- the same order on every rank."""
+    if not p2p_active() or group is not _p2p["group"]:
+        return False
+    if not (stats.is_cuda and stats.is_contiguous() and stats.dtype == torch.float64):
+        return False
+    st = torch.cuda.current_stream().cuda_stream
+    ch = _p2p["channels"].get(st)
+    if ch is None:
+        if len(_p2p["channels"]) >= _p2p["nchan"]:
+            return False
+        ch = _p2p["channels"][st] = len(_p2p["channels"])
+    cap, n = _p2p["cap"], stats.numel()
+    for lo in range(0, n, cap):      # (a vector longer than a mailbox slot goes in pieces)
+        _lib.check(_lib.lib().npp_p2p_exchange(stats.data_ptr() + 8 * lo, min(cap, n - lo), ch, st), "npp_p2p_exchange")
+        _p2p["count"] += 1
+    return True
+
+
+def p2p_ok():
+    """False if a peer never showed up for some exchange (synchronises the device)."""
+    return not p2p_active() or int(_lib.lib().npp_p2p_status()) == 0

@@ -1,0 +1,245 @@
+// One-shot SyncBatchNorm statistics exchange between the GPUs of ONE node (npp_p2p_*): every rank stores its vector straight
+// into a mailbox in each peer's HBM (xGMI peer stores through hipIpc-mapped pointers), raises a flag there, polls its own flags
+// and sums the world's vectors in rank order -- one small kernel per exchange instead of an RCCL all-reduce.
+//
+// Why: the reference converts every BatchNorm to SyncBatchNorm (augment_lip_sync.py:191, search_lip_sync.py:268-271); a training
+// step of model_augment then carries ~980 exchanges of a few KiB, each one a link of the dependent kernel chain.  A ring / tree
+// all-reduce spends 2 (W - 1) (ring) or 2 log W hops of xGMI latency plus RCCL's launch and proxy overheads on each; here it
+// is ONE hop: W - 1 peer writes in parallel, a flag, a poll.  The sum is taken in rank order on every rank, so all ranks hold
+// bit-identical statistics (as after an all-reduce), and the kernel is an ordinary launch: capturable on ANY stream, no
+// communicator-wide ordering between streams (each channel has mailboxes and a sequence counter of its own).
+//
+//   mailbox of rank r, channel c:   data [SLOTS][world][cap] doubles | flag [SLOTS][world][8 workgroups] u64
+//   exchange number s of a channel (device counter, so that hipGraph replays advance it) uses slot s % SLOTS.  A rank can
+//   only start exchange s + 1 after it has seen every peer's flag of s, i.e. after every peer has WRITTEN s; a peer writes
+//   s + 2 only after it has seen everybody's s + 1, which they raise after finishing their reads of s (one kernel after the
+//   other on the channel's stream): two slots would do, four are used.
+//   Memory: the mailboxes are allocated uncached / fine-grained when the runtime offers it (peer writes must not linger in a
+//   cache on either side), flags are read and written with system-scope atomics, the data after a system-scope acquire.
+//   A poll that sees nothing for NPP_P2P_TIMEOUT_MS (default 20 000) gives up: the kernel sets the channel's error word, which
+//   npp_p2p_status reports to the host (a peer died: the step's numbers are void, but the GPU is not left spinning).
+// RCCL (npp_syncbn_exchange) stays the transport for anything this does not cover: several nodes, vectors above the mailbox
+// capacity, a runtime without peer access.
+#include "common.h"
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+constexpr int P2P_SLOTS = 4;
+constexpr int P2P_MAX_WORLD = 16;
+constexpr int P2P_MAX_CHANNELS = 4;
+constexpr int P2P_MAX_BLOCKS = 8;      // workgroups of one exchange: each owns an interleaved share of the vector and a flag of its own
+
+struct Channel {
+  // (device pointers) mailbox of every rank as mapped into THIS process; [me] is the local allocation
+  double* data[P2P_MAX_WORLD];
+  unsigned long long* flag[P2P_MAX_WORLD];
+  unsigned long long* seq;       // local: exchange counter
+  unsigned int* err;             // local: non-zero after a timed-out poll
+};
+
+struct P2P {
+  int rank = -1, world = 0;
+  long cap = 0;                  // doubles per (slot, source rank)
+  int nchan = 0;
+  void* local = nullptr;         // this rank's allocation: nchan mailboxes + the local words
+  size_t bytes = 0;
+  void* peers[P2P_MAX_WORLD] = {};
+  Channel ch[P2P_MAX_CHANNELS];
+  long long timeout_ticks = 0;
+} g;
+
+size_t mailbox_bytes(long cap, int world) {
+  size_t b = (size_t)P2P_SLOTS * world * cap * sizeof(double) + (size_t)P2P_SLOTS * world * P2P_MAX_BLOCKS * sizeof(unsigned long long);
+  return (b + 255) & ~(size_t)255;
+}
+size_t local_words_off(long cap, int world, int nchan) { return mailbox_bytes(cap, world) * nchan; }
+size_t total_bytes(long cap, int world, int nchan) { return local_words_off(cap, world, nchan) + 256 * (size_t)nchan; }
+
+void map_channels(void* base, int r, long cap, int world, int nchan, bool local) {
+  for (int c = 0; c < nchan; ++c) {
+    char* mb = static_cast<char*>(base) + mailbox_bytes(cap, world) * c;
+    g.ch[c].data[r] = reinterpret_cast<double*>(mb);
+    g.ch[c].flag[r] = reinterpret_cast<unsigned long long*>(mb + (size_t)P2P_SLOTS * world * cap * sizeof(double));
+    if (local) {
+      char* lw = static_cast<char*>(base) + local_words_off(cap, world, nchan) + 256 * (size_t)c;
+      g.ch[c].seq = reinterpret_cast<unsigned long long*>(lw);
+      g.ch[c].err = reinterpret_cast<unsigned int*>(lw + 64);
+    }
+  }
+}
+
+struct ExArgs {
+  double* peer_data[P2P_MAX_WORLD];
+  unsigned long long* peer_flag[P2P_MAX_WORLD];
+  unsigned long long* seq;       // [0] exchange counter, [1] workgroups of the current exchange that are done
+  unsigned int* err;
+  double* v;
+  long n, cap;
+  int me, world;
+  long long timeout_ticks;
+};
+
+// Workgroup b of B handles the elements i = b * 1024 + t, + B * 1024, ...: it pushes them, raises ITS flag on every peer, polls
+// its own flags and sums its elements -- no synchronisation between the workgroups of a launch.  The exchange counter moves when
+// the last workgroup finishes (every workgroup has read it by then).
+__global__ __launch_bounds__(1024) void p2p_exchange_kernel(ExArgs a) {
+  const int t = threadIdx.x, b = blockIdx.x, B = gridDim.x;
+  __shared__ int s_bad;
+  if (t == 0) s_bad = 0;
+  const unsigned long long s = __hip_atomic_load(a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int slot = (int)(s % P2P_SLOTS);
+  const long off = ((long)slot * a.world + a.me) * a.cap;
+  const long first = (long)b * 1024 + t, step = (long)B * 1024;
+  // push: my share of the vector into slot [slot][me] of every mailbox (mine included)
+  for (int p = 0; p < a.world; ++p) {
+    double* dst = a.peer_data[p] + off;
+    for (long i = first; i < a.n; i += step) __builtin_nontemporal_store(a.v[i], dst + i);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // system scope: the stores above are visible to the peers before the flags
+  __syncthreads();
+  const long fidx = ((long)slot * a.world) * P2P_MAX_BLOCKS + b;
+  if (t < a.world)
+    __hip_atomic_store(a.peer_flag[t] + fidx + (long)a.me * P2P_MAX_BLOCKS, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // wait for the world's flags of this exchange (and workgroup) in my own mailbox
+  if (t < a.world) {
+    const unsigned long long* f = a.peer_flag[a.me] + fidx + (long)t * P2P_MAX_BLOCKS;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < s + 1) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > a.timeout_ticks) { s_bad = 1; break; }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (s_bad) {
+    if (t == 0) *a.err = 1u;
+  } else {
+    // sum in rank order: the same arithmetic on every rank
+    const double* mine = a.peer_data[a.me] + (long)slot * a.world * a.cap;
+    for (long i = first; i < a.n; i += step) {
+      double acc = 0.0;
+      for (int r = 0; r < a.world; ++r) acc += __builtin_nontemporal_load(mine + (long)r * a.cap + i);
+      a.v[i] = acc;
+    }
+  }
+  if (t == 0) {
+    const unsigned long long d = __hip_atomic_fetch_add(a.seq + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d + 1 == (unsigned long long)B) {
+      __hip_atomic_store(a.seq + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.seq, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace
+
+// bytes of an IPC handle as this library hands it around (hipIpcMemHandle_t)
+extern "C" int npp_p2p_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+// Allocate this rank's mailboxes (channels x [SLOTS][world][cap doubles] + flags), zeroed, and write the IPC handle of the
+// allocation to handle_out (npp_p2p_handle_bytes bytes).  cap_doubles: the longest vector one exchange may carry.
+extern "C" int npp_p2p_alloc(int rank, int world, int64_t cap_doubles, int channels, void* handle_out) {
+  NPP_REQUIRE(handle_out && world >= 1 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world && cap_doubles > 0 && channels >= 1 &&
+              channels <= P2P_MAX_CHANNELS, NPP_E_SHAPE, "npp_p2p_alloc: bad arguments (rank %d of %d, %ld doubles, %d channels)", rank,
+              world, (long)cap_doubles, channels);
+  NPP_REQUIRE(g.local == nullptr, NPP_E_UNSUPPORTED, "npp_p2p_alloc: mailboxes exist already (npp_p2p_close first)");
+  const size_t bytes = total_bytes(cap_doubles, world, channels);
+  void* p = nullptr;
+  // peer writes must not sit in a cache: uncached, else fine-grained, else plain device memory (one-GPU rehearsal)
+  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained); }
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, bytes); }
+  if (e != hipSuccess) { (void)hipGetLastError(); npp_set_error("npp_p2p_alloc: %s", hipGetErrorString(e)); return NPP_E_HIP; }
+  if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError(); (void)hipFree(p);
+    npp_set_error("npp_p2p_alloc: cannot zero the mailboxes");
+    return NPP_E_HIP;
+  }
+  hipIpcMemHandle_t h;
+  e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError(); (void)hipFree(p);
+    npp_set_error("npp_p2p_alloc: hipIpcGetMemHandle: %s", hipGetErrorString(e));
+    return NPP_E_UNSUPPORTED;
+  }
+  memcpy(handle_out, &h, sizeof(h));
+  g.local = p; g.bytes = bytes; g.rank = rank; g.world = world; g.cap = cap_doubles; g.nchan = channels;
+  for (int r = 0; r < P2P_MAX_WORLD; ++r) g.peers[r] = nullptr;
+  g.peers[rank] = p;
+  map_channels(p, rank, cap_doubles, world, channels, true);
+  const char* tmo = getenv("NPP_P2P_TIMEOUT_MS");
+  const long long ms = tmo ? atoll(tmo) : 20000;
+  g.timeout_ticks = ms * 100000LL;      // wall_clock64: 100 MHz
+  return NPP_OK;
+}
+
+// Map the peers' mailboxes: handles = world x npp_p2p_handle_bytes bytes in rank order (this rank's own entry is ignored).
+extern "C" int npp_p2p_open(const void* handles) {
+  NPP_REQUIRE(handles && g.local, NPP_E_NULL, "npp_p2p_open: npp_p2p_alloc first");
+  const char* hb = static_cast<const char*>(handles);
+  for (int r = 0; r < g.world; ++r) {
+    if (r == g.rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, hb + (size_t)r * sizeof(h), sizeof(h));
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      npp_set_error("npp_p2p_open: hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+      return NPP_E_UNSUPPORTED;
+    }
+    g.peers[r] = p;
+    map_channels(p, r, g.cap, g.world, g.nchan, false);
+  }
+  return NPP_OK;
+}
+
+extern "C" int64_t npp_p2p_capacity(void) { return g.local ? (int64_t)g.cap : 0; }
+extern "C" int npp_p2p_channels(void) { return g.local ? g.nchan : 0; }
+
+// In-place SUM over the ranks of `count` doubles on `stream`; every rank must issue the same sequence of exchanges per channel.
+extern "C" int npp_p2p_exchange(double* stats, int64_t count, int channel, void* stream) {
+  NPP_REQUIRE(stats && count > 0, NPP_E_NULL, "npp_p2p_exchange: null / empty buffer");
+  NPP_REQUIRE(g.local && channel >= 0 && channel < g.nchan, NPP_E_UNSUPPORTED, "npp_p2p_exchange: no mailboxes / bad channel %d", channel);
+  if (count > g.cap) {
+    npp_set_error("npp_p2p_exchange: %ld doubles exceed the mailbox capacity %ld (split the vector)", (long)count, g.cap);
+    return NPP_E_UNSUPPORTED;
+  }
+  for (int r = 0; r < g.world; ++r)
+    NPP_REQUIRE(g.peers[r], NPP_E_UNSUPPORTED, "npp_p2p_exchange: rank %d's mailbox is not mapped (npp_p2p_open)", r);
+  const Channel& c = g.ch[channel];
+  ExArgs a;
+  for (int r = 0; r < P2P_MAX_WORLD; ++r) { a.peer_data[r] = r < g.world ? c.data[r] : nullptr; a.peer_flag[r] = r < g.world ? c.flag[r] : nullptr; }
+  a.seq = c.seq; a.err = c.err; a.v = stats; a.n = count; a.cap = g.cap; a.me = g.rank; a.world = g.world;
+  a.timeout_ticks = g.timeout_ticks;
+  int blocks = (int)((count + 2047) / 2048);      // >= 2 elements per thread before another workgroup pays
+  if (blocks > P2P_MAX_BLOCKS) blocks = P2P_MAX_BLOCKS;
+  hipLaunchKernelGGL(p2p_exchange_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, a);
+  return npp_check_launch("p2p_exchange");
+}
+
+// 0: every exchange of every channel found its peers; 1: a poll timed out (host-synchronising read of the error words)
+extern "C" int npp_p2p_status(void) {
+  if (!g.local) return 0;
+  int bad = 0;
+  for (int c = 0; c < g.nchan; ++c) {
+    unsigned int e = 0;
+    if (hipMemcpy(&e, g.ch[c].err, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    bad |= e != 0;
+  }
+  return bad;
+}
+
+extern "C" int npp_p2p_close(void) {
+  if (!g.local) return NPP_OK;
+  (void)hipDeviceSynchronize();
+  for (int r = 0; r < g.world; ++r)
+    if (r != g.rank && g.peers[r]) (void)hipIpcCloseMemHandle(g.peers[r]);
+  (void)hipFree(g.local);
+  (void)hipGetLastError();
+  g = P2P();
+  return NPP_OK;
+}

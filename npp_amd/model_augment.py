@@ -522,7 +522,11 @@ class Network(nn.Module):
         # ~2000 stream switches and event pairs cost the host more than the overlap returns (59 vs ~100 img/s), so plain
         # eager SyncBN steps stay on one stream.  NPP_SYNCBN_STREAMS=1 / 3 forces either.
         sync_bn = self._sync_bn_active()
-        mode = _stream_mode() if not sync_bn else _syncbn_stream_mode()
+        # Ranks of one node exchange the statistics through peer-to-peer mailboxes (csrc/p2p.hip): an exchange is then an ordinary
+        # kernel on the stream that needs it, and the branches keep the two-stream topology of the local-BatchNorm step.
+        K.P2P_DIRECT = bool(sync_bn and x.is_cuda and os.environ.get("NPP_SYNCBN_STREAMS") is None
+                            and os.environ.get("NPP_P2P_DIRECT", "1") != "0" and self._p2p_ready())
+        mode = _stream_mode() if (not sync_bn or K.P2P_DIRECT) else _syncbn_stream_mode()
         two = mode >= 2
         K._helper_uses = 0
         K._hub_offload = None
@@ -718,6 +722,18 @@ class Network(nn.Module):
         d["_packer"] = None
         d["_auto"] = None
         return d
+
+    def _p2p_ready(self) -> bool:
+        from . import comm
+        grp = getattr(self, "_sync_pg", False)
+        if grp is False:
+            grp = None
+            for m in self.modules():
+                if isinstance(m, nn.SyncBatchNorm):
+                    grp = K._sync_group(m)[0]
+                    break
+            self._sync_pg = grp
+        return comm.ensure_p2p(grp)
 
     def _sync_bn_active(self) -> bool:
         import torch.distributed as dist

@@ -1,0 +1,120 @@
+"""The one-shot peer-to-peer SyncBatchNorm exchange (csrc/p2p.hip, npp_amd/comm.py:enable_p2p) with two real processes.
+
+Both ranks share the one GPU of the test box (hipIpc maps a buffer of the other PROCESS just the same; the peer stores then go
+through one L2 instead of xGMI): mailbox set-up over a gloo side channel, exchanges of every size, hipGraph replays (the sequence
+counter lives on the device), two channels on two streams, a peer that never shows up (bounded poll, error word), and the
+SyncBatchNorm network of tests/test_syncbn_gpu.py with this transport against the same goldens."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _vec(rank, it, n):
+    g = np.random.default_rng(1000 * it + rank)
+    return g.integers(-1000, 1000, n).astype(np.float64) / 8.0      # sums are exact in f64 whatever the order
+
+
+def _worker(rank, world, port, out, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["NPP_P2P_TIMEOUT_MS"] = "4000"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from npp_amd import comm
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    res = {"enabled": bool(comm.enable_p2p(None, channels=2))}
+    if not res["enabled"]:
+        torch.save(res, f"{out}.{rank}")
+        dist.destroy_process_group()
+        return
+    cap = comm._p2p["cap"]
+    bad = []
+    if mode == "basic":
+        sizes = [1, 2, 7, 64, 1000, 4097, cap, 3, cap - 1, 512] * 3
+        for it, n in enumerate(sizes):
+            v = torch.from_numpy(_vec(rank, it, n)).to(dev)
+            assert comm.p2p_exchange(v, None)
+            want = sum(_vec(r, it, n) for r in range(world))
+            if not np.array_equal(v.cpu().numpy(), want):
+                bad.append(("eager", it, n))
+        big = torch.from_numpy(_vec(rank, 999, 2 * cap + 5)).to(dev)      # longer than a mailbox slot: three pieces
+        assert comm.p2p_exchange(big, None)
+        res["long_vector_ok"] = bool(np.array_equal(big.cpu().numpy(), sum(_vec(r, 999, 2 * cap + 5) for r in range(world))))
+        # hipGraph: three exchanges per replay on a side stream (a channel of its own), static input refreshed between replays
+        st = torch.cuda.Stream()
+        n = 777
+        x = torch.zeros(3, n, dtype=torch.float64, device=dev)
+        y = torch.zeros_like(x)
+        with torch.cuda.stream(st):
+            y.copy_(x)
+            for k in range(3):
+                assert comm.p2p_exchange(y[k], None)       # (warm-up: also assigns the stream its channel outside the capture)
+            st.synchronize()
+            dist.barrier()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                y.copy_(x)
+                for k in range(3):
+                    assert comm.p2p_exchange(y[k], None)
+        for rep in range(6):
+            x.copy_(torch.from_numpy(np.stack([_vec(rank, 100 + 3 * rep + k, n) for k in range(3)])).to(dev))
+            torch.cuda.synchronize()
+            gr.replay()
+            torch.cuda.synchronize()
+            want = np.stack([sum(_vec(r, 100 + 3 * rep + k, n) for r in range(world)) for k in range(3)])
+            if not np.array_equal(y.cpu().numpy(), want):
+                bad.append(("graph", rep))
+        res["exchanges"] = comm._p2p["count"]
+    elif mode == "timeout":
+        # rank 1 never joins the second exchange: rank 0's poll gives up after NPP_P2P_TIMEOUT_MS (4 s here) and reports it
+        v = torch.ones(8, dtype=torch.float64, device=dev)
+        assert comm.p2p_exchange(v, None)
+        torch.cuda.synchronize()
+        res["first_ok"] = bool(comm.p2p_ok()) and float(v[0]) == world
+        if rank == 0:
+            w = torch.ones(8, dtype=torch.float64, device=dev)
+            assert comm.p2p_exchange(w, None)
+            torch.cuda.synchronize()
+            res["second_reported"] = not comm.p2p_ok()
+    res["bad"] = bad
+    res["ok"] = bool(comm.p2p_ok()) if mode != "timeout" else True
+    torch.save(res, f"{out}.{rank}")
+    dist.barrier()
+    comm.disable_p2p()
+    dist.destroy_process_group()
+
+
+def _run(mode, tmp_path, port):
+    out = str(tmp_path / "p2p")
+    mp.spawn(_worker, args=(2, port, out, mode), nprocs=2, join=True)
+    return [torch.load(f"{out}.{r}") for r in range(2)]
+
+
+def test_two_processes_exchange_through_ipc_mailboxes(tmp_path):
+    res = _run("basic", tmp_path, 29671)
+    if not all(r["enabled"] for r in res):
+        assert not any(r["enabled"] for r in res), "the ranks must agree on the transport"
+        pytest.skip("this runtime refuses hipIpc between two processes of one device")
+    for r in res:
+        assert r["bad"] == [] and r["ok"] and r["long_vector_ok"]
+        assert r["exchanges"] == 30 + 3 + 3 + 3      # (replays do not pass through the host counter)
+
+
+def test_a_missing_peer_is_reported_not_waited_for_forever(tmp_path):
+    res = _run("timeout", tmp_path, 29673)
+    if not all(r["enabled"] for r in res):
+        pytest.skip("this runtime refuses hipIpc between two processes of one device")
+    assert all(r["first_ok"] for r in res)
+    assert res[0]["second_reported"]
