@@ -150,8 +150,8 @@ def supervise_rank():
     """One rank of an N > 1 run (under torchrun, or a child of spawn_ranks): this process never touches the GPU.  It starts the
     real worker as a CHILD (NPP_BENCH_WORKER=1), watches its heartbeat file, and if the worker dies or makes no progress for
     NPP_BENCH_STALL_S seconds (a hipGraph capture of RCCL collectives that hangs at N > 1 has never been seen OR ruled out: no
-    multi-GPU box was available to the builder) kills exactly that child and starts a FRESH one with --graph 0 on a fresh
-    rendezvous port -- so that the first real 8-GPU run cannot end with no line at all.  Rank 0's worker writes its JSON record to
+    multi-GPU box was available to the builder) kills exactly that child and starts a FRESH one on a fresh rendezvous port -- first with the
+    SyncBatchNorm exchanges as collectives instead of the peer-to-peer kernel, then eager (--graph 0) -- so that the first real 8-GPU run cannot end with no line at all.  Rank 0's worker writes its JSON record to
     a result file as soon as the timed region is over; a worker that hangs after that (in the extra communicator queries) does
     not cost the measurement."""
     import subprocess
@@ -162,7 +162,10 @@ def supervise_rank():
     stall = float(os.environ.get("NPP_BENCH_STALL_S", "240"))
     tmp = tempfile.mkdtemp(prefix=f"npp_bench_r{rank}_")
     last_rc = 1
-    for attempt in range(2):
+    # attempt 0: the default step (hipGraph, SyncBatchNorm statistics through the peer-to-peer mailboxes of csrc/p2p.hip);
+    # attempt 1: the same with every exchange as an RCCL collective on the hub stream (the round-2 form: neither transport has run on
+    #            a multi-GPU box the builder had access to, so neither may be the only one); attempt 2: collectives, eager (--graph 0)
+    for attempt in range(3):
         hb = os.path.join(tmp, f"hb{attempt}")
         res = os.path.join(tmp, f"result{attempt}.json")
         open(hb, "w").close()
@@ -170,9 +173,15 @@ def supervise_rank():
                    MASTER_PORT=str(base_port + 211 + attempt))
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # the workers' rank 0 hosts the store of ITS attempt's port
         argv = list(sys.argv[1:])
+        env.setdefault("NPP_P2P_TIMEOUT_MS", "8000")        # a peer that never shows up is reported after 8 s, not 20
         if attempt == 1:
+            env["NPP_SYNCBN_P2P"] = "0"
+            env["NPP_BENCH_FALLBACK"] = ("the first attempt (peer-to-peer SyncBatchNorm exchange) died or stalled; this line is from fresh "
+                                         "workers with every exchange as a collective of the process group")
+        if attempt == 2:
             argv += ["--graph", "0"]
-            env["NPP_BENCH_FALLBACK"] = "the hipGraph attempt died or stalled; this line is from a fresh eager (--graph 0) worker"
+            env["NPP_SYNCBN_P2P"] = "0"
+            env["NPP_BENCH_FALLBACK"] = "the hipGraph attempts died or stalled; this line is from a fresh eager (--graph 0) worker"
         child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                  stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL)
         t_last, size_last, seen_any = time.time(), 0, False
@@ -258,7 +267,10 @@ def main():
         rec = {"metric": "fake", "value": 1.0, "graph_arg": args.graph, "attempt": attempt}
         if os.environ.get("NPP_BENCH_FALLBACK"):
             rec["fallback"] = os.environ["NPP_BENCH_FALLBACK"]
+        rec["syncbn_p2p"] = os.environ.get("NPP_SYNCBN_P2P", "1")
         if fake == "hang" and attempt == 0:
+            time.sleep(3600)
+        if fake == "hang2" and attempt <= 1:
             time.sleep(3600)
         if fake == "late_hang":
             with open(os.environ["NPP_BENCH_RESULT"], "w") as fh:
@@ -461,6 +473,16 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if use_dist:
+        # the peer-to-peer exchange reports a peer that never answered through an error word, not by hanging: every rank must have
+        # seen every peer in the warm-up steps, else this attempt ends here and the supervisor starts the collective form
+        from npp_amd import comm as _cm
+        okf = torch.tensor([1 if _cm.p2p_ok() else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) != 1:
+            sys.stderr.write(f"bench.py (rank {rank}): a peer-to-peer SyncBatchNorm exchange timed out during warm-up; giving up this attempt\n")
+            raise SystemExit(17)
+        _hb("peers all present")
     prof = not args.no_prof
     L = _lib.lib()
     import ctypes as C

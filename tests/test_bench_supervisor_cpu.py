@@ -1,5 +1,5 @@
 """bench.py's per-rank supervisor (N > 1 runs: VERDICT r2 item 6a) without a GPU: a worker that stops making progress is
-ended (by its own PID) and replaced by a fresh `--graph 0` worker whose record carries `fallback`; a worker lost AFTER it
+ended (by its own PID) and replaced by a fresh worker -- first on the collective SyncBatchNorm transport, then eager (`--graph 0`) -- whose record carries `fallback`; a worker lost AFTER it
 has written its record does not cost the measurement; a healthy worker's line is relayed unchanged."""
 import json
 import os
@@ -27,11 +27,17 @@ def test_healthy_worker_is_relayed():
 
 
 @pytest.mark.parametrize("fake", ["hang", "crash"])
-def test_stalled_or_dead_worker_is_replaced_by_an_eager_one(fake):
+def test_stalled_or_dead_worker_is_replaced_by_one_on_the_collective_transport(fake):
     r, rec = _run(fake)
     assert r.returncode == 0, r.stderr[-500:]
-    assert rec["attempt"] == 1 and rec["graph_arg"] == 0 and "fallback" in rec
+    assert rec["attempt"] == 1 and rec["syncbn_p2p"] == "0" and rec["graph_arg"] != 0 and "fallback" in rec
     assert "supervisor" in r.stderr
+
+
+def test_a_second_stall_ends_in_the_eager_worker():
+    r, rec = _run("hang2", timeout=90)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert rec["attempt"] == 2 and rec["graph_arg"] == 0 and rec["syncbn_p2p"] == "0" and "eager" in rec["fallback"]
 
 
 def test_worker_lost_after_its_record_keeps_the_record():
