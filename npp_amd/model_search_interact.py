@@ -13,6 +13,7 @@ from __future__ import annotations
 import math
 
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -346,7 +347,13 @@ class Network(nn.Module):
         x = K.image_to_nhwc(x, dt)
         # two task branches on two HIP streams, as in model_augment.Network.forward (the pose branch on the caller's)
         from .model_augment import _side_stream, _stream_mode, Network as _AugNet
-        two = _stream_mode() >= 2 and not _AugNet._sync_bn_active(self)
+        # SyncBatchNorm (search_lip_sync.py:268-271): with the statistics going through the peer-to-peer mailboxes (csrc/p2p.hip) an
+        # exchange is an ordinary kernel on the stream that needs it and the two branch streams stay; with collectives (which must
+        # all sit on one stream) the supernet runs on one stream
+        sync_bn = _AugNet._sync_bn_active(self)
+        K.P2P_DIRECT = bool(sync_bn and x.is_cuda and os.environ.get("NPP_SYNCBN_STREAMS") is None
+                            and os.environ.get("NPP_P2P_DIRECT", "1") != "0" and _AugNet._p2p_ready(self))
+        two = _stream_mode() >= 2 and (not sync_bn or K.P2P_DIRECT)
         K._hub_offload = None
         K._hub_stream = None
         if two:

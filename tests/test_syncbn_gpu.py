@@ -264,6 +264,102 @@ def test_syncbn_p2p_transport_equals_the_collective(tmp_path, monkeypatch):
                 assert rel_err(p2p[r][k], coll[r][k]) < 2e-2, (r, k)      # (run-to-run noise of identical code, see above)
 
 
+def _search_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace as NS
+    from helpers import load_golden, synth_tensors, template_from_golden
+    from npp_amd import _ops as K
+    from npp_amd import comm
+    from npp_amd.model_search_interact import Network
+    from npp_amd.model_augment import set_compute_dtype
+    from npp_amd.synth import synth_batch
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    orig = dist.all_reduce
+
+    def staged(t, *a, **kw):      # (gloo without device support: collectives of CUDA tensors go through the host)
+        if t.is_cuda:
+            h = t.detach().cpu()
+            orig(h, *a, **kw)
+            t.copy_(h)
+        else:
+            orig(t, *a, **kw)
+    dist.all_reduce = staged
+    g = load_golden("search_net.npz")
+    set_compute_dtype(torch.float32)
+    cfg = NS(DATASET=NS(NUM_CLASSES=20, NUM_JOINTS=16), SEARCH=NS(LAYERS=16, INIT_CHANNELS=int(g["C"])),
+             MODEL=NS(DECONV_WITH_BIAS=False, HEAD='PSP', REFINE_LAYERS=1))
+    net = Network(cfg)
+    sd = synth_tensors(template_from_golden(g), 0)
+    for k in ["alphas1", "alphas2", "alphas3", "alphas4", "alphas_pose", "alphas_par", "betas1", "betas2", "betas3",
+              "betas4", "betas_pose", "betas_par"]:
+        sd[k] = sd[k] * 8.0
+    net.load_state_dict(sd)
+    net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net).to(dev).train()
+    n = int(g["n"])
+    per = n // world
+    images, _, _, _ = synth_batch(n, int(g["size"]), seed=0)
+    x = torch.from_numpy(images[rank * per:(rank + 1) * per]).to(dev)
+    pose_list, par_list = net(x)
+    outs = {"pose_map0": pose_list[0][0], "pose_aux0": pose_list[0][1], "pose_map1": pose_list[1][0], "pose_aux1": pose_list[1][1],
+            "par_map0": par_list[0][0], "edge0": par_list[0][1], "par_map1": par_list[1][0], "edge1": par_list[1][1]}
+    sum((o.float() ** 2).sum() for o in outs.values()).backward()
+    torch.cuda.synchronize()
+    res = {"out/" + k: v.detach().float().cpu().numpy() for k, v in outs.items()}
+    res["p2p_exchanges"] = np.array(comm._p2p["count"])
+    res["p2p_ok"] = np.array(1 if comm.p2p_ok() else 0)
+    res["direct"] = np.array(1 if K.P2P_DIRECT else 0)
+    a1 = net.alphas1.grad.detach().double().cpu()
+    orig(a1)
+    res["grad/alphas1"] = a1.numpy()
+    np.savez(os.path.join(out, f"search_rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_supernet_syncbn_two_ranks_two_streams_matches_reference(tmp_path, monkeypatch):
+    """BASELINE config 5 is the MixedOp supernet under SyncBatchNorm (search_lip_sync.py:268-271).  2 ranks x 1 image with the
+    statistics through the peer-to-peer mailboxes -- the two task branches on their own streams -- must give the reference's
+    full-batch training outputs (search_net.npz), and the same outputs / architecture gradient as the single-stream run with
+    collectives (NPP_SYNCBN_P2P=0)."""
+    import socket
+    from helpers import load_golden, rel_err
+    g = load_golden("search_net.npz")
+    n = int(g["n"])
+    if n % 2:
+        pytest.skip("the golden batch does not split over two ranks")
+
+    def run(sub):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        d = tmp_path / sub
+        os.makedirs(str(d))
+        mp.spawn(_search_worker, args=(2, port, str(d)), nprocs=2, join=True)
+        return [np.load(os.path.join(str(d), f"search_rank{r}.npz")) for r in range(2)]
+
+    monkeypatch.setenv("NPP_SYNCBN_P2P", "1")
+    p2p = run("p2p")
+    if int(p2p[0]["p2p_exchanges"]) == 0:
+        pytest.skip("this runtime refuses hipIpc between two processes of one device")
+    monkeypatch.setenv("NPP_SYNCBN_P2P", "0")
+    coll = run("coll")
+    assert int(p2p[0]["direct"]) == 1 and int(coll[0]["direct"]) == 0 and int(coll[0]["p2p_exchanges"]) == 0
+    assert int(p2p[0]["p2p_ok"]) == 1 and int(p2p[1]["p2p_ok"]) == 1
+    print("supernet: exchanges through the mailboxes per step:", int(p2p[0]["p2p_exchanges"]))
+    per = n // 2
+    for r in range(2):
+        for k in p2p[r].files:
+            if k.startswith("out/"):
+                ref = g["train/" + k[4:]][r * per:(r + 1) * per]
+                assert rel_err(p2p[r][k], ref) < 1e-3 * max(1.0, np.abs(g["train/" + k[4:]]).max() / max(np.abs(ref).max(), 1e-30)), (r, k)
+                assert rel_err(p2p[r][k], coll[r][k]) < 1e-4, (r, k)
+    assert rel_err(p2p[0]["grad/alphas1"], coll[0]["grad/alphas1"]) < 2e-2
+
+
 def _ops_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
