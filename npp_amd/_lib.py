@@ -22,6 +22,11 @@ FAM = {"none": 0, "conv_igemm": 1, "conv_wgrad": 2, "dwconv": 3, "bn": 4, "eltwi
        "bilinear": 7, "loss": 8, "conv_s1": 9, "conv_g8": 10, "conv_g4": 11}
 
 
+class NppP2pSeg(C.Structure):
+    _fields_ = [("slabs", C.c_void_p), ("len", C.c_int64), ("split", C.c_int64), ("out0", C.c_void_p), ("out0_dup", C.c_void_p),
+                ("out1", C.c_void_p), ("out2", C.c_void_p), ("nrep", C.c_int32), ("zero_rest", C.c_int32)]
+
+
 class NppTensor(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("n", C.c_int64), ("h", C.c_int64), ("w", C.c_int64), ("c", C.c_int64),
                 ("ld", C.c_int64), ("dtype", C.c_int32), ("_pad", C.c_int32)]
@@ -188,6 +193,7 @@ _SIGS = {
     "npp_p2p_open": [_P],
     "npp_p2p_channels": [],
     "npp_p2p_exchange": [_P, C.c_int64, C.c_int, _P],
+    "npp_p2p_exchange_slabs": [_P, C.c_int, C.c_int, _P],
     "npp_p2p_status": [],
     "npp_p2p_close": [],
     "npp_parsing_confusion": [_T, _T, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],

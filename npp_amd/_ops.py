@@ -365,9 +365,14 @@ def hub_all_reduce(t, group, producers=None):
     Returns the event recorded on the hub after the collective (None when everything ran on the current stream)."""
     hub = _hub_stream
     cur = torch.cuda.current_stream() if t.is_cuda else None
-    if hub is None or cur is None or (P2P_DIRECT and not producers):
+    if hub is None or cur is None:
         _sum_all_reduce(t, group)
         return None
+    if P2P_DIRECT and not producers:
+        from . import comm
+        if comm.p2p_active() and comm.p2p_exchange(t, group):      # an ordinary kernel on the stream that needs the sums
+            return None
+        # (no mailbox channel left for this stream: the collective, on the hub stream as always)
     same = cur.cuda_stream == hub.cuda_stream
     waited = {hub.cuda_stream}
     for st in ([] if same else [cur]) + list(producers or ()):
@@ -1662,9 +1667,19 @@ class _BnAdd(Function):
             return sums, nb
 
         ni = ctx.needs_input_grad
+        # both sides SyncBatchNorm of one group, statistics through the peer-to-peer mailboxes: the two-sided kernels apply as well --
+        # the exchange kernel collapses the reduce's slabs, writes the LOCAL dgamma / dbeta and leaves the world's sums in replica 0
+        sync2 = None
+        if (has_b and bna is not None and bnb is not None and P2P_DIRECT and dout.is_cuda and FUSE_BN_SYNC
+                and _sync_group(bna)[0] is not None and _sync_group(bna)[0] is _sync_group(bnb)[0]):
+            from . import comm as _comm2
+            if _comm2.p2p_can(3 * a.shape[1], _sync_group(bna)[0]):
+                sync2 = _sync_group(bna)[0]
         if (has_b and bna is not None and bnb is not None and batch_a and batch_b and ni[0] and ni[3]
                 and a.shape == b.shape and a.dtype == b.dtype and cnt_a == cnt_b
-                and _sync_group(bna)[0] is None and _sync_group(bnb)[0] is None):
+                and ((_sync_group(bna)[0] is None and _sync_group(bnb)[0] is None) or sync2 is not None)
+                and (sync2 is None or (FUSE_BN_FIN and _fused_layout_ok(a) and _fused_layout_ok(b) and _fused_layout_ok(dout)
+                                       and (yrelu is None or _fused_layout_ok(yrelu))))):
             # both edges end in (local) BatchNorm: the two sides share dout and the ReLU mask -> two-sided kernels
             c = a.shape[1]
             dev = a.device
@@ -1672,7 +1687,7 @@ class _BnAdd(Function):
             fused = (FUSE_BN_FIN and _fused_layout_ok(a) and _fused_layout_ok(b) and _fused_layout_ok(dout)
                      and (yrelu is None or _fused_layout_ok(yrelu)))
             one = None
-            if fused and yrelu is None and _bn_one_blocks(a, True) > 0:
+            if fused and yrelu is None and sync2 is None and _bn_one_blocks(a, True) > 0:
                 one = _bn_one_barrier(dev)
             if one is not None:
                 sums = zeros_f64(R * 3 * c, dev)
@@ -1700,6 +1715,17 @@ class _BnAdd(Function):
                                             dgb_[2].data_ptr(), dgb_[3].data_ptr(), _byref(dxa), _byref(dxb), one.data_ptr(), s),
                       "npp_bn_bwd_one2")
                 BN_ONE_STATS[1] += 1
+                return (dxa, dgb_[0] if ni[1] else None, dgb_[1] if ni[2] else None,
+                        dxb, dgb_[2] if ni[4] else None, dgb_[3] if ni[5] else None, None, None, None, None, None, None)
+            if fused and sync2 is not None:
+                # local sums -> dbeta (both sides), dgamma_a, dgamma_b; world sums -> replica 0, the other replicas zeroed
+                ok2 = _comm2.p2p_exchange_slabs([(sums, 3 * c, R, c, (dgb_[1], dgb_[3], dgb_[0], dgb_[2]), True)], sync2)
+                assert ok2, "peer-to-peer exchange refused a vector it had accepted the size of"
+                dxa = new_nhwc(*a.shape, a.dtype, dev)
+                dxb = new_nhwc(*b.shape, b.dtype, dev)
+                check(lib().npp_bn_bwd_apply2_fin(_byref(dout), _byref(a), _byref(b), tref(yrelu), sums.data_ptr(), R, float(cnt_a),
+                                                  mia.data_ptr(), mib.data_ptr(), ptr(ga), ptr(gb), None, None, None, None,
+                                                  _byref(dxa), _byref(dxb), s), "npp_bn_bwd_apply2_fin")
                 return (dxa, dgb_[0] if ni[1] else None, dgb_[1] if ni[2] else None,
                         dxb, dgb_[2] if ni[4] else None, dgb_[3] if ni[5] else None, None, None, None, None, None, None)
             if fused:
@@ -1738,7 +1764,15 @@ class _BnAdd(Function):
             for i, (x, bn, mi, ss, batch, count, need_x, *_r) in enumerate(sides):
                 if fin[i] and _bn_one_blocks(x, False) > 0:
                     one_bar[i] = _bn_one_barrier(x.device)
-        red = [((zeros_f64(R * 2 * x.shape[1], x.device), R) if one_bar[i] is not None else reduce_side(x, mi, fin[i]))
+        # SyncBatchNorm sides whose sums will travel through the peer-to-peer mailboxes: ACC reduce (R slabs), the exchange kernel
+        # collapses the slabs itself (comm.p2p_exchange_slabs) -- no npp_bn_bwd_sum launch
+        p2p_slabs = False
+        if P2P_DIRECT and dout.is_cuda and any(fin_sync):
+            from . import comm as _comm
+            p2p_slabs = _comm.p2p_can(4 * a.shape[1], _sync_group(bna if bna is not None else bnb)[0]) and all(fs or sides[i][1] is None or not sides[i][4] or _sync_group(sides[i][1])[0] is None
+                                                   for i, fs in enumerate(fin_sync))
+        red = [((zeros_f64(R * 2 * x.shape[1], x.device), R) if one_bar[i] is not None
+                else reduce_side(x, mi, fin[i] or (p2p_slabs and fin_sync[i])))
                if bn is not None else None for i, (x, bn, mi, *_r) in enumerate(sides)]
         # phase 2 (SyncBatchNorm): collapse each side's slabs to one vector (+ the LOCAL dgamma / dbeta, which DDP
         # averages afterwards as torch.nn.SyncBatchNorm does), then ONE all-reduce of the side(s) of this node.
@@ -1750,6 +1784,21 @@ class _BnAdd(Function):
             grp, ws = _sync_group(bn)
             if grp is not None:
                 sync.append((i, grp, x.shape[1]))
+        if sync and p2p_slabs:
+            segs = []
+            for i, grp, c in sync:
+                bn_i = sides[i][1]
+                need_g_, need_b_ = sides[i][7], sides[i][8]
+                dgl = (_grad_buf(bn_i.weight if need_g_ else None, c, dout.device),
+                       _grad_buf(bn_i.bias if need_b_ else None, c, dout.device))
+                segs.append((red[i][0], 2 * c, red[i][1], c, (dgl[1], None, dgl[0], None), False))      # [0, c): sum dout -> dbeta; [c, 2c): -> dgamma
+                local[i] = dgl
+            if len({id(g_) for _, g_, _ in sync}) == 1 and _comm.p2p_exchange_slabs(segs, sync[0][1]):
+                for i, grp, c in sync:
+                    red[i] = (red[i][0], 1)
+                sync = []
+            else:      # (mailboxes too small / two groups: collapse and exchange separately, below)
+                local = [None] * len(sides)
         if sync:
             tot = torch.empty(sum(2 * c for _, _, c in sync), dtype=torch.float64, device=dout.device)
             off = 0

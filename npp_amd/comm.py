@@ -91,7 +91,7 @@ def p2p_wanted():
     return os.environ.get("NPP_SYNCBN_P2P", "1") != "0"
 
 
-def enable_p2p(group=None, channels=2):
+def enable_p2p(group=None, channels=4):
     """Collective over `group`: allocate the mailboxes, exchange the IPC handles through torch.distributed, map the peers.
     Returns True if EVERY rank succeeded (the ranks agree through a MIN all-reduce; otherwise all of them close their mailboxes
     and keep the collective transport).  Ranks of different hosts: not attempted."""
@@ -156,6 +156,20 @@ def disable_p2p():
         _p2p.update(world=0, group=None, cap=0, channels={}, nchan=0)
 
 
+def _p2p_channel(create=True):
+    """The mailbox channel of the current stream (one per stream, in order of first use -- the same order on every rank)."""
+    st = torch.cuda.current_stream().cuda_stream
+    ch = _p2p["channels"].get(st)
+    if ch is None and create and len(_p2p["channels"]) < _p2p["nchan"]:
+        ch = _p2p["channels"][st] = len(_p2p["channels"])
+    return ch, st
+
+
+def p2p_can(n_doubles, group=None) -> bool:
+    """Would an exchange of n_doubles on the CURRENT stream go through the mailboxes?"""
+    return p2p_active() and group is _p2p["group"] and n_doubles <= _p2p["cap"] and _p2p_channel()[0] is not None
+
+
 def p2p_exchange(stats, group=None):
     """In-place SUM over the ranks on the current stream; False if this tensor / stream is not the mailboxes' (the caller then
     uses the collective).  Every stream gets a channel of its own in order of first use -- the same order on every rank."""
@@ -163,16 +177,31 @@ def p2p_exchange(stats, group=None):
         return False
     if not (stats.is_cuda and stats.is_contiguous() and stats.dtype == torch.float64):
         return False
-    st = torch.cuda.current_stream().cuda_stream
-    ch = _p2p["channels"].get(st)
+    ch, st = _p2p_channel()
     if ch is None:
-        if len(_p2p["channels"]) >= _p2p["nchan"]:
-            return False
-        ch = _p2p["channels"][st] = len(_p2p["channels"])
+        return False
     cap, n = _p2p["cap"], stats.numel()
     for lo in range(0, n, cap):      # (a vector longer than a mailbox slot goes in pieces)
         _lib.check(_lib.lib().npp_p2p_exchange(stats.data_ptr() + 8 * lo, min(cap, n - lo), ch, st), "npp_p2p_exchange")
         _p2p["count"] += 1
+    return True
+
+
+def p2p_exchange_slabs(segs, group=None):
+    """segs: up to 4 tuples (slabs f64 [nrep * len], len, nrep, split, (out0, out0_dup, out1, out2) f32 tensors | None, zero_rest)
+    -- see npp_p2p_exchange_slabs.  False if the mailboxes cannot take it (the caller then reduces and exchanges separately)."""
+    if not p2p_active() or group is not _p2p["group"] or not 1 <= len(segs) <= 4 or sum(s[1] for s in segs) > _p2p["cap"]:
+        return False
+    ch, st = _p2p_channel()
+    if ch is None:
+        return False
+    arr = (_lib.NppP2pSeg * len(segs))()
+    for k, (slabs, ln, nrep, split, outs, zero_rest) in enumerate(segs):
+        assert slabs.is_cuda and slabs.dtype == torch.float64 and slabs.is_contiguous() and slabs.numel() >= nrep * ln
+        o = [t.data_ptr() if t is not None else None for t in outs]
+        arr[k] = _lib.NppP2pSeg(slabs.data_ptr(), ln, split, o[0], o[1], o[2], o[3], nrep, 1 if zero_rest else 0)
+    _lib.check(_lib.lib().npp_p2p_exchange_slabs(arr, len(segs), ch, st), "npp_p2p_exchange_slabs")
+    _p2p["count"] += 1
     return True
 
 

@@ -71,16 +71,30 @@ void map_channels(void* base, int r, long cap, int world, int nchan, bool local)
   }
 }
 
+constexpr int P2P_MAX_SEGS = 4;
 struct ExArgs {
   double* peer_data[P2P_MAX_WORLD];
   unsigned long long* peer_flag[P2P_MAX_WORLD];
   unsigned long long* seq;       // [0] exchange counter, [1] workgroups of the current exchange that are done
   unsigned int* err;
-  double* v;
+  double* v;                     // plain form: the vector (nseg == 0)
   long n, cap;
   int me, world;
   long long timeout_ticks;
+  // slab form (npp_p2p_exchange_slabs): the vector is the concatenation of nseg segments, segment k = sum over its nrep replica
+  // slabs [nrep][len]; the local sums also go to out_a (elements [0, split)) / out_b ([split, len)) as floats; the world's sum
+  // lands in replica 0
+  int nseg;
+  double* seg[P2P_MAX_SEGS];
+  long seg_len[P2P_MAX_SEGS], seg_split[P2P_MAX_SEGS];
+  int seg_nrep[P2P_MAX_SEGS], seg_zero[P2P_MAX_SEGS];
+  float* seg_out[P2P_MAX_SEGS][4];      // [0], [1], [2]: elements [0, split), [split, 2 split), [2 split, ..); [3]: a second copy of [0]
 };
+
+NPP_DEV void seg_of(const ExArgs& a, long i, int& k, long& j) {
+  k = 0; j = i;
+  while (k + 1 < a.nseg && j >= a.seg_len[k]) { j -= a.seg_len[k]; ++k; }
+}
 
 // Workgroup b of B handles the elements i = b * 1024 + t, + B * 1024, ...: it pushes them, raises ITS flag on every peer, polls
 // its own flags and sums its elements -- no synchronisation between the workgroups of a launch.  The exchange counter moves when
@@ -94,9 +108,27 @@ __global__ __launch_bounds__(1024) void p2p_exchange_kernel(ExArgs a) {
   const long off = ((long)slot * a.world + a.me) * a.cap;
   const long first = (long)b * 1024 + t, step = (long)B * 1024;
   // push: my share of the vector into slot [slot][me] of every mailbox (mine included)
-  for (int p = 0; p < a.world; ++p) {
-    double* dst = a.peer_data[p] + off;
-    for (long i = first; i < a.n; i += step) __builtin_nontemporal_store(a.v[i], dst + i);
+  if (a.nseg == 0) {
+    for (int p = 0; p < a.world; ++p) {
+      double* dst = a.peer_data[p] + off;
+      for (long i = first; i < a.n; i += step) __builtin_nontemporal_store(a.v[i], dst + i);
+    }
+  } else {
+    for (long i = first; i < a.n; i += step) {
+      int k; long j;
+      seg_of(a, i, k, j);
+      const double* sl = a.seg[k];
+      const long len = a.seg_len[k];
+      double v = 0.0;
+      for (int r = 0; r < a.seg_nrep[k]; ++r) v += sl[(long)r * len + j];
+      {
+        const long sp = a.seg_split[k];
+        const int part = sp > 0 ? (int)(j / sp) : 0;
+        if (part < 3 && a.seg_out[k][part]) a.seg_out[k][part][j - part * sp] = (float)v;
+        if (part == 0 && a.seg_out[k][3]) a.seg_out[k][3][j] = (float)v;
+      }
+      for (int p = 0; p < a.world; ++p) __builtin_nontemporal_store(v, a.peer_data[p] + off + i);
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // system scope: the stores above are visible to the peers before the flags
   __syncthreads();
@@ -122,7 +154,14 @@ __global__ __launch_bounds__(1024) void p2p_exchange_kernel(ExArgs a) {
     for (long i = first; i < a.n; i += step) {
       double acc = 0.0;
       for (int r = 0; r < a.world; ++r) acc += __builtin_nontemporal_load(mine + (long)r * a.cap + i);
-      a.v[i] = acc;
+      if (a.nseg == 0) a.v[i] = acc;
+      else {
+        int k; long j;
+        seg_of(a, i, k, j);
+        a.seg[k][j] = acc;
+        if (a.seg_zero[k])      // the consumer sums all replicas: the other slabs must not count a second time
+          for (int r = 1; r < a.seg_nrep[k]; ++r) a.seg[k][(long)r * a.seg_len[k] + j] = 0.0;
+      }
     }
   }
   if (t == 0) {
@@ -215,10 +254,54 @@ extern "C" int npp_p2p_exchange(double* stats, int64_t count, int channel, void*
   for (int r = 0; r < P2P_MAX_WORLD; ++r) { a.peer_data[r] = r < g.world ? c.data[r] : nullptr; a.peer_flag[r] = r < g.world ? c.flag[r] : nullptr; }
   a.seq = c.seq; a.err = c.err; a.v = stats; a.n = count; a.cap = g.cap; a.me = g.rank; a.world = g.world;
   a.timeout_ticks = g.timeout_ticks;
+  a.nseg = 0;
+  for (int k = 0; k < P2P_MAX_SEGS; ++k) {
+    a.seg[k] = nullptr; a.seg_len[k] = 0; a.seg_split[k] = 0; a.seg_nrep[k] = 0; a.seg_zero[k] = 0;
+    for (int q = 0; q < 4; ++q) a.seg_out[k][q] = nullptr;
+  }
   int blocks = (int)((count + 2047) / 2048);      // >= 2 elements per thread before another workgroup pays
   if (blocks > P2P_MAX_BLOCKS) blocks = P2P_MAX_BLOCKS;
   hipLaunchKernelGGL(p2p_exchange_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, a);
   return npp_check_launch("p2p_exchange");
+}
+
+// Slab form: segment k is the sum over its nrep replica slabs [nrep][len] (the f64 partial sums a BatchNorm-backward reduce leaves,
+// include/npp_hip.h NPP_STAT_REPLICAS); the LOCAL sums are also written as floats: elements [0, split) to out0 (and out0_dup),
+// [split, 2 split) to out1, the rest to out2 -- dbeta and dgamma of torch.nn.SyncBatchNorm, which are NOT reduced -- and the
+// world's sum replaces replica 0 (zero_rest: the other replicas are zeroed, for consumers that sum all of them).
+// One launch instead of npp_bn_bwd_sum + exchange: a link less in the backward chain of every SyncBatchNorm.
+extern "C" int npp_p2p_exchange_slabs(const NppP2pSeg* segs, int nseg, int channel, void* stream) {
+  NPP_REQUIRE(segs && nseg >= 1 && nseg <= P2P_MAX_SEGS, NPP_E_SHAPE, "npp_p2p_exchange_slabs: 1..%d segments", P2P_MAX_SEGS);
+  NPP_REQUIRE(g.local && channel >= 0 && channel < g.nchan, NPP_E_UNSUPPORTED, "npp_p2p_exchange_slabs: no mailboxes / bad channel %d", channel);
+  for (int r = 0; r < g.world; ++r)
+    NPP_REQUIRE(g.peers[r], NPP_E_UNSUPPORTED, "npp_p2p_exchange_slabs: rank %d's mailbox is not mapped (npp_p2p_open)", r);
+  const Channel& c = g.ch[channel];
+  ExArgs a;
+  for (int r = 0; r < P2P_MAX_WORLD; ++r) { a.peer_data[r] = r < g.world ? c.data[r] : nullptr; a.peer_flag[r] = r < g.world ? c.flag[r] : nullptr; }
+  a.seq = c.seq; a.err = c.err; a.v = nullptr; a.cap = g.cap; a.me = g.rank; a.world = g.world; a.timeout_ticks = g.timeout_ticks;
+  a.nseg = nseg;
+  long total = 0;
+  for (int k = 0; k < P2P_MAX_SEGS; ++k) {
+    if (k < nseg) {
+      const NppP2pSeg& sg = segs[k];
+      NPP_REQUIRE(sg.slabs && sg.len > 0 && sg.nrep >= 1 && sg.split >= 0 && sg.split <= sg.len, NPP_E_SHAPE, "npp_p2p_exchange_slabs: bad segment %d", k);
+      a.seg[k] = sg.slabs; a.seg_len[k] = sg.len; a.seg_split[k] = sg.split; a.seg_nrep[k] = sg.nrep; a.seg_zero[k] = sg.zero_rest;
+      a.seg_out[k][0] = sg.out0; a.seg_out[k][1] = sg.out1; a.seg_out[k][2] = sg.out2; a.seg_out[k][3] = sg.out0_dup;
+      total += sg.len;
+    } else {
+      a.seg[k] = nullptr; a.seg_len[k] = 0; a.seg_split[k] = 0; a.seg_nrep[k] = 0; a.seg_zero[k] = 0;
+      for (int q = 0; q < 4; ++q) a.seg_out[k][q] = nullptr;
+    }
+  }
+  if (total > g.cap) {
+    npp_set_error("npp_p2p_exchange_slabs: %ld doubles exceed the mailbox capacity %ld", total, g.cap);
+    return NPP_E_UNSUPPORTED;
+  }
+  a.n = total;
+  int blocks = (int)((total + 1023) / 1024);
+  if (blocks > P2P_MAX_BLOCKS) blocks = P2P_MAX_BLOCKS;
+  hipLaunchKernelGGL(p2p_exchange_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, a);
+  return npp_check_launch("p2p_exchange_slabs");
 }
 
 // 0: every exchange of every channel found its peers; 1: a poll timed out (host-synchronising read of the error words)

@@ -34,7 +34,7 @@ def _worker(rank, world, port, out, mode):
     from npp_amd import comm
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    res = {"enabled": bool(comm.enable_p2p(None, channels=2))}
+    res = {"enabled": bool(comm.enable_p2p(None, channels=2))}  # (two channels: the default stream and the graph's side stream)
     if not res["enabled"]:
         torch.save(res, f"{out}.{rank}")
         dist.destroy_process_group()
