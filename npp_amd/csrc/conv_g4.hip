@@ -34,6 +34,7 @@ typedef float f32x4w __attribute__((ext_vector_type(4)));
 
 struct G4Extra {
   int taps, nchunks, nk, P, HW;
+  int stride, OHW, OW;      // stride > 1 (forward of a strided conv): output pixel (n, oy, ox) reads input (oy * stride, ox * stride) + tap
   unsigned xbytes, wbytes;
 };
 
@@ -104,12 +105,21 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
       int q = m0_ + (wave * PA + i) * 8 + sl;
       const bool real = q < p.M;
       if (!real) q = p.M - 1;
-      abyte[i] = (unsigned)q * (unsigned)p.ldx * 2u + spa;
-      ayx[i] = 0;
-      if (TAPS) {
-        const int rem = q % e.HW;
-        const int y = rem / p.W;
-        ayx[i] = real ? ((y << 16) | (rem - y * p.W)) : (0x4000 << 16);
+      if (e.stride == 1) {
+        abyte[i] = (unsigned)q * (unsigned)p.ldx * 2u + spa;
+        ayx[i] = 0;
+        if (TAPS) {
+          const int rem = q % e.HW;
+          const int y = rem / p.W;
+          ayx[i] = real ? ((y << 16) | (rem - y * p.W)) : (0x4000 << 16);
+        }
+      } else {
+        // the centre of output pixel q in the input: (n, oy * stride + P - ph, ox * stride + P - pw) = (oy, ox) * stride for "same" padding
+        const int n_ = q / e.OHW, rem = q - n_ * e.OHW;
+        const int oy = rem / e.OW, ox = rem - oy * e.OW;
+        const int y = oy * e.stride, x = ox * e.stride;
+        abyte[i] = (unsigned)((n_ * p.H + y) * p.W + x) * (unsigned)p.ldx * 2u + spa;
+        ayx[i] = real ? ((y << 16) | x) : (0x4000 << 16);
       }
     }
     bbyte = (unsigned)(n0_ + wave * PB * 8 + sl) * (unsigned)p.Kpad * 2u + spb;   // further pieces: +8 rows each (scalar offset)
@@ -354,10 +364,14 @@ bool g4_raise_lds(const void* fp, size_t bytes) {
 bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   static const bool disabled = getenv("NPP_DISABLE_G4") != nullptr;
   if (disabled || dtype != NPP_BF16) return false;
-  if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.uph != 1 || p.upw != 1) return false;
+  static const bool strided_off = getenv("NPP_G4_NO_STRIDE") != nullptr;
+  if (p.sh != p.sw || p.sh < 1 || p.sh > 2 || (p.sh == 2 && strided_off) || p.dh != 1 || p.dw != 1 || p.uph != 1 || p.upw != 1) return false;
   if (p.KH != p.KW || (p.KH & 1) == 0 || p.KH > 5) return false;
   const int P = (p.KH - 1) / 2;
-  if (p.ph != P || p.pw != P || p.OH != p.H || p.OW != p.W) return false;
+  // stride 2 (forward of the reduction cells' convs, FactorizedReduce, the second stem conv): output (oy, ox) is centred on input
+  // (2 oy, 2 ox); the last centre must lie inside the input (taps beyond the border are masked like any other)
+  if (p.ph != P || p.pw != P || p.OH != (p.H - 1) / p.sh + 1 || p.OW != (p.W - 1) / p.sw + 1) return false;
+  if (p.sh == 2 && (p.accum || p.mask)) return false;
   const bool half = p.Cin == 32;                      // two taps per K-tile
   if (p.Cp != p.Cin || (p.Cin % 64 != 0 && !half) || p.ldx % 8 != 0 || (p.Cout % 64 != 0 && p.Cout != 32)) return false;
   if ((long)p.N * p.H * p.W * p.ldx * 2 >= (1L << 32) - 65536) return false;
@@ -380,6 +394,7 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (P == 0 && !g8_off && p.Cin >= 256 && p.Cout >= 256 && p.Cout % 128 == 0 && p.M >= 65536) return false;
   G4Extra e;
   e.taps = p.KH * p.KW; e.nchunks = half ? 1 : p.Cin / 64; e.nk = half ? (e.taps + 1) / 2 : e.taps * e.nchunks; e.P = P; e.HW = p.H * p.W;
+  e.stride = p.sh; e.OHW = p.OH * p.OW; e.OW = p.OW;
   e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
   e.wbytes = (unsigned)wbytes;
   // tile: 128 x 128 halves the operand bytes per MAC (2 blocks per CU); 64 x 64 gives 4x the blocks (4 per CU).  Measured
