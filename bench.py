@@ -146,7 +146,29 @@ def _hb(msg):
             pass
 
 
-def supervise_rank():
+def _tiers_multi():
+    """Attempts of an N > 1 rank, see supervise_rank."""
+    return [
+        ({}, [], None),
+        ({"NPP_SYNCBN_P2P": "0"}, [],
+         "the first attempt (peer-to-peer SyncBatchNorm exchange) died or stalled; this line is from fresh workers with every exchange "
+         "as a collective of the process group"),
+        ({"NPP_SYNCBN_P2P": "0"}, ["--graph", "0"], "the hipGraph attempts died or stalled; this line is from a fresh eager (--graph 0) worker"),
+    ]
+
+
+def _tiers_single():
+    """Attempts of the 1-GPU run: the replayed step on TWO hardware queues (GPU_MAX_HW_QUEUES=2: the hipGraph executor then keeps the
+    two branch chains on one queue each instead of spreading their segments over three -- 45.4 vs 45.9 ms per step, measured A/B/A on
+    one box; 8 queues: 74.5 ms), then the runtime's default in a fresh process should the first one not deliver (a capture on fewer
+    queues than captured streams has been seen to crash the runtime: the supernet, which therefore never gets this setting)."""
+    return [
+        ({"GPU_MAX_HW_QUEUES": "2"}, [], None),
+        ({}, [], "the first worker (GPU_MAX_HW_QUEUES=2) died or stalled; this line is from a fresh worker on the runtime's default queues"),
+    ]
+
+
+def supervise_rank(tiers=None):
     """One rank of an N > 1 run (under torchrun, or a child of spawn_ranks): this process never touches the GPU.  It starts the
     real worker as a CHILD (NPP_BENCH_WORKER=1), watches its heartbeat file, and if the worker dies or makes no progress for
     NPP_BENCH_STALL_S seconds (a hipGraph capture of RCCL collectives that hangs at N > 1 has never been seen OR ruled out: no
@@ -165,7 +187,9 @@ def supervise_rank():
     # attempt 0: the default step (hipGraph, SyncBatchNorm statistics through the peer-to-peer mailboxes of csrc/p2p.hip);
     # attempt 1: the same with every exchange as an RCCL collective on the hub stream (the round-2 form: neither transport has run on
     #            a multi-GPU box the builder had access to, so neither may be the only one); attempt 2: collectives, eager (--graph 0)
-    for attempt in range(3):
+    if tiers is None:
+        tiers = _tiers_multi()
+    for attempt, (tier_env, tier_argv, tier_note) in enumerate(tiers):
         hb = os.path.join(tmp, f"hb{attempt}")
         res = os.path.join(tmp, f"result{attempt}.json")
         open(hb, "w").close()
@@ -174,14 +198,10 @@ def supervise_rank():
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # the workers' rank 0 hosts the store of ITS attempt's port
         argv = list(sys.argv[1:])
         env.setdefault("NPP_P2P_TIMEOUT_MS", "8000")        # a peer that never shows up is reported after 8 s, not 20
-        if attempt == 1:
-            env["NPP_SYNCBN_P2P"] = "0"
-            env["NPP_BENCH_FALLBACK"] = ("the first attempt (peer-to-peer SyncBatchNorm exchange) died or stalled; this line is from fresh "
-                                         "workers with every exchange as a collective of the process group")
-        if attempt == 2:
-            argv += ["--graph", "0"]
-            env["NPP_SYNCBN_P2P"] = "0"
-            env["NPP_BENCH_FALLBACK"] = "the hipGraph attempts died or stalled; this line is from a fresh eager (--graph 0) worker"
+        env.update(tier_env)
+        argv += tier_argv
+        if tier_note:
+            env["NPP_BENCH_FALLBACK"] = tier_note
         child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                  stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL)
         t_last, size_last, seen_any = time.time(), 0, False
@@ -258,9 +278,14 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))
     if (args.gpus > 1 and not os.environ.get("NPP_BENCH_WORKER") and os.environ.get("NPP_BENCH_SUPERVISE", "1") != "0"):
         raise SystemExit(supervise_rank())      # a rank of an N > 1 run: watchdog parent + worker child (see supervise_rank)
+    if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1") or "1") == 1 and not os.environ.get("NPP_BENCH_WORKER")
+            and os.environ.get("NPP_BENCH_SUPERVISE", "1") != "0" and "GPU_MAX_HW_QUEUES" not in os.environ
+            and args.model == "augment" and not args.force_dist and not args.launcher):
+        # the default 1-GPU line: the worker runs as a child on two hardware queues, with a fresh default-queue worker behind it
+        raise SystemExit(supervise_rank(_tiers_single()))
     _hb("worker started")
     fake = os.environ.get("NPP_BENCH_FAKE_WORKER")
-    if fake and os.environ.get("NPP_BENCH_WORKER"):
+    if fake:
         # tests/test_bench_supervisor_cpu.py: the watchdog's logic without a GPU.  "hang": the first attempt stops making progress
         # (as a hung capture would), the --graph 0 attempt answers; "late_hang": the record is written, then the worker hangs
         attempt = int(os.environ.get("NPP_BENCH_ATTEMPT", "0"))
@@ -268,6 +293,7 @@ def main():
         if os.environ.get("NPP_BENCH_FALLBACK"):
             rec["fallback"] = os.environ["NPP_BENCH_FALLBACK"]
         rec["syncbn_p2p"] = os.environ.get("NPP_SYNCBN_P2P", "1")
+        rec["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
         if fake == "hang" and attempt == 0:
             time.sleep(3600)
         if fake == "hang2" and attempt <= 1:
@@ -612,7 +638,7 @@ def main():
                                  else "(weights pass)")) +
                                ", %dx%d, batch %d/GPU, fwd + Criterion_par + Criterion_pose + bwd + Adam step"
                                % (args.size, args.size, args.batch),
-                   "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                   "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"), "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "sync_bn": bool(sync_bn), "hip_graph": graph is not None or (args.launcher == "auto" and net._auto is not None and net._auto.graph is not None),
                    "launcher_loop": args.launcher or None, "loss": float(loss.detach())},
         "model_tflops": round(value * 3 * (FWD_GFLOP_PER_IMG.get(args.size, 243.37 * (args.size / 384.0) ** 2)

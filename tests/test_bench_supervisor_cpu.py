@@ -43,3 +43,33 @@ def test_a_second_stall_ends_in_the_eager_worker():
 def test_worker_lost_after_its_record_keeps_the_record():
     r, rec = _run("late_hang")
     assert r.returncode == 0 and rec["attempt"] == 0
+
+
+def _run_single(fake, timeout=60):
+    env = dict(os.environ, NPP_BENCH_FAKE_WORKER=fake, NPP_BENCH_STALL_S="2", NPP_BENCH_STALL_FIRST_S="2")
+    for k in ("NPP_BENCH_WORKER", "WORLD_SIZE", "RANK", "LOCAL_RANK", "GPU_MAX_HW_QUEUES"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_single_gpu_line_runs_on_two_hardware_queues_with_a_default_queue_worker_behind_it():
+    """The default 1-GPU run: a child on GPU_MAX_HW_QUEUES=2; if that child dies (a capture on fewer hardware queues than captured
+    streams has crashed the runtime for the supernet) a fresh child on the runtime's default delivers the line, marked `fallback`."""
+    r, rec = _run_single("ok")
+    assert r.returncode == 0 and rec["attempt"] == 0 and rec["hw_queues"] == "2" and "fallback" not in rec
+    r, rec = _run_single("crash")
+    assert r.returncode == 0, r.stderr[-500:]
+    assert rec["attempt"] == 1 and rec["hw_queues"] is None and "default queues" in rec["fallback"]
+
+
+def test_an_exported_queue_count_is_left_alone():
+    env = dict(os.environ, NPP_BENCH_FAKE_WORKER="ok", GPU_MAX_HW_QUEUES="4")
+    for k in ("NPP_BENCH_WORKER", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=60)
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r.returncode == 0 and rec["hw_queues"] == "4" and rec["attempt"] == 0 and "supervisor" not in r.stderr

@@ -5,6 +5,8 @@
 #   3. two --pmc passes (FETCH_SIZE, WRITE_SIZE) of the eager single-stream run -> HBM bytes per conv_s1 / conv_g8 launch
 tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+# (the profiled program must be the worker itself -- no supervisor child under rocprofv3 -- on the queue count the bench line uses)
+export GPU_MAX_HW_QUEUES=2
 out=gpurun_out/final; mkdir -p $out
 run() {  # name, extra env assignment string, bench args...
   name=$1; shift
@@ -37,6 +39,6 @@ fm=$(find /tmp/fp_pmc_mfma -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_mfma_busy.py "$fm" "$FAMS,bn_bwd,add_n,affine_add,dw" > $out/${tag}_pmc_mfma_busy.txt
 cat $out/${tag}_pmc_mfma_busy.txt
 #   5. the plain bench line (no profiler, default streams), after copying the fresh traffic file where bench.py reads it
-unset NPP_STREAMS NPP_SYNC_LAUNCH
+unset NPP_STREAMS NPP_SYNC_LAUNCH GPU_MAX_HW_QUEUES
 cp $out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
 python3 bench.py > $out/${tag}_bench_line.json 2> /dev/null; tail -c 400 $out/${tag}_bench_line.json
