@@ -157,14 +157,15 @@ def _tiers_multi():
     ]
 
 
-def _tiers_single():
+def _tiers_single(queues="2"):
     """Attempts of the 1-GPU run: the replayed step on TWO hardware queues (GPU_MAX_HW_QUEUES=2: the hipGraph executor then keeps the
     two branch chains on one queue each instead of spreading their segments over three -- 45.4 vs 45.9 ms per step, measured A/B/A on
     one box; 8 queues: 74.5 ms), then the runtime's default in a fresh process should the first one not deliver (a capture on fewer
-    queues than captured streams has been seen to crash the runtime: the supernet, which therefore never gets this setting)."""
+    queues than captured streams has been seen to crash the runtime: the supernet's step at 2 queues, which therefore gets 3 --
+    68.8 ms per step against 71.1 at the default of 4 and 238 at 6)."""
     return [
-        ({"GPU_MAX_HW_QUEUES": "2"}, [], None),
-        ({}, [], "the first worker (GPU_MAX_HW_QUEUES=2) died or stalled; this line is from a fresh worker on the runtime's default queues"),
+        ({"GPU_MAX_HW_QUEUES": queues}, [], None),
+        ({}, [], f"the first worker (GPU_MAX_HW_QUEUES={queues}) died or stalled; this line is from a fresh worker on the runtime's default queues"),
     ]
 
 
@@ -280,9 +281,9 @@ def main():
         raise SystemExit(supervise_rank())      # a rank of an N > 1 run: watchdog parent + worker child (see supervise_rank)
     if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1") or "1") == 1 and not os.environ.get("NPP_BENCH_WORKER")
             and os.environ.get("NPP_BENCH_SUPERVISE", "1") != "0" and "GPU_MAX_HW_QUEUES" not in os.environ
-            and args.model == "augment" and not args.force_dist and not args.launcher):
+            and not args.force_dist and not args.launcher and not args.alpha_pass):
         # the default 1-GPU line: the worker runs as a child on two hardware queues, with a fresh default-queue worker behind it
-        raise SystemExit(supervise_rank(_tiers_single()))
+        raise SystemExit(supervise_rank(_tiers_single("2" if args.model == "augment" else "3")))
     _hb("worker started")
     fake = os.environ.get("NPP_BENCH_FAKE_WORKER")
     if fake:
