@@ -552,6 +552,10 @@ def main():
                 traffic_note = (f"{traffic_file} was collected on kernel sources {traffic_db.get('source_hash')}, this build is "
                                 f"{_lib.kernel_source_hash()}: stale, not reported (re-run tools/final_profiles.sh)")
                 traffic_db = {}
+            elif _lib.built_source_hash() != _lib.kernel_source_hash():
+                traffic_note = (f"libnpp_hip.so was built from sources {_lib.built_source_hash()}, the tree holds "
+                                f"{_lib.kernel_source_hash()}: the counters in {traffic_file} are not this library's, not reported")
+                traffic_db = {}
         except Exception as e:      # noqa: BLE001
             traffic_db, traffic_note = {}, f"{traffic_file}: {e}"
         for fam, label in KERNELS.items():

@@ -219,6 +219,12 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def built_source_hash() -> str:
+    """The source hash compiled into the loaded library (npp_version: '... src <hash>'); 'unknown' for a library built without it."""
+    v = lib().npp_version().decode()
+    return v.rsplit(" src ", 1)[1] if " src " in v else "unknown"
+
+
 def lib():
     """Load (once) and return the C library; raises if it has not been built."""
     global _lib

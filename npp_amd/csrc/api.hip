@@ -39,7 +39,11 @@ int npp_check_launch(const char* what) {
 // "operation failed due to a previous error during capture" for a perfectly good launch.  The eager fallback calls this.
 extern "C" int npp_clear_hip_error(void) { return (int)hipGetLastError(); }
 
-extern "C" const char* npp_version(void) { return "npp_hip 0.1 (gfx950)"; }
+#ifndef NPP_SRC_HASH
+#define NPP_SRC_HASH "unknown"
+#endif
+// "... src <hash>": the hash build.sh computed over the sources (the value npp_amd._lib.kernel_source_hash() gives for the same files)
+extern "C" const char* npp_version(void) { return "npp_hip 0.1 (gfx950) src " NPP_SRC_HASH; }
 extern "C" const char* npp_last_error(void) { return g_err; }
 
 // ---- profiler ------------------------------------------------------------------------------------

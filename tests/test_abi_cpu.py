@@ -94,3 +94,10 @@ def test_train_step_batch_plumbing_is_shape_exact():
     flat_b, layout_b = TrainStep._flatten(im[:1], [a[:1] for a in lpar], [a[:1] for a in lpose], None)
     assert TrainStep._signature(flat_b, layout_b) != sig
     assert TrainStep._signature(*TrainStep._flatten(im.clone(), lpar, lpose, None)) == sig
+
+
+def test_library_carries_the_hash_of_the_sources_in_the_tree():
+    """build.sh compiles the hash of csrc/*.hip, *.h and include/npp_hip.h into npp_version(); a library left over from other sources
+    (and with it bench.py's `traffic`, which is keyed by that hash) is caught here."""
+    from npp_amd import _lib
+    assert _lib.built_source_hash() == _lib.kernel_source_hash()
