@@ -138,8 +138,12 @@ __global__ __launch_bounds__(1024) void p2p_exchange_kernel(ExArgs a) {
   // wait for the world's flags of this exchange (and workgroup) in my own mailbox
   if (t < a.world) {
     const unsigned long long* f = a.peer_flag[a.me] + fidx + (long)t * P2P_MAX_BLOCKS;
+    // once a poll has timed out the channel is dead: later exchanges do not wait again (a step has hundreds of them -- the host
+    // finds the error word after the step, npp_p2p_status, and switches transports)
+    const bool dead = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < s + 1) {
+      if (dead) { s_bad = 1; break; }
       __builtin_amdgcn_s_sleep(2);
       if (wall_clock64() - t0 > a.timeout_ticks) { s_bad = 1; break; }
     }

@@ -181,6 +181,7 @@ class TrainStep:
                     loss = self._eager(images, labels_par, labels_pose, pose_weight)
                 torch.cuda.current_stream().wait_stream(self._side)
                 return loss
+            self._check_p2p_transport()
             err = None
             try:
                 self._capture(flat, layout)
@@ -218,6 +219,25 @@ class TrainStep:
         self.graph.replay()
         K.note_training_step()         # parameters changed behind Tensor._version: derived images (packed weights) are stale
         return self._static_loss
+
+    def _check_p2p_transport(self):
+        """Before the step is frozen into a graph: did every peer answer every peer-to-peer SyncBatchNorm exchange of the eager warm-up
+        steps (csrc/p2p.hip reports a peer that never showed up through an error word, it does not hang)?  The ranks agree (MIN); if
+        any of them saw a time-out ALL of them close the mailboxes and the capture -- and every later step -- uses the collectives."""
+        from . import comm
+        if not comm.p2p_active():
+            return
+        ok = comm.p2p_ok()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item()) == 1
+        if not ok:
+            sys.stderr.write("[npp_amd.TrainStep] a peer-to-peer SyncBatchNorm exchange timed out during warm-up: every rank switches to "
+                             "the collective transport (the statistics of the warm-up steps were local to each rank)\n")
+            comm.disable_p2p()
+            comm._p2p_tried.update({id(None), id(dist.group.WORLD)} if dist.is_initialized() else {id(None)})
+            K.P2P_DIRECT = False
 
     def _abandon_capture(self, failed_here: bool):
         """Back to the eager path for good (on every rank alike, see __call__)."""

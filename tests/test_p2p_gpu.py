@@ -88,6 +88,12 @@ def _worker(rank, world, port, out, mode):
             assert comm.p2p_exchange(w, None)
             torch.cuda.synchronize()
             res["second_reported"] = not comm.p2p_ok()
+            import time
+            t0 = time.time()
+            for _ in range(50):                         # a dead channel does not wait again: 50 more exchanges take no time
+                assert comm.p2p_exchange(w, None)
+            torch.cuda.synchronize()
+            res["dead_channel_is_fast"] = time.time() - t0 < 2.0
     res["bad"] = bad
     res["ok"] = bool(comm.p2p_ok()) if mode != "timeout" else True
     torch.save(res, f"{out}.{rank}")
@@ -117,4 +123,4 @@ def test_a_missing_peer_is_reported_not_waited_for_forever(tmp_path):
     if not all(r["enabled"] for r in res):
         pytest.skip("this runtime refuses hipIpc between two processes of one device")
     assert all(r["first_ok"] for r in res)
-    assert res[0]["second_reported"]
+    assert res[0]["second_reported"] and res[0]["dead_channel_is_fast"]
