@@ -76,6 +76,33 @@ def _worker(rank, world, port, out, mode):
             want = np.stack([sum(_vec(r, 100 + 3 * rep + k, n) for r in range(world)) for k in range(3)])
             if not np.array_equal(y.cpu().numpy(), want):
                 bad.append(("graph", rep))
+        # slab form: two segments of replica slabs (16 x 2c and 16 x 3c), local sums out as floats, the world's sum in replica 0,
+        # the other replicas of the second segment zeroed
+        c1, c2, R = 40, 24, 16
+        g = np.random.default_rng(7 + rank)
+        s1 = g.integers(-50, 50, (R, 2 * c1)).astype(np.float64)
+        s2 = g.integers(-50, 50, (R, 3 * c2)).astype(np.float64)
+        t1, t2 = torch.from_numpy(s1.copy()).to(dev).reshape(-1), torch.from_numpy(s2.copy()).to(dev).reshape(-1)
+        o = [torch.full((n_,), -1.0, device=dev) for n_ in (c1, c1, c2, c2, c2, c2)]
+        ok_ = comm.p2p_exchange_slabs([(t1, 2 * c1, R, c1, (o[0], None, o[1], None), False),
+                                       (t2, 3 * c2, R, c2, (o[2], o[3], o[4], o[5]), True)], None)
+        torch.cuda.synchronize()
+        loc1, loc2 = s1.sum(0), s2.sum(0)
+        all1 = sum(np.random.default_rng(7 + r).integers(-50, 50, (R, 2 * c1)).astype(np.float64).sum(0) for r in range(world))
+        gens = [np.random.default_rng(7 + r) for r in range(world)]
+        all2 = 0
+        for gg in gens:
+            gg.integers(-50, 50, (R, 2 * c1))
+            all2 = all2 + gg.integers(-50, 50, (R, 3 * c2)).astype(np.float64).sum(0)
+        r1, r2 = t1.cpu().numpy().reshape(R, -1), t2.cpu().numpy().reshape(R, -1)
+        res["slabs_ok"] = bool(ok_ and np.array_equal(r1[0], all1) and np.array_equal(r1[1:], s1[1:])      # (not zeroed: untouched)
+                               and np.array_equal(r2[0], all2) and not r2[1:].any()
+                               and np.array_equal(o[0].cpu().numpy(), loc1[:c1].astype(np.float32))
+                               and np.array_equal(o[1].cpu().numpy(), loc1[c1:].astype(np.float32))
+                               and np.array_equal(o[2].cpu().numpy(), loc2[:c2].astype(np.float32))
+                               and np.array_equal(o[3].cpu().numpy(), loc2[:c2].astype(np.float32))
+                               and np.array_equal(o[4].cpu().numpy(), loc2[c2:2 * c2].astype(np.float32))
+                               and np.array_equal(o[5].cpu().numpy(), loc2[2 * c2:].astype(np.float32)))
         res["exchanges"] = comm._p2p["count"]
     elif mode == "timeout":
         # rank 1 never joins the second exchange: rank 0's poll gives up after NPP_P2P_TIMEOUT_MS (4 s here) and reports it
@@ -114,8 +141,8 @@ def test_two_processes_exchange_through_ipc_mailboxes(tmp_path):
         assert not any(r["enabled"] for r in res), "the ranks must agree on the transport"
         pytest.skip("this runtime refuses hipIpc between two processes of one device")
     for r in res:
-        assert r["bad"] == [] and r["ok"] and r["long_vector_ok"]
-        assert r["exchanges"] == 30 + 3 + 3 + 3      # (replays do not pass through the host counter)
+        assert r["bad"] == [] and r["ok"] and r["long_vector_ok"] and r["slabs_ok"]
+        assert r["exchanges"] == 30 + 3 + 3 + 3 + 1      # (replays do not pass through the host counter)
 
 
 def test_a_missing_peer_is_reported_not_waited_for_forever(tmp_path):
