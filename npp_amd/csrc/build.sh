@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libnpp_hip.so
-SRCS="api.hip conv_igemm.hip conv_s1.hip conv_g8.hip conv_g4.hip conv_h3.hip conv_thin.hip conv_wgrad.hip conv_wgrad_s1.hip conv_wgrad_g4.hip conv_wgrad_h3.hip dwconv.hip bn.hip bn_one.hip pool.hip se.hip bilinear.hip misc.hip loss.hip optim.hip eval.hip targets.hip comm.hip p2p.hip"
+SRCS="api.hip conv_igemm.hip conv_s1.hip conv_g8.hip conv_g4.hip conv_h3.hip conv_thin.hip conv_c32.hip conv_wgrad.hip conv_wgrad_s1.hip conv_wgrad_g4.hip conv_wgrad_h3.hip dwconv.hip bn.hip bn_one.hip pool.hip se.hip bilinear.hip misc.hip loss.hip optim.hip eval.hip targets.hip comm.hip p2p.hip"
 OBJS=""
 mkdir -p build
 # the hash of the sources this library is built from (npp_amd._lib.kernel_source_hash) goes into npp_version(): bench.py reports a

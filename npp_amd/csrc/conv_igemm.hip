@@ -611,6 +611,7 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
   {
     ProfScope prof2(NPP_FAM_CONV_G4, x->dtype, s, flops, bytes);
     if (conv_thin_launch(p, x->dtype, s)) return npp_check_launch("conv_thin");  // (same family: stride-1 fwd + dgrad)
+    if (conv_c32_launch(p, x->dtype, s)) return npp_check_launch("conv_c32");
     if (conv_h3_launch(p, x->dtype, s)) return npp_check_launch("conv_h3");
     if (conv_g4_launch(p, x->dtype, s)) return npp_check_launch("conv_g4");
     prof2.cancel();

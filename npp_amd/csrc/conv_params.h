@@ -26,3 +26,5 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream);
 bool conv_h3_launch(const IgemmParams& p, int dtype, hipStream_t stream);
 // 3x3 stride-1 convs with at most 8 output channels, or at most 8 input channels (conv_thin.hip: the edge head and its data gradient)
 bool conv_thin_launch(const IgemmParams& p, int dtype, hipStream_t stream);
+// 3x3 stride-1 conv, 32 -> 32 channels, whole problem of a tile resident in LDS (conv_c32.hip: the encoder's first stage)
+bool conv_c32_launch(const IgemmParams& p, int dtype, hipStream_t stream);

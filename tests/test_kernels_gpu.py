@@ -60,6 +60,8 @@ CONV_CASES = [
     (128, 256, 1, 1, 0, 1, 225, 225, 1, True, False, 8),   # g8 BN=256, ragged M, channel-slice input; dgrad with mask
     (256, 256, 1, 1, 0, 1, 192, 192, 2, False, False, 0),  # g8 BN=256 fwd + dgrad without mask, 4 K-tiles (deep and wide: not g4)
     (256, 128, 1, 1, 0, 1, 160, 160, 2, False, False, 0),  # g4 on a large map, dgrad N=256
+    (32, 32, 3, 1, 1, 1, 50, 96, 10, True, True, 8),       # conv_c32 (12 x 16 tiles, all nine taps resident): ragged last tile row, bias, channel-slice input
+    (32, 32, 3, 1, 1, 1, 96, 48, 6, False, False, 0),      # conv_c32 without ReLU
     (64, 128, 3, 1, 1, 1, 225, 225, 1, True, False, 0),    # 3x3 on a large map, ragged M (g8 when NPP_G8_MAXK=3: see below)
     (128, 128, 3, 1, 1, 1, 160, 160, 2, False, True, 0),   # 3x3 + bias, two channel chunks; dgrad without mask
     (128, 256, 1, 1, 0, 1, 200, 201, 2, True, True, 0),    # g4 persistent form: 1258 tiles of 128x128 over 512 slots, ragged M,
@@ -133,6 +135,7 @@ BENCH_CASES = [
     (512, 128, 1, "conv_g4"),      # PoseCell1 / ParCell1 preprocess (HBM-bound, persistent 128 x 128 tiles)
     (384, 128, 3, "conv_g4"),      # pose_auxnet (conv_h3, three channel tiles; reports under conv_g4's family)
     (128, 128, 3, "conv_g4"),      # the 30 refine-cell convs (conv_h3)
+    (32, 32, 3, "conv_g4"),        # the encoder's first stage (conv_c32: the whole tile problem resident in LDS)
 ]
 
 

@@ -29,7 +29,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 ff=$(find /tmp/fp_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 fw=$(find /tmp/fp_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-FAMS="conv_g4=conv_g4_kernel|conv_h3_kernel|conv_thin_out_kernel|conv_thin_in_kernel,conv_g8=conv_g8_kernel,conv_wgrad=conv_wgrad_g4_kernel|conv_wgrad_g4_batched_kernel|conv_wgrad_kernel|conv_wgrad_s1_kernel|conv_wgrad_h3_kernel|conv_wgrad_thin_kernel,conv_h3_kernel,conv_g4_kernel,conv_wgrad_g4_batched_kernel"
+FAMS="conv_g4=conv_g4_kernel|conv_h3_kernel|conv_thin_out_kernel|conv_thin_in_kernel|conv_c32_kernel,conv_g8=conv_g8_kernel,conv_wgrad=conv_wgrad_g4_kernel|conv_wgrad_g4_batched_kernel|conv_wgrad_kernel|conv_wgrad_s1_kernel|conv_wgrad_h3_kernel|conv_wgrad_thin_kernel,conv_h3_kernel,conv_g4_kernel,conv_wgrad_g4_batched_kernel"
 python3 tools/pmc_traffic.py "$ff" "$fw" "$FAMS" $out/${tag}_pmc_traffic.json
 python3 tools/pmc_step_total.py "$ff" "$fw" 4 > $out/${tag}_pmc_step_total.txt
 #   4. MFMA utilisation per conv family (north_star: "rocprof HBM GB/s and MFMA utilisation")
