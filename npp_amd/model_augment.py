@@ -132,6 +132,17 @@ class _DagCell(nn.Module):
         return states, (cb.result(parts) if cb is not None else K.concat(parts))
 
 
+def _preprocess_pair(pre0, s0, pre1, s1):
+    """[pre0(s0), pre1(s1)] with both convs issued before either BatchNorm is applied: under SyncBatchNorm the statistics of the two
+    then travel in ONE exchange (they sit back to back in the stream's statistics pool and the first apply flushes both)."""
+    from .operations import pending_of
+    a, b = pending_of(pre0, s0), pending_of(pre1, s1)
+    outs = []
+    for side in (a, b):
+        outs.append(K.bn_add(side, None, relu=False, training=side.bn.training) if side.bn is not None else side.x)
+    return outs
+
+
 class Cell(_DagCell):
     """Encoder cell, model_augment.py:16-62."""
 
@@ -147,7 +158,7 @@ class Cell(_DagCell):
         self._build(C, edges, concat, lambda idx: 2 if reduction and idx < 2 else 1, lambda idx: None)
 
     def forward(self, s0, s1):
-        _, out = self._run([self.preprocess0(s0), self.preprocess1(s1)], self._concat)
+        _, out = self._run(_preprocess_pair(self.preprocess0, s0, self.preprocess1, s1), self._concat)
         return out
 
     def stages(self, s0, s1, result):
@@ -186,7 +197,7 @@ class Upsample(_DagCell):
         self._build(C_prev // 4, upsample, upsample_concat, lambda idx: 1, lambda idx: 2 if idx == 0 else None)
 
     def forward(self, s0, s1):
-        _, out = self._run([self.preprocess0(s0), self.preprocess1(s1)], self._concat)
+        _, out = self._run(_preprocess_pair(self.preprocess0, s0, self.preprocess1, s1), self._concat)
         return out
 
 
