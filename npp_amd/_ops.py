@@ -339,6 +339,7 @@ GRAPH_TOPOLOGY = False  # set by train_step.TrainStep while its steps are (to be
 _hub_stream = None     # the stream Network.forward was called on while it runs its branches on two streams
 
 
+SYNC_WAVES = False     # set by Network.forward under SyncBatchNorm: cells issue the edges of every ready node before any BatchNorm apply
 P2P_DIRECT = False     # set by Network.forward: the SyncBatchNorm exchanges go through the peer-to-peer mailboxes (csrc/p2p.hip), each on
                        # the stream of the kernels that need it -- no hub stream, no lockstep (an exchange is an ordinary kernel)
 

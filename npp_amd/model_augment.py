@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import _ops as K
 from . import genotypes as gt
 from ._ops import BnSide
-from .operations import OPS, FactorizedReduce, ReLUConvBN, fused_sum, fused_sum_stages, _use_batch_stats  # noqa: F401
+from .operations import OPS, FactorizedReduce, ReLUConvBN, fused_sum, fused_sum_apply, fused_sum_pending, fused_sum_stages, _use_batch_stats  # noqa: F401
 from .operations import *  # noqa: F401,F403  (reference does `from models.operations import *`)
 
 BN_MOMENTUM = 0.1
@@ -122,10 +122,25 @@ class _DagCell(nn.Module):
         if concat is not None and all(i >= first for i in concat) and len(set(concat)) == len(concat):
             cb = K.ConcatBuffer(len(concat))
             pos = {idx: k for k, idx in enumerate(concat)}
-        for i in range(self._steps):
-            i1, i2 = self._indices[2 * i], self._indices[2 * i + 1]
-            out = cb.slot(pos[len(states)]) if cb is not None and len(states) in pos else None
-            states.append(fused_sum(self._ops[2 * i], states[i1], self._ops[2 * i + 1], states[i2], out=out))
+        if K.SYNC_WAVES and K.helper_stream_for_edge() is None:
+            # SyncBatchNorm: every node whose inputs exist runs its two edges BEFORE any of their BatchNorms is applied, so the
+            # statistics of the whole wave (nodes 0 + 1, then 2 + 3 in the encoder's cells) travel in ONE exchange
+            i = 0
+            while i < self._steps:
+                have, j, wave = len(states), i, []
+                while j < self._steps and self._indices[2 * j] < have and self._indices[2 * j + 1] < have:
+                    wave.append(fused_sum_pending(self._ops[2 * j], states[self._indices[2 * j]],
+                                                  self._ops[2 * j + 1], states[self._indices[2 * j + 1]]))
+                    j += 1
+                for a, b in wave:
+                    out = cb.slot(pos[len(states)]) if cb is not None and len(states) in pos else None
+                    states.append(fused_sum_apply(a, b, out=out))
+                i = j
+        else:
+            for i in range(self._steps):
+                i1, i2 = self._indices[2 * i], self._indices[2 * i + 1]
+                out = cb.slot(pos[len(states)]) if cb is not None and len(states) in pos else None
+                states.append(fused_sum(self._ops[2 * i], states[i1], self._ops[2 * i + 1], states[i2], out=out))
         if concat is None:
             return states
         parts = [states[i] for i in concat]
@@ -538,6 +553,7 @@ class Network(nn.Module):
         K.P2P_DIRECT = bool(sync_bn and x.is_cuda and os.environ.get("NPP_SYNCBN_STREAMS") is None
                             and os.environ.get("NPP_P2P_DIRECT", "1") != "0" and self._p2p_ready())
         mode = _stream_mode() if (not sync_bn or K.P2P_DIRECT) else _syncbn_stream_mode()
+        K.SYNC_WAVES = bool(sync_bn and os.environ.get("NPP_SYNC_WAVES", "1") != "0")
         two = mode >= 2
         K._helper_uses = 0
         K._hub_offload = None

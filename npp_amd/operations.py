@@ -80,6 +80,20 @@ def fused_sum(op1, h1, op2, h2, out=None):
     return K.bn_add(a, b, relu=False, training=training, out=out)
 
 
+def fused_sum_pending(op1, h1, op2, h2):
+    """First half of fused_sum (current stream only): the two edges' raw outputs + statistics."""
+    a, b = pending_of(op1, h1), pending_of(op2, h2)
+    if a.bn is None and b.bn is not None:
+        a, b = b, a
+    return a, b
+
+
+def fused_sum_apply(a, b, out=None):
+    """Second half of fused_sum: both BatchNorm applies folded into the add."""
+    training = a.bn.training if a.bn is not None else False
+    return K.bn_add(a, b, relu=False, training=training, out=out)
+
+
 def fused_sum_stages(op1, h1, op2, h2, result, out=None):
     """fused_sum as a generator pausing after each edge (see model_augment.Cell.stages); result: 1-element list."""
     a = pending_of(op1, h1)
