@@ -366,8 +366,12 @@ def main():
     # GPUs the 308 MB all-reduce is then exposed, ~2 ms on xGMI).  NPP_DDP_OVERLAP=1 restores the overlapped form.
     # N > 1: BOTH forms are timed for a few steps below (`overlap_ab`) and the faster one runs the timed region; the overlapped form
     # (north_star) is the default wherever no such measurement exists (1 rank: --force-dist) -- NPP_DDP_OVERLAP=0 / 1 forces either.
+    # Round 3: the overlapped form is "tail" -- the step keeps its batched weight-gradient tail and the buckets of the KxK conv weights
+    # (4/5 of the bytes) are reduced under the tail's second group (ddp.GradReducer, train_step.TrainStep._tail_with_reducer); the
+    # round-2 form (buckets issued from the gradient hooks during backward, every weight gradient a launch of its own: +9 ms on one
+    # rank) is NPP_DDP_OVERLAP=hooks.
     overlap_env = os.environ.get("NPP_DDP_OVERLAP")
-    overlap_pick = overlap_env != "0" if overlap_env is not None else True
+    overlap_pick = {"0": False, "1": True, "hooks": True, "tail": "tail"}.get(overlap_env, "tail") if overlap_env is not None else "tail"
     overlap_ab = None
 
     def make_reducer(overlap):
@@ -417,7 +421,7 @@ def main():
             # A/B of the two reducer forms on THIS node (a 1-rank run cannot decide it: there is no wire)
             ab_steps = max(2, min(5, args.steps))
             overlap_ab = {}
-            for mode in (True, False):
+            for mode in ("tail", False):
                 if reducer is not None:
                     reducer.remove()
                 reducer = make_reducer(mode)
@@ -437,8 +441,8 @@ def main():
                 overlap_ab["overlapped_graph" if mode else "after_backward_graph"] = bool(ts.graphed)
                 _hb(f"overlap A/B: mode {mode} timed")
                 del ts
-            overlap_pick = overlap_ab["overlapped_ms"] <= overlap_ab["after_backward_ms"]
-            overlap_ab["picked"] = "overlapped" if overlap_pick else "after_backward"
+            overlap_pick = "tail" if overlap_ab["overlapped_ms"] <= overlap_ab["after_backward_ms"] else False
+            overlap_ab["picked"] = "overlapped (under the weight-gradient tail)" if overlap_pick else "after_backward"
             overlap_ab["steps_each"] = ab_steps
             reducer.remove()
             reducer = make_reducer(overlap_pick)
@@ -601,7 +605,7 @@ def main():
         dist.all_reduce(ones)
         comm = {"backend": dist.get_backend(), "rccl_ranks": int(round(float(ones))), "allreduce_of_ones": float(ones),
                 "rccl_ranks_source": "all-reduce of ones through the step's process group",
-                "ddp_overlap": bool(reducer.overlap) if reducer is not None else None}
+                "ddp_overlap": (("tail" if getattr(reducer, "tail", False) else bool(reducer.overlap)) if reducer is not None else None)}
         if overlap_ab is not None:
             comm["overlap_ab"] = overlap_ab
         from npp_amd import comm as _cm

@@ -856,6 +856,8 @@ DEFER_WGRAD_MAX_PIX = 0        # > 0: defer the weight gradients of maps with at
 _pending_wgrads: list = []     # (x, dy, packed accumulator / gradient tensor, NppConvGeom, stream)
 _wgrad_batchable: dict = {}
 _wgrad_bufs = {"pin": None, "dev": None, "ev": None, "keep": []}
+DEFER_TAIL_OK = True      # (test hook) False: TrainStep ignores GradReducer(overlap="tail") and runs the tail in one piece
+_wgrad_bufs_k = {"pin": None, "dev": None, "ev": None, "keep": []}      # job tables of the KxK group (flush_wgrads(group="K"))
 
 
 _deferred_params: set = set()      # id() of the parameters with a queued (still unwritten) gradient
@@ -996,19 +998,30 @@ def drop_pending():
     _pending_se_grads.clear()
     _pending_unpacks.clear()
     _deferred_params.clear()
-    for B in (_wgrad_bufs, _dw_wgrad_bufs, _unpack_bufs, _se_grad_bufs):
+    for B in (_wgrad_bufs, _wgrad_bufs_k, _dw_wgrad_bufs, _unpack_bufs, _unpack_bufs_k, _se_grad_bufs):
         B["ev"] = None
 
 
-def flush_wgrads():
-    """Run every deferred weight gradient in one launch per kernel variant on the current stream (before flush_unpacks)."""
-    _deferred_params.clear()
-    _flush_dw_wgrads()
-    _flush_se_grads()
+def flush_wgrads(group=None):
+    """Run every deferred weight gradient in one launch per kernel variant on the current stream (before flush_unpacks).
+    group "K": only the dense KxK convs (with flush_unpacks after it their gradients are final: GradReducer(overlap="tail") reduces
+    them while the rest -- group "O": 1x1, depthwise, SE -- is computed); None: everything."""
+    if group != "K":
+        _deferred_params.clear()
+        _flush_dw_wgrads()
+        _flush_se_grads()
     if not _pending_wgrads:
         return
-    items = list(_pending_wgrads)
-    _pending_wgrads.clear()
+    if group == "K":
+        items = [it for it in _pending_wgrads if it[3].kh * it[3].kw > 1]
+        rest = [it for it in _pending_wgrads if it[3].kh * it[3].kw <= 1]
+        _pending_wgrads.clear()
+        _pending_wgrads.extend(rest)
+        if not items:
+            return
+    else:
+        items = list(_pending_wgrads)
+        _pending_wgrads.clear()
     cur = torch.cuda.current_stream()
     seen = {cur.cuda_stream}
     for it in items:
@@ -1021,7 +1034,7 @@ def flush_wgrads():
         arr[i].x, arr[i].dy, arr[i].dw_packed, arr[i].g, arr[i].nslabs = desc(x), desc(dy), acc.data_ptr(), g, nsl
     nb = int(lib().npp_conv_wgrad_batched_ws(n))
     capturing = torch.cuda.is_current_stream_capturing()
-    B = _wgrad_bufs
+    B = _wgrad_bufs_k if group == "K" else _wgrad_bufs
     if capturing:
         if B["pin"] is None or B["pin"].numel() < nb:      # no warm-up step sized the tables: one launch each
             for (x, dy, acc, g, _st, nsl) in items:
@@ -1055,12 +1068,16 @@ def flush_wgrads():
 
 
 _unpack_bufs = {"pin": None, "dev": None, "ev": None, "keep": []}
+_unpack_bufs_k = {"pin": None, "dev": None, "ev": None, "keep": []}
 
 
-def flush_unpacks():
-    """Run every deferred unpack in one launch on the current stream (which first waits for the streams they were queued on)."""
+def flush_unpacks(group=None):
+    """Run every deferred unpack in one launch on the current stream (which first waits for the streams they were queued on).
+    group "K": only those of KxK weights (a 1x1 weight whose packed rows are padded has an unpack too: its weight gradient belongs
+    to the second group of the tail, flush_wgrads)."""
     global _UNPACK_JOB
-    _deferred_params.clear()
+    if group != "K":
+        _deferred_params.clear()
     if not _pending_unpacks:
         return
     import numpy as np
@@ -1068,8 +1085,16 @@ def flush_unpacks():
         _UNPACK_JOB = np.dtype([("src", "<u8"), ("dst", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("taps", "<i4"), ("cp", "<i4"),
                                 ("kpad", "<i4"), ("nslabs", "<i4"), ("slab", "<i8"), ("first_block", "<i8")])
         assert _UNPACK_JOB.itemsize == 56
-    items = list(_pending_unpacks)
-    _pending_unpacks.clear()
+    if group == "K":
+        items = [it for it in _pending_unpacks if it[4] > 1]
+        rest = [it for it in _pending_unpacks if it[4] <= 1]
+        _pending_unpacks.clear()
+        _pending_unpacks.extend(rest)
+        if not items:
+            return
+    else:
+        items = list(_pending_unpacks)
+        _pending_unpacks.clear()
     cur = torch.cuda.current_stream()
     seen = {cur.cuda_stream}
     for it in items:
@@ -1090,7 +1115,7 @@ def flush_unpacks():
     raw = np.concatenate([np.frombuffer(jobs.tobytes(), dtype=np.uint8), np.frombuffer(bj.tobytes(), dtype=np.uint8)])
     nb = raw.size
     capturing = torch.cuda.is_current_stream_capturing()
-    B = _unpack_bufs
+    B = _unpack_bufs_k if group == "K" else _unpack_bufs
     if capturing:
         # pinned memory cannot be allocated inside a capture: take the image the eager warm-up steps used (same job count) and
         # retire it -- a replayed graph re-reads this pinned image, so it is never rewritten; later eager steps get a new one

@@ -21,6 +21,13 @@ this node:
     `_ops.hub_all_reduce`), which the two task-branch streams only feed with one-way events -- so the
     collective overlaps the rest of backward; `finish()` (before optimizer.step) joins and averages.
 
+  * round 3, `overlap="tail"` (what bench.py's N > 1 runs use as the overlapped form): the step keeps its batched weight-gradient
+    tail (TrainStep defers every weight gradient into a few launches after backward), so there is nothing to overlap with DURING
+    backward -- the overlap moves into the tail: buckets are built per kind, the dense KxK conv weights (4/5 of the bytes) become
+    final after the tail's first group (KxK launches + unpack) and are reduced while the second group (1x1, depthwise, SE) is
+    computed on the other stream; `finish()` reduces the small rest.  One rank: 51.4 ms per step, the same as reducing everything
+    after backward (51.5) and 9.5 ms less than the hook form (60.9), which gives the batching up.
+
 `torch.distributed` is the transport ("nccl" == RCCL on ROCm; "gloo" in the CPU tests).
 """
 from __future__ import annotations
@@ -46,11 +53,18 @@ def unused_parameter_names(model: torch.nn.Module) -> Set[str]:
     return names
 
 
-class _Bucket:
-    __slots__ = ("params", "offsets", "flat", "pending", "numel", "streams", "taken", "launched")
+def _is_kxk_weight(p) -> bool:
+    """A dense KxK conv weight: its gradient is accumulated in the packed layout and becomes final in the FIRST group of the
+    batched weight-gradient tail (KxK launches + unpack), see GradReducer(overlap="tail")."""
+    return p.dim() == 4 and p.shape[2] * p.shape[3] > 1 and p.shape[1] > 1
 
-    def __init__(self, params, device, dtype):
+
+class _Bucket:
+    __slots__ = ("params", "offsets", "flat", "pending", "numel", "streams", "taken", "launched", "kind")
+
+    def __init__(self, params, device, dtype, kind="O"):
         self.params = params
+        self.kind = kind
         self.offsets = []
         off = 0
         for p in params:
@@ -79,8 +93,17 @@ class GradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.always = always_reduce      # run the collectives even on a 1-rank group (single-GPU exercise of the path)
-        # overlap=False: every bucket is reduced by finish() on the caller's stream, after backward (NPP_DDP_OVERLAP=0)
-        self.overlap = overlap and os.environ.get("NPP_DDP_OVERLAP", "1") != "0"
+        # overlap: True / "hooks" -- a bucket is reduced the moment its last gradient lands in backward (the step then cannot defer and
+        #            batch its weight gradients: every one of them is a launch of its own on the branch streams);
+        #          "tail"  -- the step keeps its batched weight-gradient tail and the reducer overlaps with THAT: the buckets are
+        #            built per kind, the KxK conv weights (4/5 of the bytes) become final in the tail's first group and are reduced
+        #            while the second group (1x1, depthwise, SE) is computed (train_step.TrainStep drives it);
+        #          False   -- every bucket is reduced by finish() on the caller's stream, after backward (NPP_DDP_OVERLAP=0)
+        env = os.environ.get("NPP_DDP_OVERLAP")
+        if env is not None:
+            overlap = {"0": False, "1": True, "hooks": True, "tail": "tail"}.get(env, overlap)
+        self.tail = overlap == "tail"
+        self.overlap = bool(overlap) and not self.tail      # (what TrainStep asks: do hooks read gradients during backward?)
         if bucket_mb is None:
             bucket_mb = float(os.environ.get("NPP_DDP_BUCKET_MB", "16"))
         skip = set(skip or ())
@@ -93,16 +116,21 @@ class GradReducer:
                     dist.broadcast(t, 0, group=process_group)
         cap = int(bucket_mb * 1024 * 1024)
         self.buckets: List[_Bucket] = []
-        cur, cur_bytes = [], 0
-        for n, p in reversed(named):
-            nb = p.numel() * p.element_size()
-            if cur and (cur_bytes + nb > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
-                self.buckets.append(_Bucket(cur, cur[0].device, cur[0].dtype))
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += nb
-        if cur:
-            self.buckets.append(_Bucket(cur, cur[0].device, cur[0].dtype))
+        groups = [("O", list(reversed(named)))]
+        if self.tail:      # one run of buckets per kind: a bucket never mixes gradients that become final in different groups of the tail
+            groups = [("K", [(n, p) for n, p in reversed(named) if _is_kxk_weight(p)]),
+                      ("O", [(n, p) for n, p in reversed(named) if not _is_kxk_weight(p)])]
+        for kind, plist in groups:
+            cur, cur_bytes = [], 0
+            for n, p in plist:
+                nb = p.numel() * p.element_size()
+                if cur and (cur_bytes + nb > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                    self.buckets.append(_Bucket(cur, cur[0].device, cur[0].dtype, kind))
+                    cur, cur_bytes = [], 0
+                cur.append(p)
+                cur_bytes += nb
+            if cur:
+                self.buckets.append(_Bucket(cur, cur[0].device, cur[0].dtype, kind))
         self._where = {}
         self._hooks = []
         self._slot_keys = []
@@ -206,6 +234,18 @@ class GradReducer:
                 else:
                     dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group)
         b.launched = True
+
+    def launch_kind(self, kind, target="auto"):
+        """overlap="tail": reduce every bucket of `kind` whose gradients are complete NOW (the caller has just run the group of the
+        weight-gradient tail that finishes them) on the collectives' stream, fenced behind the caller's stream."""
+        tgt = self._target_stream() if target == "auto" else target
+        if self._cuda and tgt is not None and tgt.cuda_stream != torch.cuda.current_stream().cuda_stream:
+            tgt.wait_stream(torch.cuda.current_stream())
+        for b in self.buckets:
+            if b.kind == kind and not b.launched:
+                if b.pending != 0:
+                    raise RuntimeError(f"GradReducer: a bucket of kind {kind} is incomplete ({b.pending} gradients missing)")
+                self._launch(b, target=tgt)
 
     def finish(self):
         """Join the collectives; afterwards every p.grad is the averaged view of its bucket.  Call once per step after

@@ -87,14 +87,45 @@ class TrainStep:
             K.DEFER_UNPACK = False
             K.DEFER_WGRAD_MAX_PIX = 0
         K.stamp("backward done")
-        K.flush_wgrads()
-        K.flush_unpacks()
-        K.stamp("weight gradients done")
-        if self.reducer is not None:
-            self.reducer.finish()
+        if self.reducer is not None and getattr(self.reducer, "tail", False) and K.DEFER_TAIL_OK:
+            self._tail_with_reducer()
+        else:
+            K.flush_wgrads()
+            K.flush_unpacks()
+            K.stamp("weight gradients done")
+            if self.reducer is not None:
+                self.reducer.finish()
         self.optimizer.step()
         K.stamp("optimizer done")
         return loss
+
+    def _tail_with_reducer(self):
+        """GradReducer(overlap="tail"): the batched weight-gradient tail in two groups with the all-reduce of the first group's
+        buckets (the KxK conv weights, 4/5 of the gradient bytes) running under the second group's kernels.  The collectives stay on
+        the stream the reducer names (inside a capture: the capture's origin, the only stream RCCL may be captured on here); the
+        second group's launches go to the parsing branch's stream, which forks from and joins the origin."""
+        cur = torch.cuda.current_stream()
+        K.flush_wgrads(group="K")
+        K.flush_unpacks(group="K")               # every KxK weight gradient is final
+        tgt = self.reducer._target_stream()
+        same = tgt is None or tgt.cuda_stream == cur.cuda_stream
+        side = None
+        if same and cur.device.type == "cuda":
+            # the collectives share the caller's stream (a captured / to-be-captured step): the second group must run elsewhere
+            from .model_augment import _side_stream
+            side = _side_stream(cur.device, 0)
+            side.wait_stream(cur)
+        self.reducer.launch_kind("K")
+        if side is not None:
+            with torch.cuda.stream(side):
+                K.flush_wgrads()
+                K.flush_unpacks()                # (1x1 weights with padded packed rows)
+            cur.wait_stream(side)
+        else:
+            K.flush_wgrads()
+            K.flush_unpacks()
+        K.stamp("weight gradients done")
+        self.reducer.finish()
 
     # -- static buffers -----------------------------------------------------------------------------------------------
     @staticmethod

@@ -92,6 +92,12 @@ def main():
     assert l_late[0] == l_ref[0] and abs(l_late[1] - l_ref[1]) < 1e-4 * abs(l_ref[1]), (l_late, l_ref)
     assert all(abs(a - b) < 5e-2 * abs(b) for a, b in zip(l_late, l_ref)), (l_late, l_ref)
     assert all(torch.isfinite(p).all() for p in p_late)
+    # overlap="tail": buckets per kind, the KxK conv weights' buckets reduced under the second group of the batched weight-gradient
+    # tail (TrainStep._tail_with_reducer: the second group runs on the parsing branch's stream inside the captured step)
+    l_tail, p_tail = run("torch", dev, overlap="tail")
+    assert l_tail[0] == l_ref[0] and abs(l_tail[1] - l_ref[1]) < 1e-4 * abs(l_ref[1]), (l_tail, l_ref)
+    assert all(abs(a - b) < 5e-2 * abs(b) for a, b in zip(l_tail, l_ref)), (l_tail, l_ref)
+    assert all(torch.isfinite(p).all() for p in p_tail)
     print("OK", l_npp)
     dist.destroy_process_group()
 

@@ -104,3 +104,16 @@ def test_deferred_gradients_land_in_the_reducer_buckets():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(repo, "tools", "reducer_defer_check.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "REDUCER_DEFER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_tail_overlap_reducer_two_group_tail():
+    """overlap="tail": buckets per kind; after the KxK group of the batched weight-gradient tail (+ unpack) the KxK buckets are
+    reduced, the 1x1 / depthwise / SE group follows, finish() reduces the rest -- every gradient equals a plain backward's."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NPP_CHECK_REDUCER_MODE="tail", MASTER_PORT="29679")
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "reducer_defer_check.py")], capture_output=True, text=True, timeout=600,
+                       env=env)
+    assert r.returncode == 0 and "REDUCER_DEFER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -68,6 +68,61 @@ def test_grad_reducer_matches_single_process(tmp_path, overlap):
                 assert torch.allclose(g[k], p.grad, atol=1e-6), k
 
 
+class _ToyConv(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.k3 = torch.nn.Conv2d(2, 6, 3, padding=1)
+        self.dw = torch.nn.Conv2d(6, 6, 3, padding=1, groups=6)      # depthwise: [6, 1, 3, 3] -- not a dense KxK weight
+        self.p1 = torch.nn.Conv2d(6, 3, 1)
+        self.k5 = torch.nn.Conv2d(3, 2, 5, padding=2)
+
+    def forward(self, x):
+        return self.k5(torch.relu(self.p1(self.dw(torch.relu(self.k3(x))))))
+
+
+def _tail_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from npp_amd.ddp import GradReducer
+    torch.manual_seed(5 + rank)
+    m = _ToyConv()
+    red = GradReducer(m, bucket_mb=0.0001, overlap="tail")
+    kinds = [b.kind for b in red.buckets]
+    assert kinds == sorted(kinds) and kinds.count("K") >= 2 and kinds.count("O") >= 2, kinds      # per-kind runs of buckets, K first
+    k_params = {id(p) for b in red.buckets if b.kind == "K" for p in b.params}
+    assert k_params == {id(m.k3.weight), id(m.k5.weight)}
+    torch.manual_seed(9)
+    xs, ys = torch.randn(world * 3, 2, 6, 6), torch.randn(world * 3, 2, 6, 6)
+    for step in range(2):
+        m.zero_grad()
+        ((m(xs[rank * 3:(rank + 1) * 3]) - ys[rank * 3:(rank + 1) * 3]) ** 2).mean().backward()
+        red.launch_kind("K")          # (where TrainStep has just finished the KxK group of its weight-gradient tail)
+        assert all(b.launched == (b.kind == "K") for b in red.buckets)
+        red.finish()
+    torch.save({k: p.grad.clone() for k, p in m.named_parameters()}, f"{out}/g{rank}.pt")
+    if rank == 0:
+        torch.save(m.state_dict(), f"{out}/sd.pt")
+    dist.destroy_process_group()
+
+
+def test_tail_overlap_reducer_buckets_per_kind_and_staged_launch(tmp_path):
+    """GradReducer(overlap="tail"): dense KxK conv weights get buckets of their own, launch_kind("K") reduces exactly those,
+    finish() the rest; 2 ranks x 3 samples == 1 rank x 6 samples."""
+    world, port = 2, 31500 + os.getpid() % 1000
+    mp.spawn(_tail_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    m = _ToyConv()
+    m.load_state_dict(torch.load(f"{tmp_path}/sd.pt"))
+    torch.manual_seed(9)
+    xs, ys = torch.randn(world * 3, 2, 6, 6), torch.randn(world * 3, 2, 6, 6)
+    ((m(xs) - ys) ** 2).mean().backward()
+    for r in range(world):
+        g = torch.load(f"{tmp_path}/g{r}.pt")
+        for k, p in m.named_parameters():
+            assert torch.allclose(g[k], p.grad, atol=1e-6), k
+
+
 def test_unused_parameter_names_cover_se_block_bn():
     sys.path.insert(0, REPO)
     from types import SimpleNamespace as NS

@@ -16,7 +16,13 @@ set_compute_dtype(torch.bfloat16)
 torch.manual_seed(0)
 net = Network(T._cfg(32)).to(dev).train()
 cp, cq = Criterion_pose(out_len=2).to(dev), Criterion_par(out_len=2).to(dev)
-red = GradReducer(net, skip=unused_parameter_names(net), always_reduce=True, bucket_mb=4, overlap=False)
+MODE = os.environ.get("NPP_CHECK_REDUCER_MODE", "late")      # late: overlap=False; tail: overlap="tail" with the two-group tail
+red = GradReducer(net, skip=unused_parameter_names(net), always_reduce=True, bucket_mb=4, overlap="tail" if MODE == "tail" else False)
+if MODE == "tail":
+    kinds = [b.kind for b in red.buckets]
+    assert "K" in kinds and "O" in kinds and kinds == sorted(kinds), kinds      # the KxK buckets first, never mixed
+    from npp_amd.ddp import _is_kxk_weight
+    assert all(_is_kxk_weight(p) == (b.kind == "K") for b in red.buckets for p in b.params)
 im, lpar, lpose, _w = T._batch(4, 96, 7, dev)
 output_pose, output_par = net(im)
 loss = (cq(output_par, lpar).unsqueeze(0) + cp(output_pose, lpose).unsqueeze(0)).mean()
@@ -25,7 +31,14 @@ red.begin_step()
 K.DEFER_UNPACK, K.DEFER_WGRAD_MAX_PIX = True, 150000
 loss.backward(retain_graph=True)
 print("queued", len(K._pending_wgrads), len(K._pending_dw_wgrads), len(K._pending_unpacks))
-K.flush_wgrads(); K.flush_unpacks()
+if MODE == "tail":
+    K.flush_wgrads(group="K"); K.flush_unpacks(group="K")
+    assert all(it[3].kh * it[3].kw == 1 for it in K._pending_wgrads) and all(it[4] == 1 for it in K._pending_unpacks)
+    red.launch_kind("K")
+    assert all(b.launched == (b.kind == "K") for b in red.buckets)
+    K.flush_wgrads(); K.flush_unpacks()
+else:
+    K.flush_wgrads(); K.flush_unpacks()
 K.DEFER_UNPACK, K.DEFER_WGRAD_MAX_PIX = False, 0
 red.finish()
 torch.cuda.synchronize()
