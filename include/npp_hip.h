@@ -515,7 +515,8 @@ int npp_p2p_exchange(double* stats, int64_t count, int channel, void* stream);
 /* slab form: segment k = sum over its nrep replica slabs [nrep][len] doubles; the LOCAL sums are also written as floats
  * (elements [0, split) to out0 and out0_dup, [split, 2 split) to out1, the rest to out2; NULL = not wanted); the world's sum
  * replaces replica 0, and with zero_rest the other replicas are zeroed (a consumer that sums NPP_STAT_REPLICAS slabs).
- * nseg <= 4, sum of len <= capacity.  Replaces npp_bn_bwd_sum + npp_syncbn_exchange of a SyncBatchNorm backward. */
+ * nseg <= 8, sum of len <= capacity.  Replaces npp_bn_bwd_sum + npp_syncbn_exchange of a SyncBatchNorm backward, and carries the
+ * forward statistics of a wave of BatchNorms at 1/NPP_STAT_REPLICAS of the bytes. */
 typedef struct NppP2pSeg {
   double* slabs; int64_t len; int64_t split; float* out0; float* out0_dup; float* out1; float* out2; int32_t nrep; int32_t zero_rest;
 } NppP2pSeg;

@@ -575,12 +575,38 @@ class _SyncStatsPool(_ZeroPool):
                 for sd in self.waiting:
                     sd.sync_event = back
             else:
-                hub_all_reduce(rng, self.group)
+                if not self._flush_slabs():
+                    hub_all_reduce(rng, self.group)
             self.flushes += 1
             for sd in self.waiting:
                 sd.synced_ws = self.ws
             self.waiting = []
         self.synced_off = self.off
+
+    def _flush_slabs(self) -> bool:
+        """Peer-to-peer transport: every waiting BatchNorm's [R][2C] replica slabs are collapsed by the exchange kernel itself and
+        only the 2C sums travel (1/16 of the bytes of exchanging the pool's range as it is); the world's sums land in replica 0, the
+        other replicas are zeroed -- the consumers (npp_affine_add_fin, npp_bn_finalize) sum all replicas as before."""
+        if not P2P_DIRECT or _hub_stream is None:
+            return False
+        from . import comm
+        if not comm.p2p_active():
+            return False
+        segs = []
+        for sd in self.waiting:
+            st = sd.stats
+            if st is None or not st.is_cuda or st.dtype != torch.float64 or not st.is_contiguous() or st.numel() % R != 0:
+                return False
+            ln = st.numel() // R
+            segs.append((st, ln, R, ln, (None, None, None, None), True))
+        if not segs or not comm.p2p_can(sum(s[1] for s in segs[:8]), self.group):
+            return False
+        for lo in range(0, len(segs), 8):
+            if not comm.p2p_exchange_slabs(segs[lo:lo + 8], self.group):
+                if lo == 0:
+                    return False
+                raise RuntimeError("peer-to-peer exchange refused a later piece of a flush it had started")
+        return True
 
     def drop(self):
         self.buf, self.off, self.synced_off, self.waiting = None, 0, 0, []

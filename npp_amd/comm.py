@@ -188,9 +188,9 @@ def p2p_exchange(stats, group=None):
 
 
 def p2p_exchange_slabs(segs, group=None):
-    """segs: up to 4 tuples (slabs f64 [nrep * len], len, nrep, split, (out0, out0_dup, out1, out2) f32 tensors | None, zero_rest)
+    """segs: up to 8 tuples (slabs f64 [nrep * len], len, nrep, split, (out0, out0_dup, out1, out2) f32 tensors | None, zero_rest)
     -- see npp_p2p_exchange_slabs.  False if the mailboxes cannot take it (the caller then reduces and exchanges separately)."""
-    if not p2p_active() or group is not _p2p["group"] or not 1 <= len(segs) <= 4 or sum(s[1] for s in segs) > _p2p["cap"]:
+    if not p2p_active() or group is not _p2p["group"] or not 1 <= len(segs) <= 8 or sum(s[1] for s in segs) > _p2p["cap"]:
         return False
     ch, st = _p2p_channel()
     if ch is None:

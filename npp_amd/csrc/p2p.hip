@@ -71,7 +71,7 @@ void map_channels(void* base, int r, long cap, int world, int nchan, bool local)
   }
 }
 
-constexpr int P2P_MAX_SEGS = 4;
+constexpr int P2P_MAX_SEGS = 8;
 struct ExArgs {
   double* peer_data[P2P_MAX_WORLD];
   unsigned long long* peer_flag[P2P_MAX_WORLD];
