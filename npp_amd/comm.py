@@ -122,6 +122,8 @@ def enable_p2p(group=None, channels=4):
             _lib.check(lib.npp_p2p_open(b"".join(b for _, b in everyone)), "npp_p2p_open")
         except Exception:      # noqa: BLE001
             ok = 0
+    if ok:
+        ok = 1 if _p2p_selftest(lib, rank, world) else 0
     flag = torch.tensor([ok], dtype=torch.int32)
     backend = dist.get_backend(group)
     if backend == "nccl":
@@ -131,8 +133,28 @@ def enable_p2p(group=None, channels=4):
         lib.npp_p2p_close()
         return False
     # nobody starts exchanging before everybody has mapped everybody (the all-reduce above is that barrier)
-    _p2p.update(world=world, group=group, cap=int(lib.npp_p2p_capacity()), channels={}, nchan=int(lib.npp_p2p_channels()), count=0)
+    _p2p.update(world=world, group=group, cap=int(lib.npp_p2p_capacity()), channels={torch.cuda.current_stream().cuda_stream: 0},
+                nchan=int(lib.npp_p2p_channels()), count=0)      # (channel 0 = the stream the self-test ran on)
     return True
+
+
+def _p2p_selftest(lib, rank, world) -> bool:
+    """Four exchanges of known, changing vectors through channel 0 right after the mailboxes are mapped: every rank must read the
+    exact sums every time (a stale read of a peer's earlier vector, a missing peer or a mapping to the wrong memory shows here, before
+    any statistic depends on it).  The caller's MIN all-reduce makes every rank drop the transport if one of them fails."""
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        n = 4099
+        idx = torch.arange(n, dtype=torch.float64, device="cuda")
+        for it in range(4):
+            v = idx * (it + 1) + float((rank + 1) * (it + 3))
+            _lib.check(lib.npp_p2p_exchange(v.data_ptr(), n, 0, st), "npp_p2p_exchange")
+            want = idx * ((it + 1) * world) + float((it + 3) * world * (world + 1) // 2)
+            if not torch.equal(v, want):
+                return False
+        return int(lib.npp_p2p_status()) == 0
+    except Exception:      # noqa: BLE001
+        return False
 
 
 _p2p_tried: set = set()

@@ -190,23 +190,28 @@ extern "C" int npp_p2p_alloc(int rank, int world, int64_t cap_doubles, int chann
               world, (long)cap_doubles, channels);
   NPP_REQUIRE(g.local == nullptr, NPP_E_UNSUPPORTED, "npp_p2p_alloc: mailboxes exist already (npp_p2p_close first)");
   const size_t bytes = total_bytes(cap_doubles, world, channels);
+  // peer writes must not sit in a cache: uncached, else fine-grained, else plain device memory -- the first kind of allocation the
+  // runtime both grants AND exports (hipIpcGetMemHandle)
   void* p = nullptr;
-  // peer writes must not sit in a cache: uncached, else fine-grained, else plain device memory (one-GPU rehearsal)
-  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
-  if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained); }
-  if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, bytes); }
-  if (e != hipSuccess) { (void)hipGetLastError(); npp_set_error("npp_p2p_alloc: %s", hipGetErrorString(e)); return NPP_E_HIP; }
+  hipIpcMemHandle_t h;
+  hipError_t e = hipErrorUnknown;
+  for (int kind = 0; kind < 3 && p == nullptr; ++kind) {
+    void* q = nullptr;
+    e = kind == 0 ? hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached)
+        : kind == 1 ? hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) : hipMalloc(&q, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); continue; }
+    e = hipIpcGetMemHandle(&h, q);
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(q); continue; }
+    p = q;
+  }
+  if (p == nullptr) {
+    npp_set_error("npp_p2p_alloc: no exportable allocation (%s)", hipGetErrorString(e));
+    return NPP_E_UNSUPPORTED;
+  }
   if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
     (void)hipGetLastError(); (void)hipFree(p);
     npp_set_error("npp_p2p_alloc: cannot zero the mailboxes");
     return NPP_E_HIP;
-  }
-  hipIpcMemHandle_t h;
-  e = hipIpcGetMemHandle(&h, p);
-  if (e != hipSuccess) {
-    (void)hipGetLastError(); (void)hipFree(p);
-    npp_set_error("npp_p2p_alloc: hipIpcGetMemHandle: %s", hipGetErrorString(e));
-    return NPP_E_UNSUPPORTED;
   }
   memcpy(handle_out, &h, sizeof(h));
   g.local = p; g.bytes = bytes; g.rank = rank; g.world = world; g.cap = cap_doubles; g.nchan = channels;
