@@ -339,6 +339,7 @@ GRAPH_TOPOLOGY = False  # set by train_step.TrainStep while its steps are (to be
 _hub_stream = None     # the stream Network.forward was called on while it runs its branches on two streams
 
 
+BN_PAIRS = os.environ.get("NPP_BN_PAIRS", "1") != "0"      # under SYNC_WAVES: pairs of fused BatchNorm adds as one autograd node (_BnAddPair)
 SYNC_WAVES = False     # set by Network.forward under SyncBatchNorm: cells issue the edges of every ready node before any BatchNorm apply
 P2P_DIRECT = False     # set by Network.forward: the SyncBatchNorm exchanges go through the peer-to-peer mailboxes (csrc/p2p.hip), each on
                        # the stream of the kernels that need it -- no hub stream, no lockstep (an exchange is an ordinary kernel)
@@ -1683,6 +1684,19 @@ class _BnAdd(Function):
 
     @staticmethod
     def backward(ctx, dout):
+        gen = _BnAdd._backward_gen(ctx, dout)
+        try:
+            req = next(gen)
+            while True:      # the body asks for a peer-to-peer slab exchange (SyncBatchNorm): do it here, alone
+                from . import comm
+                req = gen.send(comm.p2p_exchange_slabs(req[0], req[1]))
+        except StopIteration as done:
+            return done.value
+
+    @staticmethod
+    def _backward_gen(ctx, dout):
+        """backward() as a generator: it yields (segments, group) where it needs a peer-to-peer slab exchange and is sent whether
+        the exchange took place -- _BnAddPair.backward runs two of these side by side and merges their exchanges into one."""
         a, b, yrelu, mia, mib, ssa, ssb = ctx.saved_tensors
         bna, bnb, batch_a, batch_b, cnt_a, cnt_b, has_b = ctx.sides
         dout = to_nhwc(dout)
@@ -1771,7 +1785,7 @@ class _BnAdd(Function):
                         dxb, dgb_[2] if ni[4] else None, dgb_[3] if ni[5] else None, None, None, None, None, None, None)
             if fused and sync2 is not None:
                 # local sums -> dbeta (both sides), dgamma_a, dgamma_b; world sums -> replica 0, the other replicas zeroed
-                ok2 = _comm2.p2p_exchange_slabs([(sums, 3 * c, R, c, (dgb_[1], dgb_[3], dgb_[0], dgb_[2]), True)], sync2)
+                ok2 = yield ([(sums, 3 * c, R, c, (dgb_[1], dgb_[3], dgb_[0], dgb_[2]), True)], sync2)
                 assert ok2, "peer-to-peer exchange refused a vector it had accepted the size of"
                 dxa = new_nhwc(*a.shape, a.dtype, dev)
                 dxb = new_nhwc(*b.shape, b.dtype, dev)
@@ -1845,7 +1859,9 @@ class _BnAdd(Function):
                        _grad_buf(bn_i.bias if need_b_ else None, c, dout.device))
                 segs.append((red[i][0], 2 * c, red[i][1], c, (dgl[1], None, dgl[0], None), False))      # [0, c): sum dout -> dbeta; [c, 2c): -> dgamma
                 local[i] = dgl
-            if len({id(g_) for _, g_, _ in sync}) == 1 and _comm.p2p_exchange_slabs(segs, sync[0][1]):
+            one_group = len({id(g_) for _, g_, _ in sync}) == 1
+            took = (yield (segs, sync[0][1])) if one_group else False
+            if took:
                 for i, grp, c in sync:
                     red[i] = (red[i][0], 1)
                 sync = []
@@ -1921,6 +1937,105 @@ class _BnAdd(Function):
         if has_b:
             dbx, dgb, dbb = outs[1]
         return da, dga, dba, dbx, dgb, dbb, None, None, None, None, None, None
+
+
+class _SubCtx:
+    """What _BnAdd.forward / _backward_gen need of an autograd context, for one half of a _BnAddPair."""
+
+    def __init__(self, saved=None, relu=False, sides=None, needs=None):
+        self.saved_tensors = saved
+        self.relu, self.sides, self.needs_input_grad = relu, sides, needs
+
+    def save_for_backward(self, *ts):
+        self.saved_tensors = ts
+
+
+class _BnAddPair(Function):
+    """Two independent fused BatchNorm adds (the two preprocess outputs of a cell, two nodes of one wave) as ONE autograd node, so
+    that under SyncBatchNorm their backward passes share one statistics exchange: both reduces run, ONE peer-to-peer slab exchange
+    carries both sets of sums, both applies follow.  Tensor args: (a, gamma_a, beta_a, b, gamma_b, beta_b) x 2, then the two
+    (sa, sb, relu, training, out, mk) tuples of _BnAdd.forward."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        tens, metas = args[:12], args[12:14]
+        subs, outs, saved = [], [], []
+        for k in range(2):
+            sub = _SubCtx()
+            outs.append(_BnAdd.forward(sub, *tens[6 * k:6 * k + 6], *metas[k]))
+            subs.append((sub.relu, sub.sides))
+            saved += list(sub.saved_tensors)
+        assert len(saved) == 14
+        ctx.save_for_backward(*saved)
+        ctx.subs = subs
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d0, d1):
+        saved = ctx.saved_tensors
+        needs = ctx.needs_input_grad
+        gens, reqs, res = [], [None, None], [None, None]
+        for k, d in enumerate((d0, d1)):
+            sub = _SubCtx(saved[7 * k:7 * k + 7], ctx.subs[k][0], ctx.subs[k][1], needs[6 * k:6 * k + 6])
+            gens.append(_BnAdd._backward_gen(sub, d))
+        for k in range(2):
+            try:
+                reqs[k] = next(gens[k])
+            except StopIteration as done:
+                res[k] = done.value
+        from . import comm
+        answers = [None, None]
+        if reqs[0] is not None and reqs[1] is not None and reqs[0][1] is reqs[1][1] and len(reqs[0][0]) + len(reqs[1][0]) <= 8:
+            took = comm.p2p_exchange_slabs(list(reqs[0][0]) + list(reqs[1][0]), reqs[0][1])      # both halves in ONE exchange
+            if took:
+                answers = [True, True]
+        for k in range(2):
+            if reqs[k] is None:
+                continue
+            ans = answers[k] if answers[k] is not None else comm.p2p_exchange_slabs(reqs[k][0], reqs[k][1])
+            try:
+                gens[k].send(ans)
+                raise RuntimeError("_BnAdd._backward_gen asked for a second exchange")
+            except StopIteration as done:
+                res[k] = done.value
+        return tuple(res[0][:6]) + tuple(res[1][:6]) + (None, None)
+
+
+def _bn_add_prepare(sa, sb, relu, training, out):
+    """The argument preparation of bn_add: (tensor args, meta) for _BnAdd / _BnAddPair."""
+    a = to_nhwc(sa.x if sa.private else take(sa.x))
+    sa.x = a
+    ga = sa.bn.weight if sa.bn is not None else None
+    ba = sa.bn.bias if sa.bn is not None else None
+    b = gb = bb = None
+    if sb is not None:
+        b = to_nhwc(sb.x if sb.private else take(sb.x))
+        sb.x = b
+        if b.dtype != a.dtype:
+            b = cast(b, a.dtype)
+            sb.x = b
+        if sb.bn is not None:
+            gb, bb = sb.bn.weight, sb.bn.bias
+    holder = mk = None
+    if out is not None:
+        y = out(a)
+        if y is not None:
+            holder = [y]
+            mk = out.mask_spec() if hasattr(out, "mask_spec") else None
+    if mk is None and holder is None and _mask_wanted(a):
+        n, c, h, w = a.shape
+        mk = (torch.empty(n * h * w * (c // 8), dtype=torch.uint8, device=a.device), 0, c // 8)
+    return (a, ga, ba, b, gb, bb), (sa, sb, bool(relu), bool(training), holder, mk)
+
+
+def bn_add_pair(spec0, spec1):
+    """bn_add(*spec0), bn_add(*spec1) (spec = (sa, sb, relu, training, out)) as one autograd node, see _BnAddPair."""
+    t0, m0 = _bn_add_prepare(*spec0)
+    t1, m1 = _bn_add_prepare(*spec1)
+    r0, r1 = _BnAddPair.apply(*t0, *t1, m0, m1)
+    _register_mask(r0, m0[5])
+    _register_mask(r1, m1[5])
+    return r0, r1
 
 
 def bn_add(sa: BnSide, sb: Optional[BnSide] = None, relu: bool = False, training: bool = True, out=None):

@@ -132,9 +132,20 @@ class _DagCell(nn.Module):
                     wave.append(fused_sum_pending(self._ops[2 * j], states[self._indices[2 * j]],
                                                   self._ops[2 * j + 1], states[self._indices[2 * j + 1]]))
                     j += 1
-                for a, b in wave:
-                    out = cb.slot(pos[len(states)]) if cb is not None and len(states) in pos else None
-                    states.append(fused_sum_apply(a, b, out=out))
+                k = 0
+                while k < len(wave):
+                    slot = lambda n_: cb.slot(pos[n_]) if cb is not None and n_ in pos else None      # noqa: E731
+                    if K.BN_PAIRS and k + 1 < len(wave):      # two nodes of the wave as one autograd node (one backward exchange)
+                        (a0, b0), (a1, b1) = wave[k], wave[k + 1]
+                        t0 = a0.bn.training if a0.bn is not None else False
+                        t1 = a1.bn.training if a1.bn is not None else False
+                        n0 = len(states)
+                        states.extend(K.bn_add_pair((a0, b0, False, t0, slot(n0)), (a1, b1, False, t1, slot(n0 + 1))))
+                        k += 2
+                    else:
+                        a, b = wave[k]
+                        states.append(fused_sum_apply(a, b, out=slot(len(states))))
+                        k += 1
                 i = j
         else:
             for i in range(self._steps):
@@ -152,6 +163,9 @@ def _preprocess_pair(pre0, s0, pre1, s1):
     then travel in ONE exchange (they sit back to back in the stream's statistics pool and the first apply flushes both)."""
     from .operations import pending_of
     a, b = pending_of(pre0, s0), pending_of(pre1, s1)
+    if K.SYNC_WAVES and K.BN_PAIRS and a.bn is not None and b.bn is not None:
+        # ... and as ONE autograd node, so that their backward passes share one exchange as well (_ops._BnAddPair)
+        return list(K.bn_add_pair((a, None, False, a.bn.training, None), (b, None, False, b.bn.training, None)))
     outs = []
     for side in (a, b):
         outs.append(K.bn_add(side, None, relu=False, training=side.bn.training) if side.bn is not None else side.x)
