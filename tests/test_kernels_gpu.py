@@ -658,6 +658,42 @@ def test_batchnorm_backward_in_one_launch_equals_the_two_launch_form(C, H, W, N,
         assert rel_err(one[3].numpy(), br.grad.numpy()) < 1e-2
 
 
+def test_pair_of_fused_batchnorm_adds_equals_two_single_ones():
+    """K.bn_add_pair (_ops._BnAddPair: two fused BatchNorm adds as ONE autograd node -- under SyncBatchNorm their backward passes
+    share one statistics exchange) against two K.bn_add calls on the same inputs, local statistics: outputs bit-equal, every
+    gradient equal up to the order of the f64 atomics; one operand of the second add is a plain tensor."""
+    from npp_amd import _ops as K
+    import copy
+    dev = _dev()
+    C, H, N = 64, 24, 4
+    xs = [(_rand((N, C, H, H), 80 + i) * (1 + 0.2 * i)).bfloat16().float() for i in range(4)]
+    gs = [_rand((N, C, H, H), 90 + i).bfloat16().float() for i in range(2)]
+    bns0 = [torch.nn.BatchNorm2d(C) for _ in range(3)]
+    for i, bn in enumerate(bns0):
+        with torch.no_grad():
+            bn.weight.copy_(_rand((C,), 95 + i) * 0.2 + 1)
+            bn.bias.copy_(_rand((C,), 98 + i) * 0.1)
+
+    def run(pair):
+        bns = [copy.deepcopy(bn).to(dev) for bn in bns0]
+        t = [_to_dev(x, torch.bfloat16).detach().requires_grad_(True) for x in xs]
+        s0 = (K.BnSide(t[0], bns[0]), K.BnSide(t[1], bns[1]), False, True, None)
+        s1 = (K.BnSide(t[2], bns[2]), K.BnSide(t[3]), False, True, None)      # BN(x2) + x3 (plain)
+        if pair:
+            y0, y1 = K.bn_add_pair(s0, s1)
+        else:
+            y0, y1 = K.bn_add(*s0), K.bn_add(*s1)
+        torch.autograd.backward([y0, y1], [_to_dev(gs[0], torch.bfloat16), _to_dev(gs[1], torch.bfloat16)])
+        torch.cuda.synchronize()
+        return ([y0.detach().float().cpu(), y1.detach().float().cpu()] + [x.grad.float().cpu() for x in t]
+                + [p.grad.cpu() for bn in bns for p in (bn.weight, bn.bias)] + [bn.running_var.cpu() for bn in bns])
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for i, (u, v) in enumerate(zip(a[2:], b[2:])):
+        assert rel_err(u.numpy(), v.numpy()) < 1e-4, i
+
+
 def test_batchnorm_one_launch_kernels_of_two_streams_do_not_wait_on_each_other():
     """Two streams run the grid-barrier kernel at the same time, 200 launches each (every stream has barrier counters of its own):
     all blocks of both launches must be resident together (csrc/bn_one.hip's register / grid-size bound) -- a deadlock would hang
