@@ -1951,54 +1951,69 @@ class _SubCtx:
 
 
 class _BnAddPair(Function):
-    """Two independent fused BatchNorm adds (the two preprocess outputs of a cell, two nodes of one wave) as ONE autograd node, so
-    that under SyncBatchNorm their backward passes share one statistics exchange: both reduces run, ONE peer-to-peer slab exchange
-    carries both sets of sums, both applies follow.  Tensor args: (a, gamma_a, beta_a, b, gamma_b, beta_b) x 2, then the two
-    (sa, sb, relu, training, out, mk) tuples of _BnAdd.forward."""
+    """n independent fused BatchNorm adds (the two preprocess outputs of a cell, two nodes of one wave, the candidates of a mixed
+    edge) as ONE autograd node, so that under SyncBatchNorm their backward passes share one statistics exchange: every reduce runs,
+    ONE peer-to-peer slab exchange carries all the sums (up to 8 segments per launch), the applies follow.
+    Args: n, then (a, gamma_a, beta_a, b, gamma_b, beta_b) x n, then the n (sa, sb, relu, training, out, mk) tuples of _BnAdd.forward."""
 
     @staticmethod
-    def forward(ctx, *args):
-        tens, metas = args[:12], args[12:14]
+    def forward(ctx, n, *args):
+        tens, metas = args[:6 * n], args[6 * n:7 * n]
         subs, outs, saved = [], [], []
-        for k in range(2):
+        for k in range(n):
             sub = _SubCtx()
             outs.append(_BnAdd.forward(sub, *tens[6 * k:6 * k + 6], *metas[k]))
             subs.append((sub.relu, sub.sides))
             saved += list(sub.saved_tensors)
-        assert len(saved) == 14
+        assert len(saved) == 7 * n
         ctx.save_for_backward(*saved)
-        ctx.subs = subs
+        ctx.subs, ctx.n = subs, n
         return tuple(outs)
 
     @staticmethod
-    def backward(ctx, d0, d1):
+    def backward(ctx, *douts):
+        n = ctx.n
         saved = ctx.saved_tensors
-        needs = ctx.needs_input_grad
-        gens, reqs, res = [], [None, None], [None, None]
-        for k, d in enumerate((d0, d1)):
+        needs = ctx.needs_input_grad[1:]
+        gens, reqs, res = [], [None] * n, [None] * n
+        for k, d in enumerate(douts):
             sub = _SubCtx(saved[7 * k:7 * k + 7], ctx.subs[k][0], ctx.subs[k][1], needs[6 * k:6 * k + 6])
             gens.append(_BnAdd._backward_gen(sub, d))
-        for k in range(2):
+        for k in range(n):      # every reduce first ...
             try:
                 reqs[k] = next(gens[k])
             except StopIteration as done:
                 res[k] = done.value
         from . import comm
-        answers = [None, None]
-        if reqs[0] is not None and reqs[1] is not None and reqs[0][1] is reqs[1][1] and len(reqs[0][0]) + len(reqs[1][0]) <= 8:
-            took = comm.p2p_exchange_slabs(list(reqs[0][0]) + list(reqs[1][0]), reqs[0][1])      # both halves in ONE exchange
-            if took:
-                answers = [True, True]
-        for k in range(2):
-            if reqs[k] is None:
-                continue
-            ans = answers[k] if answers[k] is not None else comm.p2p_exchange_slabs(reqs[k][0], reqs[k][1])
+        # ... then the requested exchanges, merged: consecutive requests of one group, at most 8 segments per launch
+        answers = [None] * n
+        asking = [k for k in range(n) if reqs[k] is not None]
+        i = 0
+        while i < len(asking):
+            grp = reqs[asking[i]][1]
+            batch, nseg = [], 0
+            while i < len(asking) and reqs[asking[i]][1] is grp and nseg + len(reqs[asking[i]][0]) <= 8:
+                batch.append(asking[i])
+                nseg += len(reqs[asking[i]][0])
+                i += 1
+            if not batch:      # (a single request of more than 8 segments: leave it to its own call below)
+                batch = [asking[i]]
+                i += 1
+            took = False
+            if len(batch) > 1:
+                took = comm.p2p_exchange_slabs([sg for k in batch for sg in reqs[k][0]], grp)
+            for k in batch:
+                answers[k] = True if took else comm.p2p_exchange_slabs(reqs[k][0], reqs[k][1])
+        for k in asking:         # ... then every apply
             try:
-                gens[k].send(ans)
+                gens[k].send(answers[k])
                 raise RuntimeError("_BnAdd._backward_gen asked for a second exchange")
             except StopIteration as done:
                 res[k] = done.value
-        return tuple(res[0][:6]) + tuple(res[1][:6]) + (None, None)
+        out = (None,)
+        for k in range(n):
+            out += tuple(res[k][:6])
+        return out + (None,) * n
 
 
 def _bn_add_prepare(sa, sb, relu, training, out):
@@ -2028,13 +2043,18 @@ def _bn_add_prepare(sa, sb, relu, training, out):
     return (a, ga, ba, b, gb, bb), (sa, sb, bool(relu), bool(training), holder, mk)
 
 
+def bn_add_multi(specs):
+    """[bn_add(*spec) for spec in specs] (spec = (sa, sb, relu, training, out)) as one autograd node, see _BnAddPair."""
+    prep = [_bn_add_prepare(*sp) for sp in specs]
+    tens = [t for ts, _m in prep for t in ts]
+    res = _BnAddPair.apply(len(prep), *tens, *[m for _ts, m in prep])
+    for r, (_ts, m) in zip(res, prep):
+        _register_mask(r, m[5])
+    return list(res)
+
+
 def bn_add_pair(spec0, spec1):
-    """bn_add(*spec0), bn_add(*spec1) (spec = (sa, sb, relu, training, out)) as one autograd node, see _BnAddPair."""
-    t0, m0 = _bn_add_prepare(*spec0)
-    t1, m1 = _bn_add_prepare(*spec1)
-    r0, r1 = _BnAddPair.apply(*t0, *t1, m0, m1)
-    _register_mask(r0, m0[5])
-    _register_mask(r1, m1[5])
+    r0, r1 = bn_add_multi([spec0, spec1])
     return r0, r1
 
 
@@ -3020,13 +3040,22 @@ def mix_bn_sum(w, sides, training: bool):
                 ok = False
     if ok:
         return _MixBnSum.apply(w, sides, *xs)
-    ys = []
-    for sd, x in zip(sides, xs):
+    ys = [None] * len(sides)
+    bn_idx = [i for i, sd in enumerate(sides) if sd.bn is not None]
+    for i, (sd, x) in enumerate(zip(sides, xs)):
         if sd.bn is None:
-            ys.append(x)
+            ys[i] = x
         else:
             sd.private = True
-            ys.append(bn_add(sd, None, relu=False, training=sd.bn.training))
+    if BN_PAIRS and len(bn_idx) >= 2 and any(_sync_group(sides[i].bn)[0] is not None for i in bn_idx):
+        # SyncBatchNorm: the candidates' BatchNorms as ONE autograd node -- their backward passes share one statistics exchange
+        # instead of one each (the forward statistics already travel together: every candidate was pending before the first apply)
+        outs = bn_add_multi([(sides[i], None, False, sides[i].bn.training, None) for i in bn_idx])
+        for i, y in zip(bn_idx, outs):
+            ys[i] = y
+    else:
+        for i in bn_idx:
+            ys[i] = bn_add(sides[i], None, relu=False, training=sides[i].bn.training)
     return _WeightedSum.apply(w, *[take(y) for y in ys])
 
 
