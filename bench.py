@@ -609,8 +609,9 @@ def main():
         if overlap_ab is not None:
             comm["overlap_ab"] = overlap_ab
         from npp_amd import comm as _cm
-        comm["syncbn_transport"] = ("p2p mailboxes (csrc/p2p.hip), %d exchanges issued by the host, peers %s" %
-                                    (_cm._p2p["count"], "all present" if _cm.p2p_ok() else "MISSING (a poll timed out: numbers void)")
+        comm["syncbn_transport"] = ("p2p mailboxes (csrc/p2p.hip, %s memory), %d exchanges issued by the host, peers %s" %
+                                    (("uncached", "fine-grained", "plain device")[max(0, min(2, int(_lib.lib().npp_p2p_alloc_kind())))],
+                                     _cm._p2p["count"], "all present" if _cm.p2p_ok() else "MISSING (a poll timed out: numbers void)")
                                     ) if _cm.p2p_active() else "all-reduce through the process group"
         comm["syncbn_streams"] = "two branch streams, exchanges in place" if K.P2P_DIRECT else "hub stream + lockstep issue"
     exposed = None

@@ -510,6 +510,7 @@ int npp_p2p_handle_bytes(void);
 int npp_p2p_alloc(int rank, int world, int64_t cap_doubles, int channels, void* handle_out);
 int npp_p2p_open(const void* handles);
 int64_t npp_p2p_capacity(void);
+int npp_p2p_alloc_kind(void);   /* 0 uncached (no cache maintenance around the flags), 1 fine-grained, 2 plain device memory; -1 none */
 int npp_p2p_channels(void);
 int npp_p2p_exchange(double* stats, int64_t count, int channel, void* stream);
 /* slab form: segment k = sum over its nrep replica slabs [nrep][len] doubles; the LOCAL sums are also written as floats
