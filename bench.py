@@ -66,6 +66,7 @@ def cpu_baseline(size, budget_s=25.0):
         t0 = time.time()
         one()
         dt = time.time() - t0
+        _hb(f"cpu baseline: {nt} threads tried")      # (the supervisor of the 1-GPU run watches for progress)
         sweep[nt] = round(dt, 2)
         if best_dt is None or dt < best_dt:
             best_t, best_dt = nt, dt
@@ -82,6 +83,7 @@ def cpu_baseline(size, budget_s=25.0):
         dt = time.time() - t0
         if it >= 1:
             times.append(dt)
+        _hb("cpu baseline: iteration done")
         it += 1
         if (time.time() - t_start > budget_s and len(times) >= 2) or len(times) >= 6:
             break
@@ -563,6 +565,7 @@ def main():
         except Exception as e:      # noqa: BLE001
             traffic_db, traffic_note = {}, f"{traffic_file}: {e}"
         for fam, label in KERNELS.items():
+            _hb(f"roofline leg: {fam}")
             # one eager step per measurement, the faster of `prof_steps` measurements is reported: a single stalled launch (seen once:
             # conv_g8 at 3x its usual time in one of two steps, rocprofv3 of the same run showing nothing) must not set the figure
             best = None
