@@ -290,6 +290,13 @@ typedef struct NppMixSide {
 } NppMixSide;
 int npp_mix_bn_fwd(const NppMixSide* sides, int k, const float* w, NppTensor* out, void* stream);
 int npp_mix_bn_bwd(const NppMixSide* sides, int k, const float* w, const NppTensor* dout, double* sums, float* dw, void* stream);
+/* SyncBatchNorm forms (search_lip_sync.py:268-271): npp_mix_bn_fwd_n takes the sample count behind `stats` (statistics summed over the
+ * ranks); the backward's two launches on their own -- between them the caller sums `sums` over the ranks (npp_p2p_exchange_slabs with
+ * zero_rest, out_all = local_sums) -- with the world's count and this rank's own sums [(k + 1)][C] for dw (not reduced). */
+int npp_mix_bn_fwd_n(const NppMixSide* sides, int k, const float* w, NppTensor* out, double count, void* stream);
+int npp_mix_bn_bwd_reduce(const NppMixSide* sides, int k, const NppTensor* dout, double* sums, void* stream);
+int npp_mix_bn_bwd_apply(const NppMixSide* sides, int k, const float* w, const NppTensor* dout, double* sums, double count,
+                         const float* local_sums, float* dw, void* stream);
 /* eval-mode / plain affine backward: dy = dout * scale * (out>0) */
 int npp_scale_mask(const NppTensor* dout, const float* scale /*[C] or NULL*/, const NppTensor* relu_out,
                    NppTensor* dx, void* stream);
@@ -520,6 +527,7 @@ int npp_p2p_exchange(double* stats, int64_t count, int channel, void* stream);
  * forward statistics of a wave of BatchNorms at 1/NPP_STAT_REPLICAS of the bytes. */
 typedef struct NppP2pSeg {
   double* slabs; int64_t len; int64_t split; float* out0; float* out0_dup; float* out1; float* out2; int32_t nrep; int32_t zero_rest;
+  float* out_all;      /* NULL, or len floats: every local sum of the segment */
 } NppP2pSeg;
 int npp_p2p_exchange_slabs(const NppP2pSeg* segs, int nseg, int channel, void* stream);
 int npp_p2p_status(void);

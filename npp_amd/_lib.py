@@ -24,7 +24,7 @@ FAM = {"none": 0, "conv_igemm": 1, "conv_wgrad": 2, "dwconv": 3, "bn": 4, "eltwi
 
 class NppP2pSeg(C.Structure):
     _fields_ = [("slabs", C.c_void_p), ("len", C.c_int64), ("split", C.c_int64), ("out0", C.c_void_p), ("out0_dup", C.c_void_p),
-                ("out1", C.c_void_p), ("out2", C.c_void_p), ("nrep", C.c_int32), ("zero_rest", C.c_int32)]
+                ("out1", C.c_void_p), ("out2", C.c_void_p), ("nrep", C.c_int32), ("zero_rest", C.c_int32), ("out_all", C.c_void_p)]
 
 
 class NppTensor(C.Structure):
@@ -118,6 +118,9 @@ _SIGS = {
     "npp_bn_fused_ok": [_T],
     "npp_mix_bn_fwd": [_P, C.c_int, _P, _T, _P],
     "npp_mix_bn_bwd": [_P, C.c_int, _P, _T, _P, _P, _P],
+    "npp_mix_bn_fwd_n": [_P, C.c_int, _P, _T, C.c_double, _P],
+    "npp_mix_bn_bwd_reduce": [_P, C.c_int, _T, _P, _P],
+    "npp_mix_bn_bwd_apply": [_P, C.c_int, _P, _T, _P, C.c_double, _P, _P, _P],
     "npp_affine_add_fin": [_T, _T, _P, _T, _P, C.c_int, _P, C.c_int64, _P],
     "npp_bn_bwd_reduce_acc": [_T, _T, _T, _P, _P, C.c_int, _P],
     "npp_bn_bwd_reduce2_acc": [_T, _T, _T, _T, _P, _P, _P, C.c_int, _P],

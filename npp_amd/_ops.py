@@ -2955,6 +2955,16 @@ def _mix_side_struct(x, mi, bn, stats, track, dx=None):
     return sd
 
 
+MIX_SYNC = os.environ.get("NPP_MIX_SYNC", "1") != "0"      # the fused mixed edge under SyncBatchNorm (peer-to-peer transport only)
+
+
+def _mix_sync_group(bn, training: bool):
+    """The process group of a SyncBatchNorm candidate that normalises with (exchanged) batch statistics, else None."""
+    if bn is None or not (training or bn.running_mean is None):
+        return None
+    return _sync_group(bn)[0]
+
+
 class _MixBnSum(Function):
     """out = sum_k w[k] * f_k(x_k), f_k = BatchNorm(affine=False, local batch statistics) of sides[k].bn or the identity."""
 
@@ -2967,6 +2977,15 @@ class _MixBnSum(Function):
         c = xs[0].shape[1]
         arr = (L.NppMixSide * k)()
         mis, keep = [], []
+        # SyncBatchNorm candidates: their statistics (all pending in this stream's pool) travel in ONE exchange, the kernel then
+        # finalizes with the world's sample count
+        sync_grp, sync_ws = None, 1
+        for sd in sides:
+            if sd.bn is not None and _sync_group(sd.bn)[0] is not None:
+                sync_grp, sync_ws = _sync_group(sd.bn)
+                break
+        if sync_grp is not None:
+            _presync_stats(sides, True)
         for i, (sd, x) in enumerate(zip(sides, xs)):
             mi = None
             if sd.bn is not None:
@@ -2979,7 +2998,12 @@ class _MixBnSum(Function):
             else:
                 arr[i] = _mix_side_struct(x, None, None, None, False)
             mis.append(mi)
-        check(lib().npp_mix_bn_fwd(C.cast(arr, C.c_void_p), k, wf.data_ptr(), _byref(out), stream_ptr()), "npp_mix_bn_fwd")
+        count = float(xs[0].shape[0] * xs[0].shape[2] * xs[0].shape[3]) * sync_ws
+        if sync_grp is not None:
+            check(lib().npp_mix_bn_fwd_n(C.cast(arr, C.c_void_p), k, wf.data_ptr(), _byref(out), count, stream_ptr()), "npp_mix_bn_fwd_n")
+        else:
+            check(lib().npp_mix_bn_fwd(C.cast(arr, C.c_void_p), k, wf.data_ptr(), _byref(out), stream_ptr()), "npp_mix_bn_fwd")
+        ctx.sync = (sync_grp, count) if sync_grp is not None else None
         ctx.k = k
         ctx.bn_side = [m is not None for m in mis]
         ctx.wdtype = w.dtype
@@ -3010,8 +3034,20 @@ class _MixBnSum(Function):
             arr[i] = sd
         sums = zeros_f64(R * (k + 1) * c, dout.device)
         gw = torch.empty(8, dtype=torch.float32, device=dout.device)
-        check(lib().npp_mix_bn_bwd(C.cast(arr, C.c_void_p), k, wf.data_ptr(), _byref(dout), sums.data_ptr(), gw.data_ptr(), stream_ptr()),
-              "npp_mix_bn_bwd")
+        if ctx.sync is not None:
+            # reduce -> the sums of the ranks through the mailboxes (replica 0 = the world's sums, the others zeroed; this rank's own
+            # sums kept as floats for dw, which is NOT reduced) -> apply with the world's count
+            from . import comm
+            grp, count = ctx.sync
+            check(lib().npp_mix_bn_bwd_reduce(C.cast(arr, C.c_void_p), k, _byref(dout), sums.data_ptr(), stream_ptr()), "npp_mix_bn_bwd_reduce")
+            local = torch.empty((k + 1) * c, dtype=torch.float32, device=dout.device)
+            if not comm.p2p_exchange_slabs([(sums, (k + 1) * c, R, c, (None, None, None, None, local), True)], grp):
+                raise RuntimeError("_MixBnSum: the peer-to-peer exchange refused the sums it had accepted the size of in forward")
+            check(lib().npp_mix_bn_bwd_apply(C.cast(arr, C.c_void_p), k, wf.data_ptr(), _byref(dout), sums.data_ptr(), count, local.data_ptr(),
+                                             gw.data_ptr(), stream_ptr()), "npp_mix_bn_bwd_apply")
+        else:
+            check(lib().npp_mix_bn_bwd(C.cast(arr, C.c_void_p), k, wf.data_ptr(), _byref(dout), sums.data_ptr(), gw.data_ptr(), stream_ptr()),
+                  "npp_mix_bn_bwd")
         g = None
         if need[0]:
             g = gw[:k] if ctx.wdtype == torch.float32 else gw[:k].to(ctx.wdtype)
@@ -3036,8 +3072,20 @@ def mix_bn_sum(w, sides, training: bool):
             if x.shape != x0.shape or x.dtype != x0.dtype or not _fused_layout_ok(x):
                 ok = False
             bn = sd.bn
-            if bn is not None and not (_local_batch_bn(bn, training) and training and bn.weight is None and bn.bias is None):
+            if bn is not None and not (training and bn.weight is None and bn.bias is None
+                                       and (_local_batch_bn(bn, training) or _mix_sync_group(bn, training) is not None)):
                 ok = False
+        if ok:
+            # SyncBatchNorm sides: all of one group, statistics through the peer-to-peer mailboxes (the sums of the backward pass
+            # travel as one segment of (k + 1) * C values)
+            grps = {id(_mix_sync_group(sd.bn, training)) for sd in sides if sd.bn is not None and _sync_group(sd.bn)[0] is not None}
+            if len(grps) > 1:
+                ok = False
+            elif grps:
+                from . import comm
+                ok = P2P_DIRECT and MIX_SYNC and comm.p2p_can((len(sides) + 1) * x0.shape[1],
+                                                               next(_sync_group(sd.bn)[0] for sd in sides
+                                                                    if sd.bn is not None and _sync_group(sd.bn)[0] is not None))
     if ok:
         return _MixBnSum.apply(w, sides, *xs)
     ys = [None] * len(sides)

@@ -221,7 +221,8 @@ def p2p_exchange_slabs(segs, group=None):
     for k, (slabs, ln, nrep, split, outs, zero_rest) in enumerate(segs):
         assert slabs.is_cuda and slabs.dtype == torch.float64 and slabs.is_contiguous() and slabs.numel() >= nrep * ln
         o = [t.data_ptr() if t is not None else None for t in outs]
-        arr[k] = _lib.NppP2pSeg(slabs.data_ptr(), ln, split, o[0], o[1], o[2], o[3], nrep, 1 if zero_rest else 0)
+        arr[k] = _lib.NppP2pSeg(slabs.data_ptr(), ln, split, o[0], o[1], o[2], o[3], nrep, 1 if zero_rest else 0,
+                                o[4] if len(o) > 4 else None)      # (outs[4]: every local sum as floats)
     _lib.check(_lib.lib().npp_p2p_exchange_slabs(arr, len(segs), ch, st), "npp_p2p_exchange_slabs")
     _p2p["count"] += 1
     return True

@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void mix_bn_bwd_reduce_kernel(MixArgs a, const
 template <typename T, int V>
 __global__ __launch_bounds__(256) void mix_bn_bwd_apply_kernel(MixArgs a, const float* __restrict__ w, const T* __restrict__ dout, long ldo,
                                                                const double* __restrict__ sums, float* __restrict__ dw, long npix, int C,
-                                                               ColMap m) {
+                                                               ColMap m, const float* __restrict__ local_sums) {
   extern __shared__ float s_mix[];      // ca [k][C], cb [k][C], cc [k][C], then K doubles (dw accumulators of block 0)
   const int t = threadIdx.x, K = a.k;
   float* s_ca = s_mix;
@@ -1056,7 +1056,9 @@ __global__ __launch_bounds__(256) void mix_bn_bwd_apply_kernel(MixArgs a, const 
     } else {
       s_ca[idx] = wk; s_cb[idx] = 0.f; s_cc[idx] = 0.f;
     }
-    if (blockIdx.x == 0) atomicAdd(&s_dw[side], s1);
+    // dw[k] = sum over the LOCAL pixels of dout * f_k(x_k): from `sums` -- unless those have been exchanged between ranks
+    // (SyncBatchNorm), in which case the caller brings the local sums [(K + 1)][C] as floats
+    if (blockIdx.x == 0) atomicAdd(&s_dw[side], local_sums ? (double)local_sums[(long)(side + 1) * C + c] : s1);
   }
   __syncthreads();
   if (blockIdx.x == 0 && t < K && dw) dw[t] = (float)s_dw[t];
@@ -1556,12 +1558,21 @@ static int mix_fill(const NppMixSide* sides, int k, const NppTensor* ref, bool b
   return NPP_OK;
 }
 
+static int mix_bn_fwd_impl(const NppMixSide* sides, int k, const float* w, NppTensor* out, double count, void* stream);
 extern "C" int npp_mix_bn_fwd(const NppMixSide* sides, int k, const float* w, NppTensor* out, void* stream) {
+  return mix_bn_fwd_impl(sides, k, w, out, 0.0, stream);
+}
+// count > 0: the number of samples behind `stats` (SyncBatchNorm: the statistics were summed over the ranks, count = all their pixels)
+extern "C" int npp_mix_bn_fwd_n(const NppMixSide* sides, int k, const float* w, NppTensor* out, double count, void* stream) {
+  return mix_bn_fwd_impl(sides, k, w, out, count, stream);
+}
+static int mix_bn_fwd_impl(const NppMixSide* sides, int k, const float* w, NppTensor* out, double count, void* stream) {
   NPP_REQUIRE(sides && w && out && out->ptr && k >= 1 && k <= 8, NPP_E_NULL, "npp_mix_bn_fwd: bad arguments");
   if (!fused_ok(out)) return NPP_E_UNSUPPORTED;
   MixArgs a;
   const int rc = mix_fill(sides, k, out, false, a, "npp_mix_bn_fwd");
   if (rc != NPP_OK) return rc;
+  if (count > 0.0) a.count = count;
   ProfScope prof(NPP_FAM_ELTWISE, out->dtype, (hipStream_t)stream, 0, (double)npix(out) * out->c * esize(out->dtype) * (k + 1));
   const size_t lds = (size_t)2 * k * out->c * sizeof(float);
   NPP_DISPATCH_TV(out->dtype, true, {
@@ -1574,25 +1585,46 @@ extern "C" int npp_mix_bn_fwd(const NppMixSide* sides, int k, const float* w, Np
   return npp_check_launch("mix_bn_fwd");
 }
 
-extern "C" int npp_mix_bn_bwd(const NppMixSide* sides, int k, const float* w, const NppTensor* dout, double* sums, float* dw, void* stream) {
-  NPP_REQUIRE(sides && w && dout && dout->ptr && sums && k >= 1 && k <= 8, NPP_E_NULL, "npp_mix_bn_bwd: bad arguments");
+// which = 1: the reduce launch only, 2: the apply launch only, 3: both.  count > 0 / local_sums: see npp_mix_bn_bwd_apply
+static int mix_bn_bwd_impl(const NppMixSide* sides, int k, const float* w, const NppTensor* dout, double* sums, float* dw, int which,
+                           double count, const float* local_sums, void* stream) {
+  NPP_REQUIRE(sides && dout && dout->ptr && sums && k >= 1 && k <= 8 && (w || which == 1), NPP_E_NULL, "npp_mix_bn_bwd: bad arguments");
   if (!fused_ok(dout)) return NPP_E_UNSUPPORTED;
   MixArgs a;
   const int rc = mix_fill(sides, k, dout, true, a, "npp_mix_bn_bwd");
   if (rc != NPP_OK) return rc;
+  if (count > 0.0) a.count = count;
   ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * (3 * k + 2));
   const int C = (int)dout->c;
   NPP_DISPATCH_TV(dout->dtype, true, {
     ColMap m = col_map(C, V);
-    const int nb = reduce_blocks(npix(dout), C, dout->dtype);
-    const size_t lds_r = (size_t)(2 * k * C + 4 * V * 256) * sizeof(float);
-    hipLaunchKernelGGL((mix_bn_bwd_reduce_kernel<T, V>), dim3((unsigned)nb, 1), dim3(256), lds_r, (hipStream_t)stream, a, (const T*)dout->ptr,
-                       (long)dout->ld, (long)npix(dout), C, m, sums);
-    dim3 grid = col_grid_ew(m, npix(dout));
-    if (grid.x > 512) grid.x = 512;
-    const size_t lds_a = (size_t)(3 * k * C + 2) * sizeof(float) + 8 * sizeof(double);
-    hipLaunchKernelGGL((mix_bn_bwd_apply_kernel<T, V>), grid, dim3(256), lds_a, (hipStream_t)stream, a, w, (const T*)dout->ptr,
-                       (long)dout->ld, (const double*)sums, dw, (long)npix(dout), C, m);
+    if (which & 1) {
+      const int nb = reduce_blocks(npix(dout), C, dout->dtype);
+      const size_t lds_r = (size_t)(2 * k * C + 4 * V * 256) * sizeof(float);
+      hipLaunchKernelGGL((mix_bn_bwd_reduce_kernel<T, V>), dim3((unsigned)nb, 1), dim3(256), lds_r, (hipStream_t)stream, a, (const T*)dout->ptr,
+                         (long)dout->ld, (long)npix(dout), C, m, sums);
+    }
+    if (which & 2) {
+      dim3 grid = col_grid_ew(m, npix(dout));
+      if (grid.x > 512) grid.x = 512;
+      const size_t lds_a = (size_t)(3 * k * C + 2) * sizeof(float) + 8 * sizeof(double);
+      hipLaunchKernelGGL((mix_bn_bwd_apply_kernel<T, V>), grid, dim3(256), lds_a, (hipStream_t)stream, a, w, (const T*)dout->ptr,
+                         (long)dout->ld, (const double*)sums, dw, (long)npix(dout), C, m, local_sums);
+    }
   });
   return npp_check_launch("mix_bn_bwd");
+}
+
+extern "C" int npp_mix_bn_bwd(const NppMixSide* sides, int k, const float* w, const NppTensor* dout, double* sums, float* dw, void* stream) {
+  return mix_bn_bwd_impl(sides, k, w, dout, sums, dw, 3, 0.0, nullptr, stream);
+}
+// The two launches of npp_mix_bn_bwd on their own, for SyncBatchNorm: between them the caller sums `sums` over the ranks
+// (npp_p2p_exchange_slabs: replica 0 holds the world's sums afterwards, the other replicas zero).  count: the world's sample count;
+// local_sums [(k + 1)][C] floats: this rank's own sums, from which dw (NOT reduced, like SyncBatchNorm's dgamma) is taken.
+extern "C" int npp_mix_bn_bwd_reduce(const NppMixSide* sides, int k, const NppTensor* dout, double* sums, void* stream) {
+  return mix_bn_bwd_impl(sides, k, nullptr, dout, sums, nullptr, 1, 0.0, nullptr, stream);
+}
+extern "C" int npp_mix_bn_bwd_apply(const NppMixSide* sides, int k, const float* w, const NppTensor* dout, double* sums, double count,
+                                    const float* local_sums, float* dw, void* stream) {
+  return mix_bn_bwd_impl(sides, k, w, dout, sums, dw, 2, count, local_sums, stream);
 }

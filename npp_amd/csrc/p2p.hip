@@ -92,6 +92,7 @@ struct ExArgs {
   long seg_len[P2P_MAX_SEGS], seg_split[P2P_MAX_SEGS];
   int seg_nrep[P2P_MAX_SEGS], seg_zero[P2P_MAX_SEGS];
   float* seg_out[P2P_MAX_SEGS][4];      // [0], [1], [2]: elements [0, split), [split, 2 split), [2 split, ..); [3]: a second copy of [0]
+  float* seg_all[P2P_MAX_SEGS];         // every local sum of the segment (len floats), or NULL
 };
 
 NPP_DEV void seg_of(const ExArgs& a, long i, int& k, long& j) {
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(1024) void p2p_exchange_kernel(ExArgs a) {
         const int part = sp > 0 ? (int)(j / sp) : 0;
         if (part < 3 && a.seg_out[k][part]) a.seg_out[k][part][j - part * sp] = (float)v;
         if (part == 0 && a.seg_out[k][3]) a.seg_out[k][3][j] = (float)v;
+        if (a.seg_all[k]) a.seg_all[k][j] = (float)v;
       }
       for (int p = 0; p < a.world; ++p) __builtin_nontemporal_store(v, a.peer_data[p] + off + i);
     }
@@ -293,7 +295,7 @@ extern "C" int npp_p2p_exchange(double* stats, int64_t count, int channel, void*
   a.light = p2p_light();
   a.nseg = 0;
   for (int k = 0; k < P2P_MAX_SEGS; ++k) {
-    a.seg[k] = nullptr; a.seg_len[k] = 0; a.seg_split[k] = 0; a.seg_nrep[k] = 0; a.seg_zero[k] = 0;
+    a.seg[k] = nullptr; a.seg_len[k] = 0; a.seg_split[k] = 0; a.seg_nrep[k] = 0; a.seg_zero[k] = 0; a.seg_all[k] = nullptr;
     for (int q = 0; q < 4; ++q) a.seg_out[k][q] = nullptr;
   }
   int blocks = (int)((count + 2047) / 2048);      // >= 2 elements per thread before another workgroup pays
@@ -325,9 +327,10 @@ extern "C" int npp_p2p_exchange_slabs(const NppP2pSeg* segs, int nseg, int chann
       NPP_REQUIRE(sg.slabs && sg.len > 0 && sg.nrep >= 1 && sg.split >= 0 && sg.split <= sg.len, NPP_E_SHAPE, "npp_p2p_exchange_slabs: bad segment %d", k);
       a.seg[k] = sg.slabs; a.seg_len[k] = sg.len; a.seg_split[k] = sg.split; a.seg_nrep[k] = sg.nrep; a.seg_zero[k] = sg.zero_rest;
       a.seg_out[k][0] = sg.out0; a.seg_out[k][1] = sg.out1; a.seg_out[k][2] = sg.out2; a.seg_out[k][3] = sg.out0_dup;
+      a.seg_all[k] = sg.out_all;
       total += sg.len;
     } else {
-      a.seg[k] = nullptr; a.seg_len[k] = 0; a.seg_split[k] = 0; a.seg_nrep[k] = 0; a.seg_zero[k] = 0;
+      a.seg[k] = nullptr; a.seg_len[k] = 0; a.seg_split[k] = 0; a.seg_nrep[k] = 0; a.seg_zero[k] = 0; a.seg_all[k] = nullptr;
       for (int q = 0; q < 4; ++q) a.seg_out[k][q] = nullptr;
     }
   }
