@@ -242,6 +242,17 @@ def supervise_rank(tiers=None):
     return abs(last_rc) or 1
 
 
+def _under_profiler() -> bool:
+    """rocprofv3 (or any rocprofiler-sdk tool) is attached to THIS process: its preloaded library has already initialised the GPU
+    here, so the process must launch the kernels itself -- starting the worker as a child would be the fork+exec from a
+    GPU-initialised process that this pool forbids, and the profiled process would no longer be the one that runs them."""
+    env = os.environ
+    if any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER", "ROCTX")) for k in env):
+        return True
+    pre = env.get("LD_PRELOAD", "") + ":" + env.get("HSA_TOOLS_LIB", "")
+    return any(s in pre for s in ("rocprofiler", "rocprof", "roctracer", "librocp"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,6 +290,8 @@ def main():
         # `python bench.py --gpus N` with no launcher: start the N ranks ourselves (one process per GPU, as the reference's
         # launcher does: augment_lip_sync.py:107-113, README.md:14).  This parent has made no GPU call and makes none.
         raise SystemExit(spawn_ranks(args.gpus))
+    if _under_profiler():      # (the supervisor must never spawn from a process the profiler has GPU-initialised)
+        os.environ["NPP_BENCH_SUPERVISE"] = "0"
     if (args.gpus > 1 and not os.environ.get("NPP_BENCH_WORKER") and os.environ.get("NPP_BENCH_SUPERVISE", "1") != "0"):
         raise SystemExit(supervise_rank())      # a rank of an N > 1 run: watchdog parent + worker child (see supervise_rank)
     if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1") or "1") == 1 and not os.environ.get("NPP_BENCH_WORKER")
@@ -529,6 +542,32 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     _hb("timed region done")
+    ranks_identical = None
+    if use_dist:
+        # Rank-order sums of the SyncBatchNorm statistics and averaged gradient buckets must leave every rank with bit-identical
+        # parameters and BatchNorm buffers: a stale or torn statistic of the peer-to-peer exchange, or a rank that used local
+        # statistics, shows up HERE and nowhere else (the loss would look plausible).  Two position-weighted sums of the raw bit
+        # patterns per group, MIN == MAX over the ranks.
+        def bit_sums(tensors):
+            a = torch.zeros(2, dtype=torch.int64, device=dev)
+            for t in tensors:
+                t = t.detach().reshape(-1)
+                if t.numel() == 0:
+                    continue
+                bits = t.view(torch.int32).to(torch.int64) if t.element_size() == 4 else (t.to(torch.int64) if not t.is_floating_point() else t.double().view(torch.int64))
+                w = (torch.arange(bits.numel(), device=dev, dtype=torch.int64) % 1021) + 1
+                a[0] += bits.sum()
+                a[1] += (bits * w).sum()
+            return a
+        mdl = net.module if hasattr(net, "module") else net
+        sums = torch.cat([bit_sums(list(mdl.parameters())), bit_sums(list(mdl.buffers()))])
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same = (lo == hi).tolist()
+        ranks_identical = {"parameters": bool(same[0] and same[1]), "bn_buffers": bool(same[2] and same[3]),
+                           "how": "MIN == MAX over the ranks of two position-weighted sums of the raw bit patterns, after the timed steps"}
+        _hb("rank identity checked")
     if args.launcher and os.environ.get("NPP_LAUNCHER_HOST_TIMES") and rank == 0:
         sys.stderr.write("host enqueue ms per step (timed region): " + ", ".join(
             f"{k} {1e3 * v / max(host['n'], 1):.2f}" for k, v in host.items() if k != "n") + "\n")
@@ -612,9 +651,9 @@ def main():
         if overlap_ab is not None:
             comm["overlap_ab"] = overlap_ab
         from npp_amd import comm as _cm
-        comm["syncbn_transport"] = ("p2p mailboxes (csrc/p2p.hip, %s memory), %d exchanges issued by the host, peers %s" %
+        comm["syncbn_transport"] = ("p2p mailboxes (csrc/p2p.hip, %s memory, %s 8-byte {data|tag} units: the mode that passed the %d-exchange acceptance test), %d exchanges issued by the host, peers %s" %
                                     (("uncached", "fine-grained", "plain device")[max(0, min(2, int(_lib.lib().npp_p2p_alloc_kind())))],
-                                     _cm._p2p["count"], "all present" if _cm.p2p_ok() else "MISSING (a poll timed out: numbers void)")
+                                     _cm._p2p.get("mode"), _cm.SELFTEST_EXCHANGES, _cm._p2p["count"], "all present" if _cm.p2p_ok() else "MISSING (a poll timed out: numbers void)")
                                     ) if _cm.p2p_active() else "all-reduce through the process group"
         comm["syncbn_streams"] = "two branch streams, exchanges in place" if K.P2P_DIRECT else "hub stream + lockstep issue"
     exposed = None
@@ -660,6 +699,7 @@ def main():
     if comm is not None:
         out.update(comm)
         out["exposed_comm_ms"] = exposed      # ms per step; None with --no-comm-ablation
+        out["ranks_bit_identical"] = ranks_identical
     if roof is not None:
         out["roofline"] = roof
         if len(roofs) > 1:
@@ -679,7 +719,8 @@ def main():
             out["rccl_ranks"] = int(_lib.lib().npp_comm_world())
             out["rccl_ranks_source"] = "ncclCommCount of libnpp_hip's RCCL communicator over the step's ranks (npp_comm_world)"
         except Exception as e:      # noqa: BLE001
-            out["rccl_ranks_source"] += f"; ncclCommCount unavailable ({type(e).__name__}: {str(e)[:120]})"
+            out["rccl_ranks_source"] = (out.get("rccl_ranks_source") or str(out.get("comm", {}).get("rccl_ranks_source", ""))) + \
+                f"; ncclCommCount unavailable ({type(e).__name__}: {str(e)[:120]})"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size)
     if use_dist:

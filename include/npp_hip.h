@@ -503,25 +503,30 @@ int npp_comm_destroy(void);
 int npp_allreduce_bucket(void* buf, int64_t count, int dtype, int average, void* stream);
 int npp_syncbn_exchange(double* stats, int64_t count, void* stream);
 /* ---- one-shot peer-to-peer statistics exchange inside one node (csrc/p2p.hip): the same in-place SUM as npp_syncbn_exchange, as
- * ONE small kernel -- every rank stores its vector into a mailbox in each peer's HBM (hipIpc-mapped, xGMI peer stores), raises a
- * flag, polls its own flags and sums in rank order (bit-identical results on all ranks).  Replaces the ~980 latency-bound RCCL
- * all-reduces per step that SyncBatchNorm (augment_lip_sync.py:191, search_lip_sync.py:268-271) costs; RCCL stays the fallback.
+ * ONE small kernel -- every rank stores its vector into a mailbox in each peer's HBM (hipIpc-mapped, xGMI peer stores) as 8-byte
+ * {32 data bits | 32-bit sequence tag} units (RCCL's "LL" wire format: data and tag arrive in one atomic store, so there is no
+ * store -> flag ordering to rely on), polls its own mailbox for the world's units of this exchange and sums in rank order
+ * (bit-identical results on all ranks).  Replaces the latency-bound RCCL all-reduces that SyncBatchNorm (augment_lip_sync.py:191,
+ * search_lip_sync.py:268-271) costs per step; RCCL stays the fallback.
  *   npp_p2p_alloc   allocate this rank's mailboxes (`channels` independent exchange sequences, vectors of <= cap_doubles) and
  *                   write the allocation's IPC handle (npp_p2p_handle_bytes() bytes) to handle_out; the host exchanges the handles
  *                   (any side channel) and passes all of them, in rank order, to
  *   npp_p2p_open    which maps the peers' mailboxes.  NPP_E_UNSUPPORTED when the runtime refuses IPC / peer access.
  *   npp_p2p_exchange  enqueue one exchange of channel `channel` on `stream` (capturable; every rank issues the same sequence per
  *                   channel; exchanges of one channel must be stream-ordered).  NPP_E_UNSUPPORTED for count > capacity.
- *   npp_p2p_status  1 if a poll ever timed out (NPP_P2P_TIMEOUT_MS, default 20 s: a peer died), else 0.  Synchronises. */
+ *   npp_p2p_status  0, or the OR of: 1 a poll timed out (NPP_P2P_TIMEOUT_MS, default 120 s: a peer died), 2 a peer overwrote a slot
+ *                   this rank had not read.  After an error the channel's exchanges return NaN sums (never silently local ones).
+ *                   Synchronises the device (hipDeviceSynchronize) before reading the error words. */
 int npp_p2p_handle_bytes(void);
 int npp_p2p_alloc(int rank, int world, int64_t cap_doubles, int channels, void* handle_out);
 int npp_p2p_open(const void* handles);
 int64_t npp_p2p_capacity(void);
-int npp_p2p_alloc_kind(void);   /* 0 uncached (no cache maintenance around the flags), 1 fine-grained, 2 plain device memory; -1 none */
+int npp_p2p_alloc_kind(void);   /* 0 uncached, 1 fine-grained (relaxed units), 2 plain device memory (release / acquire units); -1 none */
 int npp_p2p_channels(void);
+int npp_p2p_set_mode(int light);   /* 1 relaxed units, 0 release / acquire units, -1 default of the allocation kind; returns the mode in force */
 int npp_p2p_exchange(double* stats, int64_t count, int channel, void* stream);
 /* slab form: segment k = sum over its nrep replica slabs [nrep][len] doubles; the LOCAL sums are also written as floats
- * (elements [0, split) to out0 and out0_dup, [split, 2 split) to out1, the rest to out2; NULL = not wanted); the world's sum
+ * (elements [0, split) to out0 and out0_dup, [split, 2 split) to out1, [2 split, 3 split) to out2 (elements past 3 split have no float copy); NULL = not wanted); the world's sum
  * replaces replica 0, and with zero_rest the other replicas are zeroed (a consumer that sums NPP_STAT_REPLICAS slabs).
  * nseg <= 8, sum of len <= capacity.  Replaces npp_bn_bwd_sum + npp_syncbn_exchange of a SyncBatchNorm backward, and carries the
  * forward statistics of a wave of BatchNorms at 1/NPP_STAT_REPLICAS of the bytes. */

@@ -195,6 +195,7 @@ _SIGS = {
     "npp_p2p_alloc": [C.c_int, C.c_int, C.c_int64, C.c_int, _P],
     "npp_p2p_open": [_P],
     "npp_p2p_channels": [],
+    "npp_p2p_set_mode": [C.c_int],
     "npp_p2p_alloc_kind": [],
     "npp_p2p_exchange": [_P, C.c_int64, C.c_int, _P],
     "npp_p2p_exchange_slabs": [_P, C.c_int, C.c_int, _P],

@@ -600,13 +600,26 @@ class _SyncStatsPool(_ZeroPool):
                 return False
             ln = st.numel() // R
             segs.append((st, ln, R, ln, (None, None, None, None), True))
-        if not segs or not comm.p2p_can(sum(s[1] for s in segs[:8]), self.group):
+        # pieces of at most 8 segments AND at most one mailbox slot of doubles each, all validated before the first one is sent: the
+        # decision "mailboxes or collective" is made up front, never in the middle of a flush
+        if not segs:
             return False
-        for lo in range(0, len(segs), 8):
-            if not comm.p2p_exchange_slabs(segs[lo:lo + 8], self.group):
-                if lo == 0:
-                    return False
-                raise RuntimeError("peer-to-peer exchange refused a later piece of a flush it had started")
+        cap = comm._p2p["cap"]
+        pieces, cur, tot = [], [], 0
+        for sg in segs:
+            if sg[1] > cap:
+                return False
+            if cur and (len(cur) == 8 or tot + sg[1] > cap):
+                pieces.append(cur)
+                cur, tot = [], 0
+            cur.append(sg)
+            tot += sg[1]
+        pieces.append(cur)
+        if not all(comm.p2p_can(sum(s_[1] for s_ in pc), self.group) for pc in pieces):
+            return False
+        for pc in pieces:
+            if not comm.p2p_exchange_slabs(pc, self.group):
+                raise RuntimeError("peer-to-peer exchange refused a piece it had accepted the size of")
         return True
 
     def drop(self):

@@ -78,7 +78,7 @@ def syncbn_exchange(stats):
 
 
 # ---- one-shot peer-to-peer exchange of the SyncBatchNorm statistics (csrc/p2p.hip) ----------------------------------------------
-_p2p = {"world": 0, "group": None, "cap": 0, "channels": {}, "nchan": 0, "count": 0}
+_p2p = {"world": 0, "group": None, "cap": 0, "channels": {}, "nchan": 0, "count": 0, "mode": None}
 P2P_CAP_DOUBLES = int(os.environ.get("NPP_P2P_CAP", str(1 << 15)))      # 256 KiB per (slot, source rank): a merged exchange of a whole
                                                                          # lockstep stage of model_augment at C = 64 is < 100 KiB
 
@@ -122,41 +122,91 @@ def enable_p2p(group=None, channels=4):
             _lib.check(lib.npp_p2p_open(b"".join(b for _, b in everyone)), "npp_p2p_open")
         except Exception:      # noqa: BLE001
             ok = 0
-    if ok:
-        ok = 1 if _p2p_selftest(lib, rank, world) else 0
-    flag = torch.tensor([ok], dtype=torch.int32)
     backend = dist.get_backend(group)
-    if backend == "nccl":
-        flag = flag.cuda()
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) != 1:
+
+    def agree(v):      # MIN over the ranks of one int
+        flag = torch.tensor([v], dtype=torch.int32)
+        if backend == "nccl":
+            flag = flag.cuda()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item())
+
+    # everybody has mapped everybody before anybody exchanges
+    if agree(ok) != 1:
         lib.npp_p2p_close()
         return False
-    # nobody starts exchanging before everybody has mapped everybody (the all-reduce above is that barrier)
+    # acceptance test (2000 back-to-back exchanges, see _p2p_selftest): first with relaxed units, then -- collectively, if ANY rank
+    # read a wrong sum -- with release / acquire units; if that fails too every rank closes its mailboxes (collectives).  A failed
+    # test leaves the channel's sequence numbers in step on all ranks (every rank issues every exchange), so the retry is clean
+    # unless a poll timed out, which kills the channel: then the transport is dropped.
+    mode = None
+    forced = os.environ.get("NPP_P2P_LIGHT")
+    for light in ((1, 0) if forced is None else (1 if forced != "0" else 0,)):
+        lib.npp_p2p_set_mode(light)
+        _selftest_state["broken"] = False
+        passed = agree(1 if _p2p_selftest(lib, rank, world) else 0) == 1
+        if passed:
+            mode = "relaxed" if light else "fenced"
+            break
+        if agree(1 if (int(lib.npp_p2p_status()) == 0 and not _selftest_state["broken"]) else 0) != 1:
+            break
+    if mode is None:
+        lib.npp_p2p_set_mode(-1)
+        lib.npp_p2p_close()
+        return False
+    _p2p["mode"] = mode
     _p2p.update(world=world, group=group, cap=int(lib.npp_p2p_capacity()), channels={torch.cuda.current_stream().cuda_stream: 0},
                 nchan=int(lib.npp_p2p_channels()), count=0)      # (channel 0 = the stream the self-test ran on)
     return True
 
 
-def _p2p_selftest(lib, rank, world) -> bool:
-    """Four exchanges of known, changing vectors through channel 0 right after the mailboxes are mapped: every rank must read the
-    exact sums every time (a stale read of a peer's earlier vector, a missing peer or a mapping to the wrong memory shows here, before
-    any statistic depends on it).  The caller's MIN all-reduce makes every rank drop the transport if one of them fails."""
+SELFTEST_EXCHANGES = int(os.environ.get("NPP_P2P_SELFTEST", "2000"))
+
+
+def _p2p_selftest(lib, rank, world, rounds=None) -> bool:
+    """Acceptance test of the mailboxes, run right after they are mapped and before any statistic depends on them: `rounds`
+    (default 2000) exchanges BACK TO BACK on channel 0 with no host synchronisation in between -- alternating the plain and the slab
+    form, vectors that change every round and differ per rank, lengths that change (so every slot is reused hundreds of times with
+    different contents) -- and only then are all sums compared with the exact expected values (integers below 2^53: f64 sums are
+    exact in any order).  A stale read of an earlier exchange's slot, a torn unit, a missing peer or a mapping to the wrong memory
+    fails here.  The caller's MIN all-reduce makes every rank drop the transport if one of them fails."""
     try:
+        rounds = SELFTEST_EXCHANGES if rounds is None else rounds
         st = torch.cuda.current_stream().cuda_stream
-        n = 4099
-        idx = torch.arange(n, dtype=torch.float64, device="cuda")
-        for it in range(4):
-            v = idx * (it + 1) + float((rank + 1) * (it + 3))
-            _lib.check(lib.npp_p2p_exchange(v.data_ptr(), n, 0, st), "npp_p2p_exchange")
-            want = idx * ((it + 1) * world) + float((it + 3) * world * (world + 1) // 2)
-            if not torch.equal(v, want):
-                return False
+        n, R = 1031, 16
+        dev = torch.device("cuda", torch.cuda.current_device())
+        idx = torch.arange(n, dtype=torch.float64, device=dev)
+        # round `it`, rank r contributes  idx * (it + 1) + (r + 1) * (it + 3); the world's sum is known in closed form
+        its = torch.arange(rounds, dtype=torch.float64, device=dev).view(-1, 1)
+        mine = idx.view(1, -1) * (its + 1) + float(rank + 1) * (its + 3)                      # [rounds][n]
+        want = idx.view(1, -1) * ((its + 1) * world) + (its + 3) * float(world * (world + 1) // 2)
+        lens = [n - (it % 7) * 64 for it in range(rounds)]                                    # changing lengths
+        plain = mine.clone()
+        for it in range(rounds):                  # (elements past this round's length are not exchanged: preset to the expectation)
+            plain[it, lens[it]:] = want[it, lens[it]:]
+        outf = torch.zeros(n, dtype=torch.float32, device=dev)
+        for it in range(rounds):
+            ln = lens[it]
+            if it % 2 == 0:
+                _lib.check(lib.npp_p2p_exchange(plain[it].data_ptr(), ln, 0, st), "npp_p2p_exchange")
+            else:
+                # slab form: the contribution split over R replica slabs [R][ln] (every slab floor(value / R), slab 0 the rest)
+                base = torch.floor(mine[it, :ln] / R)
+                seg = base.view(1, ln).repeat(R, 1).contiguous()
+                seg[0] = mine[it, :ln] - base * (R - 1)
+                arr = (_lib.NppP2pSeg * 1)()
+                arr[0] = _lib.NppP2pSeg(seg.data_ptr(), ln, 0, outf.data_ptr(), None, None, None, R, 1, None)
+                _lib.check(lib.npp_p2p_exchange_slabs(arr, 1, 0, st), "npp_p2p_exchange_slabs")
+                plain[it, :ln] = seg.sum(0)       # (enqueued AFTER the exchange on the same stream: replica 0 = world sum, rest zero)
+        if not torch.equal(plain, want):          # the first host synchronisation since the first exchange
+            return False
         return int(lib.npp_p2p_status()) == 0
-    except Exception:      # noqa: BLE001
+    except Exception:      # noqa: BLE001  (this rank may not have issued every exchange: the channel's sequence is out of step)
+        _selftest_state["broken"] = True
         return False
 
 
+_selftest_state = {"broken": False}
 _p2p_tried: set = set()
 
 
@@ -228,6 +278,38 @@ def p2p_exchange_slabs(segs, group=None):
     return True
 
 
+def p2p_status() -> int:
+    """0, or the error bits of the mailbox channels (1: a poll timed out, 2: a slot was overwritten before it was read).
+    Synchronises the device -- every stream, the non-blocking branch / side streams the exchanges run on included."""
+    if not p2p_active():
+        return 0
+    torch.cuda.synchronize()
+    return int(_lib.lib().npp_p2p_status())
+
+
 def p2p_ok():
     """False if a peer never showed up for some exchange (synchronises the device)."""
-    return not p2p_active() or int(_lib.lib().npp_p2p_status()) == 0
+    return p2p_status() == 0
+
+
+CHECK_EVERY = int(os.environ.get("NPP_P2P_CHECK_EVERY", "50"))      # steps between two health checks of the mailboxes (0: never)
+
+
+def p2p_check(group=None, what="a training step"):
+    """Collective health check of the peer-to-peer transport (train_step.TrainStep calls it every CHECK_EVERY steps and at capture):
+    every rank reads its error words, the ranks agree through a MAX all-reduce, and ALL of them raise if any exchange of any rank
+    timed out or found an overwritten slot -- from that exchange on the channel returned NaN statistics, so the step's numbers are
+    void; the run must not go on (RCCL would have blocked instead).  Returns quietly when everything is fine."""
+    if not p2p_active():
+        return
+    bits = p2p_status()
+    grp = _p2p["group"] if group is None else group
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(grp) > 1:
+        flag = torch.tensor([bits], dtype=torch.int32, device="cuda" if dist.get_backend(grp) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=grp)
+        bits = int(flag.item())
+    if bits:
+        raise RuntimeError(f"npp_amd.comm: the peer-to-peer SyncBatchNorm exchange failed during {what} (error bits {bits}: "
+                           "1 = a peer did not answer within NPP_P2P_TIMEOUT_MS, 2 = a peer ran ahead and overwrote a mailbox slot); "
+                           "the statistics of that exchange and everything after it are NaN.  Restart from the last checkpoint; "
+                           "NPP_SYNCBN_P2P=0 keeps every exchange on RCCL collectives")

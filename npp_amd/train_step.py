@@ -201,7 +201,9 @@ class TrainStep:
         self.calls += 1
         flat, layout = self._flatten(images, labels_par, labels_pose, pose_weight)
         if not self.use_graph:
-            return self._eager(images, labels_par, labels_pose, pose_weight)
+            loss = self._eager(images, labels_par, labels_pose, pose_weight)
+            self._p2p_health()
+            return loss
         if self.graph is None:
             if self.calls <= self.warmup:
                 # eager warm-up on a side stream (allocations of these steps must not land in the capture's pool)
@@ -249,7 +251,16 @@ class TrainStep:
             self._hyper = hyper
         self.graph.replay()
         K.note_training_step()         # parameters changed behind Tensor._version: derived images (packed weights) are stale
+        self._p2p_health()
         return self._static_loss
+
+    def _p2p_health(self):
+        """Every comm.CHECK_EVERY replayed steps: did every peer-to-peer SyncBatchNorm exchange find its peers?  The check is
+        a collective of its own (device sync + MAX all-reduce of the error words): every rank raises together when any of them saw a
+        time-out or an overwritten slot -- a dead channel returns NaN statistics, the run must stop rather than train on them."""
+        from . import comm
+        if comm.CHECK_EVERY > 0 and comm.p2p_active() and self.calls % comm.CHECK_EVERY == 0:
+            comm.p2p_check(what=f"training steps {self.calls - comm.CHECK_EVERY + 1}..{self.calls}")
 
     def _check_p2p_transport(self):
         """Before the step is frozen into a graph: did every peer answer every peer-to-peer SyncBatchNorm exchange of the eager warm-up

@@ -2,7 +2,8 @@
 
 Both ranks share the one GPU of the test box (hipIpc maps a buffer of the other PROCESS just the same; the peer stores then go
 through one L2 instead of xGMI): mailbox set-up over a gloo side channel, exchanges of every size, hipGraph replays (the sequence
-counter lives on the device), two channels on two streams, a peer that never shows up (bounded poll, error word), and the
+counter lives on the device), two channels on two streams, a peer that never shows up (bounded poll, error word, NaN sums, the
+collective health check), and the
 SyncBatchNorm network of tests/test_syncbn_gpu.py with this transport against the same goldens."""
 import os
 import sys
@@ -115,13 +116,22 @@ def _worker(rank, world, port, out, mode):
             assert comm.p2p_exchange(w, None)
             torch.cuda.synchronize()
             res["second_reported"] = not comm.p2p_ok()
+            res["second_is_nan"] = bool(torch.isnan(w).all())      # a failed exchange never hands back local sums
             import time
             t0 = time.time()
             for _ in range(50):                         # a dead channel does not wait again: 50 more exchanges take no time
                 assert comm.p2p_exchange(w, None)
             torch.cuda.synchronize()
             res["dead_channel_is_fast"] = time.time() - t0 < 2.0
+            res["dead_channel_is_nan"] = bool(torch.isnan(w).all())
+        # the collective health check TrainStep runs every few steps: BOTH ranks raise, although only rank 0 saw the time-out
+        try:
+            comm.p2p_check(what="the test")
+            res["check_raised"] = False
+        except RuntimeError:
+            res["check_raised"] = True
     res["bad"] = bad
+    res["mode"] = comm._p2p.get("mode")
     res["ok"] = bool(comm.p2p_ok()) if mode != "timeout" else True
     torch.save(res, f"{out}.{rank}")
     dist.barrier()
@@ -142,6 +152,7 @@ def test_two_processes_exchange_through_ipc_mailboxes(tmp_path):
         pytest.skip("this runtime refuses hipIpc between two processes of one device")
     for r in res:
         assert r["bad"] == [] and r["ok"] and r["long_vector_ok"] and r["slabs_ok"]
+        assert r["mode"] in ("relaxed", "fenced")      # the 2000-exchange acceptance test of enable_p2p passed in this mode
         assert r["exchanges"] == 30 + 3 + 3 + 3 + 1      # (replays do not pass through the host counter)
 
 
@@ -151,3 +162,5 @@ def test_a_missing_peer_is_reported_not_waited_for_forever(tmp_path):
         pytest.skip("this runtime refuses hipIpc between two processes of one device")
     assert all(r["first_ok"] for r in res)
     assert res[0]["second_reported"] and res[0]["dead_channel_is_fast"]
+    assert res[0]["second_is_nan"] and res[0]["dead_channel_is_nan"]
+    assert all(r["check_raised"] for r in res), "the periodic health check must stop EVERY rank"

@@ -1,4 +1,5 @@
 #!/bin/bash
+export NPP_BENCH_SUPERVISE=0   # under rocprofv3 the profiled process must be the worker itself: never a supervisor that spawns one
 # GPU box: the profiling artefacts judged for a round -> gpurun_out/final/ (copy into profiles/ afterwards)
 #   1. rocprofv3 --kernel-trace --stats of the default bench command (hipGraph, two branch streams)
 #   2. the same for the eager single-stream run (per-kernel durations without overlap)
@@ -39,6 +40,6 @@ fm=$(find /tmp/fp_pmc_mfma -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_mfma_busy.py "$fm" "$FAMS,bn_bwd,add_n,affine_add,dw" > $out/${tag}_pmc_mfma_busy.txt
 cat $out/${tag}_pmc_mfma_busy.txt
 #   5. the plain bench line (no profiler, default streams), after copying the fresh traffic file where bench.py reads it
-unset NPP_STREAMS NPP_SYNC_LAUNCH GPU_MAX_HW_QUEUES
+unset NPP_STREAMS NPP_SYNC_LAUNCH GPU_MAX_HW_QUEUES NPP_BENCH_SUPERVISE
 cp $out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
 python3 bench.py > $out/${tag}_bench_line.json 2> /dev/null; tail -c 400 $out/${tag}_bench_line.json

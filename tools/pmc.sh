@@ -1,4 +1,5 @@
 #!/bin/bash
+export NPP_BENCH_SUPERVISE=0   # under rocprofv3 the profiled process must be the worker itself: never a supervisor that spawns one
 # usage: tools/pmc.sh "<kernel substring>" <python script + args...>   (run on the GPU box)
 pat=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT

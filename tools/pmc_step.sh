@@ -1,4 +1,5 @@
 #!/bin/bash
+export NPP_BENCH_SUPERVISE=0   # under rocprofv3 the profiled process must be the worker itself: never a supervisor that spawns one
 # GPU box: whole-step HBM traffic (two --pmc passes of the eager single-stream bench) -> gpurun_out/pmc_step_total${1}.txt
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; export NPP_STREAMS=1
 # NPP_SYNC_LAUNCH: with a deep launch queue rocprofv3's counter-collection intercept aborts the queue ("AQL packet is

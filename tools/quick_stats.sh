@@ -1,4 +1,5 @@
 #!/bin/bash
+export NPP_BENCH_SUPERVISE=0   # under rocprofv3 the profiled process must be the worker itself: never a supervisor that spawns one
 # GPU box: rocprofv3 --kernel-trace --stats of the default bench (hipGraph, two streams) -> gpurun_out/quick_stats.txt (per-step table)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf /tmp/qs; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/qs -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-prof > /tmp/qs.log 2>&1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export NPP_BENCH_SUPERVISE=0   # under rocprofv3 the profiled process must be the worker itself: never a supervisor that spawns one
 # GPU box: rocprofv3 --kernel-trace --stats of the search-supernet bench (config 5) -> gpurun_out/quick_stats_search.txt
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf /tmp/qss; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/qss -- python3 bench.py --model search --batch 8 --steps 5 --warmup 2 --no-cpu-baseline --no-prof > /tmp/qss.log 2>&1
