@@ -89,6 +89,11 @@ typedef struct NppPackJob {
   const float* w; void* out;
   int32_t cout, cin, kh, kw, for_dgrad, dtype;
   int64_t first_block;
+  /* merged data-gradient image (for_dgrad, taps <= 9): `out` is the image of a conv with co_total output channels -- the
+   * concatenation along Cout of several weights that read the SAME input (the three std_conv_3x3 edges on state 0 of an encoder
+   * cell, genotypes.py:30-36) -- and this weight fills the columns [co_off, co_off + cout) of every tap.  0 / 0: a plain job.
+   * (The forward image of such a group is the weights' own images back to back: rows are output channels.) */
+  int32_t co_off, co_total;
 } NppPackJob;
 /* blocks job (cout, cin, kh, kw, for_dgrad) occupies in the batched launch: first_block of job k = sum over the jobs before it.
  * The batched kernel writes real elements only: zero the (padded) images once when they are allocated. */
@@ -194,7 +199,11 @@ typedef struct NppBnFinalizeArgs {
   float* running_mean; float* running_var; int64_t* num_batches_tracked;
   float* scale_shift; float* mean_invstd;
   double count;
-  int32_t nrep; float momentum; float eps; int32_t _pad;
+  int32_t nrep; float momentum; float eps;
+  int32_t stats_c;   /* 0, or (npp_affine_add_fin only) the channel count of the statistics ROW this BatchNorm's channels sit in:
+                        replica r of `stats` = [sum: stats_c | sum of squares: stats_c] with `stats` already advanced to this
+                        BatchNorm's first channel -- the layout ONE conv launch leaves for several merged edges (a cell's
+                        same-input std_conv_3x3 edges as one conv C -> m C, model_augment.py:48-62 / genotypes.py:30-36) */
 } NppBnFinalizeArgs;
 int npp_bn_finalize2(const NppBnFinalizeArgs* a, const NppBnFinalizeArgs* b, int c, void* stream);
 /* eval mode: scale/shift from the running statistics */
@@ -261,6 +270,29 @@ int npp_bn_bwd_apply2_fin(const NppTensor* dout, const NppTensor* ya_raw, const 
                           const double* sums, int nrep, double count, const float* mean_invstd_a, const float* mean_invstd_b,
                           const float* gamma_a, const float* gamma_b, float* dgamma_a, float* dbeta_a, float* dgamma_b,
                           float* dbeta_b, NppTensor* dya_raw, NppTensor* dyb_raw, void* stream);
+/* ---- the same three fused kernels for up to NPP_BN_MULTI_MAX INDEPENDENT jobs of one shape in ONE launch (job = blockIdx.z): the
+ * BatchNorm applies / backward passes of the nodes of a cell whose inputs are ready together -- both preprocess outputs, nodes 2 + 3,
+ * nodes 4 + 5 of models/model_augment.py:48-62 (ENCODER.normal, genotypes.py:30-36) -- are equal in shape and independent; as separate
+ * launches each is one more link of the cell's dependent kernel chain.  All jobs must share n, h, w, c, dtype and the operand pattern
+ * (b present or not, BatchNorm on b or not, bit-mask or not; backward: yb present or not, relu_out present or not) and be in layouts
+ * npp_bn_fused_ok accepts; otherwise NPP_E_UNSUPPORTED is returned and NOTHING is launched (the caller runs the jobs one by one).
+ * Per job the arguments mean what they mean in npp_affine_add_fin / npp_bn_bwd_reduce(2)_acc / npp_bn_bwd_apply(2)_fin. */
+#define NPP_BN_MULTI_MAX 4
+typedef struct NppAffineAddJob {
+  NppTensor out, a, b;                 /* b.ptr NULL: no second operand */
+  NppBnFinalizeArgs fin_a, fin_b;      /* fin_b.stats NULL: b (if any) is added as is */
+  int32_t relu, _pad;
+  unsigned char* mask_bits; int64_t ld_mask;
+} NppAffineAddJob;
+int npp_affine_add_fin_multi(const NppAffineAddJob* jobs, int njobs, void* stream);
+typedef struct NppBnBwdJob {
+  NppTensor dout, ya, yb, relu_out, dya, dyb;      /* yb.ptr NULL: one BatchNorm side ([R][2C] sums), else two ([R][3C]); relu_out.ptr NULL: none */
+  const float* mi_a; const float* mi_b; const float* gamma_a; const float* gamma_b;
+  float* dgamma_a; float* dbeta_a; float* dgamma_b; float* dbeta_b;
+  double* sums; double count;
+} NppBnBwdJob;
+int npp_bn_bwd_reduce_multi(const NppBnBwdJob* jobs, int njobs, int nblocks, void* stream);      /* dya / dyb unused */
+int npp_bn_bwd_apply_multi(const NppBnBwdJob* jobs, int njobs, void* stream);
 /* BatchNorm backward of a small bf16 map in ONE launch (csrc/bn_one.hip): npp_bn_bwd_reduce(2)_acc + npp_bn_bwd_apply(2)_fin with
  * the tensors held in registers across a grid-wide barrier (no ReLU mask: the cell nodes and the ReLU-Conv-BN blocks of
  * operations.py:70-79 have none after the BatchNorm).  npp_bn_bwd_one_blocks: grid size the kernel would use, 0 = not a shape of

@@ -58,7 +58,19 @@ class NppBnFinalizeArgs(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
                 ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("scale_shift", C.c_void_p),
                 ("mean_invstd", C.c_void_p), ("count", C.c_double), ("nrep", C.c_int32), ("momentum", C.c_float),
-                ("eps", C.c_float), ("_pad", C.c_int32)]
+                ("eps", C.c_float), ("stats_c", C.c_int32)]
+
+
+class NppAffineAddJob(C.Structure):
+    _fields_ = [("out", NppTensor), ("a", NppTensor), ("b", NppTensor), ("fin_a", NppBnFinalizeArgs), ("fin_b", NppBnFinalizeArgs),
+                ("relu", C.c_int32), ("_pad", C.c_int32), ("mask_bits", C.c_void_p), ("ld_mask", C.c_int64)]
+
+
+class NppBnBwdJob(C.Structure):
+    _fields_ = [("dout", NppTensor), ("ya", NppTensor), ("yb", NppTensor), ("relu_out", NppTensor), ("dya", NppTensor), ("dyb", NppTensor),
+                ("mi_a", C.c_void_p), ("mi_b", C.c_void_p), ("gamma_a", C.c_void_p), ("gamma_b", C.c_void_p),
+                ("dgamma_a", C.c_void_p), ("dbeta_a", C.c_void_p), ("dgamma_b", C.c_void_p), ("dbeta_b", C.c_void_p),
+                ("sums", C.c_void_p), ("count", C.c_double)]
 
 
 class NppMixSide(C.Structure):
@@ -74,7 +86,8 @@ class NppAdamJob(C.Structure):
 
 class NppPackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("kh", C.c_int32),
-                ("kw", C.c_int32), ("for_dgrad", C.c_int32), ("dtype", C.c_int32), ("first_block", C.c_int64)]
+                ("kw", C.c_int32), ("for_dgrad", C.c_int32), ("dtype", C.c_int32), ("first_block", C.c_int64),
+                ("co_off", C.c_int32), ("co_total", C.c_int32)]
 
 
 _lib = None
@@ -116,6 +129,9 @@ _SIGS = {
     "npp_bn_bwd_apply": [_T, _T, _T, _P, _T, _P],
     "npp_scale_mask": [_T, _P, _T, _T, _P],
     "npp_bn_fused_ok": [_T],
+    "npp_affine_add_fin_multi": [_P, C.c_int, _P],
+    "npp_bn_bwd_reduce_multi": [_P, C.c_int, C.c_int, _P],
+    "npp_bn_bwd_apply_multi": [_P, C.c_int, _P],
     "npp_mix_bn_fwd": [_P, C.c_int, _P, _T, _P],
     "npp_mix_bn_bwd": [_P, C.c_int, _P, _T, _P, _P, _P],
     "npp_mix_bn_fwd_n": [_P, C.c_int, _P, _T, C.c_double, _P],

@@ -762,8 +762,9 @@ class WeightPacker:
     """Packs every dense-conv weight of a model (forward and data-gradient operand images) with ONE kernel
     launch whenever any of them changed (i.e. once per optimizer step) instead of ~820 tiny launches."""
 
-    def __init__(self, weights):
+    def __init__(self, weights, groups=()):
         self.weights = list(weights)
+        self.groups = [g for g in groups if g.weights[0].shape[0] % 32 == 0]      # WideGroups: merged images (conv2d_wide)
         self.sig = None
         self.epoch = -1            # TRAIN_EPOCH the images were last written at
         self.table = None
@@ -772,7 +773,21 @@ class WeightPacker:
 
     def _build(self, dtype, device):
         import numpy as np
-        jobs = (L.NppPackJob * (2 * len(self.weights)))()
+        # merged edges: the group's forward image is its weights' own forward images back to back (rows = output channels), its
+        # data-gradient image [Cin][tap][m * Cout] is filled column block by column block, one job per weight
+        fwd_slice = {}
+        self.group_bufs = []
+        for g in self.groups:
+            ws = g.weights
+            co, ci, kh, kw = ws[0].shape
+            n1 = int(lib().npp_packed_weight_elems(co, ci, kh, kw, 0))
+            buf = torch.zeros(len(ws) * n1, dtype=dtype, device=device)
+            for k, w in enumerate(ws):
+                fwd_slice[id(w)] = buf[k * n1:(k + 1) * n1]
+            dgb = torch.zeros(int(lib().npp_packed_weight_elems(len(ws) * co, ci, kh, kw, 1)), dtype=dtype, device=device)
+            self.group_bufs.append((g, buf, dgb))
+        njobs = 2 * len(self.weights) + sum(len(g.weights) for g in self.groups)
+        jobs = (L.NppPackJob * njobs)()
         outs = []
         counts = []
         blk = 0
@@ -781,17 +796,30 @@ class WeightPacker:
             co, ci, kh, kw = w.shape
             for dg in (0, 1):
                 n = lib().npp_packed_weight_elems(co, ci, kh, kw, dg)
-                out = torch.zeros(n, dtype=dtype, device=device)      # padding stays zero: the kernel writes real elements only
+                out = fwd_slice.get(id(w)) if dg == 0 else None
+                if out is None:
+                    out = torch.zeros(n, dtype=dtype, device=device)      # padding stays zero: the kernel writes real elements only
                 outs.append(out)
                 jobs[i] = L.NppPackJob(w.data_ptr(), out.data_ptr(), co, ci, kh, kw, dg, L.npp_dtype(dtype), blk)
                 nb = int(lib().npp_pack_job_blocks(co, ci, kh, kw, dg))
                 counts.append(nb)
                 blk += nb
                 i += 1
+        for g, _buf, dgb in self.group_bufs:
+            ws = g.weights
+            co, ci, kh, kw = ws[0].shape
+            for k, w in enumerate(ws):
+                jobs[i] = L.NppPackJob(w.data_ptr(), dgb.data_ptr(), co, ci, kh, kw, 1, L.npp_dtype(dtype), blk, k * co, len(ws) * co)
+                nb = int(lib().npp_pack_job_blocks(co, ci, kh, kw, 1))
+                counts.append(nb)
+                blk += nb
+                i += 1
+        assert i == njobs
         raw = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()
         self.table = torch.from_numpy(raw).to(device)
         self.block_job = torch.from_numpy(np.repeat(np.arange(len(counts), dtype=np.int32), counts)).to(device)
         self.outs = outs
+        self.njobs = njobs
         self.nblocks = blk
         self.key = (dtype, device, tuple(w.data_ptr() for w in self.weights))
 
@@ -811,10 +839,12 @@ class WeightPacker:
             self.sig = None
         if sig == self.sig and not force and self.epoch == TRAIN_EPOCH:
             return         # (eval forward: no version moved AND no training step ran since the images were written)
-        check(lib().npp_pack_weights_batched_map(self.table.data_ptr(), 2 * len(ws), self.block_job.data_ptr(), self.nblocks,
+        check(lib().npp_pack_weights_batched_map(self.table.data_ptr(), self.njobs, self.block_job.data_ptr(), self.nblocks,
                                                  stream_ptr()), "npp_pack_weights_batched_map")
         self.sig = sig
         self.epoch = TRAIN_EPOCH
+        for g, buf, dgb in self.group_bufs:
+            g.img = {(False, dtype): buf, (True, dtype): dgb}
         k = 0
         for w in ws:
             wid = id(w)
@@ -1256,94 +1286,110 @@ class _Conv2d(Function):
         if dy.dtype != x.dtype:
             dy = cast(dy, x.dtype)
         dy = _gemm_ready(dy)
-        n, ci, h, w = x.shape
         co, _, kh, kw = weight.shape
         dx = dw = db = None
         s = stream_ptr()
         if ctx.needs_input_grad[0]:
-            wp = packed_weight(weight, True, x.dtype)
-            dx = None
-            acc_flag = 0
-            if ctx.fan is not None and stride == (1, 1):
-                # x feeds several consumers: add into their shared gradient buffer (the first claimant stores)
-                dx, accumulate = ctx.fan.claim(x)
-                acc_flag = 2 if accumulate else 0
-            own = dx is None
-            if own:
-                dx = new_nhwc(n, ci, h, w, x.dtype, x.device)
-            done = False
-            while not done:
-                g = geom(kh, kw, 1, 1, dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1], dil[0], dil[1],
-                         (stride[0], stride[1]), acc_flag)
-                if relu_in and ctx.mask_bits is not None:      # the producer of x left a bit-mask: 1/16 of the mask bytes
-                    done = _conv_launch(dy, wp.data_ptr(), None, C.byref(ctx.mask_bits[0]), dx, None, g, s, "npp_conv_fwd(dgrad)",
-                                        soft=True) == 0
-                    if not acc_flag or done:
-                        MASK_STATS[0 if done else 1] += 1
-                if not done:
-                    done = _conv_launch(dy, wp.data_ptr(), None, _byref(x) if relu_in else None, dx, None, g, s,
-                                        "npp_conv_fwd(dgrad)", soft=bool(acc_flag)) == 0
-                if not done:      # this shape's kernel cannot accumulate: a tensor of its own, the fan-out node adds it
-                    FAN_STATS[1] -= 1
-                    FAN_STATS[2] += 1
-                    acc_flag = 0
-                    dx = new_nhwc(n, ci, h, w, x.dtype, x.device)
-            if SHAPE_LOG is not None:
-                SHAPE_LOG.append(("dgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
+            dx = _conv_dgrad(x, dy, packed_weight(weight, True, x.dtype), co, kh, kw, stride, pad, dil, relu_in, ctx.mask_bits, ctx.fan)
         if ctx.needs_input_grad[1]:
-            nel = lib().npp_packed_weight_elems(co, ci, kh, kw, 0)
-            g = geom(kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 1, relu_in)
-            if kh == 1 and kw == 1 and ci % 64 == 0 and co % 32 == 0:
-                wkey = (tuple(x.shape), L.nhwc_ld(x), co, L.nhwc_ld(dy), kh, kw, stride, pad, dil, x.dtype)
-                nsl = _batched_slabs(x, dy, g, wkey)
-                if nsl > 0 and weight.dtype == torch.float32 and _may_defer(weight):
-                    # batched launch in slab mode: the splits store into slabs, the batched unpack sums them into the gradient
-                    slabs = torch.empty(nsl * nel, dtype=torch.float32, device=x.device)
-                    _defer_wgrad(x, dy, slabs, g, wkey, None, nsl)
-                    dw = grad_out(weight)
-                    if dw is None:
-                        dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-                    _unpack_or_defer(slabs, dw, co, ci, 1, 1, nsl, s, True)
-                else:
-                    # packed [co][ci] == OIHW: accumulate straight into the gradient tensor
-                    dw = grad_out(weight, zero=True)            # the parameter's (zeroed) slot in its gradient bucket, or
-                    if dw is None:
-                        dw = zeros_f32(weight.numel(), x.device, own=True).view(weight.shape)     # pre-zeroed pool slice: no fill launch
-                    if not _defer_wgrad(x, dy, dw, g, wkey, weight):
-                        check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
-            else:
-                dw = grad_out(weight)
-                if dw is None:
-                    dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-                wkey = (tuple(x.shape), L.nhwc_ld(x), co, L.nhwc_ld(dy), kh, kw, stride, pad, dil, x.dtype)
-                nsl = _wgrad_splits.get(wkey)
-                if nsl is None:
-                    nsl = _wgrad_splits[wkey] = int(lib().npp_conv_wgrad_splits(_byref(x), _byref(dy), C.byref(g)))
-                defer_ok = DEFER_UNPACK and _may_defer(weight)      # (dw reaches autograd unwritten when the unpack waits)
-                bsl = _batched_slabs(x, dy, g, wkey) if (defer_ok and nsl <= 0) else 0
-                if bsl > 0:      # batched launch in slab mode
-                    slabs = torch.empty(bsl * nel, dtype=torch.float32, device=x.device)
-                    _defer_wgrad(x, dy, slabs, g, wkey, None, bsl)
-                    _unpack_or_defer(slabs, dw, co, ci, kh, kw, bsl, s, True)
-                elif nsl > 0:      # deterministic split-K: the kernel stores one slab per split, the unpack sums them
-                    slabs = torch.empty(nsl * nel, dtype=torch.float32, device=x.device)
-                    check(lib().npp_conv_wgrad_slabs(_byref(x), _byref(dy), slabs.data_ptr(), nsl, C.byref(g), s), "npp_conv_wgrad_slabs")
-                    _unpack_or_defer(slabs, dw, co, ci, kh, kw, nsl, s, defer_ok)
-                else:
-                    dwp = zeros_f32(nel, x.device)
-                    if not (defer_ok and _defer_wgrad(x, dy, dwp, g, wkey)):      # (its unpack must be deferred behind it)
-                        check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
-                    _unpack_or_defer(dwp, dw, co, ci, kh, kw, 0, s, defer_ok)
-            if SHAPE_LOG is not None:
-                SHAPE_LOG.append(("wgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
-            if dw.dtype != weight.dtype:
-                dw = dw.to(weight.dtype)
+            dw = _conv_wgrad(x, dy, weight, stride, pad, dil, relu_in)
         if has_bias and ctx.needs_input_grad[2]:
             acc = zeros_f64(R * co, x.device)
             check(lib().npp_channel_sum(_byref(dy), acc.data_ptr(), s), "npp_channel_sum")
             db = _grad_buf(bias, co, x.device)
             check(lib().npp_sum_replicas(acc.data_ptr(), R, co, db.data_ptr(), s), "npp_sum_replicas")
         return dx, dw, db, None, None, None, None, None, None, None
+
+
+def _conv_dgrad(x, dy, wp, co, kh, kw, stride, pad, dil, relu_in, mask_bits, fan):
+    """Data gradient of y = conv(relu?(x)): the same conv over dy with the flipped-tap image `wp` (co = channels of dy), masked by
+    x > 0 (bit-mask when the producer of x left one), stored -- or added into the shared gradient buffer of x's fan-out node."""
+    n, ci, h, w = x.shape
+    s = stream_ptr()
+    dx = None
+    acc_flag = 0
+    if fan is not None and stride == (1, 1):
+        # x feeds several consumers: add into their shared gradient buffer (the first claimant stores)
+        dx, accumulate = fan.claim(x)
+        acc_flag = 2 if accumulate else 0
+    if dx is None:
+        dx = new_nhwc(n, ci, h, w, x.dtype, x.device)
+    done = False
+    while not done:
+        g = geom(kh, kw, 1, 1, dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1], dil[0], dil[1],
+                 (stride[0], stride[1]), acc_flag)
+        if relu_in and mask_bits is not None:      # the producer of x left a bit-mask: 1/16 of the mask bytes
+            done = _conv_launch(dy, wp.data_ptr(), None, C.byref(mask_bits[0]), dx, None, g, s, "npp_conv_fwd(dgrad)",
+                                soft=True) == 0
+            if not acc_flag or done:
+                MASK_STATS[0 if done else 1] += 1
+        if not done:
+            done = _conv_launch(dy, wp.data_ptr(), None, _byref(x) if relu_in else None, dx, None, g, s,
+                                "npp_conv_fwd(dgrad)", soft=bool(acc_flag)) == 0
+        if not done:      # this shape's kernel cannot accumulate: a tensor of its own, the fan-out node adds it
+            FAN_STATS[1] -= 1
+            FAN_STATS[2] += 1
+            acc_flag = 0
+            dx = new_nhwc(n, ci, h, w, x.dtype, x.device)
+    if SHAPE_LOG is not None:
+        SHAPE_LOG.append(("dgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
+    return dx
+
+
+def _conv_wgrad(x, dy, weight, stride, pad, dil, relu_in):
+    """Weight gradient of y = conv(relu?(x)) w.r.t. `weight` (dy may be a channel slice of a wider buffer): immediate, or queued for
+    the batched launch at the end of backward (TrainStep); returns the tensor autograd receives."""
+    n, ci, h, w = x.shape
+    co, _, kh, kw = weight.shape
+    s = stream_ptr()
+    nel = lib().npp_packed_weight_elems(co, ci, kh, kw, 0)
+    g = geom(kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 1, relu_in)
+    if kh == 1 and kw == 1 and ci % 64 == 0 and co % 32 == 0:
+        wkey = (tuple(x.shape), L.nhwc_ld(x), co, L.nhwc_ld(dy), kh, kw, stride, pad, dil, x.dtype)
+        nsl = _batched_slabs(x, dy, g, wkey)
+        if nsl > 0 and weight.dtype == torch.float32 and _may_defer(weight):
+            # batched launch in slab mode: the splits store into slabs, the batched unpack sums them into the gradient
+            slabs = torch.empty(nsl * nel, dtype=torch.float32, device=x.device)
+            _defer_wgrad(x, dy, slabs, g, wkey, None, nsl)
+            dw = grad_out(weight)
+            if dw is None:
+                dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            _unpack_or_defer(slabs, dw, co, ci, 1, 1, nsl, s, True)
+        else:
+            # packed [co][ci] == OIHW: accumulate straight into the gradient tensor
+            dw = grad_out(weight, zero=True)            # the parameter's (zeroed) slot in its gradient bucket, or
+            if dw is None:
+                dw = zeros_f32(weight.numel(), x.device, own=True).view(weight.shape)     # pre-zeroed pool slice: no fill launch
+            if not _defer_wgrad(x, dy, dw, g, wkey, weight):
+                check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dw.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
+    else:
+        dw = grad_out(weight)
+        if dw is None:
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+        wkey = (tuple(x.shape), L.nhwc_ld(x), co, L.nhwc_ld(dy), kh, kw, stride, pad, dil, x.dtype)
+        nsl = _wgrad_splits.get(wkey)
+        if nsl is None:
+            nsl = _wgrad_splits[wkey] = int(lib().npp_conv_wgrad_splits(_byref(x), _byref(dy), C.byref(g)))
+        defer_ok = DEFER_UNPACK and _may_defer(weight)      # (dw reaches autograd unwritten when the unpack waits)
+        bsl = _batched_slabs(x, dy, g, wkey) if (defer_ok and nsl <= 0) else 0
+        if bsl > 0:      # batched launch in slab mode
+            slabs = torch.empty(bsl * nel, dtype=torch.float32, device=x.device)
+            _defer_wgrad(x, dy, slabs, g, wkey, None, bsl)
+            _unpack_or_defer(slabs, dw, co, ci, kh, kw, bsl, s, True)
+        elif nsl > 0:      # deterministic split-K: the kernel stores one slab per split, the unpack sums them
+            slabs = torch.empty(nsl * nel, dtype=torch.float32, device=x.device)
+            check(lib().npp_conv_wgrad_slabs(_byref(x), _byref(dy), slabs.data_ptr(), nsl, C.byref(g), s), "npp_conv_wgrad_slabs")
+            _unpack_or_defer(slabs, dw, co, ci, kh, kw, nsl, s, defer_ok)
+        else:
+            dwp = zeros_f32(nel, x.device)
+            if not (defer_ok and _defer_wgrad(x, dy, dwp, g, wkey)):      # (its unpack must be deferred behind it)
+                check(lib().npp_conv_wgrad(_byref(x), _byref(dy), dwp.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
+            _unpack_or_defer(dwp, dw, co, ci, kh, kw, 0, s, defer_ok)
+    if SHAPE_LOG is not None:
+        SHAPE_LOG.append(("wgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
+    if dw.dtype != weight.dtype:
+        dw = dw.to(weight.dtype)
+    return dw
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1, relu_in=False, want_stats=False, private_in=False):
@@ -1359,6 +1405,175 @@ def conv2d_crop(x, weight, stride=2, relu_in=False, want_stats=False):
     h, w = x.shape[2] - 1, x.shape[3] - 1
     out_hw = ((h - 1) // stride + 1, (w - 1) // stride + 1)
     return _Conv2d.apply(take(x), weight, None, _pair(stride), (-1, -1), (1, 1), bool(relu_in), int(want_stats), out_hw)
+
+
+# --------------------------------------------------------------------------------------------------
+# merged edges: the ReLU-conv-BN edges of a cell that read the SAME state with the SAME geometry as ONE conv launch
+# --------------------------------------------------------------------------------------------------
+# The fixed genotype hands this over on a plate (genotypes.py:30-54): three of the eight edges of an encoder cell are std_conv_3x3 on
+# state 0, the decoder cells apply three (two) std_conv_1x1 to state 1 (0), the refinement cells two std_conv_3x3 to the same state
+# twice over.  Forward: ONE conv C -> m C whose weight image is the edges' own images back to back (rows = output channels), with one
+# statistics epilogue over m C channels; every edge's raw output is a channel slice of the one result.  Backward: the BatchNorm
+# backward of each edge writes its dy straight into its slice of ONE buffer (`gslot`), the data gradient is ONE conv m C -> C with
+# K = m * taps * C -- the sum over the edges happens in the MFMA accumulators, no read-add-store pass -- and the weight gradients
+# stay per parameter (dy slices with ld = m C).  The parameters remain separate tensors under the reference's names; only the
+# derived operand images are shared.  NPP_WIDE=0 keeps one launch per edge.
+WIDE = os.environ.get("NPP_WIDE", "1") != "0"
+WIDE_STATS = [0, 0, 0]      # merged forward launches / merged data gradients that found every dy in place / ... that had to gather
+
+
+class _WideGrad:
+    """The dy buffer [N, H, W, m * C] of one merged conv: allocated when the first edge's BatchNorm backward asks for its slice."""
+    __slots__ = ("buf", "m", "c")
+
+    def __init__(self, m, c):
+        self.buf, self.m, self.c = None, m, c
+
+    def slot(self, k):
+        wg = self
+
+        def give(like):
+            n, c, h, w = like.shape
+            if c != wg.c:
+                return None
+            if wg.buf is None:
+                wg.buf = new_nhwc(n, wg.m * c, h, w, like.dtype, like.device)
+            b = wg.buf
+            if b.shape[0] != n or b.shape[2] != h or b.shape[3] != w or b.dtype != like.dtype or b.device != like.device:
+                return None
+            return _alias(b, k * c, c)
+        return give
+
+
+def _dx_into(slot, like):
+    """The tensor a BatchNorm backward writes the gradient of its raw input into: the edge's slice of a merged conv's dy buffer when
+    there is one, else a fresh tensor."""
+    if slot is not None:
+        t = slot(like)
+        if t is not None:
+            return t
+    return new_nhwc(*like.shape, like.dtype, like.device)
+
+
+class WideGroup:
+    """m conv modules (same Cin, Cout, kernel, stride 1, no bias) that a cell applies to one and the same state."""
+
+    def __init__(self, convs):
+        self.convs = list(convs)
+        self.img = {}          # (for_dgrad, dtype) -> image written by the model's WeightPacker (valid after its pack_if_stale)
+        self.calls = None      # per-forward cache: [input tensor, list of pending results]
+
+    @property
+    def weights(self):
+        return [c.weight for c in self.convs]
+
+    def images(self, dtype, need_dgrad):
+        """(forward image, data-gradient image | None) of the merged conv."""
+        ws = self.weights
+        if (False, dtype) in self.img and (True, dtype) in self.img and self.img[(False, dtype)].device == ws[0].device:
+            return self.img[(False, dtype)], self.img[(True, dtype)]
+        # no packer manages this group (a cell used on its own): build the images from the per-weight ones
+        co, ci, kh, kw = ws[0].shape
+        taps, m = kh * kw, len(ws)
+        fwd = torch.cat([packed_weight(w, False, dtype).view(-1)[:co * ((taps * ((ci + 7) // 8 * 8) + 63) // 64 * 64)] for w in ws])
+        dg = None
+        if need_dgrad:
+            rows = (ci + 31) // 32 * 32
+            cop1 = (co + 7) // 8 * 8
+            k1 = (taps * cop1 + 63) // 64 * 64
+            kg = (taps * m * co + 63) // 64 * 64
+            dg = torch.zeros(rows, kg, dtype=dtype, device=ws[0].device)
+            v = dg[:, :taps * m * co].view(rows, taps, m, co)
+            for k, w in enumerate(ws):
+                one = packed_weight(w, True, dtype).view(rows, k1)[:, :taps * cop1].view(rows, taps, cop1)[:, :, :co]
+                v[:, :, k, :] = one
+            dg = dg.view(-1)
+        return fwd, dg
+
+
+class _ConvWide(Function):
+    @staticmethod
+    def forward(ctx, x, pad, relu_in, want_stats, fan, group, wg, *weights):
+        x = _gemm_ready(to_nhwc(x))
+        n, ci, h, w = x.shape
+        m = len(weights)
+        co, _, kh, kw = weights[0].shape
+        y = new_nhwc(n, m * co, h, w, x.dtype, x.device)
+        stats = stats_buffer(R * 2 * m * co, x.device, want_stats) if want_stats else None
+        g = geom(kh, kw, 1, 1, pad[0], pad[1], 1, 1, 1, relu_in)
+        need_bwd = any(ctx.needs_input_grad)      # (grad mode is off inside forward: ask the context)
+        wp, wpd = group.images(x.dtype, need_bwd)
+        _conv_launch(x, wp.data_ptr(), None, None, y, ptr(stats), g, stream_ptr(), "npp_conv_fwd(wide)")
+        WIDE_STATS[0] += 1
+        if SHAPE_LOG is not None:
+            SHAPE_LOG.append(("fwd", n, ci, h, w, m * co, kh, kw, 1, 1))
+        ctx.save_for_backward(x, *weights)
+        ctx.wpd = wpd
+        ctx.fan = fan if x.dtype == torch.bfloat16 else None
+        ctx.mask_bits = relu_mask_of(x) if (relu_in and RELU_BITS and x.dtype == torch.bfloat16) else None
+        if relu_in and ctx.mask_bits is None and RELU_BITS and x.dtype == torch.bfloat16:
+            MASK_STATS[2] += 1
+        ctx.cfg = (pad, relu_in, m, co)
+        ctx.wg = wg
+        ctx.set_materialize_grads(False)
+        outs = tuple(_alias(y, k * co, co) for k in range(m))
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return (*outs, stats)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, *weights = ctx.saved_tensors
+        pad, relu_in, m, co = ctx.cfg
+        dys = list(grads[:m])
+        if all(d is None for d in dys):
+            return (None,) * (7 + m)
+        n, ci, h, w = x.shape
+        _, _, kh, kw = weights[0].shape
+        wg = ctx.wg
+        buf, wg.buf = wg.buf, None      # (a second backward over the same graph starts a new buffer)
+        esz = x.element_size()
+        in_place = buf is not None and buf.dtype == x.dtype and all(
+            d is not None and d.dtype == buf.dtype and d.shape[1] == co and d.data_ptr() == buf.data_ptr() + k * co * esz
+            and d.stride() == (buf.stride(0), 1, buf.stride(2), buf.stride(3)) for k, d in enumerate(dys))
+        if in_place:
+            dy_all = buf
+            WIDE_STATS[1] += 1
+        else:      # (an edge whose BatchNorm ran on a path without slots, or an unused edge): gather the slices
+            parts = []
+            for d in dys:
+                if d is None:
+                    parts.append(new_nhwc(n, co, h, w, x.dtype, x.device, zero=True))
+                else:
+                    d = to_nhwc(d)
+                    parts.append(d if d.dtype == x.dtype else cast(d, x.dtype))
+            dy_all = new_nhwc(n, m * co, h, w, x.dtype, x.device)
+            descs = [desc(t) for t in parts]
+            arr = (C.POINTER(L.NppTensor) * m)(*[C.pointer(d) for d in descs])
+            check(lib().npp_concat(arr, m, _byref(dy_all), stream_ptr()), "npp_concat")
+            WIDE_STATS[2] += 1
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv_dgrad(x, dy_all, ctx.wpd, m * co, kh, kw, (1, 1), pad, (1, 1), relu_in, ctx.mask_bits, ctx.fan)
+        dws = []
+        for k, wt in enumerate(weights):
+            if ctx.needs_input_grad[7 + k] and dys[k] is not None:
+                dws.append(_conv_wgrad(x, _alias(dy_all, k * co, co), wt, (1, 1), pad, (1, 1), relu_in))
+            else:
+                dws.append(None)
+        return (dx, None, None, None, None, None, None, *dws)
+
+
+def conv2d_wide(x, group, pad, relu_in, want_stats):
+    """The m convs of `group` applied to x in one launch: ([raw output k], [statistics view k], stats row width, [dy slot k])."""
+    xa, fan = take_acc(x)
+    ws = group.weights
+    m, co = len(ws), ws[0].shape[0]
+    wg = _WideGrad(m, co)
+    res = _ConvWide.apply(xa, _pair(pad), bool(relu_in), int(want_stats), fan, group, wg, *ws)
+    ys, stats = res[:m], res[m]
+    svs = [stats[k * co:] if stats is not None else None for k in range(m)]
+    return ys, svs, m * co, [wg.slot(k) for k in range(m)]
 
 
 # --------------------------------------------------------------------------------------------------
@@ -1438,11 +1653,15 @@ class BnSide:
     """One operand of the fused add.  kind 'bn': `x` is a raw (pre-BN) tensor with f64 stats (train) or a
     BatchNorm holder in eval mode; kind 'plain': `x` is used as is."""
 
-    __slots__ = ("x", "bn", "stats", "count", "synced_ws", "private", "stream", "sync_event")
+    __slots__ = ("x", "bn", "stats", "count", "synced_ws", "private", "stream", "sync_event", "stats_c", "gslot")
 
-    def __init__(self, x, bn=None, stats=None, private=None):
+    def __init__(self, x, bn=None, stats=None, private=None, stats_c=0, gslot=None):
         self.x = x
         self.bn = bn
+        # merged edges (conv2d_wide): `stats` starts at this edge's first channel inside statistics rows of stats_c channels
+        # ([R][sum stats_c | sumsq stats_c]); gslot(like) -> the edge's slice of the merged conv's dy buffer (BatchNorm backward)
+        self.stats_c = int(stats_c)
+        self.gslot = gslot
         # private: `x` was produced for this operand alone (a raw conv / pool output on its way into its BatchNorm), so it
         # needs no fan-out node (take): ~600 autograd nodes per step less on the host
         self.private = (bn is not None) if private is None else bool(private)
@@ -1520,7 +1739,10 @@ def _bn_finalize_args(side: BnSide, training: bool, device):
     if side.stats is None:
         side.stats = channel_stats(side.x)
     stats = side.stats
-    nrep = stats.numel() // (2 * c)
+    if side.stats_c:      # a slice of a merged conv's statistics rows: R replicas of 2 * stats_c doubles, this edge's channels at `stats`
+        nrep = R
+    else:
+        nrep = stats.numel() // (2 * c)
     count = float(side.x.shape[0] * side.x.shape[2] * side.x.shape[3])
     if side.synced_ws:            # all-reduced: the replicas now hold global partial sums
         count *= side.synced_ws
@@ -1534,14 +1756,24 @@ def _bn_finalize_args(side: BnSide, training: bool, device):
     nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
     args = L.NppBnFinalizeArgs(stats.data_ptr(), ptr(gamma), ptr(beta), ptr(bn.running_mean) if track else None,
                                ptr(bn.running_var) if track else None, ptr(nbt), ss.data_ptr(), mi.data_ptr(), count, nrep,
-                               float(mom), float(bn.eps), 0)
+                               float(mom), float(bn.eps), side.stats_c)
     return args, ss, mi, (stats, gamma, beta)
+
+
+def _compact_stats(side: BnSide):
+    """A merged edge's statistics as a [R][2C] tensor of its own (the separate finalize kernels read rows of 2C doubles)."""
+    if side.stats_c and side.stats is not None:
+        c, sc = side.x.shape[1], side.stats_c
+        rows = side.stats.as_strided((R, 2, c), (2 * sc, sc, 1))
+        side.stats = rows.contiguous().view(-1)
+        side.stats_c = 0
 
 
 def _bn_coeffs(side: BnSide, training: bool, device):
     """scale/shift (+ mean/invstd) for one BN side; updates running stats in train mode."""
     bn = side.bn
     c = side.x.shape[1]
+    _compact_stats(side)
     prep = _bn_finalize_args(side, training, device)
     if prep is not None:
         a, ss, mi, _keep = prep
@@ -1565,6 +1797,8 @@ def _bn_coeffs_pair(sa: BnSide, sb: BnSide, training: bool, device):
     use_a = training or sa.bn.running_mean is None
     use_b = training or sb.bn.running_mean is None
     if use_a and use_b and sa.x.shape[1] == sb.x.shape[1]:
+        _compact_stats(sa)
+        _compact_stats(sb)
         pa = _bn_finalize_args(sa, training, device)
         pb = _bn_finalize_args(sb, training, device)
         check(lib().npp_bn_finalize2(C.byref(pa[0]), C.byref(pb[0]), sa.x.shape[1], stream_ptr()), "npp_bn_finalize2")
@@ -1646,6 +1880,36 @@ def _bn_one_barrier(device):
     return buf
 
 
+def _fin_prepare(a, b, sa, sb, training, out):
+    """(finalize args a, finalize args b | None, output tensor) of the fused apply npp_affine_add_fin, or None when the operands are
+    not local-batch-statistics BatchNorms in a layout it takes."""
+    if not _fin_fusable(sa, sb, a, b, training):
+        return None
+    dev = a.device
+    pa = _bn_finalize_args(sa, training, dev)
+    pb = _bn_finalize_args(sb, training, dev) if (sb is not None and sb.bn is not None) else None
+    y = out[0] if out is not None else new_nhwc(*a.shape, a.dtype, dev)
+    return pa, pb, y
+
+
+def _fin_record(ctx, a, b, y, pa, pb, sa, sb, relu):
+    """What _BnAdd.backward needs after a fused apply."""
+    ctx.relu = relu
+    ctx.sides = (sa.bn, sb.bn if sb is not None else None, True, pb is not None, sa.count, sb.count if sb else None, b is not None)
+    ctx.save_for_backward(a, b, y if relu else None, pa[2], pb[2] if pb is not None else None, None, None)
+
+
+# One launch for the BatchNorm applies / backward passes of SEVERAL independent, equally shaped nodes (npp_affine_add_fin_multi,
+# npp_bn_bwd_reduce_multi, npp_bn_bwd_apply_multi): the nodes of a cell that are ready together.  NPP_BN_MULTI=0: one launch each.
+BN_MULTI = os.environ.get("NPP_BN_MULTI", "1") != "0"
+BN_MULTI_MAX = 4
+MULTI_STATS = [0, 0, 0]      # multi-job launches: forward applies / backward reduces / backward applies
+
+
+def _zero_desc():
+    return L.NppTensor(None, 0, 0, 0, 0, 0, 0, 0)
+
+
 class _BnAdd(Function):
     """out = relu?( [BN_a](a) + [BN_b](b) ).  Tensor args: a, gamma_a, beta_a, b, gamma_b, beta_b."""
 
@@ -1656,22 +1920,17 @@ class _BnAdd(Function):
         dev = a.device
         ssa = mia = ssb = mib = None
         batch_a = batch_b = False
+        ctx.gslots = (sa.gslot, sb.gslot if sb is not None else None)
         _presync_stats((sa, sb), training)
-        if _fin_fusable(sa, sb, a, b, training):
+        prep = _fin_prepare(a, b, sa, sb, training, out)
+        if prep is not None:
             # local train-mode BatchNorm(s): the finalize arithmetic runs in the prologue of the affine_add kernel
-            pa = _bn_finalize_args(sa, training, dev)
-            pb = _bn_finalize_args(sb, training, dev) if (sb is not None and sb.bn is not None) else None
-            y = out[0] if out is not None else new_nhwc(*a.shape, a.dtype, dev)
+            pa, pb, y = prep
             rc = lib().npp_affine_add_fin(_byref(y), _byref(a), C.byref(pa[0]), tref(b), C.byref(pb[0]) if pb is not None else None,
                                           int(relu), (mk[0].data_ptr() + mk[1]) if mk is not None else None,
                                           mk[2] if mk is not None else 0, stream_ptr())
             if rc == 0:
-                mia = pa[2]
-                mib = pb[2] if pb is not None else None
-                ctx.relu = relu
-                ctx.sides = (sa.bn, sb.bn if sb is not None else None, True, pb is not None, sa.count, sb.count if sb else None,
-                             b is not None)
-                ctx.save_for_backward(a, b, y if relu else None, mia, mib, None, None)
+                _fin_record(ctx, a, b, y, pa, pb, sa, sb, relu)
                 return y
             if rc != -5:      # NPP_E_UNSUPPORTED: nothing was launched, the separate kernels take it
                 check(rc, "npp_affine_add_fin")
@@ -1712,6 +1971,7 @@ class _BnAdd(Function):
         the exchange took place -- _BnAddPair.backward runs two of these side by side and merges their exchanges into one."""
         a, b, yrelu, mia, mib, ssa, ssb = ctx.saved_tensors
         bna, bnb, batch_a, batch_b, cnt_a, cnt_b, has_b = ctx.sides
+        gs = getattr(ctx, "gslots", (None, None))      # merged edges: where the raw gradients go (_WideGrad.slot)
         dout = to_nhwc(dout)
         if dout.dtype != a.dtype:
             dout = cast(dout, a.dtype)
@@ -1787,8 +2047,8 @@ class _BnAdd(Function):
             ga = bna.weight.detach() if bna.weight is not None else None
             gb = bnb.weight.detach() if bnb.weight is not None else None
             if one is not None:
-                dxa = new_nhwc(*a.shape, a.dtype, dev)
-                dxb = new_nhwc(*b.shape, b.dtype, dev)
+                dxa = _dx_into(gs[0], a)
+                dxb = _dx_into(gs[1], b)
                 check(lib().npp_bn_bwd_one2(_byref(dout), _byref(a), _byref(b), sums.data_ptr(), float(cnt_a), mia.data_ptr(),
                                             mib.data_ptr(), ptr(ga), ptr(gb), dgb_[0].data_ptr(), dgb_[1].data_ptr(),
                                             dgb_[2].data_ptr(), dgb_[3].data_ptr(), _byref(dxa), _byref(dxb), one.data_ptr(), s),
@@ -1800,16 +2060,16 @@ class _BnAdd(Function):
                 # local sums -> dbeta (both sides), dgamma_a, dgamma_b; world sums -> replica 0, the other replicas zeroed
                 ok2 = yield ([(sums, 3 * c, R, c, (dgb_[1], dgb_[3], dgb_[0], dgb_[2]), True)], sync2)
                 assert ok2, "peer-to-peer exchange refused a vector it had accepted the size of"
-                dxa = new_nhwc(*a.shape, a.dtype, dev)
-                dxb = new_nhwc(*b.shape, b.dtype, dev)
+                dxa = _dx_into(gs[0], a)
+                dxb = _dx_into(gs[1], b)
                 check(lib().npp_bn_bwd_apply2_fin(_byref(dout), _byref(a), _byref(b), tref(yrelu), sums.data_ptr(), R, float(cnt_a),
                                                   mia.data_ptr(), mib.data_ptr(), ptr(ga), ptr(gb), None, None, None, None,
                                                   _byref(dxa), _byref(dxb), s), "npp_bn_bwd_apply2_fin")
                 return (dxa, dgb_[0] if ni[1] else None, dgb_[1] if ni[2] else None,
                         dxb, dgb_[2] if ni[4] else None, dgb_[3] if ni[5] else None, None, None, None, None, None, None)
             if fused:
-                dxa = new_nhwc(*a.shape, a.dtype, dev)
-                dxb = new_nhwc(*b.shape, b.dtype, dev)
+                dxa = _dx_into(gs[0], a)
+                dxb = _dx_into(gs[1], b)
                 check(lib().npp_bn_bwd_apply2_fin(_byref(dout), _byref(a), _byref(b), tref(yrelu), sums.data_ptr(), R, float(cnt_a),
                                                   mia.data_ptr(), mib.data_ptr(), ptr(ga), ptr(gb), dgb_[0].data_ptr(),
                                                   dgb_[1].data_ptr(), dgb_[2].data_ptr(), dgb_[3].data_ptr(), _byref(dxa),
@@ -1821,8 +2081,8 @@ class _BnAdd(Function):
                                            co[:3 * c].data_ptr(), co[3 * c:].data_ptr(), dgb_[0].data_ptr(),
                                            dgb_[1].data_ptr(), dgb_[2].data_ptr(), dgb_[3].data_ptr(), c, s),
                   "npp_bn_bwd_coeffs2")
-            dxa = new_nhwc(*a.shape, a.dtype, dev)
-            dxb = new_nhwc(*b.shape, b.dtype, dev)
+            dxa = _dx_into(gs[0], a)
+            dxb = _dx_into(gs[1], b)
             check(lib().npp_bn_bwd_apply2(_byref(dout), _byref(a), _byref(b), tref(yrelu), co[:3 * c].data_ptr(),
                                           co[3 * c:].data_ptr(), _byref(dxa), _byref(dxb), s), "npp_bn_bwd_apply2")
             return (dxa, dgb_[0] if ni[1] else None, dgb_[1] if ni[2] else None,
@@ -1918,14 +2178,14 @@ class _BnAdd(Function):
                     dbt = _grad_buf(bn.bias if need_b else None, c, x.device)
                     dg, db = dgt, dbt
                 if one_bar[i] is not None:
-                    dx = new_nhwc(*x.shape, x.dtype, x.device)
+                    dx = _dx_into(gs[i], x)
                     check(lib().npp_bn_bwd_one(_byref(dout), _byref(x), sums.data_ptr(), float(count), mi.data_ptr(), ptr(gamma),
                                                ptr(dgt), ptr(dbt), _byref(dx), one_bar[i].data_ptr(), s), "npp_bn_bwd_one")
                     BN_ONE_STATS[0] += 1
                     outs.append((dx, dg if need_g else None, db if need_b else None))
                     continue
                 if fin[i] or (fin_sync[i] and nrep == 1):
-                    dx = new_nhwc(*x.shape, x.dtype, x.device)
+                    dx = _dx_into(gs[i], x)
                     check(lib().npp_bn_bwd_apply_fin(_byref(dout), _byref(x), tref(yrelu), sums.data_ptr(), nrep, float(count),
                                                      mi.data_ptr(), ptr(gamma), ptr(dgt), ptr(dbt), _byref(dx), s),
                           "npp_bn_bwd_apply_fin")
@@ -1935,12 +2195,12 @@ class _BnAdd(Function):
                 check(lib().npp_bn_bwd_coeffs(sums.data_ptr(), nrep, float(count), mi.data_ptr(), ptr(gamma), co.data_ptr(),
                                               ptr(dgt), ptr(dbt), c, s), "npp_bn_bwd_coeffs")
                 if need_x:
-                    dx = new_nhwc(*x.shape, x.dtype, x.device)
+                    dx = _dx_into(gs[i], x)
                     check(lib().npp_bn_bwd_apply(_byref(dout), _byref(x), tref(yrelu), co.data_ptr(), _byref(dx), s),
                           "npp_bn_bwd_apply")
             else:
                 if need_x:
-                    dx = new_nhwc(*x.shape, x.dtype, x.device)
+                    dx = _dx_into(gs[i], x)
                     check(lib().npp_scale_mask(_byref(dout), ss.data_ptr(), tref(yrelu), _byref(dx), s), "npp_scale_mask")
                 tot = sums.view(nrep, 2 * c).sum(0)
                 dg, db = tot[c:].float(), tot[:c].float()
@@ -1955,9 +2215,10 @@ class _BnAdd(Function):
 class _SubCtx:
     """What _BnAdd.forward / _backward_gen need of an autograd context, for one half of a _BnAddPair."""
 
-    def __init__(self, saved=None, relu=False, sides=None, needs=None):
+    def __init__(self, saved=None, relu=False, sides=None, needs=None, gslots=(None, None)):
         self.saved_tensors = saved
         self.relu, self.sides, self.needs_input_grad = relu, sides, needs
+        self.gslots = gslots
 
     def save_for_backward(self, *ts):
         self.saved_tensors = ts
@@ -1973,10 +2234,14 @@ class _BnAddPair(Function):
     def forward(ctx, n, *args):
         tens, metas = args[:6 * n], args[6 * n:7 * n]
         subs, outs, saved = [], [], []
+        ctx.n = n
+        if BN_MULTI and 2 <= n <= BN_MULTI_MAX and _BnAddPair._forward_multi(ctx, n, tens, metas, outs):
+            return tuple(outs)
+        outs = []
         for k in range(n):
             sub = _SubCtx()
             outs.append(_BnAdd.forward(sub, *tens[6 * k:6 * k + 6], *metas[k]))
-            subs.append((sub.relu, sub.sides))
+            subs.append((sub.relu, sub.sides, sub.gslots))
             saved += list(sub.saved_tensors)
         assert len(saved) == 7 * n
         ctx.save_for_backward(*saved)
@@ -1984,13 +2249,161 @@ class _BnAddPair(Function):
         return tuple(outs)
 
     @staticmethod
+    def _forward_multi(ctx, n, tens, metas, outs) -> bool:
+        """All n applies in ONE launch; False (nothing launched) when one of them is not a fused local apply or the shapes differ."""
+        preps = []
+        for k in range(n):
+            a, _ga, _ba, b, _gb, _bb = tens[6 * k:6 * k + 6]
+            sa, sb, relu, training, out, mk = metas[k]
+            _presync_stats((sa, sb), training)
+            pr = _fin_prepare(a, b, sa, sb, training, out)
+            if pr is None:
+                return False
+            preps.append(pr)
+        jobs = (L.NppAffineAddJob * n)()
+        for k in range(n):
+            a, _ga, _ba, b, _gb, _bb = tens[6 * k:6 * k + 6]
+            _sa, _sb, relu, _training, _out, mk = metas[k]
+            pa, pb, y = preps[k]
+            j = jobs[k]
+            j.out, j.a = desc(y), desc(a)
+            j.b = desc(b) if b is not None else _zero_desc()
+            j.fin_a = pa[0]
+            if pb is not None:
+                j.fin_b = pb[0]
+            j.relu = int(relu)
+            if mk is not None:
+                j.mask_bits, j.ld_mask = mk[0].data_ptr() + mk[1], mk[2]
+        rc = lib().npp_affine_add_fin_multi(C.cast(jobs, C.c_void_p), n, stream_ptr())
+        if rc == L.NPP_E_UNSUPPORTED:
+            return False
+        check(rc, "npp_affine_add_fin_multi")
+        MULTI_STATS[0] += 1
+        subs, saved = [], []
+        for k in range(n):
+            a, _ga, _ba, b, _gb, _bb = tens[6 * k:6 * k + 6]
+            sa, sb, relu, _training, _out, _mk = metas[k]
+            pa, pb, y = preps[k]
+            sub = _SubCtx()
+            sub.gslots = (sa.gslot, sb.gslot if sb is not None else None)
+            _fin_record(sub, a, b, y, pa, pb, sa, sb, relu)
+            subs.append((sub.relu, sub.sides, sub.gslots))
+            saved += list(sub.saved_tensors)
+            outs.append(y)
+        ctx.save_for_backward(*saved)
+        ctx.subs = subs
+        return True
+
+    @staticmethod
+    def _backward_multi(ctx, douts):
+        """The n backward passes as ONE reduce launch + ONE apply launch when every item is the same kind of fused local BatchNorm
+        backward (both operands BatchNorms, or one BatchNorm + nothing / a plain operand) on one shape; None otherwise (nothing launched)."""
+        n = ctx.n
+        saved = ctx.saved_tensors
+        needs = ctx.needs_input_grad[1:]
+        items = []
+        kind = None
+        for k, dout in enumerate(douts):
+            if dout is None:
+                return None
+            a, b, yrelu, mia, mib, _ssa, _ssb = saved[7 * k:7 * k + 7]
+            bna, bnb, batch_a, batch_b, cnt_a, cnt_b, has_b = ctx.subs[k][1]
+            ni = needs[6 * k:6 * k + 6]
+            if bna is None or not batch_a or not ni[0] or _sync_group(bna)[0] is not None or mia is None:
+                return None
+            two = bool(has_b and bnb is not None)
+            if two:
+                if not (batch_b and ni[3] and a.shape == b.shape and a.dtype == b.dtype and cnt_a == cnt_b and mib is not None
+                        and _sync_group(bnb)[0] is None and _fused_layout_ok(b)):
+                    return None
+            elif has_b and yrelu is not None:
+                return None      # (a plain operand behind a ReLU needs a masked copy of its own)
+            dout = to_nhwc(dout)
+            if dout.dtype != a.dtype:
+                dout = cast(dout, a.dtype)
+            if not (_fused_layout_ok(a) and _fused_layout_ok(dout) and (yrelu is None or _fused_layout_ok(yrelu))):
+                return None
+            sig = (two, yrelu is not None, tuple(a.shape), a.dtype)
+            if kind is None:
+                kind = sig
+            elif kind != sig:
+                return None
+            items.append((dout, a, b, yrelu, mia, mib, bna, bnb, cnt_a, has_b, ni, two))
+        if not FUSE_BN_FIN:
+            return None
+        two = kind[0]
+        dev = items[0][1].device
+        c = items[0][1].shape[1]
+        jobs = (L.NppBnBwdJob * n)()
+        keep, results = [], []
+        for k, (dout, a, b, yrelu, mia, mib, bna, bnb, cnt, has_b, ni, _two) in enumerate(items):
+            gs = ctx.subs[k][2]
+            sums = zeros_f64(R * (3 if two else 2) * c, dev)
+            j = jobs[k]
+            j.dout, j.ya = desc(dout), desc(a)
+            j.yb = desc(b) if two else _zero_desc()
+            j.relu_out = desc(yrelu) if yrelu is not None else _zero_desc()
+            dxa = _dx_into(gs[0], a)
+            j.dya = desc(dxa)
+            dxb = None
+            if two:
+                dxb = _dx_into(gs[1], b)
+                j.dyb = desc(dxb)
+            else:
+                j.dyb = _zero_desc()
+            j.mi_a = mia.data_ptr()
+            ga = bna.weight.detach() if bna.weight is not None else None
+            j.gamma_a = ptr(ga)
+            dga = _grad_buf(bna.weight if ni[1] else None, c, dev)
+            dba = _grad_buf(bna.bias if ni[2] else None, c, dev)
+            j.dgamma_a, j.dbeta_a = dga.data_ptr(), dba.data_ptr()
+            dgb = dbb = gb = None
+            if two:
+                j.mi_b = mib.data_ptr()
+                gb = bnb.weight.detach() if bnb.weight is not None else None
+                j.gamma_b = ptr(gb)
+                dgb = _grad_buf(bnb.weight if ni[4] else None, c, dev)
+                dbb = _grad_buf(bnb.bias if ni[5] else None, c, dev)
+                j.dgamma_b, j.dbeta_b = dgb.data_ptr(), dbb.data_ptr()
+            j.sums, j.count = sums.data_ptr(), float(cnt)
+            keep.append((sums, ga, gb))
+            if two:
+                results.append((dxa, dga if ni[1] else None, dba if ni[2] else None, dxb, dgb if ni[4] else None, dbb if ni[5] else None))
+            else:
+                passed = None
+                if has_b and ni[3]:      # the plain operand receives the incoming gradient itself: several readers from here on
+                    try:
+                        dout._npp_own = False
+                    except Exception:      # noqa: BLE001
+                        pass
+                    passed = dout
+                results.append((dxa, dga if ni[1] else None, dba if ni[2] else None, passed, None, None))
+        nb = lib().npp_reduce_blocks(items[0][1].shape[0] * items[0][1].shape[2] * items[0][1].shape[3], c, L.npp_dtype(items[0][1].dtype))
+        s = stream_ptr()
+        rc = lib().npp_bn_bwd_reduce_multi(C.cast(jobs, C.c_void_p), n, nb, s)
+        if rc == L.NPP_E_UNSUPPORTED:
+            return None
+        check(rc, "npp_bn_bwd_reduce_multi")
+        MULTI_STATS[1] += 1
+        check(lib().npp_bn_bwd_apply_multi(C.cast(jobs, C.c_void_p), n, s), "npp_bn_bwd_apply_multi")
+        MULTI_STATS[2] += 1
+        out = (None,)
+        for r in results:
+            out += r
+        return out + (None,) * n
+
+    @staticmethod
     def backward(ctx, *douts):
         n = ctx.n
+        if BN_MULTI and 2 <= n <= BN_MULTI_MAX:
+            res_m = _BnAddPair._backward_multi(ctx, douts)
+            if res_m is not None:
+                return res_m
         saved = ctx.saved_tensors
         needs = ctx.needs_input_grad[1:]
         gens, reqs, res = [], [None] * n, [None] * n
         for k, d in enumerate(douts):
-            sub = _SubCtx(saved[7 * k:7 * k + 7], ctx.subs[k][0], ctx.subs[k][1], needs[6 * k:6 * k + 6])
+            sub = _SubCtx(saved[7 * k:7 * k + 7], ctx.subs[k][0], ctx.subs[k][1], needs[6 * k:6 * k + 6], ctx.subs[k][2])
             gens.append(_BnAdd._backward_gen(sub, d))
         for k in range(n):      # every reduce first ...
             try:

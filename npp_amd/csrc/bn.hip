@@ -302,11 +302,13 @@ struct FinSide {
   const double* stats; const float* gamma; const float* beta;
   float* running_mean; float* running_var; long* nbt; float* mi;
   double count; int nrep; float momentum, eps;
+  int sc;      // channels of the statistics row the side's channels sit in: replica r = [sum sc | sum of squares sc] (sc = C for a
+               // BatchNorm with a conv of its own; sc = m C when m merged edges came out of ONE conv, NppBnFinalizeArgs.stats_c)
 };
 template <typename T, int V, bool HAS_B, bool FB, bool MASK>
-__global__ __launch_bounds__(256) void affine_add_fin_kernel(T* __restrict__ out, long ldo, const T* __restrict__ a, long lda,
+NPP_DEV void affine_add_fin_kernel_body(T* __restrict__ out, long ldo, const T* __restrict__ a, long lda,
                                                              const T* __restrict__ b, long ldb, FinSide fa, FinSide fb, int relu,
-                                                             long npix, int C, ColMap m, unsigned char* __restrict__ mk, long ldmk) {
+                                                             long npix, int C, ColMap m, unsigned char* __restrict__ mk, long ldmk, const int BX, const int GX) {
   extern __shared__ float s_ss[];      // [side][scale C | shift C]
   const int t = threadIdx.x;
   constexpr int NS = (HAS_B && FB) ? 2 : 1;
@@ -315,9 +317,9 @@ __global__ __launch_bounds__(256) void affine_add_fin_kernel(T* __restrict__ out
   const int col = t % m.cols_blk, row = t / m.cols_blk;
   const int colg = col;                       // one column block (the host checks cv <= 256)
   const int c0 = colg * V;
-  const long step = (long)gridDim.x * m.rows;
+  const long step = (long)GX * m.rows;
   const long last = npix - 1;
-  long p = (long)blockIdx.x * m.rows + row;
+  long p = (long)BX * m.rows + row;
   float va[V], vb[V], wa[V], wb[V];
   if (act && p < npix) {
     const long q2 = p + step < npix ? p + step : last;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256) void affine_add_fin_kernel(T* __restrict__ out
     // 32 L2 round trips in a row, slower than the launch this prologue replaces)
     double v0[NPP_STAT_REPLICAS], v1[NPP_STAT_REPLICAS];
 #pragma unroll
-    for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { v0[r] = f.stats[(long)r * 2 * C + c]; v1[r] = f.stats[(long)r * 2 * C + C + c]; }
+    for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { v0[r] = f.stats[(long)r * 2 * f.sc + c]; v1[r] = f.stats[(long)r * 2 * f.sc + f.sc + c]; }
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { s0 += v0[r]; s1 += v1[r]; }
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void affine_add_fin_kernel(T* __restrict__ out
     const float g = f.gamma ? f.gamma[c] : 1.f, bt = f.beta ? f.beta[c] : 0.f;
     s_ss[side * 2 * C + c] = (float)(g * invstd);
     s_ss[side * 2 * C + C + c] = (float)(bt - mean * g * invstd);
-    if (blockIdx.x == 0) {
+    if (BX == 0) {
       if (c == 0 && f.nbt) f.nbt[0] += 1;
       if (f.mi) { f.mi[c] = (float)mean; f.mi[C + c] = (float)invstd; }
       if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
@@ -418,10 +420,10 @@ __global__ __launch_bounds__(256) void affine_add_fin_kernel(T* __restrict__ out
 // ACC: the block adds its sums into slab blockIdx.x % NPP_STAT_REPLICAS of a zeroed [NPP_STAT_REPLICAS][2C] buffer (f64 atomics)
 // instead of storing a slab of its own: the few slabs are then summed by the prologue of bn_bwd_apply_fin_kernel (no coefficient launch)
 template <typename T, int V, bool HAS_RO, bool ACC = false>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
+NPP_DEV void bn_bwd_reduce_kernel_body(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
                                                             long ldy, const T* __restrict__ ro, long ldr,
                                                             const float* __restrict__ mi, long npix, int C, ColMap m,
-                                                            double* sums) {
+                                                            double* sums, const int BX, const int GX) {
   __shared__ __attribute__((aligned(16))) float red[256 * 2 * V * 2];
   const int t = threadIdx.x;
   const bool active = t < m.rows * m.cols_blk;
@@ -439,12 +441,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     invstd[j] = mi[C + chc];
   }
   if (work) {
-    const long step = (long)gridDim.x * m.rows;
+    const long step = (long)GX * m.rows;
     const long cofs = (long)colg * V;
     // RED_U pixels per iteration (2 * RED_U 16-byte loads in flight per lane).  Measured, graph-replayed, C=128 @96^2 (37.7 MB per
     // tensor): RED_U 2 / 4 / 8 = 17.0 / 18.2 / 21.4 us (4.4 / 4.2 / 3.5 TB/s) -- more loads in flight do not help, the small
     // tensors sit at a ~6 us floor set by the block-level f64 reduction tail
-    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += RED_U * step) {
+    for (long p = (long)BX * m.rows + row; p < npix; p += RED_U * step) {
       float d[RED_U][V], v[RED_U][V];
       bool ok[RED_U];
 #pragma unroll
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       }
     }
   }
-  double* rep = sums + (long)(ACC ? blockIdx.x % NPP_STAT_REPLICAS : blockIdx.x) * 2 * C;      // one partial slab per blockIdx.x
+  double* rep = sums + (long)(ACC ? BX % NPP_STAT_REPLICAS : BX) * 2 * C;      // one partial slab per BX
   double* outs[2] = {rep, rep + C};
   block_col_reduce<2, V, !ACC>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
 }
@@ -567,11 +569,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // sides share dout (and the ReLU mask), so one pass reads it once: reduce 4 -> 3 tensor reads, apply 6 -> 5 passes, and
 // half the launches.  sums: slab b = [sum d | sum d*xhat_a | sum d*xhat_b] (3C doubles).
 template <typename T, int V, bool HAS_RO, bool ACC = false>
-__global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ ya,
+NPP_DEV void bn_bwd_reduce2_kernel_body(const T* __restrict__ dout, long ldd, const T* __restrict__ ya,
                                                              long lda, const T* __restrict__ yb, long ldb,
                                                              const T* __restrict__ ro, long ldr, const float* __restrict__ mia,
                                                              const float* __restrict__ mib, long npix, int C, ColMap m,
-                                                             double* sums) {
+                                                             double* sums, const int BX, const int GX) {
   __shared__ __attribute__((aligned(16))) float red[256 * 3 * V * 2];
   const int t = threadIdx.x;
   const bool active = t < m.rows * m.cols_blk;
@@ -589,9 +591,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const T* __restrict
     mb[j] = mib[chc]; ib[j] = mib[C + chc];
   }
   if (work) {
-    const long step = (long)gridDim.x * m.rows;
+    const long step = (long)GX * m.rows;
     const long cofs = (long)colg * V;
-    for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += RED_U * step) {
+    for (long p = (long)BX * m.rows + row; p < npix; p += RED_U * step) {
       float d[RED_U][V], va[RED_U][V], vb[RED_U][V];
       bool ok[RED_U];
 #pragma unroll
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const T* __restrict
       }
     }
   }
-  double* rep = sums + (long)(ACC ? blockIdx.x % NPP_STAT_REPLICAS : blockIdx.x) * 3 * C;
+  double* rep = sums + (long)(ACC ? BX % NPP_STAT_REPLICAS : BX) * 3 * C;
   double* outs[3] = {rep, rep + C, rep + 2 * C};
   block_col_reduce<3, V, !ACC>(acc, red, t, col, row, m.rows, m.cols_blk, work, outs, colg, C);
 }
@@ -710,18 +712,18 @@ struct BwdFinSide {
   const float* mi; const float* gamma; float* dgamma; float* dbeta;
 };
 template <typename T, int V>
-__global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
+NPP_DEV void bn_bwd_apply_fin_kernel_body(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
                                                                long ldy, const T* __restrict__ ro, long ldr,
                                                                const double* __restrict__ sums, int nrep, double inv_count,
-                                                               BwdFinSide f, T* __restrict__ dy, long ldo, long npix, int C, ColMap m) {
+                                                               BwdFinSide f, T* __restrict__ dy, long ldo, long npix, int C, ColMap m, const int BX, const int GX) {
   extern __shared__ float s_co[];      // [k1 C | cb C | cc C]
   const int t = threadIdx.x;
   // first pixel pair requested before the prologue (see affine_add_fin_kernel)
   const bool act = t < m.rows * m.cols_blk;
   const int col = t % m.cols_blk, row = t / m.cols_blk;
   const int c0 = col * V;
-  const long step = (long)gridDim.x * m.rows;
-  long p = (long)blockIdx.x * m.rows + row;
+  const long step = (long)GX * m.rows;
+  long p = (long)BX * m.rows + row;
   float d[V], v[V], d2[V], v2[V], r[V], r2[V];
   if (act && p < npix) {
     const long q2 = p + step < npix ? p + step : p;
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* __restri
     s_co[c] = k1;
     s_co[C + c] = -k1 * invstd * m1;
     s_co[2 * C + c] = k1 * (mean * invstd * m1 - m0);
-    if (blockIdx.x == 0) {
+    if (BX == 0) {
       if (f.dgamma) f.dgamma[c] = (float)s1;
       if (f.dbeta) f.dbeta[c] = (float)s0;
     }
@@ -795,19 +797,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* __restri
 }
 
 template <typename T, int V>
-__global__ __launch_bounds__(256) void bn_bwd_apply2_fin_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ ya,
+NPP_DEV void bn_bwd_apply2_fin_kernel_body(const T* __restrict__ dout, long ldd, const T* __restrict__ ya,
                                                                 long lda, const T* __restrict__ yb, long ldb,
                                                                 const T* __restrict__ ro, long ldr, const double* __restrict__ sums,
                                                                 int nrep, double inv_count, BwdFinSide fa, BwdFinSide fb,
                                                                 T* __restrict__ dya, long ldoa, T* __restrict__ dyb, long ldob,
-                                                                long npix, int C, ColMap m) {
+                                                                long npix, int C, ColMap m, const int BX, const int GX) {
   extern __shared__ float s_co[];      // side a [k1 | cb | cc], side b [k1 | cb | cc]
   const int t = threadIdx.x;
   const bool act = t < m.rows * m.cols_blk;
   const int col = t % m.cols_blk, row = t / m.cols_blk;
   const int c0 = col * V;
-  const long step = (long)gridDim.x * m.rows;
-  long p = (long)blockIdx.x * m.rows + row;
+  const long step = (long)GX * m.rows;
+  long p = (long)BX * m.rows + row;
   float d[V], va[V], vb[V], r[V];
   if (act && p < npix) {
     ldv<T, V>(dout + p * ldd + c0, d);
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_fin_kernel(const T* __restr
     s_co[side * 3 * C + c] = k1;
     s_co[side * 3 * C + C + c] = -k1 * invstd * m1;
     s_co[side * 3 * C + 2 * C + c] = k1 * (mean * invstd * m1 - m0);
-    if (blockIdx.x == 0) {
+    if (BX == 0) {
       if (f.dgamma) f.dgamma[c] = (float)s1;
       if (f.dbeta) f.dbeta[c] = (float)s0;
     }
@@ -865,6 +867,88 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_fin_kernel(const T* __restr
     for (int j = 0; j < V; ++j) o[j] = fmaf(ba[j], d[j], fmaf(bb[j], vb[j], bc[j]));
     stv<T, V>(dyb + p * ldob + c0, o);
   }
+}
+
+// ---- launch forms of the five bodies above: one job per launch (blockIdx.x / gridDim.x walk the pixels), or up to NPP_BN_MULTI_MAX
+// jobs of ONE shape per launch, job = blockIdx.z (round 4: the BatchNorm applies / backward passes of the nodes of a cell that are
+// ready together -- both preprocess outputs, nodes 2 + 3, nodes 4 + 5 of models/model_augment.py:48-62 -- are independent and equal
+// in shape; as separate launches each is a 5-15 us link of the cell's dependent chain).  The job structs travel by value (kernarg).
+template <typename T, int V, bool HAS_B, bool FB, bool MASK>
+__global__ __launch_bounds__(256) void affine_add_fin_kernel(T* __restrict__ out, long ldo, const T* __restrict__ a, long lda,
+                                                             const T* __restrict__ b, long ldb, FinSide fa, FinSide fb, int relu,
+                                                             long npix, int C, ColMap m, unsigned char* __restrict__ mk, long ldmk) {
+  affine_add_fin_kernel_body<T, V, HAS_B, FB, MASK>(out, ldo, a, lda, b, ldb, fa, fb, relu, npix, C, m, mk, ldmk, blockIdx.x, gridDim.x);
+}
+template <typename T, int V, bool HAS_RO, bool ACC = false>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y, long ldy,
+                                                            const T* __restrict__ ro, long ldr, const float* __restrict__ mi,
+                                                            long npix, int C, ColMap m, double* sums) {
+  bn_bwd_reduce_kernel_body<T, V, HAS_RO, ACC>(dout, ldd, y, ldy, ro, ldr, mi, npix, C, m, sums, blockIdx.x, gridDim.x);
+}
+template <typename T, int V, bool HAS_RO, bool ACC = false>
+__global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ ya, long lda,
+                                                             const T* __restrict__ yb, long ldb, const T* __restrict__ ro, long ldr,
+                                                             const float* __restrict__ mia, const float* __restrict__ mib, long npix,
+                                                             int C, ColMap m, double* sums) {
+  bn_bwd_reduce2_kernel_body<T, V, HAS_RO, ACC>(dout, ldd, ya, lda, yb, ldb, ro, ldr, mia, mib, npix, C, m, sums, blockIdx.x, gridDim.x);
+}
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y, long ldy,
+                                                               const T* __restrict__ ro, long ldr, const double* __restrict__ sums,
+                                                               int nrep, double inv_count, BwdFinSide f, T* __restrict__ dy, long ldo,
+                                                               long npix, int C, ColMap m) {
+  bn_bwd_apply_fin_kernel_body<T, V>(dout, ldd, y, ldy, ro, ldr, sums, nrep, inv_count, f, dy, ldo, npix, C, m, blockIdx.x, gridDim.x);
+}
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply2_fin_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ ya, long lda,
+                                                                const T* __restrict__ yb, long ldb, const T* __restrict__ ro, long ldr,
+                                                                const double* __restrict__ sums, int nrep, double inv_count,
+                                                                BwdFinSide fa, BwdFinSide fb, T* __restrict__ dya, long ldoa,
+                                                                T* __restrict__ dyb, long ldob, long npix, int C, ColMap m) {
+  bn_bwd_apply2_fin_kernel_body<T, V>(dout, ldd, ya, lda, yb, ldb, ro, ldr, sums, nrep, inv_count, fa, fb, dya, ldoa, dyb, ldob, npix, C,
+                                      m, blockIdx.x, gridDim.x);
+}
+
+constexpr int BN_MULTI_MAX = 4;
+struct AffJob {
+  void* out; const void* a; const void* b; long ldo, lda, ldb;
+  FinSide fa, fb; int relu; unsigned char* mk; long ldmk;
+};
+struct AffJobs { AffJob j[BN_MULTI_MAX]; };
+template <typename T, int V, bool HAS_B, bool FB, bool MASK>
+__global__ __launch_bounds__(256) void affine_add_fin_multi_kernel(AffJobs js, long npix, int C, ColMap m) {
+  const AffJob& q = js.j[blockIdx.z];
+  affine_add_fin_kernel_body<T, V, HAS_B, FB, MASK>((T*)q.out, q.ldo, (const T*)q.a, q.lda, (const T*)q.b, q.ldb, q.fa, q.fb, q.relu, npix,
+                                                    C, m, q.mk, q.ldmk, blockIdx.x, gridDim.x);
+}
+struct BwdJob {
+  const void* dout; const void* ya; const void* yb; const void* ro; void* dya; void* dyb;
+  long ldd, lda, ldb, ldr, ldoa, ldob;
+  BwdFinSide fa, fb;
+  double* sums; double inv_count;
+};
+struct BwdJobs { BwdJob j[BN_MULTI_MAX]; };
+// TWO: both operands of the add end in BatchNorm (sums = [R][3C]); else one BatchNorm side (sums = [R][2C])
+template <typename T, int V, bool HAS_RO, bool TWO>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_multi_kernel(BwdJobs js, long npix, int C, ColMap m) {
+  const BwdJob& q = js.j[blockIdx.z];
+  if constexpr (TWO)
+    bn_bwd_reduce2_kernel_body<T, V, HAS_RO, true>((const T*)q.dout, q.ldd, (const T*)q.ya, q.lda, (const T*)q.yb, q.ldb, (const T*)q.ro,
+                                                   q.ldr, q.fa.mi, q.fb.mi, npix, C, m, q.sums, blockIdx.x, gridDim.x);
+  else
+    bn_bwd_reduce_kernel_body<T, V, HAS_RO, true>((const T*)q.dout, q.ldd, (const T*)q.ya, q.lda, (const T*)q.ro, q.ldr, q.fa.mi, npix, C,
+                                                  m, q.sums, blockIdx.x, gridDim.x);
+}
+template <typename T, int V, bool TWO>
+__global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BwdJobs js, long npix, int C, ColMap m) {
+  const BwdJob& q = js.j[blockIdx.z];
+  if constexpr (TWO)
+    bn_bwd_apply2_fin_kernel_body<T, V>((const T*)q.dout, q.ldd, (const T*)q.ya, q.lda, (const T*)q.yb, q.ldb, (const T*)q.ro, q.ldr, q.sums,
+                                        NPP_STAT_REPLICAS, q.inv_count, q.fa, q.fb, (T*)q.dya, q.ldoa, (T*)q.dyb, q.ldob, npix, C, m,
+                                        blockIdx.x, gridDim.x);
+  else
+    bn_bwd_apply_fin_kernel_body<T, V>((const T*)q.dout, q.ldd, (const T*)q.ya, q.lda, (const T*)q.ro, q.ldr, q.sums, NPP_STAT_REPLICAS,
+                                       q.inv_count, q.fa, (T*)q.dya, q.ldoa, npix, C, m, blockIdx.x, gridDim.x);
 }
 
 // ---- N-sided weighted BatchNorm sum (npp_mix_bn_*): the mixed edge of the search supernet ------------------------------------------
@@ -1236,6 +1320,7 @@ static inline FinSide fin_side(const NppBnFinalizeArgs* f) {
   s.stats = f->stats; s.gamma = f->gamma; s.beta = f->beta; s.running_mean = f->running_mean; s.running_var = f->running_var;
   s.nbt = reinterpret_cast<long*>(f->num_batches_tracked); s.mi = f->mean_invstd; s.count = f->count; s.nrep = f->nrep;
   s.momentum = f->momentum; s.eps = f->eps;
+  s.sc = 0;      // (the caller fills in the tensor's own channel count unless stats_c names a wider row)
   return s;
 }
 // out = relu?( BN_a(a) [+ BN_b(b) | + b] ) with the finalize of the BatchNorm side(s) done in the kernel's prologue (fin_a required;
@@ -1254,7 +1339,11 @@ extern "C" int npp_affine_add_fin(NppTensor* out, const NppTensor* a, const NppB
   if (mask_bits && !(out->dtype == NPP_BF16 && ld_mask >= out->c / 8)) return NPP_E_UNSUPPORTED;
   const int nt = b ? 3 : 2;
   ProfScope prof(NPP_FAM_ELTWISE, out->dtype, (hipStream_t)stream, 0, (double)npix(out) * out->c * esize(out->dtype) * nt);
-  const FinSide fa = fin_side(fin_a), fb = fin_b ? fin_side(fin_b) : fa;
+  FinSide fa = fin_side(fin_a);
+  fa.sc = fin_a->stats_c > 0 ? fin_a->stats_c : (int)out->c;
+  FinSide fb = fa;
+  if (fin_b) { fb = fin_side(fin_b); fb.sc = fin_b->stats_c > 0 ? fin_b->stats_c : (int)out->c; }
+  NPP_REQUIRE(fa.sc >= out->c && fb.sc >= out->c, NPP_E_SHAPE, "npp_affine_add_fin: stats_c below the channel count");
   const size_t lds = (size_t)(fin_b ? 4 : 2) * out->c * sizeof(float);
 #define AFN(HB, FB_, MK)                                                                                                   \
     hipLaunchKernelGGL((affine_add_fin_kernel<T, V, HB, FB_, MK>), grid, dim3(256), lds, (hipStream_t)stream, (T*)out->ptr,  \
@@ -1529,6 +1618,145 @@ extern "C" int npp_bn_bwd_apply2_fin(const NppTensor* dout, const NppTensor* ya,
                        (T*)dya->ptr, (long)dya->ld, (T*)dyb->ptr, (long)dyb->ld, (long)npix(dout), (int)dout->c, m);
   });
   return npp_check_launch("bn_bwd_apply2_fin");
+}
+
+// ---- up to NPP_BN_MULTI_MAX independent jobs of ONE shape per launch (see affine_add_fin_multi_kernel) ------------------------------
+// All jobs: the same n, h, w, c and dtype, the same operand pattern (second operand or not, BatchNorm on it or not, bit-mask or not;
+// backward: one- or two-sided, ReLU mask or not) and layouts the fused kernels take.  NPP_E_UNSUPPORTED (nothing launched) otherwise:
+// the caller launches the jobs one by one.
+extern "C" int npp_affine_add_fin_multi(const NppAffineAddJob* jobs, int njobs, void* stream) {
+  NPP_REQUIRE(jobs && njobs >= 1, NPP_E_NULL, "npp_affine_add_fin_multi: no jobs");
+  if (njobs > BN_MULTI_MAX) return NPP_E_UNSUPPORTED;
+  const NppAffineAddJob& j0 = jobs[0];
+  const bool has_b = j0.b.ptr != nullptr, fb_ = j0.fin_b.stats != nullptr, mask = j0.mask_bits != nullptr;
+  const NppTensor* ref = &j0.out;
+  AffJobs js;
+  const int Vv = ref->dtype == NPP_BF16 ? 8 : 4;
+  for (int i = 0; i < njobs; ++i) {
+    const NppAffineAddJob& q = jobs[i];
+    NPP_REQUIRE(q.out.ptr && q.a.ptr && q.fin_a.stats && q.fin_a.count > 0, NPP_E_NULL, "npp_affine_add_fin_multi: job %d: null pointer", i);
+    NPP_REQUIRE(same_shape(&q.out, &q.a) && (!q.b.ptr || same_shape(&q.out, &q.b)), NPP_E_SHAPE, "npp_affine_add_fin_multi: job %d: shape mismatch", i);
+    NPP_REQUIRE(dtype_ok(&q.out) && q.out.dtype == q.a.dtype && (!q.b.ptr || q.b.dtype == q.a.dtype), NPP_E_DTYPE, "npp_affine_add_fin_multi: dtype mismatch");
+    NPP_REQUIRE(!q.fin_b.stats || (q.b.ptr && q.fin_b.count > 0), NPP_E_NULL, "npp_affine_add_fin_multi: job %d: fin_b without b", i);
+    if (!same_shape(&q.out, ref) || q.out.dtype != ref->dtype || (q.b.ptr != nullptr) != has_b || (q.fin_b.stats != nullptr) != fb_ ||
+        (q.mask_bits != nullptr) != mask)
+      return NPP_E_UNSUPPORTED;
+    const bool vk = vec_ok(&q.out) && vec_ok(&q.a) && (!q.b.ptr || vec_ok(&q.b));
+    if (!vk || q.out.c % Vv != 0 || q.out.c / Vv > 256 || q.fin_a.nrep != NPP_STAT_REPLICAS || (fb_ && q.fin_b.nrep != NPP_STAT_REPLICAS))
+      return NPP_E_UNSUPPORTED;
+    if (mask && !(q.out.dtype == NPP_BF16 && q.ld_mask >= q.out.c / 8)) return NPP_E_UNSUPPORTED;
+    AffJob& d = js.j[i];
+    d.out = q.out.ptr; d.a = q.a.ptr; d.b = q.b.ptr; d.ldo = q.out.ld; d.lda = q.a.ld; d.ldb = q.b.ptr ? q.b.ld : 0;
+    d.fa = fin_side(&q.fin_a);
+    d.fa.sc = q.fin_a.stats_c > 0 ? q.fin_a.stats_c : (int)q.out.c;
+    d.fb = d.fa;
+    if (fb_) { d.fb = fin_side(&q.fin_b); d.fb.sc = q.fin_b.stats_c > 0 ? q.fin_b.stats_c : (int)q.out.c; }
+    NPP_REQUIRE(d.fa.sc >= q.out.c && d.fb.sc >= q.out.c, NPP_E_SHAPE, "npp_affine_add_fin_multi: stats_c below the channel count");
+    d.relu = q.relu; d.mk = q.mask_bits; d.ldmk = q.ld_mask;
+  }
+  for (int i = njobs; i < BN_MULTI_MAX; ++i) js.j[i] = js.j[0];
+  const int nt = has_b ? 3 : 2;
+  ProfScope prof(NPP_FAM_ELTWISE, ref->dtype, (hipStream_t)stream, 0, (double)npix(ref) * ref->c * esize(ref->dtype) * nt * njobs);
+  const size_t lds = (size_t)(fb_ ? 4 : 2) * ref->c * sizeof(float);
+#define AFM(HB, FB_, MK) \
+    hipLaunchKernelGGL((affine_add_fin_multi_kernel<T, V, HB, FB_, MK>), grid, dim3(256), lds, (hipStream_t)stream, js, (long)npix(ref), (int)ref->c, m)
+#define AFM_ALL(MK)                                                                                                        \
+    do {                                                                                                                   \
+      ColMap m = col_map(ref->c, V);                                                                                       \
+      dim3 grid = col_grid_ew(m, npix(ref));                                                                               \
+      if (grid.x > 1024) grid.x = 1024;                                                                                    \
+      grid.z = (unsigned)njobs;                                                                                            \
+      if (has_b) { if (fb_) AFM(true, true, MK); else AFM(true, false, MK); }                                              \
+      else AFM(false, false, MK);                                                                                          \
+    } while (0)
+  if (ref->dtype == NPP_BF16) {
+    typedef bf16_t T;
+    constexpr int V = 8;
+    if (mask) AFM_ALL(true); else AFM_ALL(false);
+  } else {
+    typedef float T;
+    constexpr int V = 4;
+    if (mask) return NPP_E_UNSUPPORTED;
+    AFM_ALL(false);
+  }
+#undef AFM_ALL
+#undef AFM
+  return npp_check_launch("affine_add_fin_multi");
+}
+
+static int bwd_jobs_fill(const NppBnBwdJob* jobs, int njobs, BwdJobs& js, bool& two, bool& has_ro, const char* who, bool need_out) {
+  NPP_REQUIRE(jobs && njobs >= 1, NPP_E_NULL, "%s: no jobs", who);
+  if (njobs > BN_MULTI_MAX) return NPP_E_UNSUPPORTED;
+  const NppTensor* ref = &jobs[0].dout;
+  two = jobs[0].yb.ptr != nullptr;
+  has_ro = jobs[0].relu_out.ptr != nullptr;
+  for (int i = 0; i < njobs; ++i) {
+    const NppBnBwdJob& q = jobs[i];
+    NPP_REQUIRE(q.dout.ptr && q.ya.ptr && q.mi_a && q.sums && q.count > 0 && (!q.yb.ptr || q.mi_b), NPP_E_NULL, "%s: job %d: null pointer", who, i);
+    NPP_REQUIRE(same_shape(&q.dout, &q.ya) && (!q.yb.ptr || same_shape(&q.dout, &q.yb)) && (!q.relu_out.ptr || same_shape(&q.dout, &q.relu_out)),
+                NPP_E_SHAPE, "%s: job %d: shape mismatch", who, i);
+    NPP_REQUIRE(dtype_ok(&q.dout) && q.dout.dtype == q.ya.dtype && (!q.yb.ptr || q.yb.dtype == q.dout.dtype) &&
+                (!q.relu_out.ptr || q.relu_out.dtype == q.dout.dtype), NPP_E_DTYPE, "%s: job %d: dtype mismatch", who, i);
+    if (!same_shape(&q.dout, ref) || q.dout.dtype != ref->dtype || (q.yb.ptr != nullptr) != two || (q.relu_out.ptr != nullptr) != has_ro)
+      return NPP_E_UNSUPPORTED;
+    if (!fused_ok(&q.dout) || !fused_ok(&q.ya) || (two && !fused_ok(&q.yb)) || (has_ro && !fused_ok(&q.relu_out))) return NPP_E_UNSUPPORTED;
+    if (need_out) {
+      NPP_REQUIRE(q.dya.ptr && same_shape(&q.dout, &q.dya) && q.dya.dtype == q.dout.dtype && (!two || (q.dyb.ptr && same_shape(&q.dout, &q.dyb) &&
+                  q.dyb.dtype == q.dout.dtype)), NPP_E_SHAPE, "%s: job %d: bad output tensors", who, i);
+      if (!fused_ok(&q.dya) || (two && !fused_ok(&q.dyb))) return NPP_E_UNSUPPORTED;
+    }
+    BwdJob& d = js.j[i];
+    d.dout = q.dout.ptr; d.ya = q.ya.ptr; d.yb = q.yb.ptr; d.ro = q.relu_out.ptr; d.dya = q.dya.ptr; d.dyb = q.dyb.ptr;
+    d.ldd = q.dout.ld; d.lda = q.ya.ld; d.ldb = q.yb.ptr ? q.yb.ld : 0; d.ldr = q.relu_out.ptr ? q.relu_out.ld : 0;
+    d.ldoa = q.dya.ptr ? q.dya.ld : 0; d.ldob = q.dyb.ptr ? q.dyb.ld : 0;
+    d.fa = BwdFinSide{q.mi_a, q.gamma_a, q.dgamma_a, q.dbeta_a};
+    d.fb = BwdFinSide{q.mi_b, q.gamma_b, q.dgamma_b, q.dbeta_b};
+    d.sums = q.sums; d.inv_count = 1.0 / q.count;
+  }
+  for (int i = njobs; i < BN_MULTI_MAX; ++i) js.j[i] = js.j[0];
+  return NPP_OK;
+}
+
+// sums of job i: zeroed [NPP_STAT_REPLICAS][2C | 3C] doubles (npp_bn_bwd_reduce(2)_acc's layout)
+extern "C" int npp_bn_bwd_reduce_multi(const NppBnBwdJob* jobs, int njobs, int nblocks, void* stream) {
+  BwdJobs js;
+  bool two, has_ro;
+  const int rc = bwd_jobs_fill(jobs, njobs, js, two, has_ro, "npp_bn_bwd_reduce_multi", false);
+  if (rc != NPP_OK) return rc;
+  NPP_REQUIRE(nblocks >= 1 && nblocks <= 65535, NPP_E_SHAPE, "npp_bn_bwd_reduce_multi: bad block count %d", nblocks);
+  const NppTensor* ref = &jobs[0].dout;
+  ProfScope prof(NPP_FAM_BN, ref->dtype, (hipStream_t)stream, 0, (double)npix(ref) * ref->c * esize(ref->dtype) * (two ? 3 : 2) * njobs);
+#define RM(RO_, TWO_) hipLaunchKernelGGL((bn_bwd_reduce_multi_kernel<T, V, RO_, TWO_>), grid, dim3(256), 0, (hipStream_t)stream, js, (long)npix(ref), (int)ref->c, m)
+  NPP_DISPATCH_TV(ref->dtype, true, {
+    ColMap m = col_map(ref->c, V);
+    dim3 grid((unsigned)nblocks, 1, (unsigned)njobs);
+    if (two) { if (has_ro) RM(true, true); else RM(false, true); }
+    else { if (has_ro) RM(true, false); else RM(false, false); }
+  });
+#undef RM
+  return npp_check_launch("bn_bwd_reduce_multi");
+}
+
+extern "C" int npp_bn_bwd_apply_multi(const NppBnBwdJob* jobs, int njobs, void* stream) {
+  BwdJobs js;
+  bool two, has_ro;
+  const int rc = bwd_jobs_fill(jobs, njobs, js, two, has_ro, "npp_bn_bwd_apply_multi", true);
+  if (rc != NPP_OK) return rc;
+  const NppTensor* ref = &jobs[0].dout;
+  ProfScope prof(NPP_FAM_BN, ref->dtype, (hipStream_t)stream, 0, (double)npix(ref) * ref->c * esize(ref->dtype) * (two ? 5 : 3) * njobs);
+  NPP_DISPATCH_TV(ref->dtype, true, {
+    ColMap m = col_map(ref->c, V);
+    dim3 grid = col_grid_ew(m, npix(ref));
+    if (grid.x > 1024) grid.x = 1024;
+    grid.z = (unsigned)njobs;
+    if (two)
+      hipLaunchKernelGGL((bn_bwd_apply_multi_kernel<T, V, true>), grid, dim3(256), (size_t)6 * ref->c * sizeof(float), (hipStream_t)stream, js,
+                         (long)npix(ref), (int)ref->c, m);
+    else
+      hipLaunchKernelGGL((bn_bwd_apply_multi_kernel<T, V, false>), grid, dim3(256), (size_t)3 * ref->c * sizeof(float), (hipStream_t)stream, js,
+                         (long)npix(ref), (int)ref->c, m);
+  });
+  return npp_check_launch("bn_bwd_apply_multi");
 }
 
 // ---- N-sided weighted BatchNorm sum (the search supernet's mixed edge), see mix_bn_fwd_kernel ---------------------------------------

@@ -10,6 +10,11 @@
 //     conflict-free, the hardware's mixed lane groups see at most 2-way conflicts
 //   * operands swapped (C^T accumulators) and conv_g4's epilogue: bias, ReLU-backward mask (bf16 tensor or NPP_MASK8 bits),
 //     accumulate into y (NppConvGeom.relu_in bit 1), BatchNorm sum / sum of squares of the stored values
+//   * round 4 -- merged edges (the three std_conv_3x3 edges that read state 0 of an encoder cell, genotypes.py:30-36, as ONE conv
+//     32 -> 96 and their data gradients as ONE conv 96 -> 32): Cout = 32 * GO output groups share the halo, which is staged once
+//     (the weight taps of group g + 1 replace those of group g behind a barrier, each group runs its own epilogue); Cin = 32 * GI
+//     input groups accumulate into the same registers (halo and taps of each group staged in turn): the sum over the three edges'
+//     gradients costs no read-add-store pass.
 #include "common.h"
 #include "conv_params.h"
 #include <stdlib.h>
@@ -26,7 +31,7 @@ constexpr int C32_RED = C32_HALO_BYTES + C32_W_BYTES;             // statistics 
 constexpr int C32_LDS = C32_RED + 4 * 32 * 2 * 4;
 
 template <bool RELU>
-__global__ __launch_bounds__(256) void conv_c32_kernel(IgemmParams p, int tiles_y, int tiles_x) {
+__global__ __launch_bounds__(256) void conv_c32_kernel(IgemmParams p, int tiles_y, int tiles_x, int GI, int GO) {
   constexpr int MI = C32_TH / 4;      // tile rows per wave (3)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63;
@@ -42,14 +47,26 @@ __global__ __launch_bounds__(256) void conv_c32_kernel(IgemmParams p, int tiles_
     y0 = ty * C32_TH;
     x0 = (r - ty * tiles_x) * 16;
   }
-  // ---- stage the halo (ReLU on the way) and the nine weight taps ------------------------------------------------------------
+  const int lrow = lane & 15, lk = lane >> 4;
+  const unsigned abase = (unsigned)((wave * MI * C32_HW + lrow) * C32_PITCH + lk * 16);
+  const unsigned bbase = (unsigned)(C32_HALO_BYTES + lrow * C32_PITCH + lk * 16);
+  for (int go = 0; go < GO; ++go) {
+  f32x4c acc[MI][2];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4c{0.f, 0.f, 0.f, 0.f};
+  for (int gi = 0; gi < GI; ++gi) {
+  if (go + gi > 0) __syncthreads();      // every wave is done with the previous group's halo / taps
+  // ---- stage the halo of input group gi (ReLU on the way; once for all output groups when GI == 1) and the nine weight taps -----
+  if (go == 0 || GI > 1)
   for (int i = t; i < C32_HALO_PX * 4; i += 256) {
     const int px = i >> 2, g = i & 3;
     const int hy = px / C32_HW, hx = px - hy * C32_HW;
     const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
     u32x4 v = {0u, 0u, 0u, 0u};
     if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
-      v = *reinterpret_cast<const u32x4*>(xg + (((long)img * p.H + gy) * p.W + gx) * p.ldx + g * 8);
+      v = *reinterpret_cast<const u32x4*>(xg + (((long)img * p.H + gy) * p.W + gx) * p.ldx + gi * 32 + g * 8);
       if (RELU) {
         const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         v = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
@@ -60,19 +77,11 @@ __global__ __launch_bounds__(256) void conv_c32_kernel(IgemmParams p, int tiles_
   for (int i = t; i < 9 * 32 * 4; i += 256) {
     const int g = i & 3, row = i >> 2;            // row = tap * 32 + co
     const int tap = row >> 5, co = row & 31;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(wg + (long)co * p.Kpad + tap * 32 + g * 8);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(wg + (long)(go * 32 + co) * p.Kpad + tap * p.Cp + gi * 32 + g * 8);
     *reinterpret_cast<u32x4*>(smem + C32_HALO_BYTES + row * C32_PITCH + g * 16) = v;
   }
   __syncthreads();
   // ---- nine taps from LDS ----------------------------------------------------------------------------------------------------
-  const int lrow = lane & 15, lk = lane >> 4;
-  f32x4c acc[MI][2];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4c{0.f, 0.f, 0.f, 0.f};
-  const unsigned abase = (unsigned)((wave * MI * C32_HW + lrow) * C32_PITCH + lk * 16);
-  const unsigned bbase = (unsigned)(C32_HALO_BYTES + lrow * C32_PITCH + lk * 16);
 #pragma unroll
   for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
@@ -92,18 +101,19 @@ __global__ __launch_bounds__(256) void conv_c32_kernel(IgemmParams p, int tiles_
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ni]), __builtin_bit_cast(bf16x8, fa[mi]),
                                                                 acc[mi][ni], 0, 0, 0);
     }
+  }  // input groups
   // ---- epilogue: acc[mi][ni][j] = C[pixel (y0 + wave*MI + mi, x0 + lrow)][channel ni*16 + 4*lk + j] --------------------------
   bf16_t* __restrict__ yg = reinterpret_cast<bf16_t*>(p.y);
   const bf16_t* __restrict__ mg = reinterpret_cast<const bf16_t*>(p.mask);
   const bool want_stats = p.stats != nullptr;
-  const int chb = (lk & 1) * 16 + (lk >> 1) * 8;
+  const int chb = go * 32 + (lk & 1) * 16 + (lk >> 1) * 8;
   float* red = reinterpret_cast<float*>(smem + C32_RED);
   const int gx = x0 + lrow;
   const bool col_ok = gx < p.W;
   f32x4c bias[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
-    bias[h] = p.bias ? *reinterpret_cast<const f32x4c*>(p.bias + h * 16 + lk * 4) : f32x4c{0.f, 0.f, 0.f, 0.f};
+    bias[h] = p.bias ? *reinterpret_cast<const f32x4c*>(p.bias + go * 32 + h * 16 + lk * 4) : f32x4c{0.f, 0.f, 0.f, 0.f};
   float ssum[2][4], ssq[2][4];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -173,10 +183,11 @@ __global__ __launch_bounds__(256) void conv_c32_kernel(IgemmParams p, int tiles_
 #pragma unroll
       for (int w = 0; w < 4; ++w) { s += red[(w * 32 + t) * 2]; q += red[(w * 32 + t) * 2 + 1]; }
       double* st = p.stats + (long)(blockIdx.x % NPP_STAT_REPLICAS) * 2 * p.Cout;
-      atomicAdd(st + t, (double)s);
-      atomicAdd(st + p.Cout + t, (double)q);
+      atomicAdd(st + go * 32 + t, (double)s);
+      atomicAdd(st + p.Cout + go * 32 + t, (double)q);
     }
   }
+  }  // output groups
 }
 
 }  // namespace
@@ -187,7 +198,10 @@ bool conv_c32_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (disabled || dtype != NPP_BF16) return false;
   if (p.KH != 3 || p.KW != 3 || p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.uph != 1 || p.upw != 1) return false;
   if (p.ph != 1 || p.pw != 1 || p.OH != p.H || p.OW != p.W) return false;
-  if (p.Cin != 32 || p.Cout != 32 || p.Cp != 32 || p.ldx % 8 != 0 || !p.vec_io || (p.mask && p.stats)) return false;
+  // 32 -> 32, or the merged edges of a cell: 32 -> 32 * GO (shared input) / 32 * GI -> 32 (summed data gradients)
+  if (p.Cin % 32 != 0 || p.Cout % 32 != 0 || p.Cp != p.Cin || p.ldx % 8 != 0 || !p.vec_io || (p.mask && p.stats)) return false;
+  const int GI = p.Cin / 32, GO = p.Cout / 32;
+  if (GI < 1 || GO < 1 || GI > 4 || GO > 4 || (GI > 1 && GO > 1)) return false;
   if (p.W % 16 != 0 || p.H < 1) return false;
   // (small maps: the tiles must fill the chip -- below ~2 tiles per CU conv_g4's 64-pixel tiles spread the work better)
   const int tiles_y = (p.H + C32_TH - 1) / C32_TH, tiles_x = p.W / 16;
@@ -201,7 +215,7 @@ bool conv_c32_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
     if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, C32_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
     raised[v] = true;
   }
-  if (v) hipLaunchKernelGGL(conv_c32_kernel<true>, dim3((unsigned)total), dim3(256), C32_LDS, stream, p, tiles_y, tiles_x);
-  else hipLaunchKernelGGL(conv_c32_kernel<false>, dim3((unsigned)total), dim3(256), C32_LDS, stream, p, tiles_y, tiles_x);
+  if (v) hipLaunchKernelGGL(conv_c32_kernel<true>, dim3((unsigned)total), dim3(256), C32_LDS, stream, p, tiles_y, tiles_x, GI, GO);
+  else hipLaunchKernelGGL(conv_c32_kernel<false>, dim3((unsigned)total), dim3(256), C32_LDS, stream, p, tiles_y, tiles_x, GI, GO);
   return true;
 }

@@ -413,8 +413,8 @@ NPP_DEV void pack_tile(const NppPackJob& j, long tb, float* lds) {
       Elt<T>::st(out + (long)co * kpad + tap * cp + c0 + c, lds[c * taps + tap]);
     }
   } else if (taps == 1) {
-    // [co][ci] -> [ci][co]: 64 x 64 transposes
-    const int cop = (j.cout + 7) / 8 * 8, kpad = (cop + 63) / 64 * 64;
+    // [co][ci] -> [ci][co]: 64 x 64 transposes (co_total > 0: this weight's columns start at co_off of a row of co_total)
+    const int cop = ((j.co_total > 0 ? j.co_total : j.cout) + 7) / 8 * 8, kpad = (cop + 63) / 64 * 64;
     const int citiles = (j.cin + PACK_DG_T1 - 1) / PACK_DG_T1;
     const int co0 = (int)(tb / citiles) * PACK_DG_T1, ci0 = (int)(tb % citiles) * PACK_DG_T1;
     const int nco = min(PACK_DG_T1, j.cout - co0), nci = min(PACK_DG_T1, j.cin - ci0);
@@ -426,10 +426,10 @@ NPP_DEV void pack_tile(const NppPackJob& j, long tb, float* lds) {
     __syncthreads();
     for (int i = t; i < nco * nci; i += 256) {
       const int ci = i / nco, co = i - ci * nco;
-      Elt<T>::st(out + (long)(ci0 + ci) * kpad + co0 + co, lds[co * pitch + ci]);
+      Elt<T>::st(out + (long)(ci0 + ci) * kpad + j.co_off + co0 + co, lds[co * pitch + ci]);
     }
   } else if (taps <= 9) {
-    const int cop = (j.cout + 7) / 8 * 8, kpad = (taps * cop + 63) / 64 * 64;
+    const int cop = ((j.co_total > 0 ? j.co_total : j.cout) + 7) / 8 * 8, kpad = (taps * cop + 63) / 64 * 64;
     const int citiles = (j.cin + PACK_DG_CI - 1) / PACK_DG_CI;
     const int co0 = (int)(tb / citiles) * PACK_DG_CO, ci0 = (int)(tb % citiles) * PACK_DG_CI;
     const int nco = min(PACK_DG_CO, j.cout - co0), nci = min(PACK_DG_CI, j.cin - ci0);
@@ -442,9 +442,10 @@ NPP_DEV void pack_tile(const NppPackJob& j, long tb, float* lds) {
     for (int i = t; i < nci * taps * nco; i += 256) {
       const int co = i % nco, r = i / nco;
       const int tp = r % taps, ci = r / taps;                          // tp = flipped tap index in the image
-      Elt<T>::st(out + (long)(ci0 + ci) * kpad + tp * cop + co0 + co, lds[co * pitch + ci * taps + (taps - 1 - tp)]);
+      Elt<T>::st(out + (long)(ci0 + ci) * kpad + tp * cop + j.co_off + co0 + co, lds[co * pitch + ci * taps + (taps - 1 - tp)]);
     }
   } else {
+    // element-wise fallback (taps > 9): plain jobs only (the host never merges such weights)
     const int cop = (j.cout + 7) / 8 * 8, kpad = (taps * cop + 63) / 64 * 64;
     const long i = tb * 256 + t;
     if (i < (long)j.cin * kpad) {

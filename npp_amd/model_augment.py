@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import _ops as K
 from . import genotypes as gt
 from ._ops import BnSide
-from .operations import OPS, FactorizedReduce, ReLUConvBN, fused_sum, fused_sum_apply, fused_sum_pending, fused_sum_stages, _use_batch_stats  # noqa: F401
+from .operations import OPS, FactorizedReduce, ReLUConvBN, fused_sum, fused_sum_apply, fused_sum_pending, fused_sum_stages, _use_batch_stats, group_wide_edges  # noqa: F401
 from .operations import *  # noqa: F401,F403  (reference does `from models.operations import *`)
 
 BN_MOMENTUM = 0.1
@@ -113,6 +113,8 @@ class _DagCell(nn.Module):
                 op = nn.Sequential(op, Interpolate(scale_factor=scale))
             self._ops += [op]
         self._indices = indices
+        # edges that apply the same ReLU-conv-BN to the same state run as ONE conv (operations.WideEdges)
+        self._wide_groups = group_wide_edges(self._ops, names, indices, [stride_of(i) for i in indices])
 
     def _run(self, states, concat=None):
         """Runs the nodes; with `concat` (state indices, all of them node outputs) also returns their concatenation, whose
@@ -122,9 +124,12 @@ class _DagCell(nn.Module):
         if concat is not None and all(i >= first for i in concat) and len(set(concat)) == len(concat):
             cb = K.ConcatBuffer(len(concat))
             pos = {idx: k for k, idx in enumerate(concat)}
-        if K.SYNC_WAVES and K.helper_stream_for_edge() is None:
-            # SyncBatchNorm: every node whose inputs exist runs its two edges BEFORE any of their BatchNorms is applied, so the
-            # statistics of the whole wave (nodes 0 + 1, then 2 + 3 in the encoder's cells) travel in ONE exchange
+        if (K.SYNC_WAVES or K.BN_MULTI) and K.helper_stream_for_edge() is None:
+            # Every node whose inputs exist runs its two edges BEFORE any of their BatchNorms is applied (nodes 2 + 3, then 4 + 5 of
+            # an encoder cell, model_augment.py:48-62).  SyncBatchNorm: the statistics of the whole wave travel in ONE exchange.
+            # Local BatchNorm: the applies of the wave are ONE launch (K.bn_add_multi -> npp_affine_add_fin_multi) and so are their
+            # backward reduces and applies -- the wave's nodes are independent and equal in shape.
+            local = not K.SYNC_WAVES
             i = 0
             while i < self._steps:
                 have, j, wave = len(states), i, []
@@ -135,7 +140,13 @@ class _DagCell(nn.Module):
                 k = 0
                 while k < len(wave):
                     slot = lambda n_: cb.slot(pos[n_]) if cb is not None and n_ in pos else None      # noqa: E731
-                    if K.BN_PAIRS and k + 1 < len(wave):      # two nodes of the wave as one autograd node (one backward exchange)
+                    if local and k + 1 < len(wave):           # the rest of the wave (at most 4 nodes) as one autograd node, one launch
+                        grp = wave[k:k + K.BN_MULTI_MAX]
+                        n0 = len(states)
+                        states.extend(K.bn_add_multi([(a_, b_, False, a_.bn.training if a_.bn is not None else False, slot(n0 + q))
+                                                      for q, (a_, b_) in enumerate(grp)]))
+                        k += len(grp)
+                    elif K.BN_PAIRS and k + 1 < len(wave):    # two nodes of the wave as one autograd node (one backward exchange)
                         (a0, b0), (a1, b1) = wave[k], wave[k + 1]
                         t0 = a0.bn.training if a0.bn is not None else False
                         t1 = a1.bn.training if a1.bn is not None else False
@@ -163,8 +174,9 @@ def _preprocess_pair(pre0, s0, pre1, s1):
     then travel in ONE exchange (they sit back to back in the stream's statistics pool and the first apply flushes both)."""
     from .operations import pending_of
     a, b = pending_of(pre0, s0), pending_of(pre1, s1)
-    if K.SYNC_WAVES and K.BN_PAIRS and a.bn is not None and b.bn is not None:
-        # ... and as ONE autograd node, so that their backward passes share one exchange as well (_ops._BnAddPair)
+    if ((K.SYNC_WAVES and K.BN_PAIRS) or (not K.SYNC_WAVES and K.BN_MULTI)) and a.bn is not None and b.bn is not None:
+        # ... and as ONE autograd node, so that their backward passes share one exchange as well (_ops._BnAddPair); with local
+        # statistics the two applies -- and the two backward passes -- are one launch each
         return list(K.bn_add_pair((a, None, False, a.bn.training, None), (b, None, False, b.bn.training, None)))
     outs = []
     for side in (a, b):
@@ -265,7 +277,13 @@ class _FuseCell(_DagCell):
         else:
             # the three preprocessed inputs are returned concatenated (fea1): they are written into that buffer directly
             cb1 = K.ConcatBuffer(3) if all(isinstance(m, ReLUConvBN) for m in pre) else None
-            outs = [pre[i](ins[i], out=cb1.slot(i)) if cb1 is not None else pre[i](ins[i]) for i in range(3)]
+            if cb1 is not None and K.BN_MULTI and not K.SYNC_WAVES:
+                # the three convs first, then their BatchNorm applies as ONE launch (and one reduce + one apply launch backward)
+                from .operations import pending_of
+                sides = [pending_of(pre[i], ins[i]) for i in range(3)]
+                outs = K.bn_add_multi([(sides[i], None, False, sides[i].bn.training, cb1.slot(i)) for i in range(3)])
+            else:
+                outs = [pre[i](ins[i], out=cb1.slot(i)) if cb1 is not None else pre[i](ins[i]) for i in range(3)]
         if self.order == 0:
             # F.interpolate(scale_factor=4/2) with the default (nearest) mode, model_augment.py:167-169
             raise NotImplementedError("order == 0 fuse cells are never built by Network (model_augment.py:357-363)")
@@ -540,8 +558,9 @@ class Network(nn.Module):
             for m in self.modules():
                 if isinstance(m, SE_Block):
                     skip.update((id(m.conv1.weight), id(m.conv2.weight)))
-            self._packer = K.WeightPacker(m.weight for m in self.modules()
-                                          if isinstance(m, nn.Conv2d) and m.groups == 1 and id(m.weight) not in skip)
+            groups = [g for m in self.modules() for g in getattr(m, "_wide_groups", ())] if K.WIDE else []
+            self._packer = K.WeightPacker((m.weight for m in self.modules()
+                                           if isinstance(m, nn.Conv2d) and m.groups == 1 and id(m.weight) not in skip), groups)
         self._packer.pack_if_stale(dt, x.device, force=self.training)
         if self.training:
             K.note_training_step()      # an optimizer step probably follows: the next eval forward must repack

@@ -155,11 +155,71 @@ class ReLUConvBN(_BnOp):
             nn.Conv2d(C_in, C_out, kernel_size, stride, padding, bias=False),
             nn.BatchNorm2d(C_out, affine=affine, momentum=BN_MOMENTUM))
 
+    _wide = None      # (WideEdges, index): this edge shares its input and geometry with other edges of its cell (see WideEdges)
+
     def pending(self, x):
+        if self._wide is not None and K.WIDE:
+            side = self._wide[0].pending(self._wide[1], x)
+            if side is not None:
+                return side
         conv, bn = self.net[1], self.net[2]
         y, st = K.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, relu_in=True,
                          want_stats=_use_batch_stats(bn))
         return BnSide(y, bn, st)
+
+
+class WideEdges(K.WideGroup):
+    """The ReLUConvBN edges of one cell that apply the same conv geometry to the same state (genotypes.py:30-54: e.g. the three
+    `std_conv_3x3` on state 0 of ENCODER.normal): the first of them to be asked runs ONE conv C -> m C for all (K.conv2d_wide) and the
+    others pick up their channel slice.  Anything that does not fit -- a different input object, SyncBatchNorm statistics, mixed
+    train / eval BatchNorms -- returns None and the edge runs on its own."""
+
+    def __init__(self, ops):
+        super().__init__([op.net[1] for op in ops])
+        self.ops = list(ops)
+        for k, op in enumerate(self.ops):
+            op._wide = (self, k)
+
+    @staticmethod
+    def mergeable(op) -> bool:
+        if type(op) not in (ReLUConvBN, StdConv):
+            return False
+        conv = op.net[1]
+        k, c = conv.kernel_size[0], conv.out_channels
+        # (channel counts the LDS-DMA kernels take for C -> m C and m C -> C: multiples of 64, or 32 for the 3x3 of conv_c32)
+        return (conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+                and conv.kernel_size[0] == conv.kernel_size[1] and conv.in_channels == c
+                and (c % 64 == 0 or (c == 32 and k == 3)))
+
+    def pending(self, k, x):
+        st = self.calls
+        if st is None or st[0] is not x:
+            if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4):
+                return None
+            bns = [op.net[2] for op in self.ops]
+            want = {_use_batch_stats(bn) for bn in bns}
+            if len(want) != 1 or 2 in want or len({bn.training for bn in bns}) != 1:
+                return None
+            conv = self.convs[0]
+            ys, svs, sc, slots = K.conv2d_wide(x, self, conv.padding, True, want.pop())
+            sides = [BnSide(ys[i], bns[i], svs[i], stats_c=sc if svs[i] is not None else 0, gslot=slots[i])
+                     for i in range(len(bns))]
+            self.calls = st = [x, sides]
+        side, st[1][k] = st[1][k], None
+        if all(sd is None for sd in st[1]):
+            self.calls = None
+        return side
+
+
+def group_wide_edges(ops, names, indices, strides):
+    """WideEdges for every set of >= 2 mergeable edges of a cell with the same (primitive, input state); `ops` may be wrapped in an
+    nn.Sequential(op, Interpolate) (decoder / fusion cells)."""
+    by = {}
+    for op, name, idx, stride in zip(ops, names, indices, strides):
+        base = op[0] if isinstance(op, nn.Sequential) else op
+        if stride == 1 and WideEdges.mergeable(base):
+            by.setdefault((name, idx), []).append(base)
+    return [WideEdges(v) for v in by.values() if len(v) >= 2]
 
 
 class DilConv(_BnOp):

@@ -43,7 +43,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.NppTensor) == 56          # void* + 5 x int64 + int32 + pad
     assert C.sizeof(_lib.NppConvGeom) == 44        # 11 x int32
     assert C.sizeof(_lib.NppAdamJob) == 64
-    assert C.sizeof(_lib.NppPackJob) == 48
+    assert C.sizeof(_lib.NppPackJob) == 56
     assert C.sizeof(_lib.NppBnFinalizeArgs) == 88  # 8 pointers + double + int32 + 2 floats + pad
 
 

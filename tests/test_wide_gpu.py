@@ -1,0 +1,217 @@
+"""Merged edges (npp_amd.operations.WideEdges / _ops.conv2d_wide): the ReLU-conv-BN edges of a cell that read the same state run as
+ONE conv C -> m C forward and ONE conv m C -> C data gradient (reference: models/genotypes.py:30-54 names the same primitive on the
+same state several times; models/model_augment.py:48-62 runs each edge on its own).
+
+Checked against a plain fp32 PyTorch-CPU restatement of `sum_k r_k * BatchNorm_k(conv_k(relu(x)))` (outputs, dx, every weight /
+gamma / beta gradient, running statistics) AND against the same modules with merging switched off (K.WIDE = False), on every
+kernel family the merged shapes reach: conv_c32 with output / input groups (32 -> 96, 96 -> 32), conv_g4 / conv_h3 (64 k), 1x1."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+from tests.helpers import rel_err, rel_l2  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(C, k, m, seed):
+    from npp_amd.operations import ReLUConvBN, WideEdges
+    g = torch.Generator().manual_seed(seed)
+    ops = []
+    for i in range(m):
+        op = ReLUConvBN(C, C, k, 1, k // 2, affine=True)
+        with torch.no_grad():
+            op.net[1].weight.copy_(torch.randn(C, C, k, k, generator=g) * (0.3 / (C * k * k) ** 0.5) * 3)
+            op.net[2].weight.copy_(torch.rand(C, generator=g) + 0.5)
+            op.net[2].bias.copy_(torch.randn(C, generator=g) * 0.2)
+        ops.append(op)
+    return ops, WideEdges
+
+
+def _reference(ops, x, rs):
+    """fp32 torch-CPU: loss = sum_k (r_k * BN_k(conv_k(relu(x)))).sum(); returns ys, dx, param grads, running stats."""
+    x = x.clone().requires_grad_(True)
+    ys, params = [], []
+    for op, r in zip(ops, rs):
+        w = op.net[1].weight.detach().clone().requires_grad_(True)
+        ga = op.net[2].weight.detach().clone().requires_grad_(True)
+        be = op.net[2].bias.detach().clone().requires_grad_(True)
+        rm, rv = torch.zeros_like(ga), torch.ones_like(ga)
+        y = F.batch_norm(F.conv2d(F.relu(x), w, None, 1, w.shape[2] // 2), rm, rv, ga, be, True, 0.1, 1e-5)
+        ys.append(y)
+        params.append((w, ga, be, rm, rv))
+    loss = sum((y * r).sum() for y, r in zip(ys, rs))
+    loss.backward()
+    return [y.detach() for y in ys], x.grad, params
+
+
+def _run_hip(ops, x_cpu, rs_cpu, dtype, wide, dev):
+    from npp_amd import _ops as K
+    import copy
+    ops = [copy.deepcopy(op).to(dev).train() for op in ops]
+    from npp_amd.operations import WideEdges
+    if wide:
+        WideEdges(ops)
+    K.fan_reset()
+    K.WIDE = bool(wide)
+    try:
+        leaf = x_cpu.to(dev).requires_grad_(True)
+        x = K.cast(leaf.contiguous(memory_format=torch.channels_last), dtype)
+        x = K.bn_add(K.BnSide(x), None)            # (a produced tensor, with a ReLU bit-mask in bf16, as a cell state is)
+        before = list(K.WIDE_STATS)
+        sides = [op.pending(x) for op in ops]
+        ys = [K.bn_add(sd, None, relu=False, training=True) for sd in sides]
+        loss = sum((y.float() * r.to(dev)).sum() for y, r in zip(ys, rs_cpu))
+        loss.backward()
+        torch.cuda.synchronize()
+        delta = [a - b for a, b in zip(K.WIDE_STATS, before)]
+    finally:
+        K.WIDE = True
+        K.fan_reset()
+    outs = [y.detach().float().cpu() for y in ys]
+    grads = [(op.net[1].weight.grad.cpu(), op.net[2].weight.grad.cpu(), op.net[2].bias.grad.cpu(),
+              op.net[2].running_mean.cpu(), op.net[2].running_var.cpu()) for op in ops]
+    return outs, leaf.grad.float().cpu(), grads, delta
+
+
+CASES = [
+    # C, k, m, H, N
+    (32, 3, 3, 96, 6),      # conv_c32: three output groups forward, three input groups in the data gradient (288 tiles)
+    (32, 3, 2, 96, 6),      # conv_c32, two groups (DECODER.upsample2's pair at 96^2)
+    (32, 3, 3, 20, 2),      # ... and a map conv_c32 does not take (the generic kernel: 96 channels fit no LDS-DMA tile)
+    (64, 3, 3, 24, 2),      # conv_g4 64 -> 192 / 192 -> 64
+    (128, 3, 2, 24, 2),     # FUSION's pairs (conv_h3 at full size, conv_g4 here)
+    (128, 1, 3, 12, 4),     # DECODER.upsample1's three 1x1 on one state
+    (64, 1, 2, 24, 2),
+    (256, 3, 3, 12, 2),     # ENCODER stage 3
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,k,m,H,N", CASES)
+def test_merged_edges_match_torch_and_the_separate_edges(C, k, m, H, N, dtype):
+    dev = torch.device("cuda:0")
+    ops, _ = _make(C, k, m, seed=C + k + m)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, C, H, H, generator=g)
+    rs = [torch.randn(N, C, H, H, generator=g) / (N * H * H) ** 0.5 for _ in range(m)]
+    ref_y, ref_dx, ref_p = _reference(ops, x, rs)
+    w_y, w_dx, w_p, delta = _run_hip(ops, x, rs, dtype, True, dev)
+    s_y, s_dx, s_p, delta_s = _run_hip(ops, x, rs, dtype, False, dev)
+    assert delta[0] == 1 and delta[1] == 1 and delta[2] == 0, f"one merged forward, one in-place merged data gradient: {delta}"
+    assert delta_s == [0, 0, 0]
+    f32 = dtype == torch.float32
+    tol_y, tol_g = (2e-4, 5e-4) if f32 else (3e-2, 4e-2)
+    err = rel_err if f32 else rel_l2
+    for k_ in range(m):
+        assert err(w_y[k_], ref_y[k_]) < tol_y, ("y", k_, err(w_y[k_], ref_y[k_]))
+        for j, name in enumerate(("dw", "dgamma", "dbeta", "running_mean", "running_var")):
+            ref = ref_p[k_][j].grad if j < 3 else ref_p[k_][j]
+            e = err(w_p[k_][j], ref)
+            assert e < tol_g, (name, k_, e)
+            # ... and the merged launch changes nothing but the order of a sum: as close to the separate edges as those are to torch
+            assert err(w_p[k_][j], s_p[k_][j]) < tol_g, (name, "vs separate", k_)
+        assert err(w_y[k_], s_y[k_]) < (1e-6 if f32 else 1e-2), ("y vs separate", k_)
+    assert err(w_dx, ref_dx) < tol_g, ("dx", err(w_dx, ref_dx))
+    assert err(w_dx, s_dx) < (1e-5 if f32 else 2e-2), ("dx vs separate", err(w_dx, s_dx))
+
+
+def test_fixed_genotype_merges_its_duplicated_edges():
+    """ENCODER.normal: three std_conv_3x3 on state 0; DECODER.upsample1: three + two std_conv_1x1; FUSION: std_conv_3x3 pairs
+    (genotypes.py:30-54) -- the groups the network builds, and the state-dict contract untouched."""
+    from types import SimpleNamespace as NS
+    from npp_amd.model_augment import Network
+    cfg = NS(DATASET=NS(NUM_CLASSES=20, NUM_JOINTS=16), TRAIN=NS(LAYERS=16, INIT_CHANNELS=64),
+             MODEL=NS(DECONV_WITH_BIAS=False, HEAD='PSP', REFINE_LAYERS=1))
+    net = Network(cfg)
+    groups = [g for mod in net.modules() for g in getattr(mod, "_wide_groups", ())]
+    normal = [c for c in list(net.cells1) + list(net.cells2) if len(c._wide_groups) == 1 and len(c._wide_groups[0].convs) == 3]
+    assert len(normal) == 26                                   # 13 normal cells per branch
+    assert sum(len(g.convs) - 1 for g in groups) >= 70          # launches saved per direction
+    assert len(net.state_dict()) == 3226                        # names and count as the reference's (tests/test_ddp_cpu.py holds the list)
+
+
+def _bn_items(n, kind, C, H, N, dtype, dev, seed):
+    """n independent fused-add items: kind 'two' = BN(a) + BN(b), 'plain' = BN(a) + b, 'one' = BN(a)."""
+    from npp_amd import _ops as K
+    g = torch.Generator().manual_seed(seed)
+    items = []
+    for k in range(n):
+        bns = [nn.BatchNorm2d(C).to(dev).train() for _ in range(2)]
+        for bn in bns:
+            with torch.no_grad():
+                bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+                bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        raw = [torch.randn(N, C, H, H, generator=g).to(dev).requires_grad_(True) for _ in range(2)]
+        items.append((bns, raw))
+    return items
+
+
+def _run_bn_items(items, kind, dtype, multi, dev, rs):
+    from npp_amd import _ops as K
+    K.fan_reset()
+    K.BN_MULTI = bool(multi)
+    try:
+        specs = []
+        for (bns, raw) in items:
+            for r in raw:
+                r.grad = None
+            for bn in bns:
+                bn.weight.grad = bn.bias.grad = None
+                bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+            xs = [K.cast(r.contiguous(memory_format=torch.channels_last), dtype) for r in raw]
+            sa = K.BnSide(xs[0], bns[0], None, private=True)
+            sb = None
+            if kind == "two":
+                sb = K.BnSide(xs[1], bns[1], None, private=True)
+            elif kind == "plain":
+                sb = K.BnSide(xs[1], private=True)
+            specs.append((sa, sb, False, True, None))
+        before = list(K.MULTI_STATS)
+        ys = K.bn_add_multi(specs)
+        loss = sum((y.float() * r).sum() for y, r in zip(ys, rs))
+        loss.backward()
+        torch.cuda.synchronize()
+        delta = [a - b for a, b in zip(K.MULTI_STATS, before)]
+    finally:
+        K.BN_MULTI = True
+        K.fan_reset()
+    out = []
+    for y, (bns, raw) in zip(ys, items):
+        out.append([y.detach().float().cpu()] + [r.grad.float().cpu() if r.grad is not None else None for r in raw] +
+                   [t.detach().float().cpu().clone() for bn in bns for t in (bn.weight.grad if bn.weight.grad is not None else torch.zeros(1),
+                                                                              bn.bias.grad if bn.bias.grad is not None else torch.zeros(1),
+                                                                              bn.running_mean, bn.running_var)])
+    return out, delta
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,kind,C,H,N", [(2, "two", 64, 24, 4), (2, "plain", 128, 12, 4), (3, "one", 128, 48, 2), (2, "one", 32, 96, 2),
+                                          (4, "two", 256, 6, 2), (3, "plain", 64, 12, 2)])
+def test_multi_job_batchnorm_launches_equal_the_single_launches(n, kind, C, H, N, dtype):
+    """npp_affine_add_fin_multi / npp_bn_bwd_reduce_multi / npp_bn_bwd_apply_multi run the bodies of the single-job kernels per
+    job: outputs, raw-input gradients, gamma / beta gradients and running statistics must agree with n separate launches to the
+    last bit of the storage type (the f64 reductions differ only in the order of their atomic adds)."""
+    dev = torch.device("cuda:0")
+    items = _bn_items(n, kind, C, H, N, dtype, dev, seed=n * 7 + C)
+    g = torch.Generator().manual_seed(3)
+    rs = [torch.randn(N, C, H, H, generator=g).to(dev) for _ in range(n)]
+    m_out, m_delta = _run_bn_items(items, kind, dtype, True, dev, rs)
+    s_out, s_delta = _run_bn_items(items, kind, dtype, False, dev, rs)
+    assert m_delta == [1, 1, 1], f"one apply, one reduce, one backward-apply launch for all {n} items: {m_delta}"
+    assert s_delta == [0, 0, 0]
+    tol = 2e-6 if dtype == torch.float32 else 1e-2
+    for k in range(n):
+        for q, (a, b) in enumerate(zip(m_out[k], s_out[k])):
+            if a is None or b is None:
+                assert a is None and b is None
+                continue
+            assert rel_err(a, b) <= tol, (k, q, rel_err(a, b))
