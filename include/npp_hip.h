@@ -371,6 +371,18 @@ int npp_se_bwd(const NppTensor* dout, const NppTensor* x, const float* w1, const
                const float* gate, NppTensor* dx, float* dz, float* ws, void* stream);
 int npp_se_bwd_acc(const NppTensor* dout, const NppTensor* x, const float* w1, const float* w2, const float* hidden,
                    const float* gate, NppTensor* dx, float* dz, float* ws, int accumulate /* dx += */, void* stream);
+/* the same for the PAIR of SE gates an encoder cell applies to one state (ENCODER.normal / .reduce: `se_connect` twice on state 1,
+ * genotypes.py:30-36; operations.py:105-129): njobs = 1 or 2 gates with their own weights on the SAME x -- one squeeze pass and one
+ * gate + scale launch forward; backward one partial-sum launch and one apply launch that writes dx = sum_j d(x * gate_j)/dx dout_j
+ * (no accumulate pass between the two).  ws: npp_se_ws_floats(N, C) floats forward, njobs times that backward. */
+typedef struct NppSeFwdJob {
+  NppTensor y; const float* w1; const float* b1; const float* w2; const float* b2; float* pooled; float* hidden; float* gate;
+} NppSeFwdJob;
+typedef struct NppSeBwdJob {
+  NppTensor dout; const float* w1; const float* w2; const float* hidden; const float* gate; float* dz;
+} NppSeBwdJob;
+int npp_se_fwd_multi(const NppTensor* x, const NppSeFwdJob* jobs, int njobs, float* ws, void* stream);
+int npp_se_bwd_multi(const NppTensor* x, const NppSeBwdJob* jobs, int njobs, NppTensor* dx, float* ws, int accumulate, void* stream);
 typedef struct NppSeGradItem {
   const float* pooled; const float* hidden; const float* dz;
   float* dw1; float* db1; float* dw2; float* db2;      /* conv1.weight [C/2][C], conv1.bias, conv2.weight [C][C/2], conv2.bias */

@@ -73,6 +73,16 @@ class NppBnBwdJob(C.Structure):
                 ("sums", C.c_void_p), ("count", C.c_double)]
 
 
+class NppSeFwdJob(C.Structure):
+    _fields_ = [("y", NppTensor), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("pooled", C.c_void_p), ("hidden", C.c_void_p), ("gate", C.c_void_p)]
+
+
+class NppSeBwdJob(C.Structure):
+    _fields_ = [("dout", NppTensor), ("w1", C.c_void_p), ("w2", C.c_void_p), ("hidden", C.c_void_p), ("gate", C.c_void_p),
+                ("dz", C.c_void_p)]
+
+
 class NppMixSide(C.Structure):
     _fields_ = [("x", NppTensor), ("dx", NppTensor), ("stats", C.c_void_p), ("mean_invstd", C.c_void_p), ("running_mean", C.c_void_p),
                 ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float)]
@@ -129,6 +139,8 @@ _SIGS = {
     "npp_bn_bwd_apply": [_T, _T, _T, _P, _T, _P],
     "npp_scale_mask": [_T, _P, _T, _T, _P],
     "npp_bn_fused_ok": [_T],
+    "npp_se_fwd_multi": [_T, _P, C.c_int, _P, _P],
+    "npp_se_bwd_multi": [_T, _P, C.c_int, _T, _P, C.c_int, _P],
     "npp_affine_add_fin_multi": [_P, C.c_int, _P],
     "npp_bn_bwd_reduce_multi": [_P, C.c_int, C.c_int, _P],
     "npp_bn_bwd_apply_multi": [_P, C.c_int, _P],

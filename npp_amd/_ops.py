@@ -2735,6 +2735,96 @@ def se_scale(x, w1, b1, w2, b2):
     return _SEScale.apply(xa, w1, b1, w2, b2, fan)
 
 
+class _SEScale2(Function):
+    """Two squeeze-excite gates with their own weights on ONE tensor (ENCODER.normal / .reduce apply `se_connect` to state 1 twice,
+    genotypes.py:30-36): one squeeze pass + one gate-and-scale launch for both; backward one partial-sum launch and one apply launch
+    that writes the SUM of the two gradients w.r.t. x (npp_se_fwd_multi / npp_se_bwd_multi).  Args: x, then (w1, b1, w2, b2) x 2."""
+
+    @staticmethod
+    def forward(ctx, x, fan, *ws):
+        x = to_nhwc(x)
+        ctx.fan = fan if x.dtype == torch.bfloat16 else None
+        n, c, h, w = x.shape
+        dev = x.device
+        jobs = (L.NppSeFwdJob * 2)()
+        ys, keep, saved = [], [], []
+        for q in range(2):
+            w1, b1, w2, b2 = ws[4 * q:4 * q + 4]
+            w1f, b1f, w2f, b2f = (_f32c(t) for t in (w1, b1, w2, b2))
+            y = new_nhwc(n, c, h, w, x.dtype, dev)
+            st = torch.empty(n * (2 * c + c // 2), dtype=torch.float32, device=dev)
+            pooled, hidden, gate = st[:n * c].view(n, c), st[n * c:n * c + n * (c // 2)].view(n, c // 2), st[n * c + n * (c // 2):].view(n, c)
+            jobs[q] = L.NppSeFwdJob(desc(y), w1f.data_ptr(), b1f.data_ptr(), w2f.data_ptr(), b2f.data_ptr(), pooled.data_ptr(),
+                                    hidden.data_ptr(), gate.data_ptr())
+            ys.append(y)
+            keep.append((w1f, b1f, w2f, b2f))
+            saved += [w1, w2, pooled, hidden, gate, b1, b2]
+        wsb = torch.empty(int(lib().npp_se_ws_floats(n, c)), dtype=torch.float32, device=dev)
+        check(lib().npp_se_fwd_multi(_byref(x), C.cast(jobs, C.c_void_p), 2, wsb.data_ptr(), stream_ptr()), "npp_se_fwd_multi")
+        ctx.save_for_backward(x, *saved)
+        ctx.set_materialize_grads(False)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        x, *rest = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dev = x.device
+        s = stream_ptr()
+        sets = [rest[7 * q:7 * q + 7] for q in range(2)]      # w1, w2, pooled, hidden, gate, b1, b2
+        dys = []
+        for d in (dy0, dy1):
+            if d is None:
+                d = new_nhwc(n, c, h, w, x.dtype, dev, zero=True)
+            d = to_nhwc(d)
+            dys.append(d if d.dtype == x.dtype else cast(d, x.dtype))
+        dx, accumulate = _claim_dx(ctx.fan, x)
+        jobs = (L.NppSeBwdJob * 2)()
+        keep, grads, dzs = [], [], []
+        for q in range(2):
+            w1, w2, pooled, hidden, gate, b1, b2 = sets[q]
+            w1f, w2f = _f32c(w1), _f32c(w2)
+            dz = torch.empty((n, c + c // 2), dtype=torch.float32, device=dev)
+            jobs[q] = L.NppSeBwdJob(desc(dys[q]), w1f.data_ptr(), w2f.data_ptr(), hidden.data_ptr(), gate.data_ptr(), dz.data_ptr())
+            keep.append((w1f, w2f))
+            dzs.append(dz)
+        wsb = torch.empty(2 * int(lib().npp_se_ws_floats(n, c)), dtype=torch.float32, device=dev)
+        check(lib().npp_se_bwd_multi(_byref(x), C.cast(jobs, C.c_void_p), 2, _byref(dx), wsb.data_ptr(), int(accumulate), s),
+              "npp_se_bwd_multi")
+        for q in range(2):
+            w1, w2, pooled, hidden, gate, b1, b2 = sets[q]
+            dw1 = _grad_buf(w1, w1.numel(), dev).view(w1.shape)
+            db1 = _grad_buf(b1, c // 2, dev)
+            dw2 = _grad_buf(w2, w2.numel(), dev).view(w2.shape)
+            db2 = _grad_buf(b2, c, dev)
+            dz = dzs[q]
+            if (DEFER_WGRAD_MAX_PIX > 0 and all(t.dtype == torch.float32 for t in (w1, b1, w2, b2))
+                    and _may_defer(w1) and _may_defer(w2) and _may_defer(b1) and _may_defer(b2)):
+                def alias(t):
+                    return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset(), t.shape, t.stride())
+                _pending_se_grads.append((pooled, hidden, dz, alias(dw1), alias(db1), alias(dw2), alias(db2), n, c,
+                                          torch.cuda.current_stream()))
+            else:
+                it = L.NppSeGradItem(pooled.data_ptr(), hidden.data_ptr(), dz.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
+                                     dw2.data_ptr(), db2.data_ptr(), n, c)
+                check(lib().npp_se_param_grads(C.byref(it), s), "npp_se_param_grads")
+            if dw1.dtype != w1.dtype:
+                dw1, db1, dw2, db2 = dw1.to(w1.dtype), db1.to(b1.dtype), dw2.to(w2.dtype), db2.to(b2.dtype)
+            grads += [dw1, db1, dw2, db2]
+        return (dx, None, *grads)
+
+
+SE_PAIR = os.environ.get("NPP_SE_PAIR", "1") != "0"
+SE_PAIR_STATS = [0]
+
+
+def se_scale_pair(x, params):
+    """params: [(w1, b1, w2, b2)] x 2 -> (y0, y1)."""
+    xa, fan = take_acc(x)
+    SE_PAIR_STATS[0] += 1
+    return _SEScale2.apply(xa, fan, *params[0], *params[1])
+
+
 # --------------------------------------------------------------------------------------------------
 # bilinear (align_corners=True)
 # --------------------------------------------------------------------------------------------------

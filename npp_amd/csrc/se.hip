@@ -18,15 +18,19 @@ namespace {
 constexpr int SE_MAX_SLABS = 16;
 
 // per-(image, slab, channel) partial sums over the slab's pixels.  MODE 0: sum a; MODE 1: sum a * b.
+// (round 4) a second job -- the pair of SE gates an encoder cell applies to ONE state, genotypes.py:30-36: two gradients dout_j
+// against the same x -- rides in the same launch: blockIdx.z = job * N + image; a2 / part2 are job 1's operand and output.
 template <typename T, int V, int MODE>
 __global__ __launch_bounds__(256) void se_part_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb,
                                                       float* __restrict__ part, int HW, int C, int cv, int cols_blk, int rows,
-                                                      int slabs) {
+                                                      int slabs, int N, const T* __restrict__ a2, long lda2, float* __restrict__ part2) {
   __shared__ float red[256 * 8];
   const int t = threadIdx.x;
   const bool active = t < rows * cols_blk;
   const int col = t % cols_blk, row = t / cols_blk;
-  const int n = blockIdx.z;
+  const int job = (int)blockIdx.z >= N ? 1 : 0;
+  const int n = (int)blockIdx.z - job * N;
+  if (job) { a = a2; lda = lda2; part = part2; }
   const int colg = blockIdx.y * cols_blk + col;
   const bool work = active && colg < cv;
   float acc[V];
@@ -155,14 +159,23 @@ NPP_DEV void matvec_cols(const float* __restrict__ W, const float* v, int I, int
   __syncthreads();
 }
 
-// y = x * gate(image); grid (chunks, N).  LDS: pooled[C] | hidden[C/2] | gate[C] | red[256]
+// y = x * gate(image); grid (chunks, N, jobs).  LDS: pooled[C] | hidden[C/2] | gate[C] | red[256]
+// jobs (blockIdx.z): gates with weights of their own on the SAME x and the same squeeze sums `part` (se_part<0> ran once)
+struct SeFwdJob {
+  void* y; long ldy;
+  const float* w1; const float* b1; const float* w2; const float* b2;
+  float* pooled_out; float* hidden_out; float* gate_out;
+};
+struct SeFwdJobs { SeFwdJob j[2]; };
 template <typename T, int V>
-__global__ __launch_bounds__(256) void se_gate_scale_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
-                                                            const float* __restrict__ part, int slabs,
-                                                            const float* __restrict__ w1, const float* __restrict__ b1,
-                                                            const float* __restrict__ w2, const float* __restrict__ b2,
-                                                            float* __restrict__ pooled_out, float* __restrict__ hidden_out,
-                                                            float* __restrict__ gate_out, int HW, int C, int cv) {
+__global__ __launch_bounds__(256) void se_gate_scale_kernel(const T* __restrict__ x, long ldx, SeFwdJobs js,
+                                                            const float* __restrict__ part, int slabs, int HW, int C, int cv) {
+  const SeFwdJob& jb = js.j[blockIdx.z];
+  T* __restrict__ y = reinterpret_cast<T*>(jb.y);
+  const long ldy = jb.ldy;
+  const float* __restrict__ w1 = jb.w1; const float* __restrict__ b1 = jb.b1;
+  const float* __restrict__ w2 = jb.w2; const float* __restrict__ b2 = jb.b2;
+  float* __restrict__ pooled_out = jb.pooled_out; float* __restrict__ hidden_out = jb.hidden_out; float* __restrict__ gate_out = jb.gate_out;
   extern __shared__ float sm[];
   const int Ch = C / 2;
   float* sp = sm;
@@ -214,20 +227,21 @@ __global__ __launch_bounds__(256) void se_gate_scale_kernel(const T* __restrict_
   }
 }
 
-// dx = dout * gate + dpooled / HW with the gate MLP's backward in the prologue.  LDS: dz2[C] | dz1[C/2] | dpool[C] | gate[C] | red[256]
-template <typename T, int V>
-__global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx,
-                                                           const float* __restrict__ part, int slabs,
-                                                           const float* __restrict__ gate, const float* __restrict__ hidden,
-                                                           const float* __restrict__ w1, const float* __restrict__ w2,
-                                                           float* __restrict__ dz_out, int HW, int C, int cv, int accum) {
+// dx = sum_j (dout_j * gate_j + dpooled_j / HW) with the gate MLPs' backward in the prologue; NJ = 1, or 2 for the pair of gates on one
+// state (their gradients w.r.t. x are summed here, no accumulate pass).  LDS per job: dz2[C] | dz1[C/2] | dpool[C] | gate[C]; red[256]
+struct SeBwdJob {
+  const void* dy; long lddy;
+  const float* part; const float* gate; const float* hidden; const float* w1; const float* w2;
+  float* dz_out;
+};
+struct SeBwdJobs { SeBwdJob j[2]; };
+template <typename T, int V, int NJ>
+__global__ __launch_bounds__(256) void se_bwd_apply_kernel(SeBwdJobs js, T* __restrict__ dx, long lddx, int slabs, int HW, int C, int cv,
+                                                           int accum) {
   extern __shared__ float sm[];
   const int Ch = C / 2;
-  float* dz2 = sm;
-  float* dz1 = sm + C;
-  float* dpl = dz1 + Ch;
-  float* sg = dpl + C;
-  float* red = sg + C;
+  const int per_job = 3 * C + Ch;
+  float* red = sm + NJ * per_job;
   const int t = threadIdx.x, n = blockIdx.y;
   const bool first = blockIdx.x == 0;
   const unsigned total = (unsigned)HW * (unsigned)cv;
@@ -235,26 +249,40 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
   const unsigned i0 = blockIdx.x * per, i1 = (i0 + per < total) ? i0 + per : total;
   const FastDiv fd((unsigned)cv);
   const float inv_hw = 1.f / (float)HW;
-  float* dzn = dz_out + (long)n * (C + Ch);
-  for (int c = t; c < C; c += 256) {
-    float s = 0.f;
-    for (int k = 0; k < slabs; ++k) s += part[((long)n * slabs + k) * C + c];
-    const float g = gate[(long)n * C + c];
-    sg[c] = g;
-    const float d = s * g * (1.f - g);
-    dz2[c] = d;
-    if (first) dzn[c] = d;
+#pragma unroll
+  for (int q = 0; q < NJ; ++q) {
+    const SeBwdJob& jb = js.j[q];
+    float* dz2 = sm + q * per_job;
+    float* dz1 = dz2 + C;
+    float* dpl = dz1 + Ch;
+    float* sg = dpl + C;
+    float* dzn = jb.dz_out + (long)n * (C + Ch);
+    for (int c = t; c < C; c += 256) {
+      float s = 0.f;
+      for (int k = 0; k < slabs; ++k) s += jb.part[((long)n * slabs + k) * C + c];
+      const float g = jb.gate[(long)n * C + c];
+      sg[c] = g;
+      const float d = s * g * (1.f - g);
+      dz2[c] = d;
+      if (first) dzn[c] = d;
+    }
+    __syncthreads();
+    // dz1[o] = relu'(hidden[o]) * sum_c w2[c][o] dz2[c]        (w2: [C][Ch])
+    matvec_cols(jb.w2, dz2, C, Ch, red, [&](int o, float s) {
+      s = jb.hidden[(long)n * Ch + o] > 0.f ? s : 0.f;
+      dz1[o] = s;
+      if (first) dzn[C + o] = s;
+    });
+    // dpooled[c] = sum_o w1[o][c] dz1[o]                       (w1: [Ch][C])
+    matvec_cols(jb.w1, dz1, Ch, C, red, [&](int c, float s) { dpl[c] = s * inv_hw; });
   }
-  __syncthreads();
-  // dz1[o] = relu'(hidden[o]) * sum_c w2[c][o] dz2[c]        (w2: [C][Ch])
-  matvec_cols(w2, dz2, C, Ch, red, [&](int o, float s) {
-    s = hidden[(long)n * Ch + o] > 0.f ? s : 0.f;
-    dz1[o] = s;
-    if (first) dzn[C + o] = s;
-  });
-  // dpooled[c] = sum_o w1[o][c] dz1[o]                       (w1: [Ch][C])
-  matvec_cols(w1, dz1, Ch, C, red, [&](int c, float s) { dpl[c] = s * inv_hw; });
-  const T* dyn = dy + (long)n * HW * lddy;
+  const T* dyn0 = reinterpret_cast<const T*>(js.j[0].dy) + (long)n * HW * js.j[0].lddy;
+  const T* dyn1 = NJ > 1 ? reinterpret_cast<const T*>(js.j[1].dy) + (long)n * HW * js.j[1].lddy : dyn0;
+  const long ld0 = js.j[0].lddy, ld1 = NJ > 1 ? js.j[1].lddy : ld0;
+  const float* sg0 = sm + 2 * C + Ch;
+  const float* dp0 = sm + C + Ch;
+  const float* sg1 = sg0 + per_job;
+  const float* dp1 = dp0 + per_job;
   T* dxn = dx + (long)n * HW * lddx;
   for (unsigned i = i0 + t; i < i1; i += 512) {
     const unsigned i2 = i + 256;
@@ -264,12 +292,21 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
     fast_divmod(i, fd, p, c);
     fast_divmod(k2, fd, p2, c2);
     float v[V], w[V];
-    ldv<T, V>(dyn + (long)p * lddy + c * V, v);
-    ldv<T, V>(dyn + (long)p2 * lddy + c2 * V, w);
+    ldv<T, V>(dyn0 + (long)p * ld0 + c * V, v);
+    ldv<T, V>(dyn0 + (long)p2 * ld0 + c2 * V, w);
+    float v1[V], w1v[V];
+    if (NJ > 1) {
+      ldv<T, V>(dyn1 + (long)p * ld1 + c * V, v1);
+      ldv<T, V>(dyn1 + (long)p2 * ld1 + c2 * V, w1v);
+    }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      v[j] = fmaf(v[j], sg[c * V + j], dpl[c * V + j]);
-      w[j] = fmaf(w[j], sg[c2 * V + j], dpl[c2 * V + j]);
+      v[j] = fmaf(v[j], sg0[c * V + j], dp0[c * V + j]);
+      w[j] = fmaf(w[j], sg0[c2 * V + j], dp0[c2 * V + j]);
+      if (NJ > 1) {
+        v[j] += fmaf(v1[j], sg1[c * V + j], dp1[c * V + j]);
+        w[j] += fmaf(w1v[j], sg1[c2 * V + j], dp1[c2 * V + j]);
+      }
     }
     if (accum) {      // dx already holds the gradient another consumer of x wrote
       float pv[V], pw[V];
@@ -350,70 +387,110 @@ int chunks_for(long elems_per_image, int n) {
 }
 
 size_t lds_fwd(int C) { return (size_t)(C + C / 2 + C + 256) * sizeof(float); }
-size_t lds_bwd(int C) { return (size_t)(C + C / 2 + C + C + 256) * sizeof(float); }
+size_t lds_bwd(int C, int nj = 1) { return (size_t)(nj * (C + C / 2 + C + C) + 256) * sizeof(float); }
 
 }  // namespace
 
-extern "C" int npp_se_supported(int c) { return (c >= 2 && c % 2 == 0 && lds_bwd(c) <= 64 * 1024) ? 1 : 0; }
+extern "C" int npp_se_supported(int c) { return (c >= 2 && c % 2 == 0 && lds_bwd(c, 2) <= 64 * 1024) ? 1 : 0; }
 
 // scratch of npp_se_fwd / npp_se_bwd: the slab partial sums, N * 16 * C floats
 extern "C" int64_t npp_se_ws_floats(int n, int c) { return (int64_t)n * SE_MAX_SLABS * c; }
 
-// y = x * gate; pooled [N][C], hidden [N][C/2], gate [N][C] are stored for the backward pass.  ws: npp_se_ws_floats(N, C) floats.
+// y_j = x * gate_j for njobs (1 or 2) gates on the same x: ONE squeeze pass, one gate + scale launch (job = blockIdx.z).
+// pooled [N][C], hidden [N][C/2], gate [N][C] of every job are stored for the backward pass.  ws: npp_se_ws_floats(N, C) floats.
+extern "C" int npp_se_fwd_multi(const NppTensor* x, const NppSeFwdJob* jobs, int njobs, float* ws, void* stream) {
+  NPP_REQUIRE(x && x->ptr && jobs && njobs >= 1 && njobs <= 2 && ws, NPP_E_NULL, "npp_se_fwd_multi: bad arguments");
+  NPP_REQUIRE(dtype_ok(x), NPP_E_DTYPE, "npp_se_fwd_multi: bad dtype");
+  NPP_REQUIRE(npp_se_supported((int)x->c), NPP_E_UNSUPPORTED, "npp_se_fwd: %ld channels", (long)x->c);
+  NPP_REQUIRE(x->h * x->w * x->c < (1L << 31), NPP_E_SHAPE, "npp_se_fwd: image too large");
+  bool vk = vec_ok(x);
+  SeFwdJobs js;
+  for (int i = 0; i < njobs; ++i) {
+    const NppSeFwdJob& q = jobs[i];
+    NPP_REQUIRE(q.y.ptr && q.w1 && q.b1 && q.w2 && q.b2 && q.pooled && q.hidden && q.gate, NPP_E_NULL, "npp_se_fwd_multi: job %d: null pointer", i);
+    NPP_REQUIRE(same_shape(x, &q.y) && q.y.dtype == x->dtype, NPP_E_SHAPE, "npp_se_fwd_multi: job %d: output does not match x", i);
+    vk = vk && vec_ok(&q.y);
+    js.j[i] = SeFwdJob{q.y.ptr, (long)q.y.ld, q.w1, q.b1, q.w2, q.b2, q.pooled, q.hidden, q.gate};
+  }
+  if (njobs < 2) js.j[1] = js.j[0];
+  const int HW = (int)(x->h * x->w), C = (int)x->c, N = (int)x->n;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(NPP_FAM_ELTWISE, x->dtype, s, 0, (double)npix(x) * C * esize(x->dtype) * (1 + 2 * njobs));
+  NPP_DISPATCH_TV(x->dtype, vk, {
+    const PartPlan pl = part_plan<V>(C, HW);
+    dim3 grid(pl.slabs, (pl.cv + pl.cols_blk - 1) / pl.cols_blk, (unsigned)N);
+    hipLaunchKernelGGL((se_part_kernel<T, V, 0>), grid, dim3(256), 0, s, (const T*)x->ptr, (long)x->ld, (const T*)nullptr, 0L, ws,
+                       HW, C, pl.cv, pl.cols_blk, pl.rows, pl.slabs, N, (const T*)nullptr, 0L, (float*)nullptr);
+    const int chunks = chunks_for((long)HW * C, N * njobs);
+    hipLaunchKernelGGL((se_gate_scale_kernel<T, V>), dim3(chunks, N, njobs), dim3(256), lds_fwd(C), s, (const T*)x->ptr, (long)x->ld,
+                       js, (const float*)ws, pl.slabs, HW, C, pl.cv);
+  });
+  return npp_check_launch("se_fwd");
+}
+
 extern "C" int npp_se_fwd(const NppTensor* x, const float* w1, const float* b1, const float* w2, const float* b2, NppTensor* y,
                           float* pooled, float* hidden, float* gate, float* ws, void* stream) {
   NPP_REQUIRE(x && y && x->ptr && y->ptr && w1 && b1 && w2 && b2 && pooled && hidden && gate && ws, NPP_E_NULL, "npp_se_fwd: null pointer");
   NPP_REQUIRE(dtype_ok(x) && x->dtype == y->dtype, NPP_E_DTYPE, "npp_se_fwd: dtype mismatch");
   NPP_REQUIRE(same_shape(x, y), NPP_E_SHAPE, "npp_se_fwd: shape mismatch");
-  NPP_REQUIRE(npp_se_supported((int)x->c), NPP_E_UNSUPPORTED, "npp_se_fwd: %ld channels", (long)x->c);
-  NPP_REQUIRE(x->h * x->w * x->c < (1L << 31), NPP_E_SHAPE, "npp_se_fwd: image too large");
-  const bool vk = vec_ok(x) && vec_ok(y);
+  NppSeFwdJob jb;
+  jb.y = *y; jb.w1 = w1; jb.b1 = b1; jb.w2 = w2; jb.b2 = b2; jb.pooled = pooled; jb.hidden = hidden; jb.gate = gate;
+  return npp_se_fwd_multi(x, &jb, 1, ws, stream);
+}
+
+// dx = sum_j d(x * gate_j(x)) / dx applied to dout_j, njobs = 1 or 2; dz_j [N][C + C/2] = the gate MLP's pre-activation gradients
+// (for npp_se_param_grads).  ws: njobs * npp_se_ws_floats(N, C) floats.  accumulate != 0: dx += (dx holds another consumer's gradient).
+extern "C" int npp_se_bwd_multi(const NppTensor* x, const NppSeBwdJob* jobs, int njobs, NppTensor* dx, float* ws, int accumulate,
+                                void* stream) {
+  NPP_REQUIRE(x && dx && x->ptr && dx->ptr && jobs && njobs >= 1 && njobs <= 2 && ws, NPP_E_NULL, "npp_se_bwd_multi: bad arguments");
+  NPP_REQUIRE(dtype_ok(x) && x->dtype == dx->dtype, NPP_E_DTYPE, "npp_se_bwd: dtype mismatch");
+  NPP_REQUIRE(same_shape(x, dx), NPP_E_SHAPE, "npp_se_bwd: shape mismatch");
+  NPP_REQUIRE(npp_se_supported((int)x->c), NPP_E_UNSUPPORTED, "npp_se_bwd: %ld channels", (long)x->c);
+  NPP_REQUIRE(x->h * x->w * x->c < (1L << 31), NPP_E_SHAPE, "npp_se_bwd: image too large");
   const int HW = (int)(x->h * x->w), C = (int)x->c, N = (int)x->n;
+  const long wsf = (long)npp_se_ws_floats(N, C);
+  bool vk = vec_ok(x) && vec_ok(dx);
+  SeBwdJobs js;
+  for (int i = 0; i < njobs; ++i) {
+    const NppSeBwdJob& q = jobs[i];
+    NPP_REQUIRE(q.dout.ptr && q.w1 && q.w2 && q.hidden && q.gate && q.dz, NPP_E_NULL, "npp_se_bwd_multi: job %d: null pointer", i);
+    NPP_REQUIRE(same_shape(x, &q.dout) && q.dout.dtype == x->dtype, NPP_E_SHAPE, "npp_se_bwd_multi: job %d: dout does not match x", i);
+    vk = vk && vec_ok(&q.dout);
+    js.j[i] = SeBwdJob{q.dout.ptr, (long)q.dout.ld, ws + i * wsf, q.gate, q.hidden, q.w1, q.w2, q.dz};
+  }
+  if (njobs < 2) js.j[1] = js.j[0];
   hipStream_t s = (hipStream_t)stream;
-  ProfScope prof(NPP_FAM_ELTWISE, x->dtype, s, 0, (double)npix(x) * C * esize(x->dtype) * 3);
+  ProfScope prof(NPP_FAM_ELTWISE, x->dtype, s, 0, (double)npix(x) * C * esize(x->dtype) * (2 + 2 * njobs));
   NPP_DISPATCH_TV(x->dtype, vk, {
     const PartPlan pl = part_plan<V>(C, HW);
-    dim3 grid(pl.slabs, (pl.cv + pl.cols_blk - 1) / pl.cols_blk, (unsigned)N);
-    hipLaunchKernelGGL((se_part_kernel<T, V, 0>), grid, dim3(256), 0, s, (const T*)x->ptr, (long)x->ld, (const T*)nullptr, 0L, ws,
-                       HW, C, pl.cv, pl.cols_blk, pl.rows, pl.slabs);
+    dim3 grid(pl.slabs, (pl.cv + pl.cols_blk - 1) / pl.cols_blk, (unsigned)(N * njobs));
+    hipLaunchKernelGGL((se_part_kernel<T, V, 1>), grid, dim3(256), 0, s, (const T*)jobs[0].dout.ptr, (long)jobs[0].dout.ld, (const T*)x->ptr,
+                       (long)x->ld, ws, HW, C, pl.cv, pl.cols_blk, pl.rows, pl.slabs, N,
+                       (const T*)(njobs > 1 ? jobs[1].dout.ptr : nullptr), (long)(njobs > 1 ? jobs[1].dout.ld : 0), ws + wsf);
     const int chunks = chunks_for((long)HW * C, N);
-    hipLaunchKernelGGL((se_gate_scale_kernel<T, V>), dim3(chunks, N), dim3(256), lds_fwd(C), s, (const T*)x->ptr, (long)x->ld,
-                       (T*)y->ptr, (long)y->ld, (const float*)ws, pl.slabs, w1, b1, w2, b2, pooled, hidden, gate, HW, C, pl.cv);
+    if (njobs > 1)
+      hipLaunchKernelGGL((se_bwd_apply_kernel<T, V, 2>), dim3(chunks, N), dim3(256), lds_bwd(C, 2), s, js, (T*)dx->ptr, (long)dx->ld,
+                         pl.slabs, HW, C, pl.cv, accumulate);
+    else
+      hipLaunchKernelGGL((se_bwd_apply_kernel<T, V, 1>), dim3(chunks, N), dim3(256), lds_bwd(C, 1), s, js, (T*)dx->ptr, (long)dx->ld,
+                         pl.slabs, HW, C, pl.cv, accumulate);
   });
-  return npp_check_launch("se_fwd");
+  return npp_check_launch("se_bwd");
 }
 
-// dx = d(x * gate(x)) / dx applied to dout; dz [N][C + C/2] = the gate MLP's pre-activation gradients (for npp_se_param_grads)
-extern "C" int npp_se_bwd_acc(const NppTensor* dout, const NppTensor* x, const float* w1, const float* w2, const float* hidden,
-                              const float* gate, NppTensor* dx, float* dz, float* ws, int accumulate, void* stream);
-extern "C" int npp_se_bwd(const NppTensor* dout, const NppTensor* x, const float* w1, const float* w2, const float* hidden,
-                          const float* gate, NppTensor* dx, float* dz, float* ws, void* stream) {
-  return npp_se_bwd_acc(dout, x, w1, w2, hidden, gate, dx, dz, ws, 0, stream);
-}
-
-// accumulate != 0: dx += the gradient (dx holds what another consumer of x wrote)
 extern "C" int npp_se_bwd_acc(const NppTensor* dout, const NppTensor* x, const float* w1, const float* w2, const float* hidden,
                               const float* gate, NppTensor* dx, float* dz, float* ws, int accumulate, void* stream) {
   NPP_REQUIRE(dout && x && dx && dout->ptr && x->ptr && dx->ptr && w1 && w2 && hidden && gate && dz && ws, NPP_E_NULL,
               "npp_se_bwd: null pointer");
   NPP_REQUIRE(dtype_ok(x) && x->dtype == dout->dtype && x->dtype == dx->dtype, NPP_E_DTYPE, "npp_se_bwd: dtype mismatch");
   NPP_REQUIRE(same_shape(dout, x) && same_shape(dout, dx), NPP_E_SHAPE, "npp_se_bwd: shape mismatch");
-  NPP_REQUIRE(npp_se_supported((int)x->c), NPP_E_UNSUPPORTED, "npp_se_bwd: %ld channels", (long)x->c);
-  NPP_REQUIRE(x->h * x->w * x->c < (1L << 31), NPP_E_SHAPE, "npp_se_bwd: image too large");
-  const bool vk = vec_ok(x) && vec_ok(dout) && vec_ok(dx);
-  const int HW = (int)(x->h * x->w), C = (int)x->c, N = (int)x->n;
-  hipStream_t s = (hipStream_t)stream;
-  ProfScope prof(NPP_FAM_ELTWISE, x->dtype, s, 0, (double)npix(x) * C * esize(x->dtype) * 4);
-  NPP_DISPATCH_TV(x->dtype, vk, {
-    const PartPlan pl = part_plan<V>(C, HW);
-    dim3 grid(pl.slabs, (pl.cv + pl.cols_blk - 1) / pl.cols_blk, (unsigned)N);
-    hipLaunchKernelGGL((se_part_kernel<T, V, 1>), grid, dim3(256), 0, s, (const T*)dout->ptr, (long)dout->ld, (const T*)x->ptr,
-                       (long)x->ld, ws, HW, C, pl.cv, pl.cols_blk, pl.rows, pl.slabs);
-    const int chunks = chunks_for((long)HW * C, N);
-    hipLaunchKernelGGL((se_bwd_apply_kernel<T, V>), dim3(chunks, N), dim3(256), lds_bwd(C), s, (const T*)dout->ptr, (long)dout->ld,
-                       (T*)dx->ptr, (long)dx->ld, (const float*)ws, pl.slabs, gate, hidden, w1, w2, dz, HW, C, pl.cv, accumulate);
-  });
-  return npp_check_launch("se_bwd");
+  NppSeBwdJob jb;
+  jb.dout = *dout; jb.w1 = w1; jb.w2 = w2; jb.hidden = hidden; jb.gate = gate; jb.dz = dz;
+  return npp_se_bwd_multi(x, &jb, 1, dx, ws, accumulate, stream);
+}
+extern "C" int npp_se_bwd(const NppTensor* dout, const NppTensor* x, const float* w1, const float* w2, const float* hidden,
+                          const float* gate, NppTensor* dx, float* dz, float* ws, void* stream) {
+  return npp_se_bwd_acc(dout, x, w1, w2, hidden, gate, dx, dz, ws, 0, stream);
 }
 
 static bool se_grad_job(const NppSeGradItem& it, SeGradJob& jb) {

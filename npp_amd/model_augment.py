@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import _ops as K
 from . import genotypes as gt
 from ._ops import BnSide
-from .operations import OPS, FactorizedReduce, ReLUConvBN, fused_sum, fused_sum_apply, fused_sum_pending, fused_sum_stages, _use_batch_stats, group_wide_edges  # noqa: F401
+from .operations import OPS, FactorizedReduce, ReLUConvBN, fused_sum, fused_sum_apply, fused_sum_pending, fused_sum_stages, _use_batch_stats, group_wide_edges, WideEdges, group_se_pairs  # noqa: F401
 from .operations import *  # noqa: F401,F403  (reference does `from models.operations import *`)
 
 BN_MOMENTUM = 0.1
@@ -115,6 +115,7 @@ class _DagCell(nn.Module):
         self._indices = indices
         # edges that apply the same ReLU-conv-BN to the same state run as ONE conv (operations.WideEdges)
         self._wide_groups = group_wide_edges(self._ops, names, indices, [stride_of(i) for i in indices])
+        self._se_pairs = group_se_pairs(self._ops, names, indices)      # two `se_connect` on one state: one launch pair for both
 
     def _run(self, states, concat=None):
         """Runs the nodes; with `concat` (state indices, all of them node outputs) also returns their concatenation, whose
@@ -445,6 +446,16 @@ class Network(nn.Module):
             C_pp, C_p = C_p, multiplier * C_curr
         self.num_inchannels = self.num_inchannels[::-1]
         widths = self.num_inchannels[::-1]
+        # The output of cell i - 2 is read by preprocess1 of cell i - 1 AND by preprocess0 of cell i (model_augment.py:413-417: s0, s1 =
+        # s1, cell(s0, s1)): inside a stage both are ReLU - Conv1x1(4C -> C) - BN, so they run as ONE conv 4C -> 2C when the first of
+        # them is asked (operations.WideEdges; the second picks up its slice one cell later), and their data gradients as one conv
+        # 2C -> 4C -- the sum of the state's two gradients happens in the MFMA accumulators.
+        self._wide_groups = []
+        for cells in (self.cells1, self.cells2):
+            for i in range(1, L):
+                a, b = cells[i - 1].preprocess1, cells[i].preprocess0
+                if type(a) is ReLUConvBN and type(b) is ReLUConvBN and WideEdges.fits([a, b]):
+                    self._wide_groups.append(WideEdges([a, b]))
 
         # encoder-stage cross-task edges (model_augment.py:301-309, _compile :576-599)
         self._indices1, ops = self._compile(gt.INTER.task1, widths)

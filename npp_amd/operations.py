@@ -187,9 +187,21 @@ class WideEdges(K.WideGroup):
         conv = op.net[1]
         k, c = conv.kernel_size[0], conv.out_channels
         # (channel counts the LDS-DMA kernels take for C -> m C and m C -> C: multiples of 64, or 32 for the 3x3 of conv_c32)
+        ci = conv.in_channels
         return (conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
-                and conv.kernel_size[0] == conv.kernel_size[1] and conv.in_channels == c
-                and (c % 64 == 0 or (c == 32 and k == 3)))
+                and conv.kernel_size[0] == conv.kernel_size[1] and (ci == c or ci % 64 == 0) and c % 32 == 0)
+
+    @staticmethod
+    def fits(ops) -> bool:
+        """m mergeable edges of one geometry whose merged widths the LDS-DMA kernels take: m C a multiple of 64 (conv_g4 / conv_h3 /
+        conv_g8 tiles, 64-channel K-tiles of the data gradient), or 32 -> 32 3x3 (conv_c32's output / input groups)."""
+        if len(ops) < 2 or not all(WideEdges.mergeable(op) for op in ops):
+            return False
+        w0 = ops[0].net[1].weight
+        if any(op.net[1].weight.shape != w0.shape or op.net[1].padding != ops[0].net[1].padding for op in ops):
+            return False
+        c, ci, k = w0.shape[0], w0.shape[1], w0.shape[2]
+        return (len(ops) * c) % 64 == 0 or (c == 32 and ci == 32 and k == 3 and len(ops) <= 4)
 
     def pending(self, k, x):
         st = self.calls
@@ -219,7 +231,7 @@ def group_wide_edges(ops, names, indices, strides):
         base = op[0] if isinstance(op, nn.Sequential) else op
         if stride == 1 and WideEdges.mergeable(base):
             by.setdefault((name, idx), []).append(base)
-    return [WideEdges(v) for v in by.values() if len(v) >= 2]
+    return [WideEdges(v) for v in by.values() if WideEdges.fits(v)]
 
 
 class DilConv(_BnOp):
@@ -253,7 +265,13 @@ class SE_Block(nn.Module):
         self.pool2 = nn.AvgPool2d(2)
         self.bn = nn.BatchNorm2d(C_in, momentum=BN_MOMENTUM)
 
+    _pair = None      # (SEPair, index): the other `se_connect` edge of the cell reads the same state (see SEPair)
+
     def _gate(self, x):
+        if self._pair is not None and K.SE_PAIR and K.SE_FUSED:
+            y = self._pair[0].gate(self._pair[1], x)
+            if y is not None:
+                return y
         return K.se_scale(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
 
     def pending(self, x):
@@ -268,6 +286,39 @@ class SE_Block(nn.Module):
         if side.bn is None:
             return side.x
         return K.bn_add(side, None, relu=False, training=self.bn.training)
+
+
+class SEPair:
+    """The two `se_connect` edges an encoder cell applies to ONE state (ENCODER.normal / .reduce, genotypes.py:30-36): the first of
+    them to be asked computes both gates in one launch pair (K.se_scale_pair: one squeeze pass, one gate-and-scale launch; backward one
+    partial-sum launch and one apply launch that sums the two gradients), the second picks up its result."""
+
+    def __init__(self, a, b):
+        self.ops = [a, b]
+        self.calls = None
+        a._pair, b._pair = (self, 0), (self, 1)
+
+    def gate(self, k, x):
+        st = self.calls
+        if st is None or st[0] is not x:
+            if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4) or not K.lib().npp_se_supported(x.shape[1]):
+                return None
+            ys = K.se_scale_pair(x, [(m.conv1.weight, m.conv1.bias, m.conv2.weight, m.conv2.bias) for m in self.ops])
+            self.calls = st = [x, list(ys)]
+        y, st[1][k] = st[1][k], None
+        if all(v is None for v in st[1]):
+            self.calls = None
+        return y
+
+
+def group_se_pairs(ops, names, indices):
+    """SEPair for every two SE_Block edges of a cell on the same state (the op may be wrapped in nn.Sequential(op, Interpolate))."""
+    by = {}
+    for op, name, idx in zip(ops, names, indices):
+        base = op[0] if isinstance(op, nn.Sequential) else op
+        if isinstance(base, SE_Block):
+            by.setdefault(idx, []).append(base)
+    return [SEPair(v[0], v[1]) for v in by.values() if len(v) == 2 and v[0].conv1.weight.shape == v[1].conv1.weight.shape]
 
 
 class Identity(nn.Module):

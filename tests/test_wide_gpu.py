@@ -215,3 +215,75 @@ def test_multi_job_batchnorm_launches_equal_the_single_launches(n, kind, C, H, N
                 assert a is None and b is None
                 continue
             assert rel_err(a, b) <= tol, (k, q, rel_err(a, b))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,H,N,stride", [(128, 24, 4, 1), (256, 12, 2, 1), (32, 96, 2, 1), (64, 48, 2, 2)])
+def test_se_pair_equals_two_single_gates_and_torch(C, H, N, stride, dtype):
+    """Two `se_connect` edges on one state (ENCODER.normal, genotypes.py:30-31) as one launch pair (operations.SEPair) against the
+    same two modules run one by one, and against a plain fp32 PyTorch-CPU squeeze-excite (operations.py:105-129)."""
+    import copy
+    from npp_amd import _ops as K
+    from npp_amd.operations import SE_Block, SEPair
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + H)
+    mods = [SE_Block(C, stride) for _ in range(2)]
+    for m in mods:
+        with torch.no_grad():
+            for p in (m.conv1.weight, m.conv2.weight):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+            for p in (m.conv1.bias, m.conv2.bias):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    x_cpu = torch.randn(N, C, H, H, generator=g)
+    oh = H // stride
+    rs = [torch.randn(N, C, oh, oh, generator=g) for _ in range(2)]
+
+    def run(pair):
+        ms = [copy.deepcopy(m).to(dev).train() for m in mods]
+        if pair:
+            SEPair(ms[0], ms[1])
+        K.fan_reset()
+        K.SE_PAIR = bool(pair)
+        try:
+            leaf = x_cpu.to(dev).requires_grad_(True)
+            x = K.bn_add(K.BnSide(K.cast(leaf.contiguous(memory_format=torch.channels_last), dtype)), None)
+            before = K.SE_PAIR_STATS[0]
+            ys = [m(x) for m in ms]
+            loss = sum((y.float() * r.to(dev)).sum() for y, r in zip(ys, rs))
+            loss.backward()
+            torch.cuda.synchronize()
+            used = K.SE_PAIR_STATS[0] - before
+        finally:
+            K.SE_PAIR = True
+            K.fan_reset()
+        return ([y.detach().float().cpu() for y in ys], leaf.grad.float().cpu(),
+                [[p.grad.float().cpu() for p in (m.conv1.weight, m.conv1.bias, m.conv2.weight, m.conv2.bias)] for m in ms], used)
+
+    p_y, p_dx, p_g, used = run(True)
+    s_y, s_dx, s_g, used_s = run(False)
+    assert used == 1 and used_s == 0
+    # torch reference (stride 2: AvgPool2 + BatchNorm follow the gate, operations.py:122-127)
+    xr = x_cpu.clone().requires_grad_(True)
+    ref_y, ref_params = [], []
+    for m in mods:
+        ps = [p.detach().clone().requires_grad_(True) for p in (m.conv1.weight, m.conv1.bias, m.conv2.weight, m.conv2.bias)]
+        z = F.adaptive_avg_pool2d(xr, 1)
+        gate = torch.sigmoid(F.conv2d(F.relu(F.conv2d(z, ps[0], ps[1])), ps[2], ps[3]))
+        y = xr * gate
+        if stride == 2:
+            y = F.batch_norm(F.avg_pool2d(y, 2), None, None, m.bn.weight.detach(), m.bn.bias.detach(), True, 0.1, 1e-5)
+        ref_y.append(y)
+        ref_params.append(ps)
+    sum((y * r).sum() for y, r in zip(ref_y, rs)).backward()
+    f32 = dtype == torch.float32
+    tol, err = (2e-4, rel_err) if f32 else (3e-2, rel_l2)
+    for k in range(2):
+        assert err(p_y[k], ref_y[k].detach()) < tol
+        assert rel_err(p_y[k], s_y[k]) <= (1e-6 if f32 else 1e-2)
+        for j in range(4):
+            # (bf16: the gate's parameter gradients are sums of products of rounded pixels that cancel to a few percent of their
+            #  terms; the single-gate path shows the same distance to torch)
+            assert err(p_g[k][j], ref_params[k][j].grad) < (1e-3 if f32 else 0.15), (k, j)
+            assert err(p_g[k][j], s_g[k][j]) < (1e-4 if f32 else 3e-2), (k, j, "vs single")
+    assert err(p_dx, xr.grad) < (5e-4 if f32 else 3e-2)
+    assert err(p_dx, s_dx) < (1e-5 if f32 else 2e-2)
