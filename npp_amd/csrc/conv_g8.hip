@@ -548,24 +548,38 @@ bool conv_g8_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
     hipLaunchKernelGGL((conv_g8_kernel<BN_, RELU_, TAPS_>), dim3(grid), dim3(512), lds, stream, q, e);     \
   } while (0)
   static const int dbg = getenv("NPP_G8_DBG") ? atoi(getenv("NPP_G8_DBG")) : 0;
-#define G8_LAUNCH_DBG(D_)                                                                                  \
+#define G8_LAUNCH_DBG(BN_, D_)                                                                             \
   do {                                                                                                     \
     constexpr size_t lds = 2 * 65536 + 8 * 512;                                                            \
-    if (!g8_raise_lds(reinterpret_cast<const void*>(conv_g8_kernel<256, false, false, D_>), lds)) return false; \
-    hipLaunchKernelGGL((conv_g8_kernel<256, false, false, D_>), dim3(grid), dim3(512), lds, stream, q, e); \
+    if (!g8_raise_lds(reinterpret_cast<const void*>(conv_g8_kernel<BN_, false, false, D_>), lds)) return false; \
+    hipLaunchKernelGGL((conv_g8_kernel<BN_, false, false, D_>), dim3(grid), dim3(512), lds, stream, q, e); \
   } while (0)
-  if (dbg && bn == 256 && !p.relu_in) {      // timing experiments (results are garbage)
-    switch (dbg) {
-      case 1: G8_LAUNCH_DBG(1); break;
-      case 2: G8_LAUNCH_DBG(2); break;
-      case 3: G8_LAUNCH_DBG(3); break;
-      case 4: G8_LAUNCH_DBG(4); break;
-      case 5: G8_LAUNCH_DBG(5); break;
-      case 7: G8_LAUNCH_DBG(7); break;
-      case 9: G8_LAUNCH_DBG(9); break;
-      case 13: G8_LAUNCH_DBG(13); break;
-      case 15: G8_LAUNCH_DBG(15); break;
-      default: return false;
+  // timing experiments (tools/g8_ablation.sh -> profiles/r04_g8_ablation.txt; results are garbage): the 1x1 shapes without input
+  // ReLU, i.e. the bare forward and every data gradient
+  if (dbg && P == 0 && !p.relu_in) {
+    if (bn == 256) {
+      switch (dbg) {
+        case 1: G8_LAUNCH_DBG(256, 1); break;
+        case 2: G8_LAUNCH_DBG(256, 2); break;
+        case 3: G8_LAUNCH_DBG(256, 3); break;
+        case 4: G8_LAUNCH_DBG(256, 4); break;
+        case 5: G8_LAUNCH_DBG(256, 5); break;
+        case 7: G8_LAUNCH_DBG(256, 7); break;
+        case 8: G8_LAUNCH_DBG(256, 8); break;
+        case 9: G8_LAUNCH_DBG(256, 9); break;
+        case 13: G8_LAUNCH_DBG(256, 13); break;
+        case 15: G8_LAUNCH_DBG(256, 15); break;
+        default: return false;
+      }
+    } else {
+      switch (dbg) {
+        case 1: G8_LAUNCH_DBG(128, 1); break;
+        case 2: G8_LAUNCH_DBG(128, 2); break;
+        case 4: G8_LAUNCH_DBG(128, 4); break;
+        case 8: G8_LAUNCH_DBG(128, 8); break;
+        case 15: G8_LAUNCH_DBG(128, 15); break;
+        default: return false;
+      }
     }
     return true;
   }
