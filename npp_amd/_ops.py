@@ -764,7 +764,7 @@ class WeightPacker:
 
     def __init__(self, weights, groups=()):
         self.weights = list(weights)
-        self.groups = [g for g in groups if g.weights[0].shape[0] % 32 == 0]      # WideGroups: merged images (conv2d_wide)
+        self.groups = [g for g in groups if g.separate_fwd or g.weights[0].shape[0] % 32 == 0]      # WideGroups: merged images (conv2d_wide)
         self.sig = None
         self.epoch = -1            # TRAIN_EPOCH the images were last written at
         self.table = None
@@ -779,12 +779,15 @@ class WeightPacker:
         self.group_bufs = []
         for g in self.groups:
             ws = g.weights
-            co, ci, kh, kw = ws[0].shape
-            n1 = int(lib().npp_packed_weight_elems(co, ci, kh, kw, 0))
-            buf = torch.zeros(len(ws) * n1, dtype=dtype, device=device)
-            for k, w in enumerate(ws):
-                fwd_slice[id(w)] = buf[k * n1:(k + 1) * n1]
-            dgb = torch.zeros(int(lib().npp_packed_weight_elems(len(ws) * co, ci, kh, kw, 1)), dtype=dtype, device=device)
+            _, ci, kh, kw = ws[0].shape
+            buf = None
+            if not g.separate_fwd:
+                co = ws[0].shape[0]
+                n1 = int(lib().npp_packed_weight_elems(co, ci, kh, kw, 0))
+                buf = torch.zeros(len(ws) * n1, dtype=dtype, device=device)
+                for k, w in enumerate(ws):
+                    fwd_slice[id(w)] = buf[k * n1:(k + 1) * n1]
+            dgb = torch.zeros(int(lib().npp_packed_weight_elems(sum(g.cos), ci, kh, kw, 1)), dtype=dtype, device=device)
             self.group_bufs.append((g, buf, dgb))
         njobs = 2 * len(self.weights) + sum(len(g.weights) for g in self.groups)
         jobs = (L.NppPackJob * njobs)()
@@ -807,13 +810,15 @@ class WeightPacker:
                 i += 1
         for g, _buf, dgb in self.group_bufs:
             ws = g.weights
-            co, ci, kh, kw = ws[0].shape
-            for k, w in enumerate(ws):
-                jobs[i] = L.NppPackJob(w.data_ptr(), dgb.data_ptr(), co, ci, kh, kw, 1, L.npp_dtype(dtype), blk, k * co, len(ws) * co)
+            ct, off = sum(g.cos), 0
+            for w in ws:
+                co, ci, kh, kw = w.shape
+                jobs[i] = L.NppPackJob(w.data_ptr(), dgb.data_ptr(), co, ci, kh, kw, 1, L.npp_dtype(dtype), blk, off, ct)
                 nb = int(lib().npp_pack_job_blocks(co, ci, kh, kw, 1))
                 counts.append(nb)
                 blk += nb
                 i += 1
+                off += co
         assert i == njobs
         raw = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()
         self.table = torch.from_numpy(raw).to(device)
@@ -844,7 +849,9 @@ class WeightPacker:
         self.sig = sig
         self.epoch = TRAIN_EPOCH
         for g, buf, dgb in self.group_bufs:
-            g.img = {(False, dtype): buf, (True, dtype): dgb}
+            g.img = {(True, dtype): dgb}
+            if buf is not None:
+                g.img[(False, dtype)] = buf
         k = 0
         for w in ws:
             wid = id(w)
@@ -1423,25 +1430,27 @@ WIDE_STATS = [0, 0, 0]      # merged forward launches / merged data gradients th
 
 
 class _WideGrad:
-    """The dy buffer [N, H, W, m * C] of one merged conv: allocated when the first edge's BatchNorm backward asks for its slice."""
-    __slots__ = ("buf", "m", "c")
+    """The dy buffer [N, H, W, sum of the members' Cout] of one merged conv: allocated when the first edge's BatchNorm backward asks
+    for its slice."""
+    __slots__ = ("buf", "cos", "offs")
 
-    def __init__(self, m, c):
-        self.buf, self.m, self.c = None, m, c
+    def __init__(self, cos):
+        self.buf, self.cos = None, list(cos)
+        self.offs = [sum(self.cos[:k]) for k in range(len(self.cos))]
 
     def slot(self, k):
         wg = self
 
         def give(like):
             n, c, h, w = like.shape
-            if c != wg.c:
+            if c != wg.cos[k]:
                 return None
             if wg.buf is None:
-                wg.buf = new_nhwc(n, wg.m * c, h, w, like.dtype, like.device)
+                wg.buf = new_nhwc(n, sum(wg.cos), h, w, like.dtype, like.device)
             b = wg.buf
             if b.shape[0] != n or b.shape[2] != h or b.shape[3] != w or b.dtype != like.dtype or b.device != like.device:
                 return None
-            return _alias(b, k * c, c)
+            return _alias(b, wg.offs[k], c)
         return give
 
 
@@ -1456,10 +1465,15 @@ def _dx_into(slot, like):
 
 
 class WideGroup:
-    """m conv modules (same Cin, Cout, kernel, stride 1, no bias) that a cell applies to one and the same state."""
+    """m conv modules (same Cin, kernel, padding, stride 1) that are applied to one and the same tensor.
+    separate_fwd = False: equal Cout, no bias -- ONE forward conv Cin -> m Cout (the weights' forward images back to back).
+    separate_fwd = True : any Cout, bias allowed -- the forward convs stay m launches (tiles chosen per width), only the DATA GRADIENT
+    is merged: one conv sum(Cout) -> Cin over the concatenated dy (the 1024 -> 512 and 1024 -> 384 layers that both read the
+    concatenated decoder features, model_augment.py:332-351: their second data gradient was a 300 MB read-add-store)."""
 
-    def __init__(self, convs):
+    def __init__(self, convs, separate_fwd=False):
         self.convs = list(convs)
+        self.separate_fwd = bool(separate_fwd)
         self.img = {}          # (for_dgrad, dtype) -> image written by the model's WeightPacker (valid after its pack_if_stale)
         self.calls = None      # per-forward cache: [input tensor, list of pending results]
 
@@ -1467,113 +1481,171 @@ class WideGroup:
     def weights(self):
         return [c.weight for c in self.convs]
 
+    @property
+    def cos(self):
+        return [c.weight.shape[0] for c in self.convs]
+
     def images(self, dtype, need_dgrad):
-        """(forward image, data-gradient image | None) of the merged conv."""
+        """(forward image | None, data-gradient image | None) of the merged conv."""
         ws = self.weights
-        if (False, dtype) in self.img and (True, dtype) in self.img and self.img[(False, dtype)].device == ws[0].device:
-            return self.img[(False, dtype)], self.img[(True, dtype)]
+        if (True, dtype) in self.img and self.img[(True, dtype)].device == ws[0].device and (self.separate_fwd or (False, dtype) in self.img):
+            return self.img.get((False, dtype)), self.img[(True, dtype)]
         # no packer manages this group (a cell used on its own): build the images from the per-weight ones
-        co, ci, kh, kw = ws[0].shape
-        taps, m = kh * kw, len(ws)
-        fwd = torch.cat([packed_weight(w, False, dtype).view(-1)[:co * ((taps * ((ci + 7) // 8 * 8) + 63) // 64 * 64)] for w in ws])
+        _, ci, kh, kw = ws[0].shape
+        taps = kh * kw
+        fwd = None
+        if not self.separate_fwd:
+            co = ws[0].shape[0]
+            fwd = torch.cat([packed_weight(w, False, dtype).view(-1)[:co * ((taps * ((ci + 7) // 8 * 8) + 63) // 64 * 64)] for w in ws])
         dg = None
         if need_dgrad:
             rows = (ci + 31) // 32 * 32
-            cop1 = (co + 7) // 8 * 8
-            k1 = (taps * cop1 + 63) // 64 * 64
-            kg = (taps * m * co + 63) // 64 * 64
+            ct = sum(self.cos)
+            ctp = (ct + 7) // 8 * 8
+            kg = (taps * ctp + 63) // 64 * 64
             dg = torch.zeros(rows, kg, dtype=dtype, device=ws[0].device)
-            v = dg[:, :taps * m * co].view(rows, taps, m, co)
-            for k, w in enumerate(ws):
+            v = dg[:, :taps * ctp].view(rows, taps, ctp)
+            off = 0
+            for w in ws:
+                co = w.shape[0]
+                cop1 = (co + 7) // 8 * 8
+                k1 = (taps * cop1 + 63) // 64 * 64
                 one = packed_weight(w, True, dtype).view(rows, k1)[:, :taps * cop1].view(rows, taps, cop1)[:, :, :co]
-                v[:, :, k, :] = one
+                v[:, :, off:off + co] = one
+                off += co
             dg = dg.view(-1)
         return fwd, dg
 
 
 class _ConvWide(Function):
+    """Args: x, pad, relu_in, want_stats, fan, group, wg, then the m weights, then the m biases (None where a conv has none)."""
+
     @staticmethod
-    def forward(ctx, x, pad, relu_in, want_stats, fan, group, wg, *weights):
+    def forward(ctx, x, pad, relu_in, want_stats, fan, group, wg, *wb):
         x = _gemm_ready(to_nhwc(x))
         n, ci, h, w = x.shape
-        m = len(weights)
-        co, _, kh, kw = weights[0].shape
-        y = new_nhwc(n, m * co, h, w, x.dtype, x.device)
-        stats = stats_buffer(R * 2 * m * co, x.device, want_stats) if want_stats else None
+        m = len(wb) // 2
+        weights, biases = wb[:m], wb[m:]
+        cos = [wt.shape[0] for wt in weights]
+        _, _, kh, kw = weights[0].shape
         g = geom(kh, kw, 1, 1, pad[0], pad[1], 1, 1, 1, relu_in)
         need_bwd = any(ctx.needs_input_grad)      # (grad mode is off inside forward: ask the context)
         wp, wpd = group.images(x.dtype, need_bwd)
-        _conv_launch(x, wp.data_ptr(), None, None, y, ptr(stats), g, stream_ptr(), "npp_conv_fwd(wide)")
+        s = stream_ptr()
+        if group.separate_fwd:
+            outs, stats_all = [], []
+            for k, wt in enumerate(weights):
+                yk = new_nhwc(n, cos[k], h, w, x.dtype, x.device)
+                st = stats_buffer(R * 2 * cos[k], x.device, want_stats) if want_stats else None
+                bf = None
+                if biases[k] is not None:
+                    bf = biases[k].detach()
+                    if bf.dtype != torch.float32:
+                        bf = bf.float()
+                _conv_launch(x, packed_weight(wt, False, x.dtype).data_ptr(), ptr(bf), None, yk, ptr(st), g, s, "npp_conv_fwd")
+                if SHAPE_LOG is not None:
+                    SHAPE_LOG.append(("fwd", n, ci, h, w, cos[k], kh, kw, 1, 1))
+                outs.append(yk)
+                stats_all.append(st)
+            outs = tuple(outs)
+        else:
+            co = cos[0]
+            y = new_nhwc(n, m * co, h, w, x.dtype, x.device)
+            stats = stats_buffer(R * 2 * m * co, x.device, want_stats) if want_stats else None
+            _conv_launch(x, wp.data_ptr(), None, None, y, ptr(stats), g, s, "npp_conv_fwd(wide)")
+            if SHAPE_LOG is not None:
+                SHAPE_LOG.append(("fwd", n, ci, h, w, m * co, kh, kw, 1, 1))
+            outs = tuple(_alias(y, k * co, co) for k in range(m))
+            stats_all = [stats]
         WIDE_STATS[0] += 1
-        if SHAPE_LOG is not None:
-            SHAPE_LOG.append(("fwd", n, ci, h, w, m * co, kh, kw, 1, 1))
-        ctx.save_for_backward(x, *weights)
+        ctx.save_for_backward(x, *weights, *[b for b in biases if b is not None])
+        ctx.has_bias = [b is not None for b in biases]
         ctx.wpd = wpd
         ctx.fan = fan if x.dtype == torch.bfloat16 else None
         ctx.mask_bits = relu_mask_of(x) if (relu_in and RELU_BITS and x.dtype == torch.bfloat16) else None
         if relu_in and ctx.mask_bits is None and RELU_BITS and x.dtype == torch.bfloat16:
             MASK_STATS[2] += 1
-        ctx.cfg = (pad, relu_in, m, co)
+        ctx.cfg = (pad, relu_in, m, cos)
         ctx.wg = wg
         ctx.set_materialize_grads(False)
-        outs = tuple(_alias(y, k * co, co) for k in range(m))
-        if stats is not None:
-            ctx.mark_non_differentiable(stats)
-        return (*outs, stats)
+        live = [st for st in stats_all if st is not None]
+        if live:
+            ctx.mark_non_differentiable(*live)
+        return (*outs, *stats_all)
 
     @staticmethod
     def backward(ctx, *grads):
-        x, *weights = ctx.saved_tensors
-        pad, relu_in, m, co = ctx.cfg
+        pad, relu_in, m, cos = ctx.cfg
+        saved = ctx.saved_tensors
+        x, weights = saved[0], saved[1:1 + m]
+        bl = list(saved[1 + m:])
+        biases = [bl.pop(0) if hb else None for hb in ctx.has_bias]
         dys = list(grads[:m])
         if all(d is None for d in dys):
-            return (None,) * (7 + m)
+            return (None,) * (7 + 2 * m)
         n, ci, h, w = x.shape
         _, _, kh, kw = weights[0].shape
         wg = ctx.wg
         buf, wg.buf = wg.buf, None      # (a second backward over the same graph starts a new buffer)
         esz = x.element_size()
+        offs = wg.offs
         in_place = buf is not None and buf.dtype == x.dtype and all(
-            d is not None and d.dtype == buf.dtype and d.shape[1] == co and d.data_ptr() == buf.data_ptr() + k * co * esz
+            d is not None and d.dtype == buf.dtype and d.shape[1] == cos[k] and d.data_ptr() == buf.data_ptr() + offs[k] * esz
             and d.stride() == (buf.stride(0), 1, buf.stride(2), buf.stride(3)) for k, d in enumerate(dys))
+        ct = sum(cos)
         if in_place:
             dy_all = buf
             WIDE_STATS[1] += 1
         else:      # (an edge whose BatchNorm ran on a path without slots, or an unused edge): gather the slices
             parts = []
-            for d in dys:
+            for k, d in enumerate(dys):
                 if d is None:
-                    parts.append(new_nhwc(n, co, h, w, x.dtype, x.device, zero=True))
+                    parts.append(new_nhwc(n, cos[k], h, w, x.dtype, x.device, zero=True))
                 else:
                     d = to_nhwc(d)
                     parts.append(d if d.dtype == x.dtype else cast(d, x.dtype))
-            dy_all = new_nhwc(n, m * co, h, w, x.dtype, x.device)
+            dy_all = new_nhwc(n, ct, h, w, x.dtype, x.device)
             descs = [desc(t) for t in parts]
             arr = (C.POINTER(L.NppTensor) * m)(*[C.pointer(d) for d in descs])
             check(lib().npp_concat(arr, m, _byref(dy_all), stream_ptr()), "npp_concat")
             WIDE_STATS[2] += 1
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _conv_dgrad(x, dy_all, ctx.wpd, m * co, kh, kw, (1, 1), pad, (1, 1), relu_in, ctx.mask_bits, ctx.fan)
-        dws = []
+            dx = _conv_dgrad(x, dy_all, ctx.wpd, ct, kh, kw, (1, 1), pad, (1, 1), relu_in, ctx.mask_bits, ctx.fan)
+        dws, dbs = [], []
+        s = stream_ptr()
         for k, wt in enumerate(weights):
-            if ctx.needs_input_grad[7 + k] and dys[k] is not None:
-                dws.append(_conv_wgrad(x, _alias(dy_all, k * co, co), wt, (1, 1), pad, (1, 1), relu_in))
+            dyk = _alias(dy_all, offs[k], cos[k]) if dys[k] is not None else None
+            if ctx.needs_input_grad[7 + k] and dyk is not None:
+                dws.append(_conv_wgrad(x, dyk, wt, (1, 1), pad, (1, 1), relu_in))
             else:
                 dws.append(None)
-        return (dx, None, None, None, None, None, None, *dws)
+            if biases[k] is not None and ctx.needs_input_grad[7 + m + k] and dyk is not None:
+                acc = zeros_f64(R * cos[k], x.device)
+                check(lib().npp_channel_sum(_byref(dyk), acc.data_ptr(), s), "npp_channel_sum")
+                db = _grad_buf(biases[k], cos[k], x.device)
+                check(lib().npp_sum_replicas(acc.data_ptr(), R, cos[k], db.data_ptr(), s), "npp_sum_replicas")
+                dbs.append(db)
+            else:
+                dbs.append(None)
+        return (dx, None, None, None, None, None, None, *dws, *dbs)
 
 
 def conv2d_wide(x, group, pad, relu_in, want_stats):
-    """The m convs of `group` applied to x in one launch: ([raw output k], [statistics view k], stats row width, [dy slot k])."""
+    """The m convs of `group` applied to x -- in one launch, or (group.separate_fwd) one each with only the data gradient merged:
+    ([raw output k], [statistics (view) k], statistics row width | 0, [dy slot k])."""
     xa, fan = take_acc(x)
     ws = group.weights
-    m, co = len(ws), ws[0].shape[0]
-    wg = _WideGrad(m, co)
-    res = _ConvWide.apply(xa, _pair(pad), bool(relu_in), int(want_stats), fan, group, wg, *ws)
-    ys, stats = res[:m], res[m]
-    svs = [stats[k * co:] if stats is not None else None for k in range(m)]
-    return ys, svs, m * co, [wg.slot(k) for k in range(m)]
+    bs = [c.bias for c in group.convs]
+    m, cos = len(ws), group.cos
+    wg = _WideGrad(cos)
+    res = _ConvWide.apply(xa, _pair(pad), bool(relu_in), int(want_stats), fan, group, wg, *ws, *bs)
+    ys = res[:m]
+    if group.separate_fwd:
+        return ys, list(res[m:2 * m]), 0, [wg.slot(k) for k in range(m)]
+    stats = res[m]
+    svs = [stats[wg.offs[k]:] if stats is not None else None for k in range(m)]
+    return ys, svs, sum(cos), [wg.slot(k) for k in range(m)]
 
 
 # --------------------------------------------------------------------------------------------------

@@ -68,10 +68,20 @@ class _Stem(nn.Sequential):
 class _Layer(nn.Sequential):
     """ReLU - Conv1x1(bias) - BN  (model_augment.py:332-351)."""
 
+    _wide = None      # (WideEdges, index): the other layer that reads the same concatenated features (Network.__init__)
+
+    def _cb(self):
+        return self[1], self[2]
+
     def forward(self, x):
         conv, bn = self[1], self[2]
-        y, st = K.conv2d(x, conv.weight, conv.bias, 1, conv.padding, 1, relu_in=True, want_stats=_use_batch_stats(bn))
-        return K.bn_add(BnSide(y, bn, st), None, relu=False, training=bn.training)
+        side = None
+        if self._wide is not None and K.WIDE:
+            side = self._wide[0].pending(self._wide[1], x)      # both layers' data gradients as ONE conv (K = 512 + 384)
+        if side is None:
+            y, st = K.conv2d(x, conv.weight, conv.bias, 1, conv.padding, 1, relu_in=True, want_stats=_use_batch_stats(bn))
+            side = BnSide(y, bn, st)
+        return K.bn_add(side, None, relu=False, training=bn.training)
 
 
 class _Head(nn.Sequential):
@@ -487,6 +497,12 @@ class Network(nn.Module):
         self.pose_auxlayer = layer(3 * Cf)
         self.par_layer = layer(4 * Cf)
         self.edge_layer = layer(3 * Cf)
+
+        # pose_auxlayer + pose_layer read the same concatenation x1 (edge_layer + par_layer: x2), model_augment.py:540-548: the forward
+        # convs keep their own launches (tiles chosen per width), their data gradients run as ONE conv over the concatenated dy --
+        # the second one was a 300 MB read-add-store into the first one's result
+        self._wide_groups.append(WideEdges([self.pose_auxlayer, self.pose_layer], separate_fwd=True))
+        self._wide_groups.append(WideEdges([self.edge_layer, self.par_layer], separate_fwd=True))
 
         self.pose_net, self.par_net = nn.ModuleList(), nn.ModuleList()
         for _ in range(3):

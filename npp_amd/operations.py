@@ -157,6 +157,9 @@ class ReLUConvBN(_BnOp):
 
     _wide = None      # (WideEdges, index): this edge shares its input and geometry with other edges of its cell (see WideEdges)
 
+    def _cb(self):
+        return self.net[1], self.net[2]
+
     def pending(self, x):
         if self._wide is not None and K.WIDE:
             side = self._wide[0].pending(self._wide[1], x)
@@ -174,8 +177,8 @@ class WideEdges(K.WideGroup):
     others pick up their channel slice.  Anything that does not fit -- a different input object, SyncBatchNorm statistics, mixed
     train / eval BatchNorms -- returns None and the edge runs on its own."""
 
-    def __init__(self, ops):
-        super().__init__([op.net[1] for op in ops])
+    def __init__(self, ops, separate_fwd=False):
+        super().__init__([op._cb()[0] for op in ops], separate_fwd=separate_fwd)
         self.ops = list(ops)
         for k, op in enumerate(self.ops):
             op._wide = (self, k)
@@ -208,7 +211,7 @@ class WideEdges(K.WideGroup):
         if st is None or st[0] is not x:
             if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4):
                 return None
-            bns = [op.net[2] for op in self.ops]
+            bns = [op._cb()[1] for op in self.ops]
             want = {_use_batch_stats(bn) for bn in bns}
             if len(want) != 1 or 2 in want or len({bn.training for bn in bns}) != 1:
                 return None

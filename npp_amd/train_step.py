@@ -90,14 +90,32 @@ class TrainStep:
         if self.reducer is not None and getattr(self.reducer, "tail", False) and K.DEFER_TAIL_OK:
             self._tail_with_reducer()
         else:
-            K.flush_wgrads()
-            K.flush_unpacks()
+            self._tail()
             K.stamp("weight gradients done")
             if self.reducer is not None:
                 self.reducer.finish()
         self.optimizer.step()
         K.stamp("optimizer done")
         return loss
+
+    def _tail(self):
+        """The batched weight-gradient launches of the step.  NPP_TAIL_SPLIT=1: the KxK group on the caller's stream and the rest (1x1,
+        depthwise, SE, their unpacks) on the parsing branch's stream at the same time -- each batched launch ends in a tail of a few
+        long workgroups during which most CUs idle; two launches in flight fill each other's tails."""
+        cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        if cur is None or os.environ.get("NPP_TAIL_SPLIT", "0") != "1":
+            K.flush_wgrads()
+            K.flush_unpacks()
+            return
+        from .model_augment import _side_stream
+        side = _side_stream(cur.device, 0)
+        side.wait_stream(cur)
+        K.flush_wgrads(group="K")
+        K.flush_unpacks(group="K")
+        with torch.cuda.stream(side):
+            K.flush_wgrads()
+            K.flush_unpacks()
+        cur.wait_stream(side)
 
     def _tail_with_reducer(self):
         """GradReducer(overlap="tail"): the batched weight-gradient tail in two groups with the all-reduce of the first group's

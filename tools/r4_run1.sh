@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_wide_gpu.py -x -q > gpurun_out/t_wide.log 2>&1; echo "wide rc=$?"; tail -4 gpurun_out/t_wide.log
-timeout -k 10 300 python -m pytest tests/test_ops_gpu.py tests/test_train_step_gpu.py -x -q > gpurun_out/t_ops.log 2>&1; echo "ops rc=$?"; tail -4 gpurun_out/t_ops.log
-timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-prof > gpurun_out/b3.json 2> gpurun_out/b3.err; echo "bench rc=$?"; tail -c 300 gpurun_out/b3.json
-NPP_SE_PAIR=0 timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-prof > gpurun_out/b3_nose.json 2> gpurun_out/b3_nose.err; echo "bench nose rc=$?"; tail -c 200 gpurun_out/b3_nose.json
+for v in 0 1 0 1; do
+NPP_TAIL_SPLIT=$v timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-prof > gpurun_out/b5_$v.json 2> gpurun_out/b5.err; echo "split=$v rc=$?"; python3 -c "
+import json;d=json.loads(open('gpurun_out/b5_$v.json').read().strip().split('\n')[-1]); print(d['value'], d['ms_per_step'])"
+done
