@@ -3356,6 +3356,30 @@ def _mse_term_bwd(saved, gs_ptr):
     return grad
 
 
+CRIT_SPLIT = os.environ.get("NPP_CRIT_SPLIT", "1") != "0"
+
+
+class _nullctx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def _criterion_side(dev):
+    """The second stream for the criteria's independent stage terms: the parsing branch's stream, while Network.forward runs its
+    branches on two streams (hub stream set) -- never in the single-stream modes (NPP_STREAMS=1, the profiling leg)."""
+    if not CRIT_SPLIT or dev.type != "cuda" or _hub_stream is None:
+        return None
+    for c in _stream_caches:
+        if isinstance(c, dict):
+            st = c.get((dev.type, dev.index, 0))
+            if isinstance(st, torch.cuda.Stream) and st.cuda_stream != torch.cuda.current_stream().cuda_stream:
+                return st
+    return None
+
+
 class _CriterionFused(Function):
     """loss = sum_i [ (sum_{t in stage i} coef_t * term_t) * exp(-lamda_i) + lamda_i ]  (core/criterion.py:139-142, 212-214).
     specs[t] = ("ce", labels, class_w, ignore, ohem, coef, stage) | ("mse", target, weight, coef, stage); xs[t] = the logits /
@@ -3368,16 +3392,32 @@ class _CriterionFused(Function):
         terms = (L.NppLossTerm * nt)()
         saved = []
         keep = []
+        # The terms of the refinement stages are independent (core/criterion.py:139-142, 212-214 sum them): the odd stages run on the
+        # parsing branch's stream while the even ones run here -- the criteria sit between the end of forward and the start of backward
+        # with nothing beside them (1.4 ms of the replayed step, one kernel in flight; round 4)
+        side = _criterion_side(dev) if len({int(sp[6] if sp[0] == "ce" else sp[4]) % 2 for sp in specs}) > 1 else None
+        cur = torch.cuda.current_stream() if side is not None else None
+        if side is not None:
+            side.wait_stream(cur)
+        ctx.on_side = []
         for k, (sp, x) in enumerate(zip(specs, xs)):
-            if sp[0] == "ce":
-                acc, den, sv = _ce_term_fwd(x, sp[1], sp[2], sp[3], sp[4])
-                coef, stage = sp[5], sp[6]
-            else:
-                acc, den, sv = _mse_term_fwd(x, sp[1], sp[2])
-                coef, stage = sp[3], sp[4]
+            stage = int(sp[6] if sp[0] == "ce" else sp[4])
+            there = side is not None and stage % 2 == 1
+            ctx.on_side.append(there)
+            if there:
+                x.record_stream(side)
+            with (torch.cuda.stream(side) if there else _nullctx()):
+                if sp[0] == "ce":
+                    acc, den, sv = _ce_term_fwd(x, sp[1], sp[2], sp[3], sp[4])
+                    coef = sp[5]
+                else:
+                    acc, den, sv = _mse_term_fwd(x, sp[1], sp[2])
+                    coef = sp[3]
             terms[k] = L.NppLossTerm(acc.data_ptr(), 0, den, float(coef), int(stage))
             saved.append((sp[0], sv))
             keep.append(acc)
+        if side is not None:
+            cur.wait_stream(side)
         lam = lamda.detach()
         if lam.dtype != torch.float32 or not lam.is_contiguous():
             lam = lam.float().contiguous()
@@ -3405,12 +3445,24 @@ class _CriterionFused(Function):
         check(lib().npp_loss_tail_bwd(gg.data_ptr(), out[1:].data_ptr(), out[1 + nt:].data_ptr(), nt, ns, gbuf.data_ptr(),
                                       gbuf[nt:].data_ptr(), stream_ptr()), "npp_loss_tail_bwd")
         grads = []
+        side = _criterion_side(out.device) if any(ctx.on_side) else None
+        cur = torch.cuda.current_stream() if side is not None else None
+        if side is not None:
+            side.wait_stream(cur)          # (after the tail's backward: the terms read their scales from gbuf)
         for k, (kind, sv) in enumerate(ctx.terms):
             if not ctx.needs_input_grad[2 + k]:
                 grads.append(None)
                 continue
             gs_ptr = gbuf.data_ptr() + 4 * k
-            grads.append(_ce_term_bwd(sv, gs_ptr) if kind == "ce" else _mse_term_bwd(sv, gs_ptr))
+            there = side is not None and ctx.on_side[k]
+            with (torch.cuda.stream(side) if there else _nullctx()):
+                gk = _ce_term_bwd(sv, gs_ptr) if kind == "ce" else _mse_term_bwd(sv, gs_ptr)
+            if there:
+                gk.record_stream(cur)      # allocated on the side stream, consumed by the heads' backward elsewhere
+            grads.append(gk)
+        if side is not None:
+            gbuf.record_stream(side)
+            cur.wait_stream(side)
         dlam = gbuf[nt:].view(ctx.lam_meta[0])
         if dlam.dtype != ctx.lam_meta[1]:
             dlam = dlam.to(ctx.lam_meta[1])
