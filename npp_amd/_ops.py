@@ -1432,10 +1432,10 @@ WIDE_STATS = [0, 0, 0]      # merged forward launches / merged data gradients th
 class _WideGrad:
     """The dy buffer [N, H, W, sum of the members' Cout] of one merged conv: allocated when the first edge's BatchNorm backward asks
     for its slice."""
-    __slots__ = ("buf", "cos", "offs")
+    __slots__ = ("buf", "cos", "offs", "stream")
 
     def __init__(self, cos):
-        self.buf, self.cos = None, list(cos)
+        self.buf, self.cos, self.stream = None, list(cos), 0
         self.offs = [sum(self.cos[:k]) for k in range(len(self.cos))]
 
     def slot(self, k):
@@ -1447,6 +1447,9 @@ class _WideGrad:
                 return None
             if wg.buf is None:
                 wg.buf = new_nhwc(n, sum(wg.cos), h, w, like.dtype, like.device)
+                wg.stream = stream_ptr() if like.is_cuda else 0
+            elif like.is_cuda and stream_ptr() != wg.stream:
+                wg.buf.record_stream(torch.cuda.current_stream())      # (an edge whose BatchNorm backward runs on the other branch's stream)
             b = wg.buf
             if b.shape[0] != n or b.shape[2] != h or b.shape[3] != w or b.dtype != like.dtype or b.device != like.device:
                 return None

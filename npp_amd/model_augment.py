@@ -509,6 +509,15 @@ class Network(nn.Module):
             self.pose_net.append(PoseCell1(gt.FUSION.pose, gt.FUSION.pose_concat, Cf, Cf, Cf, 1))
             self.par_net.append(ParCell1(gt.FUSION.par, gt.FUSION.par_concat, Cf, Cf, Cf, 1))
 
+        # The pose and the parsing refinement cell of one stage read the SAME in3 / in4 through their preprocess1 / preprocess2
+        # (ReLU - Conv1x1(4C -> C) - BN, model_augment.py:555-571): one conv 512 -> 256 for both, and -- where the bytes are -- ONE data
+        # gradient 256 -> 512 instead of two 151 MB results summed by a read-add-store.  The cells run on the two branch streams:
+        # whichever asks first runs the conv, the other stream waits for it (operations.WideEdges.pending).
+        for pc, qc in zip(self.pose_net, self.par_net):
+            for a, b in ((pc.preprocess1, qc.preprocess1), (pc.preprocess2, qc.preprocess2)):
+                if type(a) is ReLUConvBN and type(b) is ReLUConvBN and WideEdges.fits([a, b]):
+                    self._wide_groups.append(WideEdges([a, b]))
+
         def head(cin, mid, k, cout, bias1=True):
             return _Head(nn.ReLU(), nn.Conv2d(cin, mid, kernel_size=k, padding=k // 2, dilation=1, bias=bias1),
                          nn.BatchNorm2d(mid, momentum=BN_MOMENTUM), nn.ReLU(inplace=True),

@@ -219,8 +219,20 @@ class WideEdges(K.WideGroup):
             ys, svs, sc, slots = K.conv2d_wide(x, self, conv.padding, True, want.pop())
             sides = [BnSide(ys[i], bns[i], svs[i], stats_c=sc if svs[i] is not None else 0, gslot=slots[i])
                      for i in range(len(bns))]
-            self.calls = st = [x, sides]
+            cur = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self.calls = st = [x, sides, cur, ev]
         side, st[1][k] = st[1][k], None
+        if side is not None:
+            # an edge that is picked up on ANOTHER stream than the one the merged conv ran on (the refinement cells of the two task
+            # branches read the same two tensors, model_augment.py:555-571): that stream waits for the conv and owns the tensors too
+            cur = torch.cuda.current_stream()
+            if cur.cuda_stream != st[2].cuda_stream:
+                cur.wait_event(st[3])
+                side.x.record_stream(cur)
+                if side.stats is not None:
+                    side.stats.record_stream(cur)
         if all(sd is None for sd in st[1]):
             self.calls = None
         return side
