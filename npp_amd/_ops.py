@@ -764,7 +764,7 @@ class WeightPacker:
 
     def __init__(self, weights, groups=()):
         self.weights = list(weights)
-        self.groups = [g for g in groups if g.separate_fwd or g.weights[0].shape[0] % 32 == 0]      # WideGroups: merged images (conv2d_wide)
+        self.groups = list(groups)      # WideGroups: merged images (conv2d_wide)
         self.sig = None
         self.epoch = -1            # TRAIN_EPOCH the images were last written at
         self.table = None
@@ -780,15 +780,18 @@ class WeightPacker:
         for g in self.groups:
             ws = g.weights
             _, ci, kh, kw = ws[0].shape
-            buf = None
-            if not g.separate_fwd:
-                co = ws[0].shape[0]
+            run_bufs = {}
+            for r, run in enumerate(g.runs):
+                if len(run) < 2:
+                    continue
+                co = ws[run[0]].shape[0]
                 n1 = int(lib().npp_packed_weight_elems(co, ci, kh, kw, 0))
-                buf = torch.zeros(len(ws) * n1, dtype=dtype, device=device)
-                for k, w in enumerate(ws):
-                    fwd_slice[id(w)] = buf[k * n1:(k + 1) * n1]
+                buf = torch.zeros(len(run) * n1, dtype=dtype, device=device)
+                for q, k in enumerate(run):
+                    fwd_slice[id(ws[k])] = buf[q * n1:(q + 1) * n1]
+                run_bufs[r] = buf
             dgb = torch.zeros(int(lib().npp_packed_weight_elems(sum(g.cos), ci, kh, kw, 1)), dtype=dtype, device=device)
-            self.group_bufs.append((g, buf, dgb))
+            self.group_bufs.append((g, run_bufs, dgb))
         njobs = 2 * len(self.weights) + sum(len(g.weights) for g in self.groups)
         jobs = (L.NppPackJob * njobs)()
         outs = []
@@ -848,10 +851,10 @@ class WeightPacker:
                                                  stream_ptr()), "npp_pack_weights_batched_map")
         self.sig = sig
         self.epoch = TRAIN_EPOCH
-        for g, buf, dgb in self.group_bufs:
-            g.img = {(True, dtype): dgb}
-            if buf is not None:
-                g.img[(False, dtype)] = buf
+        for g, run_bufs, dgb in self.group_bufs:
+            g.img = {("d", dtype): dgb}
+            for r, buf in run_bufs.items():
+                g.img[("f", r, dtype)] = buf
         k = 0
         for w in ws:
             wid = id(w)
@@ -1432,10 +1435,10 @@ WIDE_STATS = [0, 0, 0]      # merged forward launches / merged data gradients th
 class _WideGrad:
     """The dy buffer [N, H, W, sum of the members' Cout] of one merged conv: allocated when the first edge's BatchNorm backward asks
     for its slice."""
-    __slots__ = ("buf", "cos", "offs", "stream")
+    __slots__ = ("buf", "cos", "offs", "stream", "member_stat")
 
     def __init__(self, cos):
-        self.buf, self.cos, self.stream = None, list(cos), 0
+        self.buf, self.cos, self.stream, self.member_stat = None, list(cos), 0, None
         self.offs = [sum(self.cos[:k]) for k in range(len(self.cos))]
 
     def slot(self, k):
@@ -1469,16 +1472,27 @@ def _dx_into(slot, like):
 
 class WideGroup:
     """m conv modules (same Cin, kernel, padding, stride 1) that are applied to one and the same tensor.
-    separate_fwd = False: equal Cout, no bias -- ONE forward conv Cin -> m Cout (the weights' forward images back to back).
-    separate_fwd = True : any Cout, bias allowed -- the forward convs stay m launches (tiles chosen per width), only the DATA GRADIENT
-    is merged: one conv sum(Cout) -> Cin over the concatenated dy (the 1024 -> 512 and 1024 -> 384 layers that both read the
-    concatenated decoder features, model_augment.py:332-351: their second data gradient was a 300 MB read-add-store)."""
+    Forward: consecutive members without bias and of equal Cout form a RUN that is one conv Cin -> (run width) (the weights' forward
+    images back to back); every other member -- another width, a bias: the 1024 -> 512 and 1024 -> 384 layers on the concatenated
+    decoder features, model_augment.py:332-351; the head conv that reads what two refinement cells read -- keeps a launch of its
+    own (tiles chosen per width).  separate_fwd=True forces that for all members.
+    Backward: ONE data gradient for the whole group, sum(Cout) -> Cin over the concatenated dy (the sum over the consumers happens
+    in the MFMA accumulators instead of read-add-store passes over the gradient tensor)."""
 
     def __init__(self, convs, separate_fwd=False):
         self.convs = list(convs)
         self.separate_fwd = bool(separate_fwd)
-        self.img = {}          # (for_dgrad, dtype) -> image written by the model's WeightPacker (valid after its pack_if_stale)
-        self.calls = None      # per-forward cache: [input tensor, list of pending results]
+        self.img = {}          # ("d", dtype) / ("f", run index, dtype) -> image written by the model's WeightPacker (valid after its pack_if_stale)
+        self.calls = None      # per-forward cache: [input tensor, list of pending results, stream, event]
+        runs = []
+        for k, c in enumerate(self.convs):
+            co = c.weight.shape[0]
+            if (not self.separate_fwd and runs and c.bias is None and self.convs[runs[-1][-1]].bias is None
+                    and self.convs[runs[-1][-1]].weight.shape[0] == co and co % 32 == 0):
+                runs[-1].append(k)
+            else:
+                runs.append([k])
+        self.runs = runs
 
     @property
     def weights(self):
@@ -1489,24 +1503,31 @@ class WideGroup:
         return [c.weight.shape[0] for c in self.convs]
 
     def images(self, dtype, need_dgrad):
-        """(forward image | None, data-gradient image | None) of the merged conv."""
+        """([forward image | None per run], data-gradient image | None) of the merged conv."""
         ws = self.weights
-        if (True, dtype) in self.img and self.img[(True, dtype)].device == ws[0].device and (self.separate_fwd or (False, dtype) in self.img):
-            return self.img.get((False, dtype)), self.img[(True, dtype)]
+        dev = ws[0].device
+        merged = [r for r, run in enumerate(self.runs) if len(run) > 1]
+        dg = self.img.get(("d", dtype))
+        if dg is not None and dg.device == dev and all(("f", r, dtype) in self.img for r in merged):
+            return [self.img.get(("f", r, dtype)) for r in range(len(self.runs))], dg
         # no packer manages this group (a cell used on its own): build the images from the per-weight ones
         _, ci, kh, kw = ws[0].shape
         taps = kh * kw
-        fwd = None
-        if not self.separate_fwd:
-            co = ws[0].shape[0]
-            fwd = torch.cat([packed_weight(w, False, dtype).view(-1)[:co * ((taps * ((ci + 7) // 8 * 8) + 63) // 64 * 64)] for w in ws])
+        fwd = []
+        for run in self.runs:
+            if len(run) == 1:
+                fwd.append(None)
+                continue
+            co = ws[run[0]].shape[0]
+            n1 = co * ((taps * ((ci + 7) // 8 * 8) + 63) // 64 * 64)
+            fwd.append(torch.cat([packed_weight(ws[k], False, dtype).view(-1)[:n1] for k in run]))
         dg = None
         if need_dgrad:
             rows = (ci + 31) // 32 * 32
             ct = sum(self.cos)
             ctp = (ct + 7) // 8 * 8
             kg = (taps * ctp + 63) // 64 * 64
-            dg = torch.zeros(rows, kg, dtype=dtype, device=ws[0].device)
+            dg = torch.zeros(rows, kg, dtype=dtype, device=dev)
             v = dg[:, :taps * ctp].view(rows, taps, ctp)
             off = 0
             for w in ws:
@@ -1533,11 +1554,14 @@ class _ConvWide(Function):
         _, _, kh, kw = weights[0].shape
         g = geom(kh, kw, 1, 1, pad[0], pad[1], 1, 1, 1, relu_in)
         need_bwd = any(ctx.needs_input_grad)      # (grad mode is off inside forward: ask the context)
-        wp, wpd = group.images(x.dtype, need_bwd)
+        wps, wpd = group.images(x.dtype, need_bwd)
         s = stream_ptr()
-        if group.separate_fwd:
-            outs, stats_all = [], []
-            for k, wt in enumerate(weights):
+        outs, stats_all = [None] * m, []
+        member_stat = [None] * m                  # per member: (index into stats_all, offset, statistics row width | 0)
+        for r, run in enumerate(group.runs):
+            if len(run) == 1:
+                k = run[0]
+                wt = weights[k]
                 yk = new_nhwc(n, cos[k], h, w, x.dtype, x.device)
                 st = stats_buffer(R * 2 * cos[k], x.device, want_stats) if want_stats else None
                 bf = None
@@ -1548,18 +1572,22 @@ class _ConvWide(Function):
                 _conv_launch(x, packed_weight(wt, False, x.dtype).data_ptr(), ptr(bf), None, yk, ptr(st), g, s, "npp_conv_fwd")
                 if SHAPE_LOG is not None:
                     SHAPE_LOG.append(("fwd", n, ci, h, w, cos[k], kh, kw, 1, 1))
-                outs.append(yk)
+                outs[k] = yk
+                member_stat[k] = (len(stats_all), 0, 0)
                 stats_all.append(st)
-            outs = tuple(outs)
-        else:
-            co = cos[0]
-            y = new_nhwc(n, m * co, h, w, x.dtype, x.device)
-            stats = stats_buffer(R * 2 * m * co, x.device, want_stats) if want_stats else None
-            _conv_launch(x, wp.data_ptr(), None, None, y, ptr(stats), g, s, "npp_conv_fwd(wide)")
-            if SHAPE_LOG is not None:
-                SHAPE_LOG.append(("fwd", n, ci, h, w, m * co, kh, kw, 1, 1))
-            outs = tuple(_alias(y, k * co, co) for k in range(m))
-            stats_all = [stats]
+            else:
+                co, mr = cos[run[0]], len(run)
+                y = new_nhwc(n, mr * co, h, w, x.dtype, x.device)
+                st = stats_buffer(R * 2 * mr * co, x.device, want_stats) if want_stats else None
+                _conv_launch(x, wps[r].data_ptr(), None, None, y, ptr(st), g, s, "npp_conv_fwd(wide)")
+                if SHAPE_LOG is not None:
+                    SHAPE_LOG.append(("fwd", n, ci, h, w, mr * co, kh, kw, 1, 1))
+                for q, k in enumerate(run):
+                    outs[k] = _alias(y, q * co, co)
+                    member_stat[k] = (len(stats_all), q * co, mr * co)
+                stats_all.append(st)
+        wg.member_stat = member_stat
+        outs = tuple(outs)
         WIDE_STATS[0] += 1
         ctx.save_for_backward(x, *weights, *[b for b in biases if b is not None])
         ctx.has_bias = [b is not None for b in biases]
@@ -1635,20 +1663,22 @@ class _ConvWide(Function):
 
 
 def conv2d_wide(x, group, pad, relu_in, want_stats):
-    """The m convs of `group` applied to x -- in one launch, or (group.separate_fwd) one each with only the data gradient merged:
-    ([raw output k], [statistics (view) k], statistics row width | 0, [dy slot k])."""
+    """The m convs of `group` applied to x (one launch per run of the group, see WideGroup) with ONE merged data gradient:
+    ([raw output k], [statistics (view) k], [statistics row width k | 0], [dy slot k])."""
     xa, fan = take_acc(x)
     ws = group.weights
     bs = [c.bias for c in group.convs]
     m, cos = len(ws), group.cos
     wg = _WideGrad(cos)
     res = _ConvWide.apply(xa, _pair(pad), bool(relu_in), int(want_stats), fan, group, wg, *ws, *bs)
-    ys = res[:m]
-    if group.separate_fwd:
-        return ys, list(res[m:2 * m]), 0, [wg.slot(k) for k in range(m)]
-    stats = res[m]
-    svs = [stats[wg.offs[k]:] if stats is not None else None for k in range(m)]
-    return ys, svs, sum(cos), [wg.slot(k) for k in range(m)]
+    ys, stats_list = res[:m], res[m:]
+    svs, scs = [], []
+    for k in range(m):
+        idx, off, width = wg.member_stat[k]
+        st = stats_list[idx]
+        svs.append(st[off:] if st is not None else None)
+        scs.append(width if st is not None else 0)
+    return ys, svs, scs, [wg.slot(k) for k in range(m)]
 
 
 # --------------------------------------------------------------------------------------------------

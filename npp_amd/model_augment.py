@@ -87,10 +87,20 @@ class _Layer(nn.Sequential):
 class _Head(nn.Sequential):
     """ReLU - Conv(k, bias?) - BN - ReLU - Conv1x1(bias)  (model_augment.py:365-398)."""
 
+    _wide = None      # (WideEdges, index): the first conv shares its input with the refinement cells' preprocess convs (Network.__init__)
+
+    def _cb(self):
+        return self[1], self[2]
+
     def forward(self, x):
         c1, bn, c2 = self[1], self[2], self[4]
-        y, st = K.conv2d(x, c1.weight, c1.bias, 1, c1.padding, 1, relu_in=True, want_stats=_use_batch_stats(bn))
-        y = K.bn_add(BnSide(y, bn, st), None, relu=True, training=bn.training)
+        side = None
+        if self._wide is not None and K.WIDE:
+            side = self._wide[0].pending(self._wide[1], x)
+        if side is None:
+            y, st = K.conv2d(x, c1.weight, c1.bias, 1, c1.padding, 1, relu_in=True, want_stats=_use_batch_stats(bn))
+            side = BnSide(y, bn, st)
+        y = K.bn_add(side, None, relu=True, training=bn.training)
         out, _ = K.conv2d(y, c2.weight, c2.bias, 1, 0, 1, relu_in=False)
         return out
 
@@ -513,10 +523,11 @@ class Network(nn.Module):
         # (ReLU - Conv1x1(4C -> C) - BN, model_augment.py:555-571): one conv 512 -> 256 for both, and -- where the bytes are -- ONE data
         # gradient 256 -> 512 instead of two 151 MB results summed by a read-add-store.  The cells run on the two branch streams:
         # whichever asks first runs the conv, the other stream waits for it (operations.WideEdges.pending).
+        self._cross_pairs = []
         for pc, qc in zip(self.pose_net, self.par_net):
             for a, b in ((pc.preprocess1, qc.preprocess1), (pc.preprocess2, qc.preprocess2)):
                 if type(a) is ReLUConvBN and type(b) is ReLUConvBN and WideEdges.fits([a, b]):
-                    self._wide_groups.append(WideEdges([a, b]))
+                    self._cross_pairs.append([a, b])
 
         def head(cin, mid, k, cout, bias1=True):
             return _Head(nn.ReLU(), nn.Conv2d(cin, mid, kernel_size=k, padding=k // 2, dilation=1, bias=bias1),
@@ -530,6 +541,15 @@ class Network(nn.Module):
             self.pose_auxnet.append(head(3 * Cf, 128, 3, self._num_joints))
             self.par_head.append(head(4 * Cf, 256, 1, self._num_classes))
             self.edge_head.append(head(3 * Cf, 6, 3, 2, bias1=False))
+        # ... and the first stage's in3 / in4 are read by pose_head[0] / par_head[0] as well (heads(0) comes before the cells,
+        # model_augment.py:549-553): their 512 -> 256 conv keeps its launch, its data gradient joins the pair's (K = 128 + 128 + 256)
+        for j, pair in enumerate(self._cross_pairs):
+            head0 = (self.pose_head[0], self.par_head[0])[j] if j < 2 else None
+            if head0 is not None and WideEdges.fits_mixed(pair + [head0]):
+                self._wide_groups.append(WideEdges(pair + [head0]))
+            else:
+                self._wide_groups.append(WideEdges(pair))
+        del self._cross_pairs
         self._packer = None
         self._auto = None          # auto_graph.AutoGraph, created by the first training forward under NPP_AUTO_GRAPH=1
         self._init_params()

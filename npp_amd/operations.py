@@ -206,6 +206,18 @@ class WideEdges(K.WideGroup):
         c, ci, k = w0.shape[0], w0.shape[1], w0.shape[2]
         return (len(ops) * c) % 64 == 0 or (c == 32 and ci == 32 and k == 3 and len(ops) <= 4)
 
+    @staticmethod
+    def fits_mixed(ops) -> bool:
+        """Consumers of one tensor with one kernel geometry but any widths / biases (ops with a _cb() accessor): the forward convs that
+        cannot share a launch keep their own, the data gradient is merged -- its K = sum(Cout) must be whole 64-channel tiles."""
+        convs = [op._cb()[0] for op in ops]
+        c0 = convs[0]
+        if len(ops) < 2 or any(c.kernel_size != c0.kernel_size or c.padding != c0.padding or c.in_channels != c0.in_channels
+                               or c.stride != (1, 1) or c.dilation != (1, 1) or c.groups != 1 for c in convs):
+            return False
+        return c0.kernel_size[0] == c0.kernel_size[1] and c0.in_channels % 64 == 0 and sum(c.out_channels for c in convs) % 64 == 0 \
+            and all(c.out_channels % 32 == 0 for c in convs)
+
     def pending(self, k, x):
         st = self.calls
         if st is None or st[0] is not x:
@@ -216,9 +228,8 @@ class WideEdges(K.WideGroup):
             if len(want) != 1 or 2 in want or len({bn.training for bn in bns}) != 1:
                 return None
             conv = self.convs[0]
-            ys, svs, sc, slots = K.conv2d_wide(x, self, conv.padding, True, want.pop())
-            sides = [BnSide(ys[i], bns[i], svs[i], stats_c=sc if svs[i] is not None else 0, gslot=slots[i])
-                     for i in range(len(bns))]
+            ys, svs, scs, slots = K.conv2d_wide(x, self, conv.padding, True, want.pop())
+            sides = [BnSide(ys[i], bns[i], svs[i], stats_c=scs[i], gslot=slots[i]) for i in range(len(bns))]
             cur = torch.cuda.current_stream()
             ev = torch.cuda.Event()
             ev.record(cur)
