@@ -26,6 +26,7 @@ from .operations import OPS, FactorizedReduce, ReLUConvBN, fused_sum, fused_sum_
 from .operations import *  # noqa: F401,F403  (reference does `from models.operations import *`)
 
 BN_MOMENTUM = 0.1
+_RESAMPLE_SWAP = os.environ.get("NPP_RESAMPLE_SWAP", "1") != "0"
 
 _compute_dtype = torch.float32
 
@@ -109,6 +110,13 @@ class _ResampleConv(nn.Sequential):
     """Interpolate(scale) - Conv1x1(bias): the `extra_conv` of the cross-task edges (model_augment.py:590-595)."""
 
     def forward(self, x):
+        if self[0].s > 1 and _RESAMPLE_SWAP:
+            # up-sampling edge (the decoder-stage cross-task edges, model_augment.py:626-649: up to x8 from 1024 channels at 12 x 12 to
+            # 128 at 96 x 96): the 1x1 conv mixes channels, the bilinear resampling mixes pixels with weights that sum to 1 -- they
+            # commute, bias included -- so the conv runs on the SMALL map and the (fewer) output channels are resampled: the x8 edge
+            # was a 302 MB interpolation result feeding a K = 1024 conv at 96 x 96 (and their backward passes and weight gradient)
+            y, _ = K.conv2d(x, self[1].weight, self[1].bias, 1, 0, 1, relu_in=False)
+            return self[0](y)
         y = self[0](x)
         out, _ = K.conv2d(y, self[1].weight, self[1].bias, 1, 0, 1, relu_in=False)
         return out
