@@ -595,6 +595,8 @@ class _SyncStatsPool(_ZeroPool):
             return False
         segs = []
         for sd in self.waiting:
+            if sd.rider:
+                continue
             st = sd.stats
             if st is None or not st.is_cuda or st.dtype != torch.float64 or not st.is_contiguous() or st.numel() % R != 0:
                 return False
@@ -1429,6 +1431,7 @@ def conv2d_crop(x, weight, stride=2, relu_in=False, want_stats=False):
 # stay per parameter (dy slices with ld = m C).  The parameters remain separate tensors under the reference's names; only the
 # derived operand images are shared.  NPP_WIDE=0 keeps one launch per edge.
 WIDE = os.environ.get("NPP_WIDE", "1") != "0"
+WIDE_SYNC = os.environ.get("NPP_WIDE_SYNC", "1") != "0"      # merged edges under SyncBatchNorm too (their statistics rows travel as one segment)
 WIDE_STATS = [0, 0, 0]      # merged forward launches / merged data gradients that found every dy in place / ... that had to gather
 
 
@@ -1758,15 +1761,18 @@ class BnSide:
     """One operand of the fused add.  kind 'bn': `x` is a raw (pre-BN) tensor with f64 stats (train) or a
     BatchNorm holder in eval mode; kind 'plain': `x` is used as is."""
 
-    __slots__ = ("x", "bn", "stats", "count", "synced_ws", "private", "stream", "sync_event", "stats_c", "gslot")
+    __slots__ = ("x", "bn", "stats", "count", "synced_ws", "private", "stream", "sync_event", "stats_c", "gslot", "rider")
 
-    def __init__(self, x, bn=None, stats=None, private=None, stats_c=0, gslot=None):
+    def __init__(self, x, bn=None, stats=None, private=None, stats_c=0, gslot=None, rider=False):
         self.x = x
         self.bn = bn
         # merged edges (conv2d_wide): `stats` starts at this edge's first channel inside statistics rows of stats_c channels
         # ([R][sum stats_c | sumsq stats_c]); gslot(like) -> the edge's slice of the merged conv's dy buffer (BatchNorm backward)
         self.stats_c = int(stats_c)
         self.gslot = gslot
+        # SyncBatchNorm + merged edges: the statistics rows of ALL the merged edges travel as the segment of the run's first edge;
+        # the others ride along (they wait in the pool to learn that the exchange happened, but contribute no segment of their own)
+        self.rider = bool(rider)
         # private: `x` was produced for this operand alone (a raw conv / pool output on its way into its BatchNorm), so it
         # needs no fan-out node (take): ~600 autograd nodes per step less on the host
         self.private = (bn is not None) if private is None else bool(private)

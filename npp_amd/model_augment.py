@@ -554,9 +554,9 @@ class Network(nn.Module):
         for j, pair in enumerate(self._cross_pairs):
             head0 = (self.pose_head[0], self.par_head[0])[j] if j < 2 else None
             if head0 is not None and WideEdges.fits_mixed(pair + [head0]):
-                self._wide_groups.append(WideEdges(pair + [head0]))
+                self._wide_groups.append(WideEdges(pair + [head0], cross_stream=True))
             else:
-                self._wide_groups.append(WideEdges(pair))
+                self._wide_groups.append(WideEdges(pair, cross_stream=True))
         del self._cross_pairs
         self._packer = None
         self._auto = None          # auto_graph.AutoGraph, created by the first training forward under NPP_AUTO_GRAPH=1

@@ -177,9 +177,10 @@ class WideEdges(K.WideGroup):
     others pick up their channel slice.  Anything that does not fit -- a different input object, SyncBatchNorm statistics, mixed
     train / eval BatchNorms -- returns None and the edge runs on its own."""
 
-    def __init__(self, ops, separate_fwd=False):
+    def __init__(self, ops, separate_fwd=False, cross_stream=False):
         super().__init__([op._cb()[0] for op in ops], separate_fwd=separate_fwd)
         self.ops = list(ops)
+        self.cross_stream = bool(cross_stream)      # its edges run on the two task branches' streams (refinement cells)
         for k, op in enumerate(self.ops):
             op._wide = (self, k)
 
@@ -225,11 +226,19 @@ class WideEdges(K.WideGroup):
                 return None
             bns = [op._cb()[1] for op in self.ops]
             want = {_use_batch_stats(bn) for bn in bns}
-            if len(want) != 1 or 2 in want or len({bn.training for bn in bns}) != 1:
+            if len(want) != 1 or len({bn.training for bn in bns}) != 1:
                 return None
+            if 2 in want and (len({id(K._sync_group(bn)[0]) for bn in bns}) != 1 or not K.WIDE_SYNC or self.cross_stream):
+                return None      # (SyncBatchNorm over different process groups, NPP_WIDE_SYNC=0, or edges that are picked up on two
+                                 #  streams: the statistics exchange is ordered on the stream of the pool that holds them)
             conv = self.convs[0]
             ys, svs, scs, slots = K.conv2d_wide(x, self, conv.padding, True, want.pop())
-            sides = [BnSide(ys[i], bns[i], svs[i], stats_c=scs[i], gslot=slots[i]) for i in range(len(bns))]
+            lead = {}       # run (statistics row) -> its first edge: under SyncBatchNorm that edge's segment carries the whole row
+            sides = []
+            for i in range(len(bns)):
+                run = next(r for r, members in enumerate(self.runs) if i in members)
+                sides.append(BnSide(ys[i], bns[i], svs[i], stats_c=scs[i], gslot=slots[i], rider=run in lead))
+                lead.setdefault(run, i)
             cur = torch.cuda.current_stream()
             ev = torch.cuda.Event()
             ev.record(cur)

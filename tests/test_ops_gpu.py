@@ -533,8 +533,10 @@ def test_full_network_bf16_eval_close_to_reference(size):
 def test_full_network_bf16_eval_batch8_runs_the_head_kernels_and_matches_oracle():
     """C=64, 8 x 3 x 384 x 384, bf16, eval mode: at this batch the 1x1 heads (1024->512, 1024->384, 512->256 @96^2: M = 73 728)
     run on conv_g8_kernel and the 3x3 convs of the 96^2 maps on conv_h3_kernel -- the kernels bench.py times -- which the
-    N = 1 network tests never reach (M = 9 216 goes to conv_g4).  All 8 outputs of all 8 images against the CPU oracle
-    (pinned to the reference by tests/test_oracle_golden.py), rel-L2 <= 5e-2 as at N = 1."""
+    N = 1 network tests never reach (M = 9 216 goes to conv_g4).  All 8 outputs against the CPU oracle (pinned to the reference by
+    tests/test_oracle_golden.py), rel-L2 <= 5e-2 as at N = 1.  Eval mode normalises with the running statistics, so every image is
+    independent of the others: the oracle runs on images 0, 3 and 7 (a quarter of the CPU time of all eight) and those slices of the
+    batch-8 result are compared."""
     import ctypes as C
     from npp_amd import _lib
     from npp_amd.model_augment import set_compute_dtype
@@ -545,8 +547,9 @@ def test_full_network_bf16_eval_batch8_runs_the_head_kernels_and_matches_oracle(
     n, size = 8, 384
     images, _, _, _ = synth_batch_hw(n, size, size, seed=3)
     tensors = synth_tensors(template_from_golden(gf), 0)
+    pick = [0, 3, 7]
     with torch.no_grad():
-        rpose, rpar, _ = O.network_forward(tensors, torch.from_numpy(images), train=False)
+        rpose, rpar, _ = O.network_forward(tensors, torch.from_numpy(images[pick]), train=False)
     try:
         net = _build_net(64, torch.bfloat16, gf).eval()
         L = _lib.lib()
@@ -561,7 +564,7 @@ def test_full_network_bf16_eval_batch8_runs_the_head_kernels_and_matches_oracle(
         for i in range(2):
             for nm, o, r in (("pose_map", pose_list[i][0], rpose[i][0]), ("pose_aux", pose_list[i][1], rpose[i][1]),
                              ("par_map", par_list[i][0], rpar[i][0]), ("edge", par_list[i][1], rpar[i][1])):
-                e = rel_l2(_f32(o), r.numpy())
+                e = rel_l2(_f32(o)[pick], r.numpy())
                 worst = max(worst, e)
                 assert e < BF16_EVAL_L2, (nm, i, e)
         print(f"eval 8 x 384 x 384 bf16: worst output error {worst:.3e}, conv_g8 launches {nl.value}")

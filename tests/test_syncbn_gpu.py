@@ -231,7 +231,9 @@ def test_merged_syncbn_exchange_halves_the_forward_collectives(tmp_path, monkeyp
     plain = _run(2, tmp_path / "plain")
     n_m, n_p = int(merged[0]["fwd_exchanges"]), int(plain[0]["fwd_exchanges"])
     print("forward SyncBN exchanges: merged", n_m, "per branch", n_p)
-    assert n_p >= 300 and n_m <= 0.8 * n_p, (n_m, n_p)          # seen: 247 vs 330 (a branch's own pool already merges its two edges)
+    # seen: 247 vs 330 in round 3 (a branch's own pool already merges its two edges); 221 vs 293 since the merged edges of round 4
+    # (same-input convs of a cell as one launch: their statistics travel as one segment)
+    assert n_p >= 250 and n_m <= 0.8 * n_p, (n_m, n_p)
     for r in range(2):
         for k in merged[r].files:
             if k.startswith("out/") or k.startswith("buf/"):
@@ -254,7 +256,7 @@ def test_syncbn_p2p_transport_equals_the_collective(tmp_path, monkeypatch):
     coll = _run(2, tmp_path / "coll")
     print("exchanges through the mailboxes:", int(p2p[0]["p2p_exchanges"]), "forward flushes:", int(p2p[0]["fwd_exchanges"]))
     assert int(coll[0]["p2p_exchanges"]) == 0
-    assert int(p2p[0]["p2p_exchanges"]) == int(p2p[1]["p2p_exchanges"]) >= 2 * int(p2p[0]["fwd_exchanges"]) > 300
+    assert int(p2p[0]["p2p_exchanges"]) == int(p2p[1]["p2p_exchanges"]) >= 2 * int(p2p[0]["fwd_exchanges"]) > 250
     assert int(p2p[0]["p2p_ok"]) == 1 and int(p2p[1]["p2p_ok"]) == 1
     for r in range(2):
         for k in p2p[r].files:

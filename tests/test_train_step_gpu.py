@@ -272,14 +272,15 @@ def test_search_step_graphed_runs_and_trains():
     assert all(float((a - b).abs().max()) > 1e-3 for a, b in zip(net.arch_parameters(), before))
 
 
-@pytest.mark.parametrize("C,size,batch,max_pix,min_queued,tol", [(32, 96, 4, 9300, 40, 1e-4), (64, 192, 2, 150000, 200, 6e-2)])
+@pytest.mark.parametrize("C,size,batch,max_pix,min_queued,tol", [(32, 96, 4, 9300, 40, 1e-4), (64, 192, 2, 150000, 200, 1e-3)])
 def test_batched_weight_gradients_equal_the_immediate_ones(C, size, batch, max_pix, min_queued, tol):
     """TrainStep collects the weight gradients (of maps with <= NPP_DEFER_WGRAD_MAX_PIX pixels) and runs them as one
     npp_conv_wgrad_batched launch per kernel variant before the batched unpack.  Two backward passes over ONE forward (the
     data-gradient chain is deterministic, so both see bit-identical dy): batched == launched where they arise, up to the order of
-    the f32 sums -- and the batched launch must actually have been used.  (C = 64: the SE gates' ill-conditioned float-atomic sums
-    differ by percents between ANY two backward passes and reach every gradient below them: 2e-2 seen, bound 6e-2 -- a gradient
-    that was dropped or written elsewhere is off by 1.0.)"""
+    the f32 sums -- and the batched launch must actually have been used.  (Round 4: the bound of the C = 64 case was 6e-2 while the SE
+    gates summed with float atomics; their slab sums have been deterministic since round 3, so the two passes differ only by the
+    order of the weight-gradient kernels' own f32 atomics: 1e-3, and the SE gate weights are compared as well.  A gradient that was
+    dropped or written elsewhere is off by 1.0.)"""
     from npp_amd import _ops as K
     from npp_amd.criterion import Criterion_par, Criterion_pose
     from npp_amd.model_augment import Network, set_compute_dtype
@@ -309,13 +310,11 @@ def test_batched_weight_gradients_equal_the_immediate_ones(C, size, batch, max_p
         torch.cuda.synchronize()
         assert queued >= min_queued and queued_dw >= 20, (queued, queued_dw)
         worst, worst_k = 0.0, None
-        from npp_amd.operations import SE_Block
-        se = {id(q) for m in net.modules() if isinstance(m, SE_Block) for q in m.parameters()}
         checked = 0
         for k, p in net.named_parameters():
-            # dense and depthwise conv weights: what the batched launches compute.  (Not compared: a BN bias behind a conv bias
-            # -- a pure-noise gradient -- and the SE gate MLP, whose float-atomic batch sums differ by percents from run to run.)
-            if p.grad is None or p.dim() != 4 or id(p) in se:
+            # dense, depthwise and SE-gate conv weights: what the batched launches compute.  (Not compared: a BN bias behind a conv
+            # bias -- a pure-noise gradient.)
+            if p.grad is None or p.dim() != 4:
                 continue
             den = float(p.grad.float().norm())
             if den > 1e-8:
