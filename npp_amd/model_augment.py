@@ -80,7 +80,8 @@ class _Layer(nn.Sequential):
         if self._wide is not None and K.WIDE:
             side = self._wide[0].pending(self._wide[1], x)      # both layers' data gradients as ONE conv (K = 512 + 384)
         if side is None:
-            y, st = K.conv2d(x, conv.weight, conv.bias, 1, conv.padding, 1, relu_in=True, want_stats=_use_batch_stats(bn))
+            lvl = _use_batch_stats(bn)
+            y, st = K.conv2d(x, conv.weight, conv.bias, 1, conv.padding, 1, relu_in=True, want_stats=lvl, bias_dead=lvl > 0)
             side = BnSide(y, bn, st)
         return K.bn_add(side, None, relu=False, training=bn.training)
 
@@ -99,7 +100,8 @@ class _Head(nn.Sequential):
         if self._wide is not None and K.WIDE:
             side = self._wide[0].pending(self._wide[1], x)
         if side is None:
-            y, st = K.conv2d(x, c1.weight, c1.bias, 1, c1.padding, 1, relu_in=True, want_stats=_use_batch_stats(bn))
+            lvl = _use_batch_stats(bn)
+            y, st = K.conv2d(x, c1.weight, c1.bias, 1, c1.padding, 1, relu_in=True, want_stats=lvl, bias_dead=lvl > 0)
             side = BnSide(y, bn, st)
         y = K.bn_add(side, None, relu=True, training=bn.training)
         out, _ = K.conv2d(y, c2.weight, c2.bias, 1, 0, 1, relu_in=False)

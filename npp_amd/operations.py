@@ -232,7 +232,8 @@ class WideEdges(K.WideGroup):
                 return None      # (SyncBatchNorm over different process groups, NPP_WIDE_SYNC=0, or edges that are picked up on two
                                  #  streams: the statistics exchange is ordered on the stream of the pool that holds them)
             conv = self.convs[0]
-            ys, svs, scs, slots = K.conv2d_wide(x, self, conv.padding, True, want.pop())
+            lvl = want.pop()
+            ys, svs, scs, slots = K.conv2d_wide(x, self, conv.padding, True, lvl, bias_dead=lvl > 0)      # (every member is conv -> BN)
             lead = {}       # run (statistics row) -> its first edge: under SyncBatchNorm that edge's segment carries the whole row
             sides = []
             for i in range(len(bns)):
@@ -465,7 +466,7 @@ class Pooled_Conv(nn.Module):
         for i in range(self._n):
             conv, bn = self.net[2 + 3 * i], self.net[3 + 3 * i]
             y, st = K.conv2d(y, conv.weight, conv.bias, conv.stride, conv.padding, 1, relu_in=True,
-                             want_stats=_use_batch_stats(bn))
+                             want_stats=_use_batch_stats(bn), bias_dead=_use_batch_stats(bn) > 0)
             y = K.bn_add(BnSide(y, bn, st), None, relu=False, training=bn.training)
         for _ in range(self._ups):
             y = K.bilinear(y, y.shape[2] * 2, y.shape[3] * 2)

@@ -128,8 +128,14 @@ def main(mode):
     unused = sum(1 for p in model.module.parameters() if p.grad is None or (auto and not bool(p.grad.any())))
     if auto:      # the replayed step: graph captured at the third call, never-used parameters get zeros (DDP waits for every hook)
         assert model.module._auto is not None and model.module._auto.graph is not None, "forward was never captured"
-    assert unused == 116, unused                                                       # SE_Block.bn at stride 1 (SURVEY TL;DR 7)
-    assert moved >= len(before) - 116 - 8, (moved, len(before))
+    # SE_Block.bn at stride 1 (SURVEY TL;DR 7): 116 parameters never get a gradient.  Under the replayed step "unused" is counted as
+    # "all-zero gradient", which since round 4 also holds for the ~14 conv biases in front of a train-mode BatchNorm (exact zeros)
+    assert (116 <= unused <= 116 + 16) if auto else unused == 116, unused
+    # (round 4: the ~14 conv biases that sit directly in front of a train-mode BatchNorm -- the four 1024 -> 512 / 384 layers, the
+    #  heads' first convs, Pooled_Conv -- have the exact gradient zero, which the library now returns instead of the rounding
+    #  residue of a sum that cancels: Adam leaves them where they are, the reference lets them random-walk on that residue; the
+    #  BatchNorm removes them from the function either way)
+    assert moved >= len(before) - 116 - 8 - 16, (moved, len(before))
     assert abs(optimizer.param_groups[0]["lr"] - 0.2 * config.TRAIN.LR * (0.01 if auto else 0.1)) < 1e-12   # MultiStepLR fired at step 1 (and 3)
     sd = model.state_dict()                                                            # DDP keys: `module.` prefix
     torch.save(sd, os.path.join(tmp, "ckpt.pth"))

@@ -8,9 +8,11 @@ import csv, json, os, sys
 from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-FWD_K = ("conv_s1_kernel", "conv_igemm_kernel", "conv_g8_kernel", "conv_g4_kernel", "conv_h3_kernel")
+FWD_K = ("conv_s1_kernel", "conv_igemm_kernel", "conv_g8_kernel", "conv_g4_kernel", "conv_h3_kernel", "conv_c32_kernel", "conv_thin_out_kernel",
+         "conv_thin_in_kernel")
 FIN_K = "conv_s1_finish_kernel"
-WG_K = ("wgrad_tap_kernel", "conv_wgrad_kernel", "conv_wgrad_g4_kernel", "conv_wgrad_h3_kernel")
+WG_K = ("wgrad_tap_kernel", "conv_wgrad_kernel", "conv_wgrad_g4_kernel", "conv_wgrad_h3_kernel", "conv_wgrad_narrow_kernel", "conv_wgrad_thin_kernel",
+        "conv_wgrad_g3_kernel")
 
 
 def run(path, steps=3):
