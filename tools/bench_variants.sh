@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the bench lines of the other modes / configurations -> gpurun_out/r02_bench_variants.txt (copy into profiles/)
+# GPU box: the bench lines of the other modes / configurations -> gpurun_out/<round>_bench_variants.txt (copy into profiles/)
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/${1:-r02}_bench_variants.txt
 : > $out
@@ -10,6 +10,10 @@ run() {
 }
 C="--no-cpu-baseline --no-prof --steps 10"
 run --force-dist $C
+NPP_P2P_ALONE=1 run --force-dist $C
+echo "# (the line above: NPP_P2P_ALONE=1 -- the peer-to-peer exchange kernels in the chain, 1-rank mailbox)" >> $out
+NPP_P2P_ALONE=1 run --force-dist --batch 32 $C
+echo "# (the line above: NPP_P2P_ALONE=1)" >> $out
 run --launcher eager $C
 run --launcher auto $C
 run --batch 32 $C
