@@ -276,8 +276,8 @@ __global__ __launch_bounds__(256) void affine_add_kernel(T* __restrict__ out, lo
       u32x4 w, w2;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        w[i] = (unsigned)f2bf(o[2 * i]) | ((unsigned)f2bf(o[2 * i + 1]) << 16);
-        w2[i] = (unsigned)f2bf(o2[2 * i]) | ((unsigned)f2bf(o2[2 * i + 1]) << 16);
+        w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
+        w2[i] = pack_bf16x2(o2[2 * i], o2[2 * i + 1]);
       }
       *reinterpret_cast<u32x4*>(out + p * ldo + c0) = w;
       mk[p * ldmk + colg] = (unsigned char)pos_bits_bf16x8(w);
@@ -397,8 +397,8 @@ NPP_DEV void affine_add_fin_kernel_body(T* __restrict__ out, long ldo, const T* 
       u32x4 w, w2;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        w[i] = (unsigned)f2bf(o[2 * i]) | ((unsigned)f2bf(o[2 * i + 1]) << 16);
-        w2[i] = (unsigned)f2bf(o2[2 * i]) | ((unsigned)f2bf(o2[2 * i + 1]) << 16);
+        w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
+        w2[i] = pack_bf16x2(o2[2 * i], o2[2 * i + 1]);
       }
       *reinterpret_cast<u32x4*>(out + p * ldo + c0) = w;
       mk[p * ldmk + colg] = (unsigned char)pos_bits_bf16x8(w);

@@ -24,7 +24,7 @@ for s in $SRCS; do
   [ -f "$s" ] || continue
   o=build/${s%.hip}.o
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_params.h -nt "$o" ] || [ conv_wgrad_params.h -nt "$o" ] || [ vecio.h -nt "$o" ] || [ ../../include/npp_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_params.h -nt "$o" ] || [ conv_epi.h -nt "$o" ] || [ conv_wgrad_params.h -nt "$o" ] || [ vecio.h -nt "$o" ] || [ ../../include/npp_hip.h -nt "$o" ]; then
     hipcc --offload-arch=gfx950 -O3 -fPIC -munsafe-fp-atomics -std=c++17 -Wno-unused-result -DNPP_SRC_HASH=\"$SRC_HASH\" $NPP_EXTRA_HIPCC_FLAGS -c "$s" -o "$o" &
     pids+=($!)
   fi

@@ -23,6 +23,15 @@ NPP_DEV bf16_t f2bf(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
+// two floats -> one dword of two bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32; the scalar form `f2bf(a) | f2bf(b) << 16` compiles to
+// two converts + a shift + an sdwa-or
+typedef float npp_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 npp_bf16x2 __attribute__((ext_vector_type(2)));
+NPP_DEV unsigned pack_bf16x2(float lo, float hi) {
+  const npp_f32x2 f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, npp_bf16x2));
+}
+
 template <typename T> struct Elt;
 template <> struct Elt<float> {
   static constexpr int VEC = 4;  // elements per 16 bytes
@@ -63,7 +72,7 @@ template <> struct Vec16<bf16_t> {
   static NPP_DEV void store(bf16_t* p, const float* o) {
     u32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (unsigned)f2bf(o[2 * i]) | ((unsigned)f2bf(o[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
     *reinterpret_cast<u32x4*>(p) = v;
   }
 };
@@ -84,7 +93,7 @@ NPP_DEV u32x4 add_bf16x8(const u32x4& a, const u32x4& b) {
   for (int i = 0; i < 4; ++i) {
     const float lo = __uint_as_float(a[i] << 16) + __uint_as_float(b[i] << 16);
     const float hi = __uint_as_float(a[i] & 0xFFFF0000u) + __uint_as_float(b[i] & 0xFFFF0000u);
-    r[i] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    r[i] = pack_bf16x2(lo, hi);
   }
   return r;
 }

@@ -17,6 +17,7 @@
 //     gradients costs no read-add-store pass.
 #include "common.h"
 #include "conv_params.h"
+#include "conv_epi.h"
 #include <stdlib.h>
 
 namespace {
@@ -110,6 +111,15 @@ __global__ __launch_bounds__(256) void conv_c32_kernel(IgemmParams p, int tiles_
   float* red = reinterpret_cast<float*>(smem + C32_RED);
   const int gx = x0 + lrow;
   const bool col_ok = gx < p.W;
+  const int ekind = (y0 + C32_TH <= p.H && x0 + 16 <= p.W) ? conv_epilogue_kind(p) : 0;      // (whole tiles: conv_epi.h)
+  if (ekind) {
+    const long pixb = ((long)img * p.H + y0 + wave * MI) * p.W + x0;
+    float* const red_w = red + wave * 32 * 2;
+    if (ekind == 1) conv_epilogue_lean<MI, 2, true, 0, false>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red_w);
+    else if (ekind == 2) conv_epilogue_lean<MI, 2, false, 1, false>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red_w);
+    else if (ekind == 3) conv_epilogue_lean<MI, 2, false, 1, true>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red_w);
+    else conv_epilogue_lean<MI, 2, false, 0, false>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red_w);
+  } else {
   f32x4c bias[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -130,8 +140,8 @@ __global__ __launch_bounds__(256) void conv_c32_kernel(IgemmParams p, int tiles_
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[mi][h][j] + bias[h][j];
-      pk[h][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-      pk[h][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+      pk[h][0] = pack_bf16x2(v[0], v[1]);
+      pk[h][1] = pack_bf16x2(v[2], v[3]);
       if (want_stats && live) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -177,6 +187,9 @@ __global__ __launch_bounds__(256) void conv_c32_kernel(IgemmParams p, int tiles_
           d[0] = s; d[1] = q;
         }
       }
+  }
+  }  // generic epilogue
+  if (want_stats) {
     __syncthreads();
     if (t < 32) {
       float s = 0.f, q = 0.f;

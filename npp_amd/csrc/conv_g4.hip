@@ -18,6 +18,7 @@
 // Replaces the same reference call sites as conv_s1.hip / conv_igemm.hip (models/operations.py:69-82, 202-220).
 #include "common.h"
 #include "conv_params.h"
+#include "conv_epi.h"
 #include <stdlib.h>
 
 #ifndef G4_RING
@@ -26,6 +27,9 @@
 // ablation builds (tools/pw_ab.sh): 1 = no output stores, 2 = no operand DMA, 4 = no MFMA.  Results are wrong by design.
 #ifndef G4_DBG
 #define G4_DBG 0
+#endif
+#ifndef G4_LEAN
+#define G4_LEAN 1      // the specialised epilogues of conv_epi.h for whole tiles (0: the generic one everywhere)
 #endif
 
 namespace {
@@ -237,6 +241,15 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
 
   // ---- epilogue (see conv_g8.hip): acc[mi][ni][j] = C[pixel m0 + wm*BM/2 + mi*16 + lrow][channel n0 + wn*BN/2 + ni*16 + 4*lk + j];
   // fragments ni = 2*nb, 2*nb+1 form a 32-channel block whose lanes pair up (v_permlane16_swap) into 16-byte stores
+  const int ekind = (G4_DBG == 0 && G4_LEAN && m0 + BM <= p.M) ? conv_epilogue_kind(p) : 0;      // (whole tiles: conv_epi.h)
+  if (ekind) {
+    const long pixb = (long)m0 + wm * TM;
+    float* const red_w = red + (wm * BN + wn * TN) * 2;
+    if (ekind == 1) conv_epilogue_lean<MI, NI, true, 0, false>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red_w);
+    else if (ekind == 2) conv_epilogue_lean<MI, NI, false, 1, false>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red_w);
+    else if (ekind == 3) conv_epilogue_lean<MI, NI, false, 1, true>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red_w);
+    else conv_epilogue_lean<MI, NI, false, 0, false>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red_w);
+  } else
 #pragma unroll
   for (int nb = 0; nb < NI / 2; ++nb) {
     const int cb = n0 + wn * TN + nb * 32;
@@ -285,8 +298,8 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[mi][nb * 2 + h][j] + bias[h][j];
-        pk[h][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-        pk[h][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        pk[h][0] = pack_bf16x2(v[0], v[1]);
+        pk[h][1] = pack_bf16x2(v[2], v[3]);
         if (want_stats && live) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {

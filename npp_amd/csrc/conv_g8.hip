@@ -31,6 +31,7 @@
 #include "common.h"
 #include "conv_params.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // Compile-time switches of the main loop, A/B'ed on one device with tools/g8_ab.sh:
 //   G8_SPLIT   second DMA instruction of every half-tile issued inside the MFMA cluster instead of the read section
@@ -45,6 +46,14 @@
 #ifndef G8_PRIO
 #define G8_PRIO 1
 #endif
+//   G8_DRAIN   the stores of an epilogue drain under the next K-tile (counted waits that step over them) instead of in front of it
+#ifndef G8_DRAIN
+#define G8_DRAIN 1
+#endif
+//   G8_LEAN    the specialised epilogue for whole tiles (0: the generic one everywhere)
+#ifndef G8_LEAN
+#define G8_LEAN 1
+#endif
 
 namespace {
 
@@ -56,6 +65,9 @@ struct G8Extra {
   int HW;
   int total_tiles;
   unsigned xbytes, wbytes;  // extents of the two buffer descriptors
+  int drain;                // counted waits after an epilogue that may step over its stores (0: none)
+  int stagger_key;
+  int stagger;              // start delay of workgroup b: (b & 3) * stagger ticks of the 100 MHz clock (0: none)
 };
 
 #define G8_DMA(rsrc, voff, soff, ldsoff)                                                                  \
@@ -85,6 +97,8 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
   constexpr int STA = 2 * BUF;                // per-wave BatchNorm statistics (8 x 512 B)
   constexpr int SPLIT = G8_SPLIT < 0 ? (BN == 128 ? 1 : 0) : G8_SPLIT;
   constexpr int WAITN = 4 + 2 * NB;           // DMA instructions a wave may leave in flight at a counted wait
+  constexpr int NST = 4 * MQ;                 // 16-byte store instructions per wave per epilogue
+  static_assert(WAITN + NST < 64, "vmcnt is a 6-bit counter");
   static_assert(2 * AH + 2 * BH <= BUF, "K-tile must fit its buffer");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -193,9 +207,15 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   // in the main loop with G8_SPLIT the waiting phase's own second instruction has not been issued yet: one fewer in flight
+  // After an epilogue the NST stores of the finished tile sit in the (in-order) counter BEHIND the half-tiles of the next tile's first
+  // K-tile and a half: the three counted waits of that K-tile need only operations OLDER than the stores, so they allow NST more in
+  // flight and the stores drain under the K-tile's MFMAs instead of in front of them (`drain` = such waits left).
+  int drain = 0;
   auto stage_wait_loop = [&]() {
-    if (stage_on) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN - SPLIT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stage_on) {
+      if (G8_DRAIN && drain > 0) { --drain; asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN - SPLIT + NST) : "memory"); }
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN - SPLIT) : "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
   // ---- compute stream state ------------------------------------------------------------------------------
@@ -218,7 +238,8 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
 
   auto flush_stats = [&]() {
     if (st_n0 >= 0) {
-      const int cl = lane;       // column of the wave's 64: (b, ni, lrow) = (cl>>5, (cl>>4)&1, cl&15)
+      int cl = lane;             // column of the wave's 64: (b, ni, lrow) = (cl>>5, (cl>>4)&1, cl&15)
+      asm volatile("" : "+v"(cl));      // (laundered, see epilogue_lean)
       const float s = sta[cl * 2], q = sta[cl * 2 + 1];
       const int col = st_n0 + wn * 64 + cl;
       if (col < p.Cout) {
@@ -226,7 +247,7 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
         atomicAdd(st + col, (double)s);
         atomicAdd(st + p.Cout + col, (double)q);
       }
-      sta[lane] = 0.f; sta[lane + 64] = 0.f;
+      sta[cl] = 0.f; sta[cl + 64] = 0.f;
     }
   };
 
@@ -234,19 +255,39 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
   // colbase(b,ni) + 4*lk + j]: a lane owns 4 consecutive channels of one pixel per fragment.  After packing to bf16, one
   // v_permlane16_swap per dword pairs lanes lk <-> lk^1 so that every lane holds 8 consecutive channels (16 bytes):
   // even lk: channels [4lk, 4lk+8) of the ni=0 fragment, odd lk: [16 + 4(lk-1), +8) of the ni=1 fragment.  No LDS.
-  auto epilogue = [&]() {
+  auto epilogue_generic = [&]() {
+    unsigned lng_ = (unsigned)lane;      // (laundered, see epilogue_lean)
+    asm volatile("" : "+v"(lng_));
+    const int lrow = (int)(lng_ & 15u), lk = (int)(lng_ >> 4);
     bf16_t* __restrict__ yg = reinterpret_cast<bf16_t*>(p.y);
     const bf16_t* __restrict__ mg = reinterpret_cast<const bf16_t*>(p.mask);
     const bool want_stats = p.stats != nullptr;
-    if (want_stats && st_n0 != n0c) { flush_stats(); st_n0 = n0c; }
     const int chb = (lk & 1) * 16 + (lk >> 1) * 8;            // channel (within the 32-block) of the lane's 16-byte store
+    // bit masks (NPP_MASK8: one byte covers the lane's 8 channels, 1/16 of the bytes): the loads of BOTH 32-channel blocks in front of
+    // the first store -- a load behind a store waits for the store's acknowledgement (one in-order counter)
+    unsigned mkb[2][2][MQ];
+    if (mg && p.mask_bits) {
+      const unsigned char* mg8 = reinterpret_cast<const unsigned char*>(p.mask);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int mi = 0; mi < MQ; ++mi) {
+            const long gm = (long)m0c + wm * WM + a * HM + mi * 16 + lrow;
+            mkb[b][a][mi] = gm < p.M ? (unsigned)mg8[gm * p.ldm + ((n0c + wn * 64 + b * 32 + chb) >> 3)] : 0u;
+          }
+    }
+    f32x4v bias2[2][NQ];      // (the bias of both blocks up here for the same reason)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ni = 0; ni < NQ; ++ni)
+        bias2[b][ni] = p.bias ? *reinterpret_cast<const f32x4v*>(p.bias + n0c + wn * 64 + b * 32 + ni * 16 + lk * 4) : f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int cb = n0c + wn * 64 + b * 32;
-      f32x4v bias[NQ];
-#pragma unroll
-      for (int ni = 0; ni < NQ; ++ni)
-        bias[ni] = p.bias ? *reinterpret_cast<const f32x4v*>(p.bias + cb + ni * 16 + lk * 4) : f32x4v{0.f, 0.f, 0.f, 0.f};
+      const f32x4v* bias = bias2[b];
       float ss[NQ][4], sq[NQ][4];
 #pragma unroll
       for (int ni = 0; ni < NQ; ++ni)
@@ -255,18 +296,8 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
       // ReLU-backward mask of this 32-channel block: all 2*MQ loads in flight at once (the main loop's fragment
       // registers are free here); one load per store would pay the memory latency 2*MQ times per block
       u32x4 mk[2][MQ];
-      unsigned mkb[2][MQ];
       if (mg) {
-        if (p.mask_bits) {      // NPP_MASK8: one byte covers the lane's 8 channels (1/16 of the bytes)
-          const unsigned char* mg8 = reinterpret_cast<const unsigned char*>(p.mask);
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int mi = 0; mi < MQ; ++mi) {
-              const long gm = (long)m0c + wm * WM + a * HM + mi * 16 + lrow;
-              mkb[a][mi] = gm < p.M ? (unsigned)mg8[gm * p.ldm + ((cb + chb) >> 3)] : 0u;
-            }
-        } else {
+        if (!p.mask_bits) {
 #pragma unroll
           for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -287,9 +318,9 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
           for (int ni = 0; ni < NQ; ++ni) {
             float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = acc[a][b][mi][ni][j] + bias[ni][j]; acc[a][b][mi][ni][j] = 0.f; }
-            pk[ni][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-            pk[ni][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            for (int j = 0; j < 4; ++j) v[j] = acc[a][b][mi][ni][j] + bias[ni][j];
+            pk[ni][0] = pack_bf16x2(v[0], v[1]);
+            pk[ni][1] = pack_bf16x2(v[2], v[3]);
             if (want_stats && live) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -304,7 +335,7 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
           if (live) {
             if (mg) {      // ReLU backward: keep where the forward input was positive (bf16 > 0 <=> int16 > 0)
               if (p.mask_bits) {
-                o = o & mask8_expand(mkb[a][mi]);
+                o = o & mask8_expand(mkb[b][a][mi]);
               } else {
                 const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                 s16x8 m = __builtin_elementwise_max(__builtin_bit_cast(s16x8, mk[a][mi]), z);
@@ -342,6 +373,142 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
         }
       }
     }
+  };
+
+  // Every tile takes the same time, so without this all 256 workgroups reach their epilogues together: the stores of a whole round
+  // (33 MB) hit HBM as one burst while nothing computes, and between the bursts HBM only sees the MFMA-paced operand reads.
+  const int stag_k = e.stagger_key ? (int)(blockIdx.x * 4 / gridDim.x) : (int)(blockIdx.x & 3);
+  if (e.stagger > 0 && stag_k) {
+    const unsigned long long t0 = wall_clock64(), dt = (unsigned long long)stag_k * (unsigned)e.stagger;
+    while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(16);
+  }
+  // The same epilogue for the cases the network runs (whole tiles; bias / statistics / mask format fixed at compile time; a wave-
+  // uniform base address + ONE per-lane offset computed once per kernel).  The generic form above costs ~170 VALU instructions per
+  // 16-byte store -- 64-bit row addresses, run-time format branches, two converts + shift + or per bf16 pair -- and a wave64 VALU
+  // instruction holds its SIMD for 4 cycles: 16 stores x 170 x 4 x 2 waves = ~22 000 cycles = 9-10 us per tile with no MFMA running,
+  // which is what profiles/r04_g8_ablation.txt measured as "the epilogue" (45 of 189 us forward, 139 of 254 us data gradient).
+  auto epilogue_lean = [&](auto BIAS_, auto STATS_, auto MASK_) {
+    constexpr bool BIAS = decltype(BIAS_)::value, STATS = decltype(STATS_)::value;
+    constexpr int MASK = decltype(MASK_)::value;      // 0 none, 1 bits (one byte per 8 channels), 2 bf16 tensor
+    // (laundered lane id: everything below is loop-invariant, and hoisted out of the tile loop it would live in registers the main
+    // loop does not have -- 81 spilled VGPRs when the compiler was allowed to)
+    unsigned ln_ = (unsigned)lane;
+    asm volatile("" : "+v"(ln_));
+    const unsigned lrow_ = ln_ & 15u, lk_ = ln_ >> 4;
+    const unsigned chb_ = (lk_ & 1) * 16 + (lk_ >> 1) * 8;      // channel (within the 32-block) of the lane's 16-byte store
+    const unsigned yoff_lane = (lrow_ * (unsigned)p.ldy + chb_) * 2u;
+    const unsigned moff_lane = MASK == 1 ? lrow_ * (unsigned)p.ldm + (chb_ >> 3) : (lrow_ * (unsigned)p.ldm + chb_) * 2u;
+    char* const yb = reinterpret_cast<char*>(p.y);
+    const char* const mb = reinterpret_cast<const char*>(p.mask);
+    const long row0 = (long)m0c + wm * WM;
+    const int col0 = n0c + wn * 64;
+    f32x4v bias2[2][NQ];
+    if (BIAS) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ni = 0; ni < NQ; ++ni) bias2[b][ni] = *reinterpret_cast<const f32x4v*>(p.bias + col0 + b * 32 + ni * 16 + lk_ * 4);
+    }
+    unsigned mkb[2][2][MQ];
+    if (MASK == 1) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int mi = 0; mi < MQ; ++mi)
+            mkb[b][a][mi] = *reinterpret_cast<const unsigned char*>(mb + ((row0 + a * HM + mi * 16) * p.ldm + ((col0 + b * 32) >> 3)) + moff_lane);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      u32x4 mk[2][MQ];
+      if (MASK == 2) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int mi = 0; mi < MQ; ++mi)
+            mk[a][mi] = *reinterpret_cast<const u32x4*>(mb + ((row0 + a * HM + mi * 16) * p.ldm + col0 + b * 32) * 2 + moff_lane);
+      }
+      float ss[NQ][4], sq[NQ][4];
+      if (STATS) {
+#pragma unroll
+        for (int ni = 0; ni < NQ; ++ni)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ss[ni][j] = 0.f; sq[ni][j] = 0.f; }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int mi = 0; mi < MQ; ++mi) {
+          unsigned pk[NQ][2];
+#pragma unroll
+          for (int ni = 0; ni < NQ; ++ni) {
+            f32x4v v = acc[a][b][mi][ni];
+            if (BIAS) v += bias2[b][ni];
+            pk[ni][0] = pack_bf16x2(v[0], v[1]);
+            pk[ni][1] = pack_bf16x2(v[2], v[3]);
+            if (STATS) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float r = __uint_as_float((j & 1) ? (pk[ni][j >> 1] & 0xFFFF0000u) : (pk[ni][j >> 1] << 16));
+                ss[ni][j] += r; sq[ni][j] += r * r;
+              }
+            }
+          }
+          const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+          u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+          if (MASK == 1) o = o & mask8_expand(mkb[b][a][mi]);
+          if (MASK == 2) {
+            const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            s16x8 m = __builtin_elementwise_max(__builtin_bit_cast(s16x8, mk[a][mi]), z);
+            m = (z - m) >> 15;
+            o = o & __builtin_bit_cast(u32x4, m);
+          }
+          *reinterpret_cast<u32x4*>(yb + ((row0 + a * HM + mi * 16) * p.ldy + col0 + b * 32) * 2 + yoff_lane) = o;
+          __builtin_amdgcn_sched_barrier(0);      // (one store's worth of temporaries at a time: the main loop leaves no registers to spare)
+        }
+      if (STATS) {
+        // Sum over the 16 pixel lanes of a row as a reduce-SCATTER: each of the four DPP exchanges (mirror, half mirror, xor 2, xor 1)
+        // halves the values a lane carries, so lane lrow ends with the total of value k = lrow (k = t * 8 + ni * 4 + j; t: sum | sum of
+        // squares) -- 15 exchanges instead of the 64 of an all-reduce, and ONE accumulator update per lane, all 64 lanes at distinct
+        // addresses, instead of 16 updates under an lrow == 0 branch.
+        const bool b3 = (lrow_ & 8u) != 0, b2 = (lrow_ & 4u) != 0, b1 = (lrow_ & 2u) != 0, b0 = (lrow_ & 1u) != 0;
+#define G8_XADD(keep, send, ctrl) ((keep) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (send)), ctrl, 0xF, 0xF, true)))
+        float w1[8], w2[4], w3[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float lo = ss[i >> 2][i & 3], hi = sq[i >> 2][i & 3];
+          w1[i] = G8_XADD(b3 ? hi : lo, b3 ? lo : hi, 0x140);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w2[i] = G8_XADD(b2 ? w1[4 + i] : w1[i], b2 ? w1[i] : w1[4 + i], 0x141);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w3[i] = G8_XADD(b1 ? w2[2 + i] : w2[i], b1 ? w2[i] : w2[2 + i], 0x4E);
+        const float w4 = G8_XADD(b0 ? w3[1] : w3[0], b0 ? w3[0] : w3[1], 0xB1);
+#undef G8_XADD
+        float* d = sta + (b * 32 + ((lrow_ >> 2) & 1u) * 16 + lk_ * 4 + (lrow_ & 3u)) * 2 + (lrow_ >> 3);
+        *d += w4;
+      }
+    }
+  };
+  auto epilogue = [&]() {
+    using T_ = std::true_type; using F_ = std::false_type;
+    using M0 = std::integral_constant<int, 0>; using M1 = std::integral_constant<int, 1>; using M2 = std::integral_constant<int, 2>;
+    const bool st = p.stats != nullptr, bi = p.bias != nullptr;
+    if (st && st_n0 != n0c) { flush_stats(); st_n0 = n0c; }
+    if (G8_LEAN && !p.generic_epi && m0c + BM <= p.M && !p.accum && n0c + BN <= p.Cout) {
+#ifndef G8_LEAN_ONLY
+#define G8_LEAN_ONLY 63
+#endif
+      if (!p.mask) {
+        if (st) { if (bi) { if (G8_LEAN_ONLY & 1) { epilogue_lean(T_{}, T_{}, M0{}); return; } } else { if (G8_LEAN_ONLY & 2) { epilogue_lean(F_{}, T_{}, M0{}); return; } } }
+        else    { if (bi) { if (G8_LEAN_ONLY & 4) { epilogue_lean(T_{}, F_{}, M0{}); return; } } else { if (G8_LEAN_ONLY & 8) { epilogue_lean(F_{}, F_{}, M0{}); return; } } }
+      } else if (!st && !bi) {
+        if (p.mask_bits) { if (G8_LEAN_ONLY & 16) { epilogue_lean(F_{}, F_{}, M1{}); return; } } else { if (G8_LEAN_ONLY & 32) { epilogue_lean(F_{}, F_{}, M2{}); return; } }
+      }
+    }
+    epilogue_generic();
   };
 
   // ---- prologue: K-tiles 0 and 1 (first two halves) of the stream -----------------------------------------
@@ -456,7 +623,18 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
     /* the very last phase: waves 4-7 skip the trailing barrier (waves 0-3 are one barrier ahead) */
     if (!(G8_STAGGER && last && grp == 1)) { G8_END_PHASE() }
     if (tile_end) {
-      if (!(DBG & 1)) epilogue();
+      if (!(DBG & 1)) {
+        epilogue(); drain = p.accum ? 0 : e.drain;
+        // (zeroed HERE, behind the join of the epilogue variants: zeroed inside them the 128 accumulators become 128 phis of 7 values)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int mi = 0; mi < MQ; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NQ; ++ni) acc[a][b][mi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      }
       else {   // keep the accumulators (and with them the MFMAs) alive
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -530,6 +708,16 @@ bool conv_g8_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   G8Extra e;
   e.taps = p.KH * p.KW; e.nchunks = p.Cin / 64; e.nk = e.taps * e.nchunks; e.P = P; e.HW = p.H * p.W;
   e.total_tiles = tiles;
+  static const int drain_env = getenv("NPP_G8_DRAIN") ? atoi(getenv("NPP_G8_DRAIN")) : 3;
+  e.drain = drain_env < 0 ? 0 : drain_env > 3 ? 3 : drain_env;
+  // start stagger, ns per K-tile of a tile (workgroup group k of 4 starts k quarter-tiles late).  Measured (tools/g8_stagger.sh, N = 16,
+  // 96^2): 512->256 forward 61.5 -> 54.2 us, its data gradient 103 -> 95 us at 2000; the K = 1024 shapes lose 2-4 % at any value --
+  // default: on for K-loops of <= 8 K-tiles only.
+  static const int stag_env = getenv("NPP_G8_STAGGER_NS") ? atoi(getenv("NPP_G8_STAGGER_NS")) : -1;
+  const int stag_ns = stag_env >= 0 ? stag_env : (e.nk <= 8 && tiles > 2 * 256 ? 2000 : 0);
+  e.stagger = (int)((long)stag_ns * e.nk / 4 / 10);
+  static const int stag_key = getenv("NPP_G8_STAGGER_KEY") ? atoi(getenv("NPP_G8_STAGGER_KEY")) : 1;
+  e.stagger_key = stag_key;
   e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
   e.wbytes = (unsigned)((long)npad * p.Kpad * 2);
   IgemmParams q = p;

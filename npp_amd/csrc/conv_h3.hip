@@ -21,7 +21,12 @@
 //     ReLU-backward mask as bf16 tensor or NPP_MASK8 bits, BatchNorm sum / sum-of-squares of the stored values).
 #include "common.h"
 #include "conv_params.h"
+#include "conv_epi.h"
 #include <stdlib.h>
+
+#ifndef H3_LEAN
+#define H3_LEAN 1      // the specialised epilogues of conv_epi.h for whole tiles (0: the generic one everywhere)
+#endif
 
 namespace {
 
@@ -202,6 +207,15 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_h3_kernel(IgemmParams p, 
   float* red = reinterpret_cast<float*>(smem + RED);     // [NWM][BN channels][2]
   const int gx = x0 + lrow;
   const bool col_ok = gx < p.W;
+  const int ekind = (H3_LEAN && y0 + TH <= p.H && x0 + 16 <= p.W) ? conv_epilogue_kind(p) : 0;      // (whole tiles: conv_epi.h)
+  if (ekind) {
+    const long pixb = ((long)img * p.H + y0 + wm * MI) * p.W + x0;
+    float* const red_w = red + (wm * BN + wn * TN) * 2;
+    if (ekind == 1) conv_epilogue_lean<MI, NI, true, 0, false>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red_w);
+    else if (ekind == 2) conv_epilogue_lean<MI, NI, false, 1, false>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red_w);
+    else if (ekind == 3) conv_epilogue_lean<MI, NI, false, 1, true>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red_w);
+    else conv_epilogue_lean<MI, NI, false, 0, false>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red_w);
+  } else
 #pragma unroll
   for (int nb = 0; nb < NI / 2; ++nb) {
     const int cb = n0 + wn * TN + nb * 32;
@@ -254,8 +268,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_h3_kernel(IgemmParams p, 
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[mi][nb * 2 + h][j] + bias[h][j];
-        pk[h][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-        pk[h][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        pk[h][0] = pack_bf16x2(v[0], v[1]);
+        pk[h][1] = pack_bf16x2(v[2], v[3]);
         if (want_stats && live) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {

@@ -586,6 +586,8 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
   NPP_REQUIRE(M > 0 && M < (1L << 30) && (long)x->n * x->h * x->w < (1L << 30), NPP_E_SHAPE, "npp_conv_fwd: too many pixels");
   p.M = (int)M;
   p.mask_bits = mask_bits ? 1 : 0;
+  static const bool lean_off = getenv("NPP_EPI_LEAN") && atoi(getenv("NPP_EPI_LEAN")) == 0;
+  p.generic_epi = lean_off ? 1 : 0;
   p.vec_io = (y->ld % vec == 0) && (((uintptr_t)y->ptr & 15) == 0) &&
              (!mask || mask_bits || ((mask->ld % vec == 0) && (((uintptr_t)mask->ptr & 15) == 0)));
   const int npad = round_up(p.Cout, 32);
@@ -609,17 +611,25 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * (double)M * p.Cout * (double)(g->kh * g->kw) * p.Cin;
   const double bytes = ((double)x->n * x->h * x->w * x->c + (double)M * y->c + (double)p.Cout * g->kh * g->kw * p.Cin) * esize(x->dtype);
+  // NPP_EPI_CENSUS=1: one line per launch of the LDS-DMA kernels with the epilogue flags (which specialised epilogues are worth having)
+  static const bool epi_census = getenv("NPP_EPI_CENSUS") != nullptr;
+  auto census = [&](const char* k) {
+    if (epi_census)
+      fprintf(stderr, "npp-epi %s N=%d %dx%d C %d->%d k%d bias%d stats%d mask%d accum%d relu%d\n", k, p.N, p.H, p.W, p.Cin, p.Cout, p.KH,
+              p.bias ? 1 : 0, p.stats ? 1 : 0, p.mask ? (p.mask_bits ? 1 : 2) : 0, p.accum ? 1 : 0, p.relu_in ? 1 : 0);
+    return k;
+  };
   {
     ProfScope prof2(NPP_FAM_CONV_G4, x->dtype, s, flops, bytes);
-    if (conv_thin_launch(p, x->dtype, s)) return npp_check_launch("conv_thin");  // (same family: stride-1 fwd + dgrad)
-    if (conv_c32_launch(p, x->dtype, s)) return npp_check_launch("conv_c32");
-    if (conv_h3_launch(p, x->dtype, s)) return npp_check_launch("conv_h3");
-    if (conv_g4_launch(p, x->dtype, s)) return npp_check_launch("conv_g4");
+    if (conv_thin_launch(p, x->dtype, s)) return npp_check_launch(census("conv_thin"));  // (same family: stride-1 fwd + dgrad)
+    if (conv_c32_launch(p, x->dtype, s)) return npp_check_launch(census("conv_c32"));
+    if (conv_h3_launch(p, x->dtype, s)) return npp_check_launch(census("conv_h3"));
+    if (conv_g4_launch(p, x->dtype, s)) return npp_check_launch(census("conv_g4"));
     prof2.cancel();
   }
   {
     ProfScope prof0(NPP_FAM_CONV_G8, x->dtype, s, flops, bytes);
-    if (conv_g8_launch(p, x->dtype, s)) return npp_check_launch("conv_g8");
+    if (conv_g8_launch(p, x->dtype, s)) return npp_check_launch(census("conv_g8"));
     prof0.cancel();
   }
   if (p.mask_bits) {      // only the LDS-DMA kernels above read bit-masks: the caller retries with the bf16 tensor as mask

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void conv_thin_out_kernel(IgemmParams p, int t
       const int co = 4 * kg + j;
       v[j] = acc[r][j] + ((p.bias && co < p.Cout) ? p.bias[co] : 0.f);
     }
-    const unsigned pk0 = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    const unsigned pk1 = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    const unsigned pk0 = pack_bf16x2(v[0], v[1]);
+    const unsigned pk1 = pack_bf16x2(v[2], v[3]);
     if (want_stats && live && kg < 2) {
       const float r0 = __uint_as_float(pk0 << 16), r1 = __uint_as_float(pk0 & 0xFFFF0000u);
       const float r2 = __uint_as_float(pk1 << 16), r3 = __uint_as_float(pk1 & 0xFFFF0000u);
@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(IgemmParams p, int ti
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[2 * a + h][j] + (p.bias ? p.bias[cb + h * 16 + kg * 4 + j] : 0.f);
-        pk[h][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-        pk[h][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        pk[h][0] = pack_bf16x2(v[0], v[1]);
+        pk[h][1] = pack_bf16x2(v[2], v[3]);
       }
       const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
       const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);

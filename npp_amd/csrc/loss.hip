@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void ce_pixel_grad_up_kernel(const T* __restri
           for (int e = 0; e < 4; ++e) {
             const int c0_ = q * 8 + 2 * e;
             const float lo = c0_ < CMAX ? v[c0_ < CMAX ? c0_ : 0] : 0.f, hi = c0_ + 1 < CMAX ? v[c0_ + 1 < CMAX ? c0_ + 1 : 0] : 0.f;
-            w[e] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+            w[e] = pack_bf16x2(lo, hi);
           }
           *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(out) + q * 8) = w;
         }
