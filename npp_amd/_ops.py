@@ -1671,9 +1671,14 @@ class _ConvWide(Function):
             dx = _conv_dgrad(x, dy_all, ctx.wpd, ct, kh, kw, (1, 1), pad, (1, 1), relu_in, ctx.mask_bits, ctx.fan)
         dws, dbs = [], []
         s = stream_ptr()
+        merged = None
+        if kh == 1 and kw == 1 and all(d is not None for d in dys) and all(ctx.needs_input_grad[7 + k] for k in range(m)):
+            merged = _conv_wgrad_merged(x, dy_all, weights, cos, relu_in)
         for k, wt in enumerate(weights):
             dyk = _alias(dy_all, offs[k], cos[k]) if dys[k] is not None else None
-            if ctx.needs_input_grad[7 + k] and dyk is not None:
+            if merged is not None:
+                dws.append(merged[k])
+            elif ctx.needs_input_grad[7 + k] and dyk is not None:
                 dws.append(_conv_wgrad(x, dyk, wt, (1, 1), pad, (1, 1), relu_in))
             else:
                 dws.append(None)
@@ -1682,6 +1687,50 @@ class _ConvWide(Function):
             else:
                 dbs.append(None)
         return (dx, None, None, None, None, None, None, *dws, *dbs)
+
+
+# The 1x1 members of a merged edge read the same x: as separate jobs of the batched weight-gradient launch each of them fetches it from
+# HBM for itself (1024 channels @96^2 = 302 MB, twice per branch for the layer pair; 151 MB three times for a refinement pair + head).
+# Their dy are channel slices of ONE buffer, so the group is ONE weight-gradient problem with Cout = sum of the members': the output
+# tiles of a pixel split run side by side on one XCD and share the x rows through its L2.  The job accumulates into a packed
+# [sum Cout][Cin] scratch, the batched unpack copies each member's rows into its gradient (a few MB).  NPP_WIDE_WGRAD=0: one job each.
+WIDE_WGRAD = os.environ.get("NPP_WIDE_WGRAD", "1") != "0"
+WIDE_WGRADS = [0]      # merged weight-gradient jobs queued
+
+
+def _conv_wgrad_merged(x, dy_all, weights, cos, relu_in):
+    """One deferred weight-gradient job for the 1x1 members of a merged edge: the members' gradient tensors, or None (not applicable:
+    the caller queues one job per member)."""
+    n, ci, h, w = x.shape
+    ct = sum(cos)
+    if not (WIDE_WGRAD and DEFER_UNPACK and 0 < n * h * w <= DEFER_WGRAD_MAX_PIX and x.dtype == torch.bfloat16 and ci % 64 == 0):
+        return None
+    if any(wt.dtype != torch.float32 or id(wt) in _deferred_params for wt in weights):
+        return None
+    g = geom(1, 1, 1, 1, 0, 0, 1, 1, 1, relu_in)
+    wkey = (tuple(x.shape), L.nhwc_ld(x), ct, L.nhwc_ld(dy_all), 1, 1, (1, 1), (0, 0), (1, 1), x.dtype, "merged")
+    ok = _wgrad_batchable.get(wkey)
+    if ok is None:
+        ok = _wgrad_batchable[wkey] = bool(lib().npp_conv_wgrad_batchable(_byref(x), _byref(dy_all), C.byref(g)))
+    if not ok:
+        return None
+    for wt in weights:
+        _may_defer(wt)
+    kpad = (ci + 63) // 64 * 64
+    dwp = zeros_f32(ct * kpad, x.device)
+    keep = torch.empty(0, dtype=dwp.dtype, device=dwp.device).set_(dwp.untyped_storage(), dwp.storage_offset(), dwp.shape, dwp.stride())
+    _pending_wgrads.append((x, dy_all, keep, g, torch.cuda.current_stream(), 0))
+    s = stream_ptr()
+    outs, off = [], 0
+    for wt, co in zip(weights, cos):
+        dw = grad_out(wt)
+        if dw is None:
+            dw = torch.empty(wt.shape, dtype=torch.float32, device=x.device)
+        _unpack_or_defer(dwp[off * kpad:(off + co) * kpad], dw, co, ci, 1, 1, 0, s, True)
+        outs.append(dw)
+        off += co
+    WIDE_WGRADS[0] += 1
+    return outs
 
 
 def conv2d_wide(x, group, pad, relu_in, want_stats, bias_dead=False):

@@ -356,3 +356,54 @@ def test_layers_on_one_tensor_share_one_data_gradient(dtype):
             assert (w_g[k][j] - s_g[k][j]).abs().max() <= (1e-5 if f32 else 2e-2) * max(float(s_g[k][j].abs().max()), 1e-3), (k, j)
     assert err(w_dx, xr.grad) < (5e-4 if f32 else 4e-2)
     assert err(w_dx, s_dx) < (1e-5 if f32 else 2e-2)
+
+
+def test_one_by_one_members_of_a_merged_edge_queue_one_weight_gradient_job():
+    """Under TrainStep the weight gradients are deferred to one batched launch; the 1x1 members of a merged edge read the same x and
+    their dy are channel slices of one buffer, so they queue ONE job with Cout = 256 + 128 (_conv_wgrad_merged) whose rows the batched
+    unpack hands to the two parameters.  Against the same modules with one job per member (NPP_WIDE_WGRAD=0 form)."""
+    import copy
+    from npp_amd import _ops as K
+    from npp_amd.model_augment import _Layer
+    from npp_amd.operations import WideEdges
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(12)
+    cin, couts, N, H = 256, (256, 128), 2, 24
+    layers = []
+    for co in couts:
+        lay = _Layer(nn.ReLU(), nn.Conv2d(cin, co, 1), nn.BatchNorm2d(co))
+        with torch.no_grad():
+            lay[1].weight.copy_(torch.randn(co, cin, 1, 1, generator=g) * 0.08)
+            lay[1].bias.copy_(torch.randn(co, generator=g) * 0.1)
+        layers.append(lay)
+    x_cpu = torch.randn(N, cin, H, H, generator=g)
+    rs = [torch.randn(N, co, H, H, generator=g) / (N * H * H) ** 0.5 for co in couts]
+
+    def run(merged):
+        ls = [copy.deepcopy(m).to(dev).train() for m in layers]
+        WideEdges(ls, separate_fwd=True)
+        old = (K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK, K.WIDE_WGRAD)
+        K.fan_reset()
+        try:
+            K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK, K.WIDE_WGRAD = 1 << 30, True, merged
+            leaf = x_cpu.to(dev).requires_grad_(True)
+            x = K.bn_add(K.BnSide(K.cast(leaf.contiguous(memory_format=torch.channels_last), torch.bfloat16)), None)
+            before = K.WIDE_WGRADS[0]
+            ys = [m(x) for m in ls]
+            sum((y.float() * r.to(dev)).sum() for y, r in zip(ys, rs)).backward()
+            K.flush_wgrads()
+            K.flush_unpacks()
+            torch.cuda.synchronize()
+            jobs = K.WIDE_WGRADS[0] - before
+        finally:
+            K.DEFER_WGRAD_MAX_PIX, K.DEFER_UNPACK, K.WIDE_WGRAD = old
+            K.drop_pending()
+            K.fan_reset()
+        return [m[1].weight.grad.float().cpu() for m in ls], jobs
+
+    gm, jm = run(True)
+    gs, js = run(False)
+    assert jm == 1 and js == 0
+    for a, b in zip(gm, gs):
+        assert a.shape == b.shape and float(b.abs().max()) > 0
+        assert (a - b).abs().max() <= 1e-5 * float(b.abs().max())      # (same bf16 operands, f32 accumulation in another order)
