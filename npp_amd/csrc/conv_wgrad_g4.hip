@@ -20,6 +20,10 @@
 #include <algorithm>
 #include <vector>
 
+#ifndef WG3_DEFAULT
+#define WG3_DEFAULT 0
+#endif
+
 namespace {
 
 typedef float f32x4g __attribute__((ext_vector_type(4)));
@@ -238,14 +242,20 @@ struct WG3Extra {
   unsigned xbytes, dybytes;
 };
 
-template <bool RELU, int R>
+// NW = 4: 2 x 2 waves of 64 x 64 (192 accumulator registers, one wave per SIMD).  NW = 8 (round 4): 2 x 4 waves of 64 x 32 -- 96
+// accumulator registers, TWO waves per SIMD: one wave's transposed reads and DMA issue run under the other's MFMAs, which is what the
+// 4-wave form could not do (2.9 us per K-tile against 0.64 us of MFMA time).
+template <bool RELU, int R, int NW>
 NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
   constexpr int XOFF = 16384;            // x image behind the dy tile
   constexpr int KT = 16384 + 18 * 1024;  // dy [64 px][256 B] + x [72 rows][256 B] (rows 0 .. 65 used)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int WN = NW / 2;                // waves along the input-channel axis; a wave owns 64 co x (128 / WN) ci
+  constexpr int NF = 8 / WN;                // 16-column fragments per wave: 4 / 2
+  constexpr int DPW = 16 / NW;              // dy / x pieces per wave per K-tile (x: + piece 16 / 17 on waves 0 / 1)
+  const int wm = wave / WN, wn = wave % WN;
   const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
   const auto rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, e.dybytes, 0x00020000);
 
@@ -263,11 +273,13 @@ NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
 
   // ---- staging: dy pieces 4w .. 4w+3 (4 rows x 256 B each); x pieces w, w+4, w+8, w+12 (+ piece 16 and 17 on waves 0 and 1) ----
   const int srow = lane >> 4, slot = lane & 15;
+  // (arrays of the 4-wave extents whatever NW: with a DEPENDENT array type the subscripted operand makes the LDS-DMA builtin call
+  // type-dependent, and hipcc 7.2's host pass then rejects the whole template -- "substitution failure")
   unsigned dyb[4];
   int dpix[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (wave * 4 + j) * 4 + srow;
+  for (int j = 0; j < DPW; ++j) {
+    const int row = (wave * DPW + j) * 4 + srow;
     const int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
     const int q = kt_begin * 64 + row;
     dpix[j] = q;
@@ -276,8 +288,8 @@ NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
   unsigned xb[5];
   int xpix[5], xyx[5];         // xpix: flattened OUTPUT-aligned pixel of the row (q0 - 1 + r); xyx: (y << 16) | x of that pixel
 #pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    const int piece = j < 4 ? wave + 4 * j : 16 + wave;      // (piece 16 / 17: waves 0 / 1 only)
+  for (int j = 0; j < DPW + 1; ++j) {
+    const int piece = j < DPW ? wave + NW * j : 16 + wave;      // (piece 16 / 17: waves 0 / 1 only)
     const int row = piece * 4 + srow;
     const int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
     const int q = kt_begin * 64 - 1 + row;
@@ -293,15 +305,15 @@ NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
   auto issue = [&](int slot_) {
     const int lb = slot_ * KT;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < DPW; ++j) {
       const bool live = dpix[j] < p.P;
-      WG4_DMA(rs_dy, live ? dyb[j] : 0xFFFFFFFFu, lb + (wave * 4 + j) * 1024);
+      WG4_DMA(rs_dy, live ? dyb[j] : 0xFFFFFFFFu, lb + (wave * DPW + j) * 1024);
       dpix[j] += 64; dyb[j] += dy_step;
     }
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      if (j == 4 && !extra) break;
-      const int piece = j < 4 ? wave + 4 * j : 16 + wave;
+    for (int j = 0; j < DPW + 1; ++j) {
+      if (j == DPW && !extra) break;
+      const int piece = j < DPW ? wave + NW * j : 16 + wave;
       const int y = (xyx[j] >> 16) + dyr;
       const bool ok = xpix[j] >= 0 && xpix[j] < p.P && (unsigned)y < (unsigned)p.H;
       WG4_DMA(rs_x, ok ? xb[j] : 0xFFFFFFFFu, lb + XOFF + piece * 1024);
@@ -317,7 +329,7 @@ NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
 
   // ---- transposed fragment reads (see wg4_body); B of tap s reads row s + k of the x image ------------------------------------
   const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pq = i16 & 3;
-  unsigned offA[4][2], offB[3][4][2];
+  unsigned offA[4][2], offB[3][NF][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = g * 8 + h * 4 + q4;                       // + ks*32
@@ -329,7 +341,7 @@ NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
       const int rb = row + s3;
       const int swb = ((rb & 3) << 2) | ((rb >> 2) & 3);
 #pragma unroll
-      for (int f = 0; f < 4; ++f) offB[s3][f][h] = XOFF + 256 * rb + 16 * (((wn * 8 + f * 2 + (pq >> 1)) ^ swb)) + 8 * (pq & 1);
+      for (int f = 0; f < NF; ++f) offB[s3][f][h] = XOFF + 256 * rb + 16 * (((wn * NF * 2 + f * 2 + (pq >> 1)) ^ swb)) + 8 * (pq & 1);
     }
   }
   // x coordinate (mod W) of the lane's first pixel of each (ks, half): k0 = ks*32 + g*8 + h*4
@@ -341,13 +353,13 @@ NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
   int xq0 = (kt_begin * 64) % p.W;               // x coordinate of the K-tile's first pixel
   const int xadv = 64 % p.W;
 
-  f32x4g acc[3][4][4];
+  f32x4g acc[3][4][NF];
 #pragma unroll
   for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[s3][mi][ni] = f32x4g{0.f, 0.f, 0.f, 0.f};
+      for (int ni = 0; ni < NF; ++ni) acc[s3][mi][ni] = f32x4g{0.f, 0.f, 0.f, 0.f};
 
   const int nk = kt_end - kt_begin;
   int s_slot = 0, c_slot = 0;
@@ -356,8 +368,8 @@ NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
     // every wave has issued the same number of DMA instructions per K-tile except the two "extra" waves (9 vs 8): wait for all but the
     // K-tiles still allowed in flight
     if (R > 2 && kt + R - 1 <= nk) {
-      if (extra) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(9 * (R > 2 ? R - 2 : 0)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (R > 2 ? R - 2 : 0)) : "memory");
+      if (extra) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((2 * DPW + 1) * (R > 2 ? R - 2 : 0)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DPW * (R > 2 ? R - 2 : 0)) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -388,9 +400,9 @@ NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
       }
 #pragma unroll
       for (int s3 = 0; s3 < 3; ++s3) {
-        s16x8 fb[4];
+        s16x8 fb[NF];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < NF; ++f) {
           s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offB[s3][f][0] + ks * 8192));
           s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offB[s3][f][1] + ks * 8192));
           if (s3 == 0) {
@@ -410,7 +422,7 @@ NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
+          for (int ni = 0; ni < NF; ++ni)
             acc[s3][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]),
                                                                      acc[s3][mi][ni], 0, 0, 0);
       }
@@ -423,11 +435,11 @@ NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
   const int half = lane >> 5, gg = (lane >> 4) & 1;
 #pragma unroll
   for (int s3 = 0; s3 < 3; ++s3) {
-    const int colbase = (kh * 3 + s3) * p.Cin + ci0 + wn * 64;
+    const int colbase = (kh * 3 + s3) * p.Cin + ci0 + wn * (NF * 16);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+      for (int nb = 0; nb < NF / 2; ++nb)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[s3][mi][2 * nb][j]), __float_as_uint(acc[s3][mi][2 * nb + 1][j]),
@@ -440,9 +452,9 @@ NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
   }
 }
 
-template <bool RELU, int R>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_g3_kernel(WgradParams p, WG3Extra e) {
-  wg3_body<RELU, R>(p, e, (int)blockIdx.x);
+template <bool RELU, int R, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void conv_wgrad_g3_kernel(WgradParams p, WG3Extra e) {
+  wg3_body<RELU, R, NW>(p, e, (int)blockIdx.x);
 }
 
 
@@ -782,13 +794,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_batched_kernel(const WG4Job
   wg4_body<RELU, TAPS, R>(p, e, (int)blockIdx.x - jb->first_block);
 }
 
-template <bool RELU, int R>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_g3_batched_kernel(const WG4Job* __restrict__ jobs, const int* __restrict__ block_job) {
+template <bool RELU, int R, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void conv_wgrad_g3_batched_kernel(const WG4Job* __restrict__ jobs, const int* __restrict__ block_job) {
   const int j = __builtin_amdgcn_readfirstlane(block_job[blockIdx.x]);
   const WG4Job* jb = jobs + j;
   const WgradParams p = jb->p;
   const WG3Extra e = jb->e3;
-  wg3_body<RELU, R>(p, e, (int)blockIdx.x - jb->first_block);
+  wg3_body<RELU, R, NW>(p, e, (int)blockIdx.x - jb->first_block);
 }
 
 template <int C, bool RELU>
@@ -861,15 +873,24 @@ static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradPa
   return true;
 }
 
+// NPP_WG3: 0 the three-tap kernel is off, 1 its 4-wave form, 8 its 8-wave form
+static int wg3_mode() {
+  static const int m = getenv("NPP_WG3") ? atoi(getenv("NPP_WG3")) : WG3_DEFAULT;
+  return m;
+}
 // the three-tap kernel: 3x3, Cin and Cout multiples of 128.  max_blocks: the slots this problem may fill (256 = one workgroup per CU)
 static bool wg3_prepare(const WgradParams& p, int dtype, int max_blocks, WgradParams& q, WG3Extra& e, int& nblocks) {
-  // OPT-IN (NPP_WG3=1).  Measured on MI355X (tools/wgrad_time.py, N = 16, us, this kernel at 256 workgroups vs the 128 x 128 kernel):
+  // OPT-IN (NPP_WG3=1: 4 waves, NPP_WG3=8: 8 waves).  Round 4, the 8-wave form (two waves per SIMD, 96 accumulator registers each): 128->128
+  // @96^2 114 us, 256->256 @48^2 107, 512->512 @24^2 105, 128->128 @24^2 29 -- better than the 4-wave form (132 / 126 / 126 / 35) and still
+  // behind the 128 x 128 kernel (82 / 87 / 91 / 23): rocprofv3 counts NO LDS bank conflicts and ~2 LDS-active cycles per LDS instruction on
+  // these kernels (tools/wgrad_lds_pmc.sh), so the transposed reads are not the bound either; with one workgroup per CU every K-tile
+  // still pays its barrier + DMA round trip alone, and each of the 255 workgroups ends with 192 KiB of float atomics into the same 590 KB.
+  // Round 3, the 4-wave form, measured on MI355X (tools/wgrad_time.py, N = 16, us, this kernel at 256 workgroups vs the 128 x 128 kernel):
   // 128->128 @96^2 116 vs 83, 384->128 225 vs 191, 256->256 @48^2 102 vs 85, 512->512 @24^2 100 vs 88, 256->256 @12^2 42 vs 26 --
   // slower on every shape although it stages a third of the bytes per MFMA: with 394 registers there is ONE wave per SIMD, and a
   // wave alone cannot overlap its DMA issue, its 64 transposed reads and its 96 MFMAs per K-tile (2.9 us per K-tile against
   // 0.64 us of MFMA time); the 128 x 128 kernel's two co-resident workgroups do.  Kept for the record and for the exactness test.
-  static const bool enabled = getenv("NPP_WG3") != nullptr && atoi(getenv("NPP_WG3")) != 0;
-  if (!enabled || dtype != NPP_BF16) return false;
+  if (!wg3_mode() || dtype != NPP_BF16) return false;
   if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.KH != 3 || p.KW != 3) return false;
   if (p.ph != 1 || p.pw != 1 || p.OH != p.H || p.OW != p.W) return false;
   if (p.Cin % 128 != 0 || p.Cout % 128 != 0 || p.Cp != p.Cin || !p.vec_dy || p.ldx % 8 != 0 || p.ldy % 8 != 0) return false;
@@ -1003,13 +1024,14 @@ bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
     WG3Extra e3;
     int nb3 = 0;
     if (wg3_prepare(p, dtype, 256, q, e3, nb3)) {
-      if (p.relu_in) {
-        if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g3_kernel<true, 3>), WG3_LDS)) return false;
-        hipLaunchKernelGGL((conv_wgrad_g3_kernel<true, 3>), dim3(nb3), dim3(256), WG3_LDS, stream, q, e3);
-      } else {
-        if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g3_kernel<false, 3>), WG3_LDS)) return false;
-        hipLaunchKernelGGL((conv_wgrad_g3_kernel<false, 3>), dim3(nb3), dim3(256), WG3_LDS, stream, q, e3);
-      }
+#define WG3_ONE(RELU_, NW_)                                                                                                  \
+  do {                                                                                                                        \
+    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g3_kernel<RELU_, 3, NW_>), WG3_LDS)) return false;              \
+    hipLaunchKernelGGL((conv_wgrad_g3_kernel<RELU_, 3, NW_>), dim3(nb3), dim3(64 * NW_), WG3_LDS, stream, q, e3);               \
+  } while (0)
+      if (wg3_mode() == 8) { if (p.relu_in) WG3_ONE(true, 8); else WG3_ONE(false, 8); }
+      else                 { if (p.relu_in) WG3_ONE(true, 4); else WG3_ONE(false, 4); }
+#undef WG3_ONE
       return true;
     }
   }
@@ -1116,14 +1138,14 @@ bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, in
                        jd, map_dev + off[V_]);                                                                                     \
   }
   // the three-tap jobs first: their workgroups are the longest of the step
-#define WG3_BATCH(V_, RELU_)                                                                                                       \
+#define WG3_BATCH(V_, RELU_, NW_)                                                                                                  \
   if (off[V_ + 1] > off[V_]) {                                                                                                     \
-    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g3_batched_kernel<RELU_, 3>), WG3_LDS)) return false;               \
-    hipLaunchKernelGGL((conv_wgrad_g3_batched_kernel<RELU_, 3>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(256), WG3_LDS, stream, \
+    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g3_batched_kernel<RELU_, 3, NW_>), WG3_LDS)) return false;          \
+    hipLaunchKernelGGL((conv_wgrad_g3_batched_kernel<RELU_, 3, NW_>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(64 * NW_), WG3_LDS, stream, \
                        jd, map_dev + off[V_]);                                                                                     \
   }
-  WG3_BATCH(4, false)
-  WG3_BATCH(5, true)
+  if (wg3_mode() == 8) { WG3_BATCH(4, false, 8) WG3_BATCH(5, true, 8) }
+  else                 { WG3_BATCH(4, false, 4) WG3_BATCH(5, true, 4) }
 #undef WG3_BATCH
 #define WGN_BATCH(V_, C_, RELU_)                                                                                                    \
   if (off[V_ + 1] > off[V_]) {                                                                                                     \
