@@ -3682,6 +3682,59 @@ def weighted_sum(w, ys):
     return _WeightedSum.apply(w, *[take(y) for y in ys])
 
 
+# The cells of the supernet index the softmax of the architecture parameters edge by edge (`weights[offset + j]`, `weights2[a:b]`:
+# model_search_interact.py:1010-1020 in the reference).  Autograd gives every such index a node of its own whose backward is a zero
+# fill of the whole matrix + a copy of the row + an add into the running sum: three launches per edge, ~650 per step of the supernet.
+# One node per cell instead: the pieces are views handed out together, their gradients come back together and are laid side by side by
+# ONE concatenation (pieces nobody used contribute zeros).
+class _SplitPieces(Function):
+    @staticmethod
+    def forward(ctx, w, sizes):
+        ctx.set_materialize_grads(False)
+        ctx.sizes, ctx.shape, ctx.meta = sizes, w.shape, (w.dtype, w.device)
+        outs, a = [], 0
+        for n in sizes:
+            outs.append(w[a] if n == 0 else w[a:a + n])      # n == 0: ONE row, as `w[a]` (a vector); n > 0: the slice w[a:a+n]
+            a += max(n, 1)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        if all(g is None for g in gs):
+            return None, None
+        dtype, dev = ctx.meta
+        tail = tuple(ctx.shape[1:])
+        parts = []
+        for n, g in zip(ctx.sizes, gs):
+            rows = max(n, 1)
+            if g is None:
+                parts.append(torch.zeros((rows,) + tail, dtype=dtype, device=dev))
+            else:
+                parts.append(g.reshape((rows,) + tail).to(dtype))
+        used = sum(max(n, 1) for n in ctx.sizes)
+        if used < ctx.shape[0]:
+            parts.append(torch.zeros((ctx.shape[0] - used,) + tail, dtype=dtype, device=dev))
+        return torch.cat(parts, dim=0), None
+
+
+def split_rows(w):
+    """[w[0], w[1], ...] with one autograd node for all rows."""
+    if not (isinstance(w, torch.Tensor) and w.requires_grad and torch.is_grad_enabled()):
+        return [w[i] for i in range(w.shape[0])]
+    return list(_SplitPieces.apply(w, (0,) * w.shape[0]))
+
+
+def split_slices(w, sizes):
+    """[w[0:s0], w[s0:s0+s1], ...] with one autograd node for all slices."""
+    sizes = tuple(int(n) for n in sizes)
+    if not (isinstance(w, torch.Tensor) and w.requires_grad and torch.is_grad_enabled()):
+        outs, a = [], 0
+        for n in sizes:
+            outs.append(w[a:a + n]); a += n
+        return outs
+    return list(_SplitPieces.apply(w, sizes))
+
+
 # ---- the mixed edge as one N-sided weighted BatchNorm sum (npp_mix_bn_fwd / npp_mix_bn_bwd) -----------------------------------------
 MIX_FUSE = os.environ.get("NPP_MIX_FUSE", "1") != "0"
 

@@ -128,9 +128,12 @@ class _MixedCell(nn.Module):
     def forward(self, s0, s1, s2, weights, weights2):
         states = [self.preprocess0(s0), self.preprocess1(s1), self.preprocess2(s2)]
         offset = 0
-        for _ in range(self._steps):
-            outs = [self._ops[offset + j](h, weights[offset + j]) for j, h in enumerate(states)]
-            states.append(K.weighted_sum(weights2[offset:offset + len(states)], outs))
+        # (one autograd node for all rows of `weights` / all per-node slices of `weights2` this cell uses: K.split_rows)
+        rows = K.split_rows(weights)
+        pieces = K.split_slices(weights2, [len(states) + k for k in range(self._steps)])
+        for k in range(self._steps):
+            outs = [self._ops[offset + j](h, rows[offset + j]) for j, h in enumerate(states)]
+            states.append(K.weighted_sum(pieces[k], outs))
             offset += len(outs)
         if self.order == 0:
             states[0] = K.nearest(states[0], 4)
