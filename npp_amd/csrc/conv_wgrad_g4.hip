@@ -20,6 +20,11 @@
 #include <algorithm>
 #include <vector>
 
+// ablation builds (tools/wg4_ablation.sh): 1 = no epilogue (atomics / slab stores), 2 = no MFMA, 4 = no operand DMA, 8 = no fragment reads.
+// Results are wrong by design.
+#ifndef WG4_DBG
+#define WG4_DBG 0
+#endif
 #ifndef WG3_DEFAULT
 #define WG3_DEFAULT 0
 #endif
@@ -105,7 +110,7 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool live = pix[j] < p.P && (tdx[j] & (1 << 29));
-      WG4_DMA(rs_dy, live ? dyb[j] : 0xFFFFFFFFu, lb + (wave * 4 + j) * 1024);
+      if (!(WG4_DBG & 4)) WG4_DMA(rs_dy, live ? dyb[j] : 0xFFFFFFFFu, lb + (wave * 4 + j) * 1024);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -114,7 +119,7 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
         const int y = (yx[j] >> 16) + (int)(signed char)((tdx[j] >> 8) & 0xFF), x = (yx[j] & 0xFFFF) + (int)(signed char)(tdx[j] & 0xFF);
         ok = ok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
       }
-      WG4_DMA(rs_x, ok ? xb[j] : 0xFFFFFFFFu, lb + 16384 + (wave * 4 + j) * 1024);
+      if (!(WG4_DBG & 4)) WG4_DMA(rs_x, ok ? xb[j] : 0xFFFFFFFFu, lb + 16384 + (wave * 4 + j) * 1024);
     }
     // advance this lane's rows by one K-tile (64 pixels)
 #pragma unroll
@@ -165,7 +170,8 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
     if (++c_slot == R) c_slot = 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      s16x8 fa[4], fb[4];
+      s16x8 fa[4] = {}, fb[4] = {};
+      if (!(WG4_DBG & 8))
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offA[f][0] + ks * 8192));
@@ -180,13 +186,25 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
         }
         fb[f] = b;
       }
+      if (!(WG4_DBG & 2)) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]),
                                                                 acc[mi][ni], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) asm volatile("" :: "v"(fa[f]), "v"(fb[f]));
+      }
     }
+  }
+  if (WG4_DBG & 1) {      // no epilogue: keep the accumulators alive
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) asm volatile("" :: "v"(acc[mi][ni]));
+    return;
   }
 
   // ---- epilogue: acc[mi][ni][j] = dW[co0 + wm*64 + mi*16 + 4*g + j][col0 + wn*64 + ni*16 + i16] ----------------------------
