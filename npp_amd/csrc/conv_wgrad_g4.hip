@@ -78,59 +78,78 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
   if (kt_begin >= kt_end) return;
 
   // ---- staging: wave w fills pieces 4w .. 4w+3 of each operand; lane -> row 4*piece + (lane>>4), slot lane&15 ----------
+  // The lane's four rows j = 0 .. 3 are the pixels q0 + 4j of ONE tap (the swizzled chunk differs in its low two bits only, a tap
+  // is >= 32 channels = 4 chunks wide): ONE running (pixel, y, x, byte offset) per lane, the rows derived from it with per-lane
+  // constants (round 4; ~60 instead of ~130 VALU instructions per wave and K-tile).  Measured: NO change (128->128 3x3 @96^2 82.8 us
+  // against 82.2) -- the address bookkeeping was not what the K-tile waits for.  tools/wg4_ablation.sh on the same shape: all 82 us,
+  // without the epilogue 67, without the MFMAs 69, without the DMA 64, without the fragment reads 67, none of them 20: every part
+  // costs about its full time and none hides another, which is the signature of one dependent chain per K-tile (DMA wait -> barrier ->
+  // reads -> MFMA) that two co-resident workgroups only half cover.
   const int srow = lane >> 4, slot = lane & 15;
-  unsigned dyb[4], xb[4];      // byte offset of (first K-tile's pixel, source chunk) in dy / x; advanced by 64 pixels per K-tile
-  int yx[4];                   // (y << 16) | x of the row's OUTPUT pixel (TAPS)
-  int pix[4];
-  int tdx[4];                  // (dy_ << 8 | dx_ & 0xFF) of the lane's tap for row j, bit 30: column exists, bit 29: output channel exists
+  unsigned dyb0, xb0;          // byte offset of (pixel q0 of the first K-tile, chunk of row 0) in dy / x; advanced by 64 pixels per K-tile
+  int ddy[4], dxx[4];          // row j: + these bytes (4j pixels further, its own chunk)
+  int y0v = 0, x0v = 0;        // (y, x) of output pixel q0 (TAPS)
+  int pix0;
+  int tap_dy = 0, tap_dx = 0;
+  bool col_ok;
+  unsigned co_mask = 0;        // bit j: row j's output channels exist
+  {
+    const int row0 = (wave * 4) * 4 + srow;
+    const int q0 = kt_begin * 64 + row0;
+    pix0 = q0;
+    int chunk0 = 0, ci0b = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (wave * 4 + j) * 4 + srow;
-    const int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
-    const int q = kt_begin * 64 + row;
-    pix[j] = q;
-    const int col = coltile * 128 + chunk * 8;
-    const int tap = col / p.Cin, ci = col - tap * p.Cin;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const int dy_ = kh - e.P, dx_ = kw - e.P;                 // input pixel = output pixel + (dy_, dx_)
-    const bool col_ok = tap < p.taps, co_ok = co0 + chunk * 8 < p.Cout;
-    tdx[j] = ((dy_ & 0xFF) << 8) | (dx_ & 0xFF) | (col_ok ? (1 << 30) : 0) | (co_ok ? (1 << 29) : 0);
-    dyb[j] = (unsigned)q * (unsigned)p.ldy * 2u + (unsigned)(co0 * 2 + chunk * 16);
-    xb[j] = (unsigned)q * (unsigned)p.ldx * 2u + (unsigned)(ci * 2) + (unsigned)((dy_ * p.W + dx_) * (int)p.ldx * 2);
-    yx[j] = 0;
+    for (int j = 0; j < 4; ++j) {
+      const int row = (wave * 4 + j) * 4 + srow;
+      const int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
+      const int col = coltile * 128 + chunk * 8;
+      const int tap = col / p.Cin, ci = col - tap * p.Cin;
+      if (j == 0) {
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        tap_dy = kh - e.P; tap_dx = kw - e.P;                 // input pixel = output pixel + (tap_dy, tap_dx)
+        col_ok = tap < p.taps;
+        chunk0 = chunk; ci0b = ci * 2;
+      }
+      if (co0 + chunk * 8 < p.Cout) co_mask |= 1u << j;
+      ddy[j] = 4 * j * (int)p.ldy * 2 + (chunk - chunk0) * 16;
+      dxx[j] = 4 * j * (int)p.ldx * 2 + (ci * 2 - ci0b);
+    }
+    dyb0 = (unsigned)q0 * (unsigned)p.ldy * 2u + (unsigned)(co0 * 2 + chunk0 * 16);
+    xb0 = (unsigned)q0 * (unsigned)p.ldx * 2u + (unsigned)ci0b + (unsigned)((tap_dy * p.W + tap_dx) * (int)p.ldx * 2);
     if (TAPS) {
-      const int rem = q % e.HW;
-      const int y = rem / p.W;
-      yx[j] = (y << 16) | (rem - y * p.W);
+      const int rem = q0 % e.HW;
+      y0v = rem / p.W;
+      x0v = rem - y0v * p.W;
     }
   }
   const unsigned dy_step = 64u * (unsigned)p.ldy * 2u, x_step = 64u * (unsigned)p.ldx * 2u;
+  const int adv_y = 64 / p.W, adv_x = 64 - adv_y * p.W;
+  const bool all_co = co_mask == 15u;
   auto issue = [&](int slot_) {
     const int lb = slot_ * KT;
+    const bool whole = pix0 + 12 < p.P;       // every row of this lane is a real pixel (false only in the last K-tile of a ragged problem)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool live = pix[j] < p.P && (tdx[j] & (1 << 29));
-      if (!(WG4_DBG & 4)) WG4_DMA(rs_dy, live ? dyb[j] : 0xFFFFFFFFu, lb + (wave * 4 + j) * 1024);
+      const bool live = (whole || pix0 + 4 * j < p.P) && (all_co || ((co_mask >> j) & 1u));
+      if (!(WG4_DBG & 4)) WG4_DMA(rs_dy, live ? dyb0 + (unsigned)ddy[j] : 0xFFFFFFFFu, lb + (wave * 4 + j) * 1024);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      bool ok = pix[j] < p.P && (tdx[j] & (1 << 30));
+      bool ok = (whole || pix0 + 4 * j < p.P) && col_ok;
       if (TAPS) {
-        const int y = (yx[j] >> 16) + (int)(signed char)((tdx[j] >> 8) & 0xFF), x = (yx[j] & 0xFFFF) + (int)(signed char)(tdx[j] & 0xFF);
-        ok = ok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        int xj = x0v + 4 * j, yj = y0v;                       // (W >= 12: at most one wrap)
+        if (xj >= p.W) { xj -= p.W; ++yj; }
+        if (yj >= p.H) yj -= p.H;
+        ok = ok && (unsigned)(yj + tap_dy) < (unsigned)p.H && (unsigned)(xj + tap_dx) < (unsigned)p.W;
       }
-      if (!(WG4_DBG & 4)) WG4_DMA(rs_x, ok ? xb[j] : 0xFFFFFFFFu, lb + 16384 + (wave * 4 + j) * 1024);
+      if (!(WG4_DBG & 4)) WG4_DMA(rs_x, ok ? xb0 + (unsigned)dxx[j] : 0xFFFFFFFFu, lb + 16384 + (wave * 4 + j) * 1024);
     }
-    // advance this lane's rows by one K-tile (64 pixels)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      pix[j] += 64; dyb[j] += dy_step; xb[j] += x_step;
-      if (TAPS) {
-        int y = yx[j] >> 16, x = (yx[j] & 0xFFFF) + 64;
-        while (x >= p.W) { x -= p.W; ++y; }
-        while (y >= p.H) y -= p.H;
-        yx[j] = (y << 16) | x;
-      }
+    // advance by one K-tile (64 pixels)
+    pix0 += 64; dyb0 += dy_step; xb0 += x_step;
+    if (TAPS) {
+      x0v += adv_x; y0v += adv_y;
+      if (x0v >= p.W) { x0v -= p.W; ++y0v; }
+      while (y0v >= p.H) y0v -= p.H;
     }
   };
 
@@ -863,6 +882,7 @@ static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradPa
   if (!all && !(batched && narrow_batched) && ((p.Cout <= 64 && p.taps > 1) || (p.Cout == 32 && p.Cin >= 128))) return false;
   if ((long)p.P * p.ldx * 2 >= (1L << 32) - (1L << 24) || (long)p.P * p.ldy * 2 >= (1L << 32) - (1L << 24)) return false;
   if (p.H >= 16384 || p.W >= 16384) return false;
+  if (P > 0 && p.W < 12) return false;      // (wg4_body derives a lane's four rows from one (y, x): at most one row wrap in 12 pixels)
   e.P = P; e.HW = p.H * p.W;
   e.coltiles = (p.taps * p.Cin + 127) / 128;
   e.nktiles = (p.P + 63) / 64;
