@@ -80,11 +80,13 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
   // ---- staging: wave w fills pieces 4w .. 4w+3 of each operand; lane -> row 4*piece + (lane>>4), slot lane&15 ----------
   // The lane's four rows j = 0 .. 3 are the pixels q0 + 4j of ONE tap (the swizzled chunk differs in its low two bits only, a tap
   // is >= 32 channels = 4 chunks wide): ONE running (pixel, y, x, byte offset) per lane, the rows derived from it with per-lane
-  // constants (round 4; ~60 instead of ~130 VALU instructions per wave and K-tile).  Measured: NO change (128->128 3x3 @96^2 82.8 us
-  // against 82.2) -- the address bookkeeping was not what the K-tile waits for.  tools/wg4_ablation.sh on the same shape: all 82 us,
+  // constants (round 4; ~60 instead of ~130 VALU instructions per wave and K-tile, and no wrap loops that iterate 64 / W times).
+  // Measured (tools/wgrad_time.py, us, before -> after): 256->256 3x3 @12^2 26.6 -> 19.6, 128->128 @24^2 22.9 -> 19.5, 512->512 @24^2
+  // 90 -> 82, 256->256 @48^2 87 -> 84, 128->128 @96^2 82.5 -> 85.9, 384->128 @96^2 194 -> 200: the narrow maps paid for the loops, the
+  // wide ones now pay one more add per row; the step is unchanged (38.60 ms).  tools/wg4_ablation.sh on 128->128 @96^2: all 82 us,
   // without the epilogue 67, without the MFMAs 69, without the DMA 64, without the fragment reads 67, none of them 20: every part
-  // costs about its full time and none hides another, which is the signature of one dependent chain per K-tile (DMA wait -> barrier ->
-  // reads -> MFMA) that two co-resident workgroups only half cover.
+  // costs about its full time and none hides another -- one dependent chain per K-tile (DMA wait -> barrier -> reads -> MFMA) that
+  // two co-resident workgroups only half cover.
   const int srow = lane >> 4, slot = lane & 15;
   unsigned dyb0, xb0;          // byte offset of (pixel q0 of the first K-tile, chunk of row 0) in dy / x; advanced by 64 pixels per K-tile
   int ddy[4], dxx[4];          // row j: + these bytes (4j pixels further, its own chunk)
