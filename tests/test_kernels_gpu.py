@@ -387,6 +387,35 @@ def test_h3_tile_configurations_in_subprocess(cfg):
     assert "h3 cfg ok" in r.stdout
 
 
+def test_lean_epilogues_equal_the_generic_ones(tmp_path):
+    """conv_epi.h / conv_g8's epilogue_lean against the kernels' generic epilogues (NPP_EPI_LEAN=0, read once per process): the stored
+    bf16 outputs -- forward, data gradient of a first writer through the bit-mask, accumulating second writer -- must be BIT-identical
+    (same values, same rounding, another instruction sequence); the BatchNorm statistics are summed in another order (reduce-scatter
+    instead of all-reduce over the 16 pixel lanes): equal to 1e-6 of the largest entry."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for lean in ("0", "1"):
+        path = str(tmp_path / f"epi{lean}.npz")
+        env = dict(os.environ, NPP_EPI_LEAN=lean, NPP_EPI_CENSUS="1")
+        r = subprocess.run([sys.executable, os.path.join(here, "epi_worker.py"), path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "epi ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        res[lean] = np.load(path)
+        # the cases reach every kernel that has a lean epilogue, in the three formats the network runs
+        census = [ln for ln in r.stderr.splitlines() if ln.startswith("npp-epi ")]
+        for kern in ("conv_g8", "conv_g4", "conv_h3", "conv_c32"):
+            for fmt in ("stats1 mask0 accum0", "stats0 mask1 accum0", "stats0 mask1 accum1"):
+                assert any(ln.split()[1] == kern and fmt in ln for ln in census), (kern, fmt)
+    a, b = res["0"], res["1"]
+    assert set(a.files) == set(b.files) and len(a.files) >= 35
+    for k in a.files:
+        if "_st" in k:
+            assert np.abs(a[k] - b[k]).max() <= 1e-6 * np.abs(a[k]).max(), k
+        else:
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+        assert np.abs(a[k].astype(np.float64)).max() > 0, k
+
+
 def test_deterministic_slab_weight_gradient_in_subprocess():
     """NPP_WGRAD_SLABS=1 (read once per process): the wide-map 3x3 weight gradients through conv_wgrad_h3's split-K slabs +
     npp_unpack_wgrad_sum -- parity cases, and two runs give bit-identical gradients (no float atomics on that path)."""
