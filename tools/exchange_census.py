@@ -1,0 +1,41 @@
+"""Which call sites issue the SyncBatchNorm exchanges of one step?  1-rank rehearsal (bench.py --force-dist, NPP_P2P_ALONE=1, eager)."""
+import os, sys, collections, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["NPP_BENCH_SUPERVISE"] = "0"
+os.environ["NPP_P2P_ALONE"] = "1"
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+import torch
+from npp_amd import comm
+import bench as B
+
+cnt = collections.Counter()
+size = collections.Counter()
+armed = [False]
+
+
+def wrap(name):
+    orig = getattr(comm, name)
+
+    def f(*a, **k):
+        if armed[0]:
+            st = traceback.extract_stack(limit=7)[:-1]
+            key = " < ".join(f"{os.path.basename(fr.filename)}:{fr.lineno}:{fr.name}" for fr in reversed(st[-4:]))
+            cnt[(name, key)] += 1
+            if name == "p2p_exchange_slabs":
+                size[(name, key)] += len(a[0])
+        return orig(*a, **k)
+    setattr(comm, name, f)
+
+
+wrap("p2p_exchange")
+wrap("p2p_exchange_slabs")
+sys.argv = ["bench.py", "--force-dist", "--steps", "1", "--warmup", "1", "--graph", "0", "--no-cpu-baseline", "--no-prof"]
+armed[0] = True
+try:
+    B.main()
+except SystemExit:
+    pass
+tot = sum(cnt.values())
+print("exchanges over warm-up + 1 step (divide by 2):", tot)
+for (name, key), c in cnt.most_common(25):
+    print(f"{c:6d} {name:20s} segs {size.get((name, key), 0):6d}  {key[:200]}")
