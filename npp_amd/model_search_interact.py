@@ -280,12 +280,8 @@ class Network(nn.Module):
 
     def btw(self, n_input, steps, betas):
         """beta -> per-node softmax edge weights (:1054-1065)."""
-        parts, start, n = [], 0, n_input
-        for _ in range(steps):
-            parts.append(F.softmax(betas[start:start + n], dim=-1))
-            start += n
-            n += 1
-        return torch.cat(parts, dim=0)
+        pieces = K.split_slices(betas, [n_input + k for k in range(steps)])
+        return torch.cat([F.softmax(pc, dim=-1) for pc in pieces], dim=0)
 
     def loss_entropy(self):
         """:881-890 (normalised entropy of the alpha rows)."""
@@ -311,7 +307,7 @@ class Network(nn.Module):
 
     # -- forward (:626-770) -------------------------------------------------------------------------------------
     def _mix(self, ops, base, feats, alpha_rows, beta_rows):
-        w = F.softmax(alpha_rows, dim=-1)
+        w = K.split_rows(F.softmax(alpha_rows, dim=-1))      # (one autograd node for the rows: K.split_rows)
         w2 = F.softmax(beta_rows, dim=-1)
         outs = [ops[base + j](h, w[j]) for j, h in enumerate(feats)]
         return K.weighted_sum(w2, outs)
@@ -385,6 +381,12 @@ class Network(nn.Module):
             s3 = self.stem5(s2 := self.stem4(self.stem3(x)))
         f1, f2 = [], []
         offset = 0
+        # the row blocks of the interaction parameters every tap / decoder stage uses, through ONE autograd node per tensor
+        # (K.split_slices; the reference slices `alphas1[offset:offset + n]` stage by stage, :655-700)
+        ntap = len(self._taps)
+        sz1, sz3 = list(range(1, ntap + 1)), [ntap + 1 + d for d in range(3)]
+        A1, B1, A2, B2 = (K.split_slices(t, sz1) for t in (self.alphas1, self.betas1, self.alphas2, self.betas2))
+        A3, B3, A4, B4 = (K.split_slices(t, sz3) for t in (self.alphas3, self.betas3, self.alphas4, self.betas4))
         for i, (cell1, cell2) in enumerate(zip(self.cells1, self.cells2)):
             s0, s1 = s1, cell1(s0, s1)
             with on_b():
@@ -394,10 +396,9 @@ class Network(nn.Module):
                 f2.append(s3)
                 n = len(f1)
                 meet(*f1, *f2)
-                s1 = K.add(s1, self._mix(self._ops1, offset, f2, self.alphas1[offset:offset + n], self.betas1[offset:offset + n]))
+                s1 = K.add(s1, self._mix(self._ops1, offset, f2, A1[n - 1], B1[n - 1]))
                 with on_b():
-                    s3 = K.add(s3, self._mix(self._ops2, offset, f1, self.alphas2[offset:offset + n],
-                                             self.betas2[offset:offset + n]))
+                    s3 = K.add(s3, self._mix(self._ops2, offset, f1, A2[n - 1], B2[n - 1]))
                 f1[-1], f2[-1] = s1, s3
                 offset += n
         cont = 0
@@ -410,9 +411,9 @@ class Network(nn.Module):
             n = len(f1)
             meet(*f1, *f2)
             g1 = list(f1)        # both mixes read the features as they are BEFORE this stage's adds
-            f1[-1] = K.add(o1, self._mix(self.up_ops1, cont, f2, self.alphas3[cont:cont + n], self.betas3[cont:cont + n]))
+            f1[-1] = K.add(o1, self._mix(self.up_ops1, cont, f2, A3[d], B3[d]))
             with on_b():
-                f2[-1] = K.add(o2, self._mix(self.up_ops2, cont, g1, self.alphas4[cont:cont + n], self.betas4[cont:cont + n]))
+                f2[-1] = K.add(o2, self._mix(self.up_ops2, cont, g1, A4[d], B4[d]))
             cont += n
         H, W = f1[0].shape[2], f1[0].shape[3]
         x1 = K.concat([f1[0], f1[6], K.bilinear(f1[5], H, W), K.bilinear(f1[4], H, W)])
