@@ -338,8 +338,11 @@ class Network(nn.Module):
             for m in self.modules():
                 if isinstance(m, SE_Block):
                     skip.update((id(m.conv1.weight), id(m.conv2.weight)))
-            self._packer = K.WeightPacker(m.weight for m in self.modules()
-                                          if isinstance(m, nn.Conv2d) and m.groups == 1 and id(m.weight) not in skip)
+            # (the merged edges of the fixed encoder cells get their images from the packer too, as in model_augment.Network: without
+            # the groups every merged conv rebuilt its images with a cat + a zero fill + a copy per member, ~120 launches per step)
+            groups = [g for m in self.modules() for g in getattr(m, "_wide_groups", ())] if K.WIDE else []
+            self._packer = K.WeightPacker((m.weight for m in self.modules()
+                                           if isinstance(m, nn.Conv2d) and m.groups == 1 and id(m.weight) not in skip), groups)
         self._packer.pack_if_stale(dt, x.device, force=self.training)
         if self.training:
             K.note_training_step()
