@@ -9,7 +9,8 @@ from torch.profiler import profile, ProfilerActivity
 import bench as B
 
 NSTEPS = os.environ.get("NSTEPS", "1")
-sys.argv = ["bench.py", "--model", "search", "--batch", "8", "--steps", NSTEPS, "--warmup", "1", "--graph", "0", "--no-cpu-baseline", "--no-prof"]
+MODEL_ARGS = ["--model", "search", "--batch", "8"] if os.environ.get("MODEL", "search") == "search" else []
+sys.argv = ["bench.py"] + MODEL_ARGS + ["--steps", NSTEPS, "--warmup", "1", "--graph", "0", "--no-cpu-baseline", "--no-prof"]
 # run the bench's own set-up, profiling only its timed steps: bench.main() prints its line; we wrap the whole call
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=False, with_stack=False) as prof:
     try:
