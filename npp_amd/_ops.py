@@ -116,12 +116,19 @@ class _Like:
         self.shape, self.dtype, self.device = torch.Size(shape), dtype, device
 
 
+# NPP_DBG_FAN_CENSUS=1: which backward is the LAST writer of a fan-out tensor's gradient ("next" item 1)
+FAN_CENSUS = __import__("collections").Counter() if os.environ.get("NPP_DBG_FAN_CENSUS") else None
+if FAN_CENSUS is not None:
+    import atexit
+    atexit.register(lambda: [print(f"npp-fan {n:6d} {k}", file=__import__("sys").stderr) for k, n in FAN_CENSUS.most_common()])
+
+
 class _FanAcc:
     """Shared data-gradient buffer of one fan-out tensor."""
-    __slots__ = ("buf", "stream")
+    __slots__ = ("buf", "stream", "last")
 
     def __init__(self):
-        self.buf, self.stream = None, None
+        self.buf, self.stream, self.last = None, None, None
 
     def seed(self, grad):
         """`grad` (an OWNED tensor nobody else reads: a channel slice of a concatenation's gradient) becomes the shared buffer: the
@@ -132,6 +139,10 @@ class _FanAcc:
 
     def claim(self, like):
         """(buffer, accumulate?) for a consumer about to write the gradient of `like` on the current stream, or (None, False)."""
+        if FAN_CENSUS is not None:
+            import traceback
+            fr = traceback.extract_stack(limit=4)
+            self.last = "/".join(f"{f.name}:{f.lineno}" for f in fr[:-1][-2:])      # (the backward that claims: census of the LAST writer)
         cur = stream_ptr()
         if self.buf is None:
             self.buf = new_nhwc(*like.shape, like.dtype, like.device)
@@ -190,6 +201,7 @@ class _FanOut(Function):
     def forward(ctx, x, holder):
         ctx.set_materialize_grads(False)       # aliases nobody consumed hand back None, not a zero tensor
         ctx.holder = holder                    # [ _FanAcc ] once a consumer asked for the shared gradient buffer (take_acc)
+        ctx.is_bn = bool(getattr(x, "_npp_bn", False))
         return tuple(x.view_as(x) for _ in range(_FAN_N))
 
     @staticmethod
@@ -208,6 +220,9 @@ class _FanOut(Function):
                     continue
                 seen_shared = True
             uniq.append(g)
+        if FAN_CENSUS is not None and uniq:
+            kind = "add_n" if len(uniq) > 1 else (("shared:" + str(acc.last)) if seen_shared else "single:" + str(getattr(uniq[0], "_npp_prod", "?")))
+            FAN_CENSUS[("bn" if ctx.is_bn else "other", kind, len(uniq))] += 1
         if acc is not None:
             acc.buf = acc.stream = None        # a later backward over the same graph (retain_graph) starts a new buffer
         if not uniq:
@@ -1365,6 +1380,8 @@ def _conv_dgrad(x, dy, wp, co, kh, kw, stride, pad, dil, relu_in, mask_bits, fan
             dx = new_nhwc(n, ci, h, w, x.dtype, x.device)
     if SHAPE_LOG is not None:
         SHAPE_LOG.append(("dgrad", n, ci, h, w, co, kh, kw, stride[0], dil[0]))
+    if FAN_CENSUS is not None:
+        dx._npp_prod = "conv_dgrad"
     return dx
 
 
@@ -2655,6 +2672,8 @@ def bn_add_multi(specs):
     res = _BnAddPair.apply(len(prep), *tens, *[m for _ts, m in prep])
     for r, (_ts, m) in zip(res, prep):
         _register_mask(r, m[5])
+        if FAN_CENSUS is not None:
+            r._npp_bn = True
     return list(res)
 
 
@@ -2690,6 +2709,8 @@ def bn_add(sa: BnSide, sb: Optional[BnSide] = None, relu: bool = False, training
         mk = (torch.empty(n * h * w * (c // 8), dtype=torch.uint8, device=a.device), 0, c // 8)
     res = _BnAdd.apply(a, ga, ba, b, gb, bb, sa, sb, bool(relu), bool(training), holder, mk)
     _register_mask(res, mk)
+    if FAN_CENSUS is not None:
+        res._npp_bn = True
     return res
 
 
