@@ -107,6 +107,23 @@ int npp_pack_weights_batched_map(const NppPackJob* jobs_dev, int njobs, const in
  * optional mask: y *= (mask > 0) (ReLU backward when this call is a dgrad). */
 int npp_conv_fwd(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask,
                  NppTensor* y, double* stats, const NppConvGeom* g, void* stream);
+/* Data gradient of a conv (npp_conv_fwd with the flipped-tap image, NppConvGeom.relu_in bit 1 = ADD into dx) that is the LAST writer of
+ * dx = the gradient of T = BN_a(ya) [+ BN_b(yb)] (reference: the backward of nn.BatchNorm2d behind every ReLUConvBN / node sum,
+ * models/operations.py:69-82, model_augment.py:48-62): its epilogue also adds, per channel, sum(g), sum(g * xhat_a) [, sum(g * xhat_b)]
+ * of the finished gradient g into `sums` -- NPP_STAT_REPLICAS slabs of (1 + sides) * C doubles, ZEROED by the caller, the format
+ * npp_bn_bwd_apply_fin / npp_bn_bwd_apply2_fin / npp_bn_bwd_apply_multi read -- so that no npp_bn_bwd_reduce* launch is needed.
+ * mask must be an NPP_MASK8 bit-mask.  Returns NPP_E_UNSUPPORTED WITHOUT launching when the shape does not run on a kernel with this
+ * epilogue (the caller then launches npp_conv_fwd and the stand-alone reduce). */
+typedef struct NppBnSumsArgs {
+  NppTensor ya, yb;          /* raw BatchNorm inputs, shape of dx (yb unused when two == 0) */
+  const float* mi_a;         /* [2C] mean | invstd of side a */
+  const float* mi_b;
+  double* sums;
+  int two, _pad;
+} NppBnSumsArgs;
+int npp_conv_dgrad_sums(const NppTensor* dy, const void* w_packed, const NppTensor* mask, NppTensor* dx, const NppConvGeom* g,
+                        const NppBnSumsArgs* sums, void* stream);
+
 /* The same with caller-owned scratch: small feature maps (12x12, 24x24 at batch 16) give too few output tiles for
  * 256 CUs, so the stride-1 kernel splits the reduction (taps / channel chunks) over more blocks, writes f32 partial
  * tiles to `ws` and finishes (bias, mask, rounding, statistics) in a second launch.  npp_conv_fwd_ws_bytes returns

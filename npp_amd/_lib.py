@@ -37,6 +37,11 @@ class NppConvGeom(C.Structure):
                 ("pw", C.c_int32), ("dh", C.c_int32), ("dw", C.c_int32), ("uph", C.c_int32), ("upw", C.c_int32), ("relu_in", C.c_int32)]
 
 
+class NppBnSumsArgs(C.Structure):
+    _fields_ = [("ya", NppTensor), ("yb", NppTensor), ("mi_a", C.c_void_p), ("mi_b", C.c_void_p), ("sums", C.c_void_p),
+                ("two", C.c_int32), ("_pad", C.c_int32)]
+
+
 class NppWgradItem(C.Structure):
     _fields_ = [("x", NppTensor), ("dy", NppTensor), ("dw_packed", C.c_void_p), ("g", NppConvGeom), ("nslabs", C.c_int32)]
 
@@ -112,6 +117,7 @@ _SIGS = {
     "npp_pack_weights_batched": [_P, C.c_int, C.c_int64, _P],
     "npp_pack_weights_batched_map": [_P, C.c_int, _P, C.c_int64, _P],
     "npp_conv_fwd": [_T, _P, _P, _T, _T, _P, _G, _P],
+    "npp_conv_dgrad_sums": [_T, _P, _T, _T, _G, _P, _P],
     "npp_conv_fwd_ws": [_T, _P, _P, _T, _T, _P, _G, _P, C.c_int64, _P],
     "npp_conv_wgrad": [_T, _T, _P, _G, _P],
     "npp_unpack_wgrad": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],

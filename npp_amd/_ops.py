@@ -123,19 +123,61 @@ if FAN_CENSUS is not None:
     atexit.register(lambda: [print(f"npp-fan {n:6d} {k}", file=__import__("sys").stderr) for k, n in FAN_CENSUS.most_common()])
 
 
+# BatchNorm-backward sums in the LAST writer of the gradient (npp_conv_dgrad_sums, csrc/conv_epi.h SUMS): the output T of a fused local
+# BatchNorm add carries a ticket (its raw inputs, their mean | invstd); the consumers of T were counted in forward (take()), so the data
+# gradient whose claim completes that count knows it finishes the gradient of T and adds sum g, sum g * xhat_a [, sum g * xhat_b] into the
+# slabs the BatchNorm backward's apply kernel reads -- the stand-alone npp_bn_bwd_reduce* launch (on the dependent chain, ~15 us of wall
+# time each) is skipped.  NPP_BN_SUMS=0: every BatchNorm backward reduces for itself.
+BN_SUMS = os.environ.get("NPP_BN_SUMS", "1") != "0"
+BN_SUMS_STATS = [0, 0, 0]      # tickets issued / sums delivered by a data gradient / delivered sums consumed by a BatchNorm backward
+
+
+class _BnTicket:
+    __slots__ = ("two", "ya", "yb", "mia", "mib", "c", "sums", "buf_ptr")
+
+    def __init__(self, ya, yb, mia, mib):
+        self.two = yb is not None
+        self.ya, self.yb, self.mia, self.mib, self.c = ya, yb, mia, mib, ya.shape[1]
+        self.sums, self.buf_ptr = None, 0
+
+    def take(self, dout, two):
+        """The delivered sums if they belong to `dout` (and to this kind of backward), once."""
+        sums, ptr_ = self.sums, self.buf_ptr
+        self.sums, self.buf_ptr = None, 0
+        if sums is None or ptr_ != dout.data_ptr() or two != self.two:
+            return None
+        BN_SUMS_STATS[2] += 1
+        return sums
+
+
 class _FanAcc:
     """Shared data-gradient buffer of one fan-out tensor."""
-    __slots__ = ("buf", "stream", "last")
+    __slots__ = ("buf", "stream", "last", "ticket", "st", "writers", "broken")
 
     def __init__(self):
         self.buf, self.stream, self.last = None, None, None
+        self.ticket, self.st, self.writers, self.broken = None, None, 0, False
+
+    def last_writer_ticket(self):
+        """The ticket of the fan-out tensor if the claim just made was the LAST expected one: every consumer counted in forward has now
+        written into the shared buffer on this stream (a consumer that could not is `broken`)."""
+        tk = self.ticket
+        if tk is None or self.broken or self.st is None or self.buf is None:
+            return None
+        k = self.st[1]
+        if k >= _FAN_N - 1 or self.writers != k:      # (a chained fan-out node: consumers this node does not count)
+            return None
+        return tk
 
     def seed(self, grad):
         """`grad` (an OWNED tensor nobody else reads: a channel slice of a concatenation's gradient) becomes the shared buffer: the
         consumers that come later add into it, and the slice needs no add_n pass of its own."""
         if self.buf is None and grad.dtype == torch.bfloat16:
             self.buf, self.stream = grad, stream_ptr()
+            self.writers += 1
             FAN_STATS[0] += 1
+        else:
+            self.broken = True
 
     def claim(self, like):
         """(buffer, accumulate?) for a consumer about to write the gradient of `like` on the current stream, or (None, False)."""
@@ -147,11 +189,14 @@ class _FanAcc:
         if self.buf is None:
             self.buf = new_nhwc(*like.shape, like.dtype, like.device)
             self.stream = cur
+            self.writers += 1
             FAN_STATS[0] += 1
             return self.buf, False
         if cur == self.stream and self.buf.dtype == like.dtype and self.buf.shape == like.shape:
+            self.writers += 1
             FAN_STATS[1] += 1
             return self.buf, True
+        self.broken = True
         FAN_STATS[2] += 1
         return None, False
 
@@ -183,7 +228,9 @@ def take_acc(x):
         return a, None           # (the alias came from a chained node -- a 4th, 5th ... consumer: a tensor of its own, or the chained
                                  #  node's sum would contain the shared buffer a second time)
     if not st[3]:
-        st[3].append(_FanAcc())
+        fa = _FanAcc()
+        fa.ticket, fa.st = st[4], st
+        st[3].append(fa)
     return a, st[3][0]
 
 
@@ -224,7 +271,10 @@ class _FanOut(Function):
             kind = "add_n" if len(uniq) > 1 else (("shared:" + str(acc.last)) if seen_shared else "single:" + str(getattr(uniq[0], "_npp_prod", "?")))
             FAN_CENSUS[("bn" if ctx.is_bn else "other", kind, len(uniq))] += 1
         if acc is not None:
+            if acc.ticket is not None and acc.ticket.sums is not None and not (len(uniq) == 1 and seen_shared):
+                acc.ticket.sums, acc.ticket.buf_ptr = None, 0      # (somebody's gradient came in beside the shared buffer)
             acc.buf = acc.stream = None        # a later backward over the same graph (retain_graph) starts a new buffer
+            acc.writers, acc.broken = 0, False
         if not uniq:
             return None, None
         if len(uniq) == 1:
@@ -246,7 +296,7 @@ def take(x):
         if len(_FAN_REG) > 8192:               # ops used outside a Network.forward: never grow without bound
             _FAN_REG.clear()
         holder = []
-        st = [_FanOut.apply(x, holder), 0, weakref.ref(x), holder]
+        st = [_FanOut.apply(x, holder), 0, weakref.ref(x), holder, getattr(x, "_npp_ticket", None)]
         _FAN_REG[id(x)] = st
     outs, k = st[0], st[1]
     if k < _FAN_N - 1:
@@ -1359,9 +1409,29 @@ def _conv_dgrad(x, dy, wp, co, kh, kw, stride, pad, dil, relu_in, mask_bits, fan
         # x feeds several consumers: add into their shared gradient buffer (the first claimant stores)
         dx, accumulate = fan.claim(x)
         acc_flag = 2 if accumulate else 0
+    tk = None
     if dx is None:
         dx = new_nhwc(n, ci, h, w, x.dtype, x.device)
+    elif BN_SUMS and relu_in and mask_bits is not None and x.dtype == torch.bfloat16:
+        tk = fan.last_writer_ticket()
     done = False
+    if tk is not None:
+        # this launch finishes the gradient of x = BN_a(ya) [+ BN_b(yb)]: its epilogue also delivers the BatchNorm-backward sums
+        g = geom(kh, kw, 1, 1, dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1], dil[0], dil[1],
+                 (stride[0], stride[1]), acc_flag)
+        sums = zeros_f64(R * (3 if tk.two else 2) * tk.c, x.device)
+        sa_ = L.NppBnSumsArgs()
+        sa_.ya, sa_.mi_a, sa_.sums, sa_.two = desc(tk.ya), tk.mia.data_ptr(), sums.data_ptr(), int(tk.two)
+        if tk.two:
+            sa_.yb, sa_.mi_b = desc(tk.yb), tk.mib.data_ptr()
+        rc = lib().npp_conv_dgrad_sums(_byref(dy), wp.data_ptr(), C.byref(mask_bits[0]), _byref(dx), C.byref(g), C.byref(sa_), s)
+        if rc == 0:
+            tk.sums, tk.buf_ptr = sums, dx.data_ptr()
+            BN_SUMS_STATS[1] += 1
+            MASK_STATS[0] += 1
+            done = True
+        elif rc != L.NPP_E_UNSUPPORTED:
+            check(rc, "npp_conv_dgrad_sums")
     while not done:
         g = geom(kh, kw, 1, 1, dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1], dil[0], dil[1],
                  (stride[0], stride[1]), acc_flag)
@@ -1376,6 +1446,7 @@ def _conv_dgrad(x, dy, wp, co, kh, kw, stride, pad, dil, relu_in, mask_bits, fan
         if not done:      # this shape's kernel cannot accumulate: a tensor of its own, the fan-out node adds it
             FAN_STATS[1] -= 1
             FAN_STATS[2] += 1
+            fan.broken = True
             acc_flag = 0
             dx = new_nhwc(n, ci, h, w, x.dtype, x.device)
     if SHAPE_LOG is not None:
@@ -1811,6 +1882,7 @@ class _DwConv2d(Function):
                 rc = lib().npp_dwconv_bwd_data(_byref(dy), wf.data_ptr(), _byref(x) if relu_in else None, _byref(dx), C.byref(ga), s)
                 if rc == L.NPP_E_UNSUPPORTED:
                     _unclaim()
+                    ctx.fan.broken = True
                     dx, accumulate = new_nhwc(*x.shape, x.dtype, x.device), False
                 else:
                     check(rc, "npp_dwconv_bwd_data")
@@ -1846,7 +1918,7 @@ class BnSide:
     """One operand of the fused add.  kind 'bn': `x` is a raw (pre-BN) tensor with f64 stats (train) or a
     BatchNorm holder in eval mode; kind 'plain': `x` is used as is."""
 
-    __slots__ = ("x", "bn", "stats", "count", "synced_ws", "private", "stream", "sync_event", "stats_c", "gslot", "rider")
+    __slots__ = ("x", "bn", "stats", "count", "synced_ws", "private", "stream", "sync_event", "stats_c", "gslot", "rider", "ticket")
 
     def __init__(self, x, bn=None, stats=None, private=None, stats_c=0, gslot=None, rider=False):
         self.x = x
@@ -1855,6 +1927,7 @@ class BnSide:
         # ([R][sum stats_c | sumsq stats_c]); gslot(like) -> the edge's slice of the merged conv's dy buffer (BatchNorm backward)
         self.stats_c = int(stats_c)
         self.gslot = gslot
+        self.ticket = None          # (out) the _BnTicket of the fused add this side went into, see BN_SUMS
         # SyncBatchNorm + merged edges: the statistics rows of ALL the merged edges travel as the segment of the run's first edge;
         # the others ride along (they wait in the pool to learn that the exchange happened, but contribute no segment of their own)
         self.rider = bool(rider)
@@ -2093,6 +2166,16 @@ def _fin_record(ctx, a, b, y, pa, pb, sa, sb, relu):
     ctx.relu = relu
     ctx.sides = (sa.bn, sb.bn if sb is not None else None, True, pb is not None, sa.count, sb.count if sb else None, b is not None)
     ctx.save_for_backward(a, b, y if relu else None, pa[2], pb[2] if pb is not None else None, None, None)
+    # BN_SUMS: the last writer of y's gradient may deliver the backward sums (no ReLU on y, bf16, both operands BatchNorms of one shape
+    # or one BatchNorm + nothing / a plain operand -- the forms the fused backward kernels take)
+    tk = None
+    if BN_SUMS and not relu and a.dtype == torch.bfloat16:
+        two = pb is not None
+        if (not two) or (b is not None and b.shape == a.shape and b.dtype == a.dtype):
+            tk = _BnTicket(a, b if two else None, pa[2], pb[2] if two else None)
+            BN_SUMS_STATS[0] += 1
+    ctx.ticket = tk
+    sa.ticket = tk
 
 
 # One launch for the BatchNorm applies / backward passes of SEVERAL independent, equally shaped nodes (npp_affine_add_fin_multi,
@@ -2145,6 +2228,8 @@ class _BnAdd(Function):
             check(lib().npp_affine_add(_byref(y), _byref(a), ptr(ssa), tref(b), ptr(ssb), int(relu), stream_ptr()),
                   "npp_affine_add")
         ctx.relu = relu
+        ctx.ticket = None
+        sa.ticket = None
         ctx.sides = (sa.bn, sb.bn if sb is not None else None, batch_a, batch_b, sa.count, sb.count if sb else None,
                      b is not None)
         ctx.save_for_backward(a, b, y if relu else None, mia, mib, ssa, ssb)
@@ -2227,9 +2312,12 @@ class _BnAdd(Function):
             if one is not None:
                 sums = zeros_f64(R * 3 * c, dev)
             elif fused:
-                sums = zeros_f64(R * 3 * c, dev)
-                check(lib().npp_bn_bwd_reduce2_acc(_byref(dout), _byref(a), _byref(b), tref(yrelu), mia.data_ptr(), mib.data_ptr(),
-                                                   sums.data_ptr(), nb, s), "npp_bn_bwd_reduce2_acc")
+                tk_ = getattr(ctx, "ticket", None)
+                sums = tk_.take(dout, True) if (tk_ is not None and sync2 is None) else None      # delivered by the gradient's last writer?
+                if sums is None:
+                    sums = zeros_f64(R * 3 * c, dev)
+                    check(lib().npp_bn_bwd_reduce2_acc(_byref(dout), _byref(a), _byref(b), tref(yrelu), mia.data_ptr(), mib.data_ptr(),
+                                                       sums.data_ptr(), nb, s), "npp_bn_bwd_reduce2_acc")
             else:
                 sums = torch.empty(nb * 3 * c, dtype=torch.float64, device=dev)
                 check(lib().npp_bn_bwd_reduce2(_byref(dout), _byref(a), _byref(b), tref(yrelu), mia.data_ptr(), mib.data_ptr(),
@@ -2306,7 +2394,13 @@ class _BnAdd(Function):
             from . import comm as _comm
             p2p_slabs = _comm.p2p_can(4 * a.shape[1], _sync_group(bna if bna is not None else bnb)[0]) and all(fs or sides[i][1] is None or not sides[i][4] or _sync_group(sides[i][1])[0] is None
                                                    for i, fs in enumerate(fin_sync))
-        red = [((zeros_f64(R * 2 * x.shape[1], x.device), R) if one_bar[i] is not None
+        tk_ = getattr(ctx, "ticket", None)
+        got = None
+        if (tk_ is not None and not tk_.two and len(sides) >= 1 and sides[0][1] is not None and fin[0] and one_bar[0] is None
+                and not (has_b and sides[-1][1] is not None and len(sides) > 1)):
+            got = tk_.take(dout, False)      # side a's sums were delivered by the gradient's last writer
+        red = [((got, R) if (i == 0 and got is not None) else
+                (zeros_f64(R * 2 * x.shape[1], x.device), R) if one_bar[i] is not None
                 else reduce_side(x, mi, fin[i] or (p2p_slabs and fin_sync[i])))
                if bn is not None else None for i, (x, bn, mi, *_r) in enumerate(sides)]
         # phase 2 (SyncBatchNorm): collapse each side's slabs to one vector (+ the LOCAL dgamma / dbeta, which DDP
@@ -2411,10 +2505,11 @@ class _BnAdd(Function):
 class _SubCtx:
     """What _BnAdd.forward / _backward_gen need of an autograd context, for one half of a _BnAddPair."""
 
-    def __init__(self, saved=None, relu=False, sides=None, needs=None, gslots=(None, None)):
+    def __init__(self, saved=None, relu=False, sides=None, needs=None, gslots=(None, None), ticket=None):
         self.saved_tensors = saved
         self.relu, self.sides, self.needs_input_grad = relu, sides, needs
         self.gslots = gslots
+        self.ticket = ticket
 
     def save_for_backward(self, *ts):
         self.saved_tensors = ts
@@ -2437,7 +2532,7 @@ class _BnAddPair(Function):
         for k in range(n):
             sub = _SubCtx()
             outs.append(_BnAdd.forward(sub, *tens[6 * k:6 * k + 6], *metas[k]))
-            subs.append((sub.relu, sub.sides, sub.gslots))
+            subs.append((sub.relu, sub.sides, sub.gslots, sub.ticket))
             saved += list(sub.saved_tensors)
         assert len(saved) == 7 * n
         ctx.save_for_backward(*saved)
@@ -2483,7 +2578,7 @@ class _BnAddPair(Function):
             sub = _SubCtx()
             sub.gslots = (sa.gslot, sb.gslot if sb is not None else None)
             _fin_record(sub, a, b, y, pa, pb, sa, sb, relu)
-            subs.append((sub.relu, sub.sides, sub.gslots))
+            subs.append((sub.relu, sub.sides, sub.gslots, sub.ticket))
             saved += list(sub.saved_tensors)
             outs.append(y)
         ctx.save_for_backward(*saved)
@@ -2531,10 +2626,14 @@ class _BnAddPair(Function):
         dev = items[0][1].device
         c = items[0][1].shape[1]
         jobs = (L.NppBnBwdJob * n)()
-        keep, results = [], []
+        keep, results, need_reduce = [], [], []
         for k, (dout, a, b, yrelu, mia, mib, bna, bnb, cnt, has_b, ni, _two) in enumerate(items):
             gs = ctx.subs[k][2]
-            sums = zeros_f64(R * (3 if two else 2) * c, dev)
+            tk_ = ctx.subs[k][3] if len(ctx.subs[k]) > 3 else None
+            sums = tk_.take(dout, two) if tk_ is not None else None      # delivered by the gradient's last writer: no reduce for this job
+            need_reduce.append(sums is None)
+            if sums is None:
+                sums = zeros_f64(R * (3 if two else 2) * c, dev)
             j = jobs[k]
             j.dout, j.ya = desc(dout), desc(a)
             j.yb = desc(b) if two else _zero_desc()
@@ -2576,11 +2675,24 @@ class _BnAddPair(Function):
                 results.append((dxa, dga if ni[1] else None, dba if ni[2] else None, passed, None, None))
         nb = lib().npp_reduce_blocks(items[0][1].shape[0] * items[0][1].shape[2] * items[0][1].shape[3], c, L.npp_dtype(items[0][1].dtype))
         s = stream_ptr()
-        rc = lib().npp_bn_bwd_reduce_multi(C.cast(jobs, C.c_void_p), n, nb, s)
-        if rc == L.NPP_E_UNSUPPORTED:
-            return None
-        check(rc, "npp_bn_bwd_reduce_multi")
-        MULTI_STATS[1] += 1
+        nr = sum(need_reduce)
+        if nr == n:
+            rjobs = jobs
+        else:
+            rjobs = (L.NppBnBwdJob * max(nr, 1))()
+            q = 0
+            for k in range(n):
+                if need_reduce[k]:
+                    C.memmove(C.byref(rjobs[q]), C.byref(jobs[k]), C.sizeof(L.NppBnBwdJob))
+                    q += 1
+        if nr > 0:
+            rc = lib().npp_bn_bwd_reduce_multi(C.cast(rjobs, C.c_void_p), nr, nb, s)
+            if rc == L.NPP_E_UNSUPPORTED:
+                if nr != n:
+                    raise RuntimeError("npp_bn_bwd_reduce_multi refused a subset of jobs it takes as a whole")
+                return None
+            check(rc, "npp_bn_bwd_reduce_multi")
+            MULTI_STATS[1] += 1
         check(lib().npp_bn_bwd_apply_multi(C.cast(jobs, C.c_void_p), n, s), "npp_bn_bwd_apply_multi")
         MULTI_STATS[2] += 1
         out = (None,)
@@ -2599,7 +2711,7 @@ class _BnAddPair(Function):
         needs = ctx.needs_input_grad[1:]
         gens, reqs, res = [], [None] * n, [None] * n
         for k, d in enumerate(douts):
-            sub = _SubCtx(saved[7 * k:7 * k + 7], ctx.subs[k][0], ctx.subs[k][1], needs[6 * k:6 * k + 6], ctx.subs[k][2])
+            sub = _SubCtx(saved[7 * k:7 * k + 7], ctx.subs[k][0], ctx.subs[k][1], needs[6 * k:6 * k + 6], ctx.subs[k][2], ctx.subs[k][3])
             gens.append(_BnAdd._backward_gen(sub, d))
         for k in range(n):      # every reduce first ...
             try:
@@ -2672,6 +2784,8 @@ def bn_add_multi(specs):
     res = _BnAddPair.apply(len(prep), *tens, *[m for _ts, m in prep])
     for r, (_ts, m) in zip(res, prep):
         _register_mask(r, m[5])
+        if m[0].ticket is not None:
+            r._npp_ticket, m[0].ticket = m[0].ticket, None
         if FAN_CENSUS is not None:
             r._npp_bn = True
     return list(res)
@@ -2709,6 +2823,8 @@ def bn_add(sa: BnSide, sb: Optional[BnSide] = None, relu: bool = False, training
         mk = (torch.empty(n * h * w * (c // 8), dtype=torch.uint8, device=a.device), 0, c // 8)
     res = _BnAdd.apply(a, ga, ba, b, gb, bb, sa, sb, bool(relu), bool(training), holder, mk)
     _register_mask(res, mk)
+    if sa.ticket is not None:
+        res._npp_ticket, sa.ticket = sa.ticket, None
     if FAN_CENSUS is not None:
         res._npp_bn = True
     return res

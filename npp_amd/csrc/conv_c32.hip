@@ -29,7 +29,7 @@ constexpr int C32_HALO_PX = (C32_TH + 2) * C32_HW;               // 252
 constexpr int C32_HALO_BYTES = C32_HALO_PX * C32_PITCH;           // 20160
 constexpr int C32_W_BYTES = 9 * 32 * C32_PITCH;                   // 23040
 constexpr int C32_RED = C32_HALO_BYTES + C32_W_BYTES;             // statistics exchange [4 waves][32][2] floats
-constexpr int C32_LDS = C32_RED + 4 * 32 * 2 * 4;
+constexpr int C32_LDS = C32_RED + 4 * 32 * 3 * 4;      // ([3]: the BatchNorm-backward sums form of conv_epi.h)
 
 template <bool RELU>
 __global__ __launch_bounds__(256) void conv_c32_kernel(IgemmParams p, int tiles_y, int tiles_x, int GI, int GO) {
@@ -115,7 +115,20 @@ __global__ __launch_bounds__(256) void conv_c32_kernel(IgemmParams p, int tiles_
   if (ekind) {
     const long pixb = ((long)img * p.H + y0 + wave * MI) * p.W + x0;
     float* const red_w = red + wave * 32 * 2;
-    if (ekind == 1) conv_epilogue_lean<MI, 2, true, 0, false>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red_w);
+    if (p.sum_n > 0) {      // (whole tiles with a bit mask only: ekind is 2 or 3)
+      float* const red3_w = red + wave * 32 * 3;
+      if (ekind == 3) {
+        if (p.sum_n == 2) conv_epilogue_lean<MI, 2, false, 1, true, decltype(acc), 2>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red3_w);
+        else conv_epilogue_lean<MI, 2, false, 1, true, decltype(acc), 1>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red3_w);
+      } else {
+        if (p.sum_n == 2) conv_epilogue_lean<MI, 2, false, 1, false, decltype(acc), 2>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red3_w);
+        else conv_epilogue_lean<MI, 2, false, 1, false, decltype(acc), 1>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red3_w);
+      }
+      __syncthreads();
+      conv_sums_flush<4, 32>(p, red, t, go * 32, blockIdx.x);
+      __syncthreads();      // (the next output group writes `red` again)
+    }
+    else if (ekind == 1) conv_epilogue_lean<MI, 2, true, 0, false>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red_w);
     else if (ekind == 2) conv_epilogue_lean<MI, 2, false, 1, false>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red_w);
     else if (ekind == 3) conv_epilogue_lean<MI, 2, false, 1, true>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red_w);
     else conv_epilogue_lean<MI, 2, false, 0, false>(acc, p, (unsigned)lane, pixb, p.W, go * 32, red_w);
@@ -213,6 +226,7 @@ bool conv_c32_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.ph != 1 || p.pw != 1 || p.OH != p.H || p.OW != p.W) return false;
   // 32 -> 32, or the merged edges of a cell: 32 -> 32 * GO (shared input) / 32 * GI -> 32 (summed data gradients)
   if (p.Cin % 32 != 0 || p.Cout % 32 != 0 || p.Cp != p.Cin || p.ldx % 8 != 0 || !p.vec_io || (p.mask && p.stats)) return false;
+  if (p.sum_n > 0 && (p.bias || p.stats || !p.mask || !p.mask_bits || p.generic_epi || p.H % C32_TH != 0)) return false;      // (conv_epi.h SUMS forms: whole tiles)
   const int GI = p.Cin / 32, GO = p.Cout / 32;
   if (GI < 1 || GO < 1 || GI > 4 || GO > 4 || (GI > 1 && GO > 1)) return false;
   if (p.W % 16 != 0 || p.H < 1) return false;

@@ -15,7 +15,7 @@ typedef float npp_f32x4e __attribute__((ext_vector_type(4)));
 // MASK: 0 none, 1 NPP_MASK8 bits.  The wave's fragment rows mi = 0 .. MI-1 start at pixel pixbase + mi * pixstep (both wave-uniform;
 // lane lrow owns pixel + lrow): ONE 64-bit base per tensor, 32-bit per-lane offsets.  red_w (STATS): this wave's [TN channels][2]
 // floats of the block's statistics exchange; every (channel, sum | sum of squares) of the wave's columns is WRITTEN once.
-template <int MI, int NI, bool STATS, int MASK, bool ACCUM, typename Acc>
+template <int MI, int NI, bool STATS, int MASK, bool ACCUM, typename Acc, int SUMS = 0>
 NPP_DEV void conv_epilogue_lean(Acc& acc, const IgemmParams& p, const unsigned lane, const long pixbase, const int pixstep, const int col0,
                                 float* red_w) {
   static_assert(NI % 2 == 0, "N fragments pair up into 16-byte stores");
@@ -28,6 +28,11 @@ NPP_DEV void conv_epilogue_lean(Acc& acc, const IgemmParams& p, const unsigned l
   const unsigned yoff = (lrow * (unsigned)p.ldy + chb) * 2u, ystep = (unsigned)pixstep * (unsigned)p.ldy * 2u;
   const unsigned moff = lrow * (unsigned)p.ldm + (chb >> 3), mstep = (unsigned)pixstep * (unsigned)p.ldm;
   char* const yb = reinterpret_cast<char*>(p.y) + (pixbase * p.ldy + col0) * 2;
+  // SUMS: the raw BatchNorm inputs at the same (pixel, channel) positions (their own row pitch)
+  const unsigned aoff = (lrow * (unsigned)p.sum_lda + chb) * 2u, astep = (unsigned)pixstep * (unsigned)p.sum_lda * 2u;
+  const unsigned boff = (lrow * (unsigned)p.sum_ldb + chb) * 2u, bstep = (unsigned)pixstep * (unsigned)p.sum_ldb * 2u;
+  const char* const yab = SUMS >= 1 ? reinterpret_cast<const char*>(p.sum_ya) + (pixbase * p.sum_lda + col0) * 2 : nullptr;
+  const char* const ybb = SUMS >= 2 ? reinterpret_cast<const char*>(p.sum_yb) + (pixbase * p.sum_ldb + col0) * 2 : nullptr;
   const char* const mb = reinterpret_cast<const char*>(p.mask) + (pixbase * p.ldm + (col0 >> 3));
 #pragma unroll
   for (int nb = 0; nb < NI / 2; ++nb) {
@@ -40,6 +45,13 @@ NPP_DEV void conv_epilogue_lean(Acc& acc, const IgemmParams& p, const unsigned l
     if (ACCUM) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) pv[mi] = *reinterpret_cast<const u32x4*>(yb + (yoff + mi * ystep + nb * 64));
+    }
+    // SUMS: the RAW sums  sum g, sum g * ya, sum g * yb  per tile (no per-channel constants in registers); conv_sums_flush turns them
+    // into sum g * xhat = invstd * (sum g * y - mean * sum g) per tile, in f64
+    float sg[8], sa[8], sb[8];
+    if (SUMS >= 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { sg[k] = 0.f; sa[k] = 0.f; sb[k] = 0.f; }
     }
     float ss[2][4], sq[2][4];
     if (STATS) {
@@ -70,8 +82,51 @@ NPP_DEV void conv_epilogue_lean(Acc& acc, const IgemmParams& p, const unsigned l
       if (MASK == 1) o = o & mask8_expand(mkb[mi]);
       if (ACCUM) o = add_bf16x8(o, pv[mi]);
       *reinterpret_cast<u32x4*>(yb + (yoff + mi * ystep + nb * 64)) = o;
+      if (SUMS >= 1) {      // the value just stored IS the finished gradient g of this (pixel, 8 channels)
+        const u32x4 va = *reinterpret_cast<const u32x4*>(yab + (aoff + mi * astep + nb * 64));
+        u32x4 vb = {0u, 0u, 0u, 0u};
+        if (SUMS >= 2) vb = *reinterpret_cast<const u32x4*>(ybb + (boff + mi * bstep + nb * 64));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float g = __uint_as_float((k & 1) ? (o[k >> 1] & 0xFFFF0000u) : (o[k >> 1] << 16));
+          const float xa = __uint_as_float((k & 1) ? (va[k >> 1] & 0xFFFF0000u) : (va[k >> 1] << 16));
+          sg[k] += g;
+          sa[k] = fmaf(g, xa, sa[k]);
+          if (SUMS >= 2) {
+            const float xb = __uint_as_float((k & 1) ? (vb[k >> 1] & 0xFFFF0000u) : (vb[k >> 1] << 16));
+            sb[k] = fmaf(g, xb, sb[k]);
+          }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);      // (one store's temporaries at a time: interleaved, the sixteen stores of a 128 x 128 tile cost 57 more
                                               // VGPRs and the second resident block)
+    }
+    if (SUMS >= 1) {
+      // [sg | sa] as one reduce-scatter over the 16 pixel lanes (lane lrow ends with value k = lrow: k < 8 sum g of channel chb + k,
+      // k >= 8 sum g * xhat_a of channel chb + k - 8); sb as an all-reduce over lane bit 3 + a scatter over the other three
+      const bool b3 = (lrow & 8u) != 0, b2 = (lrow & 4u) != 0, b1 = (lrow & 2u) != 0, b0 = (lrow & 1u) != 0;
+#define NPP_XADD(keep, send, ctrl) ((keep) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (send)), ctrl, 0xF, 0xF, true)))
+      float w1[8], w2[4], w3[2];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w1[i] = NPP_XADD(b3 ? sa[i] : sg[i], b3 ? sg[i] : sa[i], 0x140);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w2[i] = NPP_XADD(b2 ? w1[4 + i] : w1[i], b2 ? w1[i] : w1[4 + i], 0x141);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) w3[i] = NPP_XADD(b1 ? w2[2 + i] : w2[i], b1 ? w2[i] : w2[2 + i], 0x4E);
+      const float w4 = NPP_XADD(b0 ? w3[1] : w3[0], b0 ? w3[0] : w3[1], 0xB1);
+      red_w[(nb * 32 + chb + (lrow & 7u)) * 3 + (lrow >> 3)] = w4;
+      if (SUMS >= 2) {
+        float v1[8], v2[4], v3[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v1[i] = NPP_XADD(sb[i], sb[i], 0x140);      // both halves now hold the sum over lane bit 3
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v2[i] = NPP_XADD(b2 ? v1[4 + i] : v1[i], b2 ? v1[i] : v1[4 + i], 0x141);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) v3[i] = NPP_XADD(b1 ? v2[2 + i] : v2[i], b1 ? v2[i] : v2[2 + i], 0x4E);
+        const float v4 = NPP_XADD(b0 ? v3[1] : v3[0], b0 ? v3[0] : v3[1], 0xB1);
+        if (!b3) red_w[(nb * 32 + chb + (lrow & 7u)) * 3 + 2] = v4;
+      }
+#undef NPP_XADD
     }
     if (STATS) {
       // reduce-scatter over the 16 pixel lanes of a row: lane lrow ends with the total of value k = lrow = t*8 + h*4 + j
@@ -91,6 +146,25 @@ NPP_DEV void conv_epilogue_lean(Acc& acc, const IgemmParams& p, const unsigned l
 #undef NPP_XADD
       red_w[(nb * 32 + ((lrow >> 2) & 1u) * 16 + lk * 4 + (lrow & 3u)) * 2 + (lrow >> 3)] = w4;
     }
+  }
+}
+
+// SUMS: combine the waves' [WM][BN][3] floats in `red3` (the caller has synchronised the block AFTER the epilogue) and add them into
+// the replica slab of this block: thread t < BN owns channel n0 + t.
+template <int WM, int BN>
+NPP_DEV void conv_sums_flush(const IgemmParams& p, const float* red3, const int t, const int n0, const unsigned block) {
+  if (t < BN && n0 + t < p.Cout) {
+    const int nq = p.sum_n + 1;      // [sum g | sum g xhat_a (| sum g xhat_b)]
+    double* rep = p.sum_out + (long)(block % NPP_STAT_REPLICAS) * nq * p.Cout;
+    float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < WM; ++w)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) s[q] += red3[((w * BN) + t) * 3 + q];
+    const int ch = n0 + t;
+    atomicAdd(rep + ch, (double)s[0]);
+    atomicAdd(rep + p.Cout + ch, (double)p.sum_mia[p.Cout + ch] * ((double)s[1] - (double)p.sum_mia[ch] * (double)s[0]));
+    if (nq == 3) atomicAdd(rep + 2L * p.Cout + ch, (double)p.sum_mib[p.Cout + ch] * ((double)s[2] - (double)p.sum_mib[ch] * (double)s[0]));
   }
 }
 

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
   constexpr int R = RING_;             // ring depth (2; 4 where fewer blocks than CUs leave nobody to hide a block's DMA latency)
   constexpr int AB = BM * 128;         // bytes of the A part of a K-tile buffer: [BM rows][128 B]
   constexpr int KT = (BM + BN) * 128;  // bytes per K-tile buffer: A then B [BN rows][128 B]
-  constexpr int RED = R * KT;          // statistics exchange [WM_][BN ch][2] floats
+  constexpr int RED = R * KT;          // statistics exchange [WM_][BN ch][2] floats (BatchNorm-backward sums: [3])
   constexpr int MI = TM / 16, NI = TN / 16;      // 16 x 16 fragments per wave
   static_assert(NI >= 2 && NI % 2 == 0 && MI >= 1, "the epilogue pairs N fragments");
   constexpr int PA = BM / 32, PB = BN / 32;      // DMA instructions (1-KiB pieces) per wave per K-tile
@@ -245,7 +245,21 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
   if (ekind) {
     const long pixb = (long)m0 + wm * TM;
     float* const red_w = red + (wm * BN + wn * TN) * 2;
-    if (ekind == 1) conv_epilogue_lean<MI, NI, true, 0, false>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red_w);
+    // (64-row tiles only: on the 128 x 128 tile the three running sums cost the second resident block -- 166 -> 203 VGPRs -- for EVERY
+    // launch of the kernel; the 64-row kernels run the small, under-filled problems, where the fourth / third block per CU is idle anyway)
+    if (BM == 64 && p.sum_n > 0) {      // (the host launches this form only on whole tiles with a bit mask: ekind is 2 or 3)
+      float* const red3_w = red + (wm * BN + wn * TN) * 3;
+      if (ekind == 3) {
+        if (p.sum_n == 2) conv_epilogue_lean<MI, NI, false, 1, true, decltype(acc), 2>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red3_w);
+        else conv_epilogue_lean<MI, NI, false, 1, true, decltype(acc), 1>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red3_w);
+      } else {
+        if (p.sum_n == 2) conv_epilogue_lean<MI, NI, false, 1, false, decltype(acc), 2>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red3_w);
+        else conv_epilogue_lean<MI, NI, false, 1, false, decltype(acc), 1>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red3_w);
+      }
+      __syncthreads();
+      conv_sums_flush<WM_, BN>(p, red, t, n0, (unsigned)bid);
+    }
+    else if (ekind == 1) conv_epilogue_lean<MI, NI, true, 0, false>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red_w);
     else if (ekind == 2) conv_epilogue_lean<MI, NI, false, 1, false>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red_w);
     else if (ekind == 3) conv_epilogue_lean<MI, NI, false, 1, true>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red_w);
     else conv_epilogue_lean<MI, NI, false, 0, false>(acc, p, (unsigned)lane, pixb, 16, n0 + wn * TN, red_w);
@@ -390,6 +404,7 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   if ((long)p.N * p.H * p.W * p.ldx * 2 >= (1L << 32) - 65536) return false;
   if (!p.vec_io || (p.mask && p.stats)) return false;
   if (p.H >= 16384 || p.W >= 16384) return false;
+  if (p.sum_n > 0 && (p.bias || p.stats || !p.mask || !p.mask_bits || p.generic_epi || G4_LEAN == 0 || G4_DBG != 0)) return false;      // (conv_epi.h SUMS forms)
   const long wbytes = (long)p.Cout * p.Kpad * 2;
   if (wbytes >= (1L << 31)) return false;
   // Where this kernel is used (all measured at N = 16, bf16, graph-replayed, us; this kernel vs the other one):
@@ -420,6 +435,7 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (!half && p.Cout % 128 == 0 && (long)((p.M + 127) / 128) * (p.Cout / 128) >= big_min_tiles) { bm = 128; bn = 128; }
   if (force_tile == 64 && bn != 32) { bm = 64; bn = 64; }
   if (force_tile == 128 && p.Cout % 128 == 0 && !half) { bm = 128; bn = 128; }
+  if (p.sum_n > 0 && (p.M % bm != 0 || bm != 64)) return false;      // (whole 64-row tiles only, see the kernel)
   IgemmParams q = p;
   q.mtiles = (p.M + bm - 1) / bm; q.ntiles = p.Cout / bn;
   const int total = q.mtiles * q.ntiles;
@@ -432,7 +448,7 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   const int grid = pers ? slots : total;
 #define G4_LAUNCH(BM_, BN_, WM__, RELU_, TAPS_, HALF_, PERS_)                                              \
   do {                                                                                                     \
-    constexpr size_t lds = G4_RING * (BM_ + BN_) * 128 + WM__ * BN_ * 2 * 4;                                \
+    constexpr size_t lds = G4_RING * (BM_ + BN_) * 128 + WM__ * BN_ * 3 * 4;                                \
     if (!g4_raise_lds(reinterpret_cast<const void*>(conv_g4_kernel<BM_, BN_, WM__, RELU_, TAPS_, HALF_, PERS_>), lds)) return false; \
     hipLaunchKernelGGL((conv_g4_kernel<BM_, BN_, WM__, RELU_, TAPS_, HALF_, PERS_>), dim3(grid), dim3(256), lds, stream, q, e); \
   } while (0)
@@ -451,7 +467,7 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   static const int deep_ring = getenv("NPP_G4_DEEP_RING") ? atoi(getenv("NPP_G4_DEEP_RING")) : 4;
 #define G4_LAUNCH_DEEP_R(RELU_, TAPS_, RG_)                                                                 \
   do {                                                                                                     \
-    constexpr size_t lds = RG_ * (64 + 64) * 128 + 2 * 64 * 2 * 4;                                          \
+    constexpr size_t lds = RG_ * (64 + 64) * 128 + 2 * 64 * 3 * 4;                                          \
     if (!g4_raise_lds(reinterpret_cast<const void*>(conv_g4_kernel<64, 64, 2, RELU_, TAPS_, false, false, RG_>), lds)) return false; \
     hipLaunchKernelGGL((conv_g4_kernel<64, 64, 2, RELU_, TAPS_, false, false, RG_>), dim3(grid), dim3(256), lds, stream, q, e); \
   } while (0)

@@ -211,7 +211,23 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_h3_kernel(IgemmParams p, 
   if (ekind) {
     const long pixb = ((long)img * p.H + y0 + wm * MI) * p.W + x0;
     float* const red_w = red + (wm * BN + wn * TN) * 2;
-    if (ekind == 1) conv_epilogue_lean<MI, NI, true, 0, false>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red_w);
+    if (p.sum_n > 0) {      // (the host launches this form only on whole tiles with a bit mask: ekind is 2 or 3)
+      // the [NWM][BN][3] exchange of the sums lives in the weight ring (the kernel's LDS is full: two blocks per CU): every wave must
+      // be out of the K loop first
+      __syncthreads();
+      float* const red3 = reinterpret_cast<float*>(smem + BOFF);
+      float* const red3_w = red3 + (wm * BN + wn * TN) * 3;
+      if (ekind == 3) {
+        if (p.sum_n == 2) conv_epilogue_lean<MI, NI, false, 1, true, decltype(acc), 2>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red3_w);
+        else conv_epilogue_lean<MI, NI, false, 1, true, decltype(acc), 1>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red3_w);
+      } else {
+        if (p.sum_n == 2) conv_epilogue_lean<MI, NI, false, 1, false, decltype(acc), 2>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red3_w);
+        else conv_epilogue_lean<MI, NI, false, 1, false, decltype(acc), 1>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red3_w);
+      }
+      __syncthreads();
+      conv_sums_flush<NWM, BN>(p, red3, t, n0, blockIdx.x);
+    }
+    else if (ekind == 1) conv_epilogue_lean<MI, NI, true, 0, false>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red_w);
     else if (ekind == 2) conv_epilogue_lean<MI, NI, false, 1, false>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red_w);
     else if (ekind == 3) conv_epilogue_lean<MI, NI, false, 1, true>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red_w);
     else conv_epilogue_lean<MI, NI, false, 0, false>(acc, p, (unsigned)lane, pixb, p.W, n0 + wn * TN, red_w);
@@ -350,6 +366,7 @@ bool conv_h3_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   if ((long)p.N * p.H * p.W * p.ldx * 2 >= (1L << 32) - 131072) return false;      // 32-bit byte offsets, out-of-range sentinel
   if (p.Cin > 512) return false;                                                    // chunk * 128 must stay below the sentinel gap
   if (!p.vec_io || (p.mask && p.stats)) return false;
+  if (p.sum_n > 0 && (p.bias || p.stats || !p.mask || !p.mask_bits || p.generic_epi || H3_LEAN == 0)) return false;      // (conv_epi.h SUMS forms)
   if ((long)p.Cout * p.Kpad * 2 >= (1L << 31)) return false;
   // which shapes: measured against conv_g4 (tools/g8_time.py, NPP_TIME_SET=h3), see the table in DESIGN.md section 4
   static const int cfg = getenv("NPP_H3_CFG") ? atoi(getenv("NPP_H3_CFG")) : 0;
@@ -368,6 +385,7 @@ bool conv_h3_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
     constexpr size_t lds = 2 * APC_ * 1024 + RING_ * BN_ * 128 + NWM_ * BN_ * 2 * 4;                          \
     H3Extra e;                                                                                                \
     e.nchunks = p.Cin / 64; e.ns = 9 * e.nchunks;                                                             \
+    if (p.sum_n > 0 && p.H % TH_ != 0) return false;                                                          \
     e.tiles_y = (p.H + TH_ - 1) / TH_; e.tiles_x = p.W / 16; e.tiles_img = e.tiles_y * e.tiles_x;             \
     IgemmParams q = p;                                                                                        \
     q.ntiles = p.Cout / BN_; q.mtiles = p.N * e.tiles_img;                                                    \

@@ -525,7 +525,18 @@ extern "C" int npp_pack_weight(const float* w, int cout, int cin, int kh, int kw
 }
 
 static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask, NppTensor* y,
-                         double* stats, const NppConvGeom* g, void* ws, size_t ws_bytes, void* stream, size_t* ws_query);
+                         double* stats, const NppConvGeom* g, void* ws, size_t ws_bytes, void* stream, size_t* ws_query,
+                         const NppBnSumsArgs* sums_args = nullptr);
+
+extern "C" int npp_conv_dgrad_sums(const NppTensor* dy, const void* w_packed, const NppTensor* mask, NppTensor* dx, const NppConvGeom* g,
+                                   const NppBnSumsArgs* sums, void* stream) {
+  NPP_REQUIRE(sums && sums->ya.ptr && sums->mi_a && sums->sums && (!sums->two || (sums->yb.ptr && sums->mi_b)), NPP_E_NULL,
+              "npp_conv_dgrad_sums: null pointer");
+  NPP_REQUIRE(dx && sums->ya.dtype == dx->dtype && sums->ya.n == dx->n && sums->ya.h == dx->h && sums->ya.w == dx->w && sums->ya.c == dx->c
+              && (!sums->two || (sums->yb.dtype == dx->dtype && sums->yb.n == dx->n && sums->yb.h == dx->h && sums->yb.w == dx->w
+                                 && sums->yb.c == dx->c)), NPP_E_SHAPE, "npp_conv_dgrad_sums: the BatchNorm inputs must have the shape of dx");
+  return conv_fwd_impl(dy, w_packed, nullptr, mask, dx, nullptr, g, nullptr, 0, stream, nullptr, sums);
+}
 
 extern "C" int npp_conv_fwd(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask,
                             NppTensor* y, double* stats, const NppConvGeom* g, void* stream) {
@@ -549,7 +560,8 @@ extern "C" int64_t npp_conv_fwd_ws_bytes(const NppTensor* x, const NppTensor* y,
 }
 
 static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* bias, const NppTensor* mask, NppTensor* y,
-                         double* stats, const NppConvGeom* g, void* ws, size_t ws_bytes, void* stream, size_t* ws_query) {
+                         double* stats, const NppConvGeom* g, void* ws, size_t ws_bytes, void* stream, size_t* ws_query,
+                         const NppBnSumsArgs* sums_args) {
   NPP_REQUIRE(x && w_packed && y && g && x->ptr && y->ptr, NPP_E_NULL, "npp_conv_fwd: null pointer");
   const bool mask_bits = mask && mask->dtype == NPP_MASK8;
   NPP_REQUIRE(x->dtype == y->dtype && (!mask || mask_bits || mask->dtype == y->dtype), NPP_E_DTYPE,
@@ -588,6 +600,13 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
   p.mask_bits = mask_bits ? 1 : 0;
   static const bool lean_off = getenv("NPP_EPI_LEAN") && atoi(getenv("NPP_EPI_LEAN")) == 0;
   p.generic_epi = lean_off ? 1 : 0;
+  p.sum_ya = p.sum_yb = nullptr; p.sum_lda = p.sum_ldb = 0; p.sum_mia = p.sum_mib = nullptr; p.sum_out = nullptr; p.sum_n = 0;
+  if (sums_args) {
+    p.sum_ya = sums_args->ya.ptr; p.sum_lda = sums_args->ya.ld; p.sum_mia = sums_args->mi_a;
+    p.sum_n = 1;
+    if (sums_args->two) { p.sum_yb = sums_args->yb.ptr; p.sum_ldb = sums_args->yb.ld; p.sum_mib = sums_args->mi_b; p.sum_n = 2; }
+    p.sum_out = sums_args->sums;
+  }
   p.vec_io = (y->ld % vec == 0) && (((uintptr_t)y->ptr & 15) == 0) &&
              (!mask || mask_bits || ((mask->ld % vec == 0) && (((uintptr_t)mask->ptr & 15) == 0)));
   const int npad = round_up(p.Cout, 32);
@@ -631,6 +650,10 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
     ProfScope prof0(NPP_FAM_CONV_G8, x->dtype, s, flops, bytes);
     if (conv_g8_launch(p, x->dtype, s)) return npp_check_launch(census("conv_g8"));
     prof0.cancel();
+  }
+  if (p.sum_n > 0) {      // only conv_g4 / conv_h3 / conv_c32 have the summing epilogue: the caller launches the plain data gradient
+    npp_set_error("npp_conv_dgrad_sums: this shape runs on a kernel without the BatchNorm-backward sums epilogue");
+    return NPP_E_UNSUPPORTED;
   }
   if (p.mask_bits) {      // only the LDS-DMA kernels above read bit-masks: the caller retries with the bf16 tensor as mask
     npp_set_error("npp_conv_fwd: this shape runs on a kernel without bit-mask support");

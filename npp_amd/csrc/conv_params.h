@@ -11,6 +11,10 @@ struct IgemmParams {
   int mask_bits;   // `mask` is an NPP_MASK8 bit-mask (ldm in BYTES per pixel): conv_g4 / conv_g8 only
   int accum;       // data gradient of a fan-out tensor: ADD into y instead of storing (NppConvGeom.relu_in bit 1): conv_g4 / conv_h3 /
                    // conv_g8 / conv_thin epilogues read the 16 bytes they are about to write
+  // BatchNorm-backward sums of the tensor this data gradient completes (conv_epi.h, SUMS): y is the gradient of T = BN_a(ya) [+ BN_b(yb)]
+  // and this launch is its LAST writer -- the epilogue adds sum(g), sum(g * xhat_a) [, sum(g * xhat_b)] per channel into the replica
+  // slabs bn_bwd_apply*_fin reads (sum_n * Cout doubles per replica, NPP_STAT_REPLICAS of them).  sum_n = 0: none.
+  const void* sum_ya; const void* sum_yb; long sum_lda, sum_ldb; const float* sum_mia; const float* sum_mib; double* sum_out; int sum_n;
   int generic_epi; // NPP_EPI_LEAN=0: the LDS-DMA kernels keep their generic epilogue on every tile (A/B switch for conv_epi.h)
   int par, mtiles_c;   // generic kernel, data gradient of a stride-2 conv (uph = upw = 2): output pixels grouped by parity class,
                        // each class a stride-1 conv over the taps that do not hit an inserted zero; mtiles_c = M-tiles per class

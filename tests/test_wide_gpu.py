@@ -407,3 +407,56 @@ def test_one_by_one_members_of_a_merged_edge_queue_one_weight_gradient_job():
     for a, b in zip(gm, gs):
         assert a.shape == b.shape and float(b.abs().max()) > 0
         assert (a - b).abs().max() <= 1e-5 * float(b.abs().max())      # (same bf16 operands, f32 accumulation in another order)
+
+
+@pytest.mark.parametrize("two_sided", [True, False])
+@pytest.mark.parametrize("k,c,h", [(3, 128, 96), (3, 32, 96), (1, 128, 24), (3, 64, 24)])
+def test_last_writer_delivers_the_batchnorm_backward_sums(two_sided, k, c, h):
+    """BN_SUMS: T = BN_a(conv_a(x)) [+ BN_b(conv_b(x))] feeds two ReLU-conv consumers; the data gradient of the consumer that writes
+    T's gradient LAST (npp_conv_dgrad_sums on conv_h3 / conv_c32 / conv_g4's 64-row tiles) also delivers sum g, sum g xhat_a, sum g xhat_b,
+    and the BatchNorm backward skips its reduce launch.  Against the same graph with NPP_BN_SUMS off: the sums differ only in the order
+    of f32 partial sums, so the gradients behind the BatchNorm agree to bf16 rounding."""
+    from npp_amd import _ops as K
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(100 + k + c)
+    n = 2 if h == 96 else 8
+    x_cpu = torch.randn(n, c, h, h, generator=g)
+    wa, wb = (torch.randn(c, c, 1, 1, generator=g) * (1.0 / c ** 0.5) for _ in range(2))
+    w1, w2 = (torch.randn(c, c, k, k, generator=g) * (1.0 / (c * k * k) ** 0.5) for _ in range(2))
+    r1, r2 = (torch.randn(n, c, h, h, generator=g) for _ in range(2))
+    bna, bnb = nn.BatchNorm2d(c).to(dev).train(), nn.BatchNorm2d(c).to(dev).train()
+
+    def run(on):
+        old = K.BN_SUMS
+        K.BN_SUMS = on
+        K.fan_reset()
+        try:
+            before = list(K.BN_SUMS_STATS)
+            leaf = K.cast(x_cpu.to(dev).contiguous(memory_format=torch.channels_last), torch.bfloat16).detach().requires_grad_(True)
+            ws = [t.to(dev).requires_grad_(True) for t in (wa, wb, w1, w2)]
+            ya, sta = K.conv2d(leaf, ws[0], None, 1, 0, 1, relu_in=False, want_stats=True)
+            sides = [K.BnSide(ya, bna, sta)]
+            if two_sided:
+                yb, stb = K.conv2d(leaf, ws[1], None, 1, 0, 1, relu_in=False, want_stats=True)
+                sides.append(K.BnSide(yb, bnb, stb))
+            t = K.bn_add(*sides)
+            o1, _ = K.conv2d(t, ws[2], None, 1, k // 2, 1, relu_in=True, want_stats=False)
+            o2, _ = K.conv2d(t, ws[3], None, 1, k // 2, 1, relu_in=True, want_stats=False)
+            gd = lambda r: K.cast(r.to(dev).contiguous(memory_format=torch.channels_last), torch.bfloat16)
+            torch.autograd.backward([o1, o2], [gd(r1), gd(r2)])
+            torch.cuda.synchronize()
+            delta = [a - b for a, b in zip(K.BN_SUMS_STATS, before)]
+            return leaf.grad.float().cpu(), [w.grad.float().cpu() for w in ws if w.grad is not None], delta
+        finally:
+            K.BN_SUMS = old
+            K.drop_pending()
+            K.fan_reset()
+
+    dx1, gw1, d1 = run(True)
+    dx0, gw0, d0 = run(False)
+    assert d0 == [0, 0, 0]
+    assert d1[0] >= 1 and d1[1] == 1 and d1[2] == 1, d1      # one ticket delivered by the second consumer's data gradient and consumed
+    scale = float(dx0.abs().max())
+    assert scale > 0 and float((dx1 - dx0).abs().max()) <= 2 ** -6 * scale
+    for a, b in zip(gw1, gw0):
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max())
