@@ -38,6 +38,17 @@ NPP_DEV void conv_epilogue_lean(Acc& acc, const IgemmParams& p, const unsigned l
   for (int nb = 0; nb < NI / 2; ++nb) {
     unsigned mkb[MI];
     u32x4 pv[MI];
+    // SUMS: the raw BatchNorm inputs of the whole block in front of the first store -- a load behind a store waits for the store's
+    // acknowledgement (one in-order counter), once per row otherwise
+    u32x4 va[MI], vb[MI];
+    if (SUMS >= 1) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) va[mi] = *reinterpret_cast<const u32x4*>(yab + (aoff + mi * astep + nb * 64));
+    }
+    if (SUMS >= 2) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) vb[mi] = *reinterpret_cast<const u32x4*>(ybb + (boff + mi * bstep + nb * 64));
+    }
     if (MASK == 1) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) mkb[mi] = *reinterpret_cast<const unsigned char*>(mb + (moff + mi * mstep + nb * 4));
@@ -83,17 +94,14 @@ NPP_DEV void conv_epilogue_lean(Acc& acc, const IgemmParams& p, const unsigned l
       if (ACCUM) o = add_bf16x8(o, pv[mi]);
       *reinterpret_cast<u32x4*>(yb + (yoff + mi * ystep + nb * 64)) = o;
       if (SUMS >= 1) {      // the value just stored IS the finished gradient g of this (pixel, 8 channels)
-        const u32x4 va = *reinterpret_cast<const u32x4*>(yab + (aoff + mi * astep + nb * 64));
-        u32x4 vb = {0u, 0u, 0u, 0u};
-        if (SUMS >= 2) vb = *reinterpret_cast<const u32x4*>(ybb + (boff + mi * bstep + nb * 64));
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float g = __uint_as_float((k & 1) ? (o[k >> 1] & 0xFFFF0000u) : (o[k >> 1] << 16));
-          const float xa = __uint_as_float((k & 1) ? (va[k >> 1] & 0xFFFF0000u) : (va[k >> 1] << 16));
+          const float xa = __uint_as_float((k & 1) ? (va[mi][k >> 1] & 0xFFFF0000u) : (va[mi][k >> 1] << 16));
           sg[k] += g;
           sa[k] = fmaf(g, xa, sa[k]);
           if (SUMS >= 2) {
-            const float xb = __uint_as_float((k & 1) ? (vb[k >> 1] & 0xFFFF0000u) : (vb[k >> 1] << 16));
+            const float xb = __uint_as_float((k & 1) ? (vb[mi][k >> 1] & 0xFFFF0000u) : (vb[mi][k >> 1] << 16));
             sb[k] = fmaf(g, xb, sb[k]);
           }
         }
