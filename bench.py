@@ -583,7 +583,7 @@ def main():
         prof_steps = 2
         KERNELS = {"conv_s1": "conv_s1_kernel (stride-1 KxK conv fwd + dgrad, LDS-resident footprint, MFMA 32x32x16)",
                    "conv_g8": "conv_g8_kernel (1x1 conv fwd + dgrad: 8-phase LDS-DMA implicit GEMM, MFMA 16x16x32)",
-                   "conv_g4": "conv_g4_kernel + conv_h3_kernel + conv_c32_kernel + conv_thin (conv fwd + dgrad, incl. the merged edges of round 4: same-input edges as one conv C -> mC and one data gradient mC -> C; g4: 1x1 / 3x3 on 64x64 / 128x128 / 64x32 tiles, stride 1 and 2, LDS-DMA ring of 2; h3: 3x3 with an LDS-resident halo footprint on the >= 30k-pixel maps; c32: 32 -> 32 3x3 with halo and all nine taps resident, output / input groups; MFMA 16x16x32)",
+                   "conv_g4": "conv_g4_kernel + conv_h3_kernel + conv_c32_kernel + conv_thin (conv fwd + dgrad, incl. the merged edges of round 4: same-input edges as one conv C -> mC and one data gradient mC -> C; g4: 1x1 / 3x3 on 64x64 / 128x128 / 64x32 tiles, stride 1 and 2, LDS-DMA ring of 2; h3: 3x3 with an LDS-resident halo footprint on the >= 30k-pixel maps; c32: 32 -> 32 3x3 with halo and all nine taps resident, output / input groups; MFMA 16x16x32; 114 of the data-gradient launches per step also deliver the BatchNorm-backward sums of the gradient they finish -- two more tensor reads each, timed here, not in the algorithmic flops: the family read 0.156 before that fusion)",
                    "conv_wgrad": "weight-gradient family (conv_wgrad_g4_batched_kernel: every LDS-DMA-eligible weight gradient of the step in one launch per variant over a device job table -- pixel-major LDS-DMA + transposing reads, MFMA 16x16x32; strided / odd-channel layers on conv_wgrad_kernel)"}
         # HBM bytes per launch: rocprofv3 --pmc cannot run inside this process, so the counters come from the committed passes
         # of this same command (tools/final_profiles.sh -> profiles/rNN_pmc_traffic.json, the newest round's) -- and only while the kernel sources
