@@ -180,6 +180,10 @@ typedef struct NppWgradItem {
 } NppWgradItem;
 int npp_conv_wgrad_batchable(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g);
 int npp_conv_wgrad_batched_splits(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g);
+/* slabs the batched launch wants for this problem BY DEFAULT: > 0 for the shapes of the nine-tap halo kernel (3x3 stride 1, Cin % 64 ==
+ * 0, Cout % 128 == 0, maps of whole 8 x 16-pixel tiles -- the weight gradient of operations.py:69-82 on the 96 x 96 / 48 x 48 maps),
+ * whose pixel splits store one slab each (= npp_conv_wgrad_batched_splits); 0 for problems whose kernel accumulates. */
+int npp_conv_wgrad_batched_slabs(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g);
 int64_t npp_conv_wgrad_batched_ws(int n);
 int npp_conv_wgrad_batched(const NppWgradItem* items, int n, void* host_pinned, void* dev, int64_t ws_bytes, void* stream);
 int npp_conv_wgrad_splits(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g);
@@ -597,6 +601,8 @@ typedef struct NppP2pSeg {
 } NppP2pSeg;
 int npp_p2p_exchange_slabs(const NppP2pSeg* segs, int nseg, int channel, void* stream);
 int npp_p2p_status(void);
+int64_t npp_p2p_set_timeout_ms(int64_t ms);   /* poll timeout of later exchanges (ms > 0); returns the previous value */
+int npp_p2p_reset_errors(void);               /* clear every channel's error word (synchronises the device): the host's acceptance test, between modes */
 int npp_p2p_close(void);
 
 #ifdef __cplusplus

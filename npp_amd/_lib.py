@@ -216,6 +216,7 @@ _SIGS = {
     "npp_bilinear_bwd_ws": [_T, _T, C.c_int, _P, C.c_int64, _P],
     "npp_conv_wgrad_batchable": [_T, _T, _G],
     "npp_conv_wgrad_batched_splits": [_T, _T, _G],
+    "npp_conv_wgrad_batched_slabs": [_T, _T, _G],
     "npp_dwconv_bwd_weight_batchable": [_T, _T, _G],
     "npp_dwconv_bwd_weight_batched": [_P, C.c_int, _P, _P, C.c_int64, _P],
     "npp_conv_wgrad_batched": [_P, C.c_int, _P, _P, C.c_int64, _P],
@@ -234,13 +235,14 @@ _SIGS = {
     "npp_p2p_exchange": [_P, C.c_int64, C.c_int, _P],
     "npp_p2p_exchange_slabs": [_P, C.c_int, C.c_int, _P],
     "npp_p2p_status": [],
+    "npp_p2p_reset_errors": [],
     "npp_p2p_close": [],
     "npp_parsing_confusion": [_T, _T, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_clear_hip_error", "npp_packed_weight_elems", "npp_pack_job_blocks", "npp_reduce_blocks",
                                  "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems",
                                  "npp_conv_wgrad_splits", "npp_debug_nonfinite", "npp_conv_wgrad_batched_ws", "npp_dwconv_bwd_weight_batched_ws", "npp_bilinear_bwd_ws_bytes",
-                                 "npp_se_ws_floats", "npp_se_param_grads_batched_ws", "npp_p2p_capacity"])
+                                 "npp_se_ws_floats", "npp_se_param_grads_batched_ws", "npp_p2p_capacity", "npp_p2p_set_timeout_ms"])
 
 
 def kernel_source_hash() -> str:
@@ -305,6 +307,8 @@ def lib():
         L.npp_se_param_grads_batched_ws.argtypes = [_P, C.c_int]
         L.npp_p2p_capacity.restype = C.c_int64
         L.npp_p2p_capacity.argtypes = []
+        L.npp_p2p_set_timeout_ms.restype = C.c_int64
+        L.npp_p2p_set_timeout_ms.argtypes = [C.c_int64]
         for name, sig in _SIGS.items():
             f = getattr(L, name)
             f.restype = C.c_int

@@ -133,18 +133,28 @@ BN_SUMS_STATS = [0, 0, 0]      # tickets issued / sums delivered by a data gradi
 
 
 class _BnTicket:
-    __slots__ = ("two", "ya", "yb", "mia", "mib", "c", "sums", "buf_ptr")
+    __slots__ = ("two", "ya", "yb", "mia", "mib", "c", "sums", "buf_ptr", "buf", "buf_ver")
 
     def __init__(self, ya, yb, mia, mib):
         self.two = yb is not None
         self.ya, self.yb, self.mia, self.mib, self.c = ya, yb, mia, mib, ya.shape[1]
-        self.sums, self.buf_ptr = None, 0
+        self.sums, self.buf_ptr, self.buf, self.buf_ver = None, 0, None, 0
+
+    def deliver(self, sums, buf):
+        """`sums` belong to the gradient held in `buf` as it stands now.  The ticket keeps `buf` alive (a second owner: the autograd
+        engine's InputBuffer never accumulates another gradient into it in place) and remembers its version counter -- an in-place
+        add by anybody else (`add_`) would bump it; this library's kernels write through raw pointers and do not."""
+        self.sums, self.buf_ptr, self.buf, self.buf_ver = sums, buf.data_ptr(), buf, buf._version
+
+    def drop(self):
+        self.sums, self.buf_ptr, self.buf, self.buf_ver = None, 0, None, 0
 
     def take(self, dout, two):
         """The delivered sums if they belong to `dout` (and to this kind of backward), once."""
-        sums, ptr_ = self.sums, self.buf_ptr
-        self.sums, self.buf_ptr = None, 0
-        if sums is None or ptr_ != dout.data_ptr() or two != self.two:
+        sums, ptr_, buf, ver = self.sums, self.buf_ptr, self.buf, self.buf_ver
+        self.drop()
+        if (sums is None or buf is None or ptr_ != dout.data_ptr() or two != self.two or dout.shape != buf.shape
+                or dout.stride() != buf.stride() or buf._version != ver or dout._version != ver):
             return None
         BN_SUMS_STATS[2] += 1
         return sums
@@ -272,7 +282,7 @@ class _FanOut(Function):
             FAN_CENSUS[("bn" if ctx.is_bn else "other", kind, len(uniq))] += 1
         if acc is not None:
             if acc.ticket is not None and acc.ticket.sums is not None and not (len(uniq) == 1 and seen_shared):
-                acc.ticket.sums, acc.ticket.buf_ptr = None, 0      # (somebody's gradient came in beside the shared buffer)
+                acc.ticket.drop()      # (somebody's gradient came in beside the shared buffer)
             acc.buf = acc.stream = None        # a later backward over the same graph (retain_graph) starts a new buffer
             acc.writers, acc.broken = 0, False
         if not uniq:
@@ -1048,14 +1058,17 @@ _wgrad_batch_splits: dict = {}
 
 
 def _batched_slabs(x, dy, g, key) -> int:
-    """Slabs (= pixel splits) of this problem in the batched launch while slab mode applies, else 0."""
-    if not WGRAD_SLABS_BATCHED or DEFER_WGRAD_MAX_PIX <= 0 or not DEFER_UNPACK or x.dtype != torch.bfloat16:
+    """Slabs (= pixel splits) of this problem in the batched launch: in slab mode every problem's, otherwise only those of the
+    nine-tap halo kernel (csrc/conv_wgrad_g4.hip: wg9_body), whose splits always store slabs; else 0."""
+    if DEFER_WGRAD_MAX_PIX <= 0 or not DEFER_UNPACK or x.dtype != torch.bfloat16:
         return 0
     if x.shape[0] * x.shape[2] * x.shape[3] > DEFER_WGRAD_MAX_PIX:
         return 0
+    key = (key, WGRAD_SLABS_BATCHED)
     n = _wgrad_batch_splits.get(key)
     if n is None:
-        n = _wgrad_batch_splits[key] = int(lib().npp_conv_wgrad_batched_splits(_byref(x), _byref(dy), C.byref(g)))
+        fn = lib().npp_conv_wgrad_batched_splits if WGRAD_SLABS_BATCHED else lib().npp_conv_wgrad_batched_slabs
+        n = _wgrad_batch_splits[key] = int(fn(_byref(x), _byref(dy), C.byref(g)))
     return n
 
 
@@ -1426,7 +1439,7 @@ def _conv_dgrad(x, dy, wp, co, kh, kw, stride, pad, dil, relu_in, mask_bits, fan
             sa_.yb, sa_.mi_b = desc(tk.yb), tk.mib.data_ptr()
         rc = lib().npp_conv_dgrad_sums(_byref(dy), wp.data_ptr(), C.byref(mask_bits[0]), _byref(dx), C.byref(g), C.byref(sa_), s)
         if rc == 0:
-            tk.sums, tk.buf_ptr = sums, dx.data_ptr()
+            tk.deliver(sums, dx)
             BN_SUMS_STATS[1] += 1
             MASK_STATS[0] += 1
             done = True
@@ -1470,7 +1483,9 @@ def _conv_wgrad(x, dy, weight, stride, pad, dil, relu_in):
         if nsl > 0 and weight.dtype == torch.float32 and _may_defer(weight):
             # batched launch in slab mode: the splits store into slabs, the batched unpack sums them into the gradient
             slabs = torch.empty(nsl * nel, dtype=torch.float32, device=x.device)
-            _defer_wgrad(x, dy, slabs, g, wkey, None, nsl)
+            if not _defer_wgrad(x, dy, slabs, g, wkey, None, nsl):
+                slabs.zero_()
+                check(lib().npp_conv_wgrad(_byref(x), _byref(dy), slabs.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
             dw = grad_out(weight)
             if dw is None:
                 dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
@@ -1492,9 +1507,11 @@ def _conv_wgrad(x, dy, weight, stride, pad, dil, relu_in):
             nsl = _wgrad_splits[wkey] = int(lib().npp_conv_wgrad_splits(_byref(x), _byref(dy), C.byref(g)))
         defer_ok = DEFER_UNPACK and _may_defer(weight)      # (dw reaches autograd unwritten when the unpack waits)
         bsl = _batched_slabs(x, dy, g, wkey) if (defer_ok and nsl <= 0) else 0
-        if bsl > 0:      # batched launch in slab mode
+        if bsl > 0:      # batched launch with slabs (the nine-tap halo kernel's jobs always; every job in slab mode)
             slabs = torch.empty(bsl * nel, dtype=torch.float32, device=x.device)
-            _defer_wgrad(x, dy, slabs, g, wkey, None, bsl)
+            if not _defer_wgrad(x, dy, slabs, g, wkey, None, bsl):      # (refused after all: the accumulate form into the first slab)
+                slabs.zero_()
+                check(lib().npp_conv_wgrad(_byref(x), _byref(dy), slabs.data_ptr(), C.byref(g), s), "npp_conv_wgrad")
             _unpack_or_defer(slabs, dw, co, ci, kh, kw, bsl, s, True)
         elif nsl > 0:      # deterministic split-K: the kernel stores one slab per split, the unpack sums them
             slabs = torch.empty(nsl * nel, dtype=torch.float32, device=x.device)

@@ -135,21 +135,38 @@ def enable_p2p(group=None, channels=4):
     if agree(ok) != 1:
         lib.npp_p2p_close()
         return False
-    # acceptance test (2000 back-to-back exchanges, see _p2p_selftest): first with relaxed units, then -- collectively, if ANY rank
-    # read a wrong sum -- with release / acquire units; if that fails too every rank closes its mailboxes (collectives).  A failed
-    # test leaves the channel's sequence numbers in step on all ranks (every rank issues every exchange), so the retry is clean
-    # unless a poll timed out, which kills the channel: then the transport is dropped.
+    # acceptance test (2000 back-to-back exchanges, see _p2p_selftest).  The unit modes to try follow from what the allocator handed
+    # out: uncached / fine-grained mailboxes (kinds 0, 1) try relaxed units first and release / acquire units if ANY rank read a
+    # wrong sum or timed out; plain device memory (kind 2) is only ever run with release / acquire units -- a relaxed system-scope
+    # poll of such memory may never observe the peer's stores, and a pass there would be luck, not coherence.  The test runs with a
+    # short poll timeout (NPP_P2P_SELFTEST_TIMEOUT_MS, 5 s; the long watchdog value is restored afterwards), and between modes every
+    # rank clears its channels' error words: a timed-out channel keeps counting its exchanges, so the ranks are still in step.
     mode = None
     forced = os.environ.get("NPP_P2P_LIGHT")
-    for light in ((1, 0) if forced is None else (1 if forced != "0" else 0,)):
-        lib.npp_p2p_set_mode(light)
-        _selftest_state["broken"] = False
-        passed = agree(1 if _p2p_selftest(lib, rank, world) else 0) == 1
-        if passed:
-            mode = "relaxed" if light else "fenced"
-            break
-        if agree(1 if (int(lib.npp_p2p_status()) == 0 and not _selftest_state["broken"]) else 0) != 1:
-            break
+    kind = agree(int(lib.npp_p2p_alloc_kind()))      # (MIN over the ranks; mixed kinds: below the most careful rank's list is used)
+    kind_max = -agree(-int(lib.npp_p2p_alloc_kind()))
+    if forced is not None:
+        order = (1 if forced != "0" else 0,)
+    elif kind_max >= 2 or kind < 0:
+        order = (0,)
+    else:
+        order = (1, 0)
+    long_ms = int(lib.npp_p2p_set_timeout_ms(int(os.environ.get("NPP_P2P_SELFTEST_TIMEOUT_MS", "5000"))))
+    try:
+        for k, light in enumerate(order):
+            if k > 0:
+                if agree(1 if int(lib.npp_p2p_reset_errors()) == 0 else 0) != 1:
+                    break
+            lib.npp_p2p_set_mode(light)
+            _selftest_state["broken"] = False
+            passed = agree(1 if _p2p_selftest(lib, rank, world) else 0) == 1
+            if passed:
+                mode = "relaxed" if light else "fenced"
+                break
+            if agree(0 if _selftest_state["broken"] else 1) != 1:      # (a rank that did not issue every exchange: out of step)
+                break
+    finally:
+        lib.npp_p2p_set_timeout_ms(long_ms)
     if mode is None:
         lib.npp_p2p_set_mode(-1)
         lib.npp_p2p_close()

@@ -32,6 +32,52 @@ NPP_DEV unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f, npp_bf16x2));
 }
 
+// ---- LDS-DMA as inline asm ---------------------------------------------------------------------------------------------------------
+// `buffer_load_dwordx4 ... offen lds` (64 lanes x 16 bytes straight into LDS at M0 + 16 * lane, no VGPR destination).  Through the
+// builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc tracks the DMA as a pending LDS write and, in front of the next LDS read
+// whose memory operand it cannot prove disjoint -- every ds_read_b64_tr_b16, some ds_read_b128 -- emits `s_waitcnt vmcnt(0)`: the
+// K-tile that was issued to fly UNDER the MFMAs of the current one is waited for before the first fragment read (round 5,
+// tools/dma_wait_scan.py: conv_wgrad_g4's ring of 2 or 4 was a ring of 1, conv_g8 drained its half-tiles once per K-tile).  As inline
+// asm the DMA is invisible to that bookkeeping (cdna_hip_programming.md 5.7): completion is the kernel's own counted
+// `s_waitcnt vmcnt(N)` + barrier, which every kernel here already has.  M0 is written in the statement that reads it.
+typedef unsigned int npp_rsrc __attribute__((ext_vector_type(4)));
+NPP_DEV npp_rsrc npp_make_rsrc(const void* p, unsigned bytes) {      // raw buffer descriptor: base, stride 0, `bytes` records, DATA_FORMAT 32
+  const unsigned long long a = (unsigned long long)p;
+  npp_rsrc r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+NPP_DEV unsigned npp_lds_addr(const void* shared_ptr) {      // the LDS byte address of a pointer into __shared__ memory
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)shared_ptr;
+}
+// voff: per-lane byte offset into the buffer (out of range: the DMA writes zeros); lds: WAVE-UNIFORM LDS byte address of lane 0's 16 bytes
+#ifndef NPP_DMA_BUILTIN      // (A/B switch, tools/r5_dma_ab.sh: 1 = the compiler's builtin again)
+#define NPP_DMA_BUILTIN 0
+#endif
+NPP_DEV void npp_lds_dma16(npp_rsrc rs, unsigned voff, unsigned lds) {
+  lds = __builtin_amdgcn_readfirstlane(lds);      // (folds away when hipcc already holds it in an SGPR)
+#if NPP_DMA_BUILTIN
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)rs.y << 32) | rs.x), 0, rs.z, rs.w),
+                                           (__attribute__((address_space(3))) void*)(size_t)lds, 16, voff, 0, 0, 0);
+#else
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(voff), "s"(rs) : "memory");
+#endif
+}
+// the same with a wave-uniform byte offset `soff` added to every lane's buffer offset
+NPP_DEV void npp_lds_dma16s(npp_rsrc rs, unsigned voff, unsigned soff, unsigned lds) {
+  lds = __builtin_amdgcn_readfirstlane(lds);
+  soff = __builtin_amdgcn_readfirstlane(soff);
+#if NPP_DMA_BUILTIN
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)rs.y << 32) | rs.x), 0, rs.z, rs.w),
+                                           (__attribute__((address_space(3))) void*)(size_t)lds, 16, voff, soff, 0, 0);
+#else
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
+#endif
+}
+
 template <typename T> struct Elt;
 template <> struct Elt<float> {
   static constexpr int VEC = 4;  // elements per 16 bytes

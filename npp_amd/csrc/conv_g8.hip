@@ -70,8 +70,11 @@ struct G8Extra {
   int stagger;              // start delay of workgroup b: (b & 3) * stagger ticks of the 100 MHz clock (0: none)
 };
 
-#define G8_DMA(rsrc, voff, soff, ldsoff)                                                                  \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (ldsoff)), 16, voff, soff, 0, 0)
+// (inline asm, common.h: through the builtin hipcc drained every half-tile in flight in front of phase 1's fragment reads, once per K-tile)
+#ifndef G8_EPI_WAIT
+#define G8_EPI_WAIT 1
+#endif
+#define G8_DMA(rsrc, voff, soff, ldsoff) npp_lds_dma16s(rsrc, voff, (unsigned)(soff), smem_lds + (unsigned)(ldsoff))
 
 NPP_DEV u32x4 relu_bf16x8(u32x4 v) {
   s16x8 s = __builtin_bit_cast(s16x8, v);
@@ -106,8 +109,9 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int grp = wave >> 2;
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
-  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, e.wbytes, 0x00020000);
+  const npp_rsrc rs_x = npp_make_rsrc(p.x, e.xbytes);
+  const unsigned smem_lds = npp_lds_addr(smem);
+  const npp_rsrc rs_w = npp_make_rsrc(p.w, e.wbytes);
 
   // ---- fragment read offsets (bytes inside a half-tile) ----------------------------------------------------
   const int lrow = lane & 15, lk = lane >> 4;
@@ -625,6 +629,11 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
     if (tile_end) {
       if (!(DBG & 1)) {
         epilogue(); drain = p.accum ? 0 : e.drain;
+        // The epilogue's last vector-memory operations are still in hipcc's scoreboard when the K loop is re-entered, and because the
+        // epilogue sits INSIDE that loop the compiler protects the loop header against them: an `s_waitcnt vmcnt(0)` in front of the
+        // third fragment read of EVERY K-tile, which also drained every half-tile in flight (round 5, tools/dma_wait_scan.py; only a
+        // wait the compiler can see, and only vmcnt(0), removes it).  Drain once per output tile instead of once per K-tile.
+        if (G8_EPI_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
         // (zeroed HERE, behind the join of the epilogue variants: zeroed inside them the 128 accumulators become 128 phis of 7 values)
 #pragma unroll
         for (int a = 0; a < 2; ++a)

@@ -640,7 +640,9 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
   };
   {
     ProfScope prof2(NPP_FAM_CONV_G4, x->dtype, s, flops, bytes);
-    if (conv_thin_launch(p, x->dtype, s)) return npp_check_launch(census("conv_thin"));  // (same family: stride-1 fwd + dgrad)
+    // (conv_thin and conv_g8 have no BatchNorm-backward sums epilogue: a sums request never reaches them, it ends in
+    // NPP_E_UNSUPPORTED below and the caller launches the plain data gradient + the stand-alone reduce)
+    if (p.sum_n == 0 && conv_thin_launch(p, x->dtype, s)) return npp_check_launch(census("conv_thin"));  // (same family: stride-1 fwd + dgrad)
     if (conv_c32_launch(p, x->dtype, s)) return npp_check_launch(census("conv_c32"));
     if (conv_h3_launch(p, x->dtype, s)) return npp_check_launch(census("conv_h3"));
     if (conv_g4_launch(p, x->dtype, s)) return npp_check_launch(census("conv_g4"));
@@ -648,7 +650,7 @@ static int conv_fwd_impl(const NppTensor* x, const void* w_packed, const float* 
   }
   {
     ProfScope prof0(NPP_FAM_CONV_G8, x->dtype, s, flops, bytes);
-    if (conv_g8_launch(p, x->dtype, s)) return npp_check_launch(census("conv_g8"));
+    if (p.sum_n == 0 && conv_g8_launch(p, x->dtype, s)) return npp_check_launch(census("conv_g8"));
     prof0.cancel();
   }
   if (p.sum_n > 0) {      // only conv_g4 / conv_h3 / conv_c32 have the summing epilogue: the caller launches the plain data gradient

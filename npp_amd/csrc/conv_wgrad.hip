@@ -325,6 +325,10 @@ extern "C" int npp_conv_wgrad_batchable(const NppTensor* x, const NppTensor* dy,
   alignas(16) unsigned char job[512];
   if (conv_wgrad_g4_job_bytes() > sizeof(job)) return 0;
   int variant = 0, nblocks = 0;
+  // (slab_stride 0: the accumulate form; -1: "with the slabs npp_conv_wgrad_batched_slabs asks for" -- the halo kernel takes input
+  // channel counts, e.g. 192, that the accumulating 128 x 128 kernel refuses)
+  if (conv_wgrad_g4_batch_prepare(p, x->dtype, job, 0, WGB_MAX_BLOCKS, &variant, &nblocks)) return 1;
+  p.slab_stride = -1;
   return conv_wgrad_g4_batch_prepare(p, x->dtype, job, 0, WGB_MAX_BLOCKS, &variant, &nblocks) ? 1 : 0;
 }
 
@@ -338,8 +342,25 @@ extern "C" int npp_conv_wgrad_batched_splits(const NppTensor* x, const NppTensor
   alignas(16) unsigned char job[512];
   if (conv_wgrad_g4_job_bytes() > sizeof(job)) return 0;
   int variant = 0, nblocks = 0, splits = 0;
+  p.slab_stride = -1;      // a query: "if the caller brings slabs"
   if (!conv_wgrad_g4_batch_prepare(p, x->dtype, job, 0, WGB_MAX_BLOCKS, &variant, &nblocks, &splits)) return 0;
-  return variant >= 4 ? 0 : splits;      // (the opt-in three-tap kernel keeps its atomics)
+  return variant >= 6 ? 0 : splits;      // (the narrow kernels keep their atomics)
+}
+
+// slabs the batched launch WANTS for this problem by default: the nine-tap halo kernel (conv_wgrad_g4.hip: wg9_body) stores one slab per
+// pixel split and nothing else; 0 = the problem runs on a kernel that accumulates (no slabs unless the caller asks for the
+// deterministic form, npp_conv_wgrad_batched_splits).
+extern "C" int npp_conv_wgrad_batched_slabs(const NppTensor* x, const NppTensor* dy, const NppConvGeom* g) {
+  if (!x || !dy || !g || !x->ptr || !dy->ptr) return 0;
+  WgradParams p;
+  float dummy;
+  if (wgrad_setup(x, dy, &dummy, g, p) != NPP_OK) return 0;
+  alignas(16) unsigned char job[512];
+  if (conv_wgrad_g4_job_bytes() > sizeof(job)) return 0;
+  int variant = 0, nblocks = 0, splits = 0;
+  p.slab_stride = -1;
+  if (!conv_wgrad_g4_batch_prepare(p, x->dtype, job, 0, WGB_MAX_BLOCKS, &variant, &nblocks, &splits)) return 0;
+  return (variant == 4 || variant == 5) ? splits : 0;
 }
 
 extern "C" int64_t npp_conv_wgrad_batched_ws(int n) {
@@ -366,7 +387,7 @@ extern "C" int npp_conv_wgrad_batched(const NppWgradItem* items, int n, void* ho
       npp_set_error("npp_conv_wgrad_batched: item %d is not a shape of the batched kernel (ask npp_conv_wgrad_batchable first)", i);
       return NPP_E_UNSUPPORTED;
     }
-    if (it.nslabs > 0 && (it.nslabs != splits || variant[i] >= 4)) {
+    if (it.nslabs > 0 && (it.nslabs != splits || variant[i] >= 6)) {
       npp_set_error("npp_conv_wgrad_batched: item %d brings %d slabs, the kernel splits its pixels %d ways (npp_conv_wgrad_batched_splits)",
                     i, (int)it.nslabs, splits);
       return NPP_E_SHAPE;

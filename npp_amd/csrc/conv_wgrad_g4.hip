@@ -25,9 +25,6 @@
 #ifndef WG4_DBG
 #define WG4_DBG 0
 #endif
-#ifndef WG3_DEFAULT
-#define WG3_DEFAULT 0
-#endif
 
 namespace {
 
@@ -43,8 +40,8 @@ struct WG4Extra {
   unsigned xbytes, dybytes;
 };
 
-#define WG4_DMA(rsrc, voff, ldsoff)                                                                       \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (ldsoff)), 16, voff, 0, 0, 0)
+// (inline asm, common.h: the builtin made hipcc wait for the NEXT K-tile's DMA in front of the first transposed read of this one)
+#define WG4_DMA(rsrc, voff, ldsoff) npp_lds_dma16(rsrc, voff, smem_lds + (unsigned)(ldsoff))
 
 // R: ring depth.  2 (64 KiB: two blocks per CU) when the launch has more blocks than CUs, 4 (three K-tiles in flight, one block per
 // CU) when it has not.  Measured: no difference on any shape of the network (the K-tile time is set by the 8 DMA issues per wave,
@@ -56,8 +53,9 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
-  const auto rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, e.dybytes, 0x00020000);
+  const npp_rsrc rs_x = npp_make_rsrc(p.x, e.xbytes);
+  const unsigned smem_lds = npp_lds_addr(smem);
+  const npp_rsrc rs_dy = npp_make_rsrc(p.dy, e.dybytes);
 
   // The tiles of one pixel split read the same dy rows (and, for a KxK conv, the same x rows shifted by a tap): they must
   // share an L2.  Workgroups go to the 8 XCDs round-robin by linear id, so block b -> XCD b & 7 takes the (b >> 3)-th item of
@@ -263,242 +261,189 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_kernel(WgradParams p, WG4Ex
 }
 
 
-// ---- 3x3 layers with Cin, Cout % 128 == 0: THREE horizontal taps per workgroup (round 3) ----------------------------------------
-// The 128 x 128 kernel above stages 32 KiB per K-tile for 32 MFMAs per wave and is bound by the L2 -> LDS DMA rate (~65 GB/s per CU:
-// 4.2 TFLOP/s per CU at best, measured 0.27-0.31 MFMA-pipe utilisation).  Here a workgroup owns 128 output channels x 128 input
-// channels of ALL THREE taps of one kernel row kh: the dy tile [64 px][128 co] is shared by the three taps and so is the x tile --
-// the taps kw = 0, 1, 2 read the SAME pixel-major LDS image one row apart ([66 px][128 ci]: pixel q0 - 1 .. q0 + 64 of the
-// flattened pixel axis, shifted by (kh - 1) image rows; out-of-image rows are out-of-range DMA offsets = zeros).  34 KiB per K-tile
-// for 96 MFMAs per wave: 3x the arithmetic per staged byte.  A row of the flattened axis that wraps around an image row (output
-// pixel x == 0 for the left tap, x == W - 1 for the right tap) is removed by AND-masks on the transposed B fragments, computed per
-// lane from the K-tile's first x coordinate (4 consecutive pixels of a fragment half hold at most one border pixel, W >= 4).
-// Accumulators 3 x 64 x 64 per wave (192 registers): one workgroup per CU, ring of 3 K-tile buffers.
-struct WG3Extra {
+// ---- 3x3 layers on maps of whole 8 x 16 pixel tiles: ALL NINE taps from one LDS-resident halo (round 5) -----------------------------
+// The 128 x 128 kernel above stages 32 KiB per K-tile for 32 MFMAs per wave, and what bounds every tile kernel on this chip is the
+// L2 -> LDS rate of a CU (~30 B/clk): at 31 bytes per 1000 MACs its MFMA pipe cannot be busier than ~0.25 (measured 0.26-0.31).  Here
+// a workgroup owns 128 output channels x 64 input channels of ALL NINE taps (295 KB of f32 accumulators: 8 waves x 144 registers,
+// two waves per SIMD) and walks over 8 x 16-pixel tiles of the map: per tile it stages the dy tile [128 px][128 co] and ONCE the
+// 10 x 18-pixel halo of x [180 px][64 ci] -- 55 KiB for 9 x 128 x 64 x 128 MACs = 5.8 bytes per 1000 MACs -- and every tap reads the
+// halo through an offset of (kh, kw) pixels: the transposing read takes a per-lane address for each of its four pixel rows, so a
+// shifted window costs nothing, and the pixels past the image border are out-of-range DMA offsets (zeros) like everywhere else.
+//   * pixel-major LDS images, read back transposed (ds_read_b64_tr_b16).  dy: 256-byte rows, chunks swizzled as in wg4_body.  x: 128-byte
+//     rows, i.e. TWO pixels per 256-byte bank row; the 16-byte chunk index is XORed with 2 * (bit 1 | bit 3 << 1) of the pixel's HALO
+//     COLUMN: the eight pixels a half-wave reads -- columns c .. c+3 and c+8 .. c+11 of one halo row -- land on sixteen different
+//     16-byte positions whatever (kh, kw) shifts the window (pixels of different parity sit in different halves of the bank row, the
+//     four of one parity differ in bit 1 or bit 3 of the column), and the swizzle does not depend on the halo row: ONE address
+//     register per (kw, half), the row of (ks, kh) is an immediate offset.
+//   * the MFMA computes dW^T (A = x fragment, B = dy fragment): a lane ends with 4 consecutive input channels of one output channel,
+//     16-byte stores.  The partial tile goes to the SLAB of its pixel split with plain stores (one CU adds floats atomically at
+//     ~5 GB/s: 295 KB would be a 58 us tail per workgroup; stores run at 4x that) and the batched unpack sums the slabs --
+//     deterministic, and with ~64 tiles per split the slabs are a few hundred MB per step where the 128 x 128 kernel's
+//     two-per-CU blocks would have made GBs.
+//   * one barrier per tile (144 MFMAs per wave), the next tile's 55 pieces (7 per wave) in flight under them; two stage buffers.
+struct WG3Extra {        // the halo kernel's, the thin kernel's and the narrow kernel's view of a problem
   int HW;
-  int cintiles;          // Cin / 128
-  int ktiles_per_split, nktiles;
-  int ntiles, nblocks;   // output tiles = rowtiles * 3 * cintiles; blocks = ntiles * pixel splits
+  int cintiles;          // halo kernel: Cin / 64; thin: Cin / 128; narrow: image rows per K-tile
+  int ktiles_per_split, nktiles;      // (halo kernel: 8 x 16-pixel tiles per split / in all)
+  int ntiles, nblocks;   // output tiles; blocks = ntiles * pixel splits
   unsigned xbytes, dybytes;
 };
 
-// NW = 4: 2 x 2 waves of 64 x 64 (192 accumulator registers, one wave per SIMD).  NW = 8 (round 4): 2 x 4 waves of 64 x 32 -- 96
-// accumulator registers, TWO waves per SIMD: one wave's transposed reads and DMA issue run under the other's MFMAs, which is what the
-// 4-wave form could not do (2.9 us per K-tile against 0.64 us of MFMA time).
-template <bool RELU, int R, int NW>
-NPP_DEV void wg3_body(const WgradParams& p, const WG3Extra& e, const int bid) {
-  constexpr int XOFF = 16384;            // x image behind the dy tile
-  constexpr int KT = 16384 + 18 * 1024;  // dy [64 px][256 B] + x [72 rows][256 B] (rows 0 .. 65 used)
+template <bool RELU>
+NPP_DEV void wg9_body(const WgradParams& p, const WG3Extra& e, const int bid) {
+  constexpr int DYB = 32768;             // dy tile [8 x 16 px][128 co]
+  constexpr int XB = 23 * 1024;          // x halo  [10 x 18 px (+ 4 unused)][64 ci]
+  constexpr int ST = DYB + XB;           // bytes per stage
+  constexpr int HROW = 18 * 128;         // bytes per halo row
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  constexpr int WN = NW / 2;                // waves along the input-channel axis; a wave owns 64 co x (128 / WN) ci
-  constexpr int NF = 8 / WN;                // 16-column fragments per wave: 4 / 2
-  constexpr int DPW = 16 / NW;              // dy / x pieces per wave per K-tile (x: + piece 16 / 17 on waves 0 / 1)
-  const int wm = wave / WN, wn = wave % WN;
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
-  const auto rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, e.dybytes, 0x00020000);
+  const int wm = wave >> 2, wn = wave & 3;      // wave tile: output channels wm*64 .. +63, input channels wn*16 .. +15, nine taps
+  const npp_rsrc rs_x = npp_make_rsrc(p.x, e.xbytes);
+  const unsigned smem_lds = npp_lds_addr(smem);
+  const npp_rsrc rs_dy = npp_make_rsrc(p.dy, e.dybytes);
 
+  // (XCD-contiguous, split-major order: the channel tiles of one pixel split read the same dy tiles and halos and share an L2)
   const int xcd = bid & 7, qd = e.nblocks >> 3, rm = e.nblocks & 7;
   const int work = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
   const int split = work / e.ntiles, tile = work - split * e.ntiles;
-  const int cotile = tile % p.rowtiles, coltile = tile / p.rowtiles;      // coltile = kh * cintiles + citile
-  const int kh = coltile / e.cintiles, citile = coltile - kh * e.cintiles;
-  const int co0 = cotile * 128, ci0 = citile * 128;
-  const int dyr = kh - 1;                                                 // input row = output row + dyr
-  const int kt_begin = split * e.ktiles_per_split;
-  int kt_end = kt_begin + e.ktiles_per_split;
-  if (kt_end > e.nktiles) kt_end = e.nktiles;
-  if (kt_begin >= kt_end) return;
+  const int cotile = tile % p.rowtiles, citile = tile / p.rowtiles;
+  const int co0 = cotile * 128, ci0 = citile * 64;
+  const int st_begin = split * e.ktiles_per_split;
+  int st_end = st_begin + e.ktiles_per_split;
+  if (st_end > e.nktiles) st_end = e.nktiles;
+  if (st_begin >= st_end) return;
+  const int txn = p.W >> 4, tyn = p.H >> 3;
+  int tn, ty, tx;                        // the next tile to stage: image, tile row, tile column
+  {
+    const int per = tyn * txn;
+    tn = st_begin / per;
+    const int r = st_begin - tn * per;
+    ty = r / txn; tx = r - ty * txn;
+  }
 
-  // ---- staging: dy pieces 4w .. 4w+3 (4 rows x 256 B each); x pieces w, w+4, w+8, w+12 (+ piece 16 and 17 on waves 0 and 1) ----
-  const int srow = lane >> 4, slot = lane & 15;
-  // (arrays of the 4-wave extents whatever NW: with a DEPENDENT array type the subscripted operand makes the LDS-DMA builtin call
-  // type-dependent, and hipcc 7.2's host pass then rejects the whole template -- "substitution failure")
-  unsigned dyb[4];
-  int dpix[4];
+  // ---- staging: wave w fills dy pieces 4w .. 4w+3 (= tile row w: 4 pixels x 256 B each) and x pieces w, w+8, w+16 (8 halo pixels
+  // x 128 B each; piece 23 does not exist) ------------------------------------------------------------------------------------------
+  int ddy[4];                            // bytes from the tile's first pixel
+  {
+    const int srow = lane >> 4, slot = lane & 15;
 #pragma unroll
-  for (int j = 0; j < DPW; ++j) {
-    const int row = (wave * DPW + j) * 4 + srow;
-    const int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
-    const int q = kt_begin * 64 + row;
-    dpix[j] = q;
-    dyb[j] = (unsigned)q * (unsigned)p.ldy * 2u + (unsigned)(co0 * 2 + chunk * 16);
-  }
-  unsigned xb[5];
-  int xpix[5], xyx[5];         // xpix: flattened OUTPUT-aligned pixel of the row (q0 - 1 + r); xyx: (y << 16) | x of that pixel
-#pragma unroll
-  for (int j = 0; j < DPW + 1; ++j) {
-    const int piece = j < DPW ? wave + NW * j : 16 + wave;      // (piece 16 / 17: waves 0 / 1 only)
-    const int row = piece * 4 + srow;
-    const int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
-    const int q = kt_begin * 64 - 1 + row;
-    xpix[j] = q;
-    const int qq = q < 0 ? q + e.HW : q;                     // (pixel -1: its coordinates are never used, it is zero-filled)
-    const int rem = qq % e.HW, y = rem / p.W;
-    xyx[j] = (y << 16) | (rem - y * p.W);
-    xb[j] = (unsigned)(q + dyr * p.W) * (unsigned)p.ldx * 2u + (unsigned)((ci0 + chunk * 8) * 2);
-  }
-  const unsigned dy_step = 64u * (unsigned)p.ldy * 2u, x_step = 64u * (unsigned)p.ldx * 2u;
-  const int adv_y = 64 / p.W, adv_x = 64 - adv_y * p.W;
-  const bool extra = wave < 2;
-  auto issue = [&](int slot_) {
-    const int lb = slot_ * KT;
-#pragma unroll
-    for (int j = 0; j < DPW; ++j) {
-      const bool live = dpix[j] < p.P;
-      WG4_DMA(rs_dy, live ? dyb[j] : 0xFFFFFFFFu, lb + (wave * DPW + j) * 1024);
-      dpix[j] += 64; dyb[j] += dy_step;
+    for (int j = 0; j < 4; ++j) {
+      const int chunk = slot ^ ((srow << 2) | j);      // pixel wave*16 + 4j + srow: (px & 3) << 2 | (px >> 2) & 3
+      ddy[j] = ((wave * p.W + j * 4 + srow) * (int)p.ldy + co0 + chunk * 8) * 2;
     }
+  }
+  int dxo[3], hrc[3];                    // bytes from the tile's first pixel; (halo row << 16) | halo column (a row >= 1 << 14: never valid)
+  {
+    const int xrow = lane >> 3, xc = lane & 7;
 #pragma unroll
-    for (int j = 0; j < DPW + 1; ++j) {
-      if (j == DPW && !extra) break;
-      const int piece = j < DPW ? wave + NW * j : 16 + wave;
-      const int y = (xyx[j] >> 16) + dyr;
-      const bool ok = xpix[j] >= 0 && xpix[j] < p.P && (unsigned)y < (unsigned)p.H;
-      WG4_DMA(rs_x, ok ? xb[j] : 0xFFFFFFFFu, lb + XOFF + piece * 1024);
-      // advance by one K-tile (64 pixels)
-      xpix[j] += 64;
-      xb[j] += x_step;
-      int yy = (xyx[j] >> 16) + adv_y, xx = (xyx[j] & 0xFFFF) + adv_x;
-      if (xx >= p.W) { xx -= p.W; ++yy; }
-      while (yy >= p.H) yy -= p.H;
-      xyx[j] = (yy << 16) | xx;
+    for (int j = 0; j < 3; ++j) {
+      const int hp = (wave + 8 * j) * 8 + xrow;
+      const int hr = hp / 18, hc = hp - hr * 18;
+      const int s2 = ((hc >> 1) & 1) | (((hc >> 3) & 1) << 1);
+      const int chunk = xc ^ (s2 << 1);
+      dxo[j] = (((hr - 1) * p.W + (hc - 1)) * (int)p.ldx + ci0 + chunk * 8) * 2;
+      hrc[j] = hp < 180 ? (hr << 16) | hc : (1 << 30);
     }
+  }
+  auto issue = [&](int buf) {
+    const int lb = buf * ST;
+    const int y0 = ty * 8, x0 = tx * 16;
+    const unsigned pix = (unsigned)((tn * p.H + y0) * p.W + x0);
+    const unsigned dyb = pix * (unsigned)p.ldy * 2u, xb = pix * (unsigned)p.ldx * 2u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) WG4_DMA(rs_dy, dyb + (unsigned)ddy[j], lb + (wave * 4 + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (j == 2 && wave == 7) break;
+      const int hr = hrc[j] >> 16, hc = hrc[j] & 0xFFFF;
+      const bool ok = (unsigned)(y0 + hr - 1) < (unsigned)p.H && (unsigned)(x0 + hc - 1) < (unsigned)p.W;
+      WG4_DMA(rs_x, ok ? xb + (unsigned)dxo[j] : 0xFFFFFFFFu, lb + DYB + (wave + 8 * j) * 1024);
+    }
+    if (++tx == txn) { tx = 0; if (++ty == tyn) { ty = 0; ++tn; } }
   };
 
-  // ---- transposed fragment reads (see wg4_body); B of tap s reads row s + k of the x image ------------------------------------
+  // ---- transposed fragment reads: K index k = ks*32 + g*8 + h*4 + q4 = pixel (row k >> 4, column k & 15) of the tile -------------------
   const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pq = i16 & 3;
-  unsigned offA[4][2], offB[3][NF][2];
+  unsigned offD[4][2], offX[3][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = g * 8 + h * 4 + q4;                       // + ks*32
     const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) offA[f][h] = 256 * row + 16 * (((wm * 8 + f * 2 + (pq >> 1)) ^ sw)) + 8 * (pq & 1);
+    for (int f = 0; f < 4; ++f) offD[f][h] = 256 * row + 16 * (((wm * 8 + f * 2 + (pq >> 1)) ^ sw)) + 8 * (pq & 1);
 #pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) {
-      const int rb = row + s3;
-      const int swb = ((rb & 3) << 2) | ((rb >> 2) & 3);
-#pragma unroll
-      for (int f = 0; f < NF; ++f) offB[s3][f][h] = XOFF + 256 * rb + 16 * (((wn * NF * 2 + f * 2 + (pq >> 1)) ^ swb)) + 8 * (pq & 1);
+    for (int kw = 0; kw < 3; ++kw) {
+      const int hc = (g & 1) * 8 + h * 4 + q4 + kw;           // halo column; halo row = ks*2 + (g >> 1) + kh
+      const int s2 = ((hc >> 1) & 1) | (((hc >> 3) & 1) << 1);
+      offX[kw][h] = DYB + 128 * ((g >> 1) * 18 + hc) + 16 * ((wn * 2 + (pq >> 1)) ^ (s2 << 1)) + 8 * (pq & 1);
     }
   }
-  // x coordinate (mod W) of the lane's first pixel of each (ks, half): k0 = ks*32 + g*8 + h*4
-  int c0[2][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) c0[ks][h] = (ks * 32 + g * 8 + h * 4) % p.W;
-  int xq0 = (kt_begin * 64) % p.W;               // x coordinate of the K-tile's first pixel
-  const int xadv = 64 % p.W;
 
-  f32x4g acc[3][4][NF];
+  f32x4g acc[9][4];                      // acc[tap][nf][j] = dW[co0 + wm*64 + nf*16 + i16][tap][ci0 + wn*16 + 4*g + j]
 #pragma unroll
-  for (int s3 = 0; s3 < 3; ++s3)
+  for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NF; ++ni) acc[s3][mi][ni] = f32x4g{0.f, 0.f, 0.f, 0.f};
+    for (int nf = 0; nf < 4; ++nf) acc[tp][nf] = f32x4g{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = kt_end - kt_begin;
-  int s_slot = 0, c_slot = 0;
-  for (int i = 0; i < R - 1 && i < nk; ++i) { issue(s_slot); if (++s_slot == R) s_slot = 0; }
-  for (int kt = 0; kt < nk; ++kt) {
-    // every wave has issued the same number of DMA instructions per K-tile except the two "extra" waves (9 vs 8): wait for all but the
-    // K-tiles still allowed in flight
-    if (R > 2 && kt + R - 1 <= nk) {
-      if (extra) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((2 * DPW + 1) * (R > 2 ? R - 2 : 0)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DPW * (R > 2 ? R - 2 : 0)) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
+  int cur = 0;
+  issue(0);
+  for (int s = st_begin; s < st_end; ++s) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + R - 1 < nk) { issue(s_slot); if (++s_slot == R) s_slot = 0; }
-    const unsigned ro = (unsigned)c_slot * KT;
-    if (++c_slot == R) c_slot = 0;
+    __builtin_amdgcn_s_barrier();        // this tile has landed for every wave; nobody reads the other buffer any more
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < st_end) issue(cur ^ 1);
+    const unsigned ro = (unsigned)cur * ST;
+    cur ^= 1;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      // border masks of this lane's 2 x 4 pixels: 64-bit AND-masks over the 4 bf16 of a fragment half
-      unsigned long long mL[2], mR[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        int x0 = xq0 + c0[ks][h];
-        if (x0 >= p.W) x0 -= p.W;
-        const int zl = x0 == 0 ? 0 : p.W - x0;             // element whose x == 0 (>= 4: none)
-        const int zr = p.W - 1 - x0;                       // element whose x == W - 1
-        mL[h] = zl < 4 ? ~(0xFFFFull << (16 * zl)) : ~0ull;
-        mR[h] = zr < 4 ? ~(0xFFFFull << (16 * zr)) : ~0ull;
-      }
-      s16x8 fa[4];
+    for (int ks = 0; ks < 4; ++ks) {
+      s16x8 fd[4];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offA[f][0] + ks * 8192));
-        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offA[f][1] + ks * 8192));
-        fa[f] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offD[f][0] + ks * 8192));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offD[f][1] + ks * 8192));
+        fd[f] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3) {
-        s16x8 fb[NF];
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offB[s3][f][0] + ks * 8192));
-          s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offB[s3][f][1] + ks * 8192));
-          if (s3 == 0) {
-            b0 = __builtin_bit_cast(s16x4, __builtin_bit_cast(unsigned long long, b0) & mL[0]);
-            b1 = __builtin_bit_cast(s16x4, __builtin_bit_cast(unsigned long long, b1) & mL[1]);
-          } else if (s3 == 2) {
-            b0 = __builtin_bit_cast(s16x4, __builtin_bit_cast(unsigned long long, b0) & mR[0]);
-            b1 = __builtin_bit_cast(s16x4, __builtin_bit_cast(unsigned long long, b1) & mR[1]);
-          }
-          s16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-          if (RELU) {
-            const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            b = __builtin_elementwise_max(b, z);
-          }
-          fb[f] = b;
+      for (int tp = 0; tp < 9; ++tp) {
+        const int kh = tp / 3, kw = tp - kh * 3;
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offX[kw][0] + (ks * 2 + kh) * HROW));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offX[kw][1] + (ks * 2 + kh) * HROW));
+        s16x8 fx = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (RELU) {
+          const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+          fx = __builtin_elementwise_max(fx, z);
         }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NF; ++ni)
-            acc[s3][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]),
-                                                                     acc[s3][mi][ni], 0, 0, 0);
+        for (int nf = 0; nf < 4; ++nf)
+          acc[tp][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fx), __builtin_bit_cast(bf16x8, fd[nf]),
+                                                               acc[tp][nf], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);      // (keeps the fragment reads of the next K-step out of this one: without it the form without ReLU spills)
     }
-    xq0 += xadv;
-    if (xq0 >= p.W) xq0 -= p.W;
   }
 
-  // ---- epilogue: tap (kh, s3) -> packed columns (kh*3 + s3) * Cin + ci0 + wn*64 + ... (see wg4_body) ---------------------------
-  const int half = lane >> 5, gg = (lane >> 4) & 1;
+  // ---- epilogue: plain 16-byte stores into this split's slab ----------------------------------------------------------------------
+  float* slab = p.dwp + (long)split * p.slab_stride;
 #pragma unroll
-  for (int s3 = 0; s3 < 3; ++s3) {
-    const int colbase = (kh * 3 + s3) * p.Cin + ci0 + wn * (NF * 16);
+  for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int nb = 0; nb < NF / 2; ++nb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[s3][mi][2 * nb][j]), __float_as_uint(acc[s3][mi][2 * nb + 1][j]),
-                                                           false, false);
-          const int col = colbase + (2 * nb + half) * 16 + i16;
-          const int row0 = co0 + wm * 64 + mi * 16 + gg * 4 + j;
-          if (row0 < p.Cout) atomicAdd(p.dwp + (long)row0 * p.Kpad + col, __uint_as_float(sw[0]));
-          if (row0 + 8 < p.Cout) atomicAdd(p.dwp + (long)(row0 + 8) * p.Kpad + col, __uint_as_float(sw[1]));
-        }
-  }
+    for (int nf = 0; nf < 4; ++nf) {
+      const int co = co0 + wm * 64 + nf * 16 + i16;
+      const int col = tp * p.Cin + ci0 + wn * 16 + g * 4;
+      *reinterpret_cast<f32x4g*>(slab + (long)co * p.Kpad + col) = acc[tp][nf];
+    }
 }
 
-template <bool RELU, int R, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void conv_wgrad_g3_kernel(WgradParams p, WG3Extra e) {
-  wg3_body<RELU, R, NW>(p, e, (int)blockIdx.x);
+template <bool RELU>
+__global__ __launch_bounds__(512) void conv_wgrad_g9_kernel(WgradParams p, WG3Extra e) {
+  wg9_body<RELU>(p, e, (int)blockIdx.x);
 }
 
 
 // ---- 3x3 layers with at most 8 output channels (the edge head, 384 -> 6): dW[co][tap][ci], M = one 16-row fragment -------------------
-// The structure of wg3_body (three horizontal taps share the pixel-major x image, border masks on the transposed fragments) with a
+// Three horizontal taps share the pixel-major x image (border masks on the transposed fragments), with a
 // 16 x (3 taps x 128 ci) tile: wave w owns input channels 32w .. 32w+31 of all three taps (24 accumulator registers).  dy is 16
 // bytes per pixel: it goes through registers into a [64 px][32 B] image whose upper half stays zero (output channels 8 .. 15).
 // 40 KiB of LDS, few registers: several workgroups per CU; the kernel is bound by the x stream (113 MB at N = 16, 96 x 96, read
@@ -511,7 +456,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgradParams p, WG3
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
+  const npp_rsrc rs_x = npp_make_rsrc(p.x, e.xbytes);
+  const unsigned smem_lds = npp_lds_addr(smem);
   const int bid = (int)blockIdx.x;
   const int xcd = bid & 7, qd = e.nblocks >> 3, rm = e.nblocks & 7;
   const int work = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
@@ -820,7 +766,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_narrow_kernel(WgradParams p, W
 struct WG4Job {
   WgradParams p;
   WG4Extra e;
-  WG3Extra e3;           // (the three-tap kernel's view of the same problem: variants 4, 5)
+  WG3Extra e3;           // (the halo / narrow kernels' view of the problem: variants 4 .. 9)
   int first_block, _pad;
 };
 
@@ -833,13 +779,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_batched_kernel(const WG4Job
   wg4_body<RELU, TAPS, R>(p, e, (int)blockIdx.x - jb->first_block);
 }
 
-template <bool RELU, int R, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void conv_wgrad_g3_batched_kernel(const WG4Job* __restrict__ jobs, const int* __restrict__ block_job) {
+template <bool RELU>
+__global__ __launch_bounds__(512) void conv_wgrad_g9_batched_kernel(const WG4Job* __restrict__ jobs, const int* __restrict__ block_job) {
   const int j = __builtin_amdgcn_readfirstlane(block_job[blockIdx.x]);
   const WG4Job* jb = jobs + j;
   const WgradParams p = jb->p;
   const WG3Extra e = jb->e3;
-  wg3_body<RELU, R, NW>(p, e, (int)blockIdx.x - jb->first_block);
+  wg9_body<RELU>(p, e, (int)blockIdx.x - jb->first_block);
 }
 
 template <int C, bool RELU>
@@ -913,43 +859,34 @@ static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradPa
   return true;
 }
 
-// NPP_WG3: 0 the three-tap kernel is off, 1 its 4-wave form, 8 its 8-wave form
-static int wg3_mode() {
-  static const int m = getenv("NPP_WG3") ? atoi(getenv("NPP_WG3")) : WG3_DEFAULT;
-  return m;
+// the nine-tap halo kernel (wg9_body): 3x3 stride 1, Cin % 64 == 0, Cout % 128 == 0, maps of whole 8 x 16-pixel tiles; its pixel splits
+// store SLABS (p.slab_stride > 0, one per split: the caller learns the count from npp_conv_wgrad_batched_splits).  NPP_WG9=0: off.
+// max_blocks: the workgroups this problem may take (one per CU).  NPP_WG9_STAGES: tiles per workgroup aimed at (default 64: ~160 us of
+// MFMA work in front of 295 KB of slab stores, and the slabs of a step stay in the hundreds of MB).
+constexpr size_t WG9_LDS = 2 * (32768 + 23 * 1024);
+static bool wg9_on() {
+  static const bool on = !(getenv("NPP_WG9") && atoi(getenv("NPP_WG9")) == 0);
+  return on;
 }
-// the three-tap kernel: 3x3, Cin and Cout multiples of 128.  max_blocks: the slots this problem may fill (256 = one workgroup per CU)
-static bool wg3_prepare(const WgradParams& p, int dtype, int max_blocks, WgradParams& q, WG3Extra& e, int& nblocks) {
-  // OPT-IN (NPP_WG3=1: 4 waves, NPP_WG3=8: 8 waves).  Round 4, the 8-wave form (two waves per SIMD, 96 accumulator registers each): 128->128
-  // @96^2 114 us, 256->256 @48^2 107, 512->512 @24^2 105, 128->128 @24^2 29 -- better than the 4-wave form (132 / 126 / 126 / 35) and still
-  // behind the 128 x 128 kernel (82 / 87 / 91 / 23): rocprofv3 counts NO LDS bank conflicts and ~2 LDS-active cycles per LDS instruction on
-  // these kernels (tools/wgrad_lds_pmc.sh), so the transposed reads are not the bound either; with one workgroup per CU every K-tile
-  // still pays its barrier + DMA round trip alone, and each of the 255 workgroups ends with 192 KiB of float atomics into the same 590 KB.
-  // Round 3, the 4-wave form, measured on MI355X (tools/wgrad_time.py, N = 16, us, this kernel at 256 workgroups vs the 128 x 128 kernel):
-  // 128->128 @96^2 116 vs 83, 384->128 225 vs 191, 256->256 @48^2 102 vs 85, 512->512 @24^2 100 vs 88, 256->256 @12^2 42 vs 26 --
-  // slower on every shape although it stages a third of the bytes per MFMA: with 394 registers there is ONE wave per SIMD, and a
-  // wave alone cannot overlap its DMA issue, its 64 transposed reads and its 96 MFMAs per K-tile (2.9 us per K-tile against
-  // 0.64 us of MFMA time); the 128 x 128 kernel's two co-resident workgroups do.  Kept for the record and for the exactness test.
-  if (!wg3_mode() || dtype != NPP_BF16) return false;
+static bool wg9_prepare(const WgradParams& p, int dtype, int max_blocks, WgradParams& q, WG3Extra& e, int& nblocks, int& splits_out) {
+  if (!wg9_on() || dtype != NPP_BF16 || p.slab_stride == 0) return false;      // (slab_stride < 0: a query, > 0: the caller brought the slabs)
   if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.KH != 3 || p.KW != 3) return false;
   if (p.ph != 1 || p.pw != 1 || p.OH != p.H || p.OW != p.W) return false;
-  if (p.Cin % 128 != 0 || p.Cout % 128 != 0 || p.Cp != p.Cin || !p.vec_dy || p.ldx % 8 != 0 || p.ldy % 8 != 0) return false;
-  if (p.W < 4 || p.H >= 16384 || p.W >= 16384) return false;
-  if ((long)p.P * p.ldx * 2 >= (1L << 32) - (1L << 24) || (long)p.P * p.ldy * 2 >= (1L << 32) - (1L << 24)) return false;
+  if (p.Cin % 64 != 0 || p.Cout % 128 != 0 || p.Cp != p.Cin || !p.vec_dy || p.ldx % 8 != 0 || p.ldy % 8 != 0) return false;
+  if (p.H % 8 != 0 || p.W % 16 != 0 || p.H >= 16384 || p.W >= 16384) return false;
+  if ((long)p.P * p.ldx * 2 >= (1L << 31) || (long)p.P * p.ldy * 2 >= (1L << 31)) return false;      // (signed per-lane byte offsets)
+  static const int min_pix = getenv("NPP_WG9_MIN_PIX") ? atoi(getenv("NPP_WG9_MIN_PIX")) : 0;
+  if (p.P < min_pix) return false;
   e.HW = p.H * p.W;
-  e.cintiles = p.Cin / 128;
-  e.nktiles = (p.P + 63) / 64;
+  e.cintiles = p.Cin / 64;
+  e.nktiles = p.N * (p.H / 8) * (p.W / 16);
   e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
   e.dybytes = (unsigned)((long)p.P * p.ldy * 2);
   q = p;
   q.rowtiles = p.Cout / 128;
-  const int tiles = q.rowtiles * 3 * e.cintiles;
-  // pixel splits: every workgroup ends with 192 KiB of atomics (3 taps x 64 KiB); as wg4_prepare, balance them against the K loop:
-  // S ~ sqrt(10 * K-tiles / (3 * tiles)), never more workgroups than slots
-  static const int force_blocks = getenv("NPP_WG3_BLOCKS") ? atoi(getenv("NPP_WG3_BLOCKS")) : 0;
-  int splits = 1;
-  while ((long)(splits + 1) * (splits + 1) * tiles * 3 <= 10L * e.nktiles) ++splits;
-  if (force_blocks > 0) splits = (force_blocks + tiles - 1) / tiles;
+  const int tiles = q.rowtiles * e.cintiles;
+  static const int want = getenv("NPP_WG9_STAGES") ? atoi(getenv("NPP_WG9_STAGES")) : 64;
+  int splits = (e.nktiles + want - 1) / (want > 0 ? want : 1);
   if (splits > max_blocks / tiles) splits = max_blocks / tiles;
   if (splits < 1) splits = 1;
   if (splits > e.nktiles) splits = e.nktiles;
@@ -957,10 +894,9 @@ static bool wg3_prepare(const WgradParams& p, int dtype, int max_blocks, WgradPa
   splits = (e.nktiles + e.ktiles_per_split - 1) / e.ktiles_per_split;
   e.ntiles = tiles; e.nblocks = tiles * splits;
   nblocks = tiles * splits;
-  return tiles <= max_blocks;
+  splits_out = splits;
+  return true;
 }
-
-constexpr size_t WG3_LDS = 3 * (16384 + 18 * 1024);
 
 // the narrow kernel: 3x3, Cin == Cout in {32, 64}, image rows that tile a 96- or 128-pixel K-tile
 static size_t wgn_lds(const WgradParams& p, int rpt) {
@@ -1060,21 +996,6 @@ bool conv_wgrad_g4_launch(const WgradParams& p, int dtype, hipStream_t stream) {
       return true;
     }
   }
-  {
-    WG3Extra e3;
-    int nb3 = 0;
-    if (wg3_prepare(p, dtype, 256, q, e3, nb3)) {
-#define WG3_ONE(RELU_, NW_)                                                                                                  \
-  do {                                                                                                                        \
-    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g3_kernel<RELU_, 3, NW_>), WG3_LDS)) return false;              \
-    hipLaunchKernelGGL((conv_wgrad_g3_kernel<RELU_, 3, NW_>), dim3(nb3), dim3(64 * NW_), WG3_LDS, stream, q, e3);               \
-  } while (0)
-      if (wg3_mode() == 8) { if (p.relu_in) WG3_ONE(true, 8); else WG3_ONE(false, 8); }
-      else                 { if (p.relu_in) WG3_ONE(true, 4); else WG3_ONE(false, 4); }
-#undef WG3_ONE
-      return true;
-    }
-  }
   WG4Extra e;
   int nblocks = 0;
   if (!wg4_prepare(p, dtype, 512, q, e, nblocks)) return false;
@@ -1118,13 +1039,16 @@ bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_hos
     *nblocks = nb;
     return true;
   }
-  // (a job of the three-tap kernel may take half the slots of a 128 x 128 job: one workgroup per CU instead of two)
-  if (wg3_prepare(p, dtype, max_blocks / 2 > 0 ? max_blocks / 2 : 1, jb->p, jb->e3, nb)) {
-    memset(&jb->e, 0, sizeof(jb->e));
-    jb->first_block = 0; jb->_pad = 0;
-    *variant = 4 | (p.relu_in ? 1 : 0);
-    *nblocks = nb;
-    return true;
+  {
+    int sp9 = 0;
+    if (wg9_prepare(p, dtype, max_blocks, jb->p, jb->e3, nb, sp9)) {      // (one workgroup per CU; its splits store slabs)
+      memset(&jb->e, 0, sizeof(jb->e));
+      jb->first_block = 0; jb->_pad = 0;
+      *variant = 4 | (p.relu_in ? 1 : 0);
+      *nblocks = nb;
+      if (splits) *splits = sp9;
+      return true;
+    }
   }
   if (!wg4_prepare(p, dtype, max_blocks, jb->p, jb->e, nb, true) || nb > max_blocks) return false;
   jb->first_block = 0; jb->_pad = 0;
@@ -1177,16 +1101,16 @@ bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, in
     hipLaunchKernelGGL((conv_wgrad_g4_batched_kernel<RELU_, TAPS_, 2>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(256), lds, stream, \
                        jd, map_dev + off[V_]);                                                                                     \
   }
-  // the three-tap jobs first: their workgroups are the longest of the step
-#define WG3_BATCH(V_, RELU_, NW_)                                                                                                  \
+  // the halo-kernel jobs first: their workgroups are the longest of the step
+#define WG9_BATCH(V_, RELU_)                                                                                                       \
   if (off[V_ + 1] > off[V_]) {                                                                                                     \
-    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g3_batched_kernel<RELU_, 3, NW_>), WG3_LDS)) return false;          \
-    hipLaunchKernelGGL((conv_wgrad_g3_batched_kernel<RELU_, 3, NW_>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(64 * NW_), WG3_LDS, stream, \
+    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g9_batched_kernel<RELU_>), WG9_LDS)) return false;                  \
+    hipLaunchKernelGGL((conv_wgrad_g9_batched_kernel<RELU_>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(512), WG9_LDS, stream,  \
                        jd, map_dev + off[V_]);                                                                                     \
   }
-  if (wg3_mode() == 8) { WG3_BATCH(4, false, 8) WG3_BATCH(5, true, 8) }
-  else                 { WG3_BATCH(4, false, 4) WG3_BATCH(5, true, 4) }
-#undef WG3_BATCH
+  WG9_BATCH(4, false)
+  WG9_BATCH(5, true)
+#undef WG9_BATCH
 #define WGN_BATCH(V_, C_, RELU_)                                                                                                    \
   if (off[V_ + 1] > off[V_]) {                                                                                                     \
     if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_narrow_batched_kernel<C_, RELU_>), 65536)) return false;            \

@@ -34,8 +34,7 @@ struct WH3Extra {
   unsigned xbytes, dybytes;
 };
 
-#define WH3_DMA(rsrc, voff, ldsoff)                                                                       \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (ldsoff)), 16, voff, 0, 0, 0)
+#define WH3_DMA(rsrc, voff, ldsoff) npp_lds_dma16(rsrc, voff, smem_lds + (unsigned)(ldsoff))      // (inline asm: see common.h)
 
 constexpr int WH3_DYB = 4096;             // dy tile: 32 pixels x 128 B (64 output channels)
 constexpr int WH3_XB = 9216;              // x tile: 36 pixel rows (34 used) x 256 B (128 input channels)
@@ -47,8 +46,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(WgradParams p, WH3Ex
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;      // wave tile: 32 output channels x (3 taps x 64 input channels)
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, e.xbytes, 0x00020000);
-  const auto rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, e.dybytes, 0x00020000);
+  const npp_rsrc rs_x = npp_make_rsrc(p.x, e.xbytes);
+  const unsigned smem_lds = npp_lds_addr(smem);
+  const npp_rsrc rs_dy = npp_make_rsrc(p.dy, e.dybytes);
 
   // work list (split-major, tile-minor) in XCD-contiguous order: the tiles of one split read the same dy / x rows
   const int bid = blockIdx.x, nblocks = e.ntiles * e.splits;

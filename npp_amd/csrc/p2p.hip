@@ -374,6 +374,25 @@ extern "C" int npp_p2p_status(void) {
   return (int)bad;
 }
 
+// The poll timeout (ms) of every later exchange; returns the previous value.  The host's acceptance test runs with a few seconds
+// and restores the long watchdog value afterwards (npp_amd/comm.py).
+extern "C" int64_t npp_p2p_set_timeout_ms(int64_t ms) {
+  const long long old = g.timeout_ticks / 100000LL;
+  if (ms > 0) g.timeout_ticks = (long long)ms * 100000LL;
+  return (int64_t)old;
+}
+
+// Clear the channels' error words (after the host has agreed, collectively, to try the other unit mode: the exchange counters of a
+// dead channel keep moving, so the ranks stay in step and a cleared channel is usable again).  Synchronises the device first.
+extern "C" int npp_p2p_reset_errors(void) {
+  if (!g.local) return NPP_OK;
+  if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return NPP_E_HIP; }
+  for (int c = 0; c < g.nchan; ++c)
+    if (hipMemset(g.ch[c].err, 0, sizeof(unsigned int)) != hipSuccess) { (void)hipGetLastError(); return NPP_E_HIP; }
+  if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return NPP_E_HIP; }
+  return NPP_OK;
+}
+
 extern "C" int npp_p2p_close(void) {
   if (!g.local) return NPP_OK;
   (void)hipDeviceSynchronize();

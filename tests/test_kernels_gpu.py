@@ -210,6 +210,11 @@ def test_benched_shapes_match_cpu_reference(case, batched_wgrad):
     (384, 6, 3, 96, 96, 1, True),        # thin-output kernel (edge head): one image row = 1.5 K-tiles
     (384, 6, 3, 13, 17, 3, True),        # thin-output kernel, odd extents
     (128, 8, 3, 6, 40, 5, False),        # thin-output kernel, 8 output channels, several images per K-tile
+    (128, 128, 3, 8, 16, 3, True),       # nine-tap halo kernel (batched): ONE 8 x 16 tile per image, every halo side outside the image
+    (64, 128, 3, 16, 32, 2, True),       # halo kernel: 64 input channels (one channel tile), 2 x 2 tiles per image
+    (192, 128, 3, 24, 48, 2, False),     # halo kernel: three input-channel tiles, 3 x 3 tiles per image, no ReLU
+    (256, 256, 3, 16, 16, 4, True),      # halo kernel: two output- x four input-channel tiles
+    (128, 128, 3, 96, 96, 3, True),      # halo kernel: several pixel splits (216 tiles), the benched layer
 ])
 def test_weight_gradient_is_exact_on_integer_data(cin, cout, k, H, W, N, relu, batched):
     """Small-integer activations and gradients: every product and every partial sum is exact in f32 whatever the summation
