@@ -396,10 +396,20 @@ bool conv_h3_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
     return true;                                                                                              \
   } while (0)
   if (p.Cout % 128 == 0) {
-    switch (cfg) {
+    // Tile height.  Round 5, same box, us (tools/g8_time.py, N = 16, ReLU + statistics), TH = 8 / 6: 256->256 @48^2 59.1-60.0 / 53.1-53.6,
+    // 128->128 @48^2 21.9 / 19.3, 128->128 @96^2 57.4 / 58.4-59.3, 384->128 @96^2 131-135 / 137, 512->512 @48^2 176 / 175: grids of
+    // under two rounds of the 512 slots fill the chip better with 96-pixel tiles, full grids prefer the 128-pixel tile's fewer
+    // weight bytes per MAC.  NPP_H3_CFG forces a configuration.
+    int c128 = cfg;
+    if (cfg == 0 && p.H % 6 == 0 && (long)p.N * ((p.H + 7) / 8) * (p.W / 16) * (p.Cout / 128) < 1024) c128 = 6;
+    if (c128 == 6 && p.H % 6 != 0) c128 = 0;
+    if (c128 == 5 && p.H % 4 != 0) c128 = 0;
+    switch (c128) {
       case 1: H3_CFG(16, 128, 4, 2, 3);     // 256 pixels, 8 waves, one block per CU
       case 3: H3_CFG(12, 128, 4, 2, 3);     // 192 pixels
       case 4: H3_CFG(8, 128, 4, 2, 3);      // 128 pixels, 8 waves
+      case 6: H3_CFG(6, 128, 2, 2, 2);      // 96 pixels, 4 waves, two blocks per CU
+      case 5: H3_CFG(4, 128, 2, 2, 2);      // 64 pixels
       default: H3_CFG(8, 128, 2, 2, 2);     // 128 pixels, 4 waves, two blocks per CU
     }
   }

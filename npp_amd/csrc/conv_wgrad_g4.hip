@@ -46,9 +46,13 @@ struct WG4Extra {
 // R: ring depth.  2 (64 KiB: two blocks per CU) when the launch has more blocks than CUs, 4 (three K-tiles in flight, one block per
 // CU) when it has not.  Measured: no difference on any shape of the network (the K-tile time is set by the 8 DMA issues per wave,
 // not by their latency); kept because it costs nothing.
-template <bool RELU, bool TAPS, int R>
+// KP: pixels per K-tile.  64 (two MFMA K-steps per barrier), or 32 with a ring of 3 (48 KiB: three workgroups per CU, up to 96 KiB of
+// DMA in flight per CU) for the HBM-bound 1x1 jobs of the batched launch (NPP_WGB_K32).
+template <bool RELU, bool TAPS, int R, int KP = 64>
 NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
-  constexpr int KT = 32768;            // bytes per K-tile buffer: dy [64 px][256 B] then x [64 px][256 B]
+  constexpr int NP = KP / 16;          // 1-KiB pieces (4 pixels x 256 B) per wave and operand
+  constexpr int XO = KP * 256;         // x image behind the dy image
+  constexpr int KT = 2 * XO;           // bytes per K-tile buffer: dy [KP px][256 B] then x [KP px][256 B]
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -87,20 +91,20 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
   // two co-resident workgroups only half cover.
   const int srow = lane >> 4, slot = lane & 15;
   unsigned dyb0, xb0;          // byte offset of (pixel q0 of the first K-tile, chunk of row 0) in dy / x; advanced by 64 pixels per K-tile
-  int ddy[4], dxx[4];          // row j: + these bytes (4j pixels further, its own chunk)
+  int ddy[NP], dxx[NP];        // row j: + these bytes (4j pixels further, its own chunk)
   int y0v = 0, x0v = 0;        // (y, x) of output pixel q0 (TAPS)
   int pix0;
   int tap_dy = 0, tap_dx = 0;
   bool col_ok;
   unsigned co_mask = 0;        // bit j: row j's output channels exist
   {
-    const int row0 = (wave * 4) * 4 + srow;
-    const int q0 = kt_begin * 64 + row0;
+    const int row0 = (wave * NP) * 4 + srow;
+    const int q0 = kt_begin * KP + row0;
     pix0 = q0;
     int chunk0 = 0, ci0b = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = (wave * 4 + j) * 4 + srow;
+    for (int j = 0; j < NP; ++j) {
+      const int row = (wave * NP + j) * 4 + srow;
       const int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
       const int col = coltile * 128 + chunk * 8;
       const int tap = col / p.Cin, ci = col - tap * p.Cin;
@@ -122,19 +126,19 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
       x0v = rem - y0v * p.W;
     }
   }
-  const unsigned dy_step = 64u * (unsigned)p.ldy * 2u, x_step = 64u * (unsigned)p.ldx * 2u;
-  const int adv_y = 64 / p.W, adv_x = 64 - adv_y * p.W;
-  const bool all_co = co_mask == 15u;
+  const unsigned dy_step = (unsigned)KP * (unsigned)p.ldy * 2u, x_step = (unsigned)KP * (unsigned)p.ldx * 2u;
+  const int adv_y = KP / p.W, adv_x = KP - adv_y * p.W;
+  const bool all_co = co_mask == (1u << NP) - 1u;
   auto issue = [&](int slot_) {
     const int lb = slot_ * KT;
-    const bool whole = pix0 + 12 < p.P;       // every row of this lane is a real pixel (false only in the last K-tile of a ragged problem)
+    const bool whole = pix0 + 4 * (NP - 1) < p.P;       // every row of this lane is a real pixel (false only in the last K-tile of a ragged problem)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NP; ++j) {
       const bool live = (whole || pix0 + 4 * j < p.P) && (all_co || ((co_mask >> j) & 1u));
-      if (!(WG4_DBG & 4)) WG4_DMA(rs_dy, live ? dyb0 + (unsigned)ddy[j] : 0xFFFFFFFFu, lb + (wave * 4 + j) * 1024);
+      if (!(WG4_DBG & 4)) WG4_DMA(rs_dy, live ? dyb0 + (unsigned)ddy[j] : 0xFFFFFFFFu, lb + (wave * NP + j) * 1024);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NP; ++j) {
       bool ok = (whole || pix0 + 4 * j < p.P) && col_ok;
       if (TAPS) {
         int xj = x0v + 4 * j, yj = y0v;                       // (W >= 12: at most one wrap)
@@ -142,10 +146,10 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
         if (yj >= p.H) yj -= p.H;
         ok = ok && (unsigned)(yj + tap_dy) < (unsigned)p.H && (unsigned)(xj + tap_dx) < (unsigned)p.W;
       }
-      if (!(WG4_DBG & 4)) WG4_DMA(rs_x, ok ? xb0 + (unsigned)dxx[j] : 0xFFFFFFFFu, lb + 16384 + (wave * 4 + j) * 1024);
+      if (!(WG4_DBG & 4)) WG4_DMA(rs_x, ok ? xb0 + (unsigned)dxx[j] : 0xFFFFFFFFu, lb + XO + (wave * NP + j) * 1024);
     }
-    // advance by one K-tile (64 pixels)
-    pix0 += 64; dyb0 += dy_step; xb0 += x_step;
+    // advance by one K-tile (KP pixels)
+    pix0 += KP; dyb0 += dy_step; xb0 += x_step;
     if (TAPS) {
       x0v += adv_x; y0v += adv_y;
       if (x0v >= p.W) { x0v -= p.W; ++y0v; }
@@ -165,7 +169,7 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       offA[f][h] = 256 * row + 16 * (((wm * 8 + f * 2 + (pq >> 1)) ^ sw)) + 8 * (pq & 1);
-      offB[f][h] = 16384 + 256 * row + 16 * (((wn * 8 + f * 2 + (pq >> 1)) ^ sw)) + 8 * (pq & 1);
+      offB[f][h] = XO + 256 * row + 16 * (((wn * 8 + f * 2 + (pq >> 1)) ^ sw)) + 8 * (pq & 1);
     }
   }
 
@@ -180,7 +184,7 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
   for (int i = 0; i < R - 1 && i < nk; ++i) { issue(s_slot); if (++s_slot == R) s_slot = 0; }
   for (int kt = 0; kt < nk; ++kt) {
     // tiles 0 .. min(nk, kt+R-1)-1 are issued (8 DMA instructions per wave each); tile kt must have landed
-    if (R > 2 && kt + R - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (R > 2 ? R - 2 : 0)) : "memory");
+    if (R > 2 && kt + R - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NP * (R > 2 ? R - 2 : 0)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -188,7 +192,7 @@ NPP_DEV void wg4_body(const WgradParams& p, const WG4Extra& e, const int bid) {
     const unsigned ro = (unsigned)c_slot * KT;
     if (++c_slot == R) c_slot = 0;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KP / 32; ++ks) {
       s16x8 fa[4] = {}, fb[4] = {};
       if (!(WG4_DBG & 8))
 #pragma unroll
@@ -770,13 +774,13 @@ struct WG4Job {
   int first_block, _pad;
 };
 
-template <bool RELU, bool TAPS, int R>
+template <bool RELU, bool TAPS, int R, int KP = 64>
 __global__ __launch_bounds__(256) void conv_wgrad_g4_batched_kernel(const WG4Job* __restrict__ jobs, const int* __restrict__ block_job) {
   const int j = __builtin_amdgcn_readfirstlane(block_job[blockIdx.x]);
   const WG4Job* jb = jobs + j;
   const WgradParams p = jb->p;
   const WG4Extra e = jb->e;
-  wg4_body<RELU, TAPS, R>(p, e, (int)blockIdx.x - jb->first_block);
+  wg4_body<RELU, TAPS, R, KP>(p, e, (int)blockIdx.x - jb->first_block);
 }
 
 template <bool RELU>
@@ -811,7 +815,7 @@ bool wg4_raise_lds(const void* fp, size_t bytes) {
 
 // Eligibility + the derived parameters of one problem.  max_blocks: the slots this problem may fill (512 = the whole chip for a
 // launch of its own; a batched launch gives each job a share).  false = the shape stays with the generic kernel.
-static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradParams& q, WG4Extra& e, int& nblocks, bool batched = false) {
+static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradParams& q, WG4Extra& e, int& nblocks, bool batched = false, int kp = 64) {
   static const bool disabled = getenv("NPP_DISABLE_WG4") != nullptr;
   if (disabled || dtype != NPP_BF16) return false;
   if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1) return false;
@@ -833,7 +837,7 @@ static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradPa
   if (P > 0 && p.W < 12) return false;      // (wg4_body derives a lane's four rows from one (y, x): at most one row wrap in 12 pixels)
   e.P = P; e.HW = p.H * p.W;
   e.coltiles = (p.taps * p.Cin + 127) / 128;
-  e.nktiles = (p.P + 63) / 64;
+  e.nktiles = (p.P + 63) / 64;      // (the split rule below counts 64-pixel K-tiles whatever the kernel's K-tile is)
   e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
   e.dybytes = (unsigned)((long)p.P * p.ldy * 2);
   q = p;
@@ -854,6 +858,10 @@ static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradPa
   if (splits > e.nktiles) splits = e.nktiles;
   e.ktiles_per_split = (e.nktiles + splits - 1) / splits;
   splits = (e.nktiles + e.ktiles_per_split - 1) / e.ktiles_per_split;
+  if (kp != 64) {      // the same pixel ranges in K-tiles of kp pixels
+    e.ktiles_per_split *= 64 / kp;
+    e.nktiles = (p.P + kp - 1) / kp;
+  }
   e.ntiles = tiles; e.nblocks = tiles * splits;
   nblocks = tiles * splits;
   return true;
@@ -863,6 +871,11 @@ static bool wg4_prepare(const WgradParams& p, int dtype, int max_blocks, WgradPa
 // store SLABS (p.slab_stride > 0, one per split: the caller learns the count from npp_conv_wgrad_batched_splits).  NPP_WG9=0: off.
 // max_blocks: the workgroups this problem may take (one per CU).  NPP_WG9_STAGES: tiles per workgroup aimed at (default 64: ~160 us of
 // MFMA work in front of 295 KB of slab stores, and the slabs of a step stay in the hundreds of MB).
+// NPP_WGB_K32=1: the 1x1 jobs of the batched launch on 32-pixel K-tiles with a ring of 3 (three workgroups per CU)
+static bool wgb_k32() {
+  static const bool on = getenv("NPP_WGB_K32") && atoi(getenv("NPP_WGB_K32")) == 1;
+  return on;
+}
 constexpr size_t WG9_LDS = 2 * (32768 + 23 * 1024);
 static bool wg9_on() {
   static const bool on = !(getenv("NPP_WG9") && atoi(getenv("NPP_WG9")) == 0);
@@ -1050,7 +1063,7 @@ bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_hos
       return true;
     }
   }
-  if (!wg4_prepare(p, dtype, max_blocks, jb->p, jb->e, nb, true) || nb > max_blocks) return false;
+  if (!wg4_prepare(p, dtype, max_blocks, jb->p, jb->e, nb, true, (p.taps == 1 && wgb_k32()) ? 32 : 64) || nb > max_blocks) return false;
   jb->first_block = 0; jb->_pad = 0;
   *variant = (p.relu_in ? 1 : 0) | (jb->e.P > 0 ? 2 : 0);
   *nblocks = nb;
@@ -1094,12 +1107,26 @@ bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, in
   if (hipMemcpyAsync(const_cast<void*>(jobs_dev), jobs_host, (size_t)n * sizeof(WG4Job), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
   if (hipMemcpyAsync(const_cast<int*>(map_dev), map_host, (size_t)off[10] * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
   const WG4Job* jd = reinterpret_cast<const WG4Job*>(jobs_dev);
+  // NPP_WGB_RING: K-tile buffers of the batched 128 x 128 kernel (2: two workgroups per CU, the default; 3 / 4: one, with 2 / 3 K-tiles in flight)
+  static const int wgb_ring = getenv("NPP_WGB_RING") ? atoi(getenv("NPP_WGB_RING")) : 2;
+#define WG4_BATCH_R(V_, RELU_, TAPS_, R_)                                                                                          \
+  {                                                                                                                                \
+    constexpr size_t lds = (size_t)R_ * 32768;                                                                                     \
+    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g4_batched_kernel<RELU_, TAPS_, R_>), lds)) return false;           \
+    hipLaunchKernelGGL((conv_wgrad_g4_batched_kernel<RELU_, TAPS_, R_>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(256), lds, stream, \
+                       jd, map_dev + off[V_]);                                                                                     \
+  }
 #define WG4_BATCH(V_, RELU_, TAPS_)                                                                                                \
   if (off[V_ + 1] > off[V_]) {                                                                                                     \
-    constexpr size_t lds = 2 * 32768;                                                                                              \
-    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g4_batched_kernel<RELU_, TAPS_, 2>), lds)) return false;            \
-    hipLaunchKernelGGL((conv_wgrad_g4_batched_kernel<RELU_, TAPS_, 2>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(256), lds, stream, \
-                       jd, map_dev + off[V_]);                                                                                     \
+    if (!TAPS_ && wgb_k32()) {                                                                                                     \
+      constexpr size_t lds = 3 * 16384;                                                                                            \
+      if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g4_batched_kernel<RELU_, false, 3, 32>), lds)) return false;      \
+      hipLaunchKernelGGL((conv_wgrad_g4_batched_kernel<RELU_, false, 3, 32>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(256), lds, stream, \
+                         jd, map_dev + off[V_]);                                                                                   \
+    } else                                                                                                                         \
+    if (wgb_ring == 4) WG4_BATCH_R(V_, RELU_, TAPS_, 4)                                                                            \
+    else if (wgb_ring == 3) WG4_BATCH_R(V_, RELU_, TAPS_, 3)                                                                       \
+    else WG4_BATCH_R(V_, RELU_, TAPS_, 2)                                                                                          \
   }
   // the halo-kernel jobs first: their workgroups are the longest of the step
 #define WG9_BATCH(V_, RELU_)                                                                                                       \
@@ -1127,5 +1154,6 @@ bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, in
   WG4_BATCH(2, false, true)
   WG4_BATCH(3, true, true)
 #undef WG4_BATCH
+#undef WG4_BATCH_R
   return true;
 }

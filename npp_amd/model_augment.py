@@ -291,6 +291,8 @@ class _FuseCell(_DagCell):
     def forward(self, s0, s1, s2, foreign=None, hub=None):
         """`foreign`: index of the input produced by the other task branch; with the hub topology (Network.forward) the
         op that consumes it runs on the hub stream, so that the two branch streams never wait on each other directly."""
+        if self.order == 0:
+            return self._forward_order0(s0, s1, s2)
         pre = [self.preprocess0, self.preprocess1, self.preprocess2]
         ins = [s0, s1, s2]
         cb1 = None
@@ -315,17 +317,26 @@ class _FuseCell(_DagCell):
                 outs = K.bn_add_multi([(sides[i], None, False, sides[i].bn.training, cb1.slot(i)) for i in range(3)])
             else:
                 outs = [pre[i](ins[i], out=cb1.slot(i)) if cb1 is not None else pre[i](ins[i]) for i in range(3)]
-        if self.order == 0:
-            # F.interpolate(scale_factor=4/2) with the default (nearest) mode, model_augment.py:167-169
-            raise NotImplementedError("order == 0 fuse cells are never built by Network (model_augment.py:357-363)")
         st, fea2 = self._run(outs, self._concat)
         fea1 = cb1.result(st[0:3]) if cb1 is not None else K.concat(st[0:3])
         return fea1, fea2
 
+    def _forward_order0(self, s0, s1, s2):
+        """order == 0 (model_augment.py:119-172, 174-229; never built by the reference's Network, model_augment.py:357-363): the inputs
+        arrive at 1/4, 1/2 and full resolution, the ops on inputs 0 / 1 are followed by a bilinear x4 / x2 (`wrap` in __init__), and after
+        the node loop states 0 and 1 are replaced by F.interpolate(scale_factor=4 / 2) in its default NEAREST mode before both
+        concatenations (model_augment.py:167-171)."""
+        states = self._run([self.preprocess0(s0), self.preprocess1(s1), self.preprocess2(s2)], None)
+        states = list(states)
+        states[0] = K.nearest(states[0], 4)
+        states[1] = K.nearest(states[1], 2)
+        return K.concat(states[0:3]), K.concat([states[i] for i in self._concat])
+
     def stages(self, s0, s1, s2, foreign, hub, result):
         """forward() as a generator pausing after every preprocess and every edge (see Cell.stages); result[0] = (fea1, fea2)."""
-        if self.order == 0:
-            raise NotImplementedError("order == 0 fuse cells are never built by Network (model_augment.py:357-363)")
+        if self.order == 0:      # (no lockstep form: one stage)
+            result[0] = self._forward_order0(s0, s1, s2)
+            return
         pre = [self.preprocess0, self.preprocess1, self.preprocess2]
         ins = [s0, s1, s2]
         cb1 = K.ConcatBuffer(3) if all(isinstance(m, ReLUConvBN) for m in pre) else None

@@ -34,6 +34,14 @@ CELL_CASES = {
                       inputs=[None, (64, 48, 48), (128, 24, 24), None, (128, 24, 24), None, None]),
 }
 
+# PoseCell1 / ParCell1 with order == 0 (model_augment.py:119-229; never built by the reference's Network, model_augment.py:357-363, but
+# part of the class's surface): inputs at 1/4, 1/2 and full resolution, edge ops on inputs 0 / 1 followed by a bilinear x4 / x2,
+# the first two states of fea1 resampled by F.interpolate's default (nearest) mode.  Own golden file: tests/golden/cells_o0_golden.npz.
+CELL_CASES_O0 = {
+    "pose_cell_o0": dict(kind="pose", args=(64, 64, 32, 0), inputs=[(64, 12, 12), (64, 24, 24), (32, 48, 48)]),
+    "par_cell_o0": dict(kind="par", args=(64, 64, 32, 0), inputs=[(64, 12, 12), (64, 24, 24), (32, 48, 48)]),
+}
+
 # Criterion_pose beyond the launchers' use (core/criterion.py:92-96, 103-108, 113-115)
 POSE_CASES = {
     "weighted": dict(use_target_weight=True, sizes=[(32, 32), (32, 32)]),

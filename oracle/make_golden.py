@@ -365,10 +365,12 @@ def build_cell_case(spec, ref=True):
     return torch.nn.ModuleList(ops[base:base + len(idx)]), idx
 
 
-def gen_cells():
+def gen_cells(cases=None, fname="cells_golden.npz"):
     from oracle.cases import CELL_CASES, N, SUB
+    if cases is None:
+        cases = CELL_CASES
     out = {"torch_version": np.array(torch.__version__)}
-    for name, spec in CELL_CASES.items():
+    for name, spec in cases.items():
         torch.manual_seed(0)
         m, idx = build_cell_case(spec)
         load_synth(m, 0, prefix=f"cells.{name}.")
@@ -410,8 +412,14 @@ def gen_cells():
         sd = m.state_dict()
         out[f"{name}/sd_keys"] = np.array(list(sd.keys()))
         out[f"{name}/sd_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
-    np.savez_compressed(os.path.join(OUT, "cells_golden.npz"), **out)
-    print("cells_golden.npz", len(out), "arrays")
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, len(out), "arrays")
+
+
+def gen_cells_o0():
+    """PoseCell1 / ParCell1 with order == 0 (oracle/cases.py: CELL_CASES_O0), a file of their own."""
+    from oracle.cases import CELL_CASES_O0
+    gen_cells(CELL_CASES_O0, "cells_o0_golden.npz")
 
 
 def gen_criteria2():
@@ -604,9 +612,9 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["ops", "criteria", "tiny", "search", "search_extra", "search_eval", "eval", "cells", "criteria2"] + \
+    todo = a.only.split(",") if a.only else ["ops", "criteria", "tiny", "search", "search_extra", "search_eval", "eval", "cells", "cells_o0", "criteria2"] + \
         (["full", "full_grads", "full_eval", "cfg4"] if a.full else [])
     for t in todo:
         {"ops": gen_ops, "criteria": gen_criteria, "tiny": gen_tiny, "full": gen_full, "search": gen_search, "eval": gen_eval,
-         "cells": gen_cells, "criteria2": gen_criteria2, "cfg4": gen_cfg4, "full_grads": gen_full_grads,
+         "cells": gen_cells, "cells_o0": gen_cells_o0, "criteria2": gen_criteria2, "cfg4": gen_cfg4, "full_grads": gen_full_grads,
          "full_eval": gen_full_eval, "search_extra": gen_search_extra, "search_eval": gen_search_eval}[t]()

@@ -9,7 +9,8 @@ cp "$s" gpurun_out/quick_stats.csv
 python3 - <<'PY'
 import csv
 rows = list(csv.DictReader(open("gpurun_out/quick_stats.csv")))
-steps = 14
+# steps covered by the trace: every step (warm-up, capture and replays alike) launches pack_weights_batched_kernel exactly once
+steps = next((int(r["Calls"]) for r in rows if "pack_weights_batched_kernel" in r["Name"]), 14)
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
 print(f"kernel time per step {tot:.2f} ms, launches per step {sum(int(r['Calls']) for r in rows) / steps:.0f}")
 for r in rows[:40]:

@@ -16,7 +16,8 @@ try:
     l = load("profiles/r04_kernel_stats_bs16_bf16_eager_1stream.csv")
 except Exception:
     l = {}
-steps = 7
+# steps covered by the trace: every step (warm-up, capture and replays alike) launches pack_weights_batched_kernel exactly once
+steps = next((int(r["Calls"]) for r in rows if "pack_weights_batched_kernel" in r["Name"]), 7)
 names = sorted(set(d) | set(l), key=lambda n: -abs(d.get(n, (0, 0))[1] - l.get(n, (0, 0))[1]))
 print(f"dist: {sum(v[0] for v in d.values()) / steps:.0f} launches/step, {sum(v[1] for v in d.values()) / steps / 1e6:.2f} ms kernel time;  local: {sum(v[0] for v in l.values()) / steps:.0f}, {sum(v[1] for v in l.values()) / steps / 1e6:.2f}")
 for n in names[:28]:
