@@ -584,7 +584,7 @@ def main():
         KERNELS = {"conv_s1": "conv_s1_kernel (stride-1 KxK conv fwd + dgrad, LDS-resident footprint, MFMA 32x32x16)",
                    "conv_g8": "conv_g8_kernel (1x1 conv fwd + dgrad: 8-phase LDS-DMA implicit GEMM, MFMA 16x16x32)",
                    "conv_g4": "conv_g4_kernel + conv_h3_kernel + conv_c32_kernel + conv_thin (conv fwd + dgrad, incl. the merged edges of round 4: same-input edges as one conv C -> mC and one data gradient mC -> C; g4: 1x1 / 3x3 on 64x64 / 128x128 / 64x32 tiles, stride 1 and 2, LDS-DMA ring of 2; h3: 3x3 with an LDS-resident halo footprint on the >= 30k-pixel maps; c32: 32 -> 32 3x3 with halo and all nine taps resident, output / input groups; MFMA 16x16x32; 114 of the data-gradient launches per step also deliver the BatchNorm-backward sums of the gradient they finish -- two more tensor reads each, timed here, not in the algorithmic flops: the family read 0.156 before that fusion)",
-                   "conv_wgrad": "weight-gradient family (conv_wgrad_g4_batched_kernel: every LDS-DMA-eligible weight gradient of the step in one launch per variant over a device job table -- pixel-major LDS-DMA + transposing reads, MFMA 16x16x32; strided / odd-channel layers on conv_wgrad_kernel)"}
+                   "conv_wgrad": "weight-gradient family (every LDS-DMA-eligible weight gradient of the step in one launch per kernel variant over a device job table -- conv_wgrad_g9_batched_kernel (round 5): 3x3 layers on maps of whole 8x16-pixel tiles, all nine taps from one LDS-resident halo, 8 waves, slabs summed by the batched unpack; conv_wgrad_g4_batched_kernel: 128x128 tile of one tap, the 1x1 and small-map layers; conv_wgrad_narrow_batched_kernel: 32 / 64-channel 3x3; all pixel-major LDS-DMA (inline asm) + transposing reads, MFMA 16x16x32; strided / odd-channel layers on conv_wgrad_kernel)"}
         # HBM bytes per launch: rocprofv3 --pmc cannot run inside this process, so the counters come from the committed passes
         # of this same command (tools/final_profiles.sh -> profiles/rNN_pmc_traffic.json, the newest round's) -- and only while the kernel sources
         # still hash to what those passes ran on; otherwise `traffic` is null and `traffic_note` says why
@@ -605,6 +605,19 @@ def main():
                 traffic_db = {}
         except Exception as e:      # noqa: BLE001
             traffic_db, traffic_note = {}, f"{traffic_file}: {e}"
+        # the same families' kernel time inside the REPLAYED graph (two branch streams overlapping, rocprofv3 --kernel-trace --stats of this
+        # command): from the committed summary of the newest round, under the same source-hash rule as the traffic
+        graph_db = {}
+        try:
+            gcands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_family_graph_ms.json")))
+            if gcands:
+                with open(gcands[-1]) as fh:
+                    gd = json.load(fh)
+                if gd.get("source_hash") == _lib.kernel_source_hash() == _lib.built_source_hash():
+                    graph_db = gd
+                    graph_db["_file"] = os.path.relpath(gcands[-1], REPO)
+        except Exception:      # noqa: BLE001
+            graph_db = {}
         for fam, label in KERNELS.items():
             _hb(f"roofline leg: {fam}")
             # one eager step per measurement, the faster of `prof_steps` measurements is reported: a single stalled launch (seen once:
@@ -632,6 +645,11 @@ def main():
                               "avg_launch_us": round(ms.value * 1e3 / nl.value, 2),
                               "algorithmic_gflop_per_launch": round(fl.value / nl.value / 1e9, 4),
                               "algorithmic_mbyte_per_launch": round(by.value / nl.value / 1e6, 3)})
+                grec = graph_db.get(fam)
+                if grec and grec.get("ms_per_step"):      # (the event-timed figure above is the eager single-stream one)
+                    roofs[-1]["graph_replay"] = {"ms_per_step": grec["ms_per_step"], "launches_per_step": grec.get("launches_per_step"),
+                                                 "frac": round(fl.value / (grec["ms_per_step"] * 1e-3) / 1e12 / peak, 4),
+                                                 "source": f"rocprofv3 --kernel-trace --stats of the replayed hipGraph run, {graph_db.get('_file')}"}
         roofs.sort(key=lambda r: -r["ms_per_step"])
         roof = roofs[0] if roofs else None
         if streams_env is None:

@@ -200,13 +200,17 @@ def apply_op(c, name, pre, x, stride):
 
 
 # ---- cells (models/model_augment.py:16-229) ---------------------------------------------
-def _dag(c, pre, states, plan, up_on_input0):
-    """4 steps x 2 ops; s = op1(h1) + op2(h2)  (model_augment.py:48-62, 92-106, 153-172)."""
+def _dag(c, pre, states, plan, up_on_input0, up_scales=None):
+    """4 steps x 2 ops; s = op1(h1) + op2(h2)  (model_augment.py:48-62, 92-106, 153-172).
+    up_scales: {input index: scale} -- nn.Sequential(op, Interpolate(scale)) on the ops fed by those inputs (order == 0 fuse cells,
+    model_augment.py:143-147, 202-206)."""
     for i in range(len(plan) // 2):
         hs = []
         for j in (2 * i, 2 * i + 1):
             name, idx, stride = plan[j]
-            if up_on_input0 and idx == 0:   # nn.Sequential(op, Interpolate(2)), model_augment.py:86-87
+            if up_scales is not None and idx in up_scales:
+                h = interp(apply_op(c, name, f'{pre}_ops.{j}.0.', states[idx], stride), up_scales[idx])
+            elif up_on_input0 and idx == 0:   # nn.Sequential(op, Interpolate(2)), model_augment.py:86-87
                 h = interp(apply_op(c, name, f'{pre}_ops.{j}.0.', states[idx], stride), 2)
             else:
                 h = apply_op(c, name, f'{pre}_ops.{j}.', states[idx], stride)
@@ -243,6 +247,19 @@ def fuse_cell(c, pre, s0, s1, s2, geno):
     return torch.cat(st[0:3], dim=1), torch.cat(st[3:7], dim=1)
 
 
+def fuse_cell_order0(c, pre, s0, s1, s2, geno):
+    """PoseCell1 / ParCell1 with order=0, model_augment.py:119-172 / 174-229: inputs at 1/4, 1/2 and full resolution; the ops on inputs
+    0 / 1 are followed by Interpolate(4) / Interpolate(2) (bilinear, align_corners=True, :143-147); after the node loop states 0 and 1
+    are replaced by F.interpolate(scale_factor=4 / 2) in its default nearest mode (:167-169) before both concatenations."""
+    s0 = relu_conv_bn(c, pre + 'preprocess0.', s0, 1, 1, 0)
+    s1 = relu_conv_bn(c, pre + 'preprocess1.', s1, 1, 1, 0)
+    s2 = relu_conv_bn(c, pre + 'preprocess2.', s2, 1, 1, 0)
+    st = _dag(c, pre, [s0, s1, s2], [(n, i, 1) for n, i in geno], False, up_scales={0: 4, 1: 2})
+    st[0] = F.interpolate(st[0], scale_factor=4)
+    st[1] = F.interpolate(st[1], scale_factor=2)
+    return torch.cat(st[0:3], dim=1), torch.cat(st[3:7], dim=1)
+
+
 def cell_case(c, pre, spec, xs):
     """One entry of oracle/cases.py CELL_CASES on the inputs `xs` (None where the case has no such input); returns the list
     of outputs.  `pre` is the state-dict prefix of the block."""
@@ -253,7 +270,8 @@ def cell_case(c, pre, spec, xs):
     if kind == "upsample":
         return [upsample_cell(c, pre, xs[0], xs[1], DEC_UP1 if spec["which"] == 1 else DEC_UP2)]
     if kind in ("pose", "par"):
-        return list(fuse_cell(c, pre, xs[0], xs[1], xs[2], FUSE_POSE if kind == "pose" else FUSE_PAR))
+        fn = fuse_cell_order0 if spec["args"][3] == 0 else fuse_cell
+        return list(fn(c, pre, xs[0], xs[1], xs[2], FUSE_POSE if kind == "pose" else FUSE_PAR))
     geno = {1: INTER_T1, 2: INTER_T2, 3: INTER_T3, 4: INTER_T4}[spec["task"]][spec["stage"]]
     st = spec["stage"]
     res = [1, 1 / 2, 1 / 4, 1 / 8, 1 / 4, 1 / 2, 1]

@@ -256,7 +256,7 @@ def test_eval_parsing_tta_confusion_matches_reference():
 
 
 # ---- composite blocks, extended criteria, config 4 (oracle/cases.py) -----------------------------------------------------
-from oracle.cases import CELL_CASES, N as CELL_N, SUB, POSE_CASES, POSE_N, POSE_J, POSE_HM, CFG4_SMALL, CFG4_FULL, \
+from oracle.cases import CELL_CASES, CELL_CASES_O0, N as CELL_N, SUB, POSE_CASES, POSE_N, POSE_J, POSE_HM, CFG4_SMALL, CFG4_FULL, \
     FULL_GRAD_KEYS, FULL_GRAD_ELEMS  # noqa: E402
 
 
@@ -333,10 +333,10 @@ def check_cell_case(g, name, ys, dxs, grads, bufs, tol, tol_grad, norm=rel_err, 
     return worst_y, worst_g
 
 
-@pytest.mark.parametrize("name", list(CELL_CASES))
+@pytest.mark.parametrize("name", list(CELL_CASES) + list(CELL_CASES_O0))
 def test_cell_blocks_match_reference(name):
-    g = load_golden("cells_golden.npz")
-    spec = CELL_CASES[name]
+    g = load_golden("cells_o0_golden.npz" if name in CELL_CASES_O0 else "cells_golden.npz")
+    spec = CELL_CASES_O0[name] if name in CELL_CASES_O0 else CELL_CASES[name]
     t = synth_tensors(_case_template(g, name), 0, prefix=f"cells.{name}.")
     for k, v in t.items():
         if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):

@@ -20,6 +20,7 @@ run() {  # name, extra env assignment string, bench args...
   tail -1 $out/${tag}_${name}.log | cut -c1-300
 }
 run bs16_bf16_graph --steps 10 --warmup 3 --no-cpu-baseline
+python3 tools/family_graph_ms.py $out/${tag}_kernel_stats_bs16_bf16_graph.csv $out/${tag}_family_graph_ms.json
 export NPP_STREAMS=1
 run bs16_bf16_eager_1stream --steps 5 --warmup 2 --no-cpu-baseline --graph 0
 # (NPP_SYNC_LAUNCH: see tools/pmc_step.sh)
@@ -30,7 +31,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 ff=$(find /tmp/fp_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 fw=$(find /tmp/fp_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-FAMS="conv_g4=conv_g4_kernel|conv_h3_kernel|conv_thin_out_kernel|conv_thin_in_kernel|conv_c32_kernel,conv_g8=conv_g8_kernel,conv_wgrad=conv_wgrad_g4_kernel|conv_wgrad_g4_batched_kernel|conv_wgrad_kernel|conv_wgrad_s1_kernel|conv_wgrad_h3_kernel|conv_wgrad_thin_kernel,conv_h3_kernel,conv_g4_kernel,conv_wgrad_g4_batched_kernel"
+FAMS="conv_g4=conv_g4_kernel|conv_h3_kernel|conv_thin_out_kernel|conv_thin_in_kernel|conv_c32_kernel,conv_g8=conv_g8_kernel,conv_wgrad=conv_wgrad_g4_kernel|conv_wgrad_g4_batched_kernel|conv_wgrad_g9_batched_kernel|conv_wgrad_narrow|conv_wgrad_kernel|conv_wgrad_s1_kernel|conv_wgrad_h3_kernel|conv_wgrad_thin_kernel,conv_h3_kernel,conv_g4_kernel,conv_wgrad_g4_batched_kernel,conv_wgrad_g9_batched_kernel"
 python3 tools/pmc_traffic.py "$ff" "$fw" "$FAMS" $out/${tag}_pmc_traffic.json
 python3 tools/pmc_step_total.py "$ff" "$fw" 4 > $out/${tag}_pmc_step_total.txt
 #   4. MFMA utilisation per conv family (north_star: "rocprof HBM GB/s and MFMA utilisation")
@@ -42,4 +43,5 @@ cat $out/${tag}_pmc_mfma_busy.txt
 #   5. the plain bench line (no profiler, default streams), after copying the fresh traffic file where bench.py reads it
 unset NPP_STREAMS NPP_SYNC_LAUNCH GPU_MAX_HW_QUEUES NPP_BENCH_SUPERVISE
 cp $out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
+cp $out/${tag}_family_graph_ms.json profiles/${tag}_family_graph_ms.json
 python3 bench.py > $out/${tag}_bench_line.json 2> /dev/null; tail -c 400 $out/${tag}_bench_line.json
