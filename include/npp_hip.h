@@ -150,6 +150,7 @@ typedef struct NppUnpackJob {
   int32_t cout, cin, taps, cp, kpad, nslabs;
   int64_t slab, first_block;
 } NppUnpackJob;
+int64_t npp_unpack_job_blocks(int cout, int cin, int taps);   /* workgroups job (cout, cin, taps) takes: first_block / the block -> job map count these */
 int npp_unpack_wgrad_batched(const NppUnpackJob* jobs_dev, const int32_t* block_job_dev, int64_t total_blocks, void* stream);
 /* Many depthwise (3x3) weight gradients in one launch + one slab-sum launch: items must pass npp_dwconv_bwd_weight_batchable
  * (bf16, the run kernel's geometry); dw / ws as for npp_dwconv_bwd_weight (ws of npp_dwconv_bwd_weight_ws elements, not zeroed);

@@ -242,7 +242,7 @@ _SIGS = {
 EXPORTS = sorted(list(_SIGS) + ["npp_version", "npp_last_error", "npp_clear_hip_error", "npp_packed_weight_elems", "npp_pack_job_blocks", "npp_reduce_blocks",
                                  "npp_dwconv_bwd_weight_ws", "npp_dwconv_bwd_weight_ws_zeroed", "npp_conv_fwd_ws_bytes", "npp_adam_chunk_elems",
                                  "npp_conv_wgrad_splits", "npp_debug_nonfinite", "npp_conv_wgrad_batched_ws", "npp_dwconv_bwd_weight_batched_ws", "npp_bilinear_bwd_ws_bytes",
-                                 "npp_se_ws_floats", "npp_se_param_grads_batched_ws", "npp_p2p_capacity", "npp_p2p_set_timeout_ms"])
+                                 "npp_se_ws_floats", "npp_se_param_grads_batched_ws", "npp_p2p_capacity", "npp_p2p_set_timeout_ms", "npp_unpack_job_blocks"])
 
 
 def kernel_source_hash() -> str:
@@ -307,6 +307,8 @@ def lib():
         L.npp_se_param_grads_batched_ws.argtypes = [_P, C.c_int]
         L.npp_p2p_capacity.restype = C.c_int64
         L.npp_p2p_capacity.argtypes = []
+        L.npp_unpack_job_blocks.restype = C.c_int64
+        L.npp_unpack_job_blocks.argtypes = [C.c_int, C.c_int, C.c_int]
         L.npp_p2p_set_timeout_ms.restype = C.c_int64
         L.npp_p2p_set_timeout_ms.argtypes = [C.c_int64]
         for name, sig in _SIGS.items():

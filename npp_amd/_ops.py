@@ -1227,6 +1227,17 @@ def flush_wgrads(group=None):
             it[2].record_stream(cur)
 
 
+_unpack_blocks_cache: dict = {}
+
+
+def _unpack_blocks(co, ci, taps):
+    k = (co, ci, taps)
+    v = _unpack_blocks_cache.get(k)
+    if v is None:
+        v = _unpack_blocks_cache[k] = int(lib().npp_unpack_job_blocks(co, ci, taps))
+    return v
+
+
 _unpack_bufs = {"pin": None, "dev": None, "ev": None, "keep": []}
 _unpack_bufs_k = {"pin": None, "dev": None, "ev": None, "keep": []}
 
@@ -1267,7 +1278,7 @@ def flush_unpacks(group=None):
     nblk = np.empty(n, dtype=np.int64)
     for i, (src, dst, co, ci, taps, cp, kpad, nsl, slab, _st) in enumerate(items):
         jobs[i] = (src.data_ptr(), dst.data_ptr(), co, ci, taps, cp, kpad, nsl, slab, 0)
-        nblk[i] = (co * ci * taps + 1023) // 1024
+        nblk[i] = _unpack_blocks(co, ci, taps)
     first = np.cumsum(nblk) - nblk
     jobs["first_block"] = first
     total = int(nblk.sum())
