@@ -361,7 +361,7 @@ extern "C" int npp_conv_wgrad_batched_splits(const NppTensor* x, const NppTensor
   int variant = 0, nblocks = 0, splits = 0;
   p.slab_stride = -1;      // a query: "if the caller brings slabs"
   if (!conv_wgrad_g4_batch_prepare(p, x->dtype, job, 0, WGB_MAX_BLOCKS, &variant, &nblocks, &splits)) return 0;
-  return variant >= 6 ? 0 : splits;      // (the narrow kernels keep their atomics)
+  return (variant >= 6 && variant <= 9) ? 0 : splits;      // (the narrow kernels keep their atomics)
 }
 
 // slabs the batched launch WANTS for this problem by default: the nine-tap halo kernel (conv_wgrad_g4.hip: wg9_body) stores one slab per
@@ -377,7 +377,7 @@ extern "C" int npp_conv_wgrad_batched_slabs(const NppTensor* x, const NppTensor*
   int variant = 0, nblocks = 0, splits = 0;
   p.slab_stride = -1;
   if (!conv_wgrad_g4_batch_prepare(p, x->dtype, job, 0, WGB_MAX_BLOCKS, &variant, &nblocks, &splits)) return 0;
-  return (variant == 4 || variant == 5) ? splits : 0;
+  return (variant == 4 || variant == 5 || variant == 10 || variant == 11) ? splits : 0;
 }
 
 extern "C" int64_t npp_conv_wgrad_batched_ws(int n) {
@@ -404,7 +404,7 @@ extern "C" int npp_conv_wgrad_batched(const NppWgradItem* items, int n, void* ho
       npp_set_error("npp_conv_wgrad_batched: item %d is not a shape of the batched kernel (ask npp_conv_wgrad_batchable first)", i);
       return NPP_E_UNSUPPORTED;
     }
-    if (it.nslabs > 0 && (it.nslabs != splits || variant[i] >= 6)) {
+    if (it.nslabs > 0 && (it.nslabs != splits || (variant[i] >= 6 && variant[i] <= 9))) {
       npp_set_error("npp_conv_wgrad_batched: item %d brings %d slabs, the kernel splits its pixels %d ways (npp_conv_wgrad_batched_splits)",
                     i, (int)it.nslabs, splits);
       return NPP_E_SHAPE;

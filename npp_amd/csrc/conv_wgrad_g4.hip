@@ -293,12 +293,24 @@ struct WG3Extra {        // the halo kernel's, the thin kernel's and the narrow 
   unsigned xbytes, dybytes;
 };
 
-template <bool RELU>
+// TW: tile width.  16 (8 x 16 = 128 pixels, four MFMA K-steps per tile) for maps of whole 16-pixel columns; 8 (8 x 8 = 64 pixels, two
+// K-steps; halo 10 x 10) for the 24 x 24 maps.  With TW = 8 the two 16-lane groups of a half-wave read neighbouring halo ROWS (the
+// pitch of 10 pixels keeps their parity), so the swizzle takes its second bit from the halo row instead of column bit 3:
+// chunk ^= 2 * (column bit 1 | row bit 0 << 1) -- two address registers per (kw, half), one per parity of kh.
+template <bool RELU, int TW>
 NPP_DEV void wg9_body(const WgradParams& p, const WG3Extra& e, const int bid) {
-  constexpr int DYB = 32768;             // dy tile [8 x 16 px][128 co]
-  constexpr int XB = 23 * 1024;          // x halo  [10 x 18 px (+ 4 unused)][64 ci]
+  constexpr int HW2 = TW + 2;            // halo width
+  constexpr int HP = 10 * HW2;           // halo pixels
+  constexpr int XPC = (HP + 7) / 8;      // 1-KiB pieces of the x halo (8 pixels x 128 B)
+  constexpr int DYB = 8 * TW * 256;      // dy tile [8 x TW px][128 co]
+  constexpr int XB = XPC * 1024;         // x halo  [10 x (TW + 2) px (+ padding)][64 ci]
   constexpr int ST = DYB + XB;           // bytes per stage
-  constexpr int HROW = 18 * 128;         // bytes per halo row
+  constexpr int HROW = HW2 * 128;        // bytes per halo row
+  constexpr int KS = TW / 4;             // MFMA K-steps (32 pixels) per tile
+  constexpr int RPK = 32 / TW;           // tile rows per K-step
+  constexpr int NPD = TW / 4;            // dy pieces per wave (wave w stages tile row w)
+  constexpr int NPX = (XPC + 7) / 8;     // x pieces per wave
+  constexpr int NPAR = TW == 16 ? 1 : 2; // address variants by the parity of kh
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -317,7 +329,7 @@ NPP_DEV void wg9_body(const WgradParams& p, const WG3Extra& e, const int bid) {
   int st_end = st_begin + e.ktiles_per_split;
   if (st_end > e.nktiles) st_end = e.nktiles;
   if (st_begin >= st_end) return;
-  const int txn = p.W >> 4, tyn = p.H >> 3;
+  const int txn = p.W / TW, tyn = p.H >> 3;
   int tn, ty, tx;                        // the next tile to stage: image, tile row, tile column
   {
     const int per = tyn * txn;
@@ -325,41 +337,41 @@ NPP_DEV void wg9_body(const WgradParams& p, const WG3Extra& e, const int bid) {
     const int r = st_begin - tn * per;
     ty = r / txn; tx = r - ty * txn;
   }
+  auto swz_x = [](int hr, int hc) { return TW == 16 ? (((hc >> 1) & 1) | (((hc >> 3) & 1) << 1)) : (((hc >> 1) & 1) | ((hr & 1) << 1)); };
 
-  // ---- staging: wave w fills dy pieces 4w .. 4w+3 (= tile row w: 4 pixels x 256 B each) and x pieces w, w+8, w+16 (8 halo pixels
-  // x 128 B each; piece 23 does not exist) ------------------------------------------------------------------------------------------
-  int ddy[4];                            // bytes from the tile's first pixel
+  // ---- staging: wave w fills the dy pieces of tile row w (4 pixels x 256 B each) and the x pieces w, w + 8, ... (8 halo pixels x 128 B) ----
+  int ddy[NPD];                          // bytes from the tile's first pixel
   {
     const int srow = lane >> 4, slot = lane & 15;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int chunk = slot ^ ((srow << 2) | j);      // pixel wave*16 + 4j + srow: (px & 3) << 2 | (px >> 2) & 3
+    for (int j = 0; j < NPD; ++j) {
+      const int px = wave * TW + j * 4 + srow;
+      const int chunk = slot ^ (((px & 3) << 2) | ((px >> 2) & 3));
       ddy[j] = ((wave * p.W + j * 4 + srow) * (int)p.ldy + co0 + chunk * 8) * 2;
     }
   }
-  int dxo[3], hrc[3];                    // bytes from the tile's first pixel; (halo row << 16) | halo column (a row >= 1 << 14: never valid)
+  int dxo[NPX], hrc[NPX];                // bytes from the tile's first pixel; (halo row << 16) | halo column (a row >= 1 << 14: never valid)
   {
     const int xrow = lane >> 3, xc = lane & 7;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NPX; ++j) {
       const int hp = (wave + 8 * j) * 8 + xrow;
-      const int hr = hp / 18, hc = hp - hr * 18;
-      const int s2 = ((hc >> 1) & 1) | (((hc >> 3) & 1) << 1);
-      const int chunk = xc ^ (s2 << 1);
+      const int hr = hp / HW2, hc = hp - hr * HW2;
+      const int chunk = xc ^ (swz_x(hr, hc) << 1);
       dxo[j] = (((hr - 1) * p.W + (hc - 1)) * (int)p.ldx + ci0 + chunk * 8) * 2;
-      hrc[j] = hp < 180 ? (hr << 16) | hc : (1 << 30);
+      hrc[j] = hp < HP ? (hr << 16) | hc : (1 << 30);
     }
   }
   auto issue = [&](int buf) {
     const int lb = buf * ST;
-    const int y0 = ty * 8, x0 = tx * 16;
+    const int y0 = ty * 8, x0 = tx * TW;
     const unsigned pix = (unsigned)((tn * p.H + y0) * p.W + x0);
     const unsigned dyb = pix * (unsigned)p.ldy * 2u, xb = pix * (unsigned)p.ldx * 2u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) WG4_DMA(rs_dy, dyb + (unsigned)ddy[j], lb + (wave * 4 + j) * 1024);
+    for (int j = 0; j < NPD; ++j) WG4_DMA(rs_dy, dyb + (unsigned)ddy[j], lb + (wave * NPD + j) * 1024);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      if (j == 2 && wave == 7) break;
+    for (int j = 0; j < NPX; ++j) {
+      if (wave + 8 * j >= XPC) break;
       const int hr = hrc[j] >> 16, hc = hrc[j] & 0xFFFF;
       const bool ok = (unsigned)(y0 + hr - 1) < (unsigned)p.H && (unsigned)(x0 + hc - 1) < (unsigned)p.W;
       WG4_DMA(rs_x, ok ? xb + (unsigned)dxo[j] : 0xFFFFFFFFu, lb + DYB + (wave + 8 * j) * 1024);
@@ -367,21 +379,25 @@ NPP_DEV void wg9_body(const WgradParams& p, const WG3Extra& e, const int bid) {
     if (++tx == txn) { tx = 0; if (++ty == tyn) { ty = 0; ++tn; } }
   };
 
-  // ---- transposed fragment reads: K index k = ks*32 + g*8 + h*4 + q4 = pixel (row k >> 4, column k & 15) of the tile -------------------
+  // ---- transposed fragment reads: K index k = ks*32 + g*8 + h*4 + q4 = pixel (row k / TW, column k % TW) of the tile -------------------
   const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pq = i16 & 3;
-  unsigned offD[4][2], offX[3][2];
+  unsigned offD[4][2], offX[3][2][NPAR];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = g * 8 + h * 4 + q4;                       // + ks*32
     const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
 #pragma unroll
     for (int f = 0; f < 4; ++f) offD[f][h] = 256 * row + 16 * (((wm * 8 + f * 2 + (pq >> 1)) ^ sw)) + 8 * (pq & 1);
+    const int tr0 = TW == 16 ? (g >> 1) : g;                  // tile row of the lane's pixel in K-step 0 (+ ks * RPK)
+    const int tc = TW == 16 ? (g & 1) * 8 + h * 4 + q4 : h * 4 + q4;
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int hc = (g & 1) * 8 + h * 4 + q4 + kw;           // halo column; halo row = ks*2 + (g >> 1) + kh
-      const int s2 = ((hc >> 1) & 1) | (((hc >> 3) & 1) << 1);
-      offX[kw][h] = DYB + 128 * ((g >> 1) * 18 + hc) + 16 * ((wn * 2 + (pq >> 1)) ^ (s2 << 1)) + 8 * (pq & 1);
-    }
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int par = 0; par < NPAR; ++par) {
+        const int hc = tc + kw;                               // halo column; halo row = ks*RPK + tr0 + kh  (RPK is even for TW = 8)
+        const int s2 = swz_x(tr0 + par, hc);
+        offX[kw][h][par] = DYB + 128 * (tr0 * HW2 + hc) + 16 * ((wn * 2 + (pq >> 1)) ^ (s2 << 1)) + 8 * (pq & 1);
+      }
   }
 
   f32x4g acc[9][4];                      // acc[tap][nf][j] = dW[co0 + wm*64 + nf*16 + i16][tap][ci0 + wn*16 + 4*g + j]
@@ -401,7 +417,7 @@ NPP_DEV void wg9_body(const WgradParams& p, const WG3Extra& e, const int bid) {
     const unsigned ro = (unsigned)cur * ST;
     cur ^= 1;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       s16x8 fd[4];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
@@ -412,8 +428,9 @@ NPP_DEV void wg9_body(const WgradParams& p, const WG3Extra& e, const int bid) {
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp) {
         const int kh = tp / 3, kw = tp - kh * 3;
-        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offX[kw][0] + (ks * 2 + kh) * HROW));
-        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offX[kw][1] + (ks * 2 + kh) * HROW));
+        const int par = NPAR == 1 ? 0 : (kh & 1);
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offX[kw][0][par] + (ks * RPK + kh) * HROW));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(smem + ro + offX[kw][1][par] + (ks * RPK + kh) * HROW));
         s16x8 fx = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
         if (RELU) {
           const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -440,9 +457,9 @@ NPP_DEV void wg9_body(const WgradParams& p, const WG3Extra& e, const int bid) {
     }
 }
 
-template <bool RELU>
+template <bool RELU, int TW>
 __global__ __launch_bounds__(512) void conv_wgrad_g9_kernel(WgradParams p, WG3Extra e) {
-  wg9_body<RELU>(p, e, (int)blockIdx.x);
+  wg9_body<RELU, TW>(p, e, (int)blockIdx.x);
 }
 
 
@@ -783,13 +800,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_g4_batched_kernel(const WG4Job
   wg4_body<RELU, TAPS, R, KP>(p, e, (int)blockIdx.x - jb->first_block);
 }
 
-template <bool RELU>
+template <bool RELU, int TW>
 __global__ __launch_bounds__(512) void conv_wgrad_g9_batched_kernel(const WG4Job* __restrict__ jobs, const int* __restrict__ block_job) {
   const int j = __builtin_amdgcn_readfirstlane(block_job[blockIdx.x]);
   const WG4Job* jb = jobs + j;
   const WgradParams p = jb->p;
   const WG3Extra e = jb->e3;
-  wg9_body<RELU>(p, e, (int)blockIdx.x - jb->first_block);
+  wg9_body<RELU, TW>(p, e, (int)blockIdx.x - jb->first_block);
 }
 
 template <int C, bool RELU>
@@ -876,7 +893,8 @@ static bool wgb_k32() {
   static const bool on = getenv("NPP_WGB_K32") && atoi(getenv("NPP_WGB_K32")) == 1;
   return on;
 }
-constexpr size_t WG9_LDS = 2 * (32768 + 23 * 1024);
+constexpr size_t WG9_LDS = 2 * (32768 + 23 * 1024);      // tile width 16
+constexpr size_t WG9_LDS8 = 2 * (16384 + 13 * 1024);     // tile width 8
 static bool wg9_on() {
   static const bool on = !(getenv("NPP_WG9") && atoi(getenv("NPP_WG9")) == 0);
   return on;
@@ -886,19 +904,23 @@ static bool wg9_prepare(const WgradParams& p, int dtype, int max_blocks, WgradPa
   if (p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.KH != 3 || p.KW != 3) return false;
   if (p.ph != 1 || p.pw != 1 || p.OH != p.H || p.OW != p.W) return false;
   if (p.Cin % 64 != 0 || p.Cout % 128 != 0 || p.Cp != p.Cin || !p.vec_dy || p.ldx % 8 != 0 || p.ldy % 8 != 0) return false;
-  if (p.H % 8 != 0 || p.W % 16 != 0 || p.H >= 16384 || p.W >= 16384) return false;
+  if (p.H % 8 != 0 || p.W % 8 != 0 || p.H >= 16384 || p.W >= 16384) return false;
+  const int tw = p.W % 16 == 0 ? 16 : 8;      // (8: the 24 x 24 maps; NPP_WG9_TW8=0 leaves them to the 128 x 128 kernel)
+  static const bool tw8_on = !(getenv("NPP_WG9_TW8") && atoi(getenv("NPP_WG9_TW8")) == 0);
+  if (tw == 8 && !tw8_on) return false;
   if ((long)p.P * p.ldx * 2 >= (1L << 31) || (long)p.P * p.ldy * 2 >= (1L << 31)) return false;      // (signed per-lane byte offsets)
   static const int min_pix = getenv("NPP_WG9_MIN_PIX") ? atoi(getenv("NPP_WG9_MIN_PIX")) : 0;
   if (p.P < min_pix) return false;
-  e.HW = p.H * p.W;
+  e.HW = tw;                                  // (the halo kernel's tile width travels in this field)
   e.cintiles = p.Cin / 64;
-  e.nktiles = p.N * (p.H / 8) * (p.W / 16);
+  e.nktiles = p.N * (p.H / 8) * (p.W / tw);
   e.xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * 2);
   e.dybytes = (unsigned)((long)p.P * p.ldy * 2);
   q = p;
   q.rowtiles = p.Cout / 128;
   const int tiles = q.rowtiles * e.cintiles;
-  static const int want = getenv("NPP_WG9_STAGES") ? atoi(getenv("NPP_WG9_STAGES")) : 64;
+  static const int want16 = getenv("NPP_WG9_STAGES") ? atoi(getenv("NPP_WG9_STAGES")) : 64;
+  const int want = want16;      // (measured for the 64-pixel tiles too: the small-map 3x3 jobs of a step 0.50 / 0.43 / 0.43 / 0.44 / 0.47 ms at 128 / 64 / 48 / 32 / 16)
   int splits = (e.nktiles + want - 1) / (want > 0 ? want : 1);
   if (splits > max_blocks / tiles) splits = max_blocks / tiles;
   if (splits < 1) splits = 1;
@@ -1057,7 +1079,7 @@ bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_hos
     if (wg9_prepare(p, dtype, max_blocks, jb->p, jb->e3, nb, sp9)) {      // (one workgroup per CU; its splits store slabs)
       memset(&jb->e, 0, sizeof(jb->e));
       jb->first_block = 0; jb->_pad = 0;
-      *variant = 4 | (p.relu_in ? 1 : 0);
+      *variant = (jb->e3.HW == 16 ? 4 : 10) | (p.relu_in ? 1 : 0);      // 4, 5: tile width 16; 10, 11: tile width 8
       *nblocks = nb;
       if (splits) *splits = sp9;
       return true;
@@ -1075,23 +1097,24 @@ bool conv_wgrad_g4_batch_prepare(const WgradParams& p, int dtype, void* jobs_hos
 bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, int* map_host, const int* map_dev, const int* variant_of,
                                 const int* blocks_of, hipStream_t stream) {
   WG4Job* jobs = reinterpret_cast<WG4Job*>(jobs_host);
-  long off[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long off[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   size_t lds_narrow[4] = {0, 0, 0, 0};      // largest LDS footprint among the jobs of each narrow variant
   // longest blocks first (blocks of one launch start in block-id order): the tail of a launch is then made of short blocks
   std::vector<int> order(n);
   for (int i = 0; i < n; ++i) order[i] = i;
   static const bool lpt = !(getenv("NPP_WGB_SORT") && atoi(getenv("NPP_WGB_SORT")) == 0);
   auto klen = [&](int a) {
-    return variant_of[a] >= 6 ? jobs[a].e3.ktiles_per_split : variant_of[a] >= 4 ? 3 * jobs[a].e3.ktiles_per_split : jobs[a].e.ktiles_per_split;
+    return variant_of[a] >= 10 ? 3 * jobs[a].e3.ktiles_per_split / 2 : variant_of[a] >= 6 ? jobs[a].e3.ktiles_per_split
+           : variant_of[a] >= 4 ? 3 * jobs[a].e3.ktiles_per_split : jobs[a].e.ktiles_per_split;
   };
   for (int i = 0; i < n; ++i)
-    if (variant_of[i] >= 6) {
+    if (variant_of[i] >= 6 && variant_of[i] <= 9) {
       const size_t l = wgn_lds(jobs[i].p, jobs[i].e3.cintiles);
       if (l > lds_narrow[variant_of[i] - 6]) lds_narrow[variant_of[i] - 6] = l;
     }
   if (lpt)
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return klen(a) > klen(b); });
-  for (int v = 0; v < 10; ++v) {
+  for (int v = 0; v < 12; ++v) {
     long cnt = 0;
     for (int k = 0; k < n; ++k) {
       const int i = order[k];
@@ -1103,9 +1126,9 @@ bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, in
     }
     off[v + 1] = off[v] + cnt;
   }
-  if (off[10] == 0) return true;
+  if (off[12] == 0) return true;
   if (hipMemcpyAsync(const_cast<void*>(jobs_dev), jobs_host, (size_t)n * sizeof(WG4Job), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
-  if (hipMemcpyAsync(const_cast<int*>(map_dev), map_host, (size_t)off[10] * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
+  if (hipMemcpyAsync(const_cast<int*>(map_dev), map_host, (size_t)off[12] * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
   const WG4Job* jd = reinterpret_cast<const WG4Job*>(jobs_dev);
   // NPP_WGB_RING: K-tile buffers of the batched 128 x 128 kernel (2: two workgroups per CU, the default; 3 / 4: one, with 2 / 3 K-tiles in flight)
   static const int wgb_ring = getenv("NPP_WGB_RING") ? atoi(getenv("NPP_WGB_RING")) : 2;
@@ -1129,14 +1152,16 @@ bool conv_wgrad_g4_batch_launch(void* jobs_host, const void* jobs_dev, int n, in
     else WG4_BATCH_R(V_, RELU_, TAPS_, 2)                                                                                          \
   }
   // the halo-kernel jobs first: their workgroups are the longest of the step
-#define WG9_BATCH(V_, RELU_)                                                                                                       \
+#define WG9_BATCH(V_, RELU_, TW_, LDS_)                                                                                            \
   if (off[V_ + 1] > off[V_]) {                                                                                                     \
-    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g9_batched_kernel<RELU_>), WG9_LDS)) return false;                  \
-    hipLaunchKernelGGL((conv_wgrad_g9_batched_kernel<RELU_>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(512), WG9_LDS, stream,  \
+    if (!wg4_raise_lds(reinterpret_cast<const void*>(conv_wgrad_g9_batched_kernel<RELU_, TW_>), LDS_)) return false;                \
+    hipLaunchKernelGGL((conv_wgrad_g9_batched_kernel<RELU_, TW_>), dim3((unsigned)(off[V_ + 1] - off[V_])), dim3(512), LDS_, stream, \
                        jd, map_dev + off[V_]);                                                                                     \
   }
-  WG9_BATCH(4, false)
-  WG9_BATCH(5, true)
+  WG9_BATCH(4, false, 16, WG9_LDS)
+  WG9_BATCH(5, true, 16, WG9_LDS)
+  WG9_BATCH(10, false, 8, WG9_LDS8)
+  WG9_BATCH(11, true, 8, WG9_LDS8)
 #undef WG9_BATCH
 #define WGN_BATCH(V_, C_, RELU_)                                                                                                    \
   if (off[V_ + 1] > off[V_]) {                                                                                                     \

@@ -215,6 +215,9 @@ def test_benched_shapes_match_cpu_reference(case, batched_wgrad):
     (192, 128, 3, 24, 48, 2, False),     # halo kernel: three input-channel tiles, 3 x 3 tiles per image, no ReLU
     (256, 256, 3, 16, 16, 4, True),      # halo kernel: two output- x four input-channel tiles
     (128, 128, 3, 96, 96, 3, True),      # halo kernel: several pixel splits (216 tiles), the benched layer
+    (128, 256, 3, 24, 24, 3, False),     # halo kernel on 8 x 8 tiles (maps of whole 8-pixel columns only): 3 x 3 tiles per image, no ReLU
+    (128, 128, 3, 8, 8, 5, True),        # halo kernel, 8 x 8 tiles: one tile per image
+    (64, 128, 3, 16, 40, 2, True),       # halo kernel, 8 x 8 tiles: 2 x 5 tiles per image, 64 input channels
 ])
 def test_weight_gradient_is_exact_on_integer_data(cin, cout, k, H, W, N, relu, batched):
     """Small-integer activations and gradients: every product and every partial sum is exact in f32 whatever the summation

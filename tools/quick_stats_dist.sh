@@ -13,11 +13,16 @@ def load(p):
     return {r["Name"]: (int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(p))}
 d = load("gpurun_out/quick_stats_dist.csv")
 try:
-    l = load("profiles/r04_kernel_stats_bs16_bf16_eager_1stream.csv")
+    l = load("profiles/r05_kernel_stats_bs16_bf16_eager_1stream.csv")
 except Exception:
     l = {}
-# steps covered by the trace: every step (warm-up, capture and replays alike) launches pack_weights_batched_kernel exactly once
-steps = next((int(r["Calls"]) for r in rows if "pack_weights_batched_kernel" in r["Name"]), 7)
+# steps covered by each trace: every step launches pack_weights_batched_kernel exactly once
+def nsteps(t, default):
+    return next((v[0] for k, v in t.items() if "pack_weights_batched_kernel" in k), default)
+steps, lsteps = nsteps(d, 7), nsteps(l, 15)
+d = {k: (v[0] / steps, v[1] / steps) for k, v in d.items()}
+l = {k: (v[0] / lsteps, v[1] / lsteps) for k, v in l.items()}
+steps = 1
 names = sorted(set(d) | set(l), key=lambda n: -abs(d.get(n, (0, 0))[1] - l.get(n, (0, 0))[1]))
 print(f"dist: {sum(v[0] for v in d.values()) / steps:.0f} launches/step, {sum(v[1] for v in d.values()) / steps / 1e6:.2f} ms kernel time;  local: {sum(v[0] for v in l.values()) / steps:.0f}, {sum(v[1] for v in l.values()) / steps / 1e6:.2f}")
 for n in names[:28]:
