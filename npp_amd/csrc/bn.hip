@@ -968,11 +968,15 @@ struct MixArgs {
   int k;
 };
 
-template <typename T, int V>
+// KT: the operand count as a COMPILE-TIME constant (0: runtime a.k).  Round 5: with `if (k < K)` on a runtime K around each operand load
+// hipcc branches around every load and waits vmcnt(0) behind it (cdna_hip_programming.md, "three .s-level traps" (c)): the 7
+// operands of a mixed edge were 7 dependent round trips per pixel (11 of the backward reduce's 12 loads were followed by vmcnt(0)).
+// The supernet's mixed edges have 7 operands: that count is instantiated, any other takes the runtime form.
+template <typename T, int V, int KT>
 __global__ __launch_bounds__(256) void mix_bn_fwd_kernel(MixArgs a, const float* __restrict__ w, T* __restrict__ out, long ldo, long npix,
                                                          int C, ColMap m) {
   extern __shared__ float s_mix[];      // scale [k][C], shift [k][C]
-  const int t = threadIdx.x, K = a.k;
+  const int t = threadIdx.x, K = KT ? KT : a.k;
   float* s_sc = s_mix;
   float* s_sh = s_mix + K * C;
   for (int idx = t; idx < K * C; idx += 256) {
@@ -1023,6 +1027,15 @@ __global__ __launch_bounds__(256) void mix_bn_fwd_kernel(MixArgs a, const float*
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = sh[j];
+    if (KT) {      // all operand loads first: in flight together
+      float v[KT ? KT : 1][V];
+#pragma unroll
+      for (int k = 0; k < (KT ? KT : 1); ++k) ldv<T, V>(reinterpret_cast<const T*>(a.x[k]) + p * a.ld[k] + c0, v[k]);
+#pragma unroll
+      for (int k = 0; k < (KT ? KT : 1); ++k)
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = fmaf(v[k][j], s_sc[k * C + c0 + j], acc[j]);
+    } else
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (k < K) {
@@ -1037,11 +1050,11 @@ __global__ __launch_bounds__(256) void mix_bn_fwd_kernel(MixArgs a, const float*
 }
 
 // sums[R][(K+1)][C] += [sum d | sum d xhat_0 | ... | sum d xhat_{K-1}]   (f64 atomics into a zeroed buffer)
-template <typename T, int V>
+template <typename T, int V, int KT>
 __global__ __launch_bounds__(256) void mix_bn_bwd_reduce_kernel(MixArgs a, const T* __restrict__ dout, long ldo, long npix, int C, ColMap m,
                                                                 double* __restrict__ sums) {
   extern __shared__ float s_mix[];      // mean [k][C], invstd [k][C], then the reduction image [4 * V][256]
-  const int t = threadIdx.x, K = a.k;
+  const int t = threadIdx.x, K = KT ? KT : a.k;
   float* s_mean = s_mix;
   float* s_inv = s_mix + K * C;
   float* red = s_mix + 2 * K * C;
@@ -1066,6 +1079,15 @@ __global__ __launch_bounds__(256) void mix_bn_bwd_reduce_kernel(MixArgs a, const
       ldv<T, V>(dout + p * ldo + c0, d);
 #pragma unroll
       for (int j = 0; j < V; ++j) acc[0][j] += d[j];
+      if (KT) {      // all operand loads first: in flight together
+        float v[KT ? KT : 1][V];
+#pragma unroll
+        for (int k = 0; k < (KT ? KT : 1); ++k) ldv<T, V>(reinterpret_cast<const T*>(a.x[k]) + p * a.ld[k] + c0, v[k]);
+#pragma unroll
+        for (int k = 0; k < (KT ? KT : 1); ++k)
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[k + 1][j] = fmaf(d[j], (v[k][j] - s_mean[k * C + c0 + j]) * s_inv[k * C + c0 + j], acc[k + 1][j]);
+      } else
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         if (k < K) {
@@ -1105,12 +1127,12 @@ __global__ __launch_bounds__(256) void mix_bn_bwd_reduce_kernel(MixArgs a, const
   }
 }
 
-template <typename T, int V>
+template <typename T, int V, int KT>
 __global__ __launch_bounds__(256) void mix_bn_bwd_apply_kernel(MixArgs a, const float* __restrict__ w, const T* __restrict__ dout, long ldo,
                                                                const double* __restrict__ sums, float* __restrict__ dw, long npix, int C,
                                                                ColMap m, const float* __restrict__ local_sums) {
   extern __shared__ float s_mix[];      // ca [k][C], cb [k][C], cc [k][C], then K doubles (dw accumulators of block 0)
-  const int t = threadIdx.x, K = a.k;
+  const int t = threadIdx.x, K = KT ? KT : a.k;
   float* s_ca = s_mix;
   float* s_cb = s_mix + K * C;
   float* s_cc = s_mix + 2 * K * C;
@@ -1153,6 +1175,20 @@ __global__ __launch_bounds__(256) void mix_bn_bwd_apply_kernel(MixArgs a, const 
   for (long p = (long)blockIdx.x * m.rows + row; p < npix; p += step) {
     float d[V];
     ldv<T, V>(dout + p * ldo + c0, d);
+    if (KT) {
+      // every operand is loaded unconditionally (all loads in flight together); an identity operand has cb = cc = 0, so the one
+      // formula covers it; only the STORE hangs on the runtime "gradient wanted" pointer
+      float v[KT ? KT : 1][V];
+#pragma unroll
+      for (int k = 0; k < (KT ? KT : 1); ++k) ldv<T, V>(reinterpret_cast<const T*>(a.x[k]) + p * a.ld[k] + c0, v[k]);
+#pragma unroll
+      for (int k = 0; k < (KT ? KT : 1); ++k) {
+        float o[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = fmaf(s_ca[k * C + c0 + j], d[j], fmaf(s_cb[k * C + c0 + j], v[k][j], s_cc[k * C + c0 + j]));
+        if (a.dx[k]) stv<T, V>(reinterpret_cast<T*>(a.dx[k]) + p * a.ldd[k] + c0, o);
+      }
+    } else
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (k < K && a.dx[k]) {
@@ -1807,7 +1843,9 @@ static int mix_bn_fwd_impl(const NppMixSide* sides, int k, const float* w, NppTe
     ColMap m = col_map(out->c, V);
     dim3 grid = col_grid_ew(m, npix(out));
     if (grid.x > 512) grid.x = 512;
-    hipLaunchKernelGGL((mix_bn_fwd_kernel<T, V>), grid, dim3(256), lds, (hipStream_t)stream, a, w, (T*)out->ptr, (long)out->ld,
+    if (k == 7) hipLaunchKernelGGL((mix_bn_fwd_kernel<T, V, 7>), grid, dim3(256), lds, (hipStream_t)stream, a, w, (T*)out->ptr, (long)out->ld,
+                                   (long)npix(out), (int)out->c, m);
+    else hipLaunchKernelGGL((mix_bn_fwd_kernel<T, V, 0>), grid, dim3(256), lds, (hipStream_t)stream, a, w, (T*)out->ptr, (long)out->ld,
                        (long)npix(out), (int)out->c, m);
   });
   return npp_check_launch("mix_bn_fwd");
@@ -1829,15 +1867,19 @@ static int mix_bn_bwd_impl(const NppMixSide* sides, int k, const float* w, const
     if (which & 1) {
       const int nb = reduce_blocks(npix(dout), C, dout->dtype);
       const size_t lds_r = (size_t)(2 * k * C + 4 * V * 256) * sizeof(float);
-      hipLaunchKernelGGL((mix_bn_bwd_reduce_kernel<T, V>), dim3((unsigned)nb, 1), dim3(256), lds_r, (hipStream_t)stream, a, (const T*)dout->ptr,
-                         (long)dout->ld, (long)npix(dout), C, m, sums);
+      if (k == 7) hipLaunchKernelGGL((mix_bn_bwd_reduce_kernel<T, V, 7>), dim3((unsigned)nb, 1), dim3(256), lds_r, (hipStream_t)stream, a,
+                                     (const T*)dout->ptr, (long)dout->ld, (long)npix(dout), C, m, sums);
+      else hipLaunchKernelGGL((mix_bn_bwd_reduce_kernel<T, V, 0>), dim3((unsigned)nb, 1), dim3(256), lds_r, (hipStream_t)stream, a,
+                              (const T*)dout->ptr, (long)dout->ld, (long)npix(dout), C, m, sums);
     }
     if (which & 2) {
       dim3 grid = col_grid_ew(m, npix(dout));
       if (grid.x > 512) grid.x = 512;
       const size_t lds_a = (size_t)(3 * k * C + 2) * sizeof(float) + 8 * sizeof(double);
-      hipLaunchKernelGGL((mix_bn_bwd_apply_kernel<T, V>), grid, dim3(256), lds_a, (hipStream_t)stream, a, w, (const T*)dout->ptr,
-                         (long)dout->ld, (const double*)sums, dw, (long)npix(dout), C, m, local_sums);
+      if (k == 7) hipLaunchKernelGGL((mix_bn_bwd_apply_kernel<T, V, 7>), grid, dim3(256), lds_a, (hipStream_t)stream, a, w, (const T*)dout->ptr,
+                                     (long)dout->ld, (const double*)sums, dw, (long)npix(dout), C, m, local_sums);
+      else hipLaunchKernelGGL((mix_bn_bwd_apply_kernel<T, V, 0>), grid, dim3(256), lds_a, (hipStream_t)stream, a, w, (const T*)dout->ptr,
+                              (long)dout->ld, (const double*)sums, dw, (long)npix(dout), C, m, local_sums);
     }
   });
   return npp_check_launch("mix_bn_bwd");

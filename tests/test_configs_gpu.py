@@ -14,7 +14,7 @@ sys.path.insert(0, REPO)
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("batch,size", [(32, 384), (8, 512)])
+@pytest.mark.parametrize("batch,size", [(16, 384), (32, 384), (8, 512)])   # (16, 384) is the bench line's own workload
 def test_full_size_configuration_trains_under_the_graph(batch, size):
     import bench
     from npp_amd.criterion import Criterion_par, Criterion_pose
