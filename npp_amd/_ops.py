@@ -2210,7 +2210,8 @@ def _fin_record(ctx, a, b, y, pa, pb, sa, sb, relu):
 # npp_bn_bwd_reduce_multi, npp_bn_bwd_apply_multi): the nodes of a cell that are ready together.  NPP_BN_MULTI=0: one launch each.
 BN_MULTI = os.environ.get("NPP_BN_MULTI", "1") != "0"
 BN_MULTI_MAX = 4
-MULTI_STATS = [0, 0, 0]      # multi-job launches: forward applies / backward reduces / backward applies
+MULTI_STATS = [0, 0, 0, 0]      # multi-job launches: forward applies / backward reduces / backward applies / SyncBatchNorm exchanges between the two
+BN_MULTI_SYNC = os.environ.get("NPP_BN_MULTI_SYNC", "1") != "0"      # the multi-job backward under SyncBatchNorm (p2p mailboxes); 0: one reduce + apply per node
 
 
 def _zero_desc():
@@ -2622,19 +2623,25 @@ class _BnAddPair(Function):
         needs = ctx.needs_input_grad[1:]
         items = []
         kind = None
+        sync_grp = None
         for k, dout in enumerate(douts):
             if dout is None:
                 return None
             a, b, yrelu, mia, mib, _ssa, _ssb = saved[7 * k:7 * k + 7]
             bna, bnb, batch_a, batch_b, cnt_a, cnt_b, has_b = ctx.subs[k][1]
             ni = needs[6 * k:6 * k + 6]
-            if bna is None or not batch_a or not ni[0] or _sync_group(bna)[0] is not None or mia is None:
+            if bna is None or not batch_a or not ni[0] or mia is None:
                 return None
+            grp_k = _sync_group(bna)[0]
             two = bool(has_b and bnb is not None)
             if two:
                 if not (batch_b and ni[3] and a.shape == b.shape and a.dtype == b.dtype and cnt_a == cnt_b and mib is not None
-                        and _sync_group(bnb)[0] is None and _fused_layout_ok(b)):
+                        and _sync_group(bnb)[0] is grp_k and _fused_layout_ok(b)):
                     return None
+            if k == 0:
+                sync_grp = grp_k
+            elif grp_k is not sync_grp:
+                return None
             elif has_b and yrelu is not None:
                 return None      # (a plain operand behind a ReLU needs a masked copy of its own)
             dout = to_nhwc(dout)
@@ -2653,7 +2660,16 @@ class _BnAddPair(Function):
         two = kind[0]
         dev = items[0][1].device
         c = items[0][1].shape[1]
+        if sync_grp is not None:
+            # SyncBatchNorm (every item of ONE group): the multi-job reduce, ONE peer-to-peer slab exchange with a segment per job
+            # (it writes the LOCAL dgamma / dbeta -- DDP averages them afterwards, as torch.nn.SyncBatchNorm does -- leaves the world's
+            # sums in replica 0 and zeroes the other replicas), the multi-job apply with the world's pixel count
+            from . import comm
+            if not (P2P_DIRECT and FUSE_BN_SYNC and BN_MULTI_SYNC and dev.type == "cuda" and n <= 8
+                    and comm.p2p_can(n * (3 if two else 2) * c, sync_grp)):
+                return None
         jobs = (L.NppBnBwdJob * n)()
+        segs = []
         keep, results, need_reduce = [], [], []
         for k, (dout, a, b, yrelu, mia, mib, bna, bnb, cnt, has_b, ni, _two) in enumerate(items):
             gs = ctx.subs[k][2]
@@ -2679,7 +2695,8 @@ class _BnAddPair(Function):
             j.gamma_a = ptr(ga)
             dga = _grad_buf(bna.weight if ni[1] else None, c, dev)
             dba = _grad_buf(bna.bias if ni[2] else None, c, dev)
-            j.dgamma_a, j.dbeta_a = dga.data_ptr(), dba.data_ptr()
+            if sync_grp is None:
+                j.dgamma_a, j.dbeta_a = dga.data_ptr(), dba.data_ptr()
             dgb = dbb = gb = None
             if two:
                 j.mi_b = mib.data_ptr()
@@ -2687,7 +2704,10 @@ class _BnAddPair(Function):
                 j.gamma_b = ptr(gb)
                 dgb = _grad_buf(bnb.weight if ni[4] else None, c, dev)
                 dbb = _grad_buf(bnb.bias if ni[5] else None, c, dev)
-                j.dgamma_b, j.dbeta_b = dgb.data_ptr(), dbb.data_ptr()
+                if sync_grp is None:
+                    j.dgamma_b, j.dbeta_b = dgb.data_ptr(), dbb.data_ptr()
+            if sync_grp is not None:      # [0, c): sum dout -> dbeta (of both sides); [c, 2c) -> dgamma_a; [2c, 3c) -> dgamma_b
+                segs.append((sums, (3 if two else 2) * c, R, c, (dba, dbb, dga, dgb), True))
             j.sums, j.count = sums.data_ptr(), float(cnt)
             keep.append((sums, ga, gb))
             if two:
@@ -2721,6 +2741,10 @@ class _BnAddPair(Function):
                 return None
             check(rc, "npp_bn_bwd_reduce_multi")
             MULTI_STATS[1] += 1
+        if sync_grp is not None:
+            if not comm.p2p_exchange_slabs(segs, sync_grp):
+                raise RuntimeError("peer-to-peer exchange refused vectors it had accepted the size of")
+            MULTI_STATS[3] += 1
         check(lib().npp_bn_bwd_apply_multi(C.cast(jobs, C.c_void_p), n, s), "npp_bn_bwd_apply_multi")
         MULTI_STATS[2] += 1
         out = (None,)
