@@ -315,6 +315,26 @@ typedef struct NppBnBwdJob {
 } NppBnBwdJob;
 int npp_bn_bwd_reduce_multi(const NppBnBwdJob* jobs, int njobs, int nblocks, void* stream);      /* dya / dyb unused */
 int npp_bn_bwd_apply_multi(const NppBnBwdJob* jobs, int njobs, void* stream);
+/* ---- SyncBatchNorm with the statistics exchange INSIDE the fused kernels (torch.nn.SyncBatchNorm, augment_lip_sync.py:191 /
+ * search_lip_sync.py:268-271, over the peer-to-peer mailboxes of npp_p2p_*).  The `_x` forms take the mailbox `channel` of the launch's
+ * stream (channel < 0: exactly the plain form).  The statistics / sums handed in are the LOCAL ones (all NPP_STAT_REPLICAS slabs); the
+ * leader workgroup of each job trades them for the world's sums in the kernel's prologue -- the exchange is the channel's next one, as
+ * if npp_p2p_exchange_slabs had been launched in front of the kernel, but costs no launch (csrc/p2p_xp.h).  `count` is the WORLD's
+ * element count.  Forward: mean_invstd and the running statistics are the world's.  Backward: dgamma / dbeta receive the LOCAL sums
+ * (torch.nn.SyncBatchNorm does not reduce them; DDP averages them), the data gradient uses the world's.  Exchange vector: forward,
+ * per job [BatchNorm side][sum C | sum of squares C]; backward, per job [sum dout C | dgamma_a C (| dgamma_b C)].  Every rank must
+ * issue the same sequence of exchanges on a channel; errors as for npp_p2p_exchange (npp_p2p_status). */
+int npp_affine_add_fin_x(NppTensor* out, const NppTensor* a, const NppBnFinalizeArgs* fin_a, const NppTensor* b,
+                         const NppBnFinalizeArgs* fin_b, int relu, unsigned char* mask_bits, int64_t ld_mask, int channel, void* stream);
+int npp_affine_add_fin_multi_x(const NppAffineAddJob* jobs, int njobs, int channel, void* stream);
+int npp_bn_bwd_apply_fin_x(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out, const double* sums, int nrep,
+                           double count, const float* mean_invstd, const float* gamma, float* dgamma, float* dbeta,
+                           NppTensor* dy_raw, int channel, void* stream);
+int npp_bn_bwd_apply2_fin_x(const NppTensor* dout, const NppTensor* ya_raw, const NppTensor* yb_raw, const NppTensor* relu_out,
+                            const double* sums, int nrep, double count, const float* mean_invstd_a, const float* mean_invstd_b,
+                            const float* gamma_a, const float* gamma_b, float* dgamma_a, float* dbeta_a, float* dgamma_b,
+                            float* dbeta_b, NppTensor* dya_raw, NppTensor* dyb_raw, int channel, void* stream);
+int npp_bn_bwd_apply_multi_x(const NppBnBwdJob* jobs, int njobs, int channel, void* stream);
 /* BatchNorm backward of a small bf16 map in ONE launch (csrc/bn_one.hip): npp_bn_bwd_reduce(2)_acc + npp_bn_bwd_apply(2)_fin with
  * the tensors held in registers across a grid-wide barrier (no ReLU mask: the cell nodes and the ReLU-Conv-BN blocks of
  * operations.py:70-79 have none after the BatchNorm).  npp_bn_bwd_one_blocks: grid size the kernel would use, 0 = not a shape of

@@ -148,6 +148,11 @@ _SIGS = {
     "npp_se_fwd_multi": [_T, _P, C.c_int, _P, _P],
     "npp_se_bwd_multi": [_T, _P, C.c_int, _T, _P, C.c_int, _P],
     "npp_affine_add_fin_multi": [_P, C.c_int, _P],
+    "npp_affine_add_fin_multi_x": [_P, C.c_int, C.c_int, _P],
+    "npp_bn_bwd_apply_multi_x": [_P, C.c_int, C.c_int, _P],
+    "npp_affine_add_fin_x": [_T, _T, _P, _T, _P, C.c_int, _P, C.c_int64, C.c_int, _P],
+    "npp_bn_bwd_apply_fin_x": [_T, _T, _T, _P, C.c_int, C.c_double, _P, _P, _P, _P, _T, C.c_int, _P],
+    "npp_bn_bwd_apply2_fin_x": [_T, _T, _T, _T, _P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _T, _T, C.c_int, _P],
     "npp_bn_bwd_reduce_multi": [_P, C.c_int, C.c_int, _P],
     "npp_bn_bwd_apply_multi": [_P, C.c_int, _P],
     "npp_mix_bn_fwd": [_P, C.c_int, _P, _T, _P],

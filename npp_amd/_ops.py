@@ -672,7 +672,7 @@ class _SyncStatsPool(_ZeroPool):
         for sd in self.waiting:
             if sd.rider:
                 continue
-            st = sd.stats
+            st = sd.carry if sd.carry is not None else sd.stats
             if st is None or not st.is_cuda or st.dtype != torch.float64 or not st.is_contiguous() or st.numel() % R != 0:
                 return False
             ln = st.numel() // R
@@ -1946,7 +1946,7 @@ class BnSide:
     """One operand of the fused add.  kind 'bn': `x` is a raw (pre-BN) tensor with f64 stats (train) or a
     BatchNorm holder in eval mode; kind 'plain': `x` is used as is."""
 
-    __slots__ = ("x", "bn", "stats", "count", "synced_ws", "private", "stream", "sync_event", "stats_c", "gslot", "rider", "ticket")
+    __slots__ = ("x", "bn", "stats", "count", "synced_ws", "private", "stream", "sync_event", "stats_c", "gslot", "rider", "ticket", "mates", "carry")
 
     def __init__(self, x, bn=None, stats=None, private=None, stats_c=0, gslot=None, rider=False):
         self.x = x
@@ -1959,6 +1959,8 @@ class BnSide:
         # SyncBatchNorm + merged edges: the statistics rows of ALL the merged edges travel as the segment of the run's first edge;
         # the others ride along (they wait in the pool to learn that the exchange happened, but contribute no segment of their own)
         self.rider = bool(rider)
+        self.mates = None           # merged edges: every side of this side's run (statistics row), itself included
+        self.carry = None           # a rider promoted to carrier (its lead edge's exchange was folded into a kernel): the run's full rows
         # private: `x` was produced for this operand alone (a raw conv / pool output on its way into its BatchNorm), so it
         # needs no fan-out node (take): ~600 autograd nodes per step less on the host
         self.private = (bn is not None) if private is None else bool(private)
@@ -1994,6 +1996,68 @@ def stats_level(bn) -> int:
     if not (bn.training or bn.running_mean is None):
         return 0
     return 2 if _sync_group(bn)[0] is not None else 1
+
+
+# SyncBatchNorm exchanges INSIDE the fused kernels (csrc/p2p_xp.h): with the statistics going through the peer-to-peer mailboxes the
+# fused apply / backward-apply kernels trade their local sums for the world's in their own prologue -- the stand-alone exchange launch
+# in front of them (446 links of the step's dependent chain) disappears.  NPP_P2P_FOLD=0: every exchange a launch of its own.
+P2P_FOLD = os.environ.get("NPP_P2P_FOLD", "1") != "0"
+FOLD_STATS = [0, 0]      # exchanges folded into a forward / a backward kernel
+
+
+def _fold_channel(n_doubles, grp):
+    """The mailbox channel for an in-kernel exchange of n_doubles on the current stream, or -1."""
+    if not (P2P_FOLD and P2P_DIRECT and FUSE_BN_SYNC and not SYNC_MERGE):
+        return -1
+    from . import comm
+    return comm.p2p_fold_channel(n_doubles, grp)
+
+
+def _fold_forward(launch_sides, training: bool):
+    """launch_sides: the (sa, sb) pairs of ONE fused apply launch.  If every BatchNorm side is a SyncBatchNorm of one group whose
+    statistics are still local (written by the producing kernel into NPP_STAT_REPLICAS slabs) and the mailboxes take the vector, the
+    sides are marked exchanged (world count, off the pool's waiting list) and the channel is returned: the launch MUST then carry the
+    exchange.  -1: nothing changed, the caller exchanges as before (_presync_stats)."""
+    if not (P2P_FOLD and P2P_DIRECT and FUSE_BN_SYNC and training and not SYNC_MERGE):
+        return -1
+    grp = None
+    bn_sides, widths = [], set()
+    for sa, sb in launch_sides:
+        ns = 0
+        for sd in (sa, sb):
+            if sd is None or sd.bn is None:
+                continue
+            g_, ws = _sync_group(sd.bn)
+            if g_ is None or (grp is not None and g_ is not grp) or sd.synced_ws or sd.sync_event is not None or sd.stats is None:
+                return -1
+            st = sd.stats
+            c = sd.x.shape[1]
+            if not st.is_cuda or st.dtype != torch.float64 or (not sd.stats_c and st.numel() != R * 2 * c):
+                return -1
+            grp = g_
+            bn_sides.append((sd, ws))
+            ns += 1
+        widths.add((ns, sa.x.shape[1]))
+    if not bn_sides or len(widths) != 1:
+        return -1
+    ns, c = next(iter(widths))
+    ch = _fold_channel(len(launch_sides) * ns * 2 * c, grp)
+    if ch < 0:
+        return -1
+    pools = _sync_pool.all()
+    for sd, ws in bn_sides:
+        for pl in pools:
+            if any(w is sd for w in pl.waiting):
+                pl.waiting = [w for w in pl.waiting if w is not sd]
+                if not sd.rider and sd.mates:
+                    # the lead edge of a merged run leaves: the next waiting edge of the run carries the rows from now on
+                    nxt = next((mt for mt in sd.mates if mt is not sd and not mt.synced_ws and any(w is mt for w in pl.waiting)), None)
+                    if nxt is not None:
+                        nxt.rider = False
+                        nxt.carry = sd.carry if sd.carry is not None else sd.stats
+                break
+        sd.synced_ws = ws
+    return ch
 
 
 def _presync_stats(sides, training: bool):
@@ -2229,19 +2293,27 @@ class _BnAdd(Function):
         ssa = mia = ssb = mib = None
         batch_a = batch_b = False
         ctx.gslots = (sa.gslot, sb.gslot if sb is not None else None)
-        _presync_stats((sa, sb), training)
+        xch = -1
+        if _fin_fusable(sa, sb, a, b, training) and (mk is None or a.dtype == torch.bfloat16):
+            xch = _fold_forward([(sa, sb)], training)      # SyncBatchNorm: the exchange inside the fused kernel
+        if xch < 0:
+            _presync_stats((sa, sb), training)
         prep = _fin_prepare(a, b, sa, sb, training, out)
         if prep is not None:
             # local train-mode BatchNorm(s): the finalize arithmetic runs in the prologue of the affine_add kernel
             pa, pb, y = prep
-            rc = lib().npp_affine_add_fin(_byref(y), _byref(a), C.byref(pa[0]), tref(b), C.byref(pb[0]) if pb is not None else None,
-                                          int(relu), (mk[0].data_ptr() + mk[1]) if mk is not None else None,
-                                          mk[2] if mk is not None else 0, stream_ptr())
+            rc = lib().npp_affine_add_fin_x(_byref(y), _byref(a), C.byref(pa[0]), tref(b), C.byref(pb[0]) if pb is not None else None,
+                                            int(relu), (mk[0].data_ptr() + mk[1]) if mk is not None else None,
+                                            mk[2] if mk is not None else 0, xch, stream_ptr())
             if rc == 0:
+                if xch >= 0:
+                    FOLD_STATS[0] += 1
                 _fin_record(ctx, a, b, y, pa, pb, sa, sb, relu)
                 return y
-            if rc != -5:      # NPP_E_UNSUPPORTED: nothing was launched, the separate kernels take it
-                check(rc, "npp_affine_add_fin")
+            if rc != -5 or xch >= 0:      # NPP_E_UNSUPPORTED: nothing was launched, the separate kernels take it (never with a folded exchange)
+                check(rc, "npp_affine_add_fin_x")
+        elif xch >= 0:
+            raise RuntimeError("a SyncBatchNorm exchange was folded into a fused apply that did not take place")
         if sa.bn is not None and sb is not None and sb.bn is not None:
             (ssa, mia, batch_a), (ssb, mib, batch_b) = _bn_coeffs_pair(sa, sb, training, dev)
         else:
@@ -2342,7 +2414,7 @@ class _BnAdd(Function):
                 sums = zeros_f64(R * 3 * c, dev)
             elif fused:
                 tk_ = getattr(ctx, "ticket", None)
-                sums = tk_.take(dout, True) if (tk_ is not None and sync2 is None) else None      # delivered by the gradient's last writer?
+                sums = tk_.take(dout, True) if tk_ is not None else None      # delivered by the gradient's last writer? (LOCAL sums: exchanged below under SyncBatchNorm)
                 if sums is None:
                     sums = zeros_f64(R * 3 * c, dev)
                     check(lib().npp_bn_bwd_reduce2_acc(_byref(dout), _byref(a), _byref(b), tref(yrelu), mia.data_ptr(), mib.data_ptr(),
@@ -2370,6 +2442,17 @@ class _BnAdd(Function):
                 return (dxa, dgb_[0] if ni[1] else None, dgb_[1] if ni[2] else None,
                         dxb, dgb_[2] if ni[4] else None, dgb_[3] if ni[5] else None, None, None, None, None, None, None)
             if fused and sync2 is not None:
+                xch = _fold_channel(3 * c, sync2)
+                if xch >= 0:      # the exchange inside the apply's prologue: its leader workgroup writes the LOCAL dgamma / dbeta
+                    dxa = _dx_into(gs[0], a)
+                    dxb = _dx_into(gs[1], b)
+                    check(lib().npp_bn_bwd_apply2_fin_x(_byref(dout), _byref(a), _byref(b), tref(yrelu), sums.data_ptr(), R, float(cnt_a),
+                                                        mia.data_ptr(), mib.data_ptr(), ptr(ga), ptr(gb), dgb_[0].data_ptr(),
+                                                        dgb_[1].data_ptr(), dgb_[2].data_ptr(), dgb_[3].data_ptr(), _byref(dxa),
+                                                        _byref(dxb), xch, s), "npp_bn_bwd_apply2_fin_x")
+                    FOLD_STATS[1] += 1
+                    return (dxa, dgb_[0] if ni[1] else None, dgb_[1] if ni[2] else None,
+                            dxb, dgb_[2] if ni[4] else None, dgb_[3] if ni[5] else None, None, None, None, None, None, None)
                 # local sums -> dbeta (both sides), dgamma_a, dgamma_b; world sums -> replica 0, the other replicas zeroed
                 ok2 = yield ([(sums, 3 * c, R, c, (dgb_[1], dgb_[3], dgb_[0], dgb_[2]), True)], sync2)
                 assert ok2, "peer-to-peer exchange refused a vector it had accepted the size of"
@@ -2425,7 +2508,7 @@ class _BnAdd(Function):
                                                    for i, fs in enumerate(fin_sync))
         tk_ = getattr(ctx, "ticket", None)
         got = None
-        if (tk_ is not None and not tk_.two and len(sides) >= 1 and sides[0][1] is not None and fin[0] and one_bar[0] is None
+        if (tk_ is not None and not tk_.two and len(sides) >= 1 and sides[0][1] is not None and (fin[0] or (p2p_slabs and fin_sync[0])) and one_bar[0] is None
                 and not (has_b and sides[-1][1] is not None and len(sides) > 1)):
             got = tk_.take(dout, False)      # side a's sums were delivered by the gradient's last writer
         red = [((got, R) if (i == 0 and got is not None) else
@@ -2442,6 +2525,16 @@ class _BnAdd(Function):
             grp, ws = _sync_group(bn)
             if grp is not None:
                 sync.append((i, grp, x.shape[1]))
+        folded = [False] * len(sides)
+        if sync and p2p_slabs and P2P_FOLD and not SYNC_MERGE and len({id(g_) for _, g_, _ in sync}) == 1:
+            # every side's exchange inside its own apply launch (phase 3): nothing travels here
+            for i, grp, c in sync:
+                bn_i = sides[i][1]
+                need_g_, need_b_ = sides[i][7], sides[i][8]
+                local[i] = (_grad_buf(bn_i.weight if need_g_ else None, c, dout.device),
+                            _grad_buf(bn_i.bias if need_b_ else None, c, dout.device))
+                folded[i] = grp
+            sync = []
         if sync and p2p_slabs:
             segs = []
             for i, grp, c in sync:
@@ -2501,6 +2594,17 @@ class _BnAdd(Function):
                     check(lib().npp_bn_bwd_one(_byref(dout), _byref(x), sums.data_ptr(), float(count), mi.data_ptr(), ptr(gamma),
                                                ptr(dgt), ptr(dbt), _byref(dx), one_bar[i].data_ptr(), s), "npp_bn_bwd_one")
                     BN_ONE_STATS[0] += 1
+                    outs.append((dx, dg if need_g else None, db if need_b else None))
+                    continue
+                if folded[i]:
+                    xch = _fold_channel(2 * c, folded[i])
+                    if xch < 0:
+                        raise RuntimeError("the mailboxes refused an in-kernel exchange they had accepted the size of")
+                    dx = _dx_into(gs[i], x)
+                    check(lib().npp_bn_bwd_apply_fin_x(_byref(dout), _byref(x), tref(yrelu), sums.data_ptr(), nrep, float(count),
+                                                       mi.data_ptr(), ptr(gamma), dg.data_ptr(), db.data_ptr(), _byref(dx), xch, s),
+                          "npp_bn_bwd_apply_fin_x")
+                    FOLD_STATS[1] += 1
                     outs.append((dx, dg if need_g else None, db if need_b else None))
                     continue
                 if fin[i] or (fin_sync[i] and nrep == 1):
@@ -2572,12 +2676,22 @@ class _BnAddPair(Function):
     def _forward_multi(ctx, n, tens, metas, outs) -> bool:
         """All n applies in ONE launch; False (nothing launched) when one of them is not a fused local apply or the shapes differ."""
         preps = []
+        xch = -1
+        pat = {(tuple(tens[6 * k].shape), tens[6 * k].dtype, tens[6 * k + 3] is None,
+                metas[k][1] is not None and metas[k][1].bn is not None, metas[k][5] is None, metas[k][3]) for k in range(n)}
+        if len(pat) == 1 and all(_fin_fusable(metas[k][0], metas[k][1], tens[6 * k], tens[6 * k + 3], metas[k][3]) for k in range(n)) \
+                and (next(iter(pat))[4] or tens[0].dtype == torch.bfloat16):
+            # one shape, one operand pattern, every apply fusable: under SyncBatchNorm the ONE launch carries the exchange of all jobs
+            xch = _fold_forward([(metas[k][0], metas[k][1]) for k in range(n)], metas[0][3])
         for k in range(n):
             a, _ga, _ba, b, _gb, _bb = tens[6 * k:6 * k + 6]
             sa, sb, relu, training, out, mk = metas[k]
-            _presync_stats((sa, sb), training)
+            if xch < 0:
+                _presync_stats((sa, sb), training)
             pr = _fin_prepare(a, b, sa, sb, training, out)
             if pr is None:
+                if xch >= 0:
+                    raise RuntimeError("a SyncBatchNorm exchange was folded into a multi-job apply that did not take place")
                 return False
             preps.append(pr)
         jobs = (L.NppAffineAddJob * n)()
@@ -2594,11 +2708,13 @@ class _BnAddPair(Function):
             j.relu = int(relu)
             if mk is not None:
                 j.mask_bits, j.ld_mask = mk[0].data_ptr() + mk[1], mk[2]
-        rc = lib().npp_affine_add_fin_multi(C.cast(jobs, C.c_void_p), n, stream_ptr())
-        if rc == L.NPP_E_UNSUPPORTED:
+        rc = lib().npp_affine_add_fin_multi_x(C.cast(jobs, C.c_void_p), n, xch, stream_ptr())
+        if rc == L.NPP_E_UNSUPPORTED and xch < 0:
             return False
-        check(rc, "npp_affine_add_fin_multi")
+        check(rc, "npp_affine_add_fin_multi_x")
         MULTI_STATS[0] += 1
+        if xch >= 0:
+            FOLD_STATS[0] += 1
         subs, saved = [], []
         for k in range(n):
             a, _ga, _ba, b, _gb, _bb = tens[6 * k:6 * k + 6]
@@ -2668,6 +2784,7 @@ class _BnAddPair(Function):
             if not (P2P_DIRECT and FUSE_BN_SYNC and BN_MULTI_SYNC and dev.type == "cuda" and n <= 8
                     and comm.p2p_can(n * (3 if two else 2) * c, sync_grp)):
                 return None
+        xch = _fold_channel(n * (3 if two else 2) * c, sync_grp) if sync_grp is not None else -1      # the exchange inside the apply launch
         jobs = (L.NppBnBwdJob * n)()
         segs = []
         keep, results, need_reduce = [], [], []
@@ -2695,7 +2812,7 @@ class _BnAddPair(Function):
             j.gamma_a = ptr(ga)
             dga = _grad_buf(bna.weight if ni[1] else None, c, dev)
             dba = _grad_buf(bna.bias if ni[2] else None, c, dev)
-            if sync_grp is None:
+            if sync_grp is None or xch >= 0:
                 j.dgamma_a, j.dbeta_a = dga.data_ptr(), dba.data_ptr()
             dgb = dbb = gb = None
             if two:
@@ -2704,9 +2821,9 @@ class _BnAddPair(Function):
                 j.gamma_b = ptr(gb)
                 dgb = _grad_buf(bnb.weight if ni[4] else None, c, dev)
                 dbb = _grad_buf(bnb.bias if ni[5] else None, c, dev)
-                if sync_grp is None:
+                if sync_grp is None or xch >= 0:
                     j.dgamma_b, j.dbeta_b = dgb.data_ptr(), dbb.data_ptr()
-            if sync_grp is not None:      # [0, c): sum dout -> dbeta (of both sides); [c, 2c) -> dgamma_a; [2c, 3c) -> dgamma_b
+            if sync_grp is not None and xch < 0:      # [0, c): sum dout -> dbeta (of both sides); [c, 2c) -> dgamma_a; [2c, 3c) -> dgamma_b
                 segs.append((sums, (3 if two else 2) * c, R, c, (dba, dbb, dga, dgb), True))
             j.sums, j.count = sums.data_ptr(), float(cnt)
             keep.append((sums, ga, gb))
@@ -2741,12 +2858,14 @@ class _BnAddPair(Function):
                 return None
             check(rc, "npp_bn_bwd_reduce_multi")
             MULTI_STATS[1] += 1
-        if sync_grp is not None:
+        if sync_grp is not None and xch < 0:
             if not comm.p2p_exchange_slabs(segs, sync_grp):
                 raise RuntimeError("peer-to-peer exchange refused vectors it had accepted the size of")
             MULTI_STATS[3] += 1
-        check(lib().npp_bn_bwd_apply_multi(C.cast(jobs, C.c_void_p), n, s), "npp_bn_bwd_apply_multi")
+        check(lib().npp_bn_bwd_apply_multi_x(C.cast(jobs, C.c_void_p), n, xch, s), "npp_bn_bwd_apply_multi_x")
         MULTI_STATS[2] += 1
+        if xch >= 0:
+            FOLD_STATS[1] += 1
         out = (None,)
         for r in results:
             out += r

@@ -295,6 +295,18 @@ def p2p_exchange_slabs(segs, group=None):
     return True
 
 
+def p2p_fold_channel(n_doubles, group=None) -> int:
+    """The channel on which a fused BatchNorm kernel of the CURRENT stream carries an exchange of n_doubles inside its prologue
+    (npp_*_x entry points, csrc/p2p_xp.h), counted as an exchange; -1 if the mailboxes cannot take it."""
+    if not p2p_active() or group is not _p2p["group"] or not 0 < n_doubles <= _p2p["cap"]:
+        return -1
+    ch, _st = _p2p_channel()
+    if ch is None:
+        return -1
+    _p2p["count"] += 1
+    return ch
+
+
 def p2p_status() -> int:
     """0, or the error bits of the mailbox channels (1: a poll timed out, 2: a slot was overwritten before it was read).
     Synchronises the device -- every stream, the non-blocking branch / side streams the exchanges run on included."""

@@ -6,6 +6,8 @@
 // and the `h1 + h2` / `s1 + z1` adds (model_augment.py:58,100,443-444).
 #include "vecio.h"
 #include <stdlib.h>
+#include <string.h>
+#include "p2p_xp.h"      // XpArgs: the SyncBatchNorm exchange inside the fused kernels' prologues
 
 namespace {
 
@@ -308,10 +310,17 @@ struct FinSide {
 template <typename T, int V, bool HAS_B, bool FB, bool MASK>
 NPP_DEV void affine_add_fin_kernel_body(T* __restrict__ out, long ldo, const T* __restrict__ a, long lda,
                                                              const T* __restrict__ b, long ldb, FinSide fa, FinSide fb, int relu,
-                                                             long npix, int C, ColMap m, unsigned char* __restrict__ mk, long ldmk, const int BX, const int GX) {
+                                                             long npix, int C, ColMap m, unsigned char* __restrict__ mk, long ldmk, const int BX, const int GX,
+                                                             const XpArgs& xp, const long xoff) {
   extern __shared__ float s_ss[];      // [side][scale C | shift C]
   const int t = threadIdx.x;
   constexpr int NS = (HAS_B && FB) ? 2 : 1;
+  // SyncBatchNorm with the exchange in this prologue (p2p_xp.h): the sums below are the LOCAL ones, the leader workgroup trades them
+  // for the world's (elements [xoff + side 2C, + 2C) of the exchange vector: sum | sum of squares), f.count is the world's count
+  const bool xon = xp.world != 0;
+  XpCtx xc;
+  unsigned xbad = 0u;
+  if (xon) xc = xp_begin(xp);
   // the first pixel pair of this thread is requested BEFORE the prologue: its HBM latency then overlaps the statistics' L2 round trip
   const bool act = t < m.rows * m.cols_blk;
   const int col = t % m.cols_blk, row = t / m.cols_blk;
@@ -330,6 +339,18 @@ NPP_DEV void affine_add_fin_kernel_body(T* __restrict__ out, long ldo, const T* 
       ldv<T, V>(b + q2 * ldb + c0, wb);
     }
   }
+  if (xon)
+    xp_exchange(xp, xc, BX == 0, xoff, NS * 2 * C, xp.flags + blockIdx.z, [&](int j) {
+      const FinSide& f = j >= 2 * C ? fb : fa;
+      const int r2 = j >= 2 * C ? j - 2 * C : j;                   // [sum C | sum of squares C] of the side
+      const long at = r2 >= C ? (long)f.sc + (r2 - C) : (long)r2;  // ... inside a replica row [sum sc | sum of squares sc]
+      double part[NPP_STAT_REPLICAS], v = 0.0;
+#pragma unroll
+      for (int r = 0; r < NPP_STAT_REPLICAS; ++r) part[r] = f.stats[(long)r * 2 * f.sc + at];
+#pragma unroll
+      for (int r = 0; r < NPP_STAT_REPLICAS; ++r) v += part[r];
+      return v;
+    }, xbad);
   for (int idx = t; idx < NS * C; idx += 256) {
     const int side = idx >= C ? 1 : 0, c = idx - side * C;
     const FinSide& f = side ? fb : fa;
@@ -341,6 +362,7 @@ NPP_DEV void affine_add_fin_kernel_body(T* __restrict__ out, long ldo, const T* 
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { s0 += v0[r]; s1 += v1[r]; }
+    if (xon) { s0 = xp_get(xp, xc, xoff + (long)side * 2 * C + c, xbad); s1 = xp_get(xp, xc, xoff + (long)side * 2 * C + C + c, xbad); }
     const double mean = s0 / f.count;
     double var = s1 / f.count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -359,6 +381,7 @@ NPP_DEV void affine_add_fin_kernel_body(T* __restrict__ out, long ldo, const T* 
     }
   }
   __syncthreads();
+  if (xon) xp_end(xp, xc, xbad, gridDim.x * gridDim.y * gridDim.z);
   if (!act) return;
   float sa[V], ta[V], sb[V], tb[V];
 #pragma unroll
@@ -715,9 +738,17 @@ template <typename T, int V>
 NPP_DEV void bn_bwd_apply_fin_kernel_body(const T* __restrict__ dout, long ldd, const T* __restrict__ y,
                                                                long ldy, const T* __restrict__ ro, long ldr,
                                                                const double* __restrict__ sums, int nrep, double inv_count,
-                                                               BwdFinSide f, T* __restrict__ dy, long ldo, long npix, int C, ColMap m, const int BX, const int GX) {
+                                                               BwdFinSide f, T* __restrict__ dy, long ldo, long npix, int C, ColMap m, const int BX, const int GX,
+                                                               const XpArgs& xp, const long xoff) {
   extern __shared__ float s_co[];      // [k1 C | cb C | cc C]
   const int t = threadIdx.x;
+  // SyncBatchNorm with the exchange in this prologue (p2p_xp.h): `sums` are the LOCAL replica slabs; the leader workgroup writes the
+  // local dgamma / dbeta (torch.nn.SyncBatchNorm does not reduce them: DDP averages them) and trades the sums for the world's
+  // (elements [xoff, xoff + 2C) of the exchange vector); inv_count is the world's
+  const bool xon = xp.world != 0;
+  XpCtx xc;
+  unsigned xbad = 0u;
+  if (xon) xc = xp_begin(xp);
   // first pixel pair requested before the prologue (see affine_add_fin_kernel)
   const bool act = t < m.rows * m.cols_blk;
   const int col = t % m.cols_blk, row = t / m.cols_blk;
@@ -736,6 +767,17 @@ NPP_DEV void bn_bwd_apply_fin_kernel_body(const T* __restrict__ dout, long ldd, 
       ldv<T, V>(ro + q2 * ldr + c0, r2);
     }
   }
+  if (xon)
+    xp_exchange(xp, xc, BX == 0, xoff, 2 * C, xp.flags + blockIdx.z, [&](int j) {
+      double part[NPP_STAT_REPLICAS], v = 0.0;
+#pragma unroll
+      for (int r = 0; r < NPP_STAT_REPLICAS; ++r) part[r] = sums[(long)r * 2 * C + j];
+#pragma unroll
+      for (int r = 0; r < NPP_STAT_REPLICAS; ++r) v += part[r];
+      if (j < C) { if (f.dbeta) f.dbeta[j] = (float)v; }              // the LOCAL sums: dbeta | dgamma
+      else if (f.dgamma) f.dgamma[j - C] = (float)v;
+      return v;
+    }, xbad);
   for (int c = t; c < C; c += 256) {
     double s0 = 0.0, s1 = 0.0;
     if (nrep == 1) {      // SyncBatchNorm: the one vector that came back from the all-reduce
@@ -747,6 +789,11 @@ NPP_DEV void bn_bwd_apply_fin_kernel_body(const T* __restrict__ dout, long ldd, 
 #pragma unroll
       for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { s0 += v0[r]; s1 += v1[r]; }
     }
+    if (BX == 0 && !xon) {
+      if (f.dgamma) f.dgamma[c] = (float)s1;
+      if (f.dbeta) f.dbeta[c] = (float)s0;
+    }
+    if (xon) { s0 = xp_get(xp, xc, xoff + c, xbad); s1 = xp_get(xp, xc, xoff + C + c, xbad); }
     const float mean = f.mi[c], invstd = f.mi[C + c];
     const float g = f.gamma ? f.gamma[c] : 1.f;
     const float m0 = (float)(s0 * inv_count), m1 = (float)(s1 * inv_count);
@@ -754,12 +801,9 @@ NPP_DEV void bn_bwd_apply_fin_kernel_body(const T* __restrict__ dout, long ldd, 
     s_co[c] = k1;
     s_co[C + c] = -k1 * invstd * m1;
     s_co[2 * C + c] = k1 * (mean * invstd * m1 - m0);
-    if (BX == 0) {
-      if (f.dgamma) f.dgamma[c] = (float)s1;
-      if (f.dbeta) f.dbeta[c] = (float)s0;
-    }
   }
   __syncthreads();
+  if (xon) xp_end(xp, xc, xbad, gridDim.x * gridDim.y * gridDim.z);
   if (!act) return;
   float ca[V], cb[V], cc[V];
 #pragma unroll
@@ -802,9 +846,15 @@ NPP_DEV void bn_bwd_apply2_fin_kernel_body(const T* __restrict__ dout, long ldd,
                                                                 const T* __restrict__ ro, long ldr, const double* __restrict__ sums,
                                                                 int nrep, double inv_count, BwdFinSide fa, BwdFinSide fb,
                                                                 T* __restrict__ dya, long ldoa, T* __restrict__ dyb, long ldob,
-                                                                long npix, int C, ColMap m, const int BX, const int GX) {
+                                                                long npix, int C, ColMap m, const int BX, const int GX,
+                                                                const XpArgs& xp, const long xoff) {
   extern __shared__ float s_co[];      // side a [k1 | cb | cc], side b [k1 | cb | cc]
   const int t = threadIdx.x;
+  // (exchange in the prologue, see bn_bwd_apply_fin_kernel_body: elements [xoff, xoff + 3C) = sum dout | dgamma a | dgamma b)
+  const bool xon = xp.world != 0;
+  XpCtx xc;
+  unsigned xbad = 0u;
+  if (xon) xc = xp_begin(xp);
   const bool act = t < m.rows * m.cols_blk;
   const int col = t % m.cols_blk, row = t / m.cols_blk;
   const int c0 = col * V;
@@ -817,6 +867,18 @@ NPP_DEV void bn_bwd_apply2_fin_kernel_body(const T* __restrict__ dout, long ldd,
     ldv<T, V>(yb + p * ldb + c0, vb);
     if (ro) ldv<T, V>(ro + p * ldr + c0, r);
   }
+  if (xon)
+    xp_exchange(xp, xc, BX == 0, xoff, 3 * C, xp.flags + blockIdx.z, [&](int j) {
+      double part[NPP_STAT_REPLICAS], v = 0.0;
+#pragma unroll
+      for (int r = 0; r < NPP_STAT_REPLICAS; ++r) part[r] = sums[(long)r * 3 * C + j];
+#pragma unroll
+      for (int r = 0; r < NPP_STAT_REPLICAS; ++r) v += part[r];
+      if (j < C) { if (fa.dbeta) fa.dbeta[j] = (float)v; if (fb.dbeta) fb.dbeta[j] = (float)v; }      // the LOCAL sums
+      else if (j < 2 * C) { if (fa.dgamma) fa.dgamma[j - C] = (float)v; }
+      else if (fb.dgamma) fb.dgamma[j - 2 * C] = (float)v;
+      return v;
+    }, xbad);
   for (int idx = t; idx < 2 * C; idx += 256) {
     const int side = idx >= C ? 1 : 0, c = idx - side * C;
     const BwdFinSide& f = side ? fb : fa;
@@ -826,6 +888,11 @@ NPP_DEV void bn_bwd_apply2_fin_kernel_body(const T* __restrict__ dout, long ldd,
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int r = 0; r < NPP_STAT_REPLICAS; ++r) { s0 += v0[r]; s1 += v1[r]; }
+    if (BX == 0 && !xon) {
+      if (f.dgamma) f.dgamma[c] = (float)s1;
+      if (f.dbeta) f.dbeta[c] = (float)s0;
+    }
+    if (xon) { s0 = xp_get(xp, xc, xoff + c, xbad); s1 = xp_get(xp, xc, xoff + (long)(side + 1) * C + c, xbad); }
     const float mean = f.mi[c], invstd = f.mi[C + c];
     const float g = f.gamma ? f.gamma[c] : 1.f;
     const float m0 = (float)(s0 * inv_count), m1 = (float)(s1 * inv_count);
@@ -833,12 +900,9 @@ NPP_DEV void bn_bwd_apply2_fin_kernel_body(const T* __restrict__ dout, long ldd,
     s_co[side * 3 * C + c] = k1;
     s_co[side * 3 * C + C + c] = -k1 * invstd * m1;
     s_co[side * 3 * C + 2 * C + c] = k1 * (mean * invstd * m1 - m0);
-    if (BX == 0) {
-      if (f.dgamma) f.dgamma[c] = (float)s1;
-      if (f.dbeta) f.dbeta[c] = (float)s0;
-    }
   }
   __syncthreads();
+  if (xon) xp_end(xp, xc, xbad, gridDim.x * gridDim.y * gridDim.z);
   if (!act) return;
   float aa[V], ab[V], ac[V], ba[V], bb[V], bc[V];
 #pragma unroll
@@ -876,8 +940,8 @@ NPP_DEV void bn_bwd_apply2_fin_kernel_body(const T* __restrict__ dout, long ldd,
 template <typename T, int V, bool HAS_B, bool FB, bool MASK>
 __global__ __launch_bounds__(256) void affine_add_fin_kernel(T* __restrict__ out, long ldo, const T* __restrict__ a, long lda,
                                                              const T* __restrict__ b, long ldb, FinSide fa, FinSide fb, int relu,
-                                                             long npix, int C, ColMap m, unsigned char* __restrict__ mk, long ldmk) {
-  affine_add_fin_kernel_body<T, V, HAS_B, FB, MASK>(out, ldo, a, lda, b, ldb, fa, fb, relu, npix, C, m, mk, ldmk, blockIdx.x, gridDim.x);
+                                                             long npix, int C, ColMap m, unsigned char* __restrict__ mk, long ldmk, XpArgs xp) {
+  affine_add_fin_kernel_body<T, V, HAS_B, FB, MASK>(out, ldo, a, lda, b, ldb, fa, fb, relu, npix, C, m, mk, ldmk, blockIdx.x, gridDim.x, xp, 0L);
 }
 template <typename T, int V, bool HAS_RO, bool ACC = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y, long ldy,
@@ -896,17 +960,17 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ y, long ldy,
                                                                const T* __restrict__ ro, long ldr, const double* __restrict__ sums,
                                                                int nrep, double inv_count, BwdFinSide f, T* __restrict__ dy, long ldo,
-                                                               long npix, int C, ColMap m) {
-  bn_bwd_apply_fin_kernel_body<T, V>(dout, ldd, y, ldy, ro, ldr, sums, nrep, inv_count, f, dy, ldo, npix, C, m, blockIdx.x, gridDim.x);
+                                                               long npix, int C, ColMap m, XpArgs xp) {
+  bn_bwd_apply_fin_kernel_body<T, V>(dout, ldd, y, ldy, ro, ldr, sums, nrep, inv_count, f, dy, ldo, npix, C, m, blockIdx.x, gridDim.x, xp, 0L);
 }
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply2_fin_kernel(const T* __restrict__ dout, long ldd, const T* __restrict__ ya, long lda,
                                                                 const T* __restrict__ yb, long ldb, const T* __restrict__ ro, long ldr,
                                                                 const double* __restrict__ sums, int nrep, double inv_count,
                                                                 BwdFinSide fa, BwdFinSide fb, T* __restrict__ dya, long ldoa,
-                                                                T* __restrict__ dyb, long ldob, long npix, int C, ColMap m) {
+                                                                T* __restrict__ dyb, long ldob, long npix, int C, ColMap m, XpArgs xp) {
   bn_bwd_apply2_fin_kernel_body<T, V>(dout, ldd, ya, lda, yb, ldb, ro, ldr, sums, nrep, inv_count, fa, fb, dya, ldoa, dyb, ldob, npix, C,
-                                      m, blockIdx.x, gridDim.x);
+                                      m, blockIdx.x, gridDim.x, xp, 0L);
 }
 
 constexpr int BN_MULTI_MAX = 4;
@@ -916,10 +980,12 @@ struct AffJob {
 };
 struct AffJobs { AffJob j[BN_MULTI_MAX]; };
 template <typename T, int V, bool HAS_B, bool FB, bool MASK>
-__global__ __launch_bounds__(256) void affine_add_fin_multi_kernel(AffJobs js, long npix, int C, ColMap m) {
+__global__ __launch_bounds__(256) void affine_add_fin_multi_kernel(AffJobs js, long npix, int C, ColMap m, XpArgs xp) {
   const AffJob& q = js.j[blockIdx.z];
+  // (exchange in the prologue: job z owns elements [z NS 2C, (z + 1) NS 2C) of the exchange vector, its leader is ITS workgroup 0)
   affine_add_fin_kernel_body<T, V, HAS_B, FB, MASK>((T*)q.out, q.ldo, (const T*)q.a, q.lda, (const T*)q.b, q.ldb, q.fa, q.fb, q.relu, npix,
-                                                    C, m, q.mk, q.ldmk, blockIdx.x, gridDim.x);
+                                                    C, m, q.mk, q.ldmk, blockIdx.x, gridDim.x, xp,
+                                                    (long)blockIdx.z * ((HAS_B && FB) ? 4 : 2) * C);
 }
 struct BwdJob {
   const void* dout; const void* ya; const void* yb; const void* ro; void* dya; void* dyb;
@@ -940,15 +1006,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_multi_kernel(BwdJobs js, lo
                                                   m, q.sums, blockIdx.x, gridDim.x);
 }
 template <typename T, int V, bool TWO>
-__global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BwdJobs js, long npix, int C, ColMap m) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BwdJobs js, long npix, int C, ColMap m, XpArgs xp) {
   const BwdJob& q = js.j[blockIdx.z];
   if constexpr (TWO)
     bn_bwd_apply2_fin_kernel_body<T, V>((const T*)q.dout, q.ldd, (const T*)q.ya, q.lda, (const T*)q.yb, q.ldb, (const T*)q.ro, q.ldr, q.sums,
                                         NPP_STAT_REPLICAS, q.inv_count, q.fa, q.fb, (T*)q.dya, q.ldoa, (T*)q.dyb, q.ldob, npix, C, m,
-                                        blockIdx.x, gridDim.x);
+                                        blockIdx.x, gridDim.x, xp, (long)blockIdx.z * 3 * C);
   else
     bn_bwd_apply_fin_kernel_body<T, V>((const T*)q.dout, q.ldd, (const T*)q.ya, q.lda, (const T*)q.ro, q.ldr, q.sums, NPP_STAT_REPLICAS,
-                                       q.inv_count, q.fa, (T*)q.dya, q.ldoa, npix, C, m, blockIdx.x, gridDim.x);
+                                       q.inv_count, q.fa, (T*)q.dya, q.ldoa, npix, C, m, blockIdx.x, gridDim.x, xp, (long)blockIdx.z * 2 * C);
 }
 
 // ---- N-sided weighted BatchNorm sum (npp_mix_bn_*): the mixed edge of the search supernet ------------------------------------------
@@ -1362,8 +1428,18 @@ static inline FinSide fin_side(const NppBnFinalizeArgs* f) {
 // out = relu?( BN_a(a) [+ BN_b(b) | + b] ) with the finalize of the BatchNorm side(s) done in the kernel's prologue (fin_a required;
 // fin_b NULL: b, if any, is added as is).  scale_shift of the argument structs is not written.  NPP_E_UNSUPPORTED (nothing launched)
 // for the layouts the fused kernel does not take -- the caller then runs npp_bn_finalize + npp_affine_add.
-extern "C" int npp_affine_add_fin(NppTensor* out, const NppTensor* a, const NppBnFinalizeArgs* fin_a, const NppTensor* b,
-                                  const NppBnFinalizeArgs* fin_b, int relu, unsigned char* mask_bits, int64_t ld_mask, void* stream) {
+
+// channel >= 0: the SyncBatchNorm statistics exchange runs inside the launch's prologue (p2p_xp.h) on that mailbox channel, as the
+// channel's next exchange: n_doubles elements.  channel < 0: no exchange.  NPP_E_UNSUPPORTED before anything is launched.
+static int xp_for(int channel, long n_doubles, XpArgs* x) {
+  npp_xp_off(x);
+  if (channel < 0) return NPP_OK;
+  return npp_p2p_xp_args(channel, n_doubles, x);
+}
+
+extern "C" int npp_affine_add_fin_x(NppTensor* out, const NppTensor* a, const NppBnFinalizeArgs* fin_a, const NppTensor* b,
+                                    const NppBnFinalizeArgs* fin_b, int relu, unsigned char* mask_bits, int64_t ld_mask, int channel,
+                                    void* stream) {
   NPP_REQUIRE(out && a && out->ptr && a->ptr && fin_a && fin_a->stats, NPP_E_NULL, "npp_affine_add_fin: null pointer");
   NPP_REQUIRE(same_shape(out, a) && (!b || same_shape(out, b)), NPP_E_SHAPE, "npp_affine_add_fin: shape mismatch");
   NPP_REQUIRE(dtype_ok(out) && out->dtype == a->dtype && (!b || b->dtype == a->dtype), NPP_E_DTYPE, "npp_affine_add_fin: dtype mismatch");
@@ -1380,11 +1456,13 @@ extern "C" int npp_affine_add_fin(NppTensor* out, const NppTensor* a, const NppB
   FinSide fb = fa;
   if (fin_b) { fb = fin_side(fin_b); fb.sc = fin_b->stats_c > 0 ? fin_b->stats_c : (int)out->c; }
   NPP_REQUIRE(fa.sc >= out->c && fb.sc >= out->c, NPP_E_SHAPE, "npp_affine_add_fin: stats_c below the channel count");
+  XpArgs xp;
+  { const int xrc = xp_for(channel, (long)(fin_b ? 4 : 2) * out->c, &xp); if (xrc != NPP_OK) return xrc; }
   const size_t lds = (size_t)(fin_b ? 4 : 2) * out->c * sizeof(float);
 #define AFN(HB, FB_, MK)                                                                                                   \
     hipLaunchKernelGGL((affine_add_fin_kernel<T, V, HB, FB_, MK>), grid, dim3(256), lds, (hipStream_t)stream, (T*)out->ptr,  \
                        (long)out->ld, (const T*)a->ptr, (long)a->ld, b ? (const T*)b->ptr : nullptr, b ? (long)b->ld : 0L,  \
-                       fa, fb, relu, (long)npix(out), (int)out->c, m, mask_bits, (long)ld_mask)
+                       fa, fb, relu, (long)npix(out), (int)out->c, m, mask_bits, (long)ld_mask, xp)
 #define AFN_ALL(MK)                                                                                                        \
     do {                                                                                                                   \
       ColMap m = col_map(out->c, V);                                                                                       \
@@ -1405,6 +1483,10 @@ extern "C" int npp_affine_add_fin(NppTensor* out, const NppTensor* a, const NppB
 #undef AFN_ALL
 #undef AFN
   return npp_check_launch("affine_add_fin");
+}
+extern "C" int npp_affine_add_fin(NppTensor* out, const NppTensor* a, const NppBnFinalizeArgs* fin_a, const NppTensor* b,
+                                  const NppBnFinalizeArgs* fin_b, int relu, unsigned char* mask_bits, int64_t ld_mask, void* stream) {
+  return npp_affine_add_fin_x(out, a, fin_a, b, fin_b, relu, mask_bits, ld_mask, -1, stream);
 }
 
 static inline int reduce_blocks(long npix, long c, int dtype) {
@@ -1607,15 +1689,18 @@ extern "C" int npp_bn_bwd_reduce2_acc(const NppTensor* dout, const NppTensor* ya
   return npp_check_launch("bn_bwd_reduce2_acc");
 }
 
-extern "C" int npp_bn_bwd_apply_fin(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out, const double* sums,
-                                    int nrep, double count, const float* mean_invstd, const float* gamma, float* dgamma, float* dbeta,
-                                    NppTensor* dy_raw, void* stream) {
+extern "C" int npp_bn_bwd_apply_fin_x(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out, const double* sums,
+                                      int nrep, double count, const float* mean_invstd, const float* gamma, float* dgamma, float* dbeta,
+                                      NppTensor* dy_raw, int channel, void* stream) {
   NPP_REQUIRE(dout && y_raw && sums && mean_invstd && dy_raw && nrep >= 1 && count > 0, NPP_E_NULL, "npp_bn_bwd_apply_fin: bad arguments");
   NPP_REQUIRE(same_shape(dout, y_raw) && same_shape(dout, dy_raw) && (!relu_out || same_shape(dout, relu_out)), NPP_E_SHAPE,
               "npp_bn_bwd_apply_fin: shape mismatch");
   NPP_REQUIRE(dtype_ok(dout) && dout->dtype == y_raw->dtype && dout->dtype == dy_raw->dtype && (!relu_out || relu_out->dtype == dout->dtype),
               NPP_E_DTYPE, "npp_bn_bwd_apply_fin: dtype mismatch");
   if (!fused_ok(dout) || !fused_ok(y_raw) || !fused_ok(dy_raw) || (relu_out && !fused_ok(relu_out)) || (nrep != NPP_STAT_REPLICAS && nrep != 1)) return NPP_E_UNSUPPORTED;
+  if (channel >= 0 && nrep != NPP_STAT_REPLICAS) return NPP_E_UNSUPPORTED;      // (the in-kernel exchange collapses the local replica slabs)
+  XpArgs xp;
+  { const int xrc = xp_for(channel, 2L * dout->c, &xp); if (xrc != NPP_OK) return xrc; }
   ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 3);
   BwdFinSide f{mean_invstd, gamma, dgamma, dbeta};
   NPP_DISPATCH_TV(dout->dtype, true, {
@@ -1625,15 +1710,20 @@ extern "C" int npp_bn_bwd_apply_fin(const NppTensor* dout, const NppTensor* y_ra
     hipLaunchKernelGGL((bn_bwd_apply_fin_kernel<T, V>), grid, dim3(256), (size_t)3 * dout->c * sizeof(float), (hipStream_t)stream,
                        (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
                        relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, sums, nrep, 1.0 / count, f,
-                       (T*)dy_raw->ptr, (long)dy_raw->ld, (long)npix(dout), (int)dout->c, m);
+                       (T*)dy_raw->ptr, (long)dy_raw->ld, (long)npix(dout), (int)dout->c, m, xp);
   });
   return npp_check_launch("bn_bwd_apply_fin");
 }
+extern "C" int npp_bn_bwd_apply_fin(const NppTensor* dout, const NppTensor* y_raw, const NppTensor* relu_out, const double* sums,
+                                    int nrep, double count, const float* mean_invstd, const float* gamma, float* dgamma, float* dbeta,
+                                    NppTensor* dy_raw, void* stream) {
+  return npp_bn_bwd_apply_fin_x(dout, y_raw, relu_out, sums, nrep, count, mean_invstd, gamma, dgamma, dbeta, dy_raw, -1, stream);
+}
 
-extern "C" int npp_bn_bwd_apply2_fin(const NppTensor* dout, const NppTensor* ya, const NppTensor* yb, const NppTensor* relu_out,
-                                     const double* sums, int nrep, double count, const float* mi_a, const float* mi_b,
-                                     const float* gamma_a, const float* gamma_b, float* dgamma_a, float* dbeta_a, float* dgamma_b,
-                                     float* dbeta_b, NppTensor* dya, NppTensor* dyb, void* stream) {
+extern "C" int npp_bn_bwd_apply2_fin_x(const NppTensor* dout, const NppTensor* ya, const NppTensor* yb, const NppTensor* relu_out,
+                                       const double* sums, int nrep, double count, const float* mi_a, const float* mi_b,
+                                       const float* gamma_a, const float* gamma_b, float* dgamma_a, float* dbeta_a, float* dgamma_b,
+                                       float* dbeta_b, NppTensor* dya, NppTensor* dyb, int channel, void* stream) {
   NPP_REQUIRE(dout && ya && yb && sums && mi_a && mi_b && dya && dyb && nrep >= 1 && count > 0, NPP_E_NULL,
               "npp_bn_bwd_apply2_fin: bad arguments");
   NPP_REQUIRE(same_shape(dout, ya) && same_shape(dout, yb) && same_shape(dout, dya) && same_shape(dout, dyb) &&
@@ -1642,6 +1732,8 @@ extern "C" int npp_bn_bwd_apply2_fin(const NppTensor* dout, const NppTensor* ya,
               dout->dtype == dyb->dtype && (!relu_out || relu_out->dtype == dout->dtype), NPP_E_DTYPE, "npp_bn_bwd_apply2_fin: dtype mismatch");
   if (!fused_ok(dout) || !fused_ok(ya) || !fused_ok(yb) || !fused_ok(dya) || !fused_ok(dyb) || (relu_out && !fused_ok(relu_out)) || nrep != NPP_STAT_REPLICAS)
     return NPP_E_UNSUPPORTED;
+  XpArgs xp;
+  { const int xrc = xp_for(channel, 3L * dout->c, &xp); if (xrc != NPP_OK) return xrc; }
   ProfScope prof(NPP_FAM_BN, dout->dtype, (hipStream_t)stream, 0, (double)npix(dout) * dout->c * esize(dout->dtype) * 5);
   BwdFinSide fa{mi_a, gamma_a, dgamma_a, dbeta_a}, fb{mi_b, gamma_b, dgamma_b, dbeta_b};
   NPP_DISPATCH_TV(dout->dtype, true, {
@@ -1651,16 +1743,23 @@ extern "C" int npp_bn_bwd_apply2_fin(const NppTensor* dout, const NppTensor* ya,
     hipLaunchKernelGGL((bn_bwd_apply2_fin_kernel<T, V>), grid, dim3(256), (size_t)6 * dout->c * sizeof(float), (hipStream_t)stream,
                        (const T*)dout->ptr, (long)dout->ld, (const T*)ya->ptr, (long)ya->ld, (const T*)yb->ptr, (long)yb->ld,
                        relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, sums, nrep, 1.0 / count, fa, fb,
-                       (T*)dya->ptr, (long)dya->ld, (T*)dyb->ptr, (long)dyb->ld, (long)npix(dout), (int)dout->c, m);
+                       (T*)dya->ptr, (long)dya->ld, (T*)dyb->ptr, (long)dyb->ld, (long)npix(dout), (int)dout->c, m, xp);
   });
   return npp_check_launch("bn_bwd_apply2_fin");
+}
+extern "C" int npp_bn_bwd_apply2_fin(const NppTensor* dout, const NppTensor* ya, const NppTensor* yb, const NppTensor* relu_out,
+                                     const double* sums, int nrep, double count, const float* mi_a, const float* mi_b,
+                                     const float* gamma_a, const float* gamma_b, float* dgamma_a, float* dbeta_a, float* dgamma_b,
+                                     float* dbeta_b, NppTensor* dya, NppTensor* dyb, void* stream) {
+  return npp_bn_bwd_apply2_fin_x(dout, ya, yb, relu_out, sums, nrep, count, mi_a, mi_b, gamma_a, gamma_b, dgamma_a, dbeta_a, dgamma_b, dbeta_b,
+                                 dya, dyb, -1, stream);
 }
 
 // ---- up to NPP_BN_MULTI_MAX independent jobs of ONE shape per launch (see affine_add_fin_multi_kernel) ------------------------------
 // All jobs: the same n, h, w, c and dtype, the same operand pattern (second operand or not, BatchNorm on it or not, bit-mask or not;
 // backward: one- or two-sided, ReLU mask or not) and layouts the fused kernels take.  NPP_E_UNSUPPORTED (nothing launched) otherwise:
 // the caller launches the jobs one by one.
-extern "C" int npp_affine_add_fin_multi(const NppAffineAddJob* jobs, int njobs, void* stream) {
+extern "C" int npp_affine_add_fin_multi_x(const NppAffineAddJob* jobs, int njobs, int channel, void* stream) {
   NPP_REQUIRE(jobs && njobs >= 1, NPP_E_NULL, "npp_affine_add_fin_multi: no jobs");
   if (njobs > BN_MULTI_MAX) return NPP_E_UNSUPPORTED;
   const NppAffineAddJob& j0 = jobs[0];
@@ -1691,11 +1790,13 @@ extern "C" int npp_affine_add_fin_multi(const NppAffineAddJob* jobs, int njobs, 
     d.relu = q.relu; d.mk = q.mask_bits; d.ldmk = q.ld_mask;
   }
   for (int i = njobs; i < BN_MULTI_MAX; ++i) js.j[i] = js.j[0];
+  XpArgs xp;
+  { const int xrc = xp_for(channel, (long)njobs * (fb_ ? 4 : 2) * ref->c, &xp); if (xrc != NPP_OK) return xrc; }
   const int nt = has_b ? 3 : 2;
   ProfScope prof(NPP_FAM_ELTWISE, ref->dtype, (hipStream_t)stream, 0, (double)npix(ref) * ref->c * esize(ref->dtype) * nt * njobs);
   const size_t lds = (size_t)(fb_ ? 4 : 2) * ref->c * sizeof(float);
 #define AFM(HB, FB_, MK) \
-    hipLaunchKernelGGL((affine_add_fin_multi_kernel<T, V, HB, FB_, MK>), grid, dim3(256), lds, (hipStream_t)stream, js, (long)npix(ref), (int)ref->c, m)
+    hipLaunchKernelGGL((affine_add_fin_multi_kernel<T, V, HB, FB_, MK>), grid, dim3(256), lds, (hipStream_t)stream, js, (long)npix(ref), (int)ref->c, m, xp)
 #define AFM_ALL(MK)                                                                                                        \
     do {                                                                                                                   \
       ColMap m = col_map(ref->c, V);                                                                                       \
@@ -1718,6 +1819,9 @@ extern "C" int npp_affine_add_fin_multi(const NppAffineAddJob* jobs, int njobs, 
 #undef AFM_ALL
 #undef AFM
   return npp_check_launch("affine_add_fin_multi");
+}
+extern "C" int npp_affine_add_fin_multi(const NppAffineAddJob* jobs, int njobs, void* stream) {
+  return npp_affine_add_fin_multi_x(jobs, njobs, -1, stream);
 }
 
 static int bwd_jobs_fill(const NppBnBwdJob* jobs, int njobs, BwdJobs& js, bool& two, bool& has_ro, const char* who, bool need_out) {
@@ -1773,12 +1877,14 @@ extern "C" int npp_bn_bwd_reduce_multi(const NppBnBwdJob* jobs, int njobs, int n
   return npp_check_launch("bn_bwd_reduce_multi");
 }
 
-extern "C" int npp_bn_bwd_apply_multi(const NppBnBwdJob* jobs, int njobs, void* stream) {
+extern "C" int npp_bn_bwd_apply_multi_x(const NppBnBwdJob* jobs, int njobs, int channel, void* stream) {
   BwdJobs js;
   bool two, has_ro;
   const int rc = bwd_jobs_fill(jobs, njobs, js, two, has_ro, "npp_bn_bwd_apply_multi", true);
   if (rc != NPP_OK) return rc;
   const NppTensor* ref = &jobs[0].dout;
+  XpArgs xp;
+  { const int xrc = xp_for(channel, (long)njobs * (two ? 3 : 2) * ref->c, &xp); if (xrc != NPP_OK) return xrc; }
   ProfScope prof(NPP_FAM_BN, ref->dtype, (hipStream_t)stream, 0, (double)npix(ref) * ref->c * esize(ref->dtype) * (two ? 5 : 3) * njobs);
   NPP_DISPATCH_TV(ref->dtype, true, {
     ColMap m = col_map(ref->c, V);
@@ -1787,12 +1893,15 @@ extern "C" int npp_bn_bwd_apply_multi(const NppBnBwdJob* jobs, int njobs, void* 
     grid.z = (unsigned)njobs;
     if (two)
       hipLaunchKernelGGL((bn_bwd_apply_multi_kernel<T, V, true>), grid, dim3(256), (size_t)6 * ref->c * sizeof(float), (hipStream_t)stream, js,
-                         (long)npix(ref), (int)ref->c, m);
+                         (long)npix(ref), (int)ref->c, m, xp);
     else
       hipLaunchKernelGGL((bn_bwd_apply_multi_kernel<T, V, false>), grid, dim3(256), (size_t)3 * ref->c * sizeof(float), (hipStream_t)stream, js,
-                         (long)npix(ref), (int)ref->c, m);
+                         (long)npix(ref), (int)ref->c, m, xp);
   });
   return npp_check_launch("bn_bwd_apply_multi");
+}
+extern "C" int npp_bn_bwd_apply_multi(const NppBnBwdJob* jobs, int njobs, void* stream) {
+  return npp_bn_bwd_apply_multi_x(jobs, njobs, -1, stream);
 }
 
 // ---- N-sided weighted BatchNorm sum (the search supernet's mixed edge), see mix_bn_fwd_kernel ---------------------------------------

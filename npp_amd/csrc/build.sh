@@ -24,7 +24,9 @@ for s in $SRCS; do
   [ -f "$s" ] || continue
   o=build/${s%.hip}.o
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_params.h -nt "$o" ] || [ conv_epi.h -nt "$o" ] || [ conv_wgrad_params.h -nt "$o" ] || [ vecio.h -nt "$o" ] || [ ../../include/npp_hip.h -nt "$o" ]; then
+  stale=0      # any header newer than the object: rebuild (a struct shared by two translation units must never come from two versions)
+  for h in *.h ../../include/npp_hip.h; do [ "$h" -nt "$o" ] && stale=1; done
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ $stale = 1 ]; then
     hipcc --offload-arch=gfx950 -O3 -fPIC -munsafe-fp-atomics -std=c++17 -Wno-unused-result -DNPP_SRC_HASH=\"$SRC_HASH\" $NPP_EXTRA_HIPCC_FLAGS -c "$s" -o "$o" &
     pids+=($!)
   fi

@@ -33,11 +33,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include "p2p_xp.h"      // P2P_SLOTS, P2P_MAX_WORLD; the in-kernel form of the exchange (the fused BatchNorm kernels of bn.hip)
 
 namespace {
 
-constexpr int P2P_SLOTS = 4;
-constexpr int P2P_MAX_WORLD = 16;
 constexpr int P2P_MAX_CHANNELS = 4;
 constexpr int P2P_MAX_BLOCKS = 8;      // workgroups of one exchange: each owns an interleaved share of the vector
 
@@ -58,6 +57,7 @@ struct P2P {
   Channel ch[P2P_MAX_CHANNELS];
   long long timeout_ticks = 0;
   int alloc_kind = -1;           // 0 uncached, 1 fine-grained, 2 plain device memory
+  unsigned long long* res = nullptr;      // [nchan][cap][2 units]: the result vectors of the in-kernel exchanges (p2p_xp.h), plain device memory
 } g;
 
 size_t mailbox_bytes(long cap, int world) {
@@ -242,6 +242,16 @@ extern "C" int npp_p2p_alloc(int rank, int world, int64_t cap_doubles, int chann
     npp_set_error("npp_p2p_alloc: cannot zero the mailboxes");
     return NPP_E_HIP;
   }
+  void* res = nullptr;
+  // per channel: [cap][2 units] results, then the XP_SUB first-level counters
+  const size_t res_bytes = (size_t)channels * (cap_doubles * 2 + XP_SUB * XP_SUB_STRIDE) * sizeof(unsigned long long);
+  if (hipMalloc(&res, res_bytes) != hipSuccess || hipMemset(res, 0, res_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError(); (void)hipFree(p);
+    if (res) (void)hipFree(res);
+    npp_set_error("npp_p2p_alloc: cannot allocate the result vectors");
+    return NPP_E_HIP;
+  }
+  g.res = static_cast<unsigned long long*>(res);
   memcpy(handle_out, &h, sizeof(h));
   g.local = p; g.bytes = bytes; g.rank = rank; g.world = world; g.cap = cap_doubles; g.nchan = channels;
   for (int r = 0; r < P2P_MAX_WORLD; ++r) g.peers[r] = nullptr;
@@ -399,7 +409,29 @@ extern "C" int npp_p2p_close(void) {
   for (int r = 0; r < g.world; ++r)
     if (r != g.rank && g.peers[r]) (void)hipIpcCloseMemHandle(g.peers[r]);
   (void)hipFree(g.local);
+  if (g.res) (void)hipFree(g.res);
   (void)hipGetLastError();
   g = P2P();
+  return NPP_OK;
+}
+
+// The arguments of an in-kernel exchange (p2p_xp.h) of n_doubles on `channel`: the fused BatchNorm entry points of bn.hip call this
+// when the caller names a channel.  The exchange takes the channel's next sequence number exactly as a launch of npp_p2p_exchange*
+// on the same stream would.
+int npp_p2p_xp_args(int channel, long n_doubles, XpArgs* out) {
+  NPP_REQUIRE(out, NPP_E_NULL, "npp_p2p_xp_args: null");
+  NPP_REQUIRE(g.local && g.res && channel >= 0 && channel < g.nchan, NPP_E_UNSUPPORTED, "in-kernel exchange: no mailboxes / bad channel %d", channel);
+  if (n_doubles <= 0 || n_doubles > g.cap) {
+    npp_set_error("in-kernel exchange: %ld doubles exceed the mailbox capacity %ld", n_doubles, g.cap);
+    return NPP_E_UNSUPPORTED;
+  }
+  for (int r = 0; r < g.world; ++r)
+    NPP_REQUIRE(g.peers[r], NPP_E_UNSUPPORTED, "in-kernel exchange: rank %d's mailbox is not mapped (npp_p2p_open)", r);
+  const Channel& c = g.ch[channel];
+  for (int r = 0; r < P2P_MAX_WORLD; ++r) out->peer_data[r] = r < g.world ? c.data[r] : nullptr;
+  out->seq = c.seq; out->err = c.err; out->res = g.res + (size_t)channel * (g.cap * 2 + XP_SUB * XP_SUB_STRIDE);
+  out->sub = out->res + g.cap * 2;
+  out->flags = c.seq + 2;      // (the 64-byte block of the channel's counter: [0] number, [1] done count, [2 .. 2 + XP_MAX_JOBS) flags)
+  out->cap = g.cap; out->timeout_ticks = g.timeout_ticks; out->me = g.rank; out->world = g.world; out->light = p2p_light(); out->pad = 0;
   return NPP_OK;
 }

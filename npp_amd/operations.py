@@ -240,6 +240,10 @@ class WideEdges(K.WideGroup):
                 run = next(r for r, members in enumerate(self.runs) if i in members)
                 sides.append(BnSide(ys[i], bns[i], svs[i], stats_c=scs[i], gslot=slots[i], rider=run in lead))
                 lead.setdefault(run, i)
+            for members in self.runs:      # (K._fold_forward: who carries a run's rows once its lead edge's exchange is folded into a kernel)
+                mates = [sides[i] for i in members]
+                for sd in mates:
+                    sd.mates = mates
             cur = torch.cuda.current_stream()
             ev = torch.cuda.Event()
             ev.record(cur)
