@@ -1946,7 +1946,7 @@ class BnSide:
     """One operand of the fused add.  kind 'bn': `x` is a raw (pre-BN) tensor with f64 stats (train) or a
     BatchNorm holder in eval mode; kind 'plain': `x` is used as is."""
 
-    __slots__ = ("x", "bn", "stats", "count", "synced_ws", "private", "stream", "sync_event", "stats_c", "gslot", "rider", "ticket", "mates", "carry")
+    __slots__ = ("x", "bn", "stats", "count", "synced_ws", "private", "stream", "sync_event", "stats_c", "gslot", "rider", "ticket", "mates", "carry", "home")
 
     def __init__(self, x, bn=None, stats=None, private=None, stats_c=0, gslot=None, rider=False):
         self.x = x
@@ -1961,6 +1961,7 @@ class BnSide:
         self.rider = bool(rider)
         self.mates = None           # merged edges: every side of this side's run (statistics row), itself included
         self.carry = None           # a rider promoted to carrier (its lead edge's exchange was folded into a kernel): the run's full rows
+        self.home = None            # raw handle of the stream whose sync pool holds the un-exchanged statistics
         # private: `x` was produced for this operand alone (a raw conv / pool output on its way into its BatchNorm), so it
         # needs no fan-out node (take): ~600 autograd nodes per step less on the host
         self.private = (bn is not None) if private is None else bool(private)
@@ -1973,6 +1974,8 @@ class BnSide:
             grp, ws = _sync_group(bn)
             if grp is not None:
                 _sync_pool.cur().enlist(self, grp, ws)
+                if x.is_cuda:
+                    self.home = torch.cuda.current_stream().cuda_stream
 
 
 _SYNC_EVEN_ALONE = False   # test hook: run the SyncBN collectives on a 1-rank group (bench.py --force-dist)
@@ -2013,6 +2016,30 @@ def _fold_channel(n_doubles, grp):
     return comm.p2p_fold_channel(n_doubles, grp)
 
 
+def _leave_pool(sd, pools=None):
+    """Take `sd` off the waiting list of the sync pool that holds its statistics (it is exchanged on its own: inside a fused kernel, or
+    alone).  If it was the lead edge of a merged run, the run's next waiting edge carries the rows from now on."""
+    for pl in (_sync_pool.all() if pools is None else pools):
+        if any(w is sd for w in pl.waiting):
+            pl.waiting = [w for w in pl.waiting if w is not sd]
+            if not sd.rider and sd.mates:
+                nxt = next((mt for mt in sd.mates if mt is not sd and not mt.synced_ws and any(w is mt for w in pl.waiting)), None)
+                if nxt is not None:
+                    nxt.rider = False
+                    nxt.carry = sd.carry if sd.carry is not None else sd.stats
+            return pl
+    return None
+
+
+def fold_ready(grp) -> bool:
+    """The fused BatchNorm kernels can carry the exchanges of SyncBatchNorms of `grp` themselves (operations.WideEdges: merged edges
+    whose members are picked up on two streams are only possible then -- each consumer exchanges its own slice on its own channel)."""
+    if not (P2P_FOLD and P2P_DIRECT and FUSE_BN_SYNC and FUSE_BN_FIN and not SYNC_MERGE):
+        return False
+    from . import comm
+    return comm.p2p_active() and grp is comm._p2p["group"]
+
+
 def _fold_forward(launch_sides, training: bool):
     """launch_sides: the (sa, sb) pairs of ONE fused apply launch.  If every BatchNorm side is a SyncBatchNorm of one group whose
     statistics are still local (written by the producing kernel into NPP_STAT_REPLICAS slabs) and the mailboxes take the vector, the
@@ -2046,16 +2073,7 @@ def _fold_forward(launch_sides, training: bool):
         return -1
     pools = _sync_pool.all()
     for sd, ws in bn_sides:
-        for pl in pools:
-            if any(w is sd for w in pl.waiting):
-                pl.waiting = [w for w in pl.waiting if w is not sd]
-                if not sd.rider and sd.mates:
-                    # the lead edge of a merged run leaves: the next waiting edge of the run carries the rows from now on
-                    nxt = next((mt for mt in sd.mates if mt is not sd and not mt.synced_ws and any(w is mt for w in pl.waiting)), None)
-                    if nxt is not None:
-                        nxt.rider = False
-                        nxt.carry = sd.carry if sd.carry is not None else sd.stats
-                break
+        _leave_pool(sd, pools)
         sd.synced_ws = ws
     return ch
 
@@ -2081,7 +2099,18 @@ def _presync_stats(sides, training: bool):
             if _sync_pool.cur().holds_unsynced(sd.stats):
                 _sync_pool.cur().enlist(sd, grp, ws)
         owner = next((pl for pl in _sync_pool.all() if any(w is sd for w in pl.waiting)), None)
-        if owner is not None:
+        if owner is not None and sd.home is not None and sd.x.is_cuda and sd.home != torch.cuda.current_stream().cuda_stream:
+            # statistics that sit in ANOTHER stream's pool (an edge of a merged conv picked up on the other task branch's stream; this
+            # stream has waited for the conv): never flush that pool from here -- its other vectors belong to kernels this stream
+            # has not waited for.  This side alone: a copy of its rows, exchanged on this stream
+            _leave_pool(sd, [owner])
+            if sd.stats_c:
+                _compact_stats(sd)
+            else:
+                sd.stats = sd.stats.clone()
+            hub_all_reduce(sd.stats, grp)
+            sd.synced_ws = ws
+        elif owner is not None:
             owner.flush()
         else:
             hub_all_reduce(sd.stats, grp)

@@ -228,9 +228,12 @@ class WideEdges(K.WideGroup):
             want = {_use_batch_stats(bn) for bn in bns}
             if len(want) != 1 or len({bn.training for bn in bns}) != 1:
                 return None
-            if 2 in want and (len({id(K._sync_group(bn)[0]) for bn in bns}) != 1 or not K.WIDE_SYNC or self.cross_stream):
+            if 2 in want and (len({id(K._sync_group(bn)[0]) for bn in bns}) != 1 or not K.WIDE_SYNC
+                              or (self.cross_stream and not K.fold_ready(K._sync_group(bns[0])[0]))):
                 return None      # (SyncBatchNorm over different process groups, NPP_WIDE_SYNC=0, or edges that are picked up on two
-                                 #  streams: the statistics exchange is ordered on the stream of the pool that holds them)
+                                 #  streams while the statistics exchange is a launch ordered on the stream of the pool that holds
+                                 #  them; with the exchange inside the consuming kernels -- K.fold_ready -- every edge trades its
+                                 #  own slice on its own stream's channel)
             conv = self.convs[0]
             lvl = want.pop()
             ys, svs, scs, slots = K.conv2d_wide(x, self, conv.padding, True, lvl, bias_dead=lvl > 0)      # (every member is conv -> BN)

@@ -40,10 +40,20 @@ cnt = collections.Counter()
 orig_s, orig_p = comm.p2p_exchange_slabs, getattr(comm, "p2p_exchange", None)
 
 
+import traceback
+sites = collections.Counter()
+
+
+def _site():
+    fr = [f for f in traceback.extract_stack()[:-2] if "npp_amd" in f.filename]
+    return " < ".join(f"{os.path.basename(f.filename)}:{f.lineno}:{f.name}" for f in fr[-4:][::-1])
+
+
 def slabs(segs, group=None):
     ok = orig_s(segs, group)
     if ok:
         cnt[("fwd" if torch.is_grad_enabled() else "bwd", "slabs", len(segs), sum(s[1] for s in segs))] += 1
+        sites[_site()] += 1
     return ok
 
 
@@ -53,6 +63,7 @@ if orig_p is not None:
         ok = orig_p(t, group)
         if ok:
             cnt[("fwd" if torch.is_grad_enabled() else "bwd", "plain", 1, t.numel())] += 1
+            sites[_site()] += 1
         return ok
     comm.p2p_exchange = plain
 step(images, lpar, lpose)
@@ -61,5 +72,8 @@ tot = collections.Counter()
 for (ph, kind, nseg, n), c in sorted(cnt.items()):
     tot[(ph, kind)] += c
     print(f"{ph} {kind:5s} segs {nseg} doubles {n:6d}: {c}")
+for k, v in sites.most_common(20):
+    print(f"{v:4d}  {k}")
+print("folded fwd / bwd", K.FOLD_STATS)
 print(dict(tot), "multi stats", K.MULTI_STATS, "bn sums", K.BN_SUMS_STATS)
 dist.destroy_process_group()
