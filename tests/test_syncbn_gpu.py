@@ -122,6 +122,7 @@ def _worker(rank, world, port, out, sync=True, reducer=False):
     res["fwd_exchanges"] = np.array(sum(pl.flushes for pl in K._sync_pool.all()))      # forward SyncBN collectives issued
     from npp_amd import comm
     res["p2p_exchanges"] = np.array(comm._p2p["count"])      # ... of which (forward + backward) through the IPC mailboxes (csrc/p2p.hip)
+    res["folded"] = np.array(K.FOLD_STATS)      # ... of which inside a fused BatchNorm kernel's prologue (forward, backward launches)
     res["p2p_ok"] = np.array(1 if comm.p2p_ok() else 0)
     names = ["pose_map0", "pose_aux0", "pose_map1", "pose_aux1", "par_map0", "edge0", "par_map1", "edge1"]
     for nm, o in zip(names, outs):
@@ -264,6 +265,36 @@ def test_syncbn_p2p_transport_equals_the_collective(tmp_path, monkeypatch):
                 assert rel_err(p2p[r][k], coll[r][k]) < 1e-5, (r, k)
             if k.startswith("grad/"):
                 assert rel_err(p2p[r][k], coll[r][k]) < 2e-2, (r, k)      # (run-to-run noise of identical code, see above)
+
+
+def test_syncbn_exchange_inside_the_fused_kernels_equals_the_stand_alone_exchange(tmp_path, monkeypatch):
+    """csrc/p2p_xp.h: with the mailboxes up, the fused BatchNorm apply / backward-apply kernels trade their local sums for the world's in
+    their own prologue (leader workgroup -> mailboxes -> tagged result vector) instead of behind a p2p_exchange_kernel launch
+    (NPP_P2P_FOLD=0).  Same wire format, same rank-order sum: outputs and running statistics of the tiny NPPNet on 2 ranks must agree
+    to the float-atomics noise of the statistics kernels, the gradients to the run-to-run noise of identical code; most exchanges of
+    the step must have been folded, in both passes, and no mailbox may report an error."""
+    from helpers import rel_err
+    monkeypatch.delenv("NPP_SYNCBN_STREAMS", raising=False)      # (the default: two branch streams, an exchange is a kernel of its stream)
+    monkeypatch.setenv("NPP_SYNCBN_P2P", "1")
+    fold = _run(2, tmp_path)
+    if int(fold[0]["p2p_exchanges"]) == 0:
+        pytest.skip("this runtime refuses hipIpc between two processes of one device")
+    monkeypatch.setenv("NPP_P2P_FOLD", "0")
+    os.makedirs(str(tmp_path / "alone"))
+    alone = _run(2, tmp_path / "alone")
+    f_fwd, f_bwd = (int(v) for v in fold[0]["folded"])
+    print("folded exchanges: forward", f_fwd, "backward", f_bwd, "of", int(fold[0]["p2p_exchanges"]), "| stand-alone run:",
+          int(alone[0]["p2p_exchanges"]))
+    assert [int(v) for v in alone[0]["folded"]] == [0, 0]
+    assert list(fold[0]["folded"]) == list(fold[1]["folded"]) and f_fwd > 50 and f_bwd > 50
+    assert f_fwd + f_bwd > 0.8 * int(fold[0]["p2p_exchanges"])
+    assert int(fold[0]["p2p_ok"]) == 1 and int(fold[1]["p2p_ok"]) == 1
+    for r in range(2):
+        for k in fold[r].files:
+            if k.startswith("out/") or k.startswith("buf/"):
+                assert rel_err(fold[r][k], alone[r][k]) < 1e-5, (r, k)
+            if k.startswith("grad/"):
+                assert rel_err(fold[r][k], alone[r][k]) < 2e-2, (r, k)
 
 
 def _search_worker(rank, world, port, out):
