@@ -84,7 +84,9 @@ NPP_DEV u32x4 relu_bf16x8(u32x4 v) {
 }
 
 // BN: output channels per tile; RELU: ReLU on the input operand; TAPS: KxK (per-tap pixel shift + border test)
-// DBG (timing experiments only, NPP_G8_DBG): 1 = no epilogue, 2 = no MFMA, 4 = no DMA, 8 = no fragment reads
+// DBG (timing experiments only, NPP_G8_DBG): 1 = no epilogue, 2 = no MFMA, 4 = no DMA, 8 = no fragment reads,
+// 16 / 32 = the B (weights) / A (x) half-tiles come from out-of-range offsets: the same DMA instructions and LDS writes (zeros),
+// nothing fetched from L2 / HBM
 template <int BN, bool RELU, bool TAPS, int DBG = 0>
 __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) {
   constexpr int BM = 256;
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
         const int y = (ayx[h][i] >> 16) + s_dy, x = (ayx[h][i] & 0xFFFF) + s_dx;
         if (!((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)) v = 0xFFFFFFFFu;   // out of range: the DMA writes zeros
       }
+      if (DBG & 32) v = 0xFFFFFF00u;
       G8_DMA(rs_x, v, 0, lb + h * AH + (wave * 2 + i) * 1024);
     }
   };
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(512) void conv_g8_kernel(IgemmParams p, G8Extra e) 
 #pragma unroll
     for (int i = 0; i < NB; ++i)     // rows +8*i, +32*h of the lane's first row: a scalar offset
       if (part == 2 || (NB == 2 ? part == i : part == 1))
-        G8_DMA(rs_w, bbyte, koff + (h * 32 + i * 8) * p.Kpad * 2, lb + 2 * AH + h * BH + (wave * NB + i) * 1024);
+        G8_DMA(rs_w, (DBG & 16) ? 0xFFFFFF00u : bbyte, (DBG & 16) ? 0 : koff + (h * 32 + i * 8) * p.Kpad * 2, lb + 2 * AH + h * BH + (wave * NB + i) * 1024);
   };
   auto stage_advance = [&]() {     // after the last half-tile (A1) of a K-tile
     if (!stage_on) return;
@@ -766,6 +769,11 @@ bool conv_g8_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
         case 9: G8_LAUNCH_DBG(256, 9); break;
         case 13: G8_LAUNCH_DBG(256, 13); break;
         case 15: G8_LAUNCH_DBG(256, 15); break;
+        case 16: G8_LAUNCH_DBG(256, 16); break;
+        case 32: G8_LAUNCH_DBG(256, 32); break;
+        case 48: G8_LAUNCH_DBG(256, 48); break;
+        case 17: G8_LAUNCH_DBG(256, 17); break;
+        case 33: G8_LAUNCH_DBG(256, 33); break;
         default: return false;
       }
     } else {

@@ -85,35 +85,33 @@ def test_collective_inside_a_hipgraph(comm1):
     assert torch.equal(g, torch.full_like(g, 22.0)), g[:4]
 
 
+import os
+import bg_children      # noqa: E402  (child processes, run in the background: tests/bg_children.py)
+import sys as _sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_HERE)
+bg_children.register("comm-reducer", [_sys.executable, os.path.join(_HERE, "comm_reducer_worker.py")], timeout=600)
+bg_children.register("reducer-defer", [_sys.executable, os.path.join(_REPO, "tools", "reducer_defer_check.py")], timeout=600)
+bg_children.register("reducer-tail", [_sys.executable, os.path.join(_REPO, "tools", "reducer_defer_check.py")],
+                     dict(NPP_CHECK_REDUCER_MODE="tail"), timeout=600)
+
+
 def test_training_step_on_the_library_transport():
     """GradReducer + SyncBatchNorm + hipGraph on npp_allreduce_bucket / npp_syncbn_exchange (tests/comm_reducer_worker.py)."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "comm_reducer_worker.py")], capture_output=True, text=True, timeout=600)
+    r = bg_children.result("comm-reducer")
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_deferred_gradients_land_in_the_reducer_buckets():
     """overlap=False reducer + TrainStep's deferred / batched weight gradients (tools/reducer_defer_check.py): every gradient is a
     view of its bucket and equals a plain backward's."""
-    import os
-    import subprocess
-    import sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "reducer_defer_check.py")], capture_output=True, text=True, timeout=600)
+    r = bg_children.result("reducer-defer")
     assert r.returncode == 0 and "REDUCER_DEFER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_tail_overlap_reducer_two_group_tail():
     """overlap="tail": buckets per kind; after the KxK group of the batched weight-gradient tail (+ unpack) the KxK buckets are
     reduced, the 1x1 / depthwise / SE group follows, finish() reduces the rest -- every gradient equals a plain backward's."""
-    import os
-    import subprocess
-    import sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NPP_CHECK_REDUCER_MODE="tail", MASTER_PORT="29679")
-    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "reducer_defer_check.py")], capture_output=True, text=True, timeout=600,
-                       env=env)
+    r = bg_children.result("reducer-tail")
     assert r.returncode == 0 and "REDUCER_DEFER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

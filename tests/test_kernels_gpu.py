@@ -382,33 +382,43 @@ def test_shapes_take_their_lds_dma_kernels():
     assert _g8_launch_count(384, 6, 3, "conv_g4", 96) == 2           # the edge head: conv_thin.hip, same family
 
 
+# ---- cases that need a process of their own (switches the library reads once per process): background children, tests/bg_children.py
+import os      # noqa: E402
+import sys as _sys      # noqa: E402
+import tempfile as _tempfile      # noqa: E402
+import bg_children      # noqa: E402
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+for _cfg in ("1", "3", "4"):
+    bg_children.register(f"h3-cfg-{_cfg}", [_sys.executable, os.path.join(_HERE, "h3_cfg_worker.py")], dict(NPP_H3_CFG=_cfg), timeout=600)
+_EPI_DIR = _tempfile.mkdtemp(prefix="npp_epi_")
+for _lean in ("0", "1"):
+    bg_children.register(f"epi-{_lean}", [_sys.executable, os.path.join(_HERE, "epi_worker.py"), os.path.join(_EPI_DIR, f"epi{_lean}.npz")],
+                         dict(NPP_EPI_LEAN=_lean, NPP_EPI_CENSUS="1"), timeout=600)
+bg_children.register("wgrad-slabs", [_sys.executable, os.path.join(_HERE, "wgrad_slabs_worker.py")], dict(NPP_WGRAD_SLABS="1"), timeout=600)
+bg_children.register("g8-taps", [_sys.executable, os.path.join(_HERE, "g8_taps_worker.py")],
+                     dict(NPP_G8_MAXK="3", NPP_DISABLE_G4="1", NPP_DISABLE_H3="1"), timeout=600)
+
+
 @pytest.mark.parametrize("cfg", ["1", "3", "4"])
 def test_h3_tile_configurations_in_subprocess(cfg):
     """conv_h3's other tile shapes (NPP_H3_CFG, read once per process): 16-row / 12-row / 8-row tiles with 8 waves -- the
     halo-footprint parity cases through each of them, and the launches really are conv_h3's."""
-    import os, subprocess, sys
-    env = dict(os.environ, NPP_H3_CFG=cfg)
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "h3_cfg_worker.py")], env=env, capture_output=True, text=True,
-                       timeout=600)
+    r = bg_children.result(f"h3-cfg-{cfg}")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "h3 cfg ok" in r.stdout
 
 
-def test_lean_epilogues_equal_the_generic_ones(tmp_path):
+def test_lean_epilogues_equal_the_generic_ones():
     """conv_epi.h / conv_g8's epilogue_lean against the kernels' generic epilogues (NPP_EPI_LEAN=0, read once per process): the stored
     bf16 outputs -- forward, data gradient of a first writer through the bit-mask, accumulating second writer -- must be BIT-identical
     (same values, same rounding, another instruction sequence); the BatchNorm statistics are summed in another order (reduce-scatter
     instead of all-reduce over the 16 pixel lanes): equal to 1e-6 of the largest entry."""
-    import os, subprocess, sys
-    here = os.path.dirname(os.path.abspath(__file__))
     res = {}
     for lean in ("0", "1"):
-        path = str(tmp_path / f"epi{lean}.npz")
-        env = dict(os.environ, NPP_EPI_LEAN=lean, NPP_EPI_CENSUS="1")
-        r = subprocess.run([sys.executable, os.path.join(here, "epi_worker.py"), path], env=env, capture_output=True, text=True, timeout=600)
+        r = bg_children.result(f"epi-{lean}")
         assert r.returncode == 0 and "epi ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-        res[lean] = np.load(path)
+        res[lean] = np.load(os.path.join(_EPI_DIR, f"epi{lean}.npz"))
         # the cases reach every kernel that has a lean epilogue, in the three formats the network runs
         census = [ln for ln in r.stderr.splitlines() if ln.startswith("npp-epi ")]
         for kern in ("conv_g8", "conv_g4", "conv_h3", "conv_c32"):
@@ -427,11 +437,7 @@ def test_lean_epilogues_equal_the_generic_ones(tmp_path):
 def test_deterministic_slab_weight_gradient_in_subprocess():
     """NPP_WGRAD_SLABS=1 (read once per process): the wide-map 3x3 weight gradients through conv_wgrad_h3's split-K slabs +
     npp_unpack_wgrad_sum -- parity cases, and two runs give bit-identical gradients (no float atomics on that path)."""
-    import os, subprocess, sys
-    env = dict(os.environ, NPP_WGRAD_SLABS="1")
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "wgrad_slabs_worker.py")], env=env, capture_output=True, text=True,
-                       timeout=600)
+    r = bg_children.result("wgrad-slabs")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "wgrad slabs ok" in r.stdout
 
@@ -439,11 +445,7 @@ def test_deterministic_slab_weight_gradient_in_subprocess():
 def test_g8_taps_variant_in_subprocess():
     """The KxK (per-tap shift, zero border by out-of-range DMA) variant of conv_g8_kernel is opt-in (NPP_G8_MAXK=3, read once
     per process): run the large-map 3x3 parity cases on it in ONE child process."""
-    import os, subprocess, sys
-    env = dict(os.environ, NPP_G8_MAXK="3", NPP_DISABLE_G4="1", NPP_DISABLE_H3="1")
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "g8_taps_worker.py")], env=env, capture_output=True, text=True,
-                       timeout=600)
+    r = bg_children.result("g8-taps")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "g8 taps ok" in r.stdout
 

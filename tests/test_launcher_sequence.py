@@ -20,9 +20,15 @@ def test_launcher_setup_sequence_cpu():
     assert r.returncode == 0 and "LAUNCHER_CPU_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+import bg_children      # noqa: E402  (the two GPU runs are background children, see tests/bg_children.py)
+
+bg_children.register("launcher-gpu", [sys.executable, os.path.join(HERE, "launcher_worker.py"), "gpu"])
+bg_children.register("launcher-auto", [sys.executable, os.path.join(HERE, "launcher_worker.py"), "gpu"], dict(NPP_AUTO_GRAPH="1"))
+
+
 @pytest.mark.gpu
 def test_launcher_sequence_with_ddp_and_one_step_gpu():
-    r = _run("gpu")
+    r = bg_children.result("launcher-gpu")
     assert r.returncode == 0 and "LAUNCHER_GPU_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
@@ -30,5 +36,5 @@ def test_launcher_sequence_with_ddp_and_one_step_gpu():
 def test_launcher_sequence_with_auto_graph_gpu():
     """The same unchanged loop with NPP_AUTO_GRAPH=1: Network.forward + backward replayed as hipGraphs from the third call on
     (npp_amd/auto_graph.py), under DistributedDataParallel(find_unused_parameters=True), torch.optim.Adam and MultiStepLR."""
-    r = _run("gpu", NPP_AUTO_GRAPH="1", MASTER_PORT="29534")
+    r = bg_children.result("launcher-auto")
     assert r.returncode == 0 and "LAUNCHER_GPU_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -16,51 +16,77 @@ sys.path.insert(0, REPO)
 pytestmark = pytest.mark.gpu
 
 
-def _probe(args, env_extra):
-    so = os.path.join(REPO, "tools", "libpoison_alloc.so")
-    if not os.path.isfile(so):
-        subprocess.check_call(["hipcc", "-shared", "-fPIC", "-o", so, os.path.join(REPO, "tools", "poison_alloc.cpp")])
-    env = dict(os.environ, **{"PROBE_STEPS": "4", **env_extra})
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "poison_probe.py")] + args, env=env, capture_output=True,
-                       text=True, timeout=600)
+import bg_children      # noqa: E402  (the probes are child processes: registered here, run in the background, see tests/bg_children.py)
+
+_SO = os.path.join(REPO, "tools", "libpoison_alloc.so")
+
+
+def _reg_probe(key, args, env_extra):
+    return bg_children.register(key, [sys.executable, os.path.join(REPO, "tools", "poison_probe.py")] + args,
+                                dict({"PROBE_STEPS": "4"}, **env_extra), timeout=600)
+
+
+def _build_allocator():      # (before the first child starts: every probe loads it)
+    if not os.path.isfile(_SO):
+        subprocess.check_call(["hipcc", "-shared", "-fPIC", "-o", _SO, os.path.join(REPO, "tools", "poison_alloc.cpp")])
+
+
+bg_children.before_start(_build_allocator)
+
+
+def _probe(key, nsteps):
+    r = bg_children.result(key)
     assert r.returncode == 0 and "PROBE_DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
     steps = [ln for ln in r.stdout.splitlines() if ln.startswith("step")]
-    assert len(steps) == int(env["PROBE_STEPS"])
+    assert len(steps) == int(nsteps)
     for ln in steps:
         assert "non-finite grads 0 [] params 0 [] buffers 0 []" in ln and "nan" not in ln.split("non-finite")[0], ln
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("fanout", ["1", "0"])
+_STEP_CASES = [(d, f) for d in ["f32", "bf16"] for f in ["1", "0"]]
+for _d, _f in _STEP_CASES:
+    _reg_probe(f"poison-step-{_d}-{_f}", ["bf16"] if _d == "bf16" else [], {"NPP_FANOUT": _f})
+
+
+@pytest.mark.parametrize("dtype,fanout", _STEP_CASES)
 def test_training_step_reads_no_unwritten_memory(dtype, fanout):
-    _probe(["bf16"] if dtype == "bf16" else [], {"NPP_FANOUT": fanout})
+    _probe(f"poison-step-{dtype}-{fanout}", 4)
 
 
-@pytest.mark.parametrize("mode,dtype,steps", [("search", "f32", "3"), ("search", "bf16", "3"), ("syncbn", "f32", "3"),
-                                              ("syncbn", "bf16", "3"), ("full", "bf16", "2")])
+_OTHER_CASES = [("search", "f32", "3"), ("search", "bf16", "3"), ("syncbn", "f32", "3"), ("syncbn", "bf16", "3"), ("full", "bf16", "2")]
+for _m, _d, _n in _OTHER_CASES:
+    _reg_probe(f"poison-{_m}-{_d}", ["bf16"] if _d == "bf16" else [], {"PROBE_MODE": _m, "PROBE_STEPS": _n})
+
+
+@pytest.mark.parametrize("mode,dtype,steps", _OTHER_CASES)
 def test_other_paths_read_no_unwritten_memory(mode, dtype, steps):
     """search: SearchStep (weights pass + alpha pass with the entropy term) on the supernet; syncbn: SyncBatchNorm + GradReducer on a
     1-rank RCCL group; full: the C=64 network at 384 x 384 (the kernels the bench runs: conv_g8, conv_h3, conv_wgrad_g4 ...)."""
-    _probe(["bf16"] if dtype == "bf16" else [], {"PROBE_MODE": mode, "PROBE_STEPS": steps})
+    _probe(f"poison-{mode}-{dtype}", steps)
 
 
-@pytest.mark.parametrize("sync,overlap,dtype", [("1", "0", "f32"), ("1", "1", "f32"), ("0", "0", "f32"), ("1", "0", "bf16")])
+_GRAPH_CASES = [("1", "0", "f32"), ("1", "1", "f32"), ("0", "0", "f32"), ("1", "0", "bf16")]
+for _s, _o, _d in _GRAPH_CASES:
+    bg_children.register(f"graph-poison-{_s}-{_o}-{_d}",
+                         [sys.executable, os.path.join(REPO, "tools", "graph_poison_probe.py")] + (["bf16"] if _d == "bf16" else []),
+                         dict(PROBE_SYNC=_s, PROBE_OVERLAP=_o, PROBE_GB="2"), timeout=600)
+bg_children.register("graph-poison-search", [sys.executable, os.path.join(REPO, "tools", "graph_poison_probe.py")],
+                     dict(PROBE_MODEL="search", PROBE_GB="2"), timeout=600)
+
+
+@pytest.mark.parametrize("sync,overlap,dtype", _GRAPH_CASES)
 def test_replayed_step_reads_no_recycled_block(sync, overlap, dtype):
     """tools/graph_poison_probe.py: the hipGraph-replayed step (SyncBatchNorm + GradReducer on a 1-rank RCCL group: hub streams,
     lockstep issue; or local BatchNorm on two streams) leaves no non-finite value and no wild gradient element behind -- checked on
     gradients, parameters, buffers AND the optimizer state (a wild finite element only shows as exp_avg_sq = inf).  Regression for
     the cross-stream use-after-free of round 2 (an input read on the hub stream without record_stream)."""
-    env = dict(os.environ, PROBE_SYNC=sync, PROBE_OVERLAP=overlap, PROBE_GB="2", MASTER_PORT="29637")
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "graph_poison_probe.py")] + (["bf16"] if dtype == "bf16" else []),
-                       env=env, capture_output=True, text=True, timeout=600)
+    r = bg_children.result(f"graph-poison-{sync}-{overlap}-{dtype}")
     assert r.returncode == 0 and "GRAPH_PROBE_DONE" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 def test_replayed_search_step_reads_no_recycled_block():
     """The same probe on the supernet under SearchStep (both passes replayed as hipGraphs, two branch streams)."""
-    env = dict(os.environ, PROBE_MODEL="search", PROBE_GB="2")
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "graph_poison_probe.py")], env=env, capture_output=True, text=True,
-                       timeout=600)
+    r = bg_children.result("graph-poison-search")
     assert r.returncode == 0 and "GRAPH_PROBE_DONE" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
