@@ -514,7 +514,8 @@ static bool run_plan(const DwParams& p, RunGeom& g, int& nblk, int V) {
   const long base_threads = (long)g.N * g.OH * g.delta * g.cv;
   int nseg = (int)((256L * 256 * 3 + base_threads - 1) / base_threads);
   if (getenv("NPP_DW_THREADS")) nseg = (int)((atol(getenv("NPP_DW_THREADS")) + base_threads - 1) / base_threads);
-  const int max_seg = npx / 6 > 1 ? npx / 6 : 1;
+  static const int seg_div = getenv("NPP_DW_SEG_DIV") ? atoi(getenv("NPP_DW_SEG_DIV")) : 6;      // shortest segment (pixels of a run)
+  const int max_seg = npx / seg_div > 1 ? npx / seg_div : 1;
   if (nseg > max_seg) nseg = max_seg;
   if (nseg < 1) nseg = 1;
   int seglen = (npx + nseg - 1) / nseg;
