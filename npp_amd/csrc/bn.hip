@@ -1436,6 +1436,19 @@ static int xp_for(int channel, long n_doubles, XpArgs* x) {
   if (channel < 0) return NPP_OK;
   return npp_p2p_xp_args(channel, n_doubles, x);
 }
+// workgroups per job of the fused kernels (every workgroup repeats the prologue); NPP_BN_GRID_CAP for A/B runs
+static unsigned bn_grid_cap() {
+  static const unsigned cap = getenv("NPP_BN_GRID_CAP") ? (unsigned)atoi(getenv("NPP_BN_GRID_CAP")) : 512u;
+  return cap > 0 ? cap : 512u;
+}
+// Workgroups of a launch that carries an exchange: at most XP_MAX_BLOCKS over all its jobs (p2p_xp.h: its waiting workgroups must
+// never fill the chip -- the leader of the OTHER branch stream's kernel has to find a slot, or two ranks that schedule their two
+// streams in different orders wait for each other forever).
+static unsigned xp_grid_x(unsigned gx, int njobs, const XpArgs& x) {
+  if (x.world == 0) return gx;
+  const unsigned cap = (unsigned)(XP_MAX_BLOCKS / (njobs > 0 ? njobs : 1));
+  return gx > cap ? (cap > 0 ? cap : 1u) : gx;
+}
 
 extern "C" int npp_affine_add_fin_x(NppTensor* out, const NppTensor* a, const NppBnFinalizeArgs* fin_a, const NppTensor* b,
                                     const NppBnFinalizeArgs* fin_b, int relu, unsigned char* mask_bits, int64_t ld_mask, int channel,
@@ -1467,7 +1480,8 @@ extern "C" int npp_affine_add_fin_x(NppTensor* out, const NppTensor* a, const Np
     do {                                                                                                                   \
       ColMap m = col_map(out->c, V);                                                                                       \
       dim3 grid = col_grid_ew(m, npix(out));                                                                               \
-      if (grid.x > 1024) grid.x = 1024;     /* every block repeats the prologue */                                         \
+      if (grid.x > bn_grid_cap()) grid.x = bn_grid_cap();     /* every block repeats the prologue */                                         \
+      grid.x = xp_grid_x(grid.x, 1, xp);                                                                                   \
       if (b) { if (fin_b) AFN(true, true, MK); else AFN(true, false, MK); }                                                \
       else AFN(false, false, MK);                                                                                          \
     } while (0)
@@ -1706,7 +1720,8 @@ extern "C" int npp_bn_bwd_apply_fin_x(const NppTensor* dout, const NppTensor* y_
   NPP_DISPATCH_TV(dout->dtype, true, {
     ColMap m = col_map(dout->c, V);
     dim3 grid = col_grid_ew(m, npix(dout));
-    if (grid.x > 1024) grid.x = 1024;
+    if (grid.x > bn_grid_cap()) grid.x = bn_grid_cap();
+    grid.x = xp_grid_x(grid.x, 1, xp);
     hipLaunchKernelGGL((bn_bwd_apply_fin_kernel<T, V>), grid, dim3(256), (size_t)3 * dout->c * sizeof(float), (hipStream_t)stream,
                        (const T*)dout->ptr, (long)dout->ld, (const T*)y_raw->ptr, (long)y_raw->ld,
                        relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, sums, nrep, 1.0 / count, f,
@@ -1739,7 +1754,8 @@ extern "C" int npp_bn_bwd_apply2_fin_x(const NppTensor* dout, const NppTensor* y
   NPP_DISPATCH_TV(dout->dtype, true, {
     ColMap m = col_map(dout->c, V);
     dim3 grid = col_grid_ew(m, npix(dout));
-    if (grid.x > 1024) grid.x = 1024;
+    if (grid.x > bn_grid_cap()) grid.x = bn_grid_cap();
+    grid.x = xp_grid_x(grid.x, 1, xp);
     hipLaunchKernelGGL((bn_bwd_apply2_fin_kernel<T, V>), grid, dim3(256), (size_t)6 * dout->c * sizeof(float), (hipStream_t)stream,
                        (const T*)dout->ptr, (long)dout->ld, (const T*)ya->ptr, (long)ya->ld, (const T*)yb->ptr, (long)yb->ld,
                        relu_out ? (const T*)relu_out->ptr : nullptr, relu_out ? (long)relu_out->ld : 0L, sums, nrep, 1.0 / count, fa, fb,
@@ -1801,7 +1817,8 @@ extern "C" int npp_affine_add_fin_multi_x(const NppAffineAddJob* jobs, int njobs
     do {                                                                                                                   \
       ColMap m = col_map(ref->c, V);                                                                                       \
       dim3 grid = col_grid_ew(m, npix(ref));                                                                               \
-      if (grid.x > 1024) grid.x = 1024;                                                                                    \
+      if (grid.x > bn_grid_cap()) grid.x = bn_grid_cap();                                                                                    \
+      grid.x = xp_grid_x(grid.x, njobs, xp);                                                                               \
       grid.z = (unsigned)njobs;                                                                                            \
       if (has_b) { if (fb_) AFM(true, true, MK); else AFM(true, false, MK); }                                              \
       else AFM(false, false, MK);                                                                                          \
@@ -1889,7 +1906,8 @@ extern "C" int npp_bn_bwd_apply_multi_x(const NppBnBwdJob* jobs, int njobs, int 
   NPP_DISPATCH_TV(ref->dtype, true, {
     ColMap m = col_map(ref->c, V);
     dim3 grid = col_grid_ew(m, npix(ref));
-    if (grid.x > 1024) grid.x = 1024;
+    if (grid.x > bn_grid_cap()) grid.x = bn_grid_cap();
+    grid.x = xp_grid_x(grid.x, njobs, xp);
     grid.z = (unsigned)njobs;
     if (two)
       hipLaunchKernelGGL((bn_bwd_apply_multi_kernel<T, V, true>), grid, dim3(256), (size_t)6 * ref->c * sizeof(float), (hipStream_t)stream, js,

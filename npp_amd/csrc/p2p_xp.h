@@ -14,7 +14,12 @@
 //   * the result vector is one slot: the next exchange of the channel is a later kernel on the same stream;
 //   * no lane ever waits for another lane of its own wave: the waits are a poll of OTHER ranks' stores (leader) or of the
 //     leader's flag (one thread per workgroup), each followed by a workgroup barrier;
-//   * the leader is the first workgroup dispatched, so the workgroups spinning on the result vector cannot starve it.
+//   * the leader of a job is dispatched before the job's other workgroups, so the workgroups waiting for it cannot starve it;
+//   * a launch that carries an exchange has at most XP_MAX_BLOCKS workgroups (256 threads each, <= 133 VGPRs: three fit on a CU,
+//     XP_MAX_BLOCKS is two per CU): its waiting workgroups never fill the chip.  They wait for OTHER ranks -- if they could hold
+//     every slot, the kernel of the other branch stream could not start its leader, and two ranks whose two streams reach their
+//     kernels in opposite orders would wait for each other until the time-out.  With the cap the leaders of both streams' kernels
+//     are always resident (the stand-alone exchange kernel never had the problem: <= 8 workgroups).
 // Errors as in p2p.hip: a poll that times out or finds a slot overwritten sets the channel's error word and yields NaN sums.
 #pragma once
 #include "common.h"
@@ -24,6 +29,7 @@ constexpr int P2P_MAX_WORLD = 16;
 constexpr int XP_SUB = 16;             // first-level counters of the "every workgroup is past its prologue" count
 constexpr int XP_SUB_STRIDE = 32;      // ... 256 bytes apart (in 8-byte words)
 constexpr int XP_KEEP = 4;             // elements per leader thread kept in registers instead of travelling through the own mailbox
+constexpr int XP_MAX_BLOCKS = 512;     // workgroups of a launch that carries an exchange (two per CU of the 256), see above
 constexpr int XP_MAX_JOBS = 4;         // jobs of one multi-job launch (NPP_BN_MULTI_MAX), each with a leader and a flag of its own
 
 struct XpArgs {

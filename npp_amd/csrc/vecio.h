@@ -2,6 +2,7 @@
 // dispatch macro.  V = elements per access: Elt<T>::VEC (16 bytes) on the vector path, 1 otherwise.
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 template <typename T, int V> NPP_DEV void ldv(const T* p, float* o) {
   if constexpr (V == 1) o[0] = Elt<T>::ld(p); else Vec16<T>::load(p, o);
@@ -36,6 +37,8 @@ NPP_DEV void fast_divmod(unsigned i, const FastDiv& f, unsigned& q, unsigned& r)
 }
 
 static inline int grid_for(long items, int per_block = 256, int cap = 4096) {
+  static const int pct = getenv("NPP_GRID_CAP_PCT") ? atoi(getenv("NPP_GRID_CAP_PCT")) : 100;      // (A/B runs: the caps of every grid-stride kernel)
+  cap = cap * pct / 100 > 0 ? cap * pct / 100 : 1;
   long b = (items + per_block - 1) / per_block;
   if (b < 1) b = 1;
   if (b > cap) b = cap;
