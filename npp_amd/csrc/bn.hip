@@ -32,7 +32,8 @@ static inline dim3 col_grid(const ColMap& m, long npix) {
 
 static inline dim3 col_grid_ew(const ColMap& m, long npix) {
   long bx = (npix + 2L * m.rows - 1) / (2L * m.rows);
-  if (bx > 2048) bx = 2048;
+  static const long cap = getenv("NPP_EW_CAP") ? atol(getenv("NPP_EW_CAP")) : 2048;
+  if (bx > cap) bx = cap;
   if (bx < 1) bx = 1;
   return dim3((unsigned)bx, (unsigned)((m.cv + m.cols_blk - 1) / m.cols_blk));
 }

@@ -524,7 +524,8 @@ static bool run_plan(const DwParams& p, RunGeom& g, int& nblk, int V) {
   g.nseg = nseg; g.seglen = seglen;
   if (base_threads * nseg >= (1L << 31)) return false;
   long nb = (base_threads * nseg + 255) / 256;
-  if (nb > 1024) nb = 1024;
+  static const long nb_cap = getenv("NPP_DW_NB") ? atol(getenv("NPP_DW_NB")) : 1024;
+  if (nb > nb_cap) nb = nb_cap;
   nblk = (int)(nb < 1 ? 1 : nb);
   return true;
 }

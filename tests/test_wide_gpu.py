@@ -410,7 +410,7 @@ def test_one_by_one_members_of_a_merged_edge_queue_one_weight_gradient_job():
 
 
 @pytest.mark.parametrize("two_sided", [True, False])
-@pytest.mark.parametrize("k,c,h", [(3, 128, 96), (3, 32, 96), (1, 128, 24), (3, 64, 24)])
+@pytest.mark.parametrize("k,c,h", [(3, 128, 96), (3, 32, 96), (1, 128, 24), (3, 64, 24), (1, 128, -96), (1, 256, -96)])
 def test_last_writer_delivers_the_batchnorm_backward_sums(two_sided, k, c, h):
     """BN_SUMS: T = BN_a(conv_a(x)) [+ BN_b(conv_b(x))] feeds two ReLU-conv consumers; the data gradient of the consumer that writes
     T's gradient LAST (npp_conv_dgrad_sums on conv_h3 / conv_c32 / conv_g4's 64-row tiles) also delivers sum g, sum g xhat_a, sum g xhat_b,
@@ -419,7 +419,12 @@ def test_last_writer_delivers_the_batchnorm_backward_sums(two_sided, k, c, h):
     from npp_amd import _ops as K
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(100 + k + c)
-    n = 2 if h == 96 else 8
+    # h < 0: a 1x1 data gradient at N = 16, 96 x 96 -- the persistent shapes whose kernels (conv_g8, conv_g4's 128-row tile) have NO
+    # summing epilogue (they used to return NPP_OK with zero sums): the request must be refused, nothing delivered, the
+    # BatchNorm backward reduces for itself -- and the gradients still agree
+    routed_away = h < 0
+    h = abs(h)
+    n = 16 if routed_away else (2 if h == 96 else 8)
     x_cpu = torch.randn(n, c, h, h, generator=g)
     wa, wb = (torch.randn(c, c, 1, 1, generator=g) * (1.0 / c ** 0.5) for _ in range(2))
     w1, w2 = (torch.randn(c, c, k, k, generator=g) * (1.0 / (c * k * k) ** 0.5) for _ in range(2))
@@ -455,7 +460,10 @@ def test_last_writer_delivers_the_batchnorm_backward_sums(two_sided, k, c, h):
     dx1, gw1, d1 = run(True)
     dx0, gw0, d0 = run(False)
     assert d0 == [0, 0, 0]
-    assert d1[0] >= 1 and d1[1] == 1 and d1[2] == 1, d1      # one ticket delivered by the second consumer's data gradient and consumed
+    if routed_away:
+        assert d1[0] >= 1 and d1[1] == 0 and d1[2] == 0, d1      # a ticket was issued, no kernel claimed to have delivered its sums
+    else:
+        assert d1[0] >= 1 and d1[1] == 1 and d1[2] == 1, d1      # one ticket delivered by the second consumer's data gradient and consumed
     scale = float(dx0.abs().max())
     assert scale > 0 and float((dx1 - dx0).abs().max()) <= 2 ** -6 * scale
     for a, b in zip(gw1, gw0):
