@@ -20,6 +20,8 @@
 #include "conv_params.h"
 #include "conv_epi.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 
 #ifndef G4_RING
 #define G4_RING 2
@@ -36,10 +38,17 @@ namespace {
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
+constexpr int G4_SPLIT_MAX_TILES = 512, G4_SPLIT_MAX = 8, G4_SPLIT_SETS = 6;      // split-K scratch: tiles x shares per set, sets
+
 struct G4Extra {
   int taps, nchunks, nk, P, HW;
   int stride, OHW, OW;      // stride > 1 (forward of a strided conv): output pixel (n, oy, ox) reads input (oy * stride, ox * stride) + tap
   unsigned xbytes, wbytes;
+  // split-K (the starved grids, see conv_g4_launch): `ksplit` workgroups per output tile, each over a contiguous share of the K-tiles;
+  // part = [tile][split][256 lanes][16 floats] partial accumulators, cnt = one arrival counter per tile (zero between launches)
+  int ksplit;
+  void* part;
+  unsigned* cnt;
 };
 
 #define G4_DMA(rsrc, voff, soff, ldsoff)                                                                  \
@@ -80,7 +89,11 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
   // XCD-contiguous tile order, N-tile fastest.  Tile index tl -> XCD tl & 7 (block bid runs tiles bid, bid + G, ...: G is a
   // multiple of 8 whenever a block runs more than one tile, so all of them sit in its XCD's contiguous range)
   const int total = p.mtiles * p.ntiles;
-  const int bid = blockIdx.x;
+  constexpr bool SPLITK = BM == 64 && BN == 64 && !HALF && !PERS && RING_ >= 3;      // (the "deep" instantiations only)
+  const int S = SPLITK ? e.ksplit : 1;
+  // split-K: workgroups b, b + total, ... are the S shares of tile b (the same XCD whenever total is a multiple of 8)
+  const int bid = SPLITK && S > 1 ? (int)(blockIdx.x % (unsigned)total) : (int)blockIdx.x;
+  const int split = SPLITK && S > 1 ? (int)(blockIdx.x / (unsigned)total) : 0;
   const int G = PERS ? (int)gridDim.x : total;
   auto tile_of = [&](int tl, int& m0_, int& n0_) {
     const int xcd = tl & 7, qd = total >> 3, rm = total & 7;
@@ -131,6 +144,15 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
   };
   int s_tl = bid, s_k = 0;        // output tile / K-tile the staging stream stands at
   setup(s_tl);
+  // this workgroup's K-tiles: [kbeg, kbeg + nk) of the tile's e.nk
+  const int kbeg = SPLITK && S > 1 ? split * e.nk / S : 0;
+  const int nk = SPLITK && S > 1 ? (split + 1) * e.nk / S - kbeg : e.nk;
+  if (SPLITK && S > 1) {
+    s_chunk = kbeg % e.nchunks;
+    s_tap = kbeg / e.nchunks;
+    s_dy = s_tap / p.KW - e.P;
+    s_dx = s_tap % p.KW - e.P;
+  }
 
   auto issue = [&]() {     // the next K-tile of the stream into ring slot s_slot
     const int lb = s_slot * KT;
@@ -176,14 +198,13 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
       ++s_kt;
     }
     if (++s_slot == R) s_slot = 0;
-    if (PERS && ++s_k == e.nk) {      // the stream moves on to this block's next output tile
+    if (PERS && ++s_k == e.nk) {      // the stream moves on to this block's next output tile (never with split-K)
       s_k = 0;
       s_tl += G;
       if (s_tl < total) setup(s_tl);
     }
   };
 
-  const int nk = e.nk;
   // the K-tile stream of this block: nk K-tiles per output tile, over all of its tiles
   const int stream_total = PERS ? ((total - bid + G - 1) / G) * nk : nk;
   int issued = 0;
@@ -237,6 +258,56 @@ __global__ __launch_bounds__(256) void conv_g4_kernel(IgemmParams p, G4Extra e) 
                                                                   __builtin_bit_cast(bf16x8, fa[mi][kb]), acc[mi][ni], 0, 0, 0);
           else
             asm volatile("" :: "v"(fb[ni][kb]), "v"(fa[mi][kb]));
+  }
+
+  // ---- split-K: every share publishes its accumulators; the share that arrives LAST adds all of them in split order (the same sum
+  // whoever is last) and goes on to the ordinary epilogue -- no finish launch, which would be one more link of the step's chain.
+  // The partials are relaxed device-scope atomics (performed where every XCD sees them once the store has completed: the counter
+  // is bumped behind s_waitcnt vmcnt(0) + barrier); nothing here is a device-scope release / acquire (= an L2 write-back / invalidate).
+  if constexpr (SPLITK) {
+    if (S > 1) {
+      static_assert(!SPLITK || MI * NI == 4, "16 floats per lane");
+      __shared__ int s_last;
+      // [tile][split][fragment][256 lanes] x 16 bytes: every store / load instruction moves 4 KiB of consecutive bytes per workgroup;
+      // cache policy sc1 (bit 4): performed at device scope -- written through / read past the XCD's L2
+      const auto rs_p = __builtin_amdgcn_make_buffer_rsrc(e.part, 0, G4_SPLIT_MAX_TILES * G4_SPLIT_MAX * 16384, 0x00020000);
+      const unsigned pbase = (unsigned)(((unsigned)tl * (unsigned)S + (unsigned)split) * 16384u + (unsigned)t * 16u);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mi][ni]), rs_p, (int)(pbase + (mi * NI + ni) * 4096u), 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) {
+        const unsigned old = __hip_atomic_fetch_add(e.cnt + tl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == (unsigned)(S - 1);
+        if (s_last) __hip_atomic_store(e.cnt + tl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (ready for the next launch)
+      }
+      __syncthreads();
+      if (!s_last) return;
+      f32x4w sum[MI][NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) sum[mi][ni] = f32x4w{0.f, 0.f, 0.f, 0.f};
+      for (int s2 = 0; s2 < S; ++s2) {
+        const unsigned sbase = (unsigned)(((unsigned)tl * (unsigned)S + (unsigned)s2) * 16384u + (unsigned)t * 16u);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            f32x4w v = acc[mi][ni];
+            if (s2 != split)
+              v = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rs_p, (int)(sbase + (mi * NI + ni) * 4096u), 0, 16));
+            sum[mi][ni] += v;
+          }
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = sum[mi][ni];
+    }
   }
 
   // ---- epilogue (see conv_g8.hip): acc[mi][ni][j] = C[pixel m0 + wm*BM/2 + mi*16 + lrow][channel n0 + wn*BN/2 + ni*16 + 4*lk + j];
@@ -385,6 +456,47 @@ bool g4_raise_lds(const void* fp, size_t bytes) {
   return true;
 }
 
+// Scratch of the split-K launches: G4_SPLIT_SETS sets, a stream takes the next free one when it is first seen (launches of one stream
+// are ordered; the two branch streams -- and the streams a hipGraph capture runs on, which are not the eager ones -- run theirs
+// concurrently).  The sets are allocated together by the first eligible launch OUTSIDE a capture (TrainStep warms up eagerly first);
+// handing a set to a new stream allocates nothing, so it may happen during a capture.  A stream beyond the last set: no split-K.
+struct G4Scratch { void* part; unsigned* cnt; };
+bool g4_split_scratch(hipStream_t stream, G4Scratch& out) {
+  static std::mutex mu;
+  static std::map<hipStream_t, int> owner;
+  static G4Scratch sets[G4_SPLIT_SETS];
+  static int nsets = 0;      // 0: not allocated yet, -1: allocation failed
+  std::lock_guard<std::mutex> lock(mu);
+  if (nsets == 0) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+    const size_t part_bytes = (size_t)G4_SPLIT_MAX_TILES * G4_SPLIT_MAX * 256 * 16 * sizeof(float);      // 64 MiB per set
+    const size_t cnt_bytes = 4096;
+    char* base = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&base), G4_SPLIT_SETS * (part_bytes + cnt_bytes)) != hipSuccess ||
+        hipMemset(base, 0, G4_SPLIT_SETS * (part_bytes + cnt_bytes)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void)hipGetLastError();
+      if (base) (void)hipFree(base);
+      nsets = -1;
+      return false;
+    }
+    for (int i = 0; i < G4_SPLIT_SETS; ++i) {
+      sets[i].part = base + (size_t)i * (part_bytes + cnt_bytes);
+      sets[i].cnt = reinterpret_cast<unsigned*>(base + (size_t)i * (part_bytes + cnt_bytes) + part_bytes);
+    }
+    nsets = G4_SPLIT_SETS;
+    static_assert(G4_SPLIT_MAX_TILES * sizeof(unsigned) <= 4096, "counters");
+  }
+  if (nsets < 0) return false;
+  auto it = owner.find(stream);
+  if (it == owner.end()) {
+    if ((int)owner.size() >= nsets) return false;
+    it = owner.emplace(stream, (int)owner.size()).first;
+  }
+  out = sets[it->second];
+  return true;
+}
+
 }  // namespace
 
 // Eligibility + launch; false = the shape stays with conv_s1 / the generic kernel.
@@ -465,11 +577,37 @@ bool conv_g4_launch(const IgemmParams& p, int dtype, hipStream_t stream) {
   static const int deep_max = getenv("NPP_G4_DEEP_MAX_TILES") ? atoi(getenv("NPP_G4_DEEP_MAX_TILES")) : 1300;
   const bool deep = !pers && !half && bm == 64 && bn == 64 && total <= deep_max && e.nk >= 6;
   static const int deep_ring = getenv("NPP_G4_DEEP_RING") ? atoi(getenv("NPP_G4_DEEP_RING")) : 4;
+  // Split-K for the grids that leave CUs idle (256->256 3x3 @12^2: 144 tiles x 36 K-tiles on 256 CUs; the launch is bound by the
+  // L2 -> LDS rate of the CUs it occupies, profiles/r05_g4_ablation.txt): S workgroups per tile, each over 1/S of the K-tiles, the
+  // last one to arrive adds the partial accumulators and runs the epilogue (see the kernel).  S minimises the rounds of the
+  // S * tiles workgroups over the 256 CUs, divided by S, plus a per-share cost.  NPP_G4_SPLITK: 0 = never, n >= 2 = always n.
+  // Measured (tools/r5_g4_splitk.sh, us, S = 1 / 2 / 3 / 4): 256->256 3x3 @12^2 (144 tiles) 16.6 / 14.4 / 12.6 / 17.2; 128->128 3x3 @24^2
+  // (288 tiles: every CU busy already) 12.3 / 16.0 / 15.9 / 17.9 -- only grids of fewer tiles than CUs are split.
+  static const int split_env = getenv("NPP_G4_SPLITK") ? atoi(getenv("NPP_G4_SPLITK")) : -1;
+  e.ksplit = 1; e.part = nullptr; e.cnt = nullptr;
+  int gsplit = grid;
+  if (deep && (deep_ring == 4 || deep_ring == 3 || deep_ring == 8) && split_env != 0 && total < (split_env >= 2 ? G4_SPLIT_MAX_TILES : 256) && e.nk >= 12) {
+    int best = 1;
+    if (split_env >= 2) best = split_env;
+    else {
+      double best_cost = (double)((total + 255) / 256) + 0.05;
+      for (int sp = 2; sp <= 4 && sp * 6 <= e.nk; ++sp) {
+        const double cost = (double)((total * sp + 255) / 256) / sp + 0.05 * sp;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+      }
+    }
+    if (best > G4_SPLIT_MAX) best = G4_SPLIT_MAX;
+    if (best > e.nk) best = e.nk;
+    G4Scratch sc;
+    if (best > 1 && g4_split_scratch(stream, sc)) { e.ksplit = best; e.part = sc.part; e.cnt = sc.cnt; gsplit = total * best; }
+    static const bool dbg_split = getenv("NPP_G4_SPLIT_DBG") != nullptr;
+    if (dbg_split) fprintf(stderr, "npp-g4-split tiles %d nk %d -> S %d (wanted %d)\n", total, e.nk, e.ksplit, best);
+  }
 #define G4_LAUNCH_DEEP_R(RELU_, TAPS_, RG_)                                                                 \
   do {                                                                                                     \
     constexpr size_t lds = RG_ * (64 + 64) * 128 + 2 * 64 * 3 * 4;                                          \
     if (!g4_raise_lds(reinterpret_cast<const void*>(conv_g4_kernel<64, 64, 2, RELU_, TAPS_, false, false, RG_>), lds)) return false; \
-    hipLaunchKernelGGL((conv_g4_kernel<64, 64, 2, RELU_, TAPS_, false, false, RG_>), dim3(grid), dim3(256), lds, stream, q, e); \
+    hipLaunchKernelGGL((conv_g4_kernel<64, 64, 2, RELU_, TAPS_, false, false, RG_>), dim3(gsplit), dim3(256), lds, stream, q, e); \
   } while (0)
 #define G4_LAUNCH_DEEP(RELU_, TAPS_)                                                                        \
   do { if (deep_ring == 8) G4_LAUNCH_DEEP_R(RELU_, TAPS_, 8); else if (deep_ring == 3) G4_LAUNCH_DEEP_R(RELU_, TAPS_, 3); else G4_LAUNCH_DEEP_R(RELU_, TAPS_, 4); } while (0)

@@ -396,6 +396,9 @@ for _lean in ("0", "1"):
     bg_children.register(f"epi-{_lean}", [_sys.executable, os.path.join(_HERE, "epi_worker.py"), os.path.join(_EPI_DIR, f"epi{_lean}.npz")],
                          dict(NPP_EPI_LEAN=_lean, NPP_EPI_CENSUS="1"), timeout=600)
 bg_children.register("wgrad-slabs", [_sys.executable, os.path.join(_HERE, "wgrad_slabs_worker.py")], dict(NPP_WGRAD_SLABS="1"), timeout=600)
+for _sk in ("2", "3"):
+    bg_children.register(f"g4-splitk-{_sk}", [_sys.executable, os.path.join(_HERE, "g4_splitk_worker.py")],
+                         dict(NPP_G4_SPLITK=_sk, NPP_G4_SPLIT_DBG="1"), timeout=600)
 bg_children.register("g8-taps", [_sys.executable, os.path.join(_HERE, "g8_taps_worker.py")],
                      dict(NPP_G8_MAXK="3", NPP_DISABLE_G4="1", NPP_DISABLE_H3="1"), timeout=600)
 
@@ -440,6 +443,16 @@ def test_deterministic_slab_weight_gradient_in_subprocess():
     r = bg_children.result("wgrad-slabs")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "wgrad slabs ok" in r.stdout
+
+
+@pytest.mark.parametrize("shares", ["2", "3"])
+def test_g4_split_k_in_subprocess(shares):
+    """conv_g4's split-K form for grids of fewer tiles than CUs (NPP_G4_SPLITK forces the number of shares, read once per process):
+    parity of forward / data gradient / weight gradient on five shapes, bit-identical repeats, and the launches really were split."""
+    r = bg_children.result(f"g4-splitk-{shares}")
+    assert r.returncode == 0 and "g4 splitk ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stderr.splitlines() if ln.startswith("npp-g4-split")]
+    assert sum(1 for ln in lines if ln.endswith(f"-> S {shares} (wanted {shares})")) >= 8, lines[:20]
 
 
 def test_g8_taps_variant_in_subprocess():
