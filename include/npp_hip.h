@@ -621,6 +621,10 @@ typedef struct NppP2pSeg {
   float* out_all;      /* NULL, or len floats: every local sum of the segment */
 } NppP2pSeg;
 int npp_p2p_exchange_slabs(const NppP2pSeg* segs, int nseg, int channel, void* stream);
+/* The same in-place SUM as npp_p2p_exchange, carried by the in-kernel form of the exchange (leader workgroup -> mailboxes -> tagged
+ * result vector -> the other workgroups; what the npp_*_x BatchNorm entry points do in their prologues): for acceptance tests of the
+ * transport (npp_amd/comm.py runs it next to the two stand-alone forms before the first SyncBatchNorm depends on the mailboxes). */
+int npp_p2p_exchange_folded_test(double* stats, int64_t count, int channel, void* stream);
 int npp_p2p_status(void);
 int64_t npp_p2p_set_timeout_ms(int64_t ms);   /* poll timeout of later exchanges (ms > 0); returns the previous value */
 int npp_p2p_reset_errors(void);               /* clear every channel's error word (synchronises the device): the host's acceptance test, between modes */

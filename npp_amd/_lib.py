@@ -239,6 +239,7 @@ _SIGS = {
     "npp_p2p_alloc_kind": [],
     "npp_p2p_exchange": [_P, C.c_int64, C.c_int, _P],
     "npp_p2p_exchange_slabs": [_P, C.c_int, C.c_int, _P],
+    "npp_p2p_exchange_folded_test": [_P, C.c_int64, C.c_int, _P],
     "npp_p2p_status": [],
     "npp_p2p_reset_errors": [],
     "npp_p2p_close": [],

@@ -182,8 +182,8 @@ SELFTEST_EXCHANGES = int(os.environ.get("NPP_P2P_SELFTEST", "2000"))
 
 def _p2p_selftest(lib, rank, world, rounds=None) -> bool:
     """Acceptance test of the mailboxes, run right after they are mapped and before any statistic depends on them: `rounds`
-    (default 2000) exchanges BACK TO BACK on channel 0 with no host synchronisation in between -- alternating the plain and the slab
-    form, vectors that change every round and differ per rank, lengths that change (so every slot is reused hundreds of times with
+    (default 2000) exchanges BACK TO BACK on channel 0 with no host synchronisation in between -- alternating the plain form, the slab
+    form and the in-kernel form of the fused BatchNorm kernels (npp_p2p_exchange_folded_test), vectors that change every round and differ per rank, lengths that change (so every slot is reused hundreds of times with
     different contents) -- and only then are all sums compared with the exact expected values (integers below 2^53: f64 sums are
     exact in any order).  A stale read of an earlier exchange's slot, a torn unit, a missing peer or a mapping to the wrong memory
     fails here.  The caller's MIN all-reduce makes every rank drop the transport if one of them fails."""
@@ -204,7 +204,10 @@ def _p2p_selftest(lib, rank, world, rounds=None) -> bool:
         outf = torch.zeros(n, dtype=torch.float32, device=dev)
         for it in range(rounds):
             ln = lens[it]
-            if it % 2 == 0:
+            if it % 4 == 2:
+                # the in-kernel form (what the fused BatchNorm kernels carry in their prologues: leader workgroup, tagged result vector)
+                _lib.check(lib.npp_p2p_exchange_folded_test(plain[it].data_ptr(), ln, 0, st), "npp_p2p_exchange_folded_test")
+            elif it % 2 == 0:
                 _lib.check(lib.npp_p2p_exchange(plain[it].data_ptr(), ln, 0, st), "npp_p2p_exchange")
             else:
                 # slab form: the contribution split over R replica slabs [R][ln] (every slab floor(value / R), slab 0 the rest)

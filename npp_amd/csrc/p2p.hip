@@ -205,6 +205,21 @@ __global__ __launch_bounds__(1024) void p2p_exchange_kernel(ExArgs a) {
   }
 }
 
+// The in-kernel form of the exchange (p2p_xp.h) on a bare vector: what the fused BatchNorm kernels of bn.hip do in their prologues,
+// without the BatchNorm -- for the host's acceptance test.  Workgroup 0 is the leader; element j of the result is written back by
+// workgroup j % gridDim.x, i.e. almost always by a workgroup that had to wait for the leader and read the published units.
+__global__ __launch_bounds__(256) void p2p_xp_test_kernel(XpArgs xp, double* v, int n) {
+  XpCtx xc = xp_begin(xp);
+  unsigned bad = 0u;
+  xp_exchange(xp, xc, blockIdx.x == 0, 0L, n, xp.flags, [&](int j) { return v[j]; }, bad);
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const double w = xp_get(xp, xc, j, bad);
+    if ((unsigned)j % gridDim.x == blockIdx.x) v[j] = w;
+  }
+  __syncthreads();
+  xp_end(xp, xc, bad, gridDim.x);
+}
+
 }  // namespace
 
 // bytes of an IPC handle as this library hands it around (hipIpcMemHandle_t)
@@ -367,6 +382,17 @@ extern "C" int npp_p2p_exchange_slabs(const NppP2pSeg* segs, int nseg, int chann
   if (blocks > P2P_MAX_BLOCKS) blocks = P2P_MAX_BLOCKS;
   hipLaunchKernelGGL(p2p_exchange_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, a);
   return npp_check_launch("p2p_exchange_slabs");
+}
+
+// In-place SUM over the ranks of `count` doubles through the IN-KERNEL form of the exchange (the leader / follower protocol of the
+// fused BatchNorm kernels, p2p_xp.h) -- for acceptance tests: the same sequence number, mailboxes and result vector a folded launch uses.
+extern "C" int npp_p2p_exchange_folded_test(double* stats, int64_t count, int channel, void* stream) {
+  NPP_REQUIRE(stats && count > 0, NPP_E_NULL, "npp_p2p_exchange_folded_test: null / empty buffer");
+  XpArgs xp;
+  const int rc = npp_p2p_xp_args(channel, (long)count, &xp);
+  if (rc != NPP_OK) return rc;
+  hipLaunchKernelGGL(p2p_xp_test_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, xp, stats, (int)count);
+  return npp_check_launch("p2p_xp_test");
 }
 
 // 0: every exchange of every channel found its peers; otherwise the OR of the channels' error words (1: a poll timed out, 2: a
