@@ -152,8 +152,11 @@ def _tiers_multi():
     """Attempts of an N > 1 rank, see supervise_rank."""
     return [
         ({}, [], None),
+        ({"NPP_P2P_FOLD": "0"}, [],
+         "the first attempt (peer-to-peer SyncBatchNorm exchange inside the fused BatchNorm kernels) died or stalled; this line is from "
+         "fresh workers with every exchange a stand-alone peer-to-peer kernel (the round-4 form)"),
         ({"NPP_SYNCBN_P2P": "0"}, [],
-         "the first attempt (peer-to-peer SyncBatchNorm exchange) died or stalled; this line is from fresh workers with every exchange "
+         "the peer-to-peer attempts died or stalled; this line is from fresh workers with every exchange "
          "as a collective of the process group"),
         ({"NPP_SYNCBN_P2P": "0"}, ["--graph", "0"], "the hipGraph attempts died or stalled; this line is from a fresh eager (--graph 0) worker"),
     ]
@@ -187,9 +190,10 @@ def supervise_rank(tiers=None):
     stall = float(os.environ.get("NPP_BENCH_STALL_S", "240"))
     tmp = tempfile.mkdtemp(prefix=f"npp_bench_r{rank}_")
     last_rc = 1
-    # attempt 0: the default step (hipGraph, SyncBatchNorm statistics through the peer-to-peer mailboxes of csrc/p2p.hip);
-    # attempt 1: the same with every exchange as an RCCL collective on the hub stream (the round-2 form: neither transport has run on
-    #            a multi-GPU box the builder had access to, so neither may be the only one); attempt 2: collectives, eager (--graph 0)
+    # attempt 0: the default step (hipGraph, SyncBatchNorm statistics through the peer-to-peer mailboxes of csrc/p2p.hip, exchanged inside
+    #            the fused BatchNorm kernels); attempt 1: the same with stand-alone exchange kernels (NPP_P2P_FOLD=0);
+    # attempt 2: the same with every exchange as an RCCL collective on the hub stream (the round-2 form: neither transport has run on
+    #            a multi-GPU box the builder had access to, so neither may be the only one); attempt 3: collectives, eager (--graph 0)
     if tiers is None:
         tiers = _tiers_multi()
     for attempt, (tier_env, tier_argv, tier_note) in enumerate(tiers):
@@ -309,10 +313,13 @@ def main():
         if os.environ.get("NPP_BENCH_FALLBACK"):
             rec["fallback"] = os.environ["NPP_BENCH_FALLBACK"]
         rec["syncbn_p2p"] = os.environ.get("NPP_SYNCBN_P2P", "1")
+        rec["p2p_fold"] = os.environ.get("NPP_P2P_FOLD", "1")
         rec["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
         if fake == "hang" and attempt == 0:
             time.sleep(3600)
         if fake == "hang2" and attempt <= 1:
+            time.sleep(3600)
+        if fake == "hang3" and attempt <= 2:
             time.sleep(3600)
         if fake == "late_hang":
             with open(os.environ["NPP_BENCH_RESULT"], "w") as fh:

@@ -27,17 +27,23 @@ def test_healthy_worker_is_relayed():
 
 
 @pytest.mark.parametrize("fake", ["hang", "crash"])
-def test_stalled_or_dead_worker_is_replaced_by_one_on_the_collective_transport(fake):
+def test_stalled_or_dead_worker_is_replaced_by_one_with_stand_alone_exchange_kernels(fake):
     r, rec = _run(fake)
     assert r.returncode == 0, r.stderr[-500:]
-    assert rec["attempt"] == 1 and rec["syncbn_p2p"] == "0" and rec["graph_arg"] != 0 and "fallback" in rec
+    assert rec["attempt"] == 1 and rec["p2p_fold"] == "0" and rec["syncbn_p2p"] == "1" and rec["graph_arg"] != 0 and "fallback" in rec
     assert "supervisor" in r.stderr
 
 
-def test_a_second_stall_ends_in_the_eager_worker():
+def test_a_second_stall_ends_on_the_collective_transport():
     r, rec = _run("hang2", timeout=90)
     assert r.returncode == 0, r.stderr[-500:]
-    assert rec["attempt"] == 2 and rec["graph_arg"] == 0 and rec["syncbn_p2p"] == "0" and "eager" in rec["fallback"]
+    assert rec["attempt"] == 2 and rec["syncbn_p2p"] == "0" and rec["graph_arg"] != 0 and "collective" in rec["fallback"]
+
+
+def test_a_third_stall_ends_in_the_eager_worker():
+    r, rec = _run("hang3", timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert rec["attempt"] == 3 and rec["graph_arg"] == 0 and rec["syncbn_p2p"] == "0" and "eager" in rec["fallback"]
 
 
 def test_worker_lost_after_its_record_keeps_the_record():
