@@ -70,6 +70,8 @@ for _s, _o, _d in _GRAPH_CASES:
     bg_children.register(f"graph-poison-{_s}-{_o}-{_d}",
                          [sys.executable, os.path.join(REPO, "tools", "graph_poison_probe.py")] + (["bf16"] if _d == "bf16" else []),
                          dict(PROBE_SYNC=_s, PROBE_OVERLAP=_o, PROBE_GB="2"), timeout=600)
+bg_children.register("graph-poison-p2p", [sys.executable, os.path.join(REPO, "tools", "graph_poison_probe.py"), "bf16"],
+                     dict(PROBE_SYNC="1", PROBE_OVERLAP="0", PROBE_GB="2", NPP_P2P_ALONE="1", NPP_P2P_SELFTEST="200"), timeout=600)
 bg_children.register("graph-poison-search", [sys.executable, os.path.join(REPO, "tools", "graph_poison_probe.py")],
                      dict(PROBE_MODEL="search", PROBE_GB="2"), timeout=600)
 
@@ -82,6 +84,18 @@ def test_replayed_step_reads_no_recycled_block(sync, overlap, dtype):
     the cross-stream use-after-free of round 2 (an input read on the hub stream without record_stream)."""
     r = bg_children.result(f"graph-poison-{sync}-{overlap}-{dtype}")
     assert r.returncode == 0 and "GRAPH_PROBE_DONE" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_replayed_step_with_the_exchanges_inside_the_fused_kernels():
+    """The same probe with the SyncBatchNorm statistics going through the (1-rank) peer-to-peer mailboxes: the exchanges run inside the
+    fused BatchNorm kernels' prologues (csrc/p2p_xp.h), captured and replayed as part of the step's hipGraph -- sequence numbers,
+    result vectors and done counters advance on the device from replay to replay.  No non-finite value, no mailbox error, and the
+    exchanges really were folded."""
+    r = bg_children.result("graph-poison-p2p")
+    assert r.returncode == 0 and "GRAPH_PROBE_DONE" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    line = next(ln for ln in r.stdout.splitlines() if ln.startswith("folded exchanges"))
+    fwd, bwd = (int(v) for v in line.split("[")[1].split("]")[0].split(","))
+    assert fwd > 50 and bwd > 50 and "p2p ok active True" in line, line
 
 
 def test_replayed_search_step_reads_no_recycled_block():

@@ -85,6 +85,14 @@ for it in range(4):
         print("   adam state non-finite:", bs[:6], "wild gradients:", wild[:6], flush=True)
     print("step", it, "loss", loss, "graphed", (sstep.weights_pass.graph is not None) if search else (step.graph is not None), "non-finite grads", len(bg), bg[:6], "params", len(bp), bp[:4],
           "buffers", len(bb), bb[:4], flush=True)
+try:      # (SyncBatchNorm over the mailboxes: how many exchanges ran inside the fused kernels, and whether a mailbox reported an error)
+    from npp_amd import _ops as _K
+    from npp_amd import comm as _comm
+    print("folded exchanges (forward, backward launches):", _K.FOLD_STATS, "p2p", "ok" if _comm.p2p_ok() else "ERROR", "active", _comm.p2p_active(), flush=True)
+    if _comm.p2p_active() and not _comm.p2p_ok():
+        bad_total += 1
+except Exception as e:      # noqa: BLE001
+    print("fold stats unavailable:", e)
 print("GRAPH_PROBE_DONE" if bad_total == 0 else "GRAPH_PROBE_BAD")
 if sync:
     dist.destroy_process_group()
