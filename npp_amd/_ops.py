@@ -652,7 +652,15 @@ class _SyncStatsPool(_ZeroPool):
                     sd.sync_event = back
             else:
                 if not self._flush_slabs():
-                    hub_all_reduce(rng, self.group)
+                    if P2P_FOLD and P2P_DIRECT:
+                        # (never the pool's range in place while exchanges are folded into kernels: rows of a merged conv may be
+                        #  read by a consumer on the other branch stream at this very moment -- every vector on its own)
+                        for sd in self.waiting:
+                            if sd.stats_c:
+                                _compact_stats(sd)
+                            hub_all_reduce(sd.stats, self.group)
+                    else:
+                        hub_all_reduce(rng, self.group)
             self.flushes += 1
             for sd in self.waiting:
                 sd.synced_ws = self.ws
@@ -670,6 +678,13 @@ class _SyncStatsPool(_ZeroPool):
             return False
         segs = []
         for sd in self.waiting:
+            if P2P_FOLD and sd.stats_c:
+                # With exchanges folded into the consuming kernels, some edges of a merged conv may already have traded their slice
+                # of the conv's statistics rows -- possibly on the other branch stream, possibly right now.  The rows are never
+                # exchanged in place then: every edge still waiting here travels as a private copy of its own slice.
+                _compact_stats(sd)
+                sd.rider = False
+                sd.carry = None
             if sd.rider:
                 continue
             st = sd.carry if sd.carry is not None else sd.stats
@@ -2018,15 +2033,11 @@ def _fold_channel(n_doubles, grp):
 
 def _leave_pool(sd, pools=None):
     """Take `sd` off the waiting list of the sync pool that holds its statistics (it is exchanged on its own: inside a fused kernel, or
-    alone).  If it was the lead edge of a merged run, the run's next waiting edge carries the rows from now on."""
+    alone).  (The other edges of a merged conv that still wait do not depend on it: with P2P_FOLD a flush sends every such edge as a
+    private copy of its own slice, see _SyncStatsPool._flush_slabs.)"""
     for pl in (_sync_pool.all() if pools is None else pools):
         if any(w is sd for w in pl.waiting):
             pl.waiting = [w for w in pl.waiting if w is not sd]
-            if not sd.rider and sd.mates:
-                nxt = next((mt for mt in sd.mates if mt is not sd and not mt.synced_ws and any(w is mt for w in pl.waiting)), None)
-                if nxt is not None:
-                    nxt.rider = False
-                    nxt.carry = sd.carry if sd.carry is not None else sd.stats
             return pl
     return None
 
