@@ -1447,7 +1447,10 @@ static unsigned bn_grid_cap() {
 // streams in different orders wait for each other forever).
 static unsigned xp_grid_x(unsigned gx, int njobs, const XpArgs& x) {
   if (x.world == 0) return gx;
-  const unsigned cap = (unsigned)(XP_MAX_BLOCKS / (njobs > 0 ? njobs : 1));
+  // (NPP_XP_MAX_BLOCKS: several RANKS sharing one GPU -- the 1-GPU rehearsal of an N > 1 run, tests -- must share the budget: with
+  //  two ranks x two streams of 512 waiting workgroups each, one rank's kernels fill the chip and the other rank's leaders never start)
+  static const int budget = getenv("NPP_XP_MAX_BLOCKS") ? atoi(getenv("NPP_XP_MAX_BLOCKS")) : XP_MAX_BLOCKS;
+  const unsigned cap = (unsigned)((budget > 0 ? budget : XP_MAX_BLOCKS) / (njobs > 0 ? njobs : 1));
   return gx > cap ? (cap > 0 ? cap : 1u) : gx;
 }
 
