@@ -342,8 +342,8 @@ def main():
     if os.environ.get("NPP_BENCH_ONE_GPU"):      # rehearsal of the N > 1 flow on a 1-GPU box: every rank on device 0 (with
         local_rank = 0                           # NPP_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device)
         # the ranks share ONE chip: the workgroups that wait inside a kernel for another rank's statistics (csrc/p2p_xp.h) must leave
-        # room for that rank's kernels -- 512 slots over world ranks x two branch streams
-        os.environ.setdefault("NPP_XP_MAX_BLOCKS", str(max(32, 512 // (2 * max(1, int(os.environ.get("WORLD_SIZE", "1")))))))
+        # room for that rank's kernels -- the budget of one rank (192) over the world's ranks
+        os.environ.setdefault("NPP_XP_MAX_BLOCKS", str(max(32, 192 // max(1, int(os.environ.get("WORLD_SIZE", "1"))))))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist

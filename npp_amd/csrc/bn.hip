@@ -1443,12 +1443,12 @@ static unsigned bn_grid_cap() {
   return cap > 0 ? cap : 512u;
 }
 // Workgroups of a launch that carries an exchange: at most XP_MAX_BLOCKS over all its jobs (p2p_xp.h: its waiting workgroups must
-// never fill the chip -- the leader of the OTHER branch stream's kernel has to find a slot, or two ranks that schedule their two
-// streams in different orders wait for each other forever).
+// leave whole CUs to the kernels of the OTHER branch stream, or two ranks that reach their two streams' exchanges in opposite orders
+// can wait for each other forever).
 static unsigned xp_grid_x(unsigned gx, int njobs, const XpArgs& x) {
   if (x.world == 0) return gx;
   // (NPP_XP_MAX_BLOCKS: several RANKS sharing one GPU -- the 1-GPU rehearsal of an N > 1 run, tests -- must share the budget: with
-  //  two ranks x two streams of 512 waiting workgroups each, one rank's kernels fill the chip and the other rank's leaders never start)
+  //  two ranks x two streams of waiting workgroups, one rank's kernels can fill the chip and the other rank's leaders never start)
   static const int budget = getenv("NPP_XP_MAX_BLOCKS") ? atoi(getenv("NPP_XP_MAX_BLOCKS")) : XP_MAX_BLOCKS;
   const unsigned cap = (unsigned)((budget > 0 ? budget : XP_MAX_BLOCKS) / (njobs > 0 ? njobs : 1));
   return gx > cap ? (cap > 0 ? cap : 1u) : gx;

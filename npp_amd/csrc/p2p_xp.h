@@ -15,11 +15,15 @@
 //   * no lane ever waits for another lane of its own wave: the waits are a poll of OTHER ranks' stores (leader) or of the
 //     leader's flag (one thread per workgroup), each followed by a workgroup barrier;
 //   * the leader of a job is dispatched before the job's other workgroups, so the workgroups waiting for it cannot starve it;
-//   * a launch that carries an exchange has at most XP_MAX_BLOCKS workgroups (256 threads each, <= 133 VGPRs: three fit on a CU,
-//     XP_MAX_BLOCKS is two per CU): its waiting workgroups never fill the chip.  They wait for OTHER ranks -- if they could hold
-//     every slot, the kernel of the other branch stream could not start its leader, and two ranks whose two streams reach their
-//     kernels in opposite orders would wait for each other until the time-out.  With the cap the leaders of both streams' kernels
-//     are always resident (the stand-alone exchange kernel never had the problem: <= 8 workgroups).
+//   * a launch that carries an exchange has at most XP_MAX_BLOCKS = 192 workgroups of 256 threads over all its jobs: its waiting
+//     workgroups wait for OTHER ranks, so what they occupy must never be what another rank's progress needs.  (a) Were they allowed
+//     to hold every workgroup slot, the kernel of the other branch stream could not start its leader.  (b) Even two per CU are too
+//     many: a kernel that needs a CU's whole register file (conv_g8: 512 threads x ~250 VGPRs) cannot start on a CU that holds ONE
+//     waiting workgroup -- rank X waiting in stream A's kernel with conv_g8 pending on stream B, rank Y waiting in stream B's kernel
+//     with conv_g8 pending on stream A, is a cycle through both ranks.  192 workgroups leave >= 64 CUs free of this launch: the
+//     pending kernel makes progress there, whatever the other stream is waiting for (a rank has at most one such launch per stream,
+//     and in the cycle only ONE of them is waiting).  The stand-alone exchange kernel never had the problem: <= 8 workgroups.
+//     Cost of 192 against 512 in the 1-rank rehearsal: 39.2 -> 39.6 ms (tools/r5_xp_budget.sh).
 // Errors as in p2p.hip: a poll that times out or finds a slot overwritten sets the channel's error word and yields NaN sums.
 #pragma once
 #include "common.h"
@@ -29,7 +33,7 @@ constexpr int P2P_MAX_WORLD = 16;
 constexpr int XP_SUB = 16;             // first-level counters of the "every workgroup is past its prologue" count
 constexpr int XP_SUB_STRIDE = 32;      // ... 256 bytes apart (in 8-byte words)
 constexpr int XP_KEEP = 4;             // elements per leader thread kept in registers instead of travelling through the own mailbox
-constexpr int XP_MAX_BLOCKS = 512;     // workgroups of a launch that carries an exchange (two per CU of the 256), see above
+constexpr int XP_MAX_BLOCKS = 192;     // workgroups of a launch that carries an exchange (3/4 of the 256 CUs at one each), see above
 constexpr int XP_MAX_JOBS = 4;         // jobs of one multi-job launch (NPP_BN_MULTI_MAX), each with a leader and a flag of its own
 
 struct XpArgs {
