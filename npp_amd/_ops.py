@@ -2058,6 +2058,32 @@ def _fold_forward(launch_sides, training: bool):
     exchange.  -1: nothing changed, the caller exchanges as before (_presync_stats)."""
     if not (P2P_FOLD and P2P_DIRECT and FUSE_BN_SYNC and training and not SYNC_MERGE):
         return -1
+    ch = _fold_forward_try(launch_sides)
+    if ch < 0 and _FOLD_DBG is not None:
+        _FOLD_DBG[_fold_why(launch_sides)] += 1
+    return ch
+
+
+_FOLD_DBG = __import__("collections").Counter() if os.environ.get("NPP_DBG_FOLD") else None
+if _FOLD_DBG is not None:
+    import atexit as _atexit
+    _atexit.register(lambda: [print(f"npp-fold-refused {n:5d} {k}", file=__import__("sys").stderr) for k, n in _FOLD_DBG.most_common()])
+
+
+def _fold_why(launch_sides):
+    out = []
+    for sa, sb in launch_sides:
+        for sd in (sa, sb):
+            if sd is None or sd.bn is None:
+                out.append("plain")
+            else:
+                st = sd.stats
+                out.append(f"sync={_sync_group(sd.bn)[0] is not None} synced={sd.synced_ws} ev={sd.sync_event is not None} "
+                           f"stats={'none' if st is None else st.numel()} c={sd.x.shape[1]} sc={sd.stats_c}")
+    return " | ".join(out)
+
+
+def _fold_forward_try(launch_sides):
     grp = None
     bn_sides, widths = [], set()
     for sa, sb in launch_sides:
