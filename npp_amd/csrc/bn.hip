@@ -341,7 +341,7 @@ NPP_DEV void affine_add_fin_kernel_body(T* __restrict__ out, long ldo, const T* 
     }
   }
   if (xon)
-    xp_exchange(xp, xc, BX == 0, xoff, NS * 2 * C, xp.flags + blockIdx.z, [&](int j) {
+    xp_exchange(xp, xc, BX == 0, xoff, NS * 2 * C, [&](int j) {
       const FinSide& f = j >= 2 * C ? fb : fa;
       const int r2 = j >= 2 * C ? j - 2 * C : j;                   // [sum C | sum of squares C] of the side
       const long at = r2 >= C ? (long)f.sc + (r2 - C) : (long)r2;  // ... inside a replica row [sum sc | sum of squares sc]
@@ -769,7 +769,7 @@ NPP_DEV void bn_bwd_apply_fin_kernel_body(const T* __restrict__ dout, long ldd, 
     }
   }
   if (xon)
-    xp_exchange(xp, xc, BX == 0, xoff, 2 * C, xp.flags + blockIdx.z, [&](int j) {
+    xp_exchange(xp, xc, BX == 0, xoff, 2 * C, [&](int j) {
       double part[NPP_STAT_REPLICAS], v = 0.0;
 #pragma unroll
       for (int r = 0; r < NPP_STAT_REPLICAS; ++r) part[r] = sums[(long)r * 2 * C + j];
@@ -869,7 +869,7 @@ NPP_DEV void bn_bwd_apply2_fin_kernel_body(const T* __restrict__ dout, long ldd,
     if (ro) ldv<T, V>(ro + p * ldr + c0, r);
   }
   if (xon)
-    xp_exchange(xp, xc, BX == 0, xoff, 3 * C, xp.flags + blockIdx.z, [&](int j) {
+    xp_exchange(xp, xc, BX == 0, xoff, 3 * C, [&](int j) {
       double part[NPP_STAT_REPLICAS], v = 0.0;
 #pragma unroll
       for (int r = 0; r < NPP_STAT_REPLICAS; ++r) part[r] = sums[(long)r * 3 * C + j];

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(1024) void p2p_exchange_kernel(ExArgs a) {
 __global__ __launch_bounds__(256) void p2p_xp_test_kernel(XpArgs xp, double* v, int n) {
   XpCtx xc = xp_begin(xp);
   unsigned bad = 0u;
-  xp_exchange(xp, xc, blockIdx.x == 0, 0L, n, xp.flags, [&](int j) { return v[j]; }, bad);
+  xp_exchange(xp, xc, blockIdx.x == 0, 0L, n, [&](int j) { return v[j]; }, bad);
   for (int j = threadIdx.x; j < n; j += 256) {
     const double w = xp_get(xp, xc, j, bad);
     if ((unsigned)j % gridDim.x == blockIdx.x) v[j] = w;
@@ -457,7 +457,6 @@ int npp_p2p_xp_args(int channel, long n_doubles, XpArgs* out) {
   for (int r = 0; r < P2P_MAX_WORLD; ++r) out->peer_data[r] = r < g.world ? c.data[r] : nullptr;
   out->seq = c.seq; out->err = c.err; out->res = g.res + (size_t)channel * (g.cap * 2 + XP_SUB * XP_SUB_STRIDE);
   out->sub = out->res + g.cap * 2;
-  out->flags = c.seq + 2;      // (the 64-byte block of the channel's counter: [0] number, [1] done count, [2 .. 2 + XP_MAX_JOBS) flags)
   out->cap = g.cap; out->timeout_ticks = g.timeout_ticks; out->me = g.rank; out->world = g.world; out->light = p2p_light(); out->pad = 0;
   return NPP_OK;
 }

@@ -5,15 +5,17 @@
 // exchanged by a launch of their own in front of the kernel (p2p_exchange_kernel: ~450 links of 5-8 us in the dependent chain of a
 // step).  Here the LEADER workgroup of the kernel (blockIdx.x == 0 of a job) pushes its local sums into every rank's mailbox, polls
 // its own mailbox, sums the world's values in rank order (the same arithmetic as the stand-alone kernel: bit-identical on every
-// rank), stores them in a local result vector and raises a flag; every other workgroup waits for the flag and reads that vector (local
-// L2) instead of summing replicas.  Same wire format, same mailboxes, same sequence counter as the stand-alone kernel, so both forms can follow each other
-// on one channel: an exchange is still "the s-th of this channel" and carries tag s + 1.
+// rank) and publishes them as tagged units in a local result vector; every other workgroup waits until the vector's last element
+// carries this exchange's tag and reads its channels' sums from the vector instead of summing replicas.  Same wire format, same
+// mailboxes, same sequence counter as the stand-alone kernel, so both forms can follow each other on one channel: an exchange is
+// still "the s-th of this channel" and carries tag s + 1.
 //
 //   * every workgroup reads the channel's counter s when it starts; the counter moves to s + 1 when the LAST workgroup of the grid
 //     has passed its prologue (xp_end) -- every workgroup has read s by then, and the leader has finished its polls;
 //   * the result vector is one slot: the next exchange of the channel is a later kernel on the same stream;
 //   * no lane ever waits for another lane of its own wave: the waits are a poll of OTHER ranks' stores (leader) or of the
-//     leader's flag (one thread per workgroup), each followed by a workgroup barrier;
+//     leader's last published element (one thread per workgroup, then a workgroup barrier); a unit read before its tag arrived is
+//     read again;
 //   * the leader of a job is dispatched before the job's other workgroups, so the workgroups waiting for it cannot starve it;
 //   * a launch that carries an exchange has at most XP_MAX_BLOCKS = 192 workgroups of 256 threads over all its jobs: its waiting
 //     workgroups wait for OTHER ranks, so what they occupy must never be what another rank's progress needs.  (a) Were they allowed
@@ -34,14 +36,12 @@ constexpr int XP_SUB = 16;             // first-level counters of the "every wor
 constexpr int XP_SUB_STRIDE = 32;      // ... 256 bytes apart (in 8-byte words)
 constexpr int XP_KEEP = 4;             // elements per leader thread kept in registers instead of travelling through the own mailbox
 constexpr int XP_MAX_BLOCKS = 192;     // workgroups of a launch that carries an exchange (3/4 of the 256 CUs at one each), see above
-constexpr int XP_MAX_JOBS = 4;         // jobs of one multi-job launch (NPP_BN_MULTI_MAX), each with a leader and a flag of its own
 
 struct XpArgs {
   unsigned long long* peer_data[P2P_MAX_WORLD];      // this channel's mailbox on every rank, as mapped into this process
   unsigned long long* seq;       // [0] exchange counter, [1] workgroups of the current exchange that are done
   unsigned int* err;
   unsigned long long* res;       // local result vector: [cap][2 units {data32 | tag32}]
-  unsigned long long* flags;     // local: [XP_MAX_JOBS] flags, one per job (blockIdx.z) of a launch
   unsigned long long* sub;       // local: [XP_SUB] counters, XP_SUB_STRIDE words apart
   long cap;
   long long timeout_ticks;
@@ -83,7 +83,7 @@ NPP_DEV XpCtx xp_begin(const XpArgs& x) {
 // device-scope release / acquire pair wrote back / invalidated the XCD's whole L2: +50 us per exchange), then everybody reads its
 // elements with xp_get, which checks the tags and re-reads the rare unit that the hint overtook.
 template <typename Local>
-NPP_DEV void xp_exchange(const XpArgs& x, const XpCtx& c, bool leader, long xoff, int n, unsigned long long* flag, Local local, unsigned& bad) {
+NPP_DEV void xp_exchange(const XpArgs& x, const XpCtx& c, bool leader, long xoff, int n, Local local, unsigned& bad) {
   const int t = threadIdx.x, nt = blockDim.x;
   if (leader) {
     // this rank's own values stay in registers (XP_KEEP elements per thread: vectors up to XP_KEEP * 256 doubles, every BatchNorm
@@ -176,8 +176,8 @@ NPP_DEV void xp_exchange(const XpArgs& x, const XpCtx& c, bool leader, long xoff
   }
 }
 
-// the world's element e (after xp_exchange): normally one pass -- the flag said the units are there; a unit whose tag is still the
-// old one (the flag overtook it) is simply read again
+// the world's element e (after xp_exchange): normally one pass -- the last element's units were there; a unit whose tag is still the
+// old one (the hint overtook it) is simply read again
 NPP_DEV double xp_get(const XpArgs& x, const XpCtx& c, long e, unsigned& bad) {
   const unsigned long long* src = x.res + 2 * e;
   unsigned long long w0, w1;
